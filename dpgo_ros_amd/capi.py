@@ -1,0 +1,402 @@
+"""ctypes binding of libdpgo_hip.so -- the C-ABI declared in include/dpgo_hip.h.
+
+Python-side mirror of the reference interface for this path: the `Agent` class carries the
+DPGO::PGOAgent method names the ROS wrapper calls (src/PGOAgentROS.cpp), `Team`
+the synchronous schedule of src/PGOAgentROS.cpp:129-220.  There is no CPU fallback: loading fails
+loudly when the HIP extension has not been built, and every compute call needs a GPU.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdpgo_hip.so")
+_LIB = None
+
+
+class Measurement(C.Structure):
+    _fields_ = [("r1", C.c_int), ("p1", C.c_int), ("r2", C.c_int), ("p2", C.c_int),
+                ("R", C.c_double * 9), ("t", C.c_double * 3),
+                ("kappa", C.c_double), ("tau", C.c_double), ("weight", C.c_double),
+                ("fixed_weight", C.c_int), ("is_known_inlier", C.c_int)]
+
+
+MEAS_DTYPE = np.dtype([("r1", "<i4"), ("p1", "<i4"), ("r2", "<i4"), ("p2", "<i4"),
+                       ("R", "<f8", (9,)), ("t", "<f8", (3,)),
+                       ("kappa", "<f8"), ("tau", "<f8"), ("weight", "<f8"),
+                       ("fixed_weight", "<i4"), ("is_known_inlier", "<i4")], align=True)
+assert MEAS_DTYPE.itemsize == C.sizeof(Measurement)
+
+
+class Params(C.Structure):
+    _fields_ = [("d", C.c_int), ("r", C.c_int), ("num_robots", C.c_int), ("method", C.c_int),
+                ("rgd_stepsize", C.c_double), ("rgd_use_preconditioner", C.c_int),
+                ("rtr_iterations", C.c_int), ("rtr_tcg_iterations", C.c_int),
+                ("gradnorm_tol", C.c_double), ("rtr_initial_radius", C.c_double),
+                ("rtr_max_radius", C.c_double), ("precond_shift", C.c_double),
+                ("acceleration", C.c_int), ("restart_interval", C.c_int),
+                ("rel_change_tol", C.c_double), ("max_num_iters", C.c_int),
+                ("robust_cost_type", C.c_int), ("gnc_barc", C.c_double),
+                ("gnc_mu_step", C.c_double), ("gnc_init_mu", C.c_double),
+                ("robust_opt_num_weight_updates", C.c_int), ("robust_opt_inner_iters", C.c_int),
+                ("robust_opt_min_convergence_ratio", C.c_double), ("weights_as_float32", C.c_int)]
+
+
+class OptResult(C.Structure):
+    _fields_ = [("success", C.c_int), ("f_init", C.c_double), ("f_opt", C.c_double),
+                ("gradnorm_init", C.c_double), ("gradnorm_opt", C.c_double),
+                ("rtr_outer_iters", C.c_int), ("tcg_iters_total", C.c_int),
+                ("hessvec_count", C.c_int), ("precond_count", C.c_int), ("accepted", C.c_int)]
+
+
+class Status(C.Structure):
+    _fields_ = [("agent_id", C.c_int), ("state", C.c_int), ("instance_number", C.c_int),
+                ("iteration_number", C.c_int), ("ready_to_terminate", C.c_int),
+                ("relative_change", C.c_double)]
+
+
+METHOD_RTR, METHOD_RGD = 0, 1
+COST_L2, COST_GNC_TLS = 0, 5
+WEIGHT_LIBRARY, WEIGHT_WRAPPER = 0, 1
+OK, NOT_READY, ERR = 0, 1, -1
+
+# every symbol include/dpgo_hip.h declares (checked by tests/test_abi.py)
+EXPORTS = """dpgo_default_params dpgo_last_error dpgo_read_g2o dpgo_read_measurements_csv dpgo_partition
+dpgo_free dpgo_odometry_init dpgo_fixed_stiefel dpgo_lift dpgo_team_create dpgo_team_destroy
+dpgo_team_num_local dpgo_team_stream dpgo_team_synchronize dpgo_agent_add_measurements
+dpgo_agent_num_poses dpgo_agent_num_measurements dpgo_agent_get_neighbors dpgo_agent_public_pose_ids
+dpgo_agent_neighbor_pose_ids dpgo_agent_set_X dpgo_agent_get_X dpgo_agent_get_public_poses
+dpgo_agent_update_neighbor_poses dpgo_agent_pack_public_poses_device
+dpgo_agent_unpack_neighbor_poses_device dpgo_agent_iterate dpgo_agent_get_status
+dpgo_agent_get_opt_result dpgo_agent_iteration_number dpgo_agent_publish_requested
+dpgo_agent_build_problem dpgo_agent_eval dpgo_agent_hessvec dpgo_agent_precondition dpgo_agent_get_Q
+dpgo_agent_get_G dpgo_project_manifold dpgo_tangent_project dpgo_retract dpgo_agent_compute_residual
+dpgo_agent_robust_weight dpgo_agent_update_measurement_weights dpgo_agent_set_measurement_weight
+dpgo_agent_get_measurements dpgo_agent_should_update_weights dpgo_agent_clear_data_matrices
+dpgo_error_threshold_at_quantile dpgo_team_set_schedule dpgo_team_set_initial dpgo_team_exchange_all
+dpgo_team_run dpgo_team_iteration dpgo_team_cost dpgo_team_update_weights dpgo_team_get_counters""".split()
+
+
+class DpgoError(RuntimeError):
+    pass
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "libdpgo_hip.so is missing (%s): build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C dpgo_ros_amd/csrc`; there is no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.dpgo_last_error.restype = C.c_char_p
+        L.dpgo_team_create.restype = C.c_void_p
+        L.dpgo_team_stream.restype = C.c_void_p
+        L.dpgo_agent_robust_weight.restype = C.c_double
+        L.dpgo_error_threshold_at_quantile.restype = C.c_double
+        _LIB = L
+    return _LIB
+
+
+def _d(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _chk(rc, what):
+    if rc < 0:
+        raise DpgoError("%s failed: %s" % (what, lib().dpgo_last_error().decode()))
+    return rc
+
+
+def default_params(r=5, num_robots=1, **kw):
+    p = Params()
+    lib().dpgo_default_params(C.byref(p), r, num_robots)
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise KeyError(k)
+        setattr(p, k, v)
+    return p
+
+
+def read_g2o(path, weight_mode=WEIGHT_LIBRARY):
+    out, n = C.c_void_p(), C.c_int()
+    nm = lib().dpgo_read_g2o(path.encode(), weight_mode, C.byref(out), C.byref(n))
+    if nm < 0:
+        raise FileNotFoundError(path)
+    raw = C.string_at(out, nm * MEAS_DTYPE.itemsize)
+    lib().dpgo_free(out)
+    return np.frombuffer(raw, dtype=MEAS_DTYPE).copy(), n.value
+
+
+def read_csv(path, weight_mode=WEIGHT_LIBRARY):
+    out = C.c_void_p()
+    nm = lib().dpgo_read_measurements_csv(path.encode(), weight_mode, C.byref(out))
+    if nm < 0:
+        raise FileNotFoundError(path)
+    raw = C.string_at(out, nm * MEAS_DTYPE.itemsize)
+    lib().dpgo_free(out)
+    return np.frombuffer(raw, dtype=MEAS_DTYPE).copy()
+
+
+def partition(m, num_poses, num_robots, weight_mode=WEIGHT_LIBRARY):
+    m = m.copy()
+    lib().dpgo_partition(_d(m), len(m), num_poses, num_robots, weight_mode)
+    return m
+
+
+def odometry_init(m, num_poses):
+    T = np.zeros(12 * num_poses)
+    lib().dpgo_odometry_init(_d(np.ascontiguousarray(m)), len(m), num_poses, _d(T))
+    return T
+
+
+def fixed_stiefel(r):
+    Y = np.zeros(3 * r)
+    lib().dpgo_fixed_stiefel(r, _d(Y))
+    return Y
+
+
+def lift(T, num_poses, YLift, r):
+    X = np.zeros(r * 4 * num_poses)
+    lib().dpgo_lift(_d(np.ascontiguousarray(T)), num_poses, _d(np.ascontiguousarray(YLift)), r, _d(X))
+    return X
+
+
+def error_threshold_at_quantile(q, dim):
+    return lib().dpgo_error_threshold_at_quantile(C.c_double(q), dim)
+
+
+class Agent:
+    """One robot's block; method names follow DPGO::PGOAgent as used by PGOAgentROS."""
+
+    def __init__(self, team, agent_id):
+        self.team = team
+        self.t = team.h
+        self.id = agent_id
+        self.r = team.r
+
+    # --- structure
+    def add_measurements(self, m):
+        m = np.ascontiguousarray(m)
+        _chk(lib().dpgo_agent_add_measurements(self.t, self.id, _d(m), len(m)), "addMeasurement")
+
+    @property
+    def n(self):
+        return _chk(lib().dpgo_agent_num_poses(self.t, self.id), "num_poses")
+
+    def _vec(self):
+        return np.zeros(self.r * 4 * self.n)
+
+    def _ids(self, fn, *args):
+        c = _chk(fn(self.t, self.id, *args, None), fn.__name__)
+        out = np.zeros(max(c, 1), dtype=np.int32)
+        fn(self.t, self.id, *args, _d(out))
+        return out[:c]
+
+    def neighbors(self):
+        return self._ids(lib().dpgo_agent_get_neighbors).tolist()
+
+    def public_pose_ids(self, nbr):
+        return self._ids(lib().dpgo_agent_public_pose_ids, nbr)
+
+    def neighbor_pose_ids(self, nbr):
+        return self._ids(lib().dpgo_agent_neighbor_pose_ids, nbr)
+
+    # --- iterate / state
+    def set_X(self, X):
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        assert X.size == self.r * 4 * self.n
+        _chk(lib().dpgo_agent_set_X(self.t, self.id, _d(X)), "set_X")
+
+    def _get(self, which):
+        X = self._vec()
+        _chk(lib().dpgo_agent_get_X(self.t, self.id, which, _d(X)), "get_X")
+        return X
+
+    def get_X(self):
+        return self._get(0)
+
+    def get_Y(self):
+        return self._get(1)
+
+    def get_V(self):
+        return self._get(2)
+
+    def get_public_poses(self, nbr, aux=False):
+        ids = self.public_pose_ids(nbr)
+        out = np.zeros(max(len(ids), 1) * 4 * self.r)
+        _chk(lib().dpgo_agent_get_public_poses(self.t, self.id, nbr, int(aux), _d(out)), "getSharedPoseDict")
+        return ids, out[:len(ids) * 4 * self.r]
+
+    def update_neighbor_poses(self, nbr, frames, poses, aux=False):
+        frames = np.ascontiguousarray(frames, dtype=np.int32)
+        poses = np.ascontiguousarray(poses, dtype=np.float64)
+        _chk(lib().dpgo_agent_update_neighbor_poses(self.t, self.id, nbr, int(aux), len(frames), _d(frames), _d(poses)),
+             "updateNeighborPoses")
+
+    def iterate(self, do_opt=True):
+        return _chk(lib().dpgo_agent_iterate(self.t, self.id, int(do_opt)), "iterate") == OK
+
+    def status(self):
+        s = Status()
+        _chk(lib().dpgo_agent_get_status(self.t, self.id, C.byref(s)), "getStatus")
+        return s
+
+    def opt_result(self):
+        s = OptResult()
+        _chk(lib().dpgo_agent_get_opt_result(self.t, self.id, C.byref(s)), "opt_result")
+        return s
+
+    def publish_requested(self, clear=False):
+        return bool(lib().dpgo_agent_publish_requested(self.t, self.id, int(clear)))
+
+    # --- QuadraticProblem surface
+    def build_problem(self, aux=False):
+        return _chk(lib().dpgo_agent_build_problem(self.t, self.id, int(aux)), "build_problem")
+
+    def eval(self, X):
+        f = C.c_double()
+        eg, rg = self._vec(), self._vec()
+        _chk(lib().dpgo_agent_eval(self.t, self.id, _d(np.ascontiguousarray(X)), C.byref(f), _d(eg), _d(rg)), "eval")
+        return f.value, eg, rg
+
+    def hessvec(self, X, eta):
+        out = self._vec()
+        _chk(lib().dpgo_agent_hessvec(self.t, self.id, _d(np.ascontiguousarray(X)), _d(np.ascontiguousarray(eta)), _d(out)),
+             "hessvec")
+        return out
+
+    def precondition(self, X, V):
+        out = self._vec()
+        _chk(lib().dpgo_agent_precondition(self.t, self.id, _d(np.ascontiguousarray(X)), _d(np.ascontiguousarray(V)), _d(out)),
+             "precondition")
+        return out
+
+    def get_Q(self):
+        nb = _chk(lib().dpgo_agent_get_Q(self.t, self.id, None, None, None), "get_Q")
+        rowptr = np.zeros(self.n + 1, dtype=np.int32)
+        col = np.zeros(nb, dtype=np.int32)
+        val = np.zeros(16 * nb)
+        lib().dpgo_agent_get_Q(self.t, self.id, _d(rowptr), _d(col), _d(val))
+        return rowptr, col, val
+
+    def get_G(self):
+        G = self._vec()
+        _chk(lib().dpgo_agent_get_G(self.t, self.id, _d(G)), "get_G")
+        return G
+
+    # --- robust path
+    def measurements(self):
+        c = _chk(lib().dpgo_agent_get_measurements(self.t, self.id, None), "measurements")
+        m = np.zeros(max(c, 1), dtype=MEAS_DTYPE)
+        lib().dpgo_agent_get_measurements(self.t, self.id, _d(m))
+        return m[:c]
+
+    def compute_residual(self, meas_row):
+        m = np.ascontiguousarray(np.array([meas_row], dtype=MEAS_DTYPE))
+        res = C.c_double()
+        rc = _chk(lib().dpgo_agent_compute_residual(self.t, self.id, _d(m), C.byref(res)), "computeMeasurementResidual")
+        return rc == OK, res.value
+
+    def robust_weight(self, residual):
+        return lib().dpgo_agent_robust_weight(self.t, self.id, C.c_double(residual))
+
+    def update_measurement_weights(self):
+        _chk(lib().dpgo_agent_update_measurement_weights(self.t, self.id), "updateMeasurementWeights")
+
+    def set_measurement_weight(self, r1, p1, r2, p2, w, fixed=False):
+        return lib().dpgo_agent_set_measurement_weight(self.t, self.id, r1, p1, r2, p2, C.c_double(w), int(fixed)) == OK
+
+    def clear_data_matrices(self):
+        _chk(lib().dpgo_agent_clear_data_matrices(self.t, self.id), "clearDataMatrices")
+
+    # --- device-buffer exchange (RCCL payloads)
+    def pack_public_poses_device(self, nbr, aux, dev_ptr):
+        return _chk(lib().dpgo_agent_pack_public_poses_device(self.t, self.id, nbr, int(aux), C.c_void_p(dev_ptr)), "pack")
+
+    def unpack_neighbor_poses_device(self, nbr, aux, dev_ptr):
+        return _chk(lib().dpgo_agent_unpack_neighbor_poses_device(self.t, self.id, nbr, int(aux), C.c_void_p(dev_ptr)), "unpack")
+
+
+class Team:
+    """The agents resident on one GPU.  With every agent of the problem local, `run` executes the
+    synchronous RBCD schedule entirely on the device."""
+
+    def __init__(self, params, agent_ids, device=0, stream=None):
+        self.params = params
+        self.r = params.r
+        ids = np.ascontiguousarray(agent_ids, dtype=np.int32)
+        h = lib().dpgo_team_create(device, C.byref(params), len(ids), _d(ids), C.c_void_p(stream) if stream else None)
+        if not h:
+            raise DpgoError("dpgo_team_create: " + lib().dpgo_last_error().decode())
+        self.h = C.c_void_p(h)
+        self.agents = {int(i): Agent(self, int(i)) for i in ids}
+        self.ids = [int(i) for i in ids]
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().dpgo_team_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @classmethod
+    def from_measurements(cls, meas, params, device=0, local_ids=None, stream=None):
+        ids = list(range(params.num_robots)) if local_ids is None else list(local_ids)
+        t = cls(params, ids, device=device, stream=stream)
+        meas = np.ascontiguousarray(meas)
+        for i in ids:
+            t.agents[i].add_measurements(meas)
+        return t
+
+    def offsets(self):
+        off, acc = [], 0
+        for i in self.ids:
+            off.append(acc)
+            acc += self.agents[i].n
+        return np.array(off, dtype=np.int32)
+
+    def set_schedule(self, order):
+        o = np.ascontiguousarray(order, dtype=np.int32)
+        _chk(lib().dpgo_team_set_schedule(self.h, _d(o), len(o)), "set_schedule")
+
+    def set_initial(self, T, YLift, offsets=None):
+        off = self.offsets() if offsets is None else np.ascontiguousarray(offsets, dtype=np.int32)
+        _chk(lib().dpgo_team_set_initial(self.h, _d(np.ascontiguousarray(T)), _d(np.ascontiguousarray(YLift)), _d(off)),
+             "set_initial")
+
+    def exchange_all(self):
+        _chk(lib().dpgo_team_exchange_all(self.h), "exchange_all")
+
+    def run(self, iters):
+        _chk(lib().dpgo_team_run(self.h, iters), "team_run")
+
+    def synchronize(self):
+        _chk(lib().dpgo_team_synchronize(self.h), "synchronize")
+
+    def iteration(self):
+        return lib().dpgo_team_iteration(self.h)
+
+    def cost(self):
+        f = C.c_double()
+        _chk(lib().dpgo_team_cost(self.h, C.byref(f)), "team_cost")
+        return f.value
+
+    def update_weights(self):
+        return _chk(lib().dpgo_team_update_weights(self.h), "team_update_weights")
+
+    def counters(self):
+        out = np.zeros(8)
+        lib().dpgo_team_get_counters(self.h, _d(out), 8)
+        return out
+
+    def stream(self):
+        return lib().dpgo_team_stream(self.h)
+
+    def global_X(self):
+        return np.concatenate([self.agents[i].get_X() for i in self.ids])

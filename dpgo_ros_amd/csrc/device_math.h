@@ -1,0 +1,179 @@
+// device_math.h -- per-pose lifted-SE(3) manifold arithmetic for gfx950 (fp64, registers only).
+//
+// Serves SURVEY 8a row a5 (LiftedPose / lifted SE manifold ops used at
+// src/PGOAgentROS.cpp:1420-1422,1463-1466): tangent projection, QF retraction, polar projection.
+// Everything is templated on the relaxation rank R so that a pose (R x 4 doubles) stays in VGPRs.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace dpgo {
+
+// 3x3 symmetric eigen-decomposition by cyclic Jacobi.  S row-major; V columns = eigenvectors.
+__device__ __forceinline__ void sym3_eig(const double S[9], double w[3], double V[9]) {
+  double A[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { A[i] = S[i]; V[i] = (i % 4 == 0) ? 1.0 : 0.0; }
+  for (int sweep = 0; sweep < 12; ++sweep) {
+    const double off = A[1] * A[1] + A[2] * A[2] + A[5] * A[5];
+    const double dia = A[0] * A[0] + A[4] * A[4] + A[8] * A[8];
+    if (off <= 1e-32 * dia) break;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+      for (int q = p + 1; q < 3; ++q) {
+        const double apq = A[3 * p + q];
+        if (apq != 0.0) {
+          const double theta = (A[4 * q] - A[4 * p]) / (2.0 * apq);
+          const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+          const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const double akp = A[3 * k + p], akq = A[3 * k + q];
+            A[3 * k + p] = c * akp - s * akq;
+            A[3 * k + q] = s * akp + c * akq;
+          }
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const double apk = A[3 * p + k], aqk = A[3 * q + k];
+            A[3 * p + k] = c * apk - s * aqk;
+            A[3 * q + k] = s * apk + c * aqk;
+          }
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const double vkp = V[3 * k + p], vkq = V[3 * k + q];
+            V[3 * k + p] = c * vkp - s * vkq;
+            V[3 * k + q] = s * vkp + c * vkq;
+          }
+        }
+      }
+    }
+  }
+  w[0] = A[0]; w[1] = A[4]; w[2] = A[8];
+}
+
+// polar factor of the R x 3 block A (column-major, A[c*R + a]) in place:  A (A^T A)^{-1/2}
+template <int R>
+__device__ __forceinline__ void polar_inplace(double *A) {
+  double S[9], w[3], V[9], M[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      double s = 0;
+#pragma unroll
+      for (int a = 0; a < R; ++a) s += A[i * R + a] * A[j * R + a];
+      S[3 * i + j] = s;
+    }
+  sym3_eig(S, w, V);
+  double iw[3] = {1.0 / sqrt(w[0]), 1.0 / sqrt(w[1]), 1.0 / sqrt(w[2])};
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      double s = 0;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) s += V[3 * i + k] * V[3 * j + k] * iw[k];
+      M[3 * i + j] = s;
+    }
+  double T[3 * R];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int a = 0; a < R; ++a) {
+      double s = 0;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) s += A[i * R + a] * M[3 * i + j];
+      T[j * R + a] = s;
+    }
+#pragma unroll
+  for (int i = 0; i < 3 * R; ++i) A[i] = T[i];
+}
+
+// Q factor (positive diagonal R) of the R x 3 block A in place, modified Gram-Schmidt
+template <int R>
+__device__ __forceinline__ void qf_inplace(double *A) {
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      if (i < j) {
+        double s = 0;
+#pragma unroll
+        for (int a = 0; a < R; ++a) s += A[i * R + a] * A[j * R + a];
+#pragma unroll
+        for (int a = 0; a < R; ++a) A[j * R + a] -= s * A[i * R + a];
+      }
+    }
+    double nn = 0;
+#pragma unroll
+    for (int a = 0; a < R; ++a) nn += A[j * R + a] * A[j * R + a];
+    nn = sqrt(nn);
+#pragma unroll
+    for (int a = 0; a < R; ++a) A[j * R + a] /= nn;
+  }
+}
+
+// W <- W - Y sym(Y^T W) on the R x 3 rotation block (translation column untouched)
+template <int R>
+__device__ __forceinline__ void tangent_inplace(const double *Y, double *W) {
+  double S[9];
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      double s = 0;
+#pragma unroll
+      for (int a = 0; a < R; ++a) s += Y[p * R + a] * W[q * R + a];
+      S[3 * p + q] = s;
+    }
+  double T[3 * R];
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+#pragma unroll
+    for (int a = 0; a < R; ++a) {
+      double s = W[q * R + a];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) s -= Y[p * R + a] * 0.5 * (S[3 * p + q] + S[3 * q + p]);
+      T[q * R + a] = s;
+    }
+#pragma unroll
+  for (int i = 0; i < 3 * R; ++i) W[i] = T[i];
+}
+
+// row `a` of  W - Y sym(Y^T W): Yp/Wp point at full R x 3 blocks (LDS or global), returns 3 values
+template <int R>
+__device__ __forceinline__ void tangent_row(const double *Yp, const double *Wp, int a, double out[3]) {
+  double S[9];
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      double s = 0;
+#pragma unroll
+      for (int b = 0; b < R; ++b) s += Yp[p * R + b] * Wp[q * R + b];
+      S[3 * p + q] = s;
+    }
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    double s = Wp[q * R + a];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) s -= Yp[p * R + a] * 0.5 * (S[3 * p + q] + S[3 * q + p]);
+    out[q] = s;
+  }
+}
+
+// wave-wide sum, every lane receives the result (fixed xor tree -> bitwise reproducible)
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// sum of a short global array of partials, identical order in every wave that calls it
+__device__ __forceinline__ double sum_partials(const double *p, int count, int stride, int lane) {
+  double s = 0;
+  for (int i = lane; i < count; i += 64) s += p[(size_t)i * stride];
+  return wave_sum(s);
+}
+
+}  // namespace dpgo

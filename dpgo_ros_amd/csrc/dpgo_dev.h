@@ -1,0 +1,81 @@
+// dpgo_dev.h -- device-visible descriptors shared by the kernels and the host runtime.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace dpgo {
+
+// work vectors of one agent, each r x 4n doubles resident in HBM
+enum Buf {
+  B_X = 0, B_XPREV, B_Y, B_V, B_G,
+  B_EGRAD, B_GF, B_Z, B_ETA, B_R0, B_R1, B_D0, B_D1, B_HD,
+  B_X2, B_EGRAD2, B_GF2, B_HETA, B_T0, B_T1, B_T2,
+  NBUF
+};
+
+// one shared (inter-robot) edge as seen by the G assembly: G_i[:,c] -= sum_cp Xn[:,cp] coef[cp+4c]
+struct SharedEdgeDev {
+  int lpose;  // local pose that receives the contribution
+  int slot;   // index into the neighbour-pose slab
+  int src_agent_local;  // local index of the neighbour agent in this team, or -1 if remote
+  int src_frame;
+  double coef[16];
+};
+
+// per-edge record for residual / cost evaluation
+struct EdgeDev {
+  int i_local, j_local;    // local pose index or -1
+  int i_slot, j_slot;      // neighbour slab slot when not local
+  double R[9];             // row-major
+  double t[3];
+  double kappa, tau, weight;
+  int count_in_cost;       // 1 if this agent owns the edge for the global cost
+  int pad;
+};
+
+// trust-region / tCG scalar state (device resident, ping-pong [2])
+struct RtrState {
+  double f1, ngf, Delta;
+  double z_r, d_Pd, e_Pd, e_Pe, norm_r0, alpha;
+  double f_init, gn_init;
+  int outer_it, outer_done, tcg_active, tcg_j, tcg_status;
+  int hv_count, pc_count, tcg_total, accepted, outer_count;
+};
+
+struct NestState {
+  double gamma, alpha;
+  int iter;     // mIterationNumber of this agent
+  int pad;
+};
+
+struct AgentDev {
+  int id, n, nb, N4;
+  int npub, nshared, nnp, nedges;
+  const int *rowptr;
+  const int *col;
+  const double *qval;
+  const double *M;            // dense (Q + shift I)^-1, N4 x N4 column-major (symmetric)
+  const int *pub_pose;        // [npub] local poses that own >= 1 shared edge
+  const int *pub_ptr;         // [npub+1] CSR into se
+  const SharedEdgeDev *se;    // [nshared] sorted by lpose
+  const EdgeDev *edges;       // [nedges] all measurements of this agent
+  double *nbr[2];             // neighbour pose slabs (0 main, 1 auxiliary), [nnp][4r]
+  double *buf[NBUF];
+  double *part;               // partial-sum scratch, [PART_STRIDE * MAX_PART]
+  RtrState *st;               // [2]
+  NestState *nest;            // [1]
+  double *scal;               // [16] misc scalars: 0 relchange^2, 1 f_opt, 2 gn_opt^2, 3 f_init, 4 gn_init^2
+  double *resid;              // [nedges] residual scratch
+};
+
+constexpr int PART_STRIDE = 8;   // doubles per block of partials
+constexpr int MAX_PART = 4096;   // max blocks contributing partials
+
+struct TeamDev {
+  int num_agents;
+  int sched_len;
+  int iter;          // global iteration counter (device copy)
+  int restart_interval;
+  const int *sched;  // [sched_len] local agent index selected at iteration k % sched_len
+};
+
+}  // namespace dpgo

@@ -1,0 +1,1023 @@
+// kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4, wave64) for the RBCD hot path.
+//
+// SURVEY 8a rows served here (call sites in /root/reference, bodies external):
+//   a2  G assembly from neighbour public poses           (src/PGOAgentROS.cpp:1276,1278 feed it)
+//   a3  QuadraticProblem f / EucGrad / RieGrad / Hess-vec / PreConditioner  (:169-172)
+//   a4  RTR (Steihaug tCG) state machine + RGD step      (src/PGOAgentROSNode.cpp:85,90,96-100)
+//   a5  tangent projection / QF retraction / polar projection (:1420-1422)
+//   a6  Nesterov gamma/alpha/Y/V sequences + restart     (src/PGOAgentROSNode.cpp:126-130)
+//   a7  pack/unpack of public-pose slabs                 (:662-690, :1255-1284)
+//   a8  per-edge residuals                               (:1049)
+//
+// Layout: X is r x 4n column-major (pose = 4r contiguous doubles).  Q is block-CSR with 4x4
+// column-major blocks, row j lists (i, Q_ij) so (XQ)_j = sum_i X_i Q_ij.  One lane owns one
+// (pose, row a) pair: a 64-wide wave covers floor(64/R) poses; the 4x4 block is a wave-broadcast
+// load, the pose rows are 32-byte strided loads inside one 160-byte pose record.
+// Scalars of the inner solve (dots, alpha, beta, rho, radius) never visit the host: every
+// workgroup re-derives them from the same per-block partial sums in the same order, and
+// workgroup 0 publishes the next state into the other half of a ping-pong pair.
+#include "device_math.h"
+#include "dpgo_dev.h"
+#include "kernels.h"
+
+namespace dpgo {
+
+__device__ __forceinline__ const AgentDev &pick(const AgentDev *agents, const TeamDev *team, int sel) {
+  const int idx = sel >= 0 ? sel : team->sched[team->iter % team->sched_len];
+  return agents[idx];
+}
+__device__ __forceinline__ int pick_idx(const TeamDev *team, int sel) {
+  return sel >= 0 ? sel : team->sched[team->iter % team->sched_len];
+}
+
+constexpr int PA_OFF = 0;                            // partials of spmm-type kernels
+constexpr int PB_OFF = MAX_PART * PART_STRIDE;       // partials of precond-type kernels
+constexpr int PC_OFF = 2 * MAX_PART * PART_STRIDE;   // partials of the outer-step evaluation
+
+template <int R>
+__device__ __forceinline__ int spmm_blocks(int n) { return (n + (64 / R) - 1) / (64 / R); }
+__device__ __forceinline__ int precond_blocks(int N4) { return (N4 + 7) / 8; }
+
+// acc[c] += sum_i sum_cp src(i, cp) * Q_ij[cp, c]   for output pose j, row a
+template <int R, class Src>
+__device__ __forceinline__ void spmm_row(const AgentDev &ag, int j, Src src, double acc[4]) {
+  const int p0 = ag.rowptr[j], p1 = ag.rowptr[j + 1];
+  for (int p = p0; p < p1; ++p) {
+    const int i = ag.col[p];
+    const double2 *B = reinterpret_cast<const double2 *>(ag.qval + (size_t)16 * p);
+    double x[4];
+    src(i, x);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const double2 b01 = B[2 * c], b23 = B[2 * c + 1];
+      acc[c] += x[0] * b01.x + x[1] * b01.y + x[2] * b23.x + x[3] * b23.y;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// G assembly (a2).  One lane per (public pose, row a).  pull != 0: read the neighbour's pose
+// straight from the neighbour agent's X / Y array on this GPU (device-to-device exchange that
+// replaces the PublicPoses topic) and refresh the slab; else read the slab filled by unpack.
+template <int R>
+__global__ __launch_bounds__(64) void k_buildG(const AgentDev *agents, const TeamDev *team, int sel, int aux,
+                                               int pull) {
+  const AgentDev &ag = pick(agents, team, sel);
+  constexpr int PPB = 64 / R;
+  const int lane = threadIdx.x, lp = lane / R, a = lane - lp * R;
+  const int q = blockIdx.x * PPB + lp;
+  if (lp >= PPB || q >= ag.npub) return;
+  double acc[4] = {0, 0, 0, 0};
+  for (int e = ag.pub_ptr[q]; e < ag.pub_ptr[q + 1]; ++e) {
+    const SharedEdgeDev &se = ag.se[e];
+    double *slab = ag.nbr[aux] + (size_t)se.slot * 4 * R;
+    double x[4];
+    if (pull && se.src_agent_local >= 0) {
+      const double *src = agents[se.src_agent_local].buf[aux ? B_Y : B_X] + (size_t)se.src_frame * 4 * R;
+#pragma unroll
+      for (int cp = 0; cp < 4; ++cp) { x[cp] = src[cp * R + a]; slab[cp * R + a] = x[cp]; }
+    } else {
+#pragma unroll
+      for (int cp = 0; cp < 4; ++cp) x[cp] = slab[cp * R + a];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int cp = 0; cp < 4; ++cp) acc[c] -= x[cp] * se.coef[cp + 4 * c];
+  }
+  double *G = ag.buf[B_G] + (size_t)ag.pub_pose[q] * 4 * R;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) G[c * R + a] = acc[c];
+}
+
+// refresh every slab entry of one agent from co-resident neighbours (both sequences)
+template <int R>
+__global__ void k_pull(const AgentDev *agents, int dst) {
+  const AgentDev &ag = agents[dst];
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ag.nshared * 4 * R) return;
+  const int e = t / (4 * R), k = t - e * 4 * R;
+  const SharedEdgeDev &se = ag.se[e];
+  if (se.src_agent_local < 0) return;
+  const AgentDev &sa = agents[se.src_agent_local];
+  ag.nbr[0][(size_t)se.slot * 4 * R + k] = sa.buf[B_X][(size_t)se.src_frame * 4 * R + k];
+  ag.nbr[1][(size_t)se.slot * 4 * R + k] = sa.buf[B_Y][(size_t)se.src_frame * 4 * R + k];
+}
+
+// ------------------------------------------------------------------------------------------------
+// f, Euclidean gradient, Riemannian gradient (a3).  partials: [0] f, [1] |rgrad|^2
+template <int R>
+__global__ __launch_bounds__(64) void k_eval(const AgentDev *agents, const TeamDev *team, int sel, int xb, int egb,
+                                             int gfb, int poff) {
+  const AgentDev &ag = pick(agents, team, sel);
+  constexpr int PPB = 64 / R;
+  __shared__ double Ysh[PPB * 4 * R], Wsh[PPB * 4 * R];
+  const int lane = threadIdx.x, lp = lane / R, a = lane - lp * R;
+  const int j = blockIdx.x * PPB + lp;
+  if (blockIdx.x * PPB >= ag.n) return;
+  const bool act = lp < PPB && j < ag.n;
+  const double *X = ag.buf[xb];
+  double fpart = 0, gpart = 0, eg3 = 0;
+  if (act) {
+    double acc[4] = {0, 0, 0, 0};
+    spmm_row<R>(ag, j, [&](int i, double x[4]) {
+#pragma unroll
+      for (int cp = 0; cp < 4; ++cp) x[cp] = X[((size_t)4 * i + cp) * R + a];
+    }, acc);
+    const double *G = ag.buf[B_G] + (size_t)j * 4 * R;
+    double *EG = ag.buf[egb] + (size_t)j * 4 * R;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const double xr = X[((size_t)4 * j + c) * R + a], g = G[c * R + a];
+      fpart += (0.5 * acc[c] + g) * xr;
+      const double eg = acc[c] + g;
+      EG[c * R + a] = eg;
+      Ysh[lp * 4 * R + c * R + a] = xr;
+      Wsh[lp * 4 * R + c * R + a] = eg;
+      if (c == 3) eg3 = eg;
+    }
+  }
+  __syncthreads();
+  if (act) {
+    double o[3];
+    tangent_row<R>(Ysh + lp * 4 * R, Wsh + lp * 4 * R, a, o);
+    double *GF = ag.buf[gfb] + (size_t)j * 4 * R;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { GF[c * R + a] = o[c]; gpart += o[c] * o[c]; }
+    GF[3 * R + a] = eg3;
+    gpart += eg3 * eg3;
+  }
+  fpart = wave_sum(fpart);
+  gpart = wave_sum(gpart);
+  if (lane == 0) {
+    double *P = ag.part + poff + (size_t)blockIdx.x * PART_STRIDE;
+    P[0] = fpart; P[1] = gpart;
+  }
+}
+
+// shared tail of every Hessian-vector product: curvature correction + tangent projection.
+// in : wrow[4] = (V Q)_j row a, vrow[4] = V_j row a, Ysh/Esh = full Y_j / egrad_j staged in LDS
+// out: hrow[4] = Hess f[V]_j row a ;  Wsh used as scratch
+template <int R>
+__device__ __forceinline__ void hess_tail(const double *Ysh, const double *Esh, double *Wsh, int a,
+                                          const double wrow[4], const double vrow[4], double hrow[4], bool act) {
+  if (act) {
+    double S[9];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        double s = 0;
+#pragma unroll
+        for (int b = 0; b < R; ++b) s += Ysh[p * R + b] * Esh[q * R + b];
+        S[3 * p + q] = s;
+      }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      double s = wrow[q];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) s -= vrow[p] * 0.5 * (S[3 * p + q] + S[3 * q + p]);
+      Wsh[q * R + a] = s;
+    }
+  }
+  __syncthreads();
+  if (act) {
+    double o[3];
+    tangent_row<R>(Ysh, Wsh, a, o);
+    hrow[0] = o[0]; hrow[1] = o[1]; hrow[2] = o[2]; hrow[3] = wrow[3];
+  }
+}
+
+// generic Riemannian Hessian-vector product at point xb with Euclidean gradient egb:  ob = Hess[vb]
+// partials: [0] <v, Hv>
+template <int R>
+__global__ __launch_bounds__(64) void k_hess(const AgentDev *agents, const TeamDev *team, int sel, int xb, int egb,
+                                             int vb, int ob, int poff) {
+  const AgentDev &ag = pick(agents, team, sel);
+  constexpr int PPB = 64 / R;
+  __shared__ double Ysh[PPB * 4 * R], Esh[PPB * 4 * R], Wsh[PPB * 4 * R];
+  const int lane = threadIdx.x, lp = lane / R, a = lane - lp * R;
+  const int j = blockIdx.x * PPB + lp;
+  if (blockIdx.x * PPB >= ag.n) return;
+  const bool act = lp < PPB && j < ag.n;
+  const double *V = ag.buf[vb];
+  double wrow[4] = {0, 0, 0, 0}, vrow[4] = {0, 0, 0, 0}, hrow[4];
+  if (act) {
+    spmm_row<R>(ag, j, [&](int i, double x[4]) {
+#pragma unroll
+      for (int cp = 0; cp < 4; ++cp) x[cp] = V[((size_t)4 * i + cp) * R + a];
+    }, wrow);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      vrow[c] = V[((size_t)4 * j + c) * R + a];
+      Ysh[lp * 4 * R + c * R + a] = ag.buf[xb][((size_t)4 * j + c) * R + a];
+      Esh[lp * 4 * R + c * R + a] = ag.buf[egb][((size_t)4 * j + c) * R + a];
+    }
+  }
+  __syncthreads();
+  hess_tail<R>(Ysh + lp * 4 * R, Esh + lp * 4 * R, Wsh + lp * 4 * R, a, wrow, vrow, hrow, act);
+  double d = 0;
+  if (act) {
+    double *O = ag.buf[ob] + (size_t)j * 4 * R;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { O[c * R + a] = hrow[c]; d += vrow[c] * hrow[c]; }
+  }
+  d = wave_sum(d);
+  if (lane == 0) ag.part[poff + (size_t)blockIdx.x * PART_STRIDE] = d;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Dense preconditioner apply  z = P_X( v (Q + shift I)^-1 )  (a3 PreConditioner).
+// Workgroup = 256 threads = 8 scalar columns (2 poses) x 32 k-lanes; the input vector is staged in
+// LDS as SoA [a][k] in chunks so that M (the only large operand, N4^2 doubles) is streamed exactly
+// once with 16-byte coalesced loads.  Modes:
+//   PM_PLAIN    v = buf[vb]                        -> buf[zb]            partials [0]<z,v> [1]<v,v>
+//   PM_TCG_INIT v = gf; r0 = gf; eta = 0; d0 = -z  (tCG set-up, RtrState ping-pong)
+//   PM_TCG_STEP v = r_old + alpha Hd (on the fly), eta += alpha d, z = P(v M)   (tCG body, part 2)
+enum { PM_PLAIN = 0, PM_TCG_INIT = 1, PM_TCG_STEP = 2 };
+constexpr int KC = 1024;  // scalars of the input vector staged per chunk (KC * R * 8 bytes of LDS)
+
+template <int R, int MODE>
+__global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, const TeamDev *team, int sel, int xb, int vb,
+                                                 int zb, int sp, int max_inner) {
+  const AgentDev &ag = pick(agents, team, sel);
+  __shared__ double vs[R * KC];
+  __shared__ double zs[8 * R];
+  __shared__ double Ysh[2 * 4 * R];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int N4 = ag.N4;
+  const int nblk = precond_blocks(N4);
+  if ((int)blockIdx.x >= nblk) return;
+
+  // ---- scalar prologue (identical in every workgroup)
+  double alpha = 0, tau = 0;
+  int jpar = 0;
+  bool boundary = false;
+  RtrState S;
+  if (MODE != PM_PLAIN) {
+    S = ag.st[sp];
+    const bool idle = S.outer_done || (MODE == PM_TCG_STEP && !S.tcg_active);
+    if (idle) {
+      if (blockIdx.x == 0 && tid == 0) ag.st[sp ^ 1] = S;
+      return;
+    }
+    if (MODE == PM_TCG_STEP) {
+      const double d_Hd = sum_partials(ag.part + PA_OFF, spmm_blocks<R>(ag.n), PART_STRIDE, lane);
+      alpha = S.z_r / d_Hd;
+      const double e_Pe_new = S.e_Pe + 2.0 * alpha * S.e_Pd + alpha * alpha * S.d_Pd;
+      jpar = S.tcg_j & 1;
+      if (d_Hd <= 0 || e_Pe_new >= S.Delta * S.Delta) {
+        boundary = true;
+        tau = (-S.e_Pd + sqrt(S.e_Pd * S.e_Pd + S.d_Pd * (S.Delta * S.Delta - S.e_Pe))) / S.d_Pd;
+        if (blockIdx.x == 0 && tid == 0) {
+          RtrState T = S;
+          T.tcg_active = 0;
+          T.tcg_status = (d_Hd <= 0) ? 1 : 2;
+          ag.st[sp ^ 1] = T;
+        }
+      } else if (blockIdx.x == 0 && tid == 0) {
+        RtrState T = S;
+        T.e_Pe = e_Pe_new;
+        T.alpha = alpha;
+        T.tcg_j = S.tcg_j + 1;
+        T.pc_count = S.pc_count + 1;
+        ag.st[sp ^ 1] = T;
+      }
+    } else if (blockIdx.x == 0 && tid == 0) {
+      RtrState T = S;
+      T.tcg_active = 1; T.tcg_j = 0; T.tcg_status = 0;
+      T.e_Pd = 0; T.e_Pe = 0; T.alpha = 0;
+      T.pc_count = S.pc_count + 1;
+      T.outer_count = S.outer_count + 1;
+      ag.st[sp ^ 1] = T;
+    }
+  }
+
+  const double *Vin = (MODE == PM_PLAIN) ? ag.buf[vb] : (MODE == PM_TCG_INIT ? ag.buf[B_GF] : ag.buf[jpar ? B_R1 : B_R0]);
+  const double *Hd = ag.buf[B_HD];
+  const int col0 = 8 * blockIdx.x;
+  const int npose = min(2, ag.n - 2 * (int)blockIdx.x);
+
+  if (MODE == PM_TCG_STEP) {
+    // eta += (alpha | tau) * delta on the two poses owned by this workgroup
+    const double *D = ag.buf[jpar ? B_D1 : B_D0];
+    double *E = ag.buf[B_ETA];
+    const double stepc = boundary ? tau : alpha;
+    if (tid < npose * 4 * R) {
+      const size_t o = (size_t)col0 * R + tid;
+      E[o] += stepc * D[o];
+    }
+    if (boundary) return;
+  }
+
+  const int cg = tid >> 5, kl = tid & 31;
+  const int col = col0 + cg;
+  const bool cact = col < N4;
+  const double *Mc = ag.M + (size_t)(cact ? col : 0) * N4;
+  double acc[R];
+#pragma unroll
+  for (int a = 0; a < R; ++a) acc[a] = 0;
+
+  for (int k0 = 0; k0 < N4; k0 += KC) {
+    const int kn = min(KC, N4 - k0);
+    __syncthreads();
+    for (int t = tid; t < kn * R; t += 256) {
+      const int k = t / R, a = t - k * R;
+      double v = Vin[(size_t)(k0 + k) * R + a];
+      if (MODE == PM_TCG_STEP) v += alpha * Hd[(size_t)(k0 + k) * R + a];
+      vs[a * KC + k] = v;
+    }
+    __syncthreads();
+    if (cact) {
+      for (int k = 2 * kl; k < kn; k += 64) {
+        const double2 m = *reinterpret_cast<const double2 *>(Mc + k0 + k);
+#pragma unroll
+        for (int a = 0; a < R; ++a) {
+          const double2 v = *reinterpret_cast<const double2 *>(&vs[a * KC + k]);
+          acc[a] += v.x * m.x + v.y * m.y;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < R; ++a) {
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) acc[a] += __shfl_xor(acc[a], off, 64);
+  }
+  if (kl == 0) {
+#pragma unroll
+    for (int a = 0; a < R; ++a) zs[cg * R + a] = acc[a];
+  }
+  if (tid < npose * 4 * R) Ysh[tid] = ag.buf[xb][(size_t)col0 * R + tid];
+  __syncthreads();
+
+  // ---- epilogue: tangent projection of the two poses, dots, mode-specific stores
+  double zr = 0, rr = 0;
+  if (tid < npose * R) {
+    const int lp = tid / R, a = tid - lp * R;
+    const size_t o = (size_t)(2 * blockIdx.x + lp) * 4 * R;
+    double z[4];
+    tangent_row<R>(Ysh + lp * 4 * R, zs + lp * 4 * R, a, z);
+    z[3] = zs[lp * 4 * R + 3 * R + a];
+    double *Z = ag.buf[(MODE == PM_PLAIN) ? zb : B_Z];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      double v = Vin[o + c * R + a];
+      if (MODE == PM_TCG_STEP) {
+        v += alpha * Hd[o + c * R + a];
+        ag.buf[jpar ? B_R0 : B_R1][o + c * R + a] = v;  // r_new into the other half
+      }
+      if (MODE == PM_TCG_INIT) {
+        ag.buf[B_R0][o + c * R + a] = v;
+        ag.buf[B_ETA][o + c * R + a] = 0.0;
+        ag.buf[B_D0][o + c * R + a] = -z[c];
+      }
+      Z[o + c * R + a] = z[c];
+      zr += z[c] * v;
+      rr += v * v;
+    }
+  }
+  if (tid < 64) {
+    zr = wave_sum(zr);
+    rr = wave_sum(rr);
+    if (tid == 0) {
+      double *P = ag.part + PB_OFF + (size_t)blockIdx.x * PART_STRIDE;
+      P[0] = zr; P[1] = rr;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// tCG body, part 1:  delta <- -z + beta delta (on the fly), Hd = Hess[delta], partial <delta, Hd>.
+template <int R>
+__global__ __launch_bounds__(64) void k_tcg_hv(const AgentDev *agents, const TeamDev *team, int sel, int sp,
+                                               int max_inner) {
+  const AgentDev &ag = pick(agents, team, sel);
+  constexpr int PPB = 64 / R;
+  __shared__ double Ysh[PPB * 4 * R], Esh[PPB * 4 * R], Wsh[PPB * 4 * R];
+  const int lane = threadIdx.x, lp = lane / R, a = lane - lp * R;
+  const int j = blockIdx.x * PPB + lp;
+  if (blockIdx.x * PPB >= ag.n) return;
+  const RtrState S = ag.st[sp];
+  if (S.outer_done || !S.tcg_active) {
+    if (blockIdx.x == 0 && lane == 0) ag.st[sp ^ 1] = S;
+    return;
+  }
+  const double theta = 1.0, kappa = 0.1;
+  const int npb = precond_blocks(ag.N4);
+  const double zr_new = sum_partials(ag.part + PB_OFF, npb, PART_STRIDE, lane);
+  const double rr_new = sum_partials(ag.part + PB_OFF + 1, npb, PART_STRIDE, lane);
+  RtrState T = S;
+  double beta = 0;
+  const bool fresh = (S.tcg_j == 0);
+  if (fresh) {
+    T.z_r = zr_new; T.d_Pd = zr_new; T.norm_r0 = sqrt(rr_new);
+  } else {
+    const double nr = sqrt(rr_new);
+    const double thr = pow(S.norm_r0, theta);
+    bool stop = false;
+    if (nr <= S.norm_r0 * (thr < kappa ? thr : kappa)) { T.tcg_status = (kappa < thr) ? 3 : 4; stop = true; }
+    else if (S.tcg_j >= max_inner) { T.tcg_status = 0; stop = true; }
+    if (stop) {
+      T.tcg_active = 0;
+      if (blockIdx.x == 0 && lane == 0) ag.st[sp ^ 1] = T;
+      return;
+    }
+    beta = zr_new / S.z_r;
+    T.e_Pd = beta * (S.e_Pd + S.alpha * S.d_Pd);
+    T.d_Pd = zr_new + beta * beta * S.d_Pd;
+    T.z_r = zr_new;
+  }
+  T.hv_count = S.hv_count + 1;
+  T.tcg_total = S.tcg_total + 1;
+  if (blockIdx.x == 0 && lane == 0) ag.st[sp ^ 1] = T;
+
+  const bool act = lp < PPB && j < ag.n;
+  const int jp = S.tcg_j & 1;
+  const double *Dold = ag.buf[jp ? B_D0 : B_D1];  // delta of iteration j-1
+  double *Dnew = ag.buf[jp ? B_D1 : B_D0];        // delta of iteration j (T0 wrote D0 for j = 0)
+  const double *Z = ag.buf[B_Z];
+  double wrow[4] = {0, 0, 0, 0}, vrow[4] = {0, 0, 0, 0}, hrow[4];
+  if (act) {
+    spmm_row<R>(ag, j, [&](int i, double x[4]) {
+#pragma unroll
+      for (int cp = 0; cp < 4; ++cp) {
+        const size_t o = ((size_t)4 * i + cp) * R + a;
+        x[cp] = fresh ? Dnew[o] : (-Z[o] + beta * Dold[o]);
+      }
+    }, wrow);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const size_t o = ((size_t)4 * j + c) * R + a;
+      vrow[c] = fresh ? Dnew[o] : (-Z[o] + beta * Dold[o]);
+      if (!fresh) Dnew[o] = vrow[c];
+      Ysh[lp * 4 * R + c * R + a] = ag.buf[B_X][o];
+      Esh[lp * 4 * R + c * R + a] = ag.buf[B_EGRAD][o];
+    }
+  }
+  __syncthreads();
+  hess_tail<R>(Ysh + lp * 4 * R, Esh + lp * 4 * R, Wsh + lp * 4 * R, a, wrow, vrow, hrow, act);
+  double d = 0;
+  if (act) {
+    double *O = ag.buf[B_HD] + (size_t)j * 4 * R;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { O[c * R + a] = hrow[c]; d += vrow[c] * hrow[c]; }
+  }
+  d = wave_sum(d);
+  if (lane == 0) ag.part[PA_OFF + (size_t)blockIdx.x * PART_STRIDE] = d;
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-pose kernels: one lane per pose, the whole pose in registers
+template <int R>
+__device__ __forceinline__ void load_pose(const double *p, double *v) {
+#pragma unroll
+  for (int i = 0; i < 4 * R; ++i) v[i] = p[i];
+}
+template <int R>
+__device__ __forceinline__ void store_pose(double *p, const double *v) {
+#pragma unroll
+  for (int i = 0; i < 4 * R; ++i) p[i] = v[i];
+}
+
+// out = Retr_x(scale * eta).  guard_state >= 0: skip when the trust-region state says done.
+template <int R>
+__global__ void k_retract(const AgentDev *agents, const TeamDev *team, int sel, int xb, int eb, double scale, int ob,
+                          int guard_state) {
+  const AgentDev &ag = pick(agents, team, sel);
+  if (guard_state >= 0 && ag.st[guard_state].outer_done) return;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= ag.n) return;
+  double x[4 * R], e[4 * R];
+  load_pose<R>(ag.buf[xb] + (size_t)j * 4 * R, x);
+  load_pose<R>(ag.buf[eb] + (size_t)j * 4 * R, e);
+#pragma unroll
+  for (int i = 0; i < 4 * R; ++i) x[i] += scale * e[i];
+  qf_inplace<R>(x);
+  store_pose<R>(ag.buf[ob] + (size_t)j * 4 * R, x);
+}
+
+// raw-pointer manifold ops (unit parity + set-up)
+template <int R>
+__global__ void k_project_raw(const double *X, double *out, int n) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  double x[4 * R];
+  load_pose<R>(X + (size_t)j * 4 * R, x);
+  polar_inplace<R>(x);
+  store_pose<R>(out + (size_t)j * 4 * R, x);
+}
+template <int R>
+__global__ void k_tangent_raw(const double *X, const double *V, double *out, int n) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  double x[4 * R], v[4 * R];
+  load_pose<R>(X + (size_t)j * 4 * R, x);
+  load_pose<R>(V + (size_t)j * 4 * R, v);
+  tangent_inplace<R>(x, v);
+  store_pose<R>(out + (size_t)j * 4 * R, v);
+}
+template <int R>
+__global__ void k_retract_raw(const double *X, const double *E, double *out, int n) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  double x[4 * R], e[4 * R];
+  load_pose<R>(X + (size_t)j * 4 * R, x);
+  load_pose<R>(E + (size_t)j * 4 * R, e);
+#pragma unroll
+  for (int i = 0; i < 4 * R; ++i) x[i] += e[i];
+  qf_inplace<R>(x);
+  store_pose<R>(out + (size_t)j * 4 * R, x);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Nesterov sequences (a6).  blockIdx.y = local agent.  For every agent:
+//   XPrev = X;  gamma' = (1 + sqrt(1 + 4 N^2 gamma^2)) / 2N;  alpha = 1 / (gamma' N)
+//   Y = proj((1 - alpha) X + alpha V);  X = Y
+// and for the agents that do NOT optimize this iteration (everything but `sel`, or all when
+// only_agent >= 0 names a single non-optimizing agent):  V = proj(V)  [= proj(V + gamma (X - Y))],
+// then the periodic restart X = XPrev, V = Y = X.
+template <int R>
+__global__ void k_nest_pre(const AgentDev *agents, const TeamDev *team, int sel, int only_agent, int num_robots,
+                           int restart_interval) {
+  const int ai = only_agent >= 0 ? only_agent : (int)blockIdx.y;
+  const AgentDev &ag = agents[ai];
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= ag.n) return;
+  const bool optimizing = (sel == -2) ? false : (ai == pick_idx(team, sel));
+  const NestState ns = *ag.nest;
+  const double Nr = (double)num_robots;
+  const double gamma = (1.0 + sqrt(1.0 + 4.0 * Nr * Nr * ns.gamma * ns.gamma)) / (2.0 * Nr);
+  const double alpha = 1.0 / (gamma * Nr);
+  const bool restart = ((ns.iter + 2) % restart_interval) == 0;  // iter is pre-increment: (iter+1)+1
+  double x[4 * R], v[4 * R], y[4 * R];
+  const size_t o = (size_t)j * 4 * R;
+  load_pose<R>(ag.buf[B_X] + o, x);
+  load_pose<R>(ag.buf[B_V] + o, v);
+  store_pose<R>(ag.buf[B_XPREV] + o, x);
+#pragma unroll
+  for (int i = 0; i < 4 * R; ++i) y[i] = (1.0 - alpha) * x[i] + alpha * v[i];
+  polar_inplace<R>(y);
+  store_pose<R>(ag.buf[B_Y] + o, y);
+  if (optimizing) {
+    store_pose<R>(ag.buf[B_X] + o, y);  // the local solve starts from Y, in place on X
+    return;
+  }
+  if (restart) {
+    // X = XPrev; V = X; Y = X
+    store_pose<R>(ag.buf[B_V] + o, x);
+    store_pose<R>(ag.buf[B_Y] + o, x);
+  } else {
+    store_pose<R>(ag.buf[B_X] + o, y);
+    polar_inplace<R>(v);
+    store_pose<R>(ag.buf[B_V] + o, v);
+  }
+}
+
+// after the selected agent's local solve:  V = proj(V + gamma' (X - Y)); on restart X = XPrev
+// (the host then re-optimizes from XPrev and calls k_nest_reset).
+template <int R>
+__global__ void k_nest_post(const AgentDev *agents, const TeamDev *team, int sel, int num_robots, int restart_interval) {
+  const AgentDev &ag = pick(agents, team, sel);
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= ag.n) return;
+  const NestState ns = *ag.nest;
+  const double Nr = (double)num_robots;
+  const double gamma = (1.0 + sqrt(1.0 + 4.0 * Nr * Nr * ns.gamma * ns.gamma)) / (2.0 * Nr);
+  const bool restart = ((ns.iter + 2) % restart_interval) == 0;
+  const size_t o = (size_t)j * 4 * R;
+  double x[4 * R], v[4 * R], y[4 * R];
+  if (restart) {
+    load_pose<R>(ag.buf[B_XPREV] + o, x);
+    store_pose<R>(ag.buf[B_X] + o, x);
+    return;
+  }
+  load_pose<R>(ag.buf[B_X] + o, x);
+  load_pose<R>(ag.buf[B_V] + o, v);
+  load_pose<R>(ag.buf[B_Y] + o, y);
+#pragma unroll
+  for (int i = 0; i < 4 * R; ++i) v[i] += gamma * (x[i] - y[i]);
+  polar_inplace<R>(v);
+  store_pose<R>(ag.buf[B_V] + o, v);
+}
+
+// V = X; Y = X  (restart tail / weight update)
+__global__ void k_nest_reset(const AgentDev *agents, const TeamDev *team, int sel, int r) {
+  const AgentDev &ag = pick(agents, team, sel);
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ag.N4 * r) return;
+  const double x = ag.buf[B_X][t];
+  ag.buf[B_V][t] = x;
+  ag.buf[B_Y][t] = x;
+}
+
+// end of an iteration: advance gamma/alpha/iter of every agent (blockIdx.x = agent), and the team
+// counter.  accel == 0: only the iteration counters move.
+__global__ void k_advance(const AgentDev *agents, TeamDev *team, int only_agent, int accel, int num_robots,
+                          int restart_interval, int bump_team) {
+  const int ai = only_agent >= 0 ? only_agent : (int)blockIdx.x;
+  if (threadIdx.x != 0) return;
+  NestState ns = *agents[ai].nest;
+  if (accel) {
+    const double Nr = (double)num_robots;
+    const bool restart = ((ns.iter + 2) % restart_interval) == 0;
+    if (restart) { ns.gamma = 0; ns.alpha = 0; }
+    else {
+      ns.gamma = (1.0 + sqrt(1.0 + 4.0 * Nr * Nr * ns.gamma * ns.gamma)) / (2.0 * Nr);
+      ns.alpha = 1.0 / (ns.gamma * Nr);
+    }
+  }
+  ns.iter += 1;
+  *agents[ai].nest = ns;
+  if (bump_team && ai == 0) team->iter += 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// single-workgroup finishers (deterministic order)
+// scal[0] = |X - XPrev|_F^2 ; optionally scal[so], scal[so+1] = sum of eval partials (f, |g|^2)
+template <int R>
+__global__ __launch_bounds__(256) void k_status(const AgentDev *agents, const TeamDev *team, int sel, int only_agent,
+                                                int stat_off, int poff) {
+  const int ai = only_agent >= 0 ? only_agent : (sel == -3 ? (int)blockIdx.x : pick_idx(team, sel));
+  const AgentDev &ag = agents[ai];
+  __shared__ double red[4];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const size_t len = (size_t)ag.n * 4 * R;
+  double s = 0;
+  for (size_t t = tid; t < len; t += 256) {
+    const double d = ag.buf[B_X][t] - ag.buf[B_XPREV][t];
+    s += d * d;
+  }
+  s = wave_sum(s);
+  if (lane == 0) red[w] = s;
+  __syncthreads();
+  if (tid == 0) ag.scal[0] = (red[0] + red[1]) + (red[2] + red[3]);
+  if (stat_off >= 0 && w == 0) {
+    const int nb = spmm_blocks<R>(ag.n);
+    const double f = sum_partials(ag.part + poff, nb, PART_STRIDE, lane);
+    const double g = sum_partials(ag.part + poff + 1, nb, PART_STRIDE, lane);
+    if (lane == 0) { ag.scal[stat_off] = f; ag.scal[stat_off + 1] = g; }
+  }
+}
+
+// trust-region set-up from the initial evaluation partials
+template <int R>
+__global__ void k_rtr_begin(const AgentDev *agents, const TeamDev *team, int sel, double Delta0, double tol,
+                            int max_outer) {
+  const AgentDev &ag = pick(agents, team, sel);
+  const int lane = threadIdx.x;
+  const int nb = spmm_blocks<R>(ag.n);
+  const double f = sum_partials(ag.part + PA_OFF, nb, PART_STRIDE, lane);
+  const double g = sum_partials(ag.part + PA_OFF + 1, nb, PART_STRIDE, lane);
+  if (lane != 0) return;
+  RtrState S = {};
+  S.f1 = f; S.ngf = sqrt(g); S.Delta = Delta0;
+  S.f_init = f; S.gn_init = S.ngf;
+  S.outer_done = (S.ngf < tol) || (max_outer <= 0);
+  ag.st[0] = S;
+  ag.st[1] = S;
+  ag.scal[3] = f; ag.scal[4] = g;
+}
+
+// outer step, evaluation at the candidate x2 = Retr_x1(eta):
+//   egrad2 = x2 Q + G, rgrad2, Heta = Hess_x1[eta];  partials [0] f2 [1] |rgrad2|^2 [2] <gf,eta> [3] <eta,Heta>
+template <int R>
+__global__ __launch_bounds__(64) void k_rtr_eval2(const AgentDev *agents, const TeamDev *team, int sel, int sp) {
+  const AgentDev &ag = pick(agents, team, sel);
+  constexpr int PPB = 64 / R;
+  __shared__ double Ysh[PPB * 4 * R], Esh[PPB * 4 * R], Wsh[PPB * 4 * R];
+  const int lane = threadIdx.x, lp = lane / R, a = lane - lp * R;
+  const int j = blockIdx.x * PPB + lp;
+  if (blockIdx.x * PPB >= ag.n) return;
+  if (ag.st[sp].outer_done) return;
+  const bool act = lp < PPB && j < ag.n;
+  const double *X2 = ag.buf[B_X2], *ETA = ag.buf[B_ETA];
+  double fpart = 0, gpart = 0, ge = 0, eh = 0;
+  double acc[4] = {0, 0, 0, 0}, wrow[4] = {0, 0, 0, 0}, vrow[4] = {0, 0, 0, 0}, hrow[4], eg[4] = {0, 0, 0, 0};
+  if (act) {
+    // two SpMM rows share every Q block load
+    const int p0 = ag.rowptr[j], p1 = ag.rowptr[j + 1];
+    for (int p = p0; p < p1; ++p) {
+      const int i = ag.col[p];
+      const double2 *B = reinterpret_cast<const double2 *>(ag.qval + (size_t)16 * p);
+      double x[4], e[4];
+#pragma unroll
+      for (int cp = 0; cp < 4; ++cp) {
+        x[cp] = X2[((size_t)4 * i + cp) * R + a];
+        e[cp] = ETA[((size_t)4 * i + cp) * R + a];
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const double2 b01 = B[2 * c], b23 = B[2 * c + 1];
+        acc[c] += x[0] * b01.x + x[1] * b01.y + x[2] * b23.x + x[3] * b23.y;
+        wrow[c] += e[0] * b01.x + e[1] * b01.y + e[2] * b23.x + e[3] * b23.y;
+      }
+    }
+    const double *G = ag.buf[B_G] + (size_t)j * 4 * R;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const size_t o = ((size_t)4 * j + c) * R + a;
+      const double xr = X2[o], g = G[c * R + a];
+      fpart += (0.5 * acc[c] + g) * xr;
+      eg[c] = acc[c] + g;
+      ag.buf[B_EGRAD2][o] = eg[c];
+      Ysh[lp * 4 * R + c * R + a] = xr;
+      Wsh[lp * 4 * R + c * R + a] = eg[c];
+    }
+  }
+  __syncthreads();
+  if (act) {
+    double o3[3];
+    tangent_row<R>(Ysh + lp * 4 * R, Wsh + lp * 4 * R, a, o3);
+    double *GF2 = ag.buf[B_GF2] + (size_t)j * 4 * R;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { GF2[c * R + a] = o3[c]; gpart += o3[c] * o3[c]; }
+    GF2[3 * R + a] = eg[3];
+    gpart += eg[3] * eg[3];
+  }
+  __syncthreads();
+  if (act) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const size_t o = ((size_t)4 * j + c) * R + a;
+      vrow[c] = ETA[o];
+      Ysh[lp * 4 * R + c * R + a] = ag.buf[B_X][o];
+      Esh[lp * 4 * R + c * R + a] = ag.buf[B_EGRAD][o];
+    }
+  }
+  __syncthreads();
+  hess_tail<R>(Ysh + lp * 4 * R, Esh + lp * 4 * R, Wsh + lp * 4 * R, a, wrow, vrow, hrow, act);
+  if (act) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const size_t o = ((size_t)4 * j + c) * R + a;
+      ag.buf[B_HETA][o] = hrow[c];
+      ge += ag.buf[B_GF][o] * vrow[c];
+      eh += vrow[c] * hrow[c];
+    }
+  }
+  fpart = wave_sum(fpart); gpart = wave_sum(gpart); ge = wave_sum(ge); eh = wave_sum(eh);
+  if (lane == 0) {
+    double *P = ag.part + PC_OFF + (size_t)blockIdx.x * PART_STRIDE;
+    P[0] = fpart; P[1] = gpart; P[2] = ge; P[3] = eh;
+  }
+}
+
+// outer step, acceptance test + radius update (ROPTLIB SolversTR constants: accept rho > 0.1,
+// grow x2 when rho > 0.75 at the boundary, shrink x0.25 when rho < 0.25)
+template <int R>
+__global__ void k_rtr_accept(const AgentDev *agents, const TeamDev *team, int sel, int sp, double tol, int max_outer,
+                             double max_radius) {
+  const AgentDev &ag = pick(agents, team, sel);
+  const RtrState S = ag.st[sp];
+  if (S.outer_done) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) ag.st[sp ^ 1] = S;
+    return;
+  }
+  const int lane = threadIdx.x & 63;
+  const int nb = spmm_blocks<R>(ag.n);
+  const double f2 = sum_partials(ag.part + PC_OFF, nb, PART_STRIDE, lane);
+  const double g2 = sum_partials(ag.part + PC_OFF + 1, nb, PART_STRIDE, lane);
+  const double ge = sum_partials(ag.part + PC_OFF + 2, nb, PART_STRIDE, lane);
+  const double eh = sum_partials(ag.part + PC_OFF + 3, nb, PART_STRIDE, lane);
+  const double rho = (S.f1 - f2) / (-ge - 0.5 * eh);
+  const bool accept = rho > 0.1;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    RtrState T = S;
+    if (rho > 0.75) {
+      if (S.tcg_status == 1 || S.tcg_status == 2) T.Delta = fmin(2.0 * S.Delta, max_radius);
+    } else if (rho < 0.25) {
+      T.Delta = 0.25 * S.Delta;
+    }
+    if (accept) { T.f1 = f2; T.ngf = sqrt(g2); T.accepted = S.accepted + 1; }
+    T.hv_count = S.hv_count + 1;
+    T.outer_it = S.outer_it + 1;
+    T.outer_done = (T.outer_it >= max_outer) || (T.ngf < tol);
+    T.tcg_active = 0;
+    ag.st[sp ^ 1] = T;
+  }
+  if (!accept) return;
+  const size_t len = (size_t)ag.n * 4 * R;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < len; t += (size_t)gridDim.x * blockDim.x) {
+    ag.buf[B_X][t] = ag.buf[B_X2][t];
+    ag.buf[B_EGRAD][t] = ag.buf[B_EGRAD2][t];
+    ag.buf[B_GF][t] = ag.buf[B_GF2][t];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// exchange (a7): packed slabs in public_pose_ids / neighbor_pose_ids order
+template <int R>
+__global__ void k_pack(const double *X, const int *frames, int count, double *out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= count * 4 * R) return;
+  const int q = t / (4 * R), k = t - q * 4 * R;
+  out[t] = X[(size_t)frames[q] * 4 * R + k];
+}
+template <int R>
+__global__ void k_unpack(double *slab, const int *slots, int count, const double *in) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= count * 4 * R) return;
+  const int q = t / (4 * R), k = t - q * 4 * R;
+  slab[(size_t)slots[q] * 4 * R + k] = in[t];
+}
+
+// per-edge residual sqrt(kappa |Y_j - Y_i R|^2 + tau |p_j - p_i - Y_i t|^2) (a8) and cost partials
+template <int R>
+__global__ void k_residuals(const AgentDev *agents, int ai) {
+  const AgentDev &ag = agents[ai];
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= ag.nedges) return;
+  const EdgeDev &m = ag.edges[e];
+  const double *Xi = m.i_local >= 0 ? ag.buf[B_X] + (size_t)m.i_local * 4 * R : ag.nbr[0] + (size_t)m.i_slot * 4 * R;
+  const double *Xj = m.j_local >= 0 ? ag.buf[B_X] + (size_t)m.j_local * 4 * R : ag.nbr[0] + (size_t)m.j_slot * 4 * R;
+  double sr = 0, st = 0;
+#pragma unroll
+  for (int x = 0; x < R; ++x) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      double v = Xj[c * R + x];
+#pragma unroll
+      for (int b = 0; b < 3; ++b) v -= Xi[b * R + x] * m.R[3 * b + c];
+      sr += v * v;
+    }
+    double v = Xj[3 * R + x] - Xi[3 * R + x];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) v -= Xi[b * R + x] * m.t[b];
+    st += v * v;
+  }
+  ag.resid[e] = sqrt(m.kappa * sr + m.tau * st);
+}
+
+// scal[5] = sum over owned edges of w/2 * residual^2   (single workgroup, fixed order)
+__global__ __launch_bounds__(256) void k_cost(const AgentDev *agents, int ai) {
+  const AgentDev &ag = agents[ai];
+  __shared__ double red[4];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  double s = 0;
+  for (int e = tid; e < ag.nedges; e += 256) {
+    const EdgeDev &m = ag.edges[e];
+    if (m.count_in_cost) s += 0.5 * m.weight * ag.resid[e] * ag.resid[e];
+  }
+  s = wave_sum(s);
+  if (lane == 0) red[w] = s;
+  __syncthreads();
+  if (tid == 0) ag.scal[5] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// buf[to] = buf[from] for one agent or (sel == -3) every agent (blockIdx.y)
+__global__ void k_copy(const AgentDev *agents, const TeamDev *team, int sel, int only_agent, int r, int from, int to) {
+  const int ai = only_agent >= 0 ? only_agent : (sel == -3 ? (int)blockIdx.y : pick_idx(team, sel));
+  const AgentDev &ag = agents[ai];
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ag.N4 * r) return;
+  ag.buf[to][t] = ag.buf[from][t];
+}
+
+// dense A = Q + shift I from the block-CSR (column-major N4 x N4; A must be zeroed first)
+__global__ void k_bsr_to_dense(const int *rowptr, const int *col, const double *qval, int n, double shift, double *A) {
+  const int j = blockIdx.x;  // block row = output pose = column block of A
+  const int N4 = 4 * n;
+  for (int p = rowptr[j] + threadIdx.x / 16; p < rowptr[j + 1]; p += blockDim.x / 16) {
+    const int e = threadIdx.x % 16, cp = e % 4, c = e / 4;
+    const int i = col[p];
+    double v = qval[(size_t)16 * p + e];
+    if (i == j && cp == c) v += shift;
+    A[(size_t)(4 * j + c) * N4 + 4 * i + cp] = v;
+  }
+}
+
+// ================================================================================================
+// launch wrappers
+#define DPGO_DISPATCH_R(R_, CALL)            \
+  switch (R_) {                              \
+    case 3: { constexpr int R = 3; CALL; } break; \
+    case 4: { constexpr int R = 4; CALL; } break; \
+    case 5: { constexpr int R = 5; CALL; } break; \
+    case 6: { constexpr int R = 6; CALL; } break; \
+    case 7: { constexpr int R = 7; CALL; } break; \
+    case 8: { constexpr int R = 8; CALL; } break; \
+    default: break;                          \
+  }
+
+static inline int spmm_grid(int r, int n) { const int ppb = 64 / r; return (n + ppb - 1) / ppb; }
+
+void launch_buildG(const LaunchCtx &c, int sel, int max_npub, int aux, int pull) {
+  if (max_npub <= 0) return;
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_buildG<R>, dim3(spmm_grid(c.r, max_npub)), dim3(64), 0, c.stream, c.agents,
+                                          c.team, sel, aux, pull));
+}
+void launch_pull(const LaunchCtx &c, int dst, int nshared) {
+  if (nshared <= 0) return;
+  const int len = nshared * 4 * c.r;
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_pull<R>, dim3((len + 255) / 256), dim3(256), 0, c.stream, c.agents, dst));
+}
+void launch_eval(const LaunchCtx &c, int sel, int max_n, int xb, int egb, int gfb, int poff) {
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_eval<R>, dim3(spmm_grid(c.r, max_n)), dim3(64), 0, c.stream, c.agents,
+                                          c.team, sel, xb, egb, gfb, poff));
+}
+void launch_hess(const LaunchCtx &c, int sel, int max_n, int xb, int egb, int vb, int ob, int poff) {
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_hess<R>, dim3(spmm_grid(c.r, max_n)), dim3(64), 0, c.stream, c.agents,
+                                          c.team, sel, xb, egb, vb, ob, poff));
+}
+void launch_precond(const LaunchCtx &c, int sel, int max_n, int mode, int xb, int vb, int zb, int sp, int max_inner) {
+  const int grid = (4 * max_n + 7) / 8;
+  if (mode == PM_PLAIN) {
+    DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL((k_precond<R, PM_PLAIN>), dim3(grid), dim3(256), 0, c.stream, c.agents,
+                                            c.team, sel, xb, vb, zb, sp, max_inner));
+  } else if (mode == PM_TCG_INIT) {
+    DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL((k_precond<R, PM_TCG_INIT>), dim3(grid), dim3(256), 0, c.stream, c.agents,
+                                            c.team, sel, xb, vb, zb, sp, max_inner));
+  } else {
+    DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL((k_precond<R, PM_TCG_STEP>), dim3(grid), dim3(256), 0, c.stream, c.agents,
+                                            c.team, sel, xb, vb, zb, sp, max_inner));
+  }
+}
+void launch_tcg_hv(const LaunchCtx &c, int sel, int max_n, int sp, int max_inner) {
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_tcg_hv<R>, dim3(spmm_grid(c.r, max_n)), dim3(64), 0, c.stream, c.agents,
+                                          c.team, sel, sp, max_inner));
+}
+void launch_retract(const LaunchCtx &c, int sel, int max_n, int xb, int eb, double scale, int ob, int guard_state) {
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_retract<R>, dim3((max_n + 63) / 64), dim3(64), 0, c.stream, c.agents,
+                                          c.team, sel, xb, eb, scale, ob, guard_state));
+}
+void launch_project_raw(const LaunchCtx &c, const double *X, double *out, int n) {
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_project_raw<R>, dim3((n + 63) / 64), dim3(64), 0, c.stream, X, out, n));
+}
+void launch_tangent_raw(const LaunchCtx &c, const double *X, const double *V, double *out, int n) {
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_tangent_raw<R>, dim3((n + 63) / 64), dim3(64), 0, c.stream, X, V, out, n));
+}
+void launch_retract_raw(const LaunchCtx &c, const double *X, const double *E, double *out, int n) {
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_retract_raw<R>, dim3((n + 63) / 64), dim3(64), 0, c.stream, X, E, out, n));
+}
+void launch_nest_pre(const LaunchCtx &c, int sel, int only_agent, int num_agents, int max_n, int num_robots,
+                     int restart_interval) {
+  dim3 grid((max_n + 63) / 64, only_agent >= 0 ? 1 : num_agents);
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_nest_pre<R>, grid, dim3(64), 0, c.stream, c.agents, c.team, sel, only_agent,
+                                          num_robots, restart_interval));
+}
+void launch_nest_post(const LaunchCtx &c, int sel, int max_n, int num_robots, int restart_interval) {
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_nest_post<R>, dim3((max_n + 63) / 64), dim3(64), 0, c.stream, c.agents,
+                                          c.team, sel, num_robots, restart_interval));
+}
+void launch_nest_reset(const LaunchCtx &c, int sel, int max_n) {
+  const int len = max_n * 4 * c.r;
+  hipLaunchKernelGGL(k_nest_reset, dim3((len + 255) / 256), dim3(256), 0, c.stream, c.agents, c.team, sel, c.r);
+}
+void launch_advance(const LaunchCtx &c, int only_agent, int num_agents, int accel, int num_robots, int restart_interval,
+                    int bump_team) {
+  hipLaunchKernelGGL(k_advance, dim3(only_agent >= 0 ? 1 : num_agents), dim3(64), 0, c.stream, c.agents, c.team,
+                     only_agent, accel, num_robots, restart_interval, bump_team);
+}
+void launch_status(const LaunchCtx &c, int sel, int only_agent, int num_agents, int stat_off, int poff) {
+  const int grid = (sel == -3) ? num_agents : 1;
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_status<R>, dim3(grid), dim3(256), 0, c.stream, c.agents, c.team, sel,
+                                          only_agent, stat_off, poff));
+}
+void launch_rtr_begin(const LaunchCtx &c, int sel, double Delta0, double tol, int max_outer) {
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_rtr_begin<R>, dim3(1), dim3(64), 0, c.stream, c.agents, c.team, sel, Delta0,
+                                          tol, max_outer));
+}
+void launch_rtr_eval2(const LaunchCtx &c, int sel, int max_n, int sp) {
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_rtr_eval2<R>, dim3(spmm_grid(c.r, max_n)), dim3(64), 0, c.stream, c.agents,
+                                          c.team, sel, sp));
+}
+void launch_rtr_accept(const LaunchCtx &c, int sel, int max_n, int sp, double tol, int max_outer, double max_radius) {
+  const int len = max_n * 4 * c.r;
+  int grid = (len + 255) / 256;
+  if (grid > 64) grid = 64;
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_rtr_accept<R>, dim3(grid), dim3(256), 0, c.stream, c.agents, c.team, sel,
+                                          sp, tol, max_outer, max_radius));
+}
+void launch_pack(const LaunchCtx &c, const double *X, const int *frames, int count, double *out) {
+  if (count <= 0) return;
+  const int len = count * 4 * c.r;
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_pack<R>, dim3((len + 255) / 256), dim3(256), 0, c.stream, X, frames, count,
+                                          out));
+}
+void launch_unpack(const LaunchCtx &c, double *slab, const int *slots, int count, const double *in) {
+  if (count <= 0) return;
+  const int len = count * 4 * c.r;
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_unpack<R>, dim3((len + 255) / 256), dim3(256), 0, c.stream, slab, slots,
+                                          count, in));
+}
+void launch_residuals(const LaunchCtx &c, int ai, int nedges) {
+  if (nedges <= 0) return;
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_residuals<R>, dim3((nedges + 63) / 64), dim3(64), 0, c.stream, c.agents, ai));
+}
+void launch_cost(const LaunchCtx &c, int ai) {
+  hipLaunchKernelGGL(k_cost, dim3(1), dim3(256), 0, c.stream, c.agents, ai);
+}
+
+void launch_copy(const LaunchCtx &c, int sel, int only_agent, int num_agents, int max_n, int from, int to) {
+  const int len = max_n * 4 * c.r;
+  dim3 grid((len + 255) / 256, (sel == -3 && only_agent < 0) ? num_agents : 1);
+  hipLaunchKernelGGL(k_copy, grid, dim3(256), 0, c.stream, c.agents, c.team, sel, only_agent, c.r, from, to);
+}
+void launch_bsr_to_dense(hipStream_t s, const int *rowptr, const int *col, const double *qval, int n, double shift,
+                         double *A) {
+  (void)hipMemsetAsync(A, 0, sizeof(double) * (size_t)16 * n * n, s);
+  hipLaunchKernelGGL(k_bsr_to_dense, dim3(n), dim3(64), 0, s, rowptr, col, qval, n, shift, A);
+}
+
+}  // namespace dpgo

@@ -1,0 +1,167 @@
+// loader.cpp -- host-side dataset input for the drop-in boundary (plain C++17, no Eigen).
+//
+// Replaces, for the hot path's inputs:
+//   read_g2o_file(filename, num_poses)           src/PGODatasetPublisherNode.cpp:80
+//   PGOLogger::loadMeasurements(file, false)     src/PGODatasetPublisherNode.cpp:168
+//   contiguous-block partition + classification  src/PGODatasetPublisherNode.cpp:84-135
+//   wrapper weighting kappa=1e4 / tau=1e2, odometry => fixedWeight   src/utils.cpp:141-149
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/dpgo_hip.h"
+
+namespace {
+
+void quat_to_rot(double qx, double qy, double qz, double qw, double R[9]) {
+  const double s = std::sqrt(qx * qx + qy * qy + qz * qz + qw * qw);
+  const double x = qx / s, y = qy / s, z = qz / s, w = qw / s;
+  R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * w);     R[2] = 2 * (x * z + y * w);
+  R[3] = 2 * (x * y + z * w);     R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * w);
+  R[6] = 2 * (x * z - y * w);     R[7] = 2 * (y * z + x * w);     R[8] = 1 - 2 * (x * x + y * y);
+}
+
+// tr(S^-1) of the symmetric 3x3 [a b c; b d e; c e f]
+double trace_inverse_sym3(double a, double b, double c, double d, double e, double f) {
+  const double m00 = d * f - e * e, m11 = a * f - c * c, m22 = a * d - b * b;
+  const double det = a * m00 - b * (b * f - c * e) + c * (b * e - c * d);
+  return (m00 + m11 + m22) / det;
+}
+
+dpgo_measurement_t *to_c_array(const std::vector<dpgo_measurement_t> &v) {
+  auto *out = static_cast<dpgo_measurement_t *>(std::malloc(sizeof(dpgo_measurement_t) * (v.empty() ? 1 : v.size())));
+  if (!v.empty()) std::memcpy(out, v.data(), sizeof(dpgo_measurement_t) * v.size());
+  return out;
+}
+
+}  // namespace
+
+extern "C" {
+
+void dpgo_free(void *p) { std::free(p); }
+
+int dpgo_read_g2o(const char *path, int weight_mode, dpgo_measurement_t **out, int *num_poses) {
+  std::ifstream in(path);
+  if (!in) return -1;
+  std::vector<dpgo_measurement_t> ms;
+  std::string line, tag;
+  int max_id = -1;
+  while (std::getline(in, line)) {
+    std::istringstream ss(line);
+    if (!(ss >> tag) || tag != "EDGE_SE3:QUAT") continue;
+    int i, j;
+    double v[7], I[21];
+    if (!(ss >> i >> j)) continue;
+    bool ok = true;
+    for (double &x : v) ok = ok && static_cast<bool>(ss >> x);
+    for (double &x : I) ok = ok && static_cast<bool>(ss >> x);
+    if (!ok) continue;
+    dpgo_measurement_t m{};
+    m.r1 = 0; m.r2 = 0; m.p1 = i; m.p2 = j;
+    m.t[0] = v[0]; m.t[1] = v[1]; m.t[2] = v[2];
+    quat_to_rot(v[3], v[4], v[5], v[6], m.R);
+    if (weight_mode == DPGO_WEIGHT_WRAPPER) {
+      m.kappa = 10000.0; m.tau = 100.0;
+    } else {
+      // upper-triangular 6x6, translation block first: rows start at I[0], I[6], I[11], I[15], I[18], I[20]
+      m.tau = 3.0 / trace_inverse_sym3(I[0], I[1], I[2], I[6], I[7], I[11]);
+      m.kappa = 3.0 / (2.0 * trace_inverse_sym3(I[15], I[16], I[17], I[18], I[19], I[20]));
+    }
+    m.weight = 1.0;
+    ms.push_back(m);
+    max_id = std::max(max_id, std::max(i, j));
+  }
+  *out = to_c_array(ms);
+  *num_poses = max_id + 1;
+  return static_cast<int>(ms.size());
+}
+
+int dpgo_read_measurements_csv(const char *path, int weight_mode, dpgo_measurement_t **out) {
+  std::ifstream in(path);
+  if (!in) return -1;
+  std::vector<dpgo_measurement_t> ms;
+  std::string line;
+  std::getline(in, line);  // header
+  while (std::getline(in, line)) {
+    for (char &ch : line) if (ch == ',') ch = ' ';
+    std::istringstream ss(line);
+    double v[15];
+    bool ok = true;
+    for (double &x : v) ok = ok && static_cast<bool>(ss >> x);
+    if (!ok) continue;
+    dpgo_measurement_t m{};
+    m.r1 = (int)v[0]; m.p1 = (int)v[1]; m.r2 = (int)v[2]; m.p2 = (int)v[3];
+    quat_to_rot(v[4], v[5], v[6], v[7], m.R);
+    m.t[0] = v[8]; m.t[1] = v[9]; m.t[2] = v[10];
+    if (weight_mode == DPGO_WEIGHT_WRAPPER) {
+      m.kappa = 10000.0; m.tau = 100.0; m.weight = 1.0;
+      m.fixed_weight = (m.r1 == m.r2 && m.p1 + 1 == m.p2);
+    } else {
+      m.kappa = v[11]; m.tau = v[12];
+      m.is_known_inlier = (int)v[13];
+      m.weight = v[14];
+      m.fixed_weight = m.is_known_inlier;
+    }
+    ms.push_back(m);
+  }
+  *out = to_c_array(ms);
+  return static_cast<int>(ms.size());
+}
+
+void dpgo_partition(dpgo_measurement_t *m, int nm, int num_poses, int num_robots, int weight_mode) {
+  const int per = num_poses / num_robots;
+  for (int k = 0; k < nm; ++k) {
+    const int g1 = m[k].p1, g2 = m[k].p2;
+    const int ra = std::min(g1 / per, num_robots - 1), rb = std::min(g2 / per, num_robots - 1);
+    m[k].r1 = ra; m[k].p1 = g1 - ra * per;
+    m[k].r2 = rb; m[k].p2 = g2 - rb * per;
+    if (weight_mode == DPGO_WEIGHT_WRAPPER) m[k].fixed_weight = (ra == rb && m[k].p1 + 1 == m[k].p2);
+  }
+}
+
+void dpgo_odometry_init(const dpgo_measurement_t *m, int nm, int num_poses, double *T) {
+  std::vector<const dpgo_measurement_t *> odo(num_poses, nullptr);
+  for (int e = 0; e < nm; ++e)
+    if (m[e].r1 == m[e].r2 && m[e].p2 == m[e].p1 + 1 && !odo[m[e].p1]) odo[m[e].p1] = &m[e];
+  std::memset(T, 0, sizeof(double) * 12 * (size_t)num_poses);
+  T[0] = T[4] = T[8] = 1.0;
+  for (int i = 0; i + 1 < num_poses; ++i) {
+    const double *Ti = T + (size_t)12 * i;
+    double *Tn = T + (size_t)12 * (i + 1);
+    if (!odo[i]) { std::memcpy(Tn, Ti, sizeof(double) * 12); continue; }
+    const dpgo_measurement_t &e = *odo[i];
+    for (int c = 0; c < 3; ++c)
+      for (int a = 0; a < 3; ++a) {
+        double s = 0;
+        for (int b = 0; b < 3; ++b) s += Ti[3 * b + a] * e.R[3 * b + c];
+        Tn[3 * c + a] = s;
+      }
+    for (int a = 0; a < 3; ++a) {
+      double s = Ti[9 + a];
+      for (int b = 0; b < 3; ++b) s += Ti[3 * b + a] * e.t[b];
+      Tn[9 + a] = s;
+    }
+  }
+}
+
+void dpgo_fixed_stiefel(int r, double *YLift) {
+  std::memset(YLift, 0, sizeof(double) * 3 * r);
+  for (int c = 0; c < 3; ++c) YLift[c * r + c] = 1.0;
+}
+
+void dpgo_lift(const double *T, int num_poses, const double *YLift, int r, double *X) {
+  for (int i = 0; i < num_poses; ++i)
+    for (int c = 0; c < 4; ++c)
+      for (int a = 0; a < r; ++a) {
+        double s = 0;
+        for (int b = 0; b < 3; ++b) s += YLift[b * r + a] * T[(size_t)12 * i + 3 * c + b];
+        X[((size_t)4 * i + c) * r + a] = s;
+      }
+}
+
+}  // extern "C"

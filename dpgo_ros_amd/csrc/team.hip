@@ -1,0 +1,1084 @@
+// team.hip -- host runtime + C-ABI of libdpgo_hip.so (see include/dpgo_hip.h for the contract).
+//
+// Mirrors the DPGO::PGOAgent call surface consumed by src/PGOAgentROS.cpp:
+// addMeasurement, iterate, update(Aux)NeighborPoses, get(Aux)SharedPoseDictWithNeighbor,
+// getStatus, mLocalOptResult, updateMeasurementWeights, setMeasurementWeight, clearDataMatrices.
+// All state (X, XPrev, Y, V, Q, G, dense preconditioner, neighbour slabs, solver scalars) lives
+// in HBM; the host only sequences launches.  There is no CPU fallback: every entry point that
+// computes fails with DPGO_ERR when no HIP device is usable.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/dpgo_hip.h"
+#include "dpgo_dev.h"
+#include "kernels.h"
+
+using namespace dpgo;
+
+namespace {
+
+thread_local std::string g_err;
+void set_err(const std::string &s) { g_err = s; }
+
+#define HIPC(expr)                                                                         \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess) {                                                                \
+      set_err(std::string(#expr) + ": " + hipGetErrorString(e_) + " @" + std::to_string(__LINE__)); \
+      return DPGO_ERR;                                                                     \
+    }                                                                                      \
+  } while (0)
+
+template <class T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  int alloc(size_t count) {
+    if (count <= n && p) return 0;
+    if (p) (void)hipFree(p);
+    p = nullptr; n = 0;
+    if (hipMalloc(&p, sizeof(T) * std::max<size_t>(count, 1)) != hipSuccess) return -1;
+    n = std::max<size_t>(count, 1);
+    return 0;
+  }
+  int upload(const std::vector<T> &v, hipStream_t s) {
+    if (alloc(v.size())) return -1;
+    if (v.empty()) return 0;
+    return hipMemcpyAsync(p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice, s) == hipSuccess ? 0 : -1;
+  }
+};
+
+struct Agent {
+  int id = 0, local = 0;
+  std::vector<dpgo_measurement_t> odom, priv, shared;
+  bool index_dirty = true, data_dirty = true;
+  int n = 0;
+  // neighbour pose dictionary (sorted (robot, frame)) and per-neighbour public ids
+  std::vector<std::pair<int, int>> np;
+  std::vector<char> np_has[2];
+  std::vector<int> neighbors;
+  int state = DPGO_WAIT_FOR_DATA;
+  int iter = 0, instance = 0;
+  bool publish_requested = false;
+  bool has_X = false;
+  double mu = 0;
+  int weight_update_count = 0, robust_inner_iter = 0;
+  dpgo_opt_result_t opt{};
+  bool opt_pending_rgd = false, last_success = true;
+  // host copies of the sparse structure
+  std::vector<int> rowptr, col;
+  std::vector<double> qval;
+  int npub = 0;
+  // device storage
+  DevBuf<int> d_rowptr, d_col, d_pub_pose, d_pub_ptr, d_idx;
+  DevBuf<double> d_qval, d_M, d_vec, d_nbr, d_part, d_scal, d_resid;
+  DevBuf<SharedEdgeDev> d_se;
+  DevBuf<EdgeDev> d_edges;
+  DevBuf<RtrState> d_st;
+  DevBuf<NestState> d_nest;
+  AgentDev dev{};
+  int nedges = 0;
+};
+
+}  // namespace
+
+struct dpgo_team {
+  int device = 0;
+  dpgo_params_t prm{};
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::vector<std::unique_ptr<Agent>> ag;
+  std::map<int, int> id2local;
+  DevBuf<AgentDev> d_agents;
+  DevBuf<TeamDev> d_team;
+  DevBuf<int> d_sched;
+  DevBuf<double> d_tmp;  // scratch for raw manifold ops / dense factorisation
+  std::vector<int> sched;
+  int iter = 0;
+  bool descs_dirty = true;
+  int max_n = 0, max_npub = 0;
+  RtrState *h_state = nullptr;  // pinned
+  double *h_scal = nullptr;     // pinned [16]
+  hipGraphExec_t graph = nullptr;
+  bool graph_valid = false;
+  int tcg_chunk = 4;
+  double counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  LaunchCtx ctx() { return LaunchCtx{prm.r, stream, d_agents.p, d_team.p}; }
+};
+
+namespace {
+
+Agent *find_agent(dpgo_team *t, int id) {
+  auto it = t->id2local.find(id);
+  if (it == t->id2local.end()) { set_err("unknown agent id " + std::to_string(id)); return nullptr; }
+  return t->ag[it->second].get();
+}
+
+// 4x4 column-major blocks of one edge:  TO = T Omega, TOT = T Omega T^T, Om = Omega (x weight)
+void edge_blocks(const dpgo_measurement_t &m, double TO[16], double TOT[16], double Om[16]) {
+  const double w = m.weight, k = m.kappa, tau = m.tau;
+  std::fill(TO, TO + 16, 0.0); std::fill(TOT, TOT + 16, 0.0); std::fill(Om, Om + 16, 0.0);
+  for (int a = 0; a < 3; ++a) {
+    for (int b = 0; b < 3; ++b) {
+      TO[a + 4 * b] = w * k * m.R[3 * a + b];
+      TOT[a + 4 * b] = w * ((a == b ? k : 0.0) + tau * m.t[a] * m.t[b]);
+    }
+    TO[a + 12] = w * tau * m.t[a];
+    TOT[a + 12] = w * tau * m.t[a];
+    TOT[3 + 4 * a] = w * tau * m.t[a];
+    Om[5 * a] = w * k;
+  }
+  TO[15] = TOT[15] = Om[15] = w * tau;
+}
+
+void rebuild_index(Agent &a) {
+  if (!a.index_dirty) return;
+  int n = 0;
+  auto upd = [&](int p) { n = std::max(n, p + 1); };
+  for (auto &m : a.odom) { upd(m.p1); upd(m.p2); }
+  for (auto &m : a.priv) { upd(m.p1); upd(m.p2); }
+  std::vector<std::pair<int, int>> np;
+  for (auto &m : a.shared) {
+    if (m.r1 == a.id) { upd(m.p1); np.emplace_back(m.r2, m.p2); }
+    else { upd(m.p2); np.emplace_back(m.r1, m.p1); }
+  }
+  std::sort(np.begin(), np.end());
+  np.erase(std::unique(np.begin(), np.end()), np.end());
+  a.np = np;
+  a.np_has[0].assign(np.size(), 0);
+  a.np_has[1].assign(np.size(), 0);
+  a.neighbors.clear();
+  for (auto &p : np) if (a.neighbors.empty() || a.neighbors.back() != p.first) a.neighbors.push_back(p.first);
+  a.n = n;
+  a.index_dirty = false;
+  a.data_dirty = true;
+}
+
+int find_np(const Agent &a, int robot, int frame) {
+  auto it = std::lower_bound(a.np.begin(), a.np.end(), std::make_pair(robot, frame));
+  if (it == a.np.end() || *it != std::make_pair(robot, frame)) return -1;
+  return int(it - a.np.begin());
+}
+
+std::vector<int> public_ids(const Agent &a, int nbr) {
+  std::vector<int> f;
+  for (auto &m : a.shared) {
+    if (m.r1 == a.id && m.r2 == nbr) f.push_back(m.p1);
+    else if (m.r2 == a.id && m.r1 == nbr) f.push_back(m.p2);
+  }
+  std::sort(f.begin(), f.end());
+  f.erase(std::unique(f.begin(), f.end()), f.end());
+  return f;
+}
+
+std::vector<int> neighbor_ids(const Agent &a, int nbr) {
+  std::vector<int> f;
+  for (auto &p : a.np) if (p.first == nbr) f.push_back(p.second);
+  return f;
+}
+
+// connection Laplacian in block-CSR (row j lists (i, Q_ij)); duplicates merged in insertion order
+void build_Q(Agent &a) {
+  std::vector<std::map<int, std::array<double, 16>>> rows(a.n);
+  auto add = [&](int row, int colm, const double *v, bool transpose, double sign) {
+    auto &blk = rows[row][colm];
+    for (int cp = 0; cp < 4; ++cp)
+      for (int c = 0; c < 4; ++c) blk[cp + 4 * c] += sign * (transpose ? v[c + 4 * cp] : v[cp + 4 * c]);
+  };
+  double TO[16], TOT[16], Om[16];
+  for (int i = 0; i < a.n; ++i) rows[i][i];  // every pose owns a diagonal block
+  for (int pass = 0; pass < 2; ++pass)
+    for (auto &m : (pass ? a.priv : a.odom)) {
+      edge_blocks(m, TO, TOT, Om);
+      add(m.p1, m.p1, TOT, false, 1.0);
+      add(m.p2, m.p2, Om, false, 1.0);
+      add(m.p2, m.p1, TO, false, -1.0);  // Q_ij stored in row j
+      add(m.p1, m.p2, TO, true, -1.0);   // Q_ji = Q_ij^T stored in row i
+    }
+  for (auto &m : a.shared) {
+    edge_blocks(m, TO, TOT, Om);
+    if (m.r1 == a.id) add(m.p1, m.p1, TOT, false, 1.0);
+    else add(m.p2, m.p2, Om, false, 1.0);
+  }
+  a.rowptr.assign(a.n + 1, 0);
+  a.col.clear(); a.qval.clear();
+  for (int j = 0; j < a.n; ++j) {
+    for (auto &kv : rows[j]) {
+      a.col.push_back(kv.first);
+      a.qval.insert(a.qval.end(), kv.second.begin(), kv.second.end());
+    }
+    a.rowptr[j + 1] = (int)a.col.size();
+  }
+}
+
+}  // namespace
+
+
+namespace {
+
+// upload structure + data matrices of one agent and (re)build the dense preconditioner
+int finalize_agent(dpgo_team *t, Agent &a) {
+  rebuild_index(a);
+  if (!a.data_dirty) return 0;
+  const int r = t->prm.r, n = a.n, N4 = 4 * n;
+  const size_t len = (size_t)r * 4 * n;
+  hipStream_t s = t->stream;
+  build_Q(a);
+  // shared edges sorted by local pose
+  struct SE { int lpose; SharedEdgeDev d; };
+  std::vector<SharedEdgeDev> se;
+  double TO[16], TOT[16], Om[16];
+  for (auto &m : a.shared) {
+    edge_blocks(m, TO, TOT, Om);
+    const bool out = (m.r1 == a.id);
+    SharedEdgeDev d{};
+    d.lpose = out ? m.p1 : m.p2;
+    const int nr = out ? m.r2 : m.r1, nf = out ? m.p2 : m.p1;
+    d.slot = find_np(a, nr, nf);
+    auto it = t->id2local.find(nr);
+    d.src_agent_local = (it == t->id2local.end()) ? -1 : it->second;
+    d.src_frame = nf;
+    for (int cp = 0; cp < 4; ++cp)
+      for (int c = 0; c < 4; ++c) d.coef[cp + 4 * c] = out ? TO[c + 4 * cp] : TO[cp + 4 * c];
+    se.push_back(d);
+  }
+  std::stable_sort(se.begin(), se.end(), [](const SharedEdgeDev &x, const SharedEdgeDev &y) { return x.lpose < y.lpose; });
+  std::vector<int> pub_pose, pub_ptr;
+  for (size_t e = 0; e < se.size(); ++e) {
+    if (e == 0 || se[e].lpose != se[e - 1].lpose) { pub_pose.push_back(se[e].lpose); pub_ptr.push_back((int)e); }
+  }
+  pub_ptr.push_back((int)se.size());
+  a.npub = (int)pub_pose.size();
+  // edge records for residual / cost evaluation
+  std::vector<EdgeDev> edges;
+  auto push_edge = [&](const dpgo_measurement_t &m) {
+    EdgeDev e{};
+    e.i_local = (m.r1 == a.id) ? m.p1 : -1;
+    e.j_local = (m.r2 == a.id) ? m.p2 : -1;
+    e.i_slot = (m.r1 == a.id) ? -1 : find_np(a, m.r1, m.p1);
+    e.j_slot = (m.r2 == a.id) ? -1 : find_np(a, m.r2, m.p2);
+    std::memcpy(e.R, m.R, sizeof e.R);
+    std::memcpy(e.t, m.t, sizeof e.t);
+    e.kappa = m.kappa; e.tau = m.tau; e.weight = m.weight;
+    e.count_in_cost = (m.r1 == m.r2) ? 1 : (std::min(m.r1, m.r2) == a.id);
+    edges.push_back(e);
+  };
+  for (auto &m : a.odom) push_edge(m);
+  for (auto &m : a.priv) push_edge(m);
+  for (auto &m : a.shared) push_edge(m);
+  a.nedges = (int)edges.size();
+
+  const bool fresh_vec = a.d_vec.n < len * NBUF;
+  if (a.d_rowptr.upload(a.rowptr, s) || a.d_col.upload(a.col, s) || a.d_qval.upload(a.qval, s) ||
+      a.d_pub_pose.upload(pub_pose, s) || a.d_pub_ptr.upload(pub_ptr, s) || a.d_se.upload(se, s) ||
+      a.d_edges.upload(edges, s) || a.d_vec.alloc(len * NBUF) || a.d_nbr.alloc(2 * a.np.size() * 4 * r) ||
+      a.d_part.alloc(PART_TOTAL) || a.d_scal.alloc(16) || a.d_resid.alloc(edges.size()) || a.d_st.alloc(2) ||
+      a.d_nest.alloc(1) || a.d_M.alloc((size_t)N4 * N4)) {
+    set_err("device allocation/upload failed");
+    return DPGO_ERR;
+  }
+  if (fresh_vec) {
+    HIPC(hipMemsetAsync(a.d_vec.p, 0, sizeof(double) * len * NBUF, s));
+    HIPC(hipMemsetAsync(a.d_nbr.p, 0, sizeof(double) * a.d_nbr.n, s));
+    HIPC(hipMemsetAsync(a.d_scal.p, 0, sizeof(double) * 16, s));
+    HIPC(hipMemsetAsync(a.d_nest.p, 0, sizeof(NestState), s));
+    HIPC(hipMemsetAsync(a.d_st.p, 0, sizeof(RtrState) * 2, s));
+    HIPC(hipMemsetAsync(a.d_part.p, 0, sizeof(double) * PART_TOTAL, s));
+  }
+  // dense preconditioner  M = (Q + shift I)^-1
+  if (t->d_tmp.alloc(2 * (size_t)N4 * N4)) { set_err("scratch allocation failed"); return DPGO_ERR; }
+  double *A = t->d_tmp.p, *W = t->d_tmp.p + (size_t)N4 * N4;
+  launch_bsr_to_dense(s, a.d_rowptr.p, a.d_col.p, a.d_qval.p, n, t->prm.precond_shift, A);
+  const int fail = dense_spd_inverse(s, A, W, a.d_M.p, N4);
+  if (fail != 0) { set_err("dense Cholesky of Q + shift I failed at pivot " + std::to_string(fail)); return DPGO_ERR; }
+
+  AgentDev &d = a.dev;
+  d.id = a.id; d.n = n; d.nb = (int)a.col.size(); d.N4 = N4;
+  d.npub = a.npub; d.nshared = (int)se.size(); d.nnp = (int)a.np.size(); d.nedges = a.nedges;
+  d.rowptr = a.d_rowptr.p; d.col = a.d_col.p; d.qval = a.d_qval.p; d.M = a.d_M.p;
+  d.pub_pose = a.d_pub_pose.p; d.pub_ptr = a.d_pub_ptr.p; d.se = a.d_se.p; d.edges = a.d_edges.p;
+  d.nbr[0] = a.d_nbr.p; d.nbr[1] = a.d_nbr.p + a.np.size() * 4 * r;
+  for (int b = 0; b < NBUF; ++b) d.buf[b] = a.d_vec.p + len * b;
+  d.part = a.d_part.p; d.st = a.d_st.p; d.nest = a.d_nest.p; d.scal = a.d_scal.p; d.resid = a.d_resid.p;
+  a.data_dirty = false;
+  t->descs_dirty = true;
+  t->graph_valid = false;
+  return 0;
+}
+
+int sync_descs(dpgo_team *t) {
+  for (auto &a : t->ag) {
+    const int rc = finalize_agent(t, *a);
+    if (rc) return rc;
+  }
+  if (!t->descs_dirty) return 0;
+  std::vector<AgentDev> descs;
+  t->max_n = 0; t->max_npub = 0;
+  for (auto &a : t->ag) {
+    descs.push_back(a->dev);
+    t->max_n = std::max(t->max_n, a->n);
+    t->max_npub = std::max(t->max_npub, a->npub);
+  }
+  if (t->d_agents.upload(descs, t->stream)) { set_err("descriptor upload failed"); return DPGO_ERR; }
+  if (t->sched.empty()) for (size_t k = 0; k < t->ag.size(); ++k) t->sched.push_back((int)k);
+  if (t->d_sched.upload(t->sched, t->stream) || t->d_team.alloc(1)) { set_err("schedule upload failed"); return DPGO_ERR; }
+  TeamDev td{};
+  td.num_agents = (int)t->ag.size(); td.sched_len = (int)t->sched.size(); td.iter = t->iter;
+  td.restart_interval = t->prm.restart_interval; td.sched = t->d_sched.p;
+  HIPC(hipMemcpyAsync(t->d_team.p, &td, sizeof td, hipMemcpyHostToDevice, t->stream));
+  HIPC(hipStreamSynchronize(t->stream));
+  t->descs_dirty = false;
+  t->graph_valid = false;
+  return 0;
+}
+
+bool neighbor_poses_ready(const Agent &a, int aux) {
+  for (char h : a.np_has[aux]) if (!h) return false;
+  return true;
+}
+
+// ---- the local solve (QuadraticOptimizer::optimize), enqueued on the team stream -------------
+// sel >= 0: that local agent (host-driven), sel == -1: device-selected (graph capture).
+// Returns after enqueueing for RGD; the RTR path synchronises once per tCG chunk to read the
+// device-side solver state.
+int enqueue_optimize(dpgo_team *t, int sel, int aux, int pull, bool capture) {
+  LaunchCtx c = t->ctx();
+  const dpgo_params_t &p = t->prm;
+  const int mn = (sel >= 0) ? t->ag[sel]->n : t->max_n;
+  const int mp = (sel >= 0) ? t->ag[sel]->npub : t->max_npub;
+  const int N4 = 4 * mn;
+  const double spmm_bytes = (sel >= 0) ? 8.0 * (16.0 * t->ag[sel]->col.size() + 3.0 * p.r * 4 * mn) +
+                                             4.0 * (t->ag[sel]->col.size() + mn + 1) : 0.0;
+  launch_buildG(c, sel, mp, aux, pull);
+  if (p.method == DPGO_METHOD_RGD) {
+    launch_eval(c, sel, mn, B_X, B_EGRAD, B_GF, PART_C);
+    int dirb = B_GF;
+    if (p.rgd_use_preconditioner) {
+      launch_precond(c, sel, mn, PM_PLAIN_, B_X, B_GF, B_Z, 0, 0);
+      dirb = B_Z;
+      t->counters[0] += 1; t->counters[1] += 8.0 * N4 * (double)N4;
+    }
+    launch_retract(c, sel, mn, B_X, dirb, -p.rgd_stepsize, B_X, -1);
+    launch_eval(c, sel, mn, B_X, B_EGRAD, B_GF, PART_A);
+    t->counters[2] += 2; t->counters[3] += 2 * spmm_bytes;
+    if (sel >= 0) t->ag[sel]->opt_pending_rgd = true;
+    return 0;
+  }
+  if (capture) { set_err("RTR cannot be captured"); return DPGO_ERR; }
+  // ---- RTR: trust-region Newton with truncated CG; scalars stay on the device
+  Agent &a = *t->ag[sel];
+  launch_eval(c, sel, mn, B_X, B_EGRAD, B_GF, PART_A);
+  launch_rtr_begin(c, sel, p.rtr_initial_radius, p.gradnorm_tol, p.rtr_iterations);
+  int sp = 0;
+  RtrState *hs = t->h_state;
+  auto read_state = [&]() -> int {
+    HIPC(hipMemcpyAsync(hs, a.dev.st + sp, sizeof(RtrState), hipMemcpyDeviceToHost, t->stream));
+    HIPC(hipStreamSynchronize(t->stream));
+    return 0;
+  };
+  auto tcg_chunk = [&]() {
+    for (int q = 0; q < t->tcg_chunk; ++q) {
+      launch_tcg_hv(c, sel, mn, sp, p.rtr_tcg_iterations); sp ^= 1;
+      launch_precond(c, sel, mn, PM_TCG_STEP_, B_X, 0, 0, sp, p.rtr_tcg_iterations); sp ^= 1;
+    }
+  };
+  launch_precond(c, sel, mn, PM_TCG_INIT_, B_X, 0, 0, sp, p.rtr_tcg_iterations); sp ^= 1;
+  tcg_chunk();
+  if (read_state()) return DPGO_ERR;
+  int guard = 0;
+  while (!hs->outer_done && guard++ < 100000) {
+    if (hs->tcg_active) {
+      tcg_chunk();
+    } else {
+      launch_retract(c, sel, mn, B_X, B_ETA, 1.0, B_X2, sp);
+      launch_rtr_eval2(c, sel, mn, sp);
+      launch_rtr_accept(c, sel, mn, sp, p.gradnorm_tol, p.rtr_iterations, p.rtr_max_radius); sp ^= 1;
+      launch_precond(c, sel, mn, PM_TCG_INIT_, B_X, 0, 0, sp, p.rtr_tcg_iterations); sp ^= 1;
+      tcg_chunk();
+    }
+    if (read_state()) return DPGO_ERR;
+  }
+  a.opt.success = 1;
+  a.opt.f_init = hs->f_init; a.opt.gradnorm_init = hs->gn_init;
+  a.opt.f_opt = hs->f1; a.opt.gradnorm_opt = hs->ngf;
+  a.opt.rtr_outer_iters = hs->outer_count; a.opt.tcg_iters_total = hs->tcg_total;
+  a.opt.hessvec_count = hs->hv_count; a.opt.precond_count = hs->pc_count; a.opt.accepted = hs->accepted;
+  a.opt_pending_rgd = false;
+  t->counters[0] += hs->pc_count; t->counters[1] += hs->pc_count * 8.0 * N4 * (double)N4;
+  t->counters[2] += hs->hv_count + 1 + hs->outer_count; t->counters[3] += (hs->hv_count + 1 + hs->outer_count) * spmm_bytes;
+  return 0;
+}
+
+// one PGOAgent::iterate for local agent `li` (host-driven variant used by the per-agent API)
+int enqueue_iterate(dpgo_team *t, int li, int do_opt) {
+  Agent &a = *t->ag[li];
+  LaunchCtx c = t->ctx();
+  const dpgo_params_t &p = t->prm;
+  const bool restart = p.acceleration && ((a.iter + 2) % p.restart_interval) == 0;
+  int rc = 0;
+  if (p.acceleration) {
+    launch_nest_pre(c, do_opt ? li : -2, li, 1, a.n, p.num_robots, p.restart_interval);
+    if (do_opt) {
+      rc = enqueue_optimize(t, li, 1, 0, false);
+      if (rc) return rc;
+      launch_nest_post(c, li, a.n, p.num_robots, p.restart_interval);
+      if (restart) {
+        rc = enqueue_optimize(t, li, 0, 0, false);
+        if (rc) return rc;
+        launch_nest_reset(c, li, a.n);
+      }
+    }
+  } else {
+    launch_copy(c, li, li, 1, a.n, B_X, B_XPREV);
+    if (do_opt) rc = enqueue_optimize(t, li, 0, 0, false);
+    if (rc) return rc;
+  }
+  launch_status(c, li, li, 1, -1, PART_A);
+  launch_advance(c, li, 1, p.acceleration, p.num_robots, p.restart_interval, 0);
+  return 0;
+}
+
+int fetch_scal(dpgo_team *t, Agent &a) {
+  HIPC(hipMemcpyAsync(t->h_scal, a.dev.scal, sizeof(double) * 16, hipMemcpyDeviceToHost, t->stream));
+  HIPC(hipStreamSynchronize(t->stream));
+  return 0;
+}
+
+int refresh_rgd_result(dpgo_team *t, Agent &a) {
+  if (!a.opt_pending_rgd) return 0;
+  const int ppb = 64 / t->prm.r, nb = (a.n + ppb - 1) / ppb;
+  std::vector<double> pc((size_t)PART_STRIDE * nb), pa((size_t)PART_STRIDE * nb);
+  HIPC(hipStreamSynchronize(t->stream));
+  HIPC(hipMemcpy(pc.data(), a.dev.part + PART_C, sizeof(double) * pc.size(), hipMemcpyDeviceToHost));
+  HIPC(hipMemcpy(pa.data(), a.dev.part + PART_A, sizeof(double) * pa.size(), hipMemcpyDeviceToHost));
+  auto sum = [&](const std::vector<double> &p, int off) { double s = 0; for (int i = 0; i < nb; ++i) s += p[(size_t)i * PART_STRIDE + off]; return s; };
+  a.opt.success = 1;
+  a.opt.f_init = sum(pc, 0); a.opt.gradnorm_init = std::sqrt(sum(pc, 1));
+  a.opt.f_opt = sum(pa, 0); a.opt.gradnorm_opt = std::sqrt(sum(pa, 1));
+  a.opt.rtr_outer_iters = 0; a.opt.tcg_iters_total = 0; a.opt.hessvec_count = 0;
+  a.opt.precond_count = t->prm.rgd_use_preconditioner ? 1 : 0; a.opt.accepted = 1;
+  a.opt_pending_rgd = false;
+  return 0;
+}
+
+double robust_weight(const dpgo_params_t &p, double mu, double residual) {
+  if (p.robust_cost_type == DPGO_COST_L2) return 1.0;
+  const double r2 = residual * residual, b2 = p.gnc_barc * p.gnc_barc;
+  const double upper = (mu + 1.0) / mu * b2, lower = mu / (mu + 1.0) * b2;
+  if (r2 >= upper) return 0.0;
+  if (r2 <= lower) return 1.0;
+  return std::sqrt(b2 * mu * (mu + 1.0) / r2) - mu;
+}
+
+int compute_residuals(dpgo_team *t, Agent &a, std::vector<double> &res) {
+  LaunchCtx c = t->ctx();
+  launch_residuals(c, a.local, a.nedges);
+  res.resize(a.nedges);
+  if (a.nedges) HIPC(hipMemcpyAsync(res.data(), a.dev.resid, sizeof(double) * a.nedges, hipMemcpyDeviceToHost, t->stream));
+  HIPC(hipStreamSynchronize(t->stream));
+  return 0;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+const char *dpgo_last_error(void) { return g_err.c_str(); }
+
+void dpgo_default_params(dpgo_params_t *p, int r, int num_robots) {
+  std::memset(p, 0, sizeof *p);
+  p->d = 3; p->r = r; p->num_robots = num_robots;
+  p->method = DPGO_METHOD_RTR;
+  p->rgd_stepsize = 1e-3; p->rgd_use_preconditioner = 1;       // launch/PGOAgent.launch:16-17
+  p->rtr_iterations = 3; p->rtr_tcg_iterations = 50; p->gradnorm_tol = 1e-2;  // :18-20
+  p->rtr_initial_radius = 100.0; p->rtr_max_radius = 500.0; p->precond_shift = 0.1;
+  p->acceleration = 0; p->restart_interval = 50;                // :24-25
+  p->rel_change_tol = 0.1; p->max_num_iters = 1000;             // :37-38
+  p->robust_cost_type = DPGO_COST_L2;
+  p->gnc_barc = 5.0; p->gnc_mu_step = 2.0; p->gnc_init_mu = 1e-5;
+  p->robust_opt_num_weight_updates = 4; p->robust_opt_inner_iters = 10 * num_robots;
+  p->robust_opt_min_convergence_ratio = 0.8;
+  p->weights_as_float32 = 0;
+}
+
+dpgo_team_t *dpgo_team_create(int device, const dpgo_params_t *p, int num_local, const int *agent_ids, void *stream) {
+  if (p->d != 3 || p->r < 3 || p->r > 8) { set_err("d must be 3 and r in [3,8]"); return nullptr; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    set_err("no HIP device: libdpgo_hip has no CPU fallback");
+    return nullptr;
+  }
+  if (hipSetDevice(device) != hipSuccess) { set_err("hipSetDevice failed"); return nullptr; }
+  auto *t = new dpgo_team();
+  t->device = device; t->prm = *p;
+  if (stream) t->stream = (hipStream_t)stream;
+  else { if (hipStreamCreate(&t->stream) != hipSuccess) { delete t; set_err("hipStreamCreate failed"); return nullptr; } t->own_stream = true; }
+  if (hipHostMalloc((void **)&t->h_state, sizeof(RtrState)) != hipSuccess ||
+      hipHostMalloc((void **)&t->h_scal, sizeof(double) * 16) != hipSuccess) {
+    delete t; set_err("pinned allocation failed"); return nullptr;
+  }
+  for (int k = 0; k < num_local; ++k) {
+    auto a = std::make_unique<Agent>();
+    a->id = agent_ids[k]; a->local = k; a->mu = p->gnc_init_mu;
+    t->id2local[a->id] = k;
+    t->ag.push_back(std::move(a));
+  }
+  return t;
+}
+
+void dpgo_team_destroy(dpgo_team_t *t) {
+  if (!t) return;
+  (void)hipSetDevice(t->device);
+  (void)hipStreamSynchronize(t->stream);
+  if (t->graph) (void)hipGraphExecDestroy(t->graph);
+  t->ag.clear();
+  if (t->h_state) (void)hipHostFree(t->h_state);
+  if (t->h_scal) (void)hipHostFree(t->h_scal);
+  if (t->own_stream) (void)hipStreamDestroy(t->stream);
+  delete t;
+}
+
+int dpgo_team_num_local(const dpgo_team_t *t) { return (int)t->ag.size(); }
+void *dpgo_team_stream(dpgo_team_t *t) { return (void *)t->stream; }
+int dpgo_team_synchronize(dpgo_team_t *t) { HIPC(hipStreamSynchronize(t->stream)); return 0; }
+
+int dpgo_agent_add_measurements(dpgo_team_t *t, int id, const dpgo_measurement_t *m, int count) {
+  Agent *a = find_agent(t, id);
+  if (!a) return DPGO_ERR;
+  for (int k = 0; k < count; ++k) {
+    const dpgo_measurement_t &e = m[k];
+    if (e.r1 == id && e.r2 == id) { if (e.p1 + 1 == e.p2) a->odom.push_back(e); else a->priv.push_back(e); }
+    else if (e.r1 == id || e.r2 == id) a->shared.push_back(e);
+    else continue;
+    a->index_dirty = true;
+    if (a->state == DPGO_WAIT_FOR_DATA) a->state = DPGO_WAIT_FOR_INITIALIZATION;
+  }
+  return 0;
+}
+
+int dpgo_agent_num_poses(dpgo_team_t *t, int id) {
+  Agent *a = find_agent(t, id);
+  if (!a) return DPGO_ERR;
+  rebuild_index(*a);
+  return a->n;
+}
+
+int dpgo_agent_num_measurements(dpgo_team_t *t, int id, int *odom, int *priv, int *shared) {
+  Agent *a = find_agent(t, id);
+  if (!a) return DPGO_ERR;
+  if (odom) *odom = (int)a->odom.size();
+  if (priv) *priv = (int)a->priv.size();
+  if (shared) *shared = (int)a->shared.size();
+  return (int)(a->odom.size() + a->priv.size() + a->shared.size());
+}
+
+int dpgo_agent_get_neighbors(dpgo_team_t *t, int id, int *ids) {
+  Agent *a = find_agent(t, id);
+  if (!a) return DPGO_ERR;
+  rebuild_index(*a);
+  if (ids) std::copy(a->neighbors.begin(), a->neighbors.end(), ids);
+  return (int)a->neighbors.size();
+}
+
+int dpgo_agent_public_pose_ids(dpgo_team_t *t, int id, int nbr, int *frames) {
+  Agent *a = find_agent(t, id);
+  if (!a) return DPGO_ERR;
+  auto f = public_ids(*a, nbr);
+  if (frames) std::copy(f.begin(), f.end(), frames);
+  return (int)f.size();
+}
+
+int dpgo_agent_neighbor_pose_ids(dpgo_team_t *t, int id, int nbr, int *frames) {
+  Agent *a = find_agent(t, id);
+  if (!a) return DPGO_ERR;
+  rebuild_index(*a);
+  auto f = neighbor_ids(*a, nbr);
+  if (frames) std::copy(f.begin(), f.end(), frames);
+  return (int)f.size();
+}
+
+int dpgo_agent_set_X(dpgo_team_t *t, int id, const double *X) {
+  Agent *a = find_agent(t, id);
+  if (!a) return DPGO_ERR;
+  if (sync_descs(t)) return DPGO_ERR;
+  const size_t bytes = sizeof(double) * (size_t)t->prm.r * 4 * a->n;
+  for (int b : {B_X, B_XPREV, B_Y, B_V}) HIPC(hipMemcpyAsync(a->dev.buf[b], X, bytes, hipMemcpyHostToDevice, t->stream));
+  NestState ns{}; ns.iter = a->iter;
+  HIPC(hipMemcpyAsync(a->dev.nest, &ns, sizeof ns, hipMemcpyHostToDevice, t->stream));
+  HIPC(hipStreamSynchronize(t->stream));
+  a->has_X = true;
+  a->state = DPGO_INITIALIZED;
+  return 0;
+}
+
+int dpgo_agent_get_X(dpgo_team_t *t, int id, int which, double *X) {
+  Agent *a = find_agent(t, id);
+  if (!a) return DPGO_ERR;
+  if (!a->has_X) return DPGO_NOT_READY;
+  static const int map[4] = {B_X, B_Y, B_V, B_XPREV};
+  if (which < 0 || which > 3) return DPGO_ERR;
+  HIPC(hipMemcpyAsync(X, a->dev.buf[map[which]], sizeof(double) * (size_t)t->prm.r * 4 * a->n, hipMemcpyDeviceToHost,
+                      t->stream));
+  HIPC(hipStreamSynchronize(t->stream));
+  return 0;
+}
+
+int dpgo_agent_get_public_poses(dpgo_team_t *t, int id, int nbr, int aux, double *poses) {
+  Agent *a = find_agent(t, id);
+  if (!a) return DPGO_ERR;
+  if (!a->has_X) return DPGO_NOT_READY;
+  auto f = public_ids(*a, nbr);
+  const size_t B = (size_t)4 * t->prm.r;
+  const double *src = a->dev.buf[aux ? B_Y : B_X];
+  for (size_t k = 0; k < f.size(); ++k)
+    HIPC(hipMemcpyAsync(poses + k * B, src + f[k] * B, sizeof(double) * B, hipMemcpyDeviceToHost, t->stream));
+  HIPC(hipStreamSynchronize(t->stream));
+  return 0;
+}
+
+int dpgo_agent_update_neighbor_poses(dpgo_team_t *t, int id, int nbr, int aux, int count, const int *frames,
+                                     const double *poses) {
+  Agent *a = find_agent(t, id);
+  if (!a) return DPGO_ERR;
+  if (sync_descs(t)) return DPGO_ERR;
+  const size_t B = (size_t)4 * t->prm.r;
+  for (int k = 0; k < count; ++k) {
+    const int q = find_np(*a, nbr, frames[k]);
+    if (q < 0) continue;
+    HIPC(hipMemcpyAsync(a->dev.nbr[aux ? 1 : 0] + q * B, poses + k * B, sizeof(double) * B, hipMemcpyHostToDevice, t->stream));
+    a->np_has[aux ? 1 : 0][q] = 1;
+  }
+  HIPC(hipStreamSynchronize(t->stream));
+  return 0;
+}
+
+int dpgo_agent_pack_public_poses_device(dpgo_team_t *t, int id, int nbr, int aux, double *dev_out) {
+  Agent *a = find_agent(t, id);
+  if (!a) return DPGO_ERR;
+  if (!a->has_X) return DPGO_NOT_READY;
+  auto f = public_ids(*a, nbr);
+  if (a->d_idx.alloc(f.size())) return DPGO_ERR;
+  // frames table is tiny; stream-ordered upload keeps the call asynchronous
+  HIPC(hipMemcpyAsync(a->d_idx.p, f.data(), sizeof(int) * f.size(), hipMemcpyHostToDevice, t->stream));
+  HIPC(hipStreamSynchronize(t->stream));
+  launch_pack(t->ctx(), a->dev.buf[aux ? B_Y : B_X], a->d_idx.p, (int)f.size(), dev_out);
+  return (int)f.size();
+}
+
+int dpgo_agent_unpack_neighbor_poses_device(dpgo_team_t *t, int id, int nbr, int aux, const double *dev_in) {
+  Agent *a = find_agent(t, id);
+  if (!a) return DPGO_ERR;
+  if (sync_descs(t)) return DPGO_ERR;
+  std::vector<int> slots;
+  for (size_t q = 0; q < a->np.size(); ++q) if (a->np[q].first == nbr) { slots.push_back((int)q); a->np_has[aux ? 1 : 0][q] = 1; }
+  if (a->d_idx.alloc(slots.size())) return DPGO_ERR;
+  HIPC(hipMemcpyAsync(a->d_idx.p, slots.data(), sizeof(int) * slots.size(), hipMemcpyHostToDevice, t->stream));
+  HIPC(hipStreamSynchronize(t->stream));
+  launch_unpack(t->ctx(), a->dev.nbr[aux ? 1 : 0], a->d_idx.p, (int)slots.size(), dev_in);
+  return (int)slots.size();
+}
+
+int dpgo_agent_iterate(dpgo_team_t *t, int id, int do_optimization) {
+  Agent *a = find_agent(t, id);
+  if (!a) return DPGO_ERR;
+  if (a->state != DPGO_INITIALIZED || !a->has_X) { a->iter++; return DPGO_NOT_READY; }
+  if (sync_descs(t)) return DPGO_ERR;
+  if (t->prm.robust_cost_type != DPGO_COST_L2) a->robust_inner_iter++;
+  bool opt = do_optimization != 0;
+  a->last_success = true;
+  if (opt && !neighbor_poses_ready(*a, t->prm.acceleration ? 1 : 0)) { opt = false; a->last_success = false; }
+  const int rc = enqueue_iterate(t, a->local, opt ? 1 : 0);
+  if (rc) return rc;
+  a->iter++;
+  if (t->prm.acceleration || opt) a->publish_requested = true;
+  return a->last_success ? DPGO_OK : DPGO_NOT_READY;
+}
+
+int dpgo_agent_get_status(dpgo_team_t *t, int id, dpgo_status_t *s) {
+  Agent *a = find_agent(t, id);
+  if (!a) return DPGO_ERR;
+  s->agent_id = a->id; s->state = a->state; s->instance_number = a->instance; s->iteration_number = a->iter;
+  s->relative_change = 0; s->ready_to_terminate = 0;
+  if (!a->has_X) return DPGO_OK;
+  if (fetch_scal(t, *a)) return DPGO_ERR;
+  s->relative_change = std::sqrt(t->h_scal[0] / a->n);
+  s->ready_to_terminate = a->last_success && (s->relative_change <= t->prm.rel_change_tol);
+  return DPGO_OK;
+}
+
+int dpgo_agent_get_opt_result(dpgo_team_t *t, int id, dpgo_opt_result_t *r) {
+  Agent *a = find_agent(t, id);
+  if (!a) return DPGO_ERR;
+  if (refresh_rgd_result(t, *a)) return DPGO_ERR;
+  *r = a->opt;
+  return DPGO_OK;
+}
+
+int dpgo_agent_iteration_number(dpgo_team_t *t, int id) {
+  Agent *a = find_agent(t, id);
+  return a ? a->iter : DPGO_ERR;
+}
+
+int dpgo_agent_publish_requested(dpgo_team_t *t, int id, int clear) {
+  Agent *a = find_agent(t, id);
+  if (!a) return DPGO_ERR;
+  const int v = a->publish_requested ? 1 : 0;
+  if (clear) a->publish_requested = false;
+  return v;
+}
+
+// ---- QuadraticProblem surface --------------------------------------------------------------------
+int dpgo_agent_build_problem(dpgo_team_t *t, int id, int aux) {
+  Agent *a = find_agent(t, id);
+  if (!a) return DPGO_ERR;
+  if (sync_descs(t)) return DPGO_ERR;
+  if (!neighbor_poses_ready(*a, aux ? 1 : 0)) return DPGO_NOT_READY;
+  launch_buildG(t->ctx(), a->local, a->npub, aux ? 1 : 0, 0);
+  HIPC(hipStreamSynchronize(t->stream));
+  return 0;
+}
+
+int dpgo_agent_eval(dpgo_team_t *t, int id, const double *X, double *f, double *egrad, double *rgrad) {
+  Agent *a = find_agent(t, id);
+  if (!a) return DPGO_ERR;
+  if (sync_descs(t)) return DPGO_ERR;
+  const size_t bytes = sizeof(double) * (size_t)t->prm.r * 4 * a->n;
+  HIPC(hipMemcpyAsync(a->dev.buf[B_T0], X, bytes, hipMemcpyHostToDevice, t->stream));
+  launch_eval(t->ctx(), a->local, a->n, B_T0, B_T1, B_T2, PART_A);
+  std::vector<double> part((size_t)PART_STRIDE * MAX_PART);
+  HIPC(hipMemcpyAsync(part.data(), a->dev.part + PART_A, sizeof(double) * part.size(), hipMemcpyDeviceToHost, t->stream));
+  if (egrad) HIPC(hipMemcpyAsync(egrad, a->dev.buf[B_T1], bytes, hipMemcpyDeviceToHost, t->stream));
+  if (rgrad) HIPC(hipMemcpyAsync(rgrad, a->dev.buf[B_T2], bytes, hipMemcpyDeviceToHost, t->stream));
+  HIPC(hipStreamSynchronize(t->stream));
+  const int ppb = 64 / t->prm.r, nb = (a->n + ppb - 1) / ppb;
+  double s = 0;
+  for (int i = 0; i < nb; ++i) s += part[(size_t)i * PART_STRIDE];
+  if (f) *f = s;
+  return 0;
+}
+
+int dpgo_agent_hessvec(dpgo_team_t *t, int id, const double *X, const double *eta, double *out) {
+  Agent *a = find_agent(t, id);
+  if (!a) return DPGO_ERR;
+  if (sync_descs(t)) return DPGO_ERR;
+  const size_t bytes = sizeof(double) * (size_t)t->prm.r * 4 * a->n;
+  HIPC(hipMemcpyAsync(a->dev.buf[B_T0], X, bytes, hipMemcpyHostToDevice, t->stream));
+  HIPC(hipMemcpyAsync(a->dev.buf[B_X2], eta, bytes, hipMemcpyHostToDevice, t->stream));
+  launch_eval(t->ctx(), a->local, a->n, B_T0, B_T1, B_T2, PART_A);
+  launch_hess(t->ctx(), a->local, a->n, B_T0, B_T1, B_X2, B_HETA, PART_A);
+  HIPC(hipMemcpyAsync(out, a->dev.buf[B_HETA], bytes, hipMemcpyDeviceToHost, t->stream));
+  HIPC(hipStreamSynchronize(t->stream));
+  return 0;
+}
+
+int dpgo_agent_precondition(dpgo_team_t *t, int id, const double *X, const double *V, double *out) {
+  Agent *a = find_agent(t, id);
+  if (!a) return DPGO_ERR;
+  if (sync_descs(t)) return DPGO_ERR;
+  const size_t bytes = sizeof(double) * (size_t)t->prm.r * 4 * a->n;
+  HIPC(hipMemcpyAsync(a->dev.buf[B_T0], X, bytes, hipMemcpyHostToDevice, t->stream));
+  HIPC(hipMemcpyAsync(a->dev.buf[B_T1], V, bytes, hipMemcpyHostToDevice, t->stream));
+  launch_precond(t->ctx(), a->local, a->n, PM_PLAIN_, B_T0, B_T1, B_T2, 0, 0);
+  HIPC(hipMemcpyAsync(out, a->dev.buf[B_T2], bytes, hipMemcpyDeviceToHost, t->stream));
+  HIPC(hipStreamSynchronize(t->stream));
+  return 0;
+}
+
+int dpgo_agent_get_Q(dpgo_team_t *t, int id, int *rowptr, int *col, double *val) {
+  Agent *a = find_agent(t, id);
+  if (!a) return DPGO_ERR;
+  if (sync_descs(t)) return DPGO_ERR;
+  // read back from the device copy so the parity test sees what the kernels see
+  if (rowptr) HIPC(hipMemcpy(rowptr, a->dev.rowptr, sizeof(int) * (a->n + 1), hipMemcpyDeviceToHost));
+  if (col) HIPC(hipMemcpy(col, a->dev.col, sizeof(int) * a->col.size(), hipMemcpyDeviceToHost));
+  if (val) HIPC(hipMemcpy(val, a->dev.qval, sizeof(double) * a->qval.size(), hipMemcpyDeviceToHost));
+  return (int)a->col.size();
+}
+
+int dpgo_agent_get_G(dpgo_team_t *t, int id, double *G) {
+  Agent *a = find_agent(t, id);
+  if (!a) return DPGO_ERR;
+  if (sync_descs(t)) return DPGO_ERR;
+  HIPC(hipMemcpyAsync(G, a->dev.buf[B_G], sizeof(double) * (size_t)t->prm.r * 4 * a->n, hipMemcpyDeviceToHost, t->stream));
+  HIPC(hipStreamSynchronize(t->stream));
+  return 0;
+}
+
+// ---- manifold ops --------------------------------------------------------------------------------
+static int raw_op(dpgo_team_t *t, int which, const double *X, const double *V, int n, double *out) {
+  const size_t len = (size_t)t->prm.r * 4 * n;
+  if (t->d_tmp.alloc(3 * len)) { set_err("scratch allocation failed"); return DPGO_ERR; }
+  double *dX = t->d_tmp.p, *dV = dX + len, *dO = dV + len;
+  HIPC(hipMemcpyAsync(dX, X, sizeof(double) * len, hipMemcpyHostToDevice, t->stream));
+  if (V) HIPC(hipMemcpyAsync(dV, V, sizeof(double) * len, hipMemcpyHostToDevice, t->stream));
+  LaunchCtx c = t->ctx();
+  if (which == 0) launch_project_raw(c, dX, dO, n);
+  else if (which == 1) launch_tangent_raw(c, dX, dV, dO, n);
+  else launch_retract_raw(c, dX, dV, dO, n);
+  HIPC(hipMemcpyAsync(out, dO, sizeof(double) * len, hipMemcpyDeviceToHost, t->stream));
+  HIPC(hipStreamSynchronize(t->stream));
+  return 0;
+}
+int dpgo_project_manifold(dpgo_team_t *t, const double *X, int n, double *out) { return raw_op(t, 0, X, nullptr, n, out); }
+int dpgo_tangent_project(dpgo_team_t *t, const double *X, const double *V, int n, double *out) { return raw_op(t, 1, X, V, n, out); }
+int dpgo_retract(dpgo_team_t *t, const double *X, const double *eta, int n, double *out) { return raw_op(t, 2, X, eta, n, out); }
+
+// ---- robust path ---------------------------------------------------------------------------------
+int dpgo_agent_compute_residual(dpgo_team_t *t, int id, const dpgo_measurement_t *m, double *residual) {
+  Agent *a = find_agent(t, id);
+  if (!a) return DPGO_ERR;
+  if (!a->has_X) return DPGO_NOT_READY;
+  if (sync_descs(t)) return DPGO_ERR;
+  int e = 0, found = -1;
+  for (auto *vec : {&a->odom, &a->priv, &a->shared})
+    for (auto &x : *vec) { if (x.r1 == m->r1 && x.p1 == m->p1 && x.r2 == m->r2 && x.p2 == m->p2) found = e; ++e; }
+  if (found < 0) return DPGO_NOT_READY;
+  if (m->r1 != a->id) { const int q = find_np(*a, m->r1, m->p1); if (q < 0 || !a->np_has[0][q]) return DPGO_NOT_READY; }
+  if (m->r2 != a->id) { const int q = find_np(*a, m->r2, m->p2); if (q < 0 || !a->np_has[0][q]) return DPGO_NOT_READY; }
+  std::vector<double> res;
+  if (compute_residuals(t, *a, res)) return DPGO_ERR;
+  *residual = res[found];
+  return DPGO_OK;
+}
+
+double dpgo_agent_robust_weight(dpgo_team_t *t, int id, double residual) {
+  Agent *a = find_agent(t, id);
+  if (!a) return -1.0;
+  return robust_weight(t->prm, a->mu, residual);
+}
+
+int dpgo_agent_update_measurement_weights(dpgo_team_t *t, int id) {
+  Agent *a = find_agent(t, id);
+  if (!a) return DPGO_ERR;
+  if (sync_descs(t)) return DPGO_ERR;
+  std::vector<double> res;
+  if (a->has_X && compute_residuals(t, *a, res)) return DPGO_ERR;
+  int e = (int)a->odom.size();
+  if (a->has_X) {
+    for (auto &m : a->priv) { if (!m.fixed_weight) m.weight = robust_weight(t->prm, a->mu, res[e]); ++e; }
+    for (auto &m : a->shared) {
+      const int other = (m.r1 == a->id) ? m.r2 : m.r1;
+      bool ready = true;
+      const int q = find_np(*a, other, (m.r1 == a->id) ? m.p2 : m.p1);
+      if (q < 0 || !a->np_has[0][q]) ready = false;
+      if (!m.fixed_weight && other > a->id && ready) m.weight = robust_weight(t->prm, a->mu, res[e]);
+      ++e;
+    }
+  }
+  a->weight_update_count++;
+  a->mu *= t->prm.gnc_mu_step;
+  a->robust_inner_iter = 0;
+  a->data_dirty = true;
+  if (sync_descs(t)) return DPGO_ERR;
+  if (t->prm.acceleration && a->has_X) {
+    launch_nest_reset(t->ctx(), a->local, a->n);
+    NestState ns{}; ns.iter = a->iter;
+    HIPC(hipMemcpyAsync(a->dev.nest, &ns, sizeof ns, hipMemcpyHostToDevice, t->stream));
+    HIPC(hipStreamSynchronize(t->stream));
+  }
+  return DPGO_OK;
+}
+
+int dpgo_agent_set_measurement_weight(dpgo_team_t *t, int id, int r1, int p1, int r2, int p2, double w, int fixed) {
+  Agent *a = find_agent(t, id);
+  if (!a) return DPGO_ERR;
+  for (auto *vec : {&a->odom, &a->priv, &a->shared})
+    for (auto &m : *vec)
+      if (m.r1 == r1 && m.p1 == p1 && m.r2 == r2 && m.p2 == p2) { m.weight = w; m.fixed_weight = fixed; return DPGO_OK; }
+  return DPGO_NOT_READY;
+}
+
+int dpgo_agent_get_measurements(dpgo_team_t *t, int id, dpgo_measurement_t *out) {
+  Agent *a = find_agent(t, id);
+  if (!a) return DPGO_ERR;
+  int c = 0;
+  for (auto *vec : {&a->odom, &a->priv, &a->shared})
+    for (auto &m : *vec) { if (out) out[c] = m; ++c; }
+  return c;
+}
+
+int dpgo_agent_should_update_weights(dpgo_team_t *t, int id) {
+  Agent *a = find_agent(t, id);
+  if (!a) return DPGO_ERR;
+  if (t->prm.robust_cost_type == DPGO_COST_L2) return 0;
+  if (a->weight_update_count >= t->prm.robust_opt_num_weight_updates) return 0;
+  return a->robust_inner_iter >= t->prm.robust_opt_inner_iters;
+}
+
+int dpgo_agent_clear_data_matrices(dpgo_team_t *t, int id) {
+  Agent *a = find_agent(t, id);
+  if (!a) return DPGO_ERR;
+  a->data_dirty = true;
+  return DPGO_OK;
+}
+
+double dpgo_error_threshold_at_quantile(double quantile, int dim) {
+  // sqrt of the chi-square inverse CDF; regularised lower incomplete gamma by series + bisection
+  auto P = [&](double x) {
+    const double s = 0.5 * dim;
+    if (x <= 0) return 0.0;
+    double sum = 1.0 / s, term = 1.0 / s;
+    for (int k = 1; k < 2000; ++k) { term *= x / (s + k); sum += term; if (term < 1e-17 * sum) break; }
+    return std::exp(-x + s * std::log(x) - std::lgamma(s)) * sum;
+  };
+  double lo = 0, hi = 1000;
+  for (int it = 0; it < 200; ++it) { const double mid = 0.5 * (lo + hi); if (P(0.5 * mid) < quantile) lo = mid; else hi = mid; }
+  return std::sqrt(0.5 * (lo + hi));
+}
+
+// ---- team schedule -------------------------------------------------------------------------------
+int dpgo_team_set_schedule(dpgo_team_t *t, const int *order, int len) {
+  t->sched.clear();
+  for (int k = 0; k < len; ++k) {
+    auto it = t->id2local.find(order[k]);
+    if (it == t->id2local.end()) { set_err("schedule names a non-local agent"); return DPGO_ERR; }
+    t->sched.push_back(it->second);
+  }
+  t->descs_dirty = true;
+  return 0;
+}
+
+int dpgo_team_set_initial(dpgo_team_t *t, const double *T, const double *YLift, const int *offsets) {
+  const int r = t->prm.r;
+  if (sync_descs(t)) return DPGO_ERR;
+  for (auto &a : t->ag) {
+    std::vector<double> X((size_t)r * 4 * a->n);
+    dpgo_lift(T + (size_t)12 * offsets[a->local], a->n, YLift, r, X.data());
+    const int rc = dpgo_agent_set_X(t, a->id, X.data());
+    if (rc) return rc;
+  }
+  return dpgo_team_exchange_all(t);
+}
+
+int dpgo_team_exchange_all(dpgo_team_t *t) {
+  if (sync_descs(t)) return DPGO_ERR;
+  LaunchCtx c = t->ctx();
+  for (auto &a : t->ag) {
+    launch_pull(c, a->local, (int)a->shared.size());
+    for (size_t q = 0; q < a->np.size(); ++q)
+      if (t->id2local.count(a->np[q].first)) { a->np_has[0][q] = 1; a->np_has[1][q] = 1; }
+  }
+  HIPC(hipStreamSynchronize(t->stream));
+  return 0;
+}
+
+static int enqueue_team_iteration(dpgo_team_t *t, bool capture, bool restart) {
+  LaunchCtx c = t->ctx();
+  const dpgo_params_t &p = t->prm;
+  const int na = (int)t->ag.size();
+  const int sel = capture ? -1 : t->sched[t->iter % t->sched.size()];
+  const int mn = t->max_n;
+  int rc = 0;
+  if (p.acceleration) {
+    launch_nest_pre(c, sel, -1, na, mn, p.num_robots, p.restart_interval);
+    rc = enqueue_optimize(t, sel, 1, 1, capture);
+    if (rc) return rc;
+    launch_nest_post(c, sel, (sel >= 0) ? t->ag[sel]->n : mn, p.num_robots, p.restart_interval);
+    if (restart) {
+      rc = enqueue_optimize(t, sel, 0, 1, capture);
+      if (rc) return rc;
+      launch_nest_reset(c, sel, (sel >= 0) ? t->ag[sel]->n : mn);
+    }
+  } else {
+    launch_copy(c, -3, -1, na, mn, B_X, B_XPREV);
+    rc = enqueue_optimize(t, sel, 0, 1, capture);
+    if (rc) return rc;
+  }
+  launch_status(c, -3, -1, na, -1, PART_A);
+  launch_advance(c, -1, na, p.acceleration, p.num_robots, p.restart_interval, 1);
+  return 0;
+}
+
+int dpgo_team_run(dpgo_team_t *t, int iters) {
+  if (sync_descs(t)) return DPGO_ERR;
+  const dpgo_params_t &p = t->prm;
+  for (auto &a : t->ag) if (!a->has_X) { set_err("team_run before set_initial"); return DPGO_NOT_READY; }
+  const bool graphable = (p.method == DPGO_METHOD_RGD);
+  if (graphable && !t->graph_valid) {
+    hipGraph_t g = nullptr;
+    HIPC(hipStreamBeginCapture(t->stream, hipStreamCaptureModeThreadLocal));
+    double saved[8]; std::memcpy(saved, t->counters, sizeof saved);
+    const int rc = enqueue_team_iteration(t, true, false);
+    std::memcpy(t->counters, saved, sizeof saved);
+    HIPC(hipStreamEndCapture(t->stream, &g));
+    if (rc) { (void)hipGraphDestroy(g); return rc; }
+    if (t->graph) { (void)hipGraphExecDestroy(t->graph); t->graph = nullptr; }
+    HIPC(hipGraphInstantiate(&t->graph, g, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(g);
+    t->graph_valid = true;
+  }
+  for (int k = 0; k < iters; ++k) {
+    const bool restart = p.acceleration && ((t->iter + 2) % p.restart_interval) == 0;
+    const int sel = t->sched[t->iter % t->sched.size()];
+    if (graphable && !restart) {
+      HIPC(hipGraphLaunch(t->graph, t->stream));
+      const int n = t->ag[sel]->n, N4 = 4 * n;
+      if (p.rgd_use_preconditioner) { t->counters[0] += 1; t->counters[1] += 8.0 * N4 * (double)N4; }
+      t->counters[2] += 2;
+      t->counters[3] += 2 * (8.0 * (16.0 * t->ag[sel]->col.size() + 3.0 * p.r * 4 * n) + 4.0 * (t->ag[sel]->col.size() + n + 1));
+      t->ag[sel]->opt_pending_rgd = true;
+    } else {
+      const int rc = enqueue_team_iteration(t, false, restart);
+      if (rc) return rc;
+    }
+    t->iter++;
+    for (auto &a : t->ag) { a->iter++; if (p.robust_cost_type != DPGO_COST_L2) a->robust_inner_iter++; }
+    t->counters[4] += 1;
+  }
+  return 0;
+}
+
+int dpgo_team_iteration(dpgo_team_t *t) { return t->iter; }
+
+int dpgo_team_cost(dpgo_team_t *t, double *f) {
+  if (sync_descs(t)) return DPGO_ERR;
+  LaunchCtx c = t->ctx();
+  double total = 0;
+  for (auto &a : t->ag) launch_pull(c, a->local, (int)a->shared.size());
+  for (auto &a : t->ag) {
+    launch_residuals(c, a->local, a->nedges);
+    launch_cost(c, a->local);
+  }
+  for (auto &a : t->ag) {
+    if (fetch_scal(t, *a)) return DPGO_ERR;
+    total += t->h_scal[5];
+  }
+  *f = total;
+  return 0;
+}
+
+int dpgo_team_update_weights(dpgo_team_t *t) {
+  if (sync_descs(t)) return DPGO_ERR;
+  if (dpgo_team_exchange_all(t)) return DPGO_ERR;
+  int changed = 0;
+  for (auto &a : t->ag) if (dpgo_agent_update_measurement_weights(t, a->id)) return DPGO_ERR;
+  for (auto &a : t->ag)
+    for (auto &m : a->shared) {
+      const int other = (m.r1 == a->id) ? m.r2 : m.r1;
+      if (other < a->id || !t->id2local.count(other)) continue;
+      double w = m.weight;
+      if (t->prm.weights_as_float32) w = (double)(float)w;
+      if (dpgo_agent_set_measurement_weight(t, other, m.r1, m.p1, m.r2, m.p2, w, m.fixed_weight) == DPGO_OK) ++changed;
+      t->ag[t->id2local[other]]->data_dirty = true;
+    }
+  if (sync_descs(t)) return DPGO_ERR;
+  return changed;
+}
+
+int dpgo_team_get_counters(dpgo_team_t *t, double *out, int n) {
+  for (int k = 0; k < n && k < 8; ++k) out[k] = t->counters[k];
+  return 0;
+}
+
+}  // extern "C"

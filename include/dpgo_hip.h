@@ -1,0 +1,165 @@
+/*
+ * dpgo_hip.h -- C-ABI of the MI355X-native RBCD hot path (libdpgo_hip.so).
+ *
+ * This is the drop-in boundary underneath the C++ facade `namespace DPGO` (include/DPGO/*.h) that
+ * the ROS wrapper of mit-acl/dpgo_ros subclasses (include/dpgo_ros/PGOAgentROS.h:121
+ * `class PGOAgentROS : public PGOAgent`).  Each entry point cites the reference call site it
+ * serves (paths relative to /root/reference).  Plain pointers and sizes only; no torch types.
+ *
+ * Conventions (d = 3, k = 4, r = relaxation rank in [3,8]):
+ *   X is r x (4 n) column-major: X[(4*i + c)*r + a]; c<3 -> column c of Y_i, c=3 -> p_i.
+ *   A "pose" is the r x 4 block of 4r contiguous doubles (Eigen column-major LiftedPose::getData()).
+ *   All arithmetic is fp64 on the device.  Host pointers unless the name says _device.
+ * Return codes: 0 = ok, >0 = not available yet (the facade maps to `false`), <0 = fatal (CHECK).
+ */
+#ifndef DPGO_HIP_H
+#define DPGO_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* RelativeSEMeasurement(r1,r2,p1,p2,R,t,kappa,tau) + weight, fixedWeight
+ * (src/utils.cpp:109-149; src/PGOAgentROS.cpp:740-745) */
+typedef struct {
+  int r1, p1, r2, p2;
+  double R[9]; /* row-major 3x3 */
+  double t[3];
+  double kappa, tau, weight;
+  int fixed_weight;
+  int is_known_inlier;
+} dpgo_measurement_t;
+
+enum { DPGO_METHOD_RTR = 0, DPGO_METHOD_RGD = 1 };       /* ROptParameters::ROptMethod */
+enum { DPGO_COST_L2 = 0, DPGO_COST_GNC_TLS = 5 };         /* RobustCostParameters::Type */
+enum { DPGO_WAIT_FOR_DATA = 0, DPGO_WAIT_FOR_INITIALIZATION = 1, DPGO_INITIALIZED = 2 }; /* msg/Status.msg:1-3 */
+enum { DPGO_WEIGHT_LIBRARY = 0, DPGO_WEIGHT_WRAPPER = 1 }; /* info-matrix vs kappa=1e4,tau=1e2 */
+enum { DPGO_OK = 0, DPGO_NOT_READY = 1, DPGO_ERR = -1 };
+
+/* PGOAgentParameters fields written by src/PGOAgentROSNode.cpp:80-231 */
+typedef struct {
+  int d, r, num_robots;
+  int method;
+  double rgd_stepsize;
+  int rgd_use_preconditioner;
+  int rtr_iterations;
+  int rtr_tcg_iterations;
+  double gradnorm_tol;
+  double rtr_initial_radius;
+  double rtr_max_radius;
+  double precond_shift;
+  int acceleration;
+  int restart_interval;
+  double rel_change_tol;
+  int max_num_iters;
+  int robust_cost_type;
+  double gnc_barc, gnc_mu_step, gnc_init_mu;
+  int robust_opt_num_weight_updates, robust_opt_inner_iters;
+  double robust_opt_min_convergence_ratio;
+  int weights_as_float32;
+} dpgo_params_t;
+
+/* mLocalOptResult.{success,fInit,fOpt,gradNormInit,gradNormOpt} (src/PGOAgentROS.cpp:169-172) */
+typedef struct {
+  int success;
+  double f_init, f_opt, gradnorm_init, gradnorm_opt;
+  int rtr_outer_iters, tcg_iters_total, hessvec_count, precond_count, accepted;
+} dpgo_opt_result_t;
+
+/* PGOAgentStatus(agentID,state,instanceNumber,iterationNumber,readyToTerminate,relativeChange)
+ * (src/utils.cpp:262-281; tests/testUtils.cpp:56-65) */
+typedef struct {
+  int agent_id, state, instance_number, iteration_number, ready_to_terminate;
+  double relative_change;
+} dpgo_status_t;
+
+void dpgo_default_params(dpgo_params_t *p, int r, int num_robots);
+const char *dpgo_last_error(void);
+
+/* ---- dataset input: read_g2o_file (src/PGODatasetPublisherNode.cpp:80),
+ *      PGOLogger::loadMeasurements (:168), contiguous partition (:84-135) ---- */
+int dpgo_read_g2o(const char *path, int weight_mode, dpgo_measurement_t **out, int *num_poses);
+int dpgo_read_measurements_csv(const char *path, int weight_mode, dpgo_measurement_t **out);
+void dpgo_partition(dpgo_measurement_t *m, int nm, int num_poses, int num_robots, int weight_mode);
+void dpgo_free(void *p);
+void dpgo_odometry_init(const dpgo_measurement_t *m, int nm, int num_poses, double *T /* 3x4 per pose */);
+void dpgo_fixed_stiefel(int r, double *YLift);
+void dpgo_lift(const double *T, int num_poses, const double *YLift, int r, double *X);
+
+/* ---- a team = the agents resident on one GPU (one process per GPU) ---- */
+typedef struct dpgo_team dpgo_team_t;
+/* agent_ids: global robot ids hosted here.  stream: hipStream_t or NULL (library-owned stream). */
+dpgo_team_t *dpgo_team_create(int device, const dpgo_params_t *p, int num_local, const int *agent_ids,
+                              void *stream);
+void dpgo_team_destroy(dpgo_team_t *t);
+int dpgo_team_num_local(const dpgo_team_t *t);
+void *dpgo_team_stream(dpgo_team_t *t);
+int dpgo_team_synchronize(dpgo_team_t *t);
+
+/* PGOAgent::addMeasurement (src/PGOAgentROS.cpp:277,1307).  Measurements not touching `id` are ignored. */
+int dpgo_agent_add_measurements(dpgo_team_t *t, int id, const dpgo_measurement_t *m, int count);
+int dpgo_agent_num_poses(dpgo_team_t *t, int id);                       /* num_poses() :285 */
+int dpgo_agent_num_measurements(dpgo_team_t *t, int id, int *odom, int *priv, int *shared); /* :343-345 */
+int dpgo_agent_get_neighbors(dpgo_team_t *t, int id, int *ids);         /* getNeighbors() :663 */
+int dpgo_agent_public_pose_ids(dpgo_team_t *t, int id, int nbr, int *frames);
+int dpgo_agent_neighbor_pose_ids(dpgo_team_t *t, int id, int nbr, int *frames); /* activeNeighborPublicPoseIDs :1394 */
+/* initializeInGlobalFrame-equivalent entry: set the lifted iterate (r x 4n); X->XPrev,Y,V; INITIALIZED */
+int dpgo_agent_set_X(dpgo_team_t *t, int id, const double *X);
+/* which: 0 X, 1 Y (auxiliary), 2 V, 3 XPrev */
+int dpgo_agent_get_X(dpgo_team_t *t, int id, int which, double *X);
+/* getSharedPoseDictWithNeighbor / getAuxSharedPoseDictWithNeighbor (:668,:666); order = public_pose_ids */
+int dpgo_agent_get_public_poses(dpgo_team_t *t, int id, int nbr, int aux, double *poses);
+/* updateNeighborPoses / updateAuxNeighborPoses (:1276,:1278) */
+int dpgo_agent_update_neighbor_poses(dpgo_team_t *t, int id, int nbr, int aux, int count,
+                                     const int *frames, const double *poses);
+/* same exchange with device buffers (packed slab, order = public_pose_ids / neighbor_pose_ids):
+ * the RCCL point-to-point payload that replaces msg/PublicPoses.msg (:662-690, :1255-1284) */
+int dpgo_agent_pack_public_poses_device(dpgo_team_t *t, int id, int nbr, int aux, double *dev_out);
+int dpgo_agent_unpack_neighbor_poses_device(dpgo_team_t *t, int id, int nbr, int aux, const double *dev_in);
+
+int dpgo_agent_iterate(dpgo_team_t *t, int id, int do_optimization);    /* :160 (true), :1185 (false) */
+int dpgo_agent_get_status(dpgo_team_t *t, int id, dpgo_status_t *s);     /* getStatus() :616 */
+int dpgo_agent_get_opt_result(dpgo_team_t *t, int id, dpgo_opt_result_t *r); /* :169-172 */
+int dpgo_agent_iteration_number(dpgo_team_t *t, int id);                 /* iteration_number() :139 */
+int dpgo_agent_publish_requested(dpgo_team_t *t, int id, int clear);     /* mPublishPublicPosesRequested :109-112 */
+
+/* ---- QuadraticProblem surface for parity (f, EucGrad, RieGrad, Hessian, PreConditioner) ---- */
+int dpgo_agent_build_problem(dpgo_team_t *t, int id, int aux);
+int dpgo_agent_eval(dpgo_team_t *t, int id, const double *X, double *f, double *egrad, double *rgrad);
+int dpgo_agent_hessvec(dpgo_team_t *t, int id, const double *X, const double *eta, double *out);
+int dpgo_agent_precondition(dpgo_team_t *t, int id, const double *X, const double *V, double *out);
+int dpgo_agent_get_Q(dpgo_team_t *t, int id, int *rowptr, int *col, double *val); /* returns #blocks */
+int dpgo_agent_get_G(dpgo_team_t *t, int id, double *G);
+
+/* ---- lifted SE manifold ops on the device (host in/out), n poses of r x 4 ---- */
+int dpgo_project_manifold(dpgo_team_t *t, const double *X, int n, double *out);
+int dpgo_tangent_project(dpgo_team_t *t, const double *X, const double *V, int n, double *out);
+int dpgo_retract(dpgo_team_t *t, const double *X, const double *eta, int n, double *out);
+
+/* ---- robust path (src/PGOAgentROS.cpp:1218,1049,1050,1341,210,1351; Node.cpp:201) ---- */
+int dpgo_agent_compute_residual(dpgo_team_t *t, int id, const dpgo_measurement_t *m, double *residual);
+double dpgo_agent_robust_weight(dpgo_team_t *t, int id, double residual);
+int dpgo_agent_update_measurement_weights(dpgo_team_t *t, int id);
+int dpgo_agent_set_measurement_weight(dpgo_team_t *t, int id, int r1, int p1, int r2, int p2, double w, int fixed);
+int dpgo_agent_get_measurements(dpgo_team_t *t, int id, dpgo_measurement_t *out);
+int dpgo_agent_should_update_weights(dpgo_team_t *t, int id);
+int dpgo_agent_clear_data_matrices(dpgo_team_t *t, int id);
+double dpgo_error_threshold_at_quantile(double quantile, int dim);
+
+/* ---- synchronous schedule on the device (src/PGOAgentROS.cpp:129-220,443-504,1161-1189):
+ *      all agents of the problem live in this team; exchange is device-to-device ---- */
+int dpgo_team_set_schedule(dpgo_team_t *t, const int *order, int len);
+int dpgo_team_set_initial(dpgo_team_t *t, const double *T, const double *YLift, const int *offsets);
+int dpgo_team_exchange_all(dpgo_team_t *t);
+/* run `iters` global RBCD iterations without host synchronisation (RGD: one hipGraph replay each) */
+int dpgo_team_run(dpgo_team_t *t, int iters);
+int dpgo_team_iteration(dpgo_team_t *t);
+/* global cost of the concatenated iterate, evaluated on the device */
+int dpgo_team_cost(dpgo_team_t *t, double *f);
+int dpgo_team_update_weights(dpgo_team_t *t);
+/* counters for the roofline report: launches and algorithmic bytes of the dominant kernels */
+int dpgo_team_get_counters(dpgo_team_t *t, double *out, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

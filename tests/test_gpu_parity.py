@@ -1,0 +1,140 @@
+"""GPU parity tests proper: every call goes through the C-ABI (libdpgo_hip.so) and is compared with
+the CPU oracle on the same seeded inputs.  Tolerances are fp64 round-off level per operation
+(summation order differs) and are written next to each assertion."""
+import numpy as np
+import pytest
+
+from dpgo_ros_amd import capi
+from oracle import oracle as O
+from tests.util import load, make_pair, params_pair, random_point, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def scratch_team():
+    t = capi.Team(capi.default_params(r=5, num_robots=1), [0])
+    yield t
+    t.close()
+
+
+@pytest.mark.parametrize("r", [3, 4, 5, 6, 8])
+def test_manifold_ops(r):
+    rng = np.random.default_rng(r)
+    n = 257
+    t = capi.Team(capi.default_params(r=r, num_robots=1), [0])
+    # well-conditioned inputs, as in the algorithm (combinations of nearby Stiefel points):
+    # the polar factor's sensitivity is cond(A)^2 * eps
+    X = O.project_manifold(rng.standard_normal(r * 4 * n), r, n) + 0.2 * rng.standard_normal(r * 4 * n)
+    out = np.zeros_like(X)
+    capi._chk(capi.lib().dpgo_project_manifold(t.h, capi._d(X), n, capi._d(out)), "project")
+    ref = O.project_manifold(X, r, n)
+    assert relerr(out, ref) < 1e-12
+    Y = out.reshape(n, 4, r)[:, :3, :]
+    gram = np.einsum("nia,nja->nij", Y, Y)
+    assert np.abs(gram - np.eye(3)).max() < 1e-12  # KAT 3: Y^T Y = I
+    V = rng.standard_normal(r * 4 * n)
+    tp = np.zeros_like(X)
+    capi._chk(capi.lib().dpgo_tangent_project(t.h, capi._d(ref), capi._d(V), n, capi._d(tp)), "tangent")
+    assert relerr(tp, O.tangent_project(ref, V, r, n)) < 1e-13
+    eta = 0.3 * O.tangent_project(ref, V, r, n)
+    rt = np.zeros_like(X)
+    capi._chk(capi.lib().dpgo_retract(t.h, capi._d(ref), capi._d(eta), n, capi._d(rt)), "retract")
+    assert relerr(rt, O.retract(ref, eta, r, n)) < 1e-13
+    t.close()
+
+
+@pytest.mark.parametrize("dataset,N,r", [("tinyGrid3D", 2, 5), ("smallGrid3D", 2, 5), ("smallGrid3D", 3, 3),
+                                         ("sphere2500", 5, 5)])
+def test_problem_surface(dataset, N, r):
+    """Q, G, f, EucGrad, RieGrad, Hess-vec and preconditioner of every agent vs the oracle."""
+    th, to, n = make_pair(dataset, N, r=r)
+    rng = np.random.default_rng(7)
+    for k in range(N):
+        ah, ao = th.agents[k], to.agents[k]
+        assert ah.n == ao.n
+        assert ah.neighbors() == ao.neighbors()
+        for nb in ao.neighbors():
+            assert np.array_equal(ah.public_pose_ids(nb), ao.public_pose_ids(nb))
+            assert np.array_equal(ah.neighbor_pose_ids(nb), ao.neighbor_pose_ids(nb))
+        ah.build_problem(False)
+        ao.build_problem(False)
+        rp_h, col_h, val_h = ah.get_Q()
+        rp_o, col_o, val_o = ao.get_Q()
+        assert np.array_equal(rp_h, rp_o) and np.array_equal(col_h, col_o)  # index work: bit exact
+        assert relerr(val_h, val_o) < 1e-15
+        assert relerr(ah.get_G(), ao.get_G()) < 1e-14
+        X = random_point(rng, r, ah.n)
+        fh, egh, rgh = ah.eval(X)
+        fo, ego, rgo = ao.eval(X)
+        assert abs(fh - fo) <= 1e-12 * abs(fo)
+        assert relerr(egh, ego) < 1e-13 and relerr(rgh, rgo) < 1e-13
+        eta = O.tangent_project(X, rng.standard_normal(X.size), r, ah.n)
+        assert relerr(ah.hessvec(X, eta), ao.hessvec(X, eta)) < 1e-13
+        V = rng.standard_normal(X.size)
+        # dense inverse vs sparse Cholesky: cond(Q + 0.1 I) ~ 1e5..1e6 bounds the agreement
+        assert relerr(ah.precondition(X, V), ao.precondition(X, V)) < 1e-9
+    th.close()
+
+
+@pytest.mark.parametrize("accel", [0, 1])
+@pytest.mark.parametrize("method", [capi.METHOD_RGD, capi.METHOD_RTR])
+def test_agent_api_iterates(method, accel):
+    """Drive both implementations through the per-agent API exactly as PGOAgentROS does:
+    iterate(false) on everyone else, publish, iterate(true) on the token holder, publish."""
+    N, r = 2, 5
+    kw = dict(method=method, acceleration=accel, rgd_stepsize=0.2, restart_interval=7, gradnorm_tol=1e-2)
+    th, to, n = make_pair("smallGrid3D", N, r=r, **kw)
+
+    def publish(team, b, with_aux):
+        a = team.agents[b]
+        for c in a.neighbors():
+            ids, P = a.get_public_poses(c, False)
+            team.agents[c].update_neighbor_poses(b, ids, P, False)
+            if with_aux:
+                ids, P = a.get_public_poses(c, True)
+                team.agents[c].update_neighbor_poses(b, ids, P, True)
+
+    for k in range(16):
+        sel = k % N
+        for team in (th, to):
+            for b in range(N):
+                if b != sel:
+                    team.agents[b].iterate(False)
+                    if accel:
+                        publish(team, b, True)
+            assert team.agents[sel].iterate(True)
+            publish(team, sel, bool(accel))
+        for b in range(N):
+            # iterates: 1e-9 absolute after k RBCD iterations (preconditioner solves differ at 1e-10)
+            assert np.abs(th.agents[b].get_X() - to.agents[b].get_X()).max() < 1e-8, (k, b)
+            sh, so = th.agents[b].status(), to.agents[b].status()
+            assert abs(sh.relative_change - so.relative_change) < 1e-8
+        rh, ro = th.agents[sel].opt_result(), to.agents[sel].opt_result()
+        assert abs(rh.f_init - ro.f_init) <= 1e-9 * abs(ro.f_init)
+        assert abs(rh.f_opt - ro.f_opt) <= 1e-9 * abs(ro.f_opt)
+        assert abs(rh.gradnorm_init - ro.gradnorm_init) <= 1e-7 * max(1.0, ro.gradnorm_init)
+        if method == capi.METHOD_RTR:
+            assert rh.tcg_iters_total == ro.tcg_iters_total and rh.accepted == ro.accepted
+    th.close()
+
+
+@pytest.mark.parametrize("dataset,N,method,accel,iters", [
+    ("smallGrid3D", 2, capi.METHOD_RGD, 0, 30),
+    ("smallGrid3D", 2, capi.METHOD_RGD, 1, 30),
+    ("smallGrid3D", 2, capi.METHOD_RTR, 0, 12),
+    ("smallGrid3D", 2, capi.METHOD_RTR, 1, 12),
+    ("sphere2500", 5, capi.METHOD_RGD, 1, 60),
+    ("sphere2500", 5, capi.METHOD_RTR, 0, 10),
+])
+def test_team_run_matches_oracle(dataset, N, method, accel, iters):
+    kw = dict(method=method, acceleration=accel, rgd_stepsize=0.1, restart_interval=25, gradnorm_tol=1e-2)
+    th, to, n = make_pair(dataset, N, **kw)
+    th.run(iters)
+    for _ in range(iters):
+        to.iterate()
+    Xh, Xo = th.global_X(), to.global_X()
+    assert np.abs(Xh - Xo).max() < 1e-7
+    fh, fo = th.cost(), to.cost()
+    assert abs(fh - fo) <= 1e-9 * abs(fo)
+    th.close()
