@@ -75,7 +75,7 @@ dpgo_agent_get_G dpgo_project_manifold dpgo_tangent_project dpgo_retract dpgo_ag
 dpgo_agent_robust_weight dpgo_agent_update_measurement_weights dpgo_agent_set_measurement_weight
 dpgo_agent_get_measurements dpgo_agent_should_update_weights dpgo_agent_clear_data_matrices
 dpgo_error_threshold_at_quantile dpgo_team_set_schedule dpgo_team_set_initial dpgo_team_exchange_all
-dpgo_team_run dpgo_team_iteration dpgo_team_cost dpgo_team_update_weights dpgo_team_get_counters""".split()
+dpgo_agent_pull_local dpgo_team_time_kernel dpgo_team_run dpgo_team_iteration dpgo_team_cost dpgo_team_update_weights dpgo_team_get_counters""".split()
 
 
 class DpgoError(RuntimeError):
@@ -311,6 +311,9 @@ class Agent:
     def clear_data_matrices(self):
         _chk(lib().dpgo_agent_clear_data_matrices(self.t, self.id), "clearDataMatrices")
 
+    def pull_local(self):
+        _chk(lib().dpgo_agent_pull_local(self.t, self.id), "pull_local")
+
     # --- device-buffer exchange (RCCL payloads)
     def pack_public_poses_device(self, nbr, aux, dev_ptr):
         return _chk(lib().dpgo_agent_pack_public_poses_device(self.t, self.id, nbr, int(aux), C.c_void_p(dev_ptr)), "pack")
@@ -397,6 +400,11 @@ class Team:
 
     def stream(self):
         return lib().dpgo_team_stream(self.h)
+
+    def time_kernel(self, agent_id, which, reps=200):
+        ms, nbytes = C.c_double(), C.c_double()
+        _chk(lib().dpgo_team_time_kernel(self.h, agent_id, which, reps, C.byref(ms), C.byref(nbytes)), "time_kernel")
+        return ms.value, nbytes.value
 
     def global_X(self):
         return np.concatenate([self.agents[i].get_X() for i in self.ids])

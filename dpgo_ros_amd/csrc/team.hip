@@ -1081,4 +1081,44 @@ int dpgo_team_get_counters(dpgo_team_t *t, double *out, int n) {
   return 0;
 }
 
+int dpgo_agent_pull_local(dpgo_team_t *t, int id) {
+  Agent *a = find_agent(t, id);
+  if (!a) return DPGO_ERR;
+  if (sync_descs(t)) return DPGO_ERR;
+  launch_pull(t->ctx(), a->local, (int)a->shared.size());
+  for (size_t q = 0; q < a->np.size(); ++q)
+    if (t->id2local.count(a->np[q].first)) { a->np_has[0][q] = 1; a->np_has[1][q] = 1; }
+  return 0;
+}
+
+// average duration of one launch of a hot kernel, HIP events on the team stream (roofline leg of bench.py)
+int dpgo_team_time_kernel(dpgo_team_t *t, int id, int which, int reps, double *avg_ms, double *algorithmic_bytes) {
+  Agent *a = find_agent(t, id);
+  if (!a) return DPGO_ERR;
+  if (sync_descs(t)) return DPGO_ERR;
+  LaunchCtx c = t->ctx();
+  const int n = a->n, r = t->prm.r;
+  const double N4 = 4.0 * n;
+  const double vec = 8.0 * r * 4 * n;
+  auto launch = [&]() {
+    if (which == 0) launch_precond(c, a->local, n, PM_PLAIN_, B_X, B_GF, B_T2, 0, 0);
+    else if (which == 1) launch_eval(c, a->local, n, B_X, B_T1, B_T2, PART_C);
+    else launch_hess(c, a->local, n, B_X, B_EGRAD, B_GF, B_T2, PART_C);
+  };
+  if (which == 0) *algorithmic_bytes = 8.0 * N4 * N4 + 3.0 * vec;          // M once, v + X in, z out
+  else *algorithmic_bytes = 8.0 * (16.0 * a->col.size() + 3.0 * r * 4 * n) + 4.0 * (a->col.size() + n + 1);
+  hipEvent_t e0, e1;
+  HIPC(hipEventCreate(&e0)); HIPC(hipEventCreate(&e1));
+  for (int k = 0; k < 3; ++k) launch();
+  HIPC(hipEventRecord(e0, t->stream));
+  for (int k = 0; k < reps; ++k) launch();
+  HIPC(hipEventRecord(e1, t->stream));
+  HIPC(hipEventSynchronize(e1));
+  float ms = 0;
+  HIPC(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  *avg_ms = (double)ms / reps;
+  return 0;
+}
+
 }  // extern "C"

@@ -1,7 +1,7 @@
 /*
  * dpgo_hip.h -- C-ABI of the MI355X-native RBCD hot path (libdpgo_hip.so).
  *
- * This is the drop-in boundary underneath the C++ facade `namespace DPGO` (include/DPGO/*.h) that
+ * This is the drop-in boundary underneath the C++ facade `namespace DPGO` (headers under include/DPGO/) that
  * the ROS wrapper of mit-acl/dpgo_ros subclasses (include/dpgo_ros/PGOAgentROS.h:121
  * `class PGOAgentROS : public PGOAgent`).  Each entry point cites the reference call site it
  * serves (paths relative to /root/reference).  Plain pointers and sizes only; no torch types.
@@ -156,6 +156,11 @@ int dpgo_team_iteration(dpgo_team_t *t);
 /* global cost of the concatenated iterate, evaluated on the device */
 int dpgo_team_cost(dpgo_team_t *t, double *f);
 int dpgo_team_update_weights(dpgo_team_t *t);
+/* refresh this agent's neighbour slabs from co-resident agents (device-to-device) */
+int dpgo_agent_pull_local(dpgo_team_t *t, int id);
+/* average HIP-event duration of one launch of a hot kernel on the team stream.
+ * which: 0 dense preconditioner apply, 1 cost+gradient SpMM, 2 Hessian-vector SpMM */
+int dpgo_team_time_kernel(dpgo_team_t *t, int id, int which, int reps, double *avg_ms, double *algorithmic_bytes);
 /* counters for the roofline report: launches and algorithmic bytes of the dominant kernels */
 int dpgo_team_get_counters(dpgo_team_t *t, double *out, int n);
 
