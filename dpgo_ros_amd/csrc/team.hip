@@ -131,7 +131,7 @@ void edge_blocks(const dpgo_measurement_t &m, double TO[16], double TOT[16], dou
   for (int a = 0; a < 3; ++a) {
     for (int b = 0; b < 3; ++b) {
       TO[a + 4 * b] = w * k * m.R[3 * a + b];
-      TOT[a + 4 * b] = w * ((a == b ? k : 0.0) + tau * m.t[a] * m.t[b]);
+      TOT[a + 4 * b] = w * ((a == b ? k : 0.0) + tau * (m.t[a] * m.t[b]));
     }
     TO[a + 12] = w * tau * m.t[a];
     TOT[a + 12] = w * tau * m.t[a];

@@ -185,7 +185,7 @@ void orc_edge_blocks(const orc_meas_t *m, double TO[16], double TOT[16], double 
   for (int a = 0; a < 3; ++a) {
     for (int b = 0; b < 3; ++b) {
       TO[a + 4 * b] = w * k * m->R[3 * a + b];
-      TOT[a + 4 * b] = w * ((a == b ? k : 0.0) + tau * m->t[a] * m->t[b]);
+      TOT[a + 4 * b] = w * ((a == b ? k : 0.0) + tau * (m->t[a] * m->t[b]));
     }
     TO[a + 4 * 3] = w * tau * m->t[a];
     TOT[a + 4 * 3] = w * tau * m->t[a];
