@@ -50,9 +50,16 @@ struct NestState {
 struct AgentDev {
   int id, n, nb, N4;
   int npub, nshared, nnp, nedges;
-  const int *rowptr;
+  const int *rowptr;          // full block-CSR (dense assembly, read-back)
   const int *col;
   const double *qval;
+  int ell_w, pad0;            // ELL part of the same matrix: slot-major [ell_w][n], padded with (j, 0)
+  const int *ell_col;
+  const double *ell_val;
+  const int *trowptr;         // CSR tail: blocks beyond ell_w of long rows
+  const int *tcol;
+  const double *tval;
+  const int *pub_index;       // [n] index into pub_pose/pub_ptr or -1
   const double *M;            // dense (Q + shift I)^-1, N4 x N4 column-major (symmetric)
   const int *pub_pose;        // [npub] local poses that own >= 1 shared edge
   const int *pub_ptr;         // [npub+1] CSR into se
@@ -69,12 +76,20 @@ struct AgentDev {
 
 constexpr int PART_STRIDE = 8;   // doubles per block of partials
 constexpr int MAX_PART = 4096;   // max blocks contributing partials
+// regions of AgentDev::part (each MAX_PART * PART_STRIDE doubles)
+constexpr int PART_A = 0;                             // SpMM-type kernels (eval / Hess-vec)
+constexpr int PART_B = MAX_PART * PART_STRIDE;        // preconditioner-type kernels
+constexpr int PART_C = 2 * MAX_PART * PART_STRIDE;    // outer-step / initial evaluation
+constexpr int PART_D = 3 * MAX_PART * PART_STRIDE;    // per-pose kernels: |X - XPrev|^2 partials
+constexpr int PART_TOTAL = 4 * MAX_PART * PART_STRIDE;
 
 struct TeamDev {
   int num_agents;
   int sched_len;
   int iter;          // global iteration counter (device copy)
   int restart_interval;
+  int cur_sel;       // agent selected in the running iteration (published by the first kernel)
+  int pad;
   const int *sched;  // [sched_len] local agent index selected at iteration k % sched_len
 };
 

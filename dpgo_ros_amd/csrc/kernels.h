@@ -12,12 +12,23 @@ struct LaunchCtx {
   TeamDev *team;           // device
 };
 
+// preconditioner kernel modes (see kernels.hip)
+constexpr int PM_PLAIN_ = 0, PM_TCG_INIT_ = 1, PM_TCG_STEP_ = 2, PM_RGD_ = 3;
+
+struct EvalOpts {
+  int gmode = 0;    // 0 G from buffer, 1 assemble from slab, 2 assemble pulling from co-resident agents
+  int aux = 0;      // neighbour sequence for G assembly: 0 X, 1 auxiliary Y
+  int advance = 0;  // fold the end-of-iteration bookkeeping of the whole team into this launch
+  int accel = 0, num_robots = 1, restart_interval = 1;
+};
+
 // `sel`: local agent index, or -1 = the agent the device-side schedule selects this iteration
 void launch_buildG(const LaunchCtx &c, int sel, int max_npub, int aux, int pull);
 void launch_pull(const LaunchCtx &c, int dst, int nshared);
-void launch_eval(const LaunchCtx &c, int sel, int max_n, int xb, int egb, int gfb, int poff);
+void launch_eval(const LaunchCtx &c, int sel, int max_n, int xb, int egb, int gfb, int poff, const EvalOpts &o);
 void launch_hess(const LaunchCtx &c, int sel, int max_n, int xb, int egb, int vb, int ob, int poff);
-void launch_precond(const LaunchCtx &c, int sel, int max_n, int mode, int xb, int vb, int zb, int sp, int max_inner);
+void launch_precond(const LaunchCtx &c, int sel, int max_n, int mode, int xb, int vb, int zb, int sp, int max_inner,
+                    double step, int accel, int num_robots);
 void launch_tcg_hv(const LaunchCtx &c, int sel, int max_n, int sp, int max_inner);
 void launch_retract(const LaunchCtx &c, int sel, int max_n, int xb, int eb, double scale, int ob, int guard_state);
 void launch_project_raw(const LaunchCtx &c, const double *X, double *out, int n);
@@ -29,7 +40,7 @@ void launch_nest_post(const LaunchCtx &c, int sel, int max_n, int num_robots, in
 void launch_nest_reset(const LaunchCtx &c, int sel, int max_n);
 void launch_advance(const LaunchCtx &c, int only_agent, int num_agents, int accel, int num_robots, int restart_interval,
                     int bump_team);
-void launch_status(const LaunchCtx &c, int sel, int only_agent, int num_agents, int stat_off, int poff);
+void launch_status(const LaunchCtx &c, int sel, int only_agent, int num_agents, int max_n);
 void launch_rtr_begin(const LaunchCtx &c, int sel, double Delta0, double tol, int max_outer);
 void launch_rtr_eval2(const LaunchCtx &c, int sel, int max_n, int sp);
 void launch_rtr_accept(const LaunchCtx &c, int sel, int max_n, int sp, double tol, int max_outer, double max_radius);
@@ -37,16 +48,10 @@ void launch_pack(const LaunchCtx &c, const double *X, const int *frames, int cou
 void launch_unpack(const LaunchCtx &c, double *slab, const int *slots, int count, const double *in);
 void launch_residuals(const LaunchCtx &c, int ai, int nedges);
 void launch_cost(const LaunchCtx &c, int ai);
-
-void launch_copy(const LaunchCtx &c, int sel, int only_agent, int num_agents, int max_n, int from, int to);
+void launch_noop(const LaunchCtx &c, int grid, int block);
+void launch_copy(const LaunchCtx &c, int sel, int only_agent, int num_agents, int max_n, int from, int to, int publish);
 void launch_bsr_to_dense(hipStream_t s, const int *rowptr, const int *col, const double *qval, int n, double shift,
                          double *A);
-
-constexpr int PM_PLAIN_ = 0, PM_TCG_INIT_ = 1, PM_TCG_STEP_ = 2;
-constexpr int PART_A = 0;
-constexpr int PART_B = MAX_PART * PART_STRIDE;
-constexpr int PART_C = 2 * MAX_PART * PART_STRIDE;
-constexpr int PART_TOTAL = 3 * MAX_PART * PART_STRIDE;
 
 // dense_inverse.hip: M = (A)^-1 for a symmetric positive definite N x N column-major matrix.
 // A is destroyed; work must hold N*N doubles.  Returns 0, or the (1-based) failing pivot block.

@@ -9,10 +9,12 @@
 //   a7  pack/unpack of public-pose slabs                 (:662-690, :1255-1284)
 //   a8  per-edge residuals                               (:1049)
 //
-// Layout: X is r x 4n column-major (pose = 4r contiguous doubles).  Q is block-CSR with 4x4
-// column-major blocks, row j lists (i, Q_ij) so (XQ)_j = sum_i X_i Q_ij.  One lane owns one
-// (pose, row a) pair: a 64-wide wave covers floor(64/R) poses; the 4x4 block is a wave-broadcast
-// load, the pose rows are 32-byte strided loads inside one 160-byte pose record.
+// Layout: X is r x 4n column-major (pose = 4r contiguous doubles).  Q is stored twice: block-CSR
+// (row j lists (i, Q_ij), (XQ)_j = sum_i X_i Q_ij) for assembly/read-back, and slot-major ELL
+// (+ CSR tail for long rows) for the SpMM kernels, so that the column indices and the 4x4 blocks of
+// a row are fetched with loads that do not depend on each other (the operands are L2/MALL resident;
+// what bounds these kernels is the number of dependent round trips, not bytes).  One lane owns one
+// (pose, row a) pair: a 64-wide wave covers floor(64/R) poses.
 // Scalars of the inner solve (dots, alpha, beta, rho, radius) never visit the host: every
 // workgroup re-derives them from the same per-block partial sums in the same order, and
 // workgroup 0 publishes the next state into the other half of a ping-pong pair.
@@ -22,52 +24,84 @@
 
 namespace dpgo {
 
-__device__ __forceinline__ const AgentDev &pick(const AgentDev *agents, const TeamDev *team, int sel) {
-  const int idx = sel >= 0 ? sel : team->sched[team->iter % team->sched_len];
-  return agents[idx];
-}
-__device__ __forceinline__ int pick_idx(const TeamDev *team, int sel) {
+// agent selection.  First kernel of an iteration: from the device-side schedule (and it publishes
+// team->cur_sel); every later kernel: team->cur_sel, so that the last kernel may advance team->iter.
+__device__ __forceinline__ int sel_sched(const TeamDev *team, int sel) {
   return sel >= 0 ? sel : team->sched[team->iter % team->sched_len];
 }
-
-constexpr int PA_OFF = 0;                            // partials of spmm-type kernels
-constexpr int PB_OFF = MAX_PART * PART_STRIDE;       // partials of precond-type kernels
-constexpr int PC_OFF = 2 * MAX_PART * PART_STRIDE;   // partials of the outer-step evaluation
+__device__ __forceinline__ int sel_cur(const TeamDev *team, int sel) { return sel >= 0 ? sel : team->cur_sel; }
 
 template <int R>
 __device__ __forceinline__ int spmm_blocks(int n) { return (n + (64 / R) - 1) / (64 / R); }
 __device__ __forceinline__ int precond_blocks(int N4) { return (N4 + 7) / 8; }
 
-// acc[c] += sum_i sum_cp src(i, cp) * Q_ij[cp, c]   for output pose j, row a
-template <int R, class Src>
-__device__ __forceinline__ void spmm_row(const AgentDev &ag, int j, Src src, double acc[4]) {
-  const int p0 = ag.rowptr[j], p1 = ag.rowptr[j + 1];
+__device__ __forceinline__ double2 ld2(const double *p) { return *reinterpret_cast<const double2 *>(p); }
+typedef double v2d_t __attribute__((ext_vector_type(2)));
+#ifndef DPGO_M_NT
+#define DPGO_M_NT 1
+#endif
+__device__ __forceinline__ double2 ld2_nt(const double *p) {
+#if DPGO_M_NT
+  const v2d_t v = __builtin_nontemporal_load(reinterpret_cast<const v2d_t *>(p));
+  return make_double2(v.x, v.y);
+#else
+  return *reinterpret_cast<const double2 *>(p);
+#endif
+}
+
+// one group of up to 4 ELL slots: every index/block load is issued before the first use
+template <int R, int NV, class Src>
+__device__ __forceinline__ void ell_group(const AgentDev &ag, int j, int slot0, Src src, double (*acc)[4]) {
+  const int W = ag.ell_w, n = ag.n;
+  int idx[4];
+  double2 B[4][8];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const bool valid = slot0 + u < W;
+    idx[u] = valid ? ag.ell_col[(size_t)(slot0 + u) * n + j] : j;
+    const double *bp = ag.ell_val + ((size_t)(valid ? slot0 + u : 0) * n + j) * 16;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) B[u][q] = valid ? ld2(bp + 2 * q) : make_double2(0.0, 0.0);
+  }
+  double x[4][NV][4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) src(idx[u], x[u]);
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        acc[v][c] += x[u][v][0] * B[u][2 * c].x + x[u][v][1] * B[u][2 * c].y + x[u][v][2] * B[u][2 * c + 1].x +
+                     x[u][v][3] * B[u][2 * c + 1].y;
+}
+
+// acc[v][c] += sum_i sum_cp src_v(i, cp) * Q_ij[cp, c]   for output pose j, row a; NV vectors at once
+template <int R, int NV, class Src>
+__device__ __forceinline__ void spmm_row(const AgentDev &ag, int j, Src src, double (*acc)[4]) {
+  ell_group<R, NV>(ag, j, 0, src, acc);
+  if (ag.ell_w > 4) ell_group<R, NV>(ag, j, 4, src, acc);
+  const int p0 = ag.trowptr[j], p1 = ag.trowptr[j + 1];
   for (int p = p0; p < p1; ++p) {
-    const int i = ag.col[p];
-    const double2 *B = reinterpret_cast<const double2 *>(ag.qval + (size_t)16 * p);
-    double x[4];
+    const int i = ag.tcol[p];
+    const double *bp = ag.tval + (size_t)16 * p;
+    double x[NV][4];
     src(i, x);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const double2 b01 = B[2 * c], b23 = B[2 * c + 1];
-      acc[c] += x[0] * b01.x + x[1] * b01.y + x[2] * b23.x + x[3] * b23.y;
-    }
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const double2 b01 = ld2(bp + 4 * c), b23 = ld2(bp + 4 * c + 2);
+        acc[v][c] += x[v][0] * b01.x + x[v][1] * b01.y + x[v][2] * b23.x + x[v][3] * b23.y;
+      }
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// G assembly (a2).  One lane per (public pose, row a).  pull != 0: read the neighbour's pose
-// straight from the neighbour agent's X / Y array on this GPU (device-to-device exchange that
-// replaces the PublicPoses topic) and refresh the slab; else read the slab filled by unpack.
+// G_j row a from the shared edges of public pose index q (a2)
 template <int R>
-__global__ __launch_bounds__(64) void k_buildG(const AgentDev *agents, const TeamDev *team, int sel, int aux,
-                                               int pull) {
-  const AgentDev &ag = pick(agents, team, sel);
-  constexpr int PPB = 64 / R;
-  const int lane = threadIdx.x, lp = lane / R, a = lane - lp * R;
-  const int q = blockIdx.x * PPB + lp;
-  if (lp >= PPB || q >= ag.npub) return;
-  double acc[4] = {0, 0, 0, 0};
+__device__ __forceinline__ void g_row(const AgentDev *agents, const AgentDev &ag, int q, int a, int aux, int pull,
+                                      double g[4]) {
+  g[0] = g[1] = g[2] = g[3] = 0.0;
   for (int e = ag.pub_ptr[q]; e < ag.pub_ptr[q + 1]; ++e) {
     const SharedEdgeDev &se = ag.se[e];
     double *slab = ag.nbr[aux] + (size_t)se.slot * 4 * R;
@@ -83,11 +117,27 @@ __global__ __launch_bounds__(64) void k_buildG(const AgentDev *agents, const Tea
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
-      for (int cp = 0; cp < 4; ++cp) acc[c] -= x[cp] * se.coef[cp + 4 * c];
+      for (int cp = 0; cp < 4; ++cp) g[c] -= x[cp] * se.coef[cp + 4 * c];
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// stand-alone G assembly.  One lane per (public pose, row a).  pull != 0: read the neighbour's pose
+// straight from the neighbour agent's X / Y array on this GPU (device-to-device exchange that
+// replaces the PublicPoses topic) and refresh the slab; else read the slab filled by unpack.
+template <int R>
+__global__ __launch_bounds__(64) void k_buildG(const AgentDev *agents, const TeamDev *team, int sel, int aux,
+                                               int pull) {
+  const AgentDev &ag = agents[sel_cur(team, sel)];
+  constexpr int PPB = 64 / R;
+  const int lane = threadIdx.x, lp = lane / R, a = lane - lp * R;
+  const int q = blockIdx.x * PPB + lp;
+  if (lp >= PPB || q >= ag.npub) return;
+  double g[4];
+  g_row<R>(agents, ag, q, a, aux, pull, g);
   double *G = ag.buf[B_G] + (size_t)ag.pub_pose[q] * 4 * R;
 #pragma unroll
-  for (int c = 0; c < 4; ++c) G[c * R + a] = acc[c];
+  for (int c = 0; c < 4; ++c) G[c * R + a] = g[c];
 }
 
 // refresh every slab entry of one agent from co-resident neighbours (both sequences)
@@ -104,33 +154,69 @@ __global__ void k_pull(const AgentDev *agents, int dst) {
   ag.nbr[1][(size_t)se.slot * 4 * R + k] = sa.buf[B_Y][(size_t)se.src_frame * 4 * R + k];
 }
 
+// end of an iteration: advance gamma/alpha/iter of one agent
+__device__ __forceinline__ void advance_agent(const AgentDev &ag, int accel, int num_robots, int restart_interval) {
+  NestState ns = *ag.nest;
+  if (accel) {
+    const double Nr = (double)num_robots;
+    const bool restart = ((ns.iter + 2) % restart_interval) == 0;
+    if (restart) { ns.gamma = 0; ns.alpha = 0; }
+    else {
+      ns.gamma = (1.0 + sqrt(1.0 + 4.0 * Nr * Nr * ns.gamma * ns.gamma)) / (2.0 * Nr);
+      ns.alpha = 1.0 / (ns.gamma * Nr);
+    }
+  }
+  ns.iter += 1;
+  *ag.nest = ns;
+}
+
 // ------------------------------------------------------------------------------------------------
 // f, Euclidean gradient, Riemannian gradient (a3).  partials: [0] f, [1] |rgrad|^2
+// gmode: 0 G from the buffer, 1 assemble G from the slab, 2 assemble G pulling from co-resident
+// agents (both also store G).  advance: fold the end-of-iteration bookkeeping of the whole team
+// into workgroup 0 (this kernel reads neither team->iter nor the Nesterov state).
 template <int R>
-__global__ __launch_bounds__(64) void k_eval(const AgentDev *agents, const TeamDev *team, int sel, int xb, int egb,
-                                             int gfb, int poff) {
-  const AgentDev &ag = pick(agents, team, sel);
+__global__ __launch_bounds__(64) void k_eval(const AgentDev *agents, TeamDev *team, int sel, int xb, int egb, int gfb,
+                                             int poff, int gmode, int aux, int advance, int accel, int num_robots,
+                                             int restart_interval) {
+  const AgentDev &ag = agents[sel_cur(team, sel)];
   constexpr int PPB = 64 / R;
   __shared__ double Ysh[PPB * 4 * R], Wsh[PPB * 4 * R];
   const int lane = threadIdx.x, lp = lane / R, a = lane - lp * R;
   const int j = blockIdx.x * PPB + lp;
+  if (advance && blockIdx.x == 0 && lane == 0) {
+    for (int k = 0; k < team->num_agents; ++k) advance_agent(agents[k], accel, num_robots, restart_interval);
+    team->iter += 1;
+  }
   if (blockIdx.x * PPB >= ag.n) return;
   const bool act = lp < PPB && j < ag.n;
   const double *X = ag.buf[xb];
   double fpart = 0, gpart = 0, eg3 = 0;
   if (act) {
-    double acc[4] = {0, 0, 0, 0};
-    spmm_row<R>(ag, j, [&](int i, double x[4]) {
+    double acc[1][4] = {{0, 0, 0, 0}};
+    spmm_row<R, 1>(ag, j, [&](int i, double(*x)[4]) {
 #pragma unroll
-      for (int cp = 0; cp < 4; ++cp) x[cp] = X[((size_t)4 * i + cp) * R + a];
+      for (int cp = 0; cp < 4; ++cp) x[0][cp] = X[((size_t)4 * i + cp) * R + a];
     }, acc);
-    const double *G = ag.buf[B_G] + (size_t)j * 4 * R;
+    double g[4] = {0, 0, 0, 0};
+    const int q = ag.pub_index[j];
+    double *Gj = ag.buf[B_G] + (size_t)j * 4 * R;
+    if (q >= 0) {
+      if (gmode == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) g[c] = Gj[c * R + a];
+      } else {
+        g_row<R>(agents, ag, q, a, aux, gmode == 2, g);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) Gj[c * R + a] = g[c];
+      }
+    }
     double *EG = ag.buf[egb] + (size_t)j * 4 * R;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const double xr = X[((size_t)4 * j + c) * R + a], g = G[c * R + a];
-      fpart += (0.5 * acc[c] + g) * xr;
-      const double eg = acc[c] + g;
+      const double xr = X[((size_t)4 * j + c) * R + a];
+      fpart += (0.5 * acc[0][c] + g[c]) * xr;
+      const double eg = acc[0][c] + g[c];
       EG[c * R + a] = eg;
       Ysh[lp * 4 * R + c * R + a] = xr;
       Wsh[lp * 4 * R + c * R + a] = eg;
@@ -193,7 +279,7 @@ __device__ __forceinline__ void hess_tail(const double *Ysh, const double *Esh, 
 template <int R>
 __global__ __launch_bounds__(64) void k_hess(const AgentDev *agents, const TeamDev *team, int sel, int xb, int egb,
                                              int vb, int ob, int poff) {
-  const AgentDev &ag = pick(agents, team, sel);
+  const AgentDev &ag = agents[sel_cur(team, sel)];
   constexpr int PPB = 64 / R;
   __shared__ double Ysh[PPB * 4 * R], Esh[PPB * 4 * R], Wsh[PPB * 4 * R];
   const int lane = threadIdx.x, lp = lane / R, a = lane - lp * R;
@@ -201,12 +287,12 @@ __global__ __launch_bounds__(64) void k_hess(const AgentDev *agents, const TeamD
   if (blockIdx.x * PPB >= ag.n) return;
   const bool act = lp < PPB && j < ag.n;
   const double *V = ag.buf[vb];
-  double wrow[4] = {0, 0, 0, 0}, vrow[4] = {0, 0, 0, 0}, hrow[4];
+  double w[1][4] = {{0, 0, 0, 0}}, vrow[4] = {0, 0, 0, 0}, hrow[4];
   if (act) {
-    spmm_row<R>(ag, j, [&](int i, double x[4]) {
+    spmm_row<R, 1>(ag, j, [&](int i, double(*x)[4]) {
 #pragma unroll
-      for (int cp = 0; cp < 4; ++cp) x[cp] = V[((size_t)4 * i + cp) * R + a];
-    }, wrow);
+      for (int cp = 0; cp < 4; ++cp) x[0][cp] = V[((size_t)4 * i + cp) * R + a];
+    }, w);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       vrow[c] = V[((size_t)4 * j + c) * R + a];
@@ -215,7 +301,7 @@ __global__ __launch_bounds__(64) void k_hess(const AgentDev *agents, const TeamD
     }
   }
   __syncthreads();
-  hess_tail<R>(Ysh + lp * 4 * R, Esh + lp * 4 * R, Wsh + lp * 4 * R, a, wrow, vrow, hrow, act);
+  hess_tail<R>(Ysh + lp * 4 * R, Esh + lp * 4 * R, Wsh + lp * 4 * R, a, w[0], vrow, hrow, act);
   double d = 0;
   if (act) {
     double *O = ag.buf[ob] + (size_t)j * 4 * R;
@@ -228,22 +314,28 @@ __global__ __launch_bounds__(64) void k_hess(const AgentDev *agents, const TeamD
 
 // ------------------------------------------------------------------------------------------------
 // Dense preconditioner apply  z = P_X( v (Q + shift I)^-1 )  (a3 PreConditioner).
-// Workgroup = 256 threads = 8 scalar columns (2 poses) x 32 k-lanes; the input vector is staged in
-// LDS as SoA [a][k] in chunks so that M (the only large operand, N4^2 doubles) is streamed exactly
-// once with 16-byte coalesced loads.  Modes:
+// Workgroup = 256 threads = 8 scalar columns (2 poses) x 32 k-lanes.  M (the only large operand,
+// N4^2 doubles, streamed exactly once, non-temporal so it does not evict the small operands from
+// L2) is fetched with 16-byte coalesced loads that are ALL issued before the first use: one memory
+// round trip per 2048-row chunk.  The input vector is staged in LDS as SoA [a][k].  Modes:
 //   PM_PLAIN    v = buf[vb]                        -> buf[zb]            partials [0]<z,v> [1]<v,v>
 //   PM_TCG_INIT v = gf; r0 = gf; eta = 0; d0 = -z  (tCG set-up, RtrState ping-pong)
 //   PM_TCG_STEP v = r_old + alpha Hd (on the fly), eta += alpha d, z = P(v M)   (tCG body, part 2)
-enum { PM_PLAIN = 0, PM_TCG_INIT = 1, PM_TCG_STEP = 2 };
-constexpr int KC = 1024;  // scalars of the input vector staged per chunk (KC * R * 8 bytes of LDS)
+//   PM_RGD      v = gf; X <- Retr_X(-step z); [V <- proj(V + gamma (X - Y))]; partial [2] |X - XPrev|^2
+//               (the whole RGD step + Nesterov V update of the two poses this workgroup owns)
+constexpr int KC = 2048;       // scalars of the input vector staged per chunk (KC * R * 8 bytes of LDS)
+constexpr int MREG = KC / 64;  // double2 registers per thread per chunk
+constexpr int KCP = KC + 4;    // LDS row pitch: 8*a + 2*k distinct banks for the transposing fill (no 5-way conflict)
 
 template <int R, int MODE>
 __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, const TeamDev *team, int sel, int xb, int vb,
-                                                 int zb, int sp, int max_inner) {
-  const AgentDev &ag = pick(agents, team, sel);
-  __shared__ double vs[R * KC];
+                                                 int zb, int sp, int max_inner, double step, int accel,
+                                                 int num_robots) {
+  const AgentDev &ag = agents[sel_cur(team, sel)];
+  __shared__ double vs[R * KCP];
   __shared__ double zs[8 * R];
   __shared__ double Ysh[2 * 4 * R];
+  __shared__ double Esh[3][2 * 4 * R];  // PM_RGD: V, Yaux, XPrev of the two poses
   const int tid = threadIdx.x, lane = tid & 63;
   const int N4 = ag.N4;
   const int nblk = precond_blocks(N4);
@@ -254,15 +346,15 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, const T
   int jpar = 0;
   bool boundary = false;
   RtrState S;
-  if (MODE != PM_PLAIN) {
+  if (MODE == PM_TCG_INIT_ || MODE == PM_TCG_STEP_) {
     S = ag.st[sp];
-    const bool idle = S.outer_done || (MODE == PM_TCG_STEP && !S.tcg_active);
+    const bool idle = S.outer_done || (MODE == PM_TCG_STEP_ && !S.tcg_active);
     if (idle) {
       if (blockIdx.x == 0 && tid == 0) ag.st[sp ^ 1] = S;
       return;
     }
-    if (MODE == PM_TCG_STEP) {
-      const double d_Hd = sum_partials(ag.part + PA_OFF, spmm_blocks<R>(ag.n), PART_STRIDE, lane);
+    if (MODE == PM_TCG_STEP_) {
+      const double d_Hd = sum_partials(ag.part + PART_A, spmm_blocks<R>(ag.n), PART_STRIDE, lane);
       alpha = S.z_r / d_Hd;
       const double e_Pe_new = S.e_Pe + 2.0 * alpha * S.e_Pd + alpha * alpha * S.d_Pd;
       jpar = S.tcg_j & 1;
@@ -293,12 +385,13 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, const T
     }
   }
 
-  const double *Vin = (MODE == PM_PLAIN) ? ag.buf[vb] : (MODE == PM_TCG_INIT ? ag.buf[B_GF] : ag.buf[jpar ? B_R1 : B_R0]);
+  const double *Vin = (MODE == PM_PLAIN_) ? ag.buf[vb]
+                      : ((MODE == PM_TCG_INIT_ || MODE == PM_RGD_) ? ag.buf[B_GF] : ag.buf[jpar ? B_R1 : B_R0]);
   const double *Hd = ag.buf[B_HD];
   const int col0 = 8 * blockIdx.x;
   const int npose = min(2, ag.n - 2 * (int)blockIdx.x);
 
-  if (MODE == PM_TCG_STEP) {
+  if (MODE == PM_TCG_STEP_) {
     // eta += (alpha | tau) * delta on the two poses owned by this workgroup
     const double *D = ag.buf[jpar ? B_D1 : B_D0];
     double *E = ag.buf[B_ETA];
@@ -318,24 +411,81 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, const T
 #pragma unroll
   for (int a = 0; a < R; ++a) acc[a] = 0;
 
+  constexpr int NSTG = (KC * R / 2 + 255) / 256;  // staged 16-byte pairs per lane per chunk
+#ifndef DPGO_PC_ORDER
+#define DPGO_PC_ORDER 0
+#endif
   for (int k0 = 0; k0 < N4; k0 += KC) {
     const int kn = min(KC, N4 - k0);
-    __syncthreads();
-    for (int t = tid; t < kn * R; t += 256) {
-      const int k = t / R, a = t - k * R;
-      double v = Vin[(size_t)(k0 + k) * R + a];
-      if (MODE == PM_TCG_STEP) v += alpha * Hd[(size_t)(k0 + k) * R + a];
-      vs[a * KC + k] = v;
+    double2 mreg[MREG];
+    if constexpr (DPGO_PC_ORDER != 0 && NSTG + MREG <= 60) {
+      // every load of the chunk is issued back to back (vmcnt holds <= 64): the M slab and the input
+      // vector (16-byte pairs) return as one stream; a single wait, then LDS fill and FMAs.
+      double2 v[NSTG];
+      if (DPGO_PC_ORDER == 2) {
+#pragma unroll
+        for (int m = 0; m < MREG; ++m) {
+          const int k = 2 * kl + 64 * m;
+          mreg[m] = (cact && k < kn) ? ld2_nt(Mc + k0 + k) : make_double2(0.0, 0.0);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < NSTG; ++u) {
+        const int tt = 2 * (tid + 256 * u);  // kn * R is even
+        v[u] = (tt < kn * R) ? ld2(Vin + (size_t)k0 * R + tt) : make_double2(0.0, 0.0);
+        if (MODE == PM_TCG_STEP_ && tt < kn * R) {
+          const double2 h = ld2(Hd + (size_t)k0 * R + tt);
+          v[u].x += alpha * h.x; v[u].y += alpha * h.y;
+        }
+      }
+      if (DPGO_PC_ORDER == 1) {
+#pragma unroll
+        for (int m = 0; m < MREG; ++m) {
+          const int k = 2 * kl + 64 * m;
+          mreg[m] = (cact && k < kn) ? ld2_nt(Mc + k0 + k) : make_double2(0.0, 0.0);
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < NSTG; ++u) {
+        const int tt = 2 * (tid + 256 * u);
+        if (tt < KC * R) {
+          const int k = tt / R, a = tt - k * R;
+          vs[a * KCP + k] = v[u].x;
+          const int k1 = (tt + 1) / R, a1 = (tt + 1) - k1 * R;
+          vs[a1 * KCP + k1] = v[u].y;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int m = 0; m < MREG; ++m) {
+        const int k = 2 * kl + 64 * m;
+        mreg[m] = (cact && k < kn) ? ld2_nt(Mc + k0 + k) : make_double2(0.0, 0.0);
+      }
+      __syncthreads();
+      for (int t0 = tid; t0 < KC * R; t0 += 256 * 8) {  // 8 independent loads in flight per lane
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int tt = t0 + 256 * u;
+          v[u] = (tt < kn * R) ? Vin[(size_t)k0 * R + tt] : 0.0;
+          if (MODE == PM_TCG_STEP_ && tt < kn * R) v[u] += alpha * Hd[(size_t)k0 * R + tt];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int tt = t0 + 256 * u;
+          if (tt < KC * R) { const int k = tt / R, a = tt - k * R; vs[a * KCP + k] = v[u]; }
+        }
+      }
     }
     __syncthreads();
-    if (cact) {
-      for (int k = 2 * kl; k < kn; k += 64) {
-        const double2 m = *reinterpret_cast<const double2 *>(Mc + k0 + k);
 #pragma unroll
-        for (int a = 0; a < R; ++a) {
-          const double2 v = *reinterpret_cast<const double2 *>(&vs[a * KC + k]);
-          acc[a] += v.x * m.x + v.y * m.y;
-        }
+    for (int m = 0; m < MREG; ++m) {
+      const int k = 2 * kl + 64 * m;
+#pragma unroll
+      for (int a = 0; a < R; ++a) {
+        const double2 v = *reinterpret_cast<const double2 *>(&vs[a * KCP + k]);
+        acc[a] += v.x * mreg[m].x + v.y * mreg[m].y;
       }
     }
   }
@@ -348,8 +498,53 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, const T
 #pragma unroll
     for (int a = 0; a < R; ++a) zs[cg * R + a] = acc[a];
   }
-  if (tid < npose * 4 * R) Ysh[tid] = ag.buf[xb][(size_t)col0 * R + tid];
+  if (tid < npose * 4 * R) {
+    Ysh[tid] = ag.buf[xb][(size_t)col0 * R + tid];
+    if (MODE == PM_RGD_) {
+      Esh[0][tid] = ag.buf[B_V][(size_t)col0 * R + tid];
+      Esh[1][tid] = ag.buf[B_Y][(size_t)col0 * R + tid];
+      Esh[2][tid] = ag.buf[B_XPREV][(size_t)col0 * R + tid];
+    }
+  }
   __syncthreads();
+
+  if (MODE == PM_RGD_) {
+    // one lane per pose finishes the step in registers: z = P(zs), X = qf(X - step z), V update
+    double rel = 0;
+    if (tid < npose) {
+      const int lp = tid;
+      const size_t o = (size_t)(2 * blockIdx.x + lp) * 4 * R;
+      double x[4 * R], z[4 * R];
+#pragma unroll
+      for (int i = 0; i < 4 * R; ++i) { x[i] = Ysh[lp * 4 * R + i]; z[i] = zs[lp * 4 * R + i]; }
+      tangent_inplace<R>(x, z);
+#pragma unroll
+      for (int i = 0; i < 4 * R; ++i) x[i] -= step * z[i];
+      qf_inplace<R>(x);
+#pragma unroll
+      for (int i = 0; i < 4 * R; ++i) {
+        ag.buf[B_X][o + i] = x[i];
+        const double d = x[i] - Esh[2][lp * 4 * R + i];
+        rel += d * d;
+      }
+      if (accel) {
+        const NestState ns = *ag.nest;
+        const double Nr = (double)num_robots;
+        const double gamma = (1.0 + sqrt(1.0 + 4.0 * Nr * Nr * ns.gamma * ns.gamma)) / (2.0 * Nr);
+        double v[4 * R];
+#pragma unroll
+        for (int i = 0; i < 4 * R; ++i) v[i] = Esh[0][lp * 4 * R + i] + gamma * (x[i] - Esh[1][lp * 4 * R + i]);
+        polar_inplace<R>(v);
+#pragma unroll
+        for (int i = 0; i < 4 * R; ++i) ag.buf[B_V][o + i] = v[i];
+      }
+    }
+    if (tid < 64) {
+      rel = wave_sum(rel);
+      if (tid == 0) ag.part[PART_B + (size_t)blockIdx.x * PART_STRIDE + 2] = rel;
+    }
+    return;
+  }
 
   // ---- epilogue: tangent projection of the two poses, dots, mode-specific stores
   double zr = 0, rr = 0;
@@ -359,15 +554,15 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, const T
     double z[4];
     tangent_row<R>(Ysh + lp * 4 * R, zs + lp * 4 * R, a, z);
     z[3] = zs[lp * 4 * R + 3 * R + a];
-    double *Z = ag.buf[(MODE == PM_PLAIN) ? zb : B_Z];
+    double *Z = ag.buf[(MODE == PM_PLAIN_) ? zb : B_Z];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       double v = Vin[o + c * R + a];
-      if (MODE == PM_TCG_STEP) {
+      if (MODE == PM_TCG_STEP_) {
         v += alpha * Hd[o + c * R + a];
         ag.buf[jpar ? B_R0 : B_R1][o + c * R + a] = v;  // r_new into the other half
       }
-      if (MODE == PM_TCG_INIT) {
+      if (MODE == PM_TCG_INIT_) {
         ag.buf[B_R0][o + c * R + a] = v;
         ag.buf[B_ETA][o + c * R + a] = 0.0;
         ag.buf[B_D0][o + c * R + a] = -z[c];
@@ -381,7 +576,7 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, const T
     zr = wave_sum(zr);
     rr = wave_sum(rr);
     if (tid == 0) {
-      double *P = ag.part + PB_OFF + (size_t)blockIdx.x * PART_STRIDE;
+      double *P = ag.part + PART_B + (size_t)blockIdx.x * PART_STRIDE;
       P[0] = zr; P[1] = rr;
     }
   }
@@ -392,7 +587,7 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, const T
 template <int R>
 __global__ __launch_bounds__(64) void k_tcg_hv(const AgentDev *agents, const TeamDev *team, int sel, int sp,
                                                int max_inner) {
-  const AgentDev &ag = pick(agents, team, sel);
+  const AgentDev &ag = agents[sel_cur(team, sel)];
   constexpr int PPB = 64 / R;
   __shared__ double Ysh[PPB * 4 * R], Esh[PPB * 4 * R], Wsh[PPB * 4 * R];
   const int lane = threadIdx.x, lp = lane / R, a = lane - lp * R;
@@ -405,8 +600,8 @@ __global__ __launch_bounds__(64) void k_tcg_hv(const AgentDev *agents, const Tea
   }
   const double theta = 1.0, kappa = 0.1;
   const int npb = precond_blocks(ag.N4);
-  const double zr_new = sum_partials(ag.part + PB_OFF, npb, PART_STRIDE, lane);
-  const double rr_new = sum_partials(ag.part + PB_OFF + 1, npb, PART_STRIDE, lane);
+  const double zr_new = sum_partials(ag.part + PART_B, npb, PART_STRIDE, lane);
+  const double rr_new = sum_partials(ag.part + PART_B + 1, npb, PART_STRIDE, lane);
   RtrState T = S;
   double beta = 0;
   const bool fresh = (S.tcg_j == 0);
@@ -437,15 +632,15 @@ __global__ __launch_bounds__(64) void k_tcg_hv(const AgentDev *agents, const Tea
   const double *Dold = ag.buf[jp ? B_D0 : B_D1];  // delta of iteration j-1
   double *Dnew = ag.buf[jp ? B_D1 : B_D0];        // delta of iteration j (T0 wrote D0 for j = 0)
   const double *Z = ag.buf[B_Z];
-  double wrow[4] = {0, 0, 0, 0}, vrow[4] = {0, 0, 0, 0}, hrow[4];
+  double w[1][4] = {{0, 0, 0, 0}}, vrow[4] = {0, 0, 0, 0}, hrow[4];
   if (act) {
-    spmm_row<R>(ag, j, [&](int i, double x[4]) {
+    spmm_row<R, 1>(ag, j, [&](int i, double(*x)[4]) {
 #pragma unroll
       for (int cp = 0; cp < 4; ++cp) {
         const size_t o = ((size_t)4 * i + cp) * R + a;
-        x[cp] = fresh ? Dnew[o] : (-Z[o] + beta * Dold[o]);
+        x[0][cp] = fresh ? Dnew[o] : (-Z[o] + beta * Dold[o]);
       }
-    }, wrow);
+    }, w);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const size_t o = ((size_t)4 * j + c) * R + a;
@@ -456,7 +651,7 @@ __global__ __launch_bounds__(64) void k_tcg_hv(const AgentDev *agents, const Tea
     }
   }
   __syncthreads();
-  hess_tail<R>(Ysh + lp * 4 * R, Esh + lp * 4 * R, Wsh + lp * 4 * R, a, wrow, vrow, hrow, act);
+  hess_tail<R>(Ysh + lp * 4 * R, Esh + lp * 4 * R, Wsh + lp * 4 * R, a, w[0], vrow, hrow, act);
   double d = 0;
   if (act) {
     double *O = ag.buf[B_HD] + (size_t)j * 4 * R;
@@ -464,70 +659,107 @@ __global__ __launch_bounds__(64) void k_tcg_hv(const AgentDev *agents, const Tea
     for (int c = 0; c < 4; ++c) { O[c * R + a] = hrow[c]; d += vrow[c] * hrow[c]; }
   }
   d = wave_sum(d);
-  if (lane == 0) ag.part[PA_OFF + (size_t)blockIdx.x * PART_STRIDE] = d;
+  if (lane == 0) ag.part[PART_A + (size_t)blockIdx.x * PART_STRIDE] = d;
 }
 
 // ------------------------------------------------------------------------------------------------
-// per-pose kernels: one lane per pose, the whole pose in registers
+// per-pose kernels: one lane per pose with the whole pose in registers.  A 64-pose tile (64 * 4R
+// contiguous doubles) moves between HBM and registers through LDS so that every global access is a
+// fully coalesced 512-byte wave transaction instead of 64 strided 8-byte ones.
 template <int R>
-__device__ __forceinline__ void load_pose(const double *p, double *v) {
+struct Tile {
+  static constexpr int P = 4 * R + 1;  // odd pitch: conflict-free row access
+  double d[64 * P];
+};
+// 64 lanes x 4R elements = exactly one tile: fixed trip count, every load issued before the first
+// LDS store (a runtime-bounded loop makes the compiler wait for each load in turn)
+template <int R>
+__device__ __forceinline__ void tile_in(Tile<R> &t, const double *g, int j0, int cnt, int tid) {
+  const double *src = g + (size_t)j0 * 4 * R;
+  const int total = cnt * 4 * R;
+  double tmp[4 * R];
 #pragma unroll
-  for (int i = 0; i < 4 * R; ++i) v[i] = p[i];
+  for (int k = 0; k < 4 * R; ++k) {
+    const int e = tid + 64 * k;
+    tmp[k] = (e < total) ? src[e] : 0.0;
+  }
+#pragma unroll
+  for (int k = 0; k < 4 * R; ++k) {
+    const int e = tid + 64 * k;
+    t.d[(e / (4 * R)) * Tile<R>::P + e % (4 * R)] = tmp[k];
+  }
 }
 template <int R>
-__device__ __forceinline__ void store_pose(double *p, const double *v) {
+__device__ __forceinline__ void tile_out(const Tile<R> &t, double *g, int j0, int cnt, int tid) {
+  double *dst = g + (size_t)j0 * 4 * R;
+  const int total = cnt * 4 * R;
 #pragma unroll
-  for (int i = 0; i < 4 * R; ++i) p[i] = v[i];
+  for (int k = 0; k < 4 * R; ++k) {
+    const int e = tid + 64 * k;
+    if (e < total) dst[e] = t.d[(e / (4 * R)) * Tile<R>::P + e % (4 * R)];
+  }
+}
+template <int R>
+__device__ __forceinline__ void tile_get(const Tile<R> &t, int row, double *v) {
+#pragma unroll
+  for (int i = 0; i < 4 * R; ++i) v[i] = t.d[row * Tile<R>::P + i];
+}
+template <int R>
+__device__ __forceinline__ void tile_put(Tile<R> &t, int row, const double *v) {
+#pragma unroll
+  for (int i = 0; i < 4 * R; ++i) t.d[row * Tile<R>::P + i] = v[i];
 }
 
 // out = Retr_x(scale * eta).  guard_state >= 0: skip when the trust-region state says done.
 template <int R>
-__global__ void k_retract(const AgentDev *agents, const TeamDev *team, int sel, int xb, int eb, double scale, int ob,
-                          int guard_state) {
-  const AgentDev &ag = pick(agents, team, sel);
+__global__ __launch_bounds__(64) void k_retract(const AgentDev *agents, const TeamDev *team, int sel, int xb, int eb,
+                                                double scale, int ob, int guard_state) {
+  const AgentDev &ag = agents[sel_cur(team, sel)];
   if (guard_state >= 0 && ag.st[guard_state].outer_done) return;
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= ag.n) return;
-  double x[4 * R], e[4 * R];
-  load_pose<R>(ag.buf[xb] + (size_t)j * 4 * R, x);
-  load_pose<R>(ag.buf[eb] + (size_t)j * 4 * R, e);
+  const int j0 = blockIdx.x * 64, tid = threadIdx.x;
+  if (j0 >= ag.n) return;
+  const int cnt = min(64, ag.n - j0);
+  __shared__ Tile<R> TA, TB;
+  tile_in<R>(TA, ag.buf[xb], j0, cnt, tid);
+  tile_in<R>(TB, ag.buf[eb], j0, cnt, tid);
+  __syncthreads();
+  if (tid < cnt) {
+    double x[4 * R], e[4 * R];
+    tile_get<R>(TA, tid, x);
+    tile_get<R>(TB, tid, e);
 #pragma unroll
-  for (int i = 0; i < 4 * R; ++i) x[i] += scale * e[i];
-  qf_inplace<R>(x);
-  store_pose<R>(ag.buf[ob] + (size_t)j * 4 * R, x);
+    for (int i = 0; i < 4 * R; ++i) x[i] += scale * e[i];
+    qf_inplace<R>(x);
+    tile_put<R>(TA, tid, x);
+  }
+  __syncthreads();
+  tile_out<R>(TA, ag.buf[ob], j0, cnt, tid);
 }
 
-// raw-pointer manifold ops (unit parity + set-up)
-template <int R>
-__global__ void k_project_raw(const double *X, double *out, int n) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
-  double x[4 * R];
-  load_pose<R>(X + (size_t)j * 4 * R, x);
-  polar_inplace<R>(x);
-  store_pose<R>(out + (size_t)j * 4 * R, x);
-}
-template <int R>
-__global__ void k_tangent_raw(const double *X, const double *V, double *out, int n) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
-  double x[4 * R], v[4 * R];
-  load_pose<R>(X + (size_t)j * 4 * R, x);
-  load_pose<R>(V + (size_t)j * 4 * R, v);
-  tangent_inplace<R>(x, v);
-  store_pose<R>(out + (size_t)j * 4 * R, v);
-}
-template <int R>
-__global__ void k_retract_raw(const double *X, const double *E, double *out, int n) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
-  double x[4 * R], e[4 * R];
-  load_pose<R>(X + (size_t)j * 4 * R, x);
-  load_pose<R>(E + (size_t)j * 4 * R, e);
+// raw-pointer manifold ops (unit parity + set-up): OP 0 polar projection, 1 tangent projection, 2 retraction
+template <int R, int OP>
+__global__ __launch_bounds__(64) void k_raw_op(const double *X, const double *V, double *out, int n) {
+  const int j0 = blockIdx.x * 64, tid = threadIdx.x;
+  const int cnt = min(64, n - j0);
+  __shared__ Tile<R> TA, TB;
+  tile_in<R>(TA, X, j0, cnt, tid);
+  if (OP != 0) tile_in<R>(TB, V, j0, cnt, tid);
+  __syncthreads();
+  if (tid < cnt) {
+    double x[4 * R], v[4 * R];
+    tile_get<R>(TA, tid, x);
+    if (OP == 0) { polar_inplace<R>(x); tile_put<R>(TA, tid, x); }
+    if (OP == 1) { tile_get<R>(TB, tid, v); tangent_inplace<R>(x, v); tile_put<R>(TA, tid, v); }
+    if (OP == 2) {
+      tile_get<R>(TB, tid, v);
 #pragma unroll
-  for (int i = 0; i < 4 * R; ++i) x[i] += e[i];
-  qf_inplace<R>(x);
-  store_pose<R>(out + (size_t)j * 4 * R, x);
+      for (int i = 0; i < 4 * R; ++i) x[i] += v[i];
+      qf_inplace<R>(x);
+      tile_put<R>(TA, tid, x);
+    }
+  }
+  __syncthreads();
+  tile_out<R>(TA, out, j0, cnt, tid);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -535,75 +767,108 @@ __global__ void k_retract_raw(const double *X, const double *E, double *out, int
 //   XPrev = X;  gamma' = (1 + sqrt(1 + 4 N^2 gamma^2)) / 2N;  alpha = 1 / (gamma' N)
 //   Y = proj((1 - alpha) X + alpha V);  X = Y
 // and for the agents that do NOT optimize this iteration (everything but `sel`, or all when
-// only_agent >= 0 names a single non-optimizing agent):  V = proj(V)  [= proj(V + gamma (X - Y))],
-// then the periodic restart X = XPrev, V = Y = X.
+// sel == -2):  V = proj(V)  [= proj(V + gamma (X - Y))], then the periodic restart X = XPrev,
+// V = Y = X; partial [0] of PART_D = |X_new - XPrev|^2.  First kernel of an accelerated iteration:
+// publishes team->cur_sel.
 template <int R>
-__global__ void k_nest_pre(const AgentDev *agents, const TeamDev *team, int sel, int only_agent, int num_robots,
-                           int restart_interval) {
+__global__ __launch_bounds__(64) void k_nest_pre(const AgentDev *agents, TeamDev *team, int sel, int only_agent,
+                                                 int num_robots, int restart_interval) {
   const int ai = only_agent >= 0 ? only_agent : (int)blockIdx.y;
   const AgentDev &ag = agents[ai];
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= ag.n) return;
-  const bool optimizing = (sel == -2) ? false : (ai == pick_idx(team, sel));
+  const int selected = (sel == -2) ? -1 : sel_sched(team, sel);
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && sel == -1) team->cur_sel = selected;
+  const int j0 = blockIdx.x * 64, tid = threadIdx.x;
+  if (j0 >= ag.n) return;
+  const int cnt = min(64, ag.n - j0);
+  const bool optimizing = (ai == selected);
   const NestState ns = *ag.nest;
   const double Nr = (double)num_robots;
   const double gamma = (1.0 + sqrt(1.0 + 4.0 * Nr * Nr * ns.gamma * ns.gamma)) / (2.0 * Nr);
   const double alpha = 1.0 / (gamma * Nr);
   const bool restart = ((ns.iter + 2) % restart_interval) == 0;  // iter is pre-increment: (iter+1)+1
+  __shared__ Tile<R> TX, TV;
+  tile_in<R>(TX, ag.buf[B_X], j0, cnt, tid);
+  tile_in<R>(TV, ag.buf[B_V], j0, cnt, tid);
+  __syncthreads();
+  tile_out<R>(TX, ag.buf[B_XPREV], j0, cnt, tid);
   double x[4 * R], v[4 * R], y[4 * R];
-  const size_t o = (size_t)j * 4 * R;
-  load_pose<R>(ag.buf[B_X] + o, x);
-  load_pose<R>(ag.buf[B_V] + o, v);
-  store_pose<R>(ag.buf[B_XPREV] + o, x);
+  double rel = 0;
+  if (tid < cnt) {
+    tile_get<R>(TX, tid, x);
+    tile_get<R>(TV, tid, v);
 #pragma unroll
-  for (int i = 0; i < 4 * R; ++i) y[i] = (1.0 - alpha) * x[i] + alpha * v[i];
-  polar_inplace<R>(y);
-  store_pose<R>(ag.buf[B_Y] + o, y);
-  if (optimizing) {
-    store_pose<R>(ag.buf[B_X] + o, y);  // the local solve starts from Y, in place on X
-    return;
+    for (int i = 0; i < 4 * R; ++i) y[i] = (1.0 - alpha) * x[i] + alpha * v[i];
+    polar_inplace<R>(y);
+    if (!optimizing && !restart) {
+      polar_inplace<R>(v);
+#pragma unroll
+      for (int i = 0; i < 4 * R; ++i) { const double d = y[i] - x[i]; rel += d * d; }
+    }
   }
-  if (restart) {
-    // X = XPrev; V = X; Y = X
-    store_pose<R>(ag.buf[B_V] + o, x);
-    store_pose<R>(ag.buf[B_Y] + o, x);
+  __syncthreads();
+  if (tid < cnt) {
+    if (optimizing || !restart) { tile_put<R>(TX, tid, y); tile_put<R>(TV, tid, v); }
+    // restart of a non-optimizing agent: X = XPrev (tile still holds x); V = Y = X
+  }
+  __syncthreads();
+  if (optimizing) {
+    tile_out<R>(TX, ag.buf[B_Y], j0, cnt, tid);
+    tile_out<R>(TX, ag.buf[B_X], j0, cnt, tid);  // the local solve starts from Y, in place on X
+  } else if (restart) {
+    tile_out<R>(TX, ag.buf[B_Y], j0, cnt, tid);
+    tile_out<R>(TX, ag.buf[B_V], j0, cnt, tid);
   } else {
-    store_pose<R>(ag.buf[B_X] + o, y);
-    polar_inplace<R>(v);
-    store_pose<R>(ag.buf[B_V] + o, v);
+    tile_out<R>(TX, ag.buf[B_Y], j0, cnt, tid);
+    tile_out<R>(TX, ag.buf[B_X], j0, cnt, tid);
+    tile_out<R>(TV, ag.buf[B_V], j0, cnt, tid);
+  }
+  if (!optimizing) {
+    rel = wave_sum(rel);
+    if (tid == 0) ag.part[PART_D + (size_t)blockIdx.x * PART_STRIDE] = rel;
   }
 }
 
-// after the selected agent's local solve:  V = proj(V + gamma' (X - Y)); on restart X = XPrev
-// (the host then re-optimizes from XPrev and calls k_nest_reset).
+// after the selected agent's local solve (unfused path):  V = proj(V + gamma' (X - Y)); on restart
+// X = XPrev (the host then re-optimizes from XPrev and calls k_nest_reset).
 template <int R>
-__global__ void k_nest_post(const AgentDev *agents, const TeamDev *team, int sel, int num_robots, int restart_interval) {
-  const AgentDev &ag = pick(agents, team, sel);
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= ag.n) return;
+__global__ __launch_bounds__(64) void k_nest_post(const AgentDev *agents, const TeamDev *team, int sel, int num_robots,
+                                                  int restart_interval) {
+  const AgentDev &ag = agents[sel_cur(team, sel)];
+  const int j0 = blockIdx.x * 64, tid = threadIdx.x;
+  if (j0 >= ag.n) return;
+  const int cnt = min(64, ag.n - j0);
   const NestState ns = *ag.nest;
   const double Nr = (double)num_robots;
   const double gamma = (1.0 + sqrt(1.0 + 4.0 * Nr * Nr * ns.gamma * ns.gamma)) / (2.0 * Nr);
   const bool restart = ((ns.iter + 2) % restart_interval) == 0;
-  const size_t o = (size_t)j * 4 * R;
-  double x[4 * R], v[4 * R], y[4 * R];
+  __shared__ Tile<R> TX, TV, TY;
   if (restart) {
-    load_pose<R>(ag.buf[B_XPREV] + o, x);
-    store_pose<R>(ag.buf[B_X] + o, x);
+    tile_in<R>(TX, ag.buf[B_XPREV], j0, cnt, tid);
+    __syncthreads();
+    tile_out<R>(TX, ag.buf[B_X], j0, cnt, tid);
     return;
   }
-  load_pose<R>(ag.buf[B_X] + o, x);
-  load_pose<R>(ag.buf[B_V] + o, v);
-  load_pose<R>(ag.buf[B_Y] + o, y);
+  tile_in<R>(TX, ag.buf[B_X], j0, cnt, tid);
+  tile_in<R>(TV, ag.buf[B_V], j0, cnt, tid);
+  tile_in<R>(TY, ag.buf[B_Y], j0, cnt, tid);
+  __syncthreads();
+  if (tid < cnt) {
+    double x[4 * R], v[4 * R], y[4 * R];
+    tile_get<R>(TX, tid, x);
+    tile_get<R>(TV, tid, v);
+    tile_get<R>(TY, tid, y);
 #pragma unroll
-  for (int i = 0; i < 4 * R; ++i) v[i] += gamma * (x[i] - y[i]);
-  polar_inplace<R>(v);
-  store_pose<R>(ag.buf[B_V] + o, v);
+    for (int i = 0; i < 4 * R; ++i) v[i] += gamma * (x[i] - y[i]);
+    polar_inplace<R>(v);
+    tile_put<R>(TV, tid, v);
+  }
+  __syncthreads();
+  tile_out<R>(TV, ag.buf[B_V], j0, cnt, tid);
 }
 
 // V = X; Y = X  (restart tail / weight update)
 __global__ void k_nest_reset(const AgentDev *agents, const TeamDev *team, int sel, int r) {
-  const AgentDev &ag = pick(agents, team, sel);
+  const AgentDev &ag = agents[sel_cur(team, sel)];
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= ag.N4 * r) return;
   const double x = ag.buf[B_X][t];
@@ -611,64 +876,58 @@ __global__ void k_nest_reset(const AgentDev *agents, const TeamDev *team, int se
   ag.buf[B_Y][t] = x;
 }
 
-// end of an iteration: advance gamma/alpha/iter of every agent (blockIdx.x = agent), and the team
-// counter.  accel == 0: only the iteration counters move.
+// end of an iteration (unfused paths): advance gamma/alpha/iter of every agent, and the team counter
 __global__ void k_advance(const AgentDev *agents, TeamDev *team, int only_agent, int accel, int num_robots,
                           int restart_interval, int bump_team) {
   const int ai = only_agent >= 0 ? only_agent : (int)blockIdx.x;
   if (threadIdx.x != 0) return;
-  NestState ns = *agents[ai].nest;
-  if (accel) {
-    const double Nr = (double)num_robots;
-    const bool restart = ((ns.iter + 2) % restart_interval) == 0;
-    if (restart) { ns.gamma = 0; ns.alpha = 0; }
-    else {
-      ns.gamma = (1.0 + sqrt(1.0 + 4.0 * Nr * Nr * ns.gamma * ns.gamma)) / (2.0 * Nr);
-      ns.alpha = 1.0 / (ns.gamma * Nr);
-    }
-  }
-  ns.iter += 1;
-  *agents[ai].nest = ns;
+  advance_agent(agents[ai], accel, num_robots, restart_interval);
   if (bump_team && ai == 0) team->iter += 1;
 }
 
-// ------------------------------------------------------------------------------------------------
-// single-workgroup finishers (deterministic order)
-// scal[0] = |X - XPrev|_F^2 ; optionally scal[so], scal[so+1] = sum of eval partials (f, |g|^2)
+// PART_D partial [0] = |X - XPrev|_F^2 over a 64-pose tile (blockIdx.y = agent when sel == -3)
 template <int R>
-__global__ __launch_bounds__(256) void k_status(const AgentDev *agents, const TeamDev *team, int sel, int only_agent,
-                                                int stat_off, int poff) {
-  const int ai = only_agent >= 0 ? only_agent : (sel == -3 ? (int)blockIdx.x : pick_idx(team, sel));
+__global__ __launch_bounds__(64) void k_status(const AgentDev *agents, const TeamDev *team, int sel, int only_agent) {
+  const int ai = only_agent >= 0 ? only_agent : (sel == -3 ? (int)blockIdx.y : sel_cur(team, sel));
   const AgentDev &ag = agents[ai];
-  __shared__ double red[4];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const size_t len = (size_t)ag.n * 4 * R;
-  double s = 0;
-  for (size_t t = tid; t < len; t += 256) {
-    const double d = ag.buf[B_X][t] - ag.buf[B_XPREV][t];
-    s += d * d;
+  const int j0 = blockIdx.x * 64, tid = threadIdx.x;
+  if (j0 >= ag.n) return;
+  const size_t lo = (size_t)j0 * 4 * R, hi = (size_t)min(ag.n, j0 + 64) * 4 * R;
+  double s = 0, xa[4 * R], xb[4 * R];
+#pragma unroll
+  for (int k = 0; k < 4 * R; ++k) {
+    const size_t t = lo + tid + 64 * k;
+    xa[k] = (t < hi) ? ag.buf[B_X][t] : 0.0;
+    xb[k] = (t < hi) ? ag.buf[B_XPREV][t] : 0.0;
   }
+#pragma unroll
+  for (int k = 0; k < 4 * R; ++k) { const double d = xa[k] - xb[k]; s += d * d; }
   s = wave_sum(s);
-  if (lane == 0) red[w] = s;
-  __syncthreads();
-  if (tid == 0) ag.scal[0] = (red[0] + red[1]) + (red[2] + red[3]);
-  if (stat_off >= 0 && w == 0) {
-    const int nb = spmm_blocks<R>(ag.n);
-    const double f = sum_partials(ag.part + poff, nb, PART_STRIDE, lane);
-    const double g = sum_partials(ag.part + poff + 1, nb, PART_STRIDE, lane);
-    if (lane == 0) { ag.scal[stat_off] = f; ag.scal[stat_off + 1] = g; }
-  }
+  if (tid == 0) ag.part[PART_D + (size_t)blockIdx.x * PART_STRIDE] = s;
+}
+
+// buf[to] = buf[from] for one agent or (sel == -3) every agent (blockIdx.y).  As the first kernel of a
+// non-accelerated iteration (publish != 0) it also publishes team->cur_sel.
+__global__ void k_copy(const AgentDev *agents, TeamDev *team, int sel, int only_agent, int r, int from, int to,
+                       int publish) {
+  const int ai = only_agent >= 0 ? only_agent : (sel == -3 ? (int)blockIdx.y : sel_cur(team, sel));
+  if (publish && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+    team->cur_sel = team->sched[team->iter % team->sched_len];
+  const AgentDev &ag = agents[ai];
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ag.N4 * r) return;
+  ag.buf[to][t] = ag.buf[from][t];
 }
 
 // trust-region set-up from the initial evaluation partials
 template <int R>
 __global__ void k_rtr_begin(const AgentDev *agents, const TeamDev *team, int sel, double Delta0, double tol,
                             int max_outer) {
-  const AgentDev &ag = pick(agents, team, sel);
+  const AgentDev &ag = agents[sel_cur(team, sel)];
   const int lane = threadIdx.x;
   const int nb = spmm_blocks<R>(ag.n);
-  const double f = sum_partials(ag.part + PA_OFF, nb, PART_STRIDE, lane);
-  const double g = sum_partials(ag.part + PA_OFF + 1, nb, PART_STRIDE, lane);
+  const double f = sum_partials(ag.part + PART_A, nb, PART_STRIDE, lane);
+  const double g = sum_partials(ag.part + PART_A + 1, nb, PART_STRIDE, lane);
   if (lane != 0) return;
   RtrState S = {};
   S.f1 = f; S.ngf = sqrt(g); S.Delta = Delta0;
@@ -676,14 +935,14 @@ __global__ void k_rtr_begin(const AgentDev *agents, const TeamDev *team, int sel
   S.outer_done = (S.ngf < tol) || (max_outer <= 0);
   ag.st[0] = S;
   ag.st[1] = S;
-  ag.scal[3] = f; ag.scal[4] = g;
 }
 
 // outer step, evaluation at the candidate x2 = Retr_x1(eta):
 //   egrad2 = x2 Q + G, rgrad2, Heta = Hess_x1[eta];  partials [0] f2 [1] |rgrad2|^2 [2] <gf,eta> [3] <eta,Heta>
+// (both SpMM rows share every Q block load)
 template <int R>
 __global__ __launch_bounds__(64) void k_rtr_eval2(const AgentDev *agents, const TeamDev *team, int sel, int sp) {
-  const AgentDev &ag = pick(agents, team, sel);
+  const AgentDev &ag = agents[sel_cur(team, sel)];
   constexpr int PPB = 64 / R;
   __shared__ double Ysh[PPB * 4 * R], Esh[PPB * 4 * R], Wsh[PPB * 4 * R];
   const int lane = threadIdx.x, lp = lane / R, a = lane - lp * R;
@@ -693,33 +952,23 @@ __global__ __launch_bounds__(64) void k_rtr_eval2(const AgentDev *agents, const 
   const bool act = lp < PPB && j < ag.n;
   const double *X2 = ag.buf[B_X2], *ETA = ag.buf[B_ETA];
   double fpart = 0, gpart = 0, ge = 0, eh = 0;
-  double acc[4] = {0, 0, 0, 0}, wrow[4] = {0, 0, 0, 0}, vrow[4] = {0, 0, 0, 0}, hrow[4], eg[4] = {0, 0, 0, 0};
+  double acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, vrow[4] = {0, 0, 0, 0}, hrow[4], eg[4] = {0, 0, 0, 0};
   if (act) {
-    // two SpMM rows share every Q block load
-    const int p0 = ag.rowptr[j], p1 = ag.rowptr[j + 1];
-    for (int p = p0; p < p1; ++p) {
-      const int i = ag.col[p];
-      const double2 *B = reinterpret_cast<const double2 *>(ag.qval + (size_t)16 * p);
-      double x[4], e[4];
+    spmm_row<R, 2>(ag, j, [&](int i, double(*x)[4]) {
 #pragma unroll
       for (int cp = 0; cp < 4; ++cp) {
-        x[cp] = X2[((size_t)4 * i + cp) * R + a];
-        e[cp] = ETA[((size_t)4 * i + cp) * R + a];
+        x[0][cp] = X2[((size_t)4 * i + cp) * R + a];
+        x[1][cp] = ETA[((size_t)4 * i + cp) * R + a];
       }
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const double2 b01 = B[2 * c], b23 = B[2 * c + 1];
-        acc[c] += x[0] * b01.x + x[1] * b01.y + x[2] * b23.x + x[3] * b23.y;
-        wrow[c] += e[0] * b01.x + e[1] * b01.y + e[2] * b23.x + e[3] * b23.y;
-      }
-    }
+    }, acc);
+    const bool pub = ag.pub_index[j] >= 0;
     const double *G = ag.buf[B_G] + (size_t)j * 4 * R;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const size_t o = ((size_t)4 * j + c) * R + a;
-      const double xr = X2[o], g = G[c * R + a];
-      fpart += (0.5 * acc[c] + g) * xr;
-      eg[c] = acc[c] + g;
+      const double xr = X2[o], g = pub ? G[c * R + a] : 0.0;
+      fpart += (0.5 * acc[0][c] + g) * xr;
+      eg[c] = acc[0][c] + g;
       ag.buf[B_EGRAD2][o] = eg[c];
       Ysh[lp * 4 * R + c * R + a] = xr;
       Wsh[lp * 4 * R + c * R + a] = eg[c];
@@ -746,7 +995,7 @@ __global__ __launch_bounds__(64) void k_rtr_eval2(const AgentDev *agents, const 
     }
   }
   __syncthreads();
-  hess_tail<R>(Ysh + lp * 4 * R, Esh + lp * 4 * R, Wsh + lp * 4 * R, a, wrow, vrow, hrow, act);
+  hess_tail<R>(Ysh + lp * 4 * R, Esh + lp * 4 * R, Wsh + lp * 4 * R, a, acc[1], vrow, hrow, act);
   if (act) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -758,7 +1007,7 @@ __global__ __launch_bounds__(64) void k_rtr_eval2(const AgentDev *agents, const 
   }
   fpart = wave_sum(fpart); gpart = wave_sum(gpart); ge = wave_sum(ge); eh = wave_sum(eh);
   if (lane == 0) {
-    double *P = ag.part + PC_OFF + (size_t)blockIdx.x * PART_STRIDE;
+    double *P = ag.part + PART_C + (size_t)blockIdx.x * PART_STRIDE;
     P[0] = fpart; P[1] = gpart; P[2] = ge; P[3] = eh;
   }
 }
@@ -768,7 +1017,7 @@ __global__ __launch_bounds__(64) void k_rtr_eval2(const AgentDev *agents, const 
 template <int R>
 __global__ void k_rtr_accept(const AgentDev *agents, const TeamDev *team, int sel, int sp, double tol, int max_outer,
                              double max_radius) {
-  const AgentDev &ag = pick(agents, team, sel);
+  const AgentDev &ag = agents[sel_cur(team, sel)];
   const RtrState S = ag.st[sp];
   if (S.outer_done) {
     if (blockIdx.x == 0 && threadIdx.x == 0) ag.st[sp ^ 1] = S;
@@ -776,10 +1025,10 @@ __global__ void k_rtr_accept(const AgentDev *agents, const TeamDev *team, int se
   }
   const int lane = threadIdx.x & 63;
   const int nb = spmm_blocks<R>(ag.n);
-  const double f2 = sum_partials(ag.part + PC_OFF, nb, PART_STRIDE, lane);
-  const double g2 = sum_partials(ag.part + PC_OFF + 1, nb, PART_STRIDE, lane);
-  const double ge = sum_partials(ag.part + PC_OFF + 2, nb, PART_STRIDE, lane);
-  const double eh = sum_partials(ag.part + PC_OFF + 3, nb, PART_STRIDE, lane);
+  const double f2 = sum_partials(ag.part + PART_C, nb, PART_STRIDE, lane);
+  const double g2 = sum_partials(ag.part + PART_C + 1, nb, PART_STRIDE, lane);
+  const double ge = sum_partials(ag.part + PART_C + 2, nb, PART_STRIDE, lane);
+  const double eh = sum_partials(ag.part + PART_C + 3, nb, PART_STRIDE, lane);
   const double rho = (S.f1 - f2) / (-ge - 0.5 * eh);
   const bool accept = rho > 0.1;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -865,14 +1114,7 @@ __global__ __launch_bounds__(256) void k_cost(const AgentDev *agents, int ai) {
   if (tid == 0) ag.scal[5] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// buf[to] = buf[from] for one agent or (sel == -3) every agent (blockIdx.y)
-__global__ void k_copy(const AgentDev *agents, const TeamDev *team, int sel, int only_agent, int r, int from, int to) {
-  const int ai = only_agent >= 0 ? only_agent : (sel == -3 ? (int)blockIdx.y : pick_idx(team, sel));
-  const AgentDev &ag = agents[ai];
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= ag.N4 * r) return;
-  ag.buf[to][t] = ag.buf[from][t];
-}
+__global__ void k_noop(const AgentDev *agents, int ai) { (void)agents; (void)ai; }
 
 // dense A = Q + shift I from the block-CSR (column-major N4 x N4; A must be zeroed first)
 __global__ void k_bsr_to_dense(const int *rowptr, const int *col, const double *qval, int n, double shift, double *A) {
@@ -912,26 +1154,26 @@ void launch_pull(const LaunchCtx &c, int dst, int nshared) {
   const int len = nshared * 4 * c.r;
   DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_pull<R>, dim3((len + 255) / 256), dim3(256), 0, c.stream, c.agents, dst));
 }
-void launch_eval(const LaunchCtx &c, int sel, int max_n, int xb, int egb, int gfb, int poff) {
+void launch_eval(const LaunchCtx &c, int sel, int max_n, int xb, int egb, int gfb, int poff, const EvalOpts &o) {
   DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_eval<R>, dim3(spmm_grid(c.r, max_n)), dim3(64), 0, c.stream, c.agents,
-                                          c.team, sel, xb, egb, gfb, poff));
+                                          c.team, sel, xb, egb, gfb, poff, o.gmode, o.aux, o.advance, o.accel,
+                                          o.num_robots, o.restart_interval));
 }
 void launch_hess(const LaunchCtx &c, int sel, int max_n, int xb, int egb, int vb, int ob, int poff) {
   DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_hess<R>, dim3(spmm_grid(c.r, max_n)), dim3(64), 0, c.stream, c.agents,
                                           c.team, sel, xb, egb, vb, ob, poff));
 }
-void launch_precond(const LaunchCtx &c, int sel, int max_n, int mode, int xb, int vb, int zb, int sp, int max_inner) {
+void launch_precond(const LaunchCtx &c, int sel, int max_n, int mode, int xb, int vb, int zb, int sp, int max_inner,
+                    double step, int accel, int num_robots) {
   const int grid = (4 * max_n + 7) / 8;
-  if (mode == PM_PLAIN) {
-    DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL((k_precond<R, PM_PLAIN>), dim3(grid), dim3(256), 0, c.stream, c.agents,
-                                            c.team, sel, xb, vb, zb, sp, max_inner));
-  } else if (mode == PM_TCG_INIT) {
-    DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL((k_precond<R, PM_TCG_INIT>), dim3(grid), dim3(256), 0, c.stream, c.agents,
-                                            c.team, sel, xb, vb, zb, sp, max_inner));
-  } else {
-    DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL((k_precond<R, PM_TCG_STEP>), dim3(grid), dim3(256), 0, c.stream, c.agents,
-                                            c.team, sel, xb, vb, zb, sp, max_inner));
-  }
+#define PC_CALL(M)                                                                                              \
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL((k_precond<R, M>), dim3(grid), dim3(256), 0, c.stream, c.agents, c.team, \
+                                          sel, xb, vb, zb, sp, max_inner, step, accel, num_robots))
+  if (mode == PM_PLAIN_) { PC_CALL(PM_PLAIN_); }
+  else if (mode == PM_TCG_INIT_) { PC_CALL(PM_TCG_INIT_); }
+  else if (mode == PM_TCG_STEP_) { PC_CALL(PM_TCG_STEP_); }
+  else { PC_CALL(PM_RGD_); }
+#undef PC_CALL
 }
 void launch_tcg_hv(const LaunchCtx &c, int sel, int max_n, int sp, int max_inner) {
   DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_tcg_hv<R>, dim3(spmm_grid(c.r, max_n)), dim3(64), 0, c.stream, c.agents,
@@ -942,13 +1184,13 @@ void launch_retract(const LaunchCtx &c, int sel, int max_n, int xb, int eb, doub
                                           c.team, sel, xb, eb, scale, ob, guard_state));
 }
 void launch_project_raw(const LaunchCtx &c, const double *X, double *out, int n) {
-  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_project_raw<R>, dim3((n + 63) / 64), dim3(64), 0, c.stream, X, out, n));
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL((k_raw_op<R, 0>), dim3((n + 63) / 64), dim3(64), 0, c.stream, X, X, out, n));
 }
 void launch_tangent_raw(const LaunchCtx &c, const double *X, const double *V, double *out, int n) {
-  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_tangent_raw<R>, dim3((n + 63) / 64), dim3(64), 0, c.stream, X, V, out, n));
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL((k_raw_op<R, 1>), dim3((n + 63) / 64), dim3(64), 0, c.stream, X, V, out, n));
 }
 void launch_retract_raw(const LaunchCtx &c, const double *X, const double *E, double *out, int n) {
-  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_retract_raw<R>, dim3((n + 63) / 64), dim3(64), 0, c.stream, X, E, out, n));
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL((k_raw_op<R, 2>), dim3((n + 63) / 64), dim3(64), 0, c.stream, X, E, out, n));
 }
 void launch_nest_pre(const LaunchCtx &c, int sel, int only_agent, int num_agents, int max_n, int num_robots,
                      int restart_interval) {
@@ -969,10 +1211,9 @@ void launch_advance(const LaunchCtx &c, int only_agent, int num_agents, int acce
   hipLaunchKernelGGL(k_advance, dim3(only_agent >= 0 ? 1 : num_agents), dim3(64), 0, c.stream, c.agents, c.team,
                      only_agent, accel, num_robots, restart_interval, bump_team);
 }
-void launch_status(const LaunchCtx &c, int sel, int only_agent, int num_agents, int stat_off, int poff) {
-  const int grid = (sel == -3) ? num_agents : 1;
-  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_status<R>, dim3(grid), dim3(256), 0, c.stream, c.agents, c.team, sel,
-                                          only_agent, stat_off, poff));
+void launch_status(const LaunchCtx &c, int sel, int only_agent, int num_agents, int max_n) {
+  dim3 grid((max_n + 63) / 64, (sel == -3 && only_agent < 0) ? num_agents : 1);
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_status<R>, grid, dim3(64), 0, c.stream, c.agents, c.team, sel, only_agent));
 }
 void launch_rtr_begin(const LaunchCtx &c, int sel, double Delta0, double tol, int max_outer) {
   DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_rtr_begin<R>, dim3(1), dim3(64), 0, c.stream, c.agents, c.team, sel, Delta0,
@@ -1005,14 +1246,16 @@ void launch_residuals(const LaunchCtx &c, int ai, int nedges) {
   if (nedges <= 0) return;
   DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_residuals<R>, dim3((nedges + 63) / 64), dim3(64), 0, c.stream, c.agents, ai));
 }
+void launch_noop(const LaunchCtx &c, int grid, int block) {
+  hipLaunchKernelGGL(k_noop, dim3(grid), dim3(block), 0, c.stream, c.agents, 0);
+}
 void launch_cost(const LaunchCtx &c, int ai) {
   hipLaunchKernelGGL(k_cost, dim3(1), dim3(256), 0, c.stream, c.agents, ai);
 }
-
-void launch_copy(const LaunchCtx &c, int sel, int only_agent, int num_agents, int max_n, int from, int to) {
+void launch_copy(const LaunchCtx &c, int sel, int only_agent, int num_agents, int max_n, int from, int to, int publish) {
   const int len = max_n * 4 * c.r;
   dim3 grid((len + 255) / 256, (sel == -3 && only_agent < 0) ? num_agents : 1);
-  hipLaunchKernelGGL(k_copy, grid, dim3(256), 0, c.stream, c.agents, c.team, sel, only_agent, c.r, from, to);
+  hipLaunchKernelGGL(k_copy, grid, dim3(256), 0, c.stream, c.agents, c.team, sel, only_agent, c.r, from, to, publish);
 }
 void launch_bsr_to_dense(hipStream_t s, const int *rowptr, const int *col, const double *qval, int n, double shift,
                          double *A) {

@@ -80,8 +80,9 @@ struct Agent {
   std::vector<double> qval;
   int npub = 0;
   // device storage
-  DevBuf<int> d_rowptr, d_col, d_pub_pose, d_pub_ptr, d_idx;
-  DevBuf<double> d_qval, d_M, d_vec, d_nbr, d_part, d_scal, d_resid;
+  DevBuf<int> d_rowptr, d_col, d_pub_pose, d_pub_ptr, d_idx, d_ell_col, d_trowptr, d_tcol, d_pub_index;
+  DevBuf<double> d_qval, d_M, d_vec, d_nbr, d_part, d_scal, d_resid, d_ell_val, d_tval;
+  int rel_src = 0;  // where the last |X - XPrev|^2 partials live: 0 PART_D (per 64-pose tile), 1 PART_B[2] (fused RGD)
   DevBuf<SharedEdgeDev> d_se;
   DevBuf<EdgeDev> d_edges;
   DevBuf<RtrState> d_st;
@@ -109,7 +110,8 @@ struct dpgo_team {
   int max_n = 0, max_npub = 0;
   RtrState *h_state = nullptr;  // pinned
   double *h_scal = nullptr;     // pinned [16]
-  hipGraphExec_t graph = nullptr;
+  static constexpr int NGRAPH = 5;       // graphs of 1, 2, 4, 8, 16 identical iterations
+  hipGraphExec_t graph[NGRAPH] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   bool graph_valid = false;
   int tcg_chunk = 4;
   double counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -278,6 +280,29 @@ int finalize_agent(dpgo_team *t, Agent &a) {
   for (auto &m : a.shared) push_edge(m);
   a.nedges = (int)edges.size();
 
+  // ELL (slot-major, width <= 8) + CSR tail copy of Q for the SpMM kernels
+  int maxlen = 0;
+  for (int j = 0; j < n; ++j) maxlen = std::max(maxlen, a.rowptr[j + 1] - a.rowptr[j]);
+  const int EW = std::min(maxlen, 8);
+  std::vector<int> ell_col((size_t)EW * n), trowptr(n + 1, 0), tcol;
+  std::vector<double> ell_val((size_t)EW * n * 16, 0.0), tval;
+  for (int j = 0; j < n; ++j) {
+    const int p0 = a.rowptr[j], p1 = a.rowptr[j + 1];
+    for (int u = 0; u < EW; ++u) {
+      const int p = p0 + u;
+      ell_col[(size_t)u * n + j] = (p < p1) ? a.col[p] : j;
+      if (p < p1) std::copy(a.qval.begin() + (size_t)16 * p, a.qval.begin() + (size_t)16 * (p + 1), ell_val.begin() + ((size_t)u * n + j) * 16);
+    }
+    for (int p = p0 + EW; p < p1; ++p) { tcol.push_back(a.col[p]); tval.insert(tval.end(), a.qval.begin() + (size_t)16 * p, a.qval.begin() + (size_t)16 * (p + 1)); }
+    trowptr[j + 1] = (int)tcol.size();
+  }
+  std::vector<int> pub_index(n, -1);
+  for (size_t q = 0; q < pub_pose.size(); ++q) pub_index[pub_pose[q]] = (int)q;
+  if (a.d_ell_col.upload(ell_col, s) || a.d_ell_val.upload(ell_val, s) || a.d_trowptr.upload(trowptr, s) ||
+      a.d_tcol.upload(tcol, s) || a.d_tval.upload(tval, s) || a.d_pub_index.upload(pub_index, s)) {
+    set_err("device allocation/upload failed");
+    return DPGO_ERR;
+  }
   const bool fresh_vec = a.d_vec.n < len * NBUF;
   if (a.d_rowptr.upload(a.rowptr, s) || a.d_col.upload(a.col, s) || a.d_qval.upload(a.qval, s) ||
       a.d_pub_pose.upload(pub_pose, s) || a.d_pub_ptr.upload(pub_ptr, s) || a.d_se.upload(se, s) ||
@@ -306,6 +331,8 @@ int finalize_agent(dpgo_team *t, Agent &a) {
   d.id = a.id; d.n = n; d.nb = (int)a.col.size(); d.N4 = N4;
   d.npub = a.npub; d.nshared = (int)se.size(); d.nnp = (int)a.np.size(); d.nedges = a.nedges;
   d.rowptr = a.d_rowptr.p; d.col = a.d_col.p; d.qval = a.d_qval.p; d.M = a.d_M.p;
+  d.ell_w = EW; d.ell_col = a.d_ell_col.p; d.ell_val = a.d_ell_val.p;
+  d.trowptr = a.d_trowptr.p; d.tcol = a.d_tcol.p; d.tval = a.d_tval.p; d.pub_index = a.d_pub_index.p;
   d.pub_pose = a.d_pub_pose.p; d.pub_ptr = a.d_pub_ptr.p; d.se = a.d_se.p; d.edges = a.d_edges.p;
   d.nbr[0] = a.d_nbr.p; d.nbr[1] = a.d_nbr.p + a.np.size() * 4 * r;
   for (int b = 0; b < NBUF; ++b) d.buf[b] = a.d_vec.p + len * b;
@@ -349,35 +376,54 @@ bool neighbor_poses_ready(const Agent &a, int aux) {
 
 // ---- the local solve (QuadraticOptimizer::optimize), enqueued on the team stream -------------
 // sel >= 0: that local agent (host-driven), sel == -1: device-selected (graph capture).
-// Returns after enqueueing for RGD; the RTR path synchronises once per tCG chunk to read the
+// RGD returns after enqueueing; the RTR path synchronises once per tCG chunk to read the
 // device-side solver state.
-int enqueue_optimize(dpgo_team *t, int sel, int aux, int pull, bool capture) {
+//   fused: the iteration's tail (Nesterov V update, |X - XPrev|^2, end-of-iteration bookkeeping)
+//          is folded into the RGD kernels (no restart in this iteration); `last` folds k_advance.
+struct OptFlags { int aux = 0, pull = 0; bool capture = false, fused = false, last_advances = false; };
+
+EvalOpts eval_opts(const dpgo_team *t, int gmode, int aux, int advance) {
+  EvalOpts o;
+  o.gmode = gmode; o.aux = aux; o.advance = advance;
+  o.accel = t->prm.acceleration; o.num_robots = t->prm.num_robots; o.restart_interval = t->prm.restart_interval;
+  return o;
+}
+
+double spmm_bytes_of(const dpgo_team *t, const Agent &a) {
+  return 8.0 * (16.0 * a.col.size() + 3.0 * t->prm.r * 4 * a.n) + 4.0 * (a.col.size() + a.n + 1);
+}
+
+int enqueue_optimize(dpgo_team *t, int sel, const OptFlags &fl) {
   LaunchCtx c = t->ctx();
   const dpgo_params_t &p = t->prm;
   const int mn = (sel >= 0) ? t->ag[sel]->n : t->max_n;
-  const int mp = (sel >= 0) ? t->ag[sel]->npub : t->max_npub;
   const int N4 = 4 * mn;
-  const double spmm_bytes = (sel >= 0) ? 8.0 * (16.0 * t->ag[sel]->col.size() + 3.0 * p.r * 4 * mn) +
-                                             4.0 * (t->ag[sel]->col.size() + mn + 1) : 0.0;
-  launch_buildG(c, sel, mp, aux, pull);
+  const int gmode = fl.pull ? 2 : 1;
   if (p.method == DPGO_METHOD_RGD) {
-    launch_eval(c, sel, mn, B_X, B_EGRAD, B_GF, PART_C);
-    int dirb = B_GF;
-    if (p.rgd_use_preconditioner) {
-      launch_precond(c, sel, mn, PM_PLAIN_, B_X, B_GF, B_Z, 0, 0);
-      dirb = B_Z;
-      t->counters[0] += 1; t->counters[1] += 8.0 * N4 * (double)N4;
+    launch_eval(c, sel, mn, B_X, B_EGRAD, B_GF, PART_C, eval_opts(t, gmode, fl.aux, 0));
+    if (fl.fused && p.rgd_use_preconditioner) {
+      launch_precond(c, sel, mn, PM_RGD_, B_X, B_GF, B_Z, 0, 0, p.rgd_stepsize, p.acceleration, p.num_robots);
+    } else {
+      int dirb = B_GF;
+      if (p.rgd_use_preconditioner) {
+        launch_precond(c, sel, mn, PM_PLAIN_, B_X, B_GF, B_Z, 0, 0, 0.0, 0, p.num_robots);
+        dirb = B_Z;
+      }
+      launch_retract(c, sel, mn, B_X, dirb, -p.rgd_stepsize, B_X, -1);
     }
-    launch_retract(c, sel, mn, B_X, dirb, -p.rgd_stepsize, B_X, -1);
-    launch_eval(c, sel, mn, B_X, B_EGRAD, B_GF, PART_A);
-    t->counters[2] += 2; t->counters[3] += 2 * spmm_bytes;
-    if (sel >= 0) t->ag[sel]->opt_pending_rgd = true;
+    launch_eval(c, sel, mn, B_X, B_EGRAD, B_GF, PART_A, eval_opts(t, 0, 0, fl.last_advances ? 1 : 0));
+    if (sel >= 0 && !fl.capture) {
+      Agent &a = *t->ag[sel];
+      if (p.rgd_use_preconditioner) { t->counters[0] += 1; t->counters[1] += 8.0 * N4 * (double)N4; }
+      t->counters[2] += 2; t->counters[3] += 2 * spmm_bytes_of(t, a);
+      a.opt_pending_rgd = true;
+    }
     return 0;
   }
-  if (capture) { set_err("RTR cannot be captured"); return DPGO_ERR; }
+  if (fl.capture) { set_err("RTR cannot be captured"); return DPGO_ERR; }
   // ---- RTR: trust-region Newton with truncated CG; scalars stay on the device
   Agent &a = *t->ag[sel];
-  launch_eval(c, sel, mn, B_X, B_EGRAD, B_GF, PART_A);
+  launch_eval(c, sel, mn, B_X, B_EGRAD, B_GF, PART_A, eval_opts(t, gmode, fl.aux, 0));
   launch_rtr_begin(c, sel, p.rtr_initial_radius, p.gradnorm_tol, p.rtr_iterations);
   int sp = 0;
   RtrState *hs = t->h_state;
@@ -389,10 +435,13 @@ int enqueue_optimize(dpgo_team *t, int sel, int aux, int pull, bool capture) {
   auto tcg_chunk = [&]() {
     for (int q = 0; q < t->tcg_chunk; ++q) {
       launch_tcg_hv(c, sel, mn, sp, p.rtr_tcg_iterations); sp ^= 1;
-      launch_precond(c, sel, mn, PM_TCG_STEP_, B_X, 0, 0, sp, p.rtr_tcg_iterations); sp ^= 1;
+      launch_precond(c, sel, mn, PM_TCG_STEP_, B_X, 0, 0, sp, p.rtr_tcg_iterations, 0.0, 0, p.num_robots); sp ^= 1;
     }
   };
-  launch_precond(c, sel, mn, PM_TCG_INIT_, B_X, 0, 0, sp, p.rtr_tcg_iterations); sp ^= 1;
+  auto tcg_init = [&]() {
+    launch_precond(c, sel, mn, PM_TCG_INIT_, B_X, 0, 0, sp, p.rtr_tcg_iterations, 0.0, 0, p.num_robots); sp ^= 1;
+  };
+  tcg_init();
   tcg_chunk();
   if (read_state()) return DPGO_ERR;
   int guard = 0;
@@ -403,7 +452,7 @@ int enqueue_optimize(dpgo_team *t, int sel, int aux, int pull, bool capture) {
       launch_retract(c, sel, mn, B_X, B_ETA, 1.0, B_X2, sp);
       launch_rtr_eval2(c, sel, mn, sp);
       launch_rtr_accept(c, sel, mn, sp, p.gradnorm_tol, p.rtr_iterations, p.rtr_max_radius); sp ^= 1;
-      launch_precond(c, sel, mn, PM_TCG_INIT_, B_X, 0, 0, sp, p.rtr_tcg_iterations); sp ^= 1;
+      tcg_init();
       tcg_chunk();
     }
     if (read_state()) return DPGO_ERR;
@@ -415,7 +464,8 @@ int enqueue_optimize(dpgo_team *t, int sel, int aux, int pull, bool capture) {
   a.opt.hessvec_count = hs->hv_count; a.opt.precond_count = hs->pc_count; a.opt.accepted = hs->accepted;
   a.opt_pending_rgd = false;
   t->counters[0] += hs->pc_count; t->counters[1] += hs->pc_count * 8.0 * N4 * (double)N4;
-  t->counters[2] += hs->hv_count + 1 + hs->outer_count; t->counters[3] += (hs->hv_count + 1 + hs->outer_count) * spmm_bytes;
+  t->counters[2] += hs->hv_count + 1 + hs->outer_count;
+  t->counters[3] += (hs->hv_count + 1 + hs->outer_count) * spmm_bytes_of(t, a);
   return 0;
 }
 
@@ -425,25 +475,34 @@ int enqueue_iterate(dpgo_team *t, int li, int do_opt) {
   LaunchCtx c = t->ctx();
   const dpgo_params_t &p = t->prm;
   const bool restart = p.acceleration && ((a.iter + 2) % p.restart_interval) == 0;
+  const bool fused = do_opt && p.method == DPGO_METHOD_RGD && p.rgd_use_preconditioner && !restart;
+  OptFlags fl;
+  fl.fused = fused;
   int rc = 0;
+  a.rel_src = 0;
   if (p.acceleration) {
     launch_nest_pre(c, do_opt ? li : -2, li, 1, a.n, p.num_robots, p.restart_interval);
     if (do_opt) {
-      rc = enqueue_optimize(t, li, 1, 0, false);
+      fl.aux = 1;
+      rc = enqueue_optimize(t, li, fl);
       if (rc) return rc;
-      launch_nest_post(c, li, a.n, p.num_robots, p.restart_interval);
+      if (!fused) launch_nest_post(c, li, a.n, p.num_robots, p.restart_interval);
       if (restart) {
-        rc = enqueue_optimize(t, li, 0, 0, false);
+        fl.aux = 0;
+        rc = enqueue_optimize(t, li, fl);
         if (rc) return rc;
         launch_nest_reset(c, li, a.n);
       }
+      if (fused) a.rel_src = 1; else launch_status(c, li, li, 1, a.n);
     }
   } else {
-    launch_copy(c, li, li, 1, a.n, B_X, B_XPREV);
-    if (do_opt) rc = enqueue_optimize(t, li, 0, 0, false);
-    if (rc) return rc;
+    launch_copy(c, li, li, 1, a.n, B_X, B_XPREV, 0);
+    if (do_opt) {
+      rc = enqueue_optimize(t, li, fl);
+      if (rc) return rc;
+    }
+    if (fused) a.rel_src = 1; else launch_status(c, li, li, 1, a.n);
   }
-  launch_status(c, li, li, 1, -1, PART_A);
   launch_advance(c, li, 1, p.acceleration, p.num_robots, p.restart_interval, 0);
   return 0;
 }
@@ -541,7 +600,7 @@ void dpgo_team_destroy(dpgo_team_t *t) {
   if (!t) return;
   (void)hipSetDevice(t->device);
   (void)hipStreamSynchronize(t->stream);
-  if (t->graph) (void)hipGraphExecDestroy(t->graph);
+  for (auto &g : t->graph) if (g) (void)hipGraphExecDestroy(g);
   t->ag.clear();
   if (t->h_state) (void)hipHostFree(t->h_state);
   if (t->h_scal) (void)hipHostFree(t->h_scal);
@@ -710,9 +769,17 @@ int dpgo_agent_get_status(dpgo_team_t *t, int id, dpgo_status_t *s) {
   if (!a) return DPGO_ERR;
   s->agent_id = a->id; s->state = a->state; s->instance_number = a->instance; s->iteration_number = a->iter;
   s->relative_change = 0; s->ready_to_terminate = 0;
-  if (!a->has_X) return DPGO_OK;
-  if (fetch_scal(t, *a)) return DPGO_ERR;
-  s->relative_change = std::sqrt(t->h_scal[0] / a->n);
+  if (!a->has_X || a->iter == 0) return DPGO_OK;
+  // |X - XPrev|^2 partials were left by the last kernel that moved X (fixed summation order)
+  const int cnt = a->rel_src ? (4 * a->n + 7) / 8 : (a->n + 63) / 64;
+  const int off = a->rel_src ? PART_B + 2 : PART_D;
+  std::vector<double> part((size_t)cnt * PART_STRIDE);
+  HIPC(hipMemcpyAsync(part.data(), a->dev.part + off, sizeof(double) * ((size_t)(cnt - 1) * PART_STRIDE + 1),
+                      hipMemcpyDeviceToHost, t->stream));
+  HIPC(hipStreamSynchronize(t->stream));
+  double sum = 0;
+  for (int k = 0; k < cnt; ++k) sum += part[(size_t)k * PART_STRIDE];
+  s->relative_change = std::sqrt(sum / a->n);
   s->ready_to_terminate = a->last_success && (s->relative_change <= t->prm.rel_change_tol);
   return DPGO_OK;
 }
@@ -755,7 +822,7 @@ int dpgo_agent_eval(dpgo_team_t *t, int id, const double *X, double *f, double *
   if (sync_descs(t)) return DPGO_ERR;
   const size_t bytes = sizeof(double) * (size_t)t->prm.r * 4 * a->n;
   HIPC(hipMemcpyAsync(a->dev.buf[B_T0], X, bytes, hipMemcpyHostToDevice, t->stream));
-  launch_eval(t->ctx(), a->local, a->n, B_T0, B_T1, B_T2, PART_A);
+  launch_eval(t->ctx(), a->local, a->n, B_T0, B_T1, B_T2, PART_A, eval_opts(t, 0, 0, 0));
   std::vector<double> part((size_t)PART_STRIDE * MAX_PART);
   HIPC(hipMemcpyAsync(part.data(), a->dev.part + PART_A, sizeof(double) * part.size(), hipMemcpyDeviceToHost, t->stream));
   if (egrad) HIPC(hipMemcpyAsync(egrad, a->dev.buf[B_T1], bytes, hipMemcpyDeviceToHost, t->stream));
@@ -775,7 +842,7 @@ int dpgo_agent_hessvec(dpgo_team_t *t, int id, const double *X, const double *et
   const size_t bytes = sizeof(double) * (size_t)t->prm.r * 4 * a->n;
   HIPC(hipMemcpyAsync(a->dev.buf[B_T0], X, bytes, hipMemcpyHostToDevice, t->stream));
   HIPC(hipMemcpyAsync(a->dev.buf[B_X2], eta, bytes, hipMemcpyHostToDevice, t->stream));
-  launch_eval(t->ctx(), a->local, a->n, B_T0, B_T1, B_T2, PART_A);
+  launch_eval(t->ctx(), a->local, a->n, B_T0, B_T1, B_T2, PART_A, eval_opts(t, 0, 0, 0));
   launch_hess(t->ctx(), a->local, a->n, B_T0, B_T1, B_X2, B_HETA, PART_A);
   HIPC(hipMemcpyAsync(out, a->dev.buf[B_HETA], bytes, hipMemcpyDeviceToHost, t->stream));
   HIPC(hipStreamSynchronize(t->stream));
@@ -789,7 +856,7 @@ int dpgo_agent_precondition(dpgo_team_t *t, int id, const double *X, const doubl
   const size_t bytes = sizeof(double) * (size_t)t->prm.r * 4 * a->n;
   HIPC(hipMemcpyAsync(a->dev.buf[B_T0], X, bytes, hipMemcpyHostToDevice, t->stream));
   HIPC(hipMemcpyAsync(a->dev.buf[B_T1], V, bytes, hipMemcpyHostToDevice, t->stream));
-  launch_precond(t->ctx(), a->local, a->n, PM_PLAIN_, B_T0, B_T1, B_T2, 0, 0);
+  launch_precond(t->ctx(), a->local, a->n, PM_PLAIN_, B_T0, B_T1, B_T2, 0, 0, 0.0, 0, t->prm.num_robots);
   HIPC(hipMemcpyAsync(out, a->dev.buf[B_T2], bytes, hipMemcpyDeviceToHost, t->stream));
   HIPC(hipStreamSynchronize(t->stream));
   return 0;
@@ -979,24 +1046,34 @@ static int enqueue_team_iteration(dpgo_team_t *t, bool capture, bool restart) {
   const int na = (int)t->ag.size();
   const int sel = capture ? -1 : t->sched[t->iter % t->sched.size()];
   const int mn = t->max_n;
+  const bool fused = p.method == DPGO_METHOD_RGD && p.rgd_use_preconditioner && !restart;
+  OptFlags fl;
+  fl.pull = 1; fl.capture = capture; fl.fused = fused; fl.last_advances = fused;
   int rc = 0;
   if (p.acceleration) {
+    // K1 Nesterov Y/X/V of every agent (+ publishes the selected agent), then the local solve
     launch_nest_pre(c, sel, -1, na, mn, p.num_robots, p.restart_interval);
-    rc = enqueue_optimize(t, sel, 1, 1, capture);
+    fl.aux = 1;
+    rc = enqueue_optimize(t, sel, fl);
     if (rc) return rc;
-    launch_nest_post(c, sel, (sel >= 0) ? t->ag[sel]->n : mn, p.num_robots, p.restart_interval);
-    if (restart) {
-      rc = enqueue_optimize(t, sel, 0, 1, capture);
-      if (rc) return rc;
-      launch_nest_reset(c, sel, (sel >= 0) ? t->ag[sel]->n : mn);
+    if (!fused) {
+      const int ns = (sel >= 0) ? t->ag[sel]->n : mn;
+      launch_nest_post(c, sel, ns, p.num_robots, p.restart_interval);
+      if (restart) {
+        fl.aux = 0;
+        rc = enqueue_optimize(t, sel, fl);
+        if (rc) return rc;
+        launch_nest_reset(c, sel, ns);
+      }
+      launch_status(c, sel, -1, 1, ns);
     }
   } else {
-    launch_copy(c, -3, -1, na, mn, B_X, B_XPREV);
-    rc = enqueue_optimize(t, sel, 0, 1, capture);
+    launch_copy(c, -3, -1, na, mn, B_X, B_XPREV, capture ? 1 : 0);
+    rc = enqueue_optimize(t, sel, fl);
     if (rc) return rc;
+    if (!fused) launch_status(c, -3, -1, na, mn);
   }
-  launch_status(c, -3, -1, na, -1, PART_A);
-  launch_advance(c, -1, na, p.acceleration, p.num_robots, p.restart_interval, 1);
+  if (!fused) launch_advance(c, -1, na, p.acceleration, p.num_robots, p.restart_interval, 1);
   return 0;
 }
 
@@ -1004,37 +1081,61 @@ int dpgo_team_run(dpgo_team_t *t, int iters) {
   if (sync_descs(t)) return DPGO_ERR;
   const dpgo_params_t &p = t->prm;
   for (auto &a : t->ag) if (!a->has_X) { set_err("team_run before set_initial"); return DPGO_NOT_READY; }
-  const bool graphable = (p.method == DPGO_METHOD_RGD);
+  const bool graphable = (p.method == DPGO_METHOD_RGD) && p.rgd_use_preconditioner;
   if (graphable && !t->graph_valid) {
-    hipGraph_t g = nullptr;
-    HIPC(hipStreamBeginCapture(t->stream, hipStreamCaptureModeThreadLocal));
-    double saved[8]; std::memcpy(saved, t->counters, sizeof saved);
-    const int rc = enqueue_team_iteration(t, true, false);
-    std::memcpy(t->counters, saved, sizeof saved);
-    HIPC(hipStreamEndCapture(t->stream, &g));
-    if (rc) { (void)hipGraphDestroy(g); return rc; }
-    if (t->graph) { (void)hipGraphExecDestroy(t->graph); t->graph = nullptr; }
-    HIPC(hipGraphInstantiate(&t->graph, g, nullptr, nullptr, 0));
-    (void)hipGraphDestroy(g);
+    // the schedule, the counters and the Nesterov scalars live on the device, so every iteration is
+    // the same launch sequence: capture it 1/2/4/8/16 times to amortise the graph-launch gap
+    for (int gi = 0; gi < dpgo_team::NGRAPH; ++gi) {
+      hipGraph_t g = nullptr;
+      HIPC(hipStreamBeginCapture(t->stream, hipStreamCaptureModeThreadLocal));
+      int rc = 0;
+      for (int rep = 0; rep < (1 << gi) && !rc; ++rep) rc = enqueue_team_iteration(t, true, false);
+      HIPC(hipStreamEndCapture(t->stream, &g));
+      if (rc) { (void)hipGraphDestroy(g); return rc; }
+      if (t->graph[gi]) { (void)hipGraphExecDestroy(t->graph[gi]); t->graph[gi] = nullptr; }
+      HIPC(hipGraphInstantiate(&t->graph[gi], g, nullptr, nullptr, 0));
+      (void)hipGraphDestroy(g);
+    }
     t->graph_valid = true;
   }
-  for (int k = 0; k < iters; ++k) {
+  auto account = [&](int sel) {
+    const int n = t->ag[sel]->n, N4 = 4 * n;
+    t->counters[0] += 1; t->counters[1] += 8.0 * N4 * (double)N4;
+    t->counters[2] += 2; t->counters[3] += 2 * spmm_bytes_of(t, *t->ag[sel]);
+  };
+  int k = 0;
+  while (k < iters) {
     const bool restart = p.acceleration && ((t->iter + 2) % p.restart_interval) == 0;
-    const int sel = t->sched[t->iter % t->sched.size()];
+    int batch = 1;
     if (graphable && !restart) {
-      HIPC(hipGraphLaunch(t->graph, t->stream));
-      const int n = t->ag[sel]->n, N4 = 4 * n;
-      if (p.rgd_use_preconditioner) { t->counters[0] += 1; t->counters[1] += 8.0 * N4 * (double)N4; }
-      t->counters[2] += 2;
-      t->counters[3] += 2 * (8.0 * (16.0 * t->ag[sel]->col.size() + 3.0 * p.r * 4 * n) + 4.0 * (t->ag[sel]->col.size() + n + 1));
-      t->ag[sel]->opt_pending_rgd = true;
+      // iterations until the next restart iteration (which runs un-captured)
+      int until = iters - k;
+      if (p.acceleration) {
+        const int to_restart = (p.restart_interval - ((t->iter + 2) % p.restart_interval)) % p.restart_interval;
+        until = std::min(until, to_restart == 0 ? 1 : to_restart);
+      }
+      int gi = 0;
+      while (gi + 1 < dpgo_team::NGRAPH && (2 << gi) <= until) ++gi;
+      batch = 1 << gi;
+      HIPC(hipGraphLaunch(t->graph[gi], t->stream));
+      for (auto &a : t->ag) a->rel_src = 0;
+      for (int q = 0; q < batch; ++q) {
+        const int sel = t->sched[(t->iter + q) % t->sched.size()];
+        account(sel);
+        if (q == batch - 1) { t->ag[sel]->opt_pending_rgd = true; t->ag[sel]->rel_src = 1; }
+      }
     } else {
+      const int sel = t->sched[t->iter % t->sched.size()];
+      for (auto &a : t->ag) a->rel_src = 0;
       const int rc = enqueue_team_iteration(t, false, restart);
       if (rc) return rc;
+      const bool fused = p.method == DPGO_METHOD_RGD && p.rgd_use_preconditioner && !restart;
+      if (fused) t->ag[sel]->rel_src = 1;
     }
-    t->iter++;
-    for (auto &a : t->ag) { a->iter++; if (p.robust_cost_type != DPGO_COST_L2) a->robust_inner_iter++; }
-    t->counters[4] += 1;
+    t->iter += batch;
+    for (auto &a : t->ag) { a->iter += batch; if (p.robust_cost_type != DPGO_COST_L2) a->robust_inner_iter += batch; }
+    t->counters[4] += batch;
+    k += batch;
   }
   return 0;
 }
@@ -1101,9 +1202,15 @@ int dpgo_team_time_kernel(dpgo_team_t *t, int id, int which, int reps, double *a
   const double N4 = 4.0 * n;
   const double vec = 8.0 * r * 4 * n;
   auto launch = [&]() {
-    if (which == 0) launch_precond(c, a->local, n, PM_PLAIN_, B_X, B_GF, B_T2, 0, 0);
-    else if (which == 1) launch_eval(c, a->local, n, B_X, B_T1, B_T2, PART_C);
-    else launch_hess(c, a->local, n, B_X, B_EGRAD, B_GF, B_T2, PART_C);
+    if (which == 0) launch_precond(c, a->local, n, PM_PLAIN_, B_X, B_GF, B_T2, 0, 0, 0.0, 0, t->prm.num_robots);
+    else if (which == 1) launch_eval(c, a->local, n, B_X, B_T1, B_T2, PART_C, eval_opts(t, 0, 0, 0));
+    else if (which == 2) launch_hess(c, a->local, n, B_X, B_EGRAD, B_GF, B_T2, PART_C);
+    else if (which == 3) launch_retract(c, a->local, n, B_X, B_GF, 0.0, B_X2, -1);
+    else if (which == 4) launch_nest_pre(c, -2, -1, (int)t->ag.size(), t->max_n, t->prm.num_robots, 1 << 30);
+    else if (which == 5) launch_noop(c, 1, 64);
+    else if (which == 6) launch_noop(c, 256, 256);
+    else if (which == 7) launch_status(c, -3, -1, (int)t->ag.size(), t->max_n);
+    else launch_copy(c, -3, -1, (int)t->ag.size(), t->max_n, B_X, B_XPREV, 0);
   };
   if (which == 0) *algorithmic_bytes = 8.0 * N4 * N4 + 3.0 * vec;          // M once, v + X in, z out
   else *algorithmic_bytes = 8.0 * (16.0 * a->col.size() + 3.0 * r * 4 * n) + 4.0 * (a->col.size() + n + 1);
