@@ -82,6 +82,9 @@ struct Agent {
   // device storage
   DevBuf<int> d_rowptr, d_col, d_pub_pose, d_pub_ptr, d_idx, d_ell_col, d_trowptr, d_tcol, d_pub_index;
   DevBuf<double> d_qval, d_M, d_vec, d_nbr, d_part, d_scal, d_resid, d_ell_val, d_tval;
+  std::map<int, std::unique_ptr<DevBuf<int>>> d_pubframes, d_nbrslots;  // per neighbour, cached on the device
+  std::map<int, int> n_pubframes, n_nbrslots;
+  DevBuf<double> d_xfer;
   int rel_src = 0;  // where the last |X - XPrev|^2 partials live: 0 PART_D (per 64-pose tile), 1 PART_B[2] (fused RGD)
   DevBuf<SharedEdgeDev> d_se;
   DevBuf<EdgeDev> d_edges;
@@ -326,6 +329,20 @@ int finalize_agent(dpgo_team *t, Agent &a) {
   launch_bsr_to_dense(s, a.d_rowptr.p, a.d_col.p, a.d_qval.p, n, t->prm.precond_shift, A);
   const int fail = dense_spd_inverse(s, A, W, a.d_M.p, N4);
   if (fail != 0) { set_err("dense Cholesky of Q + shift I failed at pivot " + std::to_string(fail)); return DPGO_ERR; }
+
+  // per-neighbour index tables for the packed-slab exchange (a7)
+  size_t max_xfer = 1;
+  for (int nb : a.neighbors) {
+    const std::vector<int> fr = public_ids(a, nb);
+    std::vector<int> slots;
+    for (size_t q = 0; q < a.np.size(); ++q) if (a.np[q].first == nb) slots.push_back((int)q);
+    auto &bf = a.d_pubframes[nb]; if (!bf) bf = std::make_unique<DevBuf<int>>();
+    auto &bs = a.d_nbrslots[nb]; if (!bs) bs = std::make_unique<DevBuf<int>>();
+    if (bf->upload(fr, s) || bs->upload(slots, s)) { set_err("index upload failed"); return DPGO_ERR; }
+    a.n_pubframes[nb] = (int)fr.size(); a.n_nbrslots[nb] = (int)slots.size();
+    max_xfer = std::max(max_xfer, std::max(fr.size(), slots.size()));
+  }
+  if (a.d_xfer.alloc(max_xfer * 4 * r)) { set_err("device allocation failed"); return DPGO_ERR; }
 
   AgentDev &d = a.dev;
   d.id = a.id; d.n = n; d.nb = (int)a.col.size(); d.N4 = N4;
@@ -697,11 +714,12 @@ int dpgo_agent_get_public_poses(dpgo_team_t *t, int id, int nbr, int aux, double
   Agent *a = find_agent(t, id);
   if (!a) return DPGO_ERR;
   if (!a->has_X) return DPGO_NOT_READY;
-  auto f = public_ids(*a, nbr);
-  const size_t B = (size_t)4 * t->prm.r;
-  const double *src = a->dev.buf[aux ? B_Y : B_X];
-  for (size_t k = 0; k < f.size(); ++k)
-    HIPC(hipMemcpyAsync(poses + k * B, src + f[k] * B, sizeof(double) * B, hipMemcpyDeviceToHost, t->stream));
+  if (sync_descs(t)) return DPGO_ERR;
+  auto it = a->d_pubframes.find(nbr);
+  if (it == a->d_pubframes.end()) return 0;
+  const int cnt = a->n_pubframes[nbr];
+  launch_pack(t->ctx(), a->dev.buf[aux ? B_Y : B_X], it->second->p, cnt, a->d_xfer.p);
+  HIPC(hipMemcpyAsync(poses, a->d_xfer.p, sizeof(double) * (size_t)cnt * 4 * t->prm.r, hipMemcpyDeviceToHost, t->stream));
   HIPC(hipStreamSynchronize(t->stream));
   return 0;
 }
@@ -726,26 +744,22 @@ int dpgo_agent_pack_public_poses_device(dpgo_team_t *t, int id, int nbr, int aux
   Agent *a = find_agent(t, id);
   if (!a) return DPGO_ERR;
   if (!a->has_X) return DPGO_NOT_READY;
-  auto f = public_ids(*a, nbr);
-  if (a->d_idx.alloc(f.size())) return DPGO_ERR;
-  // frames table is tiny; stream-ordered upload keeps the call asynchronous
-  HIPC(hipMemcpyAsync(a->d_idx.p, f.data(), sizeof(int) * f.size(), hipMemcpyHostToDevice, t->stream));
-  HIPC(hipStreamSynchronize(t->stream));
-  launch_pack(t->ctx(), a->dev.buf[aux ? B_Y : B_X], a->d_idx.p, (int)f.size(), dev_out);
-  return (int)f.size();
+  if (sync_descs(t)) return DPGO_ERR;
+  auto it = a->d_pubframes.find(nbr);
+  if (it == a->d_pubframes.end()) return 0;
+  launch_pack(t->ctx(), a->dev.buf[aux ? B_Y : B_X], it->second->p, a->n_pubframes[nbr], dev_out);  // asynchronous
+  return a->n_pubframes[nbr];
 }
 
 int dpgo_agent_unpack_neighbor_poses_device(dpgo_team_t *t, int id, int nbr, int aux, const double *dev_in) {
   Agent *a = find_agent(t, id);
   if (!a) return DPGO_ERR;
   if (sync_descs(t)) return DPGO_ERR;
-  std::vector<int> slots;
-  for (size_t q = 0; q < a->np.size(); ++q) if (a->np[q].first == nbr) { slots.push_back((int)q); a->np_has[aux ? 1 : 0][q] = 1; }
-  if (a->d_idx.alloc(slots.size())) return DPGO_ERR;
-  HIPC(hipMemcpyAsync(a->d_idx.p, slots.data(), sizeof(int) * slots.size(), hipMemcpyHostToDevice, t->stream));
-  HIPC(hipStreamSynchronize(t->stream));
-  launch_unpack(t->ctx(), a->dev.nbr[aux ? 1 : 0], a->d_idx.p, (int)slots.size(), dev_in);
-  return (int)slots.size();
+  auto it = a->d_nbrslots.find(nbr);
+  if (it == a->d_nbrslots.end()) return 0;
+  for (size_t q = 0; q < a->np.size(); ++q) if (a->np[q].first == nbr) a->np_has[aux ? 1 : 0][q] = 1;
+  launch_unpack(t->ctx(), a->dev.nbr[aux ? 1 : 0], it->second->p, a->n_nbrslots[nbr], dev_in);  // asynchronous
+  return a->n_nbrslots[nbr];
 }
 
 int dpgo_agent_iterate(dpgo_team_t *t, int id, int do_optimization) {

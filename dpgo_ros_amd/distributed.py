@@ -1,0 +1,156 @@
+"""One process per GPU: the synchronous RBCD schedule across ranks with RCCL point-to-point.
+
+Replaces the ROS transport of the reference for this path:
+  * `PublicPoses` messages (msg/PublicPoses.msg, src/PGOAgentROS.cpp:662-690 send, :1255-1284 receive)
+    become packed r x 4 fp64 slabs sent with `torch.distributed` isend/irecv (backend "nccl" = RCCL
+    over xGMI; "gloo" in the CPU tests);
+  * the UPDATE token (src/PGOAgentROS.cpp:443-504, 1161-1189) needs no message: the schedule is a
+    deterministic function of the global iteration counter that every rank evaluates locally.
+Exchange is pull-before-use: right before agent `sel` optimizes, each of its neighbours' owners
+sends the neighbour's current public poses (X, and the auxiliary Y sequence under acceleration);
+this equals the reference's staleness gate with maxDelayedIterations = 0 (:136-149).
+
+The module is transport + schedule only.  The compute backend is any object with
+    iterate(agent, do_opt), pack(agent, nbr, aux) -> tensor, unpack(agent, nbr, aux, tensor),
+    pull_local(agent), partial_cost() -> float
+(`HipBackend` below for the product; the CPU tests plug the oracle in through the same protocol).
+"""
+import numpy as np
+
+
+def topology(meas, num_robots):
+    """neighbour sets and public-pose counts, derived from the (partitioned) measurement list that
+    every rank holds.  npub[(a, b)] = number of distinct poses of a that appear in edges with b."""
+    nbrs = {a: set() for a in range(num_robots)}
+    pub = {}
+    for e in meas:
+        a, b = int(e["r1"]), int(e["r2"])
+        if a == b:
+            continue
+        nbrs[a].add(b)
+        nbrs[b].add(a)
+        pub.setdefault((a, b), set()).add(int(e["p1"]))
+        pub.setdefault((b, a), set()).add(int(e["p2"]))
+    return {a: sorted(s) for a, s in nbrs.items()}, {k: len(v) for k, v in pub.items()}
+
+
+def owner_of(agent, world):
+    return agent % world
+
+
+class HipBackend:
+    """local agents on this rank's GPU, through the C-ABI (dpgo_ros_amd.capi)."""
+
+    def __init__(self, meas, params, local_ids, device, torch_module, host_staging=False):
+        """host_staging: bounce the slabs through pinned host tensors (for the `gloo` transport, which
+        cannot move device tensors; used by the 2-process single-GPU test).  RCCL runs use False."""
+        from . import capi
+        self.torch = torch_module
+        self.r = params.r
+        self.device = device
+        self.host_staging = host_staging
+        stream = torch_module.cuda.current_stream().cuda_stream
+        self.team = capi.Team.from_measurements(meas, params, device=device, local_ids=local_ids, stream=stream) \
+            if local_ids else None
+        self._buf = {}
+
+    def buffer(self, key, count):
+        if key not in self._buf:
+            self._buf[key] = self.torch.empty(count * 4 * self.r, dtype=self.torch.float64, device="cuda")
+        return self._buf[key]
+
+    def iterate(self, agent, do_opt):
+        return self.team.agents[agent].iterate(do_opt)
+
+    def pack(self, agent, nbr, aux, count):
+        t = self.buffer(("s", agent, nbr, aux), count)
+        self.team.agents[agent].pack_public_poses_device(nbr, aux, t.data_ptr())
+        if self.host_staging:
+            return t.cpu()  # synchronises the (current) stream the pack kernel ran on
+        return t
+
+    def recv_buffer(self, agent, nbr, aux, count):
+        if self.host_staging:
+            key = ("rh", agent, nbr, aux)
+            if key not in self._buf:
+                self._buf[key] = self.torch.empty(count * 4 * self.r, dtype=self.torch.float64)
+            return self._buf[key]
+        return self.buffer(("r", agent, nbr, aux), count)
+
+    def unpack(self, agent, nbr, aux, tensor):
+        if self.host_staging:
+            d = self.buffer(("r", agent, nbr, aux), tensor.numel() // (4 * self.r))
+            d.copy_(tensor)
+            tensor = d
+        self.team.agents[agent].unpack_neighbor_poses_device(nbr, aux, tensor.data_ptr())
+
+    def pull_local(self, agent):
+        self.team.agents[agent].pull_local()
+
+    def partial_cost(self):
+        return self.team.cost() if self.team is not None else 0.0
+
+    def close(self):
+        if self.team is not None:
+            self.team.close()
+
+
+class DistributedRBCD:
+    def __init__(self, dist, backend, meas, num_robots, acceleration, rank, world, schedule=None):
+        self.dist, self.be = dist, backend
+        self.N, self.rank, self.world = num_robots, rank, world
+        self.accel = bool(acceleration)
+        self.nbrs, self.npub = topology(meas, num_robots)
+        self.owner = [owner_of(a, world) for a in range(num_robots)]
+        self.mine = [a for a in range(num_robots) if self.owner[a] == rank]
+        self.schedule = list(range(num_robots)) if schedule is None else list(schedule)
+        self.k = 0
+
+    def exchange_to(self, sel, seqs=(0, 1)):
+        """neighbours of `sel` that live on other ranks send their public poses to sel's rank."""
+        d = self.dist
+        ops, todo = [], []
+        rs = self.owner[sel]
+        for b in self.nbrs[sel]:
+            rb = self.owner[b]
+            if rb == rs:
+                continue
+            cnt = self.npub[(b, sel)]
+            for aux in seqs:
+                if self.rank == rb:
+                    ops.append(d.P2POp(d.isend, self.be.pack(b, sel, aux, cnt), rs))
+                if self.rank == rs:
+                    t = self.be.recv_buffer(sel, b, aux, cnt)
+                    ops.append(d.P2POp(d.irecv, t, rb))
+                    todo.append((b, aux, t))
+        if ops:
+            for w in d.batch_isend_irecv(ops):
+                w.wait()
+        for b, aux, t in todo:
+            self.be.unpack(sel, b, aux, t)
+        if self.rank == rs:
+            self.be.pull_local(sel)
+
+    def exchange_all(self):
+        for a in range(self.N):
+            self.exchange_to(a)
+
+    def step(self):
+        """one global RBCD iteration (src/PGOAgentROS.cpp:129-220): everyone but the token holder
+        calls iterate(false) first, then the token holder receives its neighbours' poses and optimizes."""
+        sel = self.schedule[self.k % len(self.schedule)]
+        for a in self.mine:
+            if a != sel:
+                self.be.iterate(a, False)
+        self.exchange_to(sel, seqs=(0, 1) if self.accel else (0,))
+        if self.owner[sel] == self.rank:
+            self.be.iterate(sel, True)
+        self.k += 1
+        return sel
+
+    def global_cost(self, torch_module, device):
+        """f of the concatenated iterate: owned-edge partial sums, one 1-double all-reduce."""
+        self.exchange_all()
+        t = torch_module.tensor([self.be.partial_cost()], dtype=torch_module.float64, device=device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return float(t.item())

@@ -1,0 +1,137 @@
+"""N > 1 path on CPU: world_size-2 `gloo` run of dpgo_ros_amd.distributed (ownership, neighbour
+topology, pull-before-use exchange order, schedule) with the CPU oracle plugged in as the compute
+backend.  The transport must not change a single bit relative to the single-process oracle team."""
+import os
+import socket
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+from tests.util import DATA, ROOT, load
+
+
+class OracleBackend:
+    """test-only compute backend for DistributedRBCD: oracle agents + CPU tensors."""
+
+    def __init__(self, meas, params, local_ids, T, Y, offsets):
+        import torch
+        from oracle import oracle as O
+        self.torch, self.O, self.r = torch, O, params.r
+        self.agents = {}
+        for a in local_ids:
+            ag = O.Agent(a, params)
+            ag.add_measurements(meas)
+            ag.set_X(O.lift(T[12 * offsets[a]:12 * (offsets[a] + ag.n)], ag.n, Y, params.r))
+            self.agents[a] = ag
+        self._buf = {}
+
+    def iterate(self, agent, do_opt):
+        return self.agents[agent].iterate(do_opt)
+
+    def pack(self, agent, nbr, aux, count):
+        ids, P = self.agents[agent].get_public_poses(nbr, bool(aux))
+        assert len(ids) == count
+        return self.torch.from_numpy(P.copy())
+
+    def recv_buffer(self, agent, nbr, aux, count):
+        return self._buf.setdefault((agent, nbr, aux), self.torch.empty(count * 4 * self.r, dtype=self.torch.float64))
+
+    def unpack(self, agent, nbr, aux, tensor):
+        ag = self.agents[agent]
+        ag.update_neighbor_poses(nbr, ag.neighbor_pose_ids(nbr), tensor.numpy(), bool(aux))
+
+    def pull_local(self, agent):
+        ag = self.agents[agent]
+        for b in ag.neighbors():
+            if b in self.agents:
+                for aux in (False, True):
+                    ids, P = self.agents[b].get_public_poses(agent, aux)
+                    ag.update_neighbor_poses(b, ids, P, aux)
+
+    def partial_cost(self):
+        f = 0.0
+        for a, ag in self.agents.items():
+            for m in ag.measurements():
+                if m["r1"] != m["r2"] and min(m["r1"], m["r2"]) != a:
+                    continue
+                ok, res = ag.compute_residual(m)
+                assert ok
+                f += 0.5 * m["weight"] * res * res
+        return f
+
+
+def _worker(rank, world, port, cfg, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from dpgo_ros_amd.distributed import DistributedRBCD, owner_of
+    from oracle import oracle as O
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ds, N, kw, iters = cfg
+    m, mp, n = load(ds, N)
+    params = O.default_params(r=5, num_robots=N, **kw)
+    T, Y = O.odometry_init(m, n), O.fixed_stiefel(5)
+    per = n // N
+    offsets = {a: a * per for a in range(N)}
+    mine = [a for a in range(N) if owner_of(a, world) == rank]
+    be = OracleBackend(mp, params, mine, T, Y, offsets)
+    drv = DistributedRBCD(dist, be, mp, N, kw.get("acceleration", 0), rank, world)
+    drv.exchange_all()
+    costs = []
+    for k in range(iters):
+        drv.step()
+        if k % 3 == 2:
+            costs.append(drv.global_cost(torch, "cpu"))
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), costs=np.array(costs),
+             **{"X%d" % a: be.agents[a].get_X() for a in mine})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+CASES = [
+    ("smallGrid3D", 3, dict(method=0, gradnorm_tol=1e-2), 9),
+    ("smallGrid3D", 3, dict(method=1, acceleration=1, rgd_stepsize=0.2, restart_interval=4), 12),
+    ("smallGrid3D", 2, dict(method=0, acceleration=1, restart_interval=5, gradnorm_tol=1e-2), 8),
+]
+
+
+@pytest.mark.parametrize("cfg", CASES)
+def test_two_rank_gloo_run_is_bitwise_the_single_process_schedule(cfg):
+    import torch.multiprocessing as mp_
+    from oracle import oracle as O
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    with tempfile.TemporaryDirectory() as d:
+        mp_.spawn(_worker, args=(2, port, cfg, d), nprocs=2, join=True)
+        outs = [np.load(os.path.join(d, "rank%d.npz" % r)) for r in range(2)]
+        ds, N, kw, iters = cfg
+        m, mp, n = load(ds, N)
+        ref = O.Team(mp, n, O.default_params(r=5, num_robots=N, **kw))
+        ref.set_initial(O.odometry_init(m, n), O.fixed_stiefel(5))
+        costs = []
+        for k in range(iters):
+            ref.iterate()
+            if k % 3 == 2:
+                costs.append(ref.cost())
+        for a in range(N):
+            Xa = outs[a % 2]["X%d" % a]
+            assert np.array_equal(Xa, ref.agents[a].get_X()), "agent %d differs" % a
+        for r in range(2):  # both ranks see the same all-reduced cost
+            assert np.allclose(outs[r]["costs"], costs, rtol=1e-13, atol=0)
+
+
+def test_topology_matches_agent_bookkeeping():
+    from dpgo_ros_amd.distributed import topology
+    from oracle import oracle as O
+    m, mp, n = load("sphere2500", 5)
+    nbrs, npub = topology(mp, 5)
+    t = O.Team(mp, n, O.default_params(r=5, num_robots=5))
+    for a in range(5):
+        assert nbrs[a] == t.agents[a].neighbors()
+        for b in nbrs[a]:
+            assert npub[(a, b)] == len(t.agents[a].public_pose_ids(b)) == len(t.agents[b].neighbor_pose_ids(a))
+    assert nbrs == {0: [1], 1: [0, 2], 2: [1, 3], 3: [2, 4], 4: [3]}  # chain
