@@ -69,7 +69,7 @@ dpgo_agent_num_poses dpgo_agent_num_measurements dpgo_agent_get_neighbors dpgo_a
 dpgo_agent_neighbor_pose_ids dpgo_agent_set_X dpgo_agent_get_X dpgo_agent_get_public_poses
 dpgo_agent_update_neighbor_poses dpgo_agent_pack_public_poses_device
 dpgo_agent_unpack_neighbor_poses_device dpgo_agent_iterate dpgo_agent_get_status
-dpgo_agent_get_opt_result dpgo_agent_iteration_number dpgo_agent_publish_requested
+dpgo_agent_get_opt_result dpgo_agent_iteration_number dpgo_agent_publish_requested dpgo_agent_set_iteration_number
 dpgo_agent_build_problem dpgo_agent_eval dpgo_agent_hessvec dpgo_agent_precondition dpgo_agent_get_Q
 dpgo_agent_get_G dpgo_project_manifold dpgo_tangent_project dpgo_retract dpgo_agent_compute_residual
 dpgo_agent_robust_weight dpgo_agent_update_measurement_weights dpgo_agent_set_measurement_weight

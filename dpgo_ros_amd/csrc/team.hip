@@ -811,6 +811,19 @@ int dpgo_agent_iteration_number(dpgo_team_t *t, int id) {
   return a ? a->iter : DPGO_ERR;
 }
 
+int dpgo_agent_set_iteration_number(dpgo_team_t *t, int id, int iteration) {
+  Agent *a = find_agent(t, id);
+  if (!a) return DPGO_ERR;
+  a->iter = iteration;
+  if (a->has_X) {
+    NestState ns{};
+    HIPC(hipMemcpy(&ns, a->dev.nest, sizeof ns, hipMemcpyDeviceToHost));
+    ns.iter = iteration;
+    HIPC(hipMemcpy(a->dev.nest, &ns, sizeof ns, hipMemcpyHostToDevice));
+  }
+  return DPGO_OK;
+}
+
 int dpgo_agent_publish_requested(dpgo_team_t *t, int id, int clear) {
   Agent *a = find_agent(t, id);
   if (!a) return DPGO_ERR;

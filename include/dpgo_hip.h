@@ -121,6 +121,7 @@ int dpgo_agent_get_status(dpgo_team_t *t, int id, dpgo_status_t *s);     /* getS
 int dpgo_agent_get_opt_result(dpgo_team_t *t, int id, dpgo_opt_result_t *r); /* :169-172 */
 int dpgo_agent_iteration_number(dpgo_team_t *t, int id);                 /* iteration_number() :139 */
 int dpgo_agent_publish_requested(dpgo_team_t *t, int id, int clear);     /* mPublishPublicPosesRequested :109-112 */
+int dpgo_agent_set_iteration_number(dpgo_team_t *t, int id, int iteration); /* mIterationNumber = ... (RECOVER, :1196) */
 
 /* ---- QuadraticProblem surface for parity (f, EucGrad, RieGrad, Hessian, PreConditioner) ---- */
 int dpgo_agent_build_problem(dpgo_team_t *t, int id, int aux);

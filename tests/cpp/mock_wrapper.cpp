@@ -1,0 +1,102 @@
+// mock_wrapper.cpp -- drives the DPGO:: facade exactly the way PGOAgentROS does:
+//   add measurements -> initialize -> lifting matrix -> public poses -> iterate(true/false) -> status.
+// ROS is absent from this image, so this subclass stands in for `class PGOAgentROS : public PGOAgent`
+// and touches the same protected members (src/PGOAgentROS.cpp).
+// Usage: mock_wrapper <g2o> <num_robots> <iterations> [accel]   -> prints one cost line per iteration.
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include <vector>
+
+#include <DPGO/PGOAgent.h>
+
+using namespace DPGO;
+
+class MockAgentROS : public PGOAgent {
+ public:
+  MockAgentROS(unsigned id, const PGOAgentParameters &p) : PGOAgent(id, p) {}
+  // protected members, as the wrapper uses them
+  bool publishRequested() { const bool v = mPublishPublicPosesRequested; mPublishPublicPosesRequested = false; return v; }
+  PGOAgentState state() const { return mState; }
+  double relChange() const { return mStatus.relativeChange; }
+  const ROPTResult &optResult() const { return mLocalOptResult; }
+  std::shared_ptr<PoseGraph> graph() { return mPoseGraph; }
+  void setIteration(unsigned k) { mIterationNumber = k; }
+  bool hasYLift() const { return YLift.has_value(); }
+  void reset() override { PGOAgent::reset(); }
+};
+
+static void publish(std::vector<std::unique_ptr<MockAgentROS>> &team, unsigned b, bool aux) {
+  for (unsigned nbr : team[b]->getNeighbors()) {
+    PoseDict map;
+    if (!(aux ? team[b]->getAuxSharedPoseDictWithNeighbor(map, nbr) : team[b]->getSharedPoseDictWithNeighbor(map, nbr))) continue;
+    if (aux) team[nbr]->updateAuxNeighborPoses(b, map); else team[nbr]->updateNeighborPoses(b, map);
+  }
+}
+
+static double global_cost(std::vector<std::unique_ptr<MockAgentROS>> &team) {
+  double f = 0;
+  for (auto &a : team)
+    for (auto *m : a->graph()->allMeasurements()) {
+      if (m->r1 != m->r2 && std::min(m->r1, m->r2) != a->getID()) continue;
+      double res = 0;
+      if (!a->computeMeasurementResidual(*m, &res)) { std::fprintf(stderr, "residual unavailable\n"); std::exit(2); }
+      f += 0.5 * m->weight * res * res;
+    }
+  return f;
+}
+
+int main(int argc, char **argv) {
+  if (argc < 4) return 1;
+  const unsigned N = (unsigned)std::atoi(argv[2]);
+  const int iters = std::atoi(argv[3]);
+  const bool accel = argc > 4 && std::atoi(argv[4]) != 0;
+  size_t num_poses = 0;
+  std::vector<RelativeSEMeasurement> dataset = read_g2o_file(argv[1], num_poses);
+  PGOAgentParameters params(3, 5, N);
+  params.localOptimizationParams.method = ROptParameters::ROptMethod::RTR;
+  params.localOptimizationParams.gradnorm_tol = 1e-2;
+  params.acceleration = accel;
+  params.restartInterval = 7;
+  params.relChangeTol = 0.2;
+  std::vector<std::unique_ptr<MockAgentROS>> team;
+  for (unsigned k = 0; k < N; ++k) team.emplace_back(new MockAgentROS(k, params));
+  // src/PGODatasetPublisherNode.cpp:84-135 partition; every robot ends with all edges incident to it
+  const unsigned per = (unsigned)num_poses / N;
+  for (const auto &mIn : dataset) {
+    const unsigned ra = std::min<unsigned>(mIn.p1 / per, N - 1), rb = std::min<unsigned>(mIn.p2 / per, N - 1);
+    RelativeSEMeasurement m(ra, rb, mIn.p1 - ra * per, mIn.p2 - rb * per, mIn.R, mIn.t, mIn.kappa, mIn.tau);
+    team[ra]->addMeasurement(m);
+    if (rb != ra) team[rb]->addMeasurement(m);
+  }
+  // lifting matrix from robot 0 (:404, :928); local initialisation; robot 0 defines the global frame (:348-353)
+  Matrix YLift;
+  if (!team[0]->getLiftingMatrix(YLift)) return 3;
+  for (unsigned k = 0; k < N; ++k) { team[k]->setLiftingMatrix(YLift); team[k]->initialize(); }
+  team[0]->initializeInGlobalFrame(Pose(3));
+  for (unsigned round = 0; round < N; ++round)  // frame alignment spreads along the chain (:1276)
+    for (unsigned b = 0; b < N; ++b)
+      if (team[b]->state() == PGOAgentState::INITIALIZED) { publish(team, b, false); if (accel) publish(team, b, true); }
+  for (unsigned k = 0; k < N; ++k) if (team[k]->state() != PGOAgentState::INITIALIZED) { std::fprintf(stderr, "robot %u not initialised\n", k); return 4; }
+  Matrix anchor;
+  if (!team[0]->getSharedPose(0, anchor)) return 5;
+  for (auto &a : team) a->setGlobalAnchor(anchor);  // :431-438, :932-939
+  std::printf("init cost %.12e\n", global_cost(team));
+  for (int k = 0; k < iters; ++k) {
+    const unsigned sel = (unsigned)k % N;  // RoundRobin token (:464-473)
+    for (unsigned b = 0; b < N; ++b)
+      if (b != sel) { team[b]->iterate(false); if (team[b]->publishRequested()) { publish(team, b, false); if (accel) publish(team, b, true); } }
+    if (!team[sel]->iterate(true)) { std::fprintf(stderr, "iterate failed\n"); return 6; }
+    if (team[sel]->publishRequested()) { publish(team, sel, false); if (accel) publish(team, sel, true); }
+    for (auto &a : team) for (auto &b : team) if (a != b) a->setNeighborStatus(b->getStatus());
+    std::printf("iter %d robot %u cost %.12e relchange %.6e fdec %.3e terminate %d\n", k + 1, sel, global_cost(team),
+                team[sel]->relChange(), team[sel]->optResult().fInit - team[sel]->optResult().fOpt, (int)team[0]->shouldTerminate());
+  }
+  PoseArray T(3, 1);
+  if (!team[N - 1]->getTrajectoryInGlobalFrame(T)) return 7;
+  const Matrix R0 = T.rotation(0);
+  double orth = 0;
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { double s = 0; for (int k = 0; k < 3; ++k) s += R0(k, i) * R0(k, j); orth += std::abs(s - (i == j)); }
+  std::printf("trajectory poses %u orthogonality_defect %.3e\n", T.n(), orth);
+  return 0;
+}

@@ -1,0 +1,97 @@
+"""The C++ facade `namespace DPGO` (include/DPGO/*.h) driven by a mock of PGOAgentROS
+(tests/cpp/mock_wrapper.cpp).  CPU: it compiles against the C-ABI; GPU: its iterates follow the
+oracle started from the same (replicated) multi-robot initialisation."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.util import DATA, ROOT, load
+
+BIN = os.path.join(ROOT, "tests", "cpp", "mock_wrapper")
+
+
+def _compile():
+    lib = os.path.join(ROOT, "dpgo_ros_amd")
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "cpp", "mock_wrapper.cpp"), "-o", BIN, "-L" + lib, "-ldpgo_hip", "-Wl,-rpath," + lib]
+    subprocess.check_call(cmd)
+
+
+def test_facade_compiles_against_the_c_abi():
+    _compile()
+    assert os.path.exists(BIN)
+    hdr = open(os.path.join(ROOT, "include", "DPGO", "PGOAgent.h")).read()
+    for name in ("iterate", "addMeasurement", "getSharedPoseDictWithNeighbor", "getAuxSharedPoseDictWithNeighbor",
+                 "updateNeighborPoses", "updateAuxNeighborPoses", "getLiftingMatrix", "setLiftingMatrix", "setGlobalAnchor",
+                 "initializeInGlobalFrame", "getTrajectoryInGlobalFrame", "getPoseInGlobalFrame",
+                 "getNeighborPoseInGlobalFrame", "shouldTerminate", "shouldUpdateMeasurementWeights",
+                 "updateMeasurementWeights", "setMeasurementWeight", "computeMeasurementResidual", "setNeighborStatus",
+                 "hasNeighborStatus", "getNeighborStatus", "isRobotActive", "setRobotActive", "numActiveRobots",
+                 "isRobotInitialized", "mPublishPublicPosesRequested", "mPublishAsynchronousRequested", "mLocalOptResult",
+                 "mTeamStatus", "mWeightUpdateCount", "mRobustOptInnerIter", "mIterationNumber", "neighborPoseDict",
+                 "globalAnchor", "YLift", "mRobustCost", "mPoseGraph", "mState", "mParams"):
+        assert re.search(r"\b%s\b" % name, hdr), name  # SURVEY App. A surface
+
+
+def _replicated_initial_guess(m, mp, n, N):
+    """the facade's initialisation: per-robot odometry chains, robot 0 = world frame, robot k aligned
+    through its first shared loop closure with an already initialised neighbour (chain order)."""
+    per = n // N
+    T = np.zeros((n, 3, 4))
+    start = [k * per for k in range(N)] + [n]
+    local = {}
+    for k in range(N):
+        odo = mp[(mp["r1"] == k) & (mp["r2"] == k) & (mp["p1"] + 1 == mp["p2"])].copy()
+        odo["r1"] = 0; odo["r2"] = 0
+        nk = start[k + 1] - start[k]
+        local[k] = O.odometry_init(odo, nk).reshape(nk, 4, 3).transpose(0, 2, 1)  # (i, row, col)
+    def compose(A, B):
+        C = np.zeros((3, 4)); C[:, :3] = A[:, :3] @ B[:, :3]; C[:, 3] = A[:, :3] @ B[:, 3] + A[:, 3]; return C
+    def inv(A):
+        C = np.zeros((3, 4)); C[:, :3] = A[:, :3].T; C[:, 3] = -A[:, :3].T @ A[:, 3]; return C
+    world = {0: np.hstack([np.eye(3), np.zeros((3, 1))])}
+    for _ in range(N):
+        for k in range(N):
+            if k in world:
+                continue
+            sh = mp[((mp["r1"] == k) | (mp["r2"] == k)) & (mp["r1"] != mp["r2"])]
+            for e in sh:
+                out = e["r1"] == k
+                nb = int(e["r2"] if out else e["r1"])
+                if nb not in world:
+                    continue
+                Tm = np.hstack([e["R"].reshape(3, 3), e["t"].reshape(3, 1)])
+                Tn = compose(world[nb], local[nb][int(e["p2"] if out else e["p1"])])
+                Tmine = compose(Tn, inv(Tm)) if out else compose(Tn, Tm)
+                world[k] = compose(Tmine, inv(local[k][int(e["p1"] if out else e["p2"])]))
+                break
+    for k in range(N):
+        for i in range(start[k + 1] - start[k]):
+            T[start[k] + i] = compose(world[k], local[k][i])
+    return T.transpose(0, 2, 1).reshape(-1)  # 3 x 4 column-major per pose
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("accel", [0, 1])
+def test_mock_wrapper_follows_the_oracle(accel):
+    _compile()
+    N, iters = 2, 12
+    out = subprocess.check_output([BIN, os.path.join(DATA, "smallGrid3D.g2o"), str(N), str(iters), str(accel)], text=True)
+    costs = [float(x) for x in re.findall(r"iter \d+ robot \d+ cost (\S+)", out)]
+    init = float(re.search(r"init cost (\S+)", out).group(1))
+    assert len(costs) == iters
+    m, mp, n = load("smallGrid3D", N)
+    T = _replicated_initial_guess(m, mp, n, N)
+    ref = O.Team(mp, n, O.default_params(r=5, num_robots=N, method=O.METHOD_RTR, gradnorm_tol=1e-2, acceleration=accel,
+                                         restart_interval=7, rel_change_tol=0.2, rtr_max_radius=500.0))
+    ref.set_initial(T, O.fixed_stiefel(5))
+    assert abs(init - ref.cost()) <= 1e-9 * ref.cost()
+    for k in range(iters):
+        ref.iterate()
+        assert abs(costs[k] - ref.cost()) <= 1e-8 * ref.cost(), k
+    defect = float(re.search(r"orthogonality_defect (\S+)", out).group(1))
+    assert defect < 1e-9
