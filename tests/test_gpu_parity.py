@@ -189,3 +189,111 @@ def test_two_processes_one_gpu_exchange_through_device_slabs():
     for a in range(N):
         assert np.abs(outs[a % 2]["X%d" % a] - ref.agents[a].get_X()).max() < 1e-8
     assert abs(float(outs[0]["cost"]) - ref.cost()) <= 1e-9 * ref.cost()
+
+
+def _pair_from(meas_partitioned, n_total, N, T, **kw):
+    ph, po = params_pair(r=5, num_robots=N, **kw)
+    th = capi.Team.from_measurements(meas_partitioned.view(capi.MEAS_DTYPE), ph)
+    to = O.Team(meas_partitioned, n_total, po)
+    Y = O.fixed_stiefel(5)
+    th.set_initial(T, Y)
+    to.set_initial(T, Y)
+    return th, to
+
+
+def test_gnc_tls_reweighting_rounds():
+    """a8: residual kernel -> GNC-TLS weights (owner = lower-ID endpoint) -> weight hand-over to the
+    higher-ID endpoint (optionally rounded to float32 as on the wire, msg/RelativeMeasurementWeights.msg:8)
+    -> Q / G / dense preconditioner rebuilt; compared with the oracle after every UPDATE_WEIGHT round."""
+    from tests.util import add_outliers
+    N = 3
+    m, _, n = load("smallGrid3D", 1)
+    mo = add_outliers(m, n, frac=0.1, seed=0)
+    mp = O.partition(mo, n, N)
+    T = O.odometry_init(mo, n)
+    for f32 in (0, 1):
+        kw = dict(method=capi.METHOD_RTR, gradnorm_tol=1e-2, robust_cost_type=capi.COST_GNC_TLS, gnc_barc=3.0,
+                  gnc_mu_step=2.0, gnc_init_mu=1e-2, robust_opt_num_weight_updates=3, robust_opt_inner_iters=6,
+                  weights_as_float32=f32)
+        th, to = _pair_from(mp, n, N, T, **kw)
+        for rnd in range(3):
+            th.run(6)
+            for _ in range(6):
+                to.iterate()
+            assert np.abs(th.global_X() - to.global_X()).max() < 1e-7, rnd
+            ch_h, ch_o = th.update_weights(), to.update_weights()
+            assert ch_h == ch_o
+            for a in range(N):
+                wh, wo = th.agents[a].measurements(), to.agents[a].measurements()
+                assert np.array_equal(wh["p1"], wo["p1"]) and np.array_equal(wh["fixed_weight"], wo["fixed_weight"])
+                assert np.abs(wh["weight"] - wo["weight"]).max() < 1e-7
+                assert 0 < (wo["weight"] < 1).sum()  # the outliers are being down-weighted
+        th.run(4)
+        for _ in range(4):
+            to.iterate()
+        assert np.abs(th.global_X() - to.global_X()).max() < 1e-6
+        assert abs(th.cost() - to.cost()) <= 1e-7 * abs(to.cost())
+        th.close()
+
+
+@pytest.mark.parametrize("mode,accel", [(capi.WEIGHT_WRAPPER, 0), (capi.WEIGHT_LIBRARY, 1)])
+def test_tunnels_eight_agents(mode, accel):
+    """BASELINE configs[4] inputs (8 robots, all-to-all neighbours, 700-1000 shared edges per agent) under
+    the synchronous schedule; per-robot odometry chains as the (deliberately crude) common initial guess."""
+    from tests.util import load_tunnels
+    m = load_tunnels(mode)
+    N = 8
+    if mode == capi.WEIGHT_LIBRARY:
+        m = m.copy(); m["weight"] = 1.0
+    nk = [0] * N
+    for e in m:
+        nk[e["r1"]] = max(nk[e["r1"]], int(e["p1"]) + 1)
+        nk[e["r2"]] = max(nk[e["r2"]], int(e["p2"]) + 1)
+    Ts = []
+    for k in range(N):
+        odo = m[(m["r1"] == k) & (m["r2"] == k) & (m["p1"] + 1 == m["p2"])].copy()
+        odo["r1"] = 0; odo["r2"] = 0
+        Ts.append(O.odometry_init(odo, nk[k]))
+    T = np.concatenate(Ts)
+    kw = dict(method=capi.METHOD_RTR, gradnorm_tol=1e-2, acceleration=accel, restart_interval=11)
+    th, to = _pair_from(m, sum(nk), N, T, **kw)
+    assert [th.agents[k].n for k in range(N)] == nk
+    assert all(len(th.agents[k].neighbors()) == 7 for k in range(N))
+    f0 = to.cost()
+    th.run(16)
+    for _ in range(16):
+        to.iterate()
+    assert np.abs(th.global_X() - to.global_X()).max() < 1e-6
+    assert abs(th.cost() - to.cost()) <= 1e-8 * abs(to.cost()) and to.cost() < f0
+    th.close()
+
+
+def test_long_rows_take_the_csr_tail():
+    """a pose with more than 8 blocks in its row exercises the CSR tail behind the 8-slot ELL part."""
+    rng = np.random.default_rng(5)
+    n = 40
+    pairs = [(i, i + 1) for i in range(n - 1)] + [(3, j) for j in range(6, 30, 2)] + [(j, 17) for j in range(20, 38, 3)]
+    m = np.zeros(len(pairs), dtype=O.MEAS_DTYPE)
+    for k, (i, j) in enumerate(pairs):
+        Q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+        Q *= np.sign(np.linalg.det(Q))
+        m[k]["p1"], m[k]["p2"] = i, j
+        m[k]["R"], m[k]["t"] = Q.reshape(-1), rng.standard_normal(3)
+        m[k]["kappa"], m[k]["tau"], m[k]["weight"] = 30.0 + k, 7.0, 1.0
+    T = O.odometry_init(m, n)
+    th, to = _pair_from(m, n, 1, T, method=capi.METHOD_RTR, gradnorm_tol=1e-6, rtr_iterations=5)
+    ah, ao = th.agents[0], to.agents[0]
+    ah.build_problem(False); ao.build_problem(False)
+    rp, _, _ = ah.get_Q()
+    assert np.diff(rp).max() > 8
+    X = random_point(rng, 5, n)
+    fh, egh, rgh = ah.eval(X)
+    fo, ego, rgo = ao.eval(X)
+    assert abs(fh - fo) <= 1e-12 * abs(fo) and relerr(egh, ego) < 1e-13 and relerr(rgh, rgo) < 1e-13
+    eta = O.tangent_project(X, rng.standard_normal(X.size), 5, n)
+    assert relerr(ah.hessvec(X, eta), ao.hessvec(X, eta)) < 1e-13
+    th.run(3)
+    for _ in range(3):
+        to.iterate()
+    assert np.abs(th.global_X() - to.global_X()).max() < 1e-8
+    th.close()

@@ -41,3 +41,36 @@ def make_pair(dataset, num_robots, r=5, init="odom", **kw):
 
 def relerr(a, b):
     return np.abs(a - b).max() / max(1.0, np.abs(b).max())
+
+
+def add_outliers(m, n, frac=0.1, seed=0):
+    """seeded synthetic outlier loop closures (10 % extra edges, endpoints uniform, R uniform
+    on SO(3), t uniform in the bounding box of the odometry-chained trajectory)."""
+    rng = np.random.default_rng(seed)
+    T = O.odometry_init(m, n).reshape(n, 4, 3)
+    lo, hi = T[:, 3, :].min(0), T[:, 3, :].max(0)
+    k = max(1, int(frac * len(m)))
+    out = np.zeros(k, dtype=O.MEAS_DTYPE)
+    for e in range(k):
+        i, j = rng.integers(0, n, 2)
+        while abs(int(i) - int(j)) < 2:
+            i, j = rng.integers(0, n, 2)
+        Q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+        Q *= np.sign(np.linalg.det(Q))
+        out[e]["p1"], out[e]["p2"] = i, j
+        out[e]["R"] = Q.reshape(-1)
+        out[e]["t"] = lo + rng.random(3) * (hi - lo)
+        out[e]["kappa"], out[e]["tau"], out[e]["weight"] = np.median(m["kappa"]), np.median(m["tau"]), 1.0
+    return np.concatenate([m, out])
+
+
+def load_tunnels(weight_mode=0):
+    """the 8 per-robot CSVs merged into one edge list (a shared edge listed by both robots is kept once)"""
+    seen, rows = set(), []
+    for k in range(8):
+        for e in O.read_csv(os.path.join(DATA, "tunnels", "robot%d" % k, "measurements.csv"), weight_mode):
+            key = (int(e["r1"]), int(e["p1"]), int(e["r2"]), int(e["p2"]))
+            if key not in seen:
+                seen.add(key)
+                rows.append(e)
+    return np.array(rows, dtype=O.MEAS_DTYPE)
