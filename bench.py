@@ -140,7 +140,8 @@ def multi_gpu(args):
     be = HipBackend(mp, prm, mine, local_rank, torch)
     per = n // NA
     if be.team is not None:
-        be.team.set_initial(T, Y, offsets=np.array([a * per for a in mine], dtype=np.int32))
+        with be.stream_context():
+            be.team.set_initial(T, Y, offsets=np.array([a * per for a in mine], dtype=np.int32))
     drv = DistributedRBCD(dist, be, mp, NA, RGD["acceleration"], rank, world)
     drv.exchange_all()
     for _ in range(args.warmup):
@@ -153,9 +154,10 @@ def multi_gpu(args):
     dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    ms = tmax.item() / args.steps * 1e3
+    with be.stream_context():
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        ms = tmax.item() / args.steps * 1e3
     cost = drv.global_cost(torch, "cuda")
     dist.barrier()
     be.close()

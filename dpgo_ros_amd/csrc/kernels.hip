@@ -403,6 +403,19 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, const T
     if (boundary) return;
   }
 
+  // epilogue operands of the two poses this workgroup owns: requested now, consumed after the M stream
+  double pre_x = 0, pre_v = 0, pre_y = 0, pre_p = 0;
+  double nest_gamma = 0;
+  if (tid < npose * 4 * R) {
+    pre_x = ag.buf[xb][(size_t)col0 * R + tid];
+    if (MODE == PM_RGD_) {
+      pre_v = ag.buf[B_V][(size_t)col0 * R + tid];
+      pre_y = ag.buf[B_Y][(size_t)col0 * R + tid];
+      pre_p = ag.buf[B_XPREV][(size_t)col0 * R + tid];
+    }
+  }
+  if (MODE == PM_RGD_ && accel) nest_gamma = ag.nest->gamma;
+
   const int cg = tid >> 5, kl = tid & 31;
   const int col = col0 + cg;
   const bool cact = col < N4;
@@ -499,12 +512,8 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, const T
     for (int a = 0; a < R; ++a) zs[cg * R + a] = acc[a];
   }
   if (tid < npose * 4 * R) {
-    Ysh[tid] = ag.buf[xb][(size_t)col0 * R + tid];
-    if (MODE == PM_RGD_) {
-      Esh[0][tid] = ag.buf[B_V][(size_t)col0 * R + tid];
-      Esh[1][tid] = ag.buf[B_Y][(size_t)col0 * R + tid];
-      Esh[2][tid] = ag.buf[B_XPREV][(size_t)col0 * R + tid];
-    }
+    Ysh[tid] = pre_x;
+    if (MODE == PM_RGD_) { Esh[0][tid] = pre_v; Esh[1][tid] = pre_y; Esh[2][tid] = pre_p; }
   }
   __syncthreads();
 
@@ -528,9 +537,8 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, const T
         rel += d * d;
       }
       if (accel) {
-        const NestState ns = *ag.nest;
         const double Nr = (double)num_robots;
-        const double gamma = (1.0 + sqrt(1.0 + 4.0 * Nr * Nr * ns.gamma * ns.gamma)) / (2.0 * Nr);
+        const double gamma = (1.0 + sqrt(1.0 + 4.0 * Nr * Nr * nest_gamma * nest_gamma)) / (2.0 * Nr);
         double v[4 * R];
 #pragma unroll
         for (int i = 0; i < 4 * R; ++i) v[i] = Esh[0][lp * 4 * R + i] + gamma * (x[i] - Esh[1][lp * 4 * R + i]);

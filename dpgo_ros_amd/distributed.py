@@ -49,10 +49,16 @@ class HipBackend:
         self.r = params.r
         self.device = device
         self.host_staging = host_staging
-        stream = torch_module.cuda.current_stream().cuda_stream
+        # one explicit (non-default) stream for kernels AND collectives: torch.distributed orders its RCCL
+        # work against the *current* torch stream, so every launch of this rank runs under stream_context()
+        self.stream = torch_module.cuda.Stream(device=device)
+        stream = self.stream.cuda_stream
         self.team = capi.Team.from_measurements(meas, params, device=device, local_ids=local_ids, stream=stream) \
             if local_ids else None
         self._buf = {}
+
+    def stream_context(self):
+        return self.torch.cuda.stream(self.stream)
 
     def buffer(self, key, count):
         if key not in self._buf:
@@ -106,8 +112,16 @@ class DistributedRBCD:
         self.schedule = list(range(num_robots)) if schedule is None else list(schedule)
         self.k = 0
 
+    def _ctx(self):
+        import contextlib
+        return self.be.stream_context() if hasattr(self.be, "stream_context") else contextlib.nullcontext()
+
     def exchange_to(self, sel, seqs=(0, 1)):
         """neighbours of `sel` that live on other ranks send their public poses to sel's rank."""
+        with self._ctx():
+            self._exchange_to(sel, seqs)
+
+    def _exchange_to(self, sel, seqs):
         d = self.dist
         ops, todo = [], []
         rs = self.owner[sel]
@@ -139,18 +153,20 @@ class DistributedRBCD:
         """one global RBCD iteration (src/PGOAgentROS.cpp:129-220): everyone but the token holder
         calls iterate(false) first, then the token holder receives its neighbours' poses and optimizes."""
         sel = self.schedule[self.k % len(self.schedule)]
-        for a in self.mine:
-            if a != sel:
-                self.be.iterate(a, False)
-        self.exchange_to(sel, seqs=(0, 1) if self.accel else (0,))
-        if self.owner[sel] == self.rank:
-            self.be.iterate(sel, True)
+        with self._ctx():
+            for a in self.mine:
+                if a != sel:
+                    self.be.iterate(a, False)
+            self._exchange_to(sel, (0, 1) if self.accel else (0,))
+            if self.owner[sel] == self.rank:
+                self.be.iterate(sel, True)
         self.k += 1
         return sel
 
     def global_cost(self, torch_module, device):
         """f of the concatenated iterate: owned-edge partial sums, one 1-double all-reduce."""
         self.exchange_all()
-        t = torch_module.tensor([self.be.partial_cost()], dtype=torch_module.float64, device=device)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-        return float(t.item())
+        with self._ctx():
+            t = torch_module.tensor([self.be.partial_cost()], dtype=torch_module.float64, device=device)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+            return float(t.item())

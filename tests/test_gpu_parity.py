@@ -297,3 +297,16 @@ def test_long_rows_take_the_csr_tail():
         to.iterate()
     assert np.abs(th.global_X() - to.global_X()).max() < 1e-8
     th.close()
+
+
+@pytest.mark.parametrize("r", [3, 4, 6, 8])
+@pytest.mark.parametrize("method", [capi.METHOD_RGD, capi.METHOD_RTR])
+def test_other_relaxation_ranks(r, method):
+    kw = dict(method=method, acceleration=1, rgd_stepsize=0.2, restart_interval=5, gradnorm_tol=1e-2)
+    th, to, n = make_pair("smallGrid3D", 2, r=r, **kw)
+    th.run(9)
+    for _ in range(9):
+        to.iterate()
+    assert np.abs(th.global_X() - to.global_X()).max() < 1e-7
+    assert abs(th.cost() - to.cost()) <= 1e-9 * abs(to.cost())
+    th.close()
