@@ -325,14 +325,13 @@ __global__ __launch_bounds__(64) void k_hess(const AgentDev *agents, const TeamD
 //               (the whole RGD step + Nesterov V update of the two poses this workgroup owns)
 constexpr int KC = 2048;       // scalars of the input vector staged per chunk (KC * R * 8 bytes of LDS)
 constexpr int MREG = KC / 64;  // double2 registers per thread per chunk
-constexpr int KCP = KC + 4;    // LDS row pitch: 8*a + 2*k distinct banks for the transposing fill (no 5-way conflict)
 
 template <int R, int MODE>
 __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, const TeamDev *team, int sel, int xb, int vb,
                                                  int zb, int sp, int max_inner, double step, int accel,
                                                  int num_robots) {
   const AgentDev &ag = agents[sel_cur(team, sel)];
-  __shared__ double vs[R * KCP];
+  __shared__ double vs[R * KC];
   __shared__ double zs[8 * R];
   __shared__ double Ysh[2 * 4 * R];
   __shared__ double Esh[3][2 * 4 * R];  // PM_RGD: V, Yaux, XPrev of the two poses
@@ -424,82 +423,57 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, const T
 #pragma unroll
   for (int a = 0; a < R; ++a) acc[a] = 0;
 
-  constexpr int NSTG = (KC * R / 2 + 255) / 256;  // staged 16-byte pairs per lane per chunk
-#ifndef DPGO_PC_ORDER
-#define DPGO_PC_ORDER 0
-#endif
+  // Per chunk of KC rows: (1) the input vector is copied into LDS in its native [k][a] layout with one
+  // batch of 16-byte loads, (2) barrier, (3) the whole M slab of this workgroup is requested (32 x 16 B per
+  // lane, non-temporal), (4) the FMA loop drains the slab in issue order, so arithmetic overlaps the
+  // stream.  A lane reads the 2R contiguous doubles v[k][:], v[k+1][:] as R ds_read_b128 (16R-byte lane
+  // stride: conflict-free for R = 3, 5).  Measured (scratch/pc_bench.hip): ingest per CU, not HBM, is
+  // the limit -- every workgroup has to pull the full 8*R*N4-byte vector through L2 next to its slab.
+  constexpr int NSTG = (KC * R / 2 + 255) / 256;  // 16-byte pairs per lane per chunk
   for (int k0 = 0; k0 < N4; k0 += KC) {
     const int kn = min(KC, N4 - k0);
-    double2 mreg[MREG];
-    if constexpr (DPGO_PC_ORDER != 0 && NSTG + MREG <= 60) {
-      // every load of the chunk is issued back to back (vmcnt holds <= 64): the M slab and the input
-      // vector (16-byte pairs) return as one stream; a single wait, then LDS fill and FMAs.
+    if (k0 > 0) __syncthreads();
+    {
       double2 v[NSTG];
-      if (DPGO_PC_ORDER == 2) {
-#pragma unroll
-        for (int m = 0; m < MREG; ++m) {
-          const int k = 2 * kl + 64 * m;
-          mreg[m] = (cact && k < kn) ? ld2_nt(Mc + k0 + k) : make_double2(0.0, 0.0);
-        }
-      }
 #pragma unroll
       for (int u = 0; u < NSTG; ++u) {
         const int tt = 2 * (tid + 256 * u);  // kn * R is even
         v[u] = (tt < kn * R) ? ld2(Vin + (size_t)k0 * R + tt) : make_double2(0.0, 0.0);
-        if (MODE == PM_TCG_STEP_ && tt < kn * R) {
-          const double2 h = ld2(Hd + (size_t)k0 * R + tt);
-          v[u].x += alpha * h.x; v[u].y += alpha * h.y;
-        }
       }
-      if (DPGO_PC_ORDER == 1) {
+      if (MODE == PM_TCG_STEP_) {
 #pragma unroll
-        for (int m = 0; m < MREG; ++m) {
-          const int k = 2 * kl + 64 * m;
-          mreg[m] = (cact && k < kn) ? ld2_nt(Mc + k0 + k) : make_double2(0.0, 0.0);
+        for (int u = 0; u < NSTG; ++u) {
+          const int tt = 2 * (tid + 256 * u);
+          if (tt < kn * R) {
+            const double2 h = ld2(Hd + (size_t)k0 * R + tt);
+            v[u].x += alpha * h.x; v[u].y += alpha * h.y;
+          }
         }
       }
-      __syncthreads();
 #pragma unroll
       for (int u = 0; u < NSTG; ++u) {
         const int tt = 2 * (tid + 256 * u);
-        if (tt < KC * R) {
-          const int k = tt / R, a = tt - k * R;
-          vs[a * KCP + k] = v[u].x;
-          const int k1 = (tt + 1) / R, a1 = (tt + 1) - k1 * R;
-          vs[a1 * KCP + k1] = v[u].y;
-        }
-      }
-    } else {
-#pragma unroll
-      for (int m = 0; m < MREG; ++m) {
-        const int k = 2 * kl + 64 * m;
-        mreg[m] = (cact && k < kn) ? ld2_nt(Mc + k0 + k) : make_double2(0.0, 0.0);
-      }
-      __syncthreads();
-      for (int t0 = tid; t0 < KC * R; t0 += 256 * 8) {  // 8 independent loads in flight per lane
-        double v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int tt = t0 + 256 * u;
-          v[u] = (tt < kn * R) ? Vin[(size_t)k0 * R + tt] : 0.0;
-          if (MODE == PM_TCG_STEP_ && tt < kn * R) v[u] += alpha * Hd[(size_t)k0 * R + tt];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int tt = t0 + 256 * u;
-          if (tt < KC * R) { const int k = tt / R, a = tt - k * R; vs[a * KCP + k] = v[u]; }
-        }
+        if (tt < KC * R) *reinterpret_cast<double2 *>(&vs[tt]) = v[u];
       }
     }
     __syncthreads();
+    double2 mreg[MREG];
 #pragma unroll
     for (int m = 0; m < MREG; ++m) {
       const int k = 2 * kl + 64 * m;
+      mreg[m] = (cact && k < kn) ? ld2_nt(Mc + k0 + k) : make_double2(0.0, 0.0);
+    }
 #pragma unroll
-      for (int a = 0; a < R; ++a) {
-        const double2 v = *reinterpret_cast<const double2 *>(&vs[a * KCP + k]);
-        acc[a] += v.x * mreg[m].x + v.y * mreg[m].y;
+    for (int m = 0; m < MREG; ++m) {
+      const int k = 2 * kl + 64 * m;
+      double w[2 * R];
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        const double2 t2 = *reinterpret_cast<const double2 *>(&vs[k * R + 2 * j]);
+        w[2 * j] = t2.x; w[2 * j + 1] = t2.y;
       }
+#pragma unroll
+      for (int a = 0; a < R; ++a) acc[a] += w[a] * mreg[m].x + w[R + a] * mreg[m].y;
     }
   }
 #pragma unroll
