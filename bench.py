@@ -178,7 +178,8 @@ def main():
            "config": {"workload": "sphere2500.g2o, 5 agents, synchronous round-robin RBCD, RGD(step 0.2, dense "
                                   "preconditioner) + Nesterov (restart 20), r=5, library weighting",
                       "agents": 5, "poses_per_agent": 500, "placement": "agent a on rank a % N"}}
-    if args.gpus <= 1 and int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+    force_dist = os.environ.get("DPGO_BENCH_FORCE_DIST") == "1"  # exercise the N > 1 driver with one rank
+    if args.gpus <= 1 and int(os.environ.get("WORLD_SIZE", "1")) <= 1 and not force_dist:
         ms, roof, conv, cpu, counters = single_gpu(args)
         out.update({"value": ms, "ms_per_step": ms, "roofline": roof, "cpu_baseline": cpu, "convergence": conv,
                     "iters_to_relcost_1e-6": conv["rgd_nesterov"]["iters_to_relcost_1e-6"],

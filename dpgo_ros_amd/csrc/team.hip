@@ -783,7 +783,7 @@ int dpgo_agent_get_status(dpgo_team_t *t, int id, dpgo_status_t *s) {
   if (!a) return DPGO_ERR;
   s->agent_id = a->id; s->state = a->state; s->instance_number = a->instance; s->iteration_number = a->iter;
   s->relative_change = 0; s->ready_to_terminate = 0;
-  if (!a->has_X || a->iter == 0) return DPGO_OK;
+  if (!a->has_X || a->iter == 0 || a->rel_src == 2) { s->ready_to_terminate = a->has_X && a->iter > 0 && a->last_success; return DPGO_OK; }
   // |X - XPrev|^2 partials were left by the last kernel that moved X (fixed summation order)
   const int cnt = a->rel_src ? (4 * a->n + 7) / 8 : (a->n + 63) / 64;
   const int off = a->rel_src ? PART_B + 2 : PART_D;
@@ -1067,40 +1067,82 @@ int dpgo_team_exchange_all(dpgo_team_t *t) {
   return 0;
 }
 
-static int enqueue_team_iteration(dpgo_team_t *t, bool capture, bool restart) {
+// One global RBCD iteration over the agents of this team.
+//   sel: local index of the agent that optimizes, -1 = device-selected (graph capture), -2 = the
+//        selected agent lives on another rank (every local agent runs iterate(false)).
+//   phase: 0 whole iteration; 1 = begin (everything before the neighbour exchange: Nesterov Y/X/V of all
+//          local agents); 2 = end (local solve of `sel` + bookkeeping).
+static int enqueue_team_iteration(dpgo_team_t *t, bool capture, bool restart, int sel, int phase) {
   LaunchCtx c = t->ctx();
   const dpgo_params_t &p = t->prm;
   const int na = (int)t->ag.size();
-  const int sel = capture ? -1 : t->sched[t->iter % t->sched.size()];
   const int mn = t->max_n;
-  const bool fused = p.method == DPGO_METHOD_RGD && p.rgd_use_preconditioner && !restart;
+  const bool fused = p.method == DPGO_METHOD_RGD && p.rgd_use_preconditioner && !restart && sel != -2;
   OptFlags fl;
   fl.pull = 1; fl.capture = capture; fl.fused = fused; fl.last_advances = fused;
   int rc = 0;
-  if (p.acceleration) {
-    // K1 Nesterov Y/X/V of every agent (+ publishes the selected agent), then the local solve
-    launch_nest_pre(c, sel, -1, na, mn, p.num_robots, p.restart_interval);
-    fl.aux = 1;
+  if (phase != 2) {
+    if (p.acceleration) launch_nest_pre(c, sel, -1, na, mn, p.num_robots, p.restart_interval);  // K1 (+ publishes cur_sel)
+    else launch_copy(c, -3, -1, na, mn, B_X, B_XPREV, capture ? 1 : 0);
+  }
+  if (phase == 1) return 0;
+  if (sel != -2) {
+    fl.aux = p.acceleration ? 1 : 0;
     rc = enqueue_optimize(t, sel, fl);
     if (rc) return rc;
     if (!fused) {
       const int ns = (sel >= 0) ? t->ag[sel]->n : mn;
-      launch_nest_post(c, sel, ns, p.num_robots, p.restart_interval);
-      if (restart) {
-        fl.aux = 0;
-        rc = enqueue_optimize(t, sel, fl);
-        if (rc) return rc;
-        launch_nest_reset(c, sel, ns);
+      if (p.acceleration) {
+        launch_nest_post(c, sel, ns, p.num_robots, p.restart_interval);
+        if (restart) {
+          fl.aux = 0;
+          rc = enqueue_optimize(t, sel, fl);
+          if (rc) return rc;
+          launch_nest_reset(c, sel, ns);
+        }
       }
       launch_status(c, sel, -1, 1, ns);
     }
-  } else {
-    launch_copy(c, -3, -1, na, mn, B_X, B_XPREV, capture ? 1 : 0);
-    rc = enqueue_optimize(t, sel, fl);
-    if (rc) return rc;
-    if (!fused) launch_status(c, -3, -1, na, mn);
   }
   if (!fused) launch_advance(c, -1, na, p.acceleration, p.num_robots, p.restart_interval, 1);
+  return 0;
+}
+
+// host-side bookkeeping after one global iteration in which local agent `sel` (or nobody: -2) optimized
+static void account_iteration(dpgo_team_t *t, int sel, bool fused) {
+  const dpgo_params_t &p = t->prm;
+  for (auto &a : t->ag) {
+    a->rel_src = p.acceleration ? 0 : 2;  // non-accelerated iterate(false) leaves X untouched
+    a->iter += 1;
+    if (p.robust_cost_type != DPGO_COST_L2) a->robust_inner_iter += 1;
+    if (p.acceleration) a->publish_requested = true;
+  }
+  if (sel >= 0) {
+    t->ag[sel]->rel_src = fused ? 1 : 0;
+    t->ag[sel]->publish_requested = true;
+  }
+  t->iter += 1;
+  t->counters[4] += 1;
+}
+
+int dpgo_team_step_begin(dpgo_team_t *t, int sel_id) {
+  if (sync_descs(t)) return DPGO_ERR;
+  auto it = t->id2local.find(sel_id);
+  const int sel = (it == t->id2local.end()) ? -2 : it->second;
+  const bool restart = t->prm.acceleration && ((t->iter + 2) % t->prm.restart_interval) == 0;
+  return enqueue_team_iteration(t, false, restart, sel, 1);
+}
+
+int dpgo_team_step_end(dpgo_team_t *t, int sel_id) {
+  auto it = t->id2local.find(sel_id);
+  const int sel = (it == t->id2local.end()) ? -2 : it->second;
+  const dpgo_params_t &p = t->prm;
+  const bool restart = p.acceleration && ((t->iter + 2) % p.restart_interval) == 0;
+  if (sel >= 0 && !neighbor_poses_ready(*t->ag[sel], p.acceleration ? 1 : 0)) { set_err("neighbour poses missing"); return DPGO_NOT_READY; }
+  const int rc = enqueue_team_iteration(t, false, restart, sel, 2);
+  if (rc) return rc;
+  const bool fused = p.method == DPGO_METHOD_RGD && p.rgd_use_preconditioner && !restart && sel >= 0;
+  account_iteration(t, sel, fused);
   return 0;
 }
 
@@ -1116,7 +1158,7 @@ int dpgo_team_run(dpgo_team_t *t, int iters) {
       hipGraph_t g = nullptr;
       HIPC(hipStreamBeginCapture(t->stream, hipStreamCaptureModeThreadLocal));
       int rc = 0;
-      for (int rep = 0; rep < (1 << gi) && !rc; ++rep) rc = enqueue_team_iteration(t, true, false);
+      for (int rep = 0; rep < (1 << gi) && !rc; ++rep) rc = enqueue_team_iteration(t, true, false, -1, 0);
       HIPC(hipStreamEndCapture(t->stream, &g));
       if (rc) { (void)hipGraphDestroy(g); return rc; }
       if (t->graph[gi]) { (void)hipGraphExecDestroy(t->graph[gi]); t->graph[gi] = nullptr; }
@@ -1145,7 +1187,7 @@ int dpgo_team_run(dpgo_team_t *t, int iters) {
       while (gi + 1 < dpgo_team::NGRAPH && (2 << gi) <= until) ++gi;
       batch = 1 << gi;
       HIPC(hipGraphLaunch(t->graph[gi], t->stream));
-      for (auto &a : t->ag) a->rel_src = 0;
+      for (auto &a : t->ag) a->rel_src = p.acceleration ? 0 : 2;
       for (int q = 0; q < batch; ++q) {
         const int sel = t->sched[(t->iter + q) % t->sched.size()];
         account(sel);
@@ -1153,8 +1195,8 @@ int dpgo_team_run(dpgo_team_t *t, int iters) {
       }
     } else {
       const int sel = t->sched[t->iter % t->sched.size()];
-      for (auto &a : t->ag) a->rel_src = 0;
-      const int rc = enqueue_team_iteration(t, false, restart);
+      for (auto &a : t->ag) a->rel_src = p.acceleration ? 0 : 2;
+      const int rc = enqueue_team_iteration(t, false, restart, sel, 0);
       if (rc) return rc;
       const bool fused = p.method == DPGO_METHOD_RGD && p.rgd_use_preconditioner && !restart;
       if (fused) t->ag[sel]->rel_src = 1;

@@ -93,6 +93,15 @@ class HipBackend:
     def pull_local(self, agent):
         self.team.agents[agent].pull_local()
 
+    # batched form of the iteration (one launch for all local agents instead of one call per agent)
+    def step_begin(self, sel):
+        if self.team is not None:
+            self.team.step_begin(sel)
+
+    def step_end(self, sel):
+        if self.team is not None:
+            self.team.step_end(sel)
+
     def partial_cost(self):
         return self.team.cost() if self.team is not None else 0.0
 
@@ -121,7 +130,7 @@ class DistributedRBCD:
         with self._ctx():
             self._exchange_to(sel, seqs)
 
-    def _exchange_to(self, sel, seqs):
+    def _exchange_to(self, sel, seqs, pull=True):
         d = self.dist
         ops, todo = [], []
         rs = self.owner[sel]
@@ -142,7 +151,7 @@ class DistributedRBCD:
                 w.wait()
         for b, aux, t in todo:
             self.be.unpack(sel, b, aux, t)
-        if self.rank == rs:
+        if self.rank == rs and pull:  # the batched step pulls co-resident poses inside the G-assembly kernel
             self.be.pull_local(sel)
 
     def exchange_all(self):
@@ -154,12 +163,17 @@ class DistributedRBCD:
         calls iterate(false) first, then the token holder receives its neighbours' poses and optimizes."""
         sel = self.schedule[self.k % len(self.schedule)]
         with self._ctx():
-            for a in self.mine:
-                if a != sel:
-                    self.be.iterate(a, False)
-            self._exchange_to(sel, (0, 1) if self.accel else (0,))
-            if self.owner[sel] == self.rank:
-                self.be.iterate(sel, True)
+            if hasattr(self.be, "step_begin"):
+                self.be.step_begin(sel)
+                self._exchange_to(sel, (0, 1) if self.accel else (0,), pull=False)
+                self.be.step_end(sel)
+            else:
+                for a in self.mine:
+                    if a != sel:
+                        self.be.iterate(a, False)
+                self._exchange_to(sel, (0, 1) if self.accel else (0,))
+                if self.owner[sel] == self.rank:
+                    self.be.iterate(sel, True)
         self.k += 1
         return sel
 

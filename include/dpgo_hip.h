@@ -153,6 +153,11 @@ int dpgo_team_set_initial(dpgo_team_t *t, const double *T, const double *YLift, 
 int dpgo_team_exchange_all(dpgo_team_t *t);
 /* run `iters` global RBCD iterations without host synchronisation (RGD: one hipGraph replay each) */
 int dpgo_team_run(dpgo_team_t *t, int iters);
+/* the same iteration split around the neighbour exchange, for teams that hold only part of the agents
+ * (one process per GPU): begin = iterate(false) part of every local agent; [exchange]; end = local solve
+ * of `sel_id` if it lives here + bookkeeping.  sel_id is a global robot id. */
+int dpgo_team_step_begin(dpgo_team_t *t, int sel_id);
+int dpgo_team_step_end(dpgo_team_t *t, int sel_id);
 int dpgo_team_iteration(dpgo_team_t *t);
 /* global cost of the concatenated iterate, evaluated on the device */
 int dpgo_team_cost(dpgo_team_t *t, double *f);
