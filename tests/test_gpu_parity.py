@@ -310,3 +310,34 @@ def test_other_relaxation_ranks(r, method):
     assert np.abs(th.global_X() - to.global_X()).max() < 1e-7
     assert abs(th.cost() - to.cost()) <= 1e-9 * abs(to.cost())
     th.close()
+
+
+def test_asapp_style_seeded_random_order_on_tunnels():
+    """BASELINE configs[4] stand-in: the asynchronous ASAPP run is nondeterministic in the
+    reference (Poisson clocks), so it is replayed as a SEEDED random activation order: each event is one
+    preconditioned RGD step (stepsize 0.2, README.md:52) of one agent with whatever neighbour poses are
+    current, no acceleration (launch/asapp_demo.launch)."""
+    from tests.util import load_tunnels
+    m = load_tunnels(capi.WEIGHT_WRAPPER)
+    N = 8
+    nk = [0] * N
+    for e in m:
+        nk[e["r1"]] = max(nk[e["r1"]], int(e["p1"]) + 1)
+        nk[e["r2"]] = max(nk[e["r2"]], int(e["p2"]) + 1)
+    Ts = []
+    for k in range(N):
+        odo = m[(m["r1"] == k) & (m["r2"] == k) & (m["p1"] + 1 == m["p2"])].copy()
+        odo["r1"] = 0; odo["r2"] = 0
+        Ts.append(O.odometry_init(odo, nk[k]))
+    T = np.concatenate(Ts)
+    order = np.random.default_rng(2024).integers(0, N, 64).astype(np.int32)
+    th, to = _pair_from(m, sum(nk), N, T, method=capi.METHOD_RGD, rgd_stepsize=0.2, acceleration=0)
+    th.set_schedule(order)
+    to.set_schedule(order)
+    f0 = to.cost()
+    th.run(64)
+    for _ in range(64):
+        to.iterate()
+    assert np.abs(th.global_X() - to.global_X()).max() < 1e-7
+    assert abs(th.cost() - to.cost()) <= 1e-9 * abs(to.cost()) and to.cost() < f0
+    th.close()
