@@ -55,6 +55,7 @@ def single_gpu(args):
     team.run(args.warmup)
     team.synchronize()
     torch.cuda.synchronize()
+    c0 = team.counters()
     t0 = time.perf_counter()
     team.run(args.steps)
     team.synchronize()
@@ -62,6 +63,8 @@ def single_gpu(args):
     dt = time.perf_counter() - t0
     ms = dt / args.steps * 1e3
     counters = team.counters()
+    c_timed = counters - c0
+    iter_bytes = (c_timed[1] + c_timed[3]) / max(c_timed[4], 1)   # algorithmic bytes per RBCD iteration
 
     # ---- roofline leg: dominant kernel = dense preconditioner apply, HIP events on the team stream
     k_ms, k_bytes = team.time_kernel(1, 0, reps=500)
@@ -76,6 +79,24 @@ def single_gpu(args):
             "spmm_eval": {"kernel": "k_eval<5>", "bytes_per_launch": s_bytes, "us_per_launch": s_ms * 1e3,
                           "achieved": s_bytes / (s_ms * 1e-3) / 1e9}}
     roof["frac"] = roof["achieved"] / roof["peak"]
+    roof["iteration"] = {"algorithmic_bytes": iter_bytes, "achieved": iter_bytes / (ms * 1e-3) / 1e9, "unit": "GB/s",
+                         "note": "B_iter = #precond x B_P + #eval x B from the run's own counters, / ms per iteration"}
+
+    # ---- RTR + Nesterov, the reference's synchronous default (PGOAgentROSNode.cpp:82-85), timed the same way
+    p3 = capi.default_params(r=WORKLOAD["r"], num_robots=WORKLOAD["num_robots"], **RTR)
+    t3 = capi.Team.from_measurements(mp, p3, device=0)
+    t3.set_initial(T, Y)
+    t3.run(50)
+    t3.synchronize()
+    k0 = t3.counters()
+    a0 = time.perf_counter()
+    t3.run(300)
+    t3.synchronize()
+    rtr_ms = (time.perf_counter() - a0) / 300 * 1e3
+    k1 = t3.counters() - k0
+    rtr = {"ms_per_iter": rtr_ms, "precond_per_iter": k1[0] / 300, "spmm_per_iter": k1[2] / 300,
+           "algorithmic_bytes_per_iter": (k1[1] + k1[3]) / 300, "achieved_GBps": (k1[1] + k1[3]) / 300 / (rtr_ms * 1e-3) / 1e9}
+    t3.close()
 
     # ---- convergence leg (untimed): iterations to (f_k - f*)/f* <= 1e-6
     fstar = F_STAR[WORKLOAD["dataset"]]
@@ -101,6 +122,7 @@ def single_gpu(args):
 
     cpu = cpu_baseline(mp, n, T, Y)
     team.close()
+    conv["rtr_nesterov"]["timed"] = rtr
     return ms, roof, conv, cpu, counters
 
 
