@@ -38,6 +38,7 @@ struct RtrState {
   double z_r, d_Pd, e_Pd, e_Pe, norm_r0, alpha;
   double f_init, gn_init;
   int outer_it, outer_done, tcg_active, tcg_j, tcg_status;
+  int need_init, pad0;  // need_init: the next tCG has not been set up yet (after begin / accept)
   int hv_count, pc_count, tcg_total, accepted, outer_count;
 };
 

@@ -347,7 +347,9 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, const T
   RtrState S;
   if (MODE == PM_TCG_INIT_ || MODE == PM_TCG_STEP_) {
     S = ag.st[sp];
-    const bool idle = S.outer_done || (MODE == PM_TCG_STEP_ && !S.tcg_active);
+    // phase gating: the host enqueues [init, (hv, step) x J, retract, eval2, accept] patterns blindly;
+    // a kernel whose phase is not due forwards the state and returns
+    const bool idle = S.outer_done || (MODE == PM_TCG_STEP_ && !S.tcg_active) || (MODE == PM_TCG_INIT_ && !S.need_init);
     if (idle) {
       if (blockIdx.x == 0 && tid == 0) ag.st[sp ^ 1] = S;
       return;
@@ -376,7 +378,7 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, const T
       }
     } else if (blockIdx.x == 0 && tid == 0) {
       RtrState T = S;
-      T.tcg_active = 1; T.tcg_j = 0; T.tcg_status = 0;
+      T.tcg_active = 1; T.tcg_j = 0; T.tcg_status = 0; T.need_init = 0;
       T.e_Pd = 0; T.e_Pe = 0; T.alpha = 0;
       T.pc_count = S.pc_count + 1;
       T.outer_count = S.outer_count + 1;
@@ -697,7 +699,10 @@ template <int R>
 __global__ __launch_bounds__(64) void k_retract(const AgentDev *agents, const TeamDev *team, int sel, int xb, int eb,
                                                 double scale, int ob, int guard_state) {
   const AgentDev &ag = agents[sel_cur(team, sel)];
-  if (guard_state >= 0 && ag.st[guard_state].outer_done) return;
+  if (guard_state >= 0) {
+    const RtrState S = ag.st[guard_state];
+    if (S.outer_done || S.tcg_active || S.need_init) return;  // only between the end of tCG and the accept step
+  }
   const int j0 = blockIdx.x * 64, tid = threadIdx.x;
   if (j0 >= ag.n) return;
   const int cnt = min(64, ag.n - j0);
@@ -915,6 +920,7 @@ __global__ void k_rtr_begin(const AgentDev *agents, const TeamDev *team, int sel
   S.f1 = f; S.ngf = sqrt(g); S.Delta = Delta0;
   S.f_init = f; S.gn_init = S.ngf;
   S.outer_done = (S.ngf < tol) || (max_outer <= 0);
+  S.need_init = 1;
   ag.st[0] = S;
   ag.st[1] = S;
 }
@@ -930,7 +936,10 @@ __global__ __launch_bounds__(64) void k_rtr_eval2(const AgentDev *agents, const 
   const int lane = threadIdx.x, lp = lane / R, a = lane - lp * R;
   const int j = blockIdx.x * PPB + lp;
   if (blockIdx.x * PPB >= ag.n) return;
-  if (ag.st[sp].outer_done) return;
+  {
+    const RtrState S = ag.st[sp];
+    if (S.outer_done || S.tcg_active || S.need_init) return;
+  }
   const bool act = lp < PPB && j < ag.n;
   const double *X2 = ag.buf[B_X2], *ETA = ag.buf[B_ETA];
   double fpart = 0, gpart = 0, ge = 0, eh = 0;
@@ -1001,7 +1010,7 @@ __global__ void k_rtr_accept(const AgentDev *agents, const TeamDev *team, int se
                              double max_radius) {
   const AgentDev &ag = agents[sel_cur(team, sel)];
   const RtrState S = ag.st[sp];
-  if (S.outer_done) {
+  if (S.outer_done || S.tcg_active || S.need_init) {
     if (blockIdx.x == 0 && threadIdx.x == 0) ag.st[sp ^ 1] = S;
     return;
   }
@@ -1025,6 +1034,7 @@ __global__ void k_rtr_accept(const AgentDev *agents, const TeamDev *team, int se
     T.outer_it = S.outer_it + 1;
     T.outer_done = (T.outer_it >= max_outer) || (T.ngf < tol);
     T.tcg_active = 0;
+    T.need_init = 1;
     ag.st[sp ^ 1] = T;
   }
   if (!accept) return;

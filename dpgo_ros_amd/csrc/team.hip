@@ -85,6 +85,7 @@ struct Agent {
   std::map<int, std::unique_ptr<DevBuf<int>>> d_pubframes, d_nbrslots;  // per neighbour, cached on the device
   std::map<int, int> n_pubframes, n_nbrslots;
   DevBuf<double> d_xfer;
+  int tcg_hint = 4, outer_hint = -1;  // launch-pattern sizing from the previous solve of this agent
   int rel_src = 0;  // where the last |X - XPrev|^2 partials live: 0 PART_D (per 64-pose tile), 1 PART_B[2] (fused RGD)
   DevBuf<SharedEdgeDev> d_se;
   DevBuf<EdgeDev> d_edges;
@@ -449,31 +450,37 @@ int enqueue_optimize(dpgo_team *t, int sel, const OptFlags &fl) {
     HIPC(hipStreamSynchronize(t->stream));
     return 0;
   };
-  auto tcg_chunk = [&]() {
-    for (int q = 0; q < t->tcg_chunk; ++q) {
+  // One outer iteration = [tCG init, (Hess-vec, step) x J, retract, evaluate, accept].  Every kernel is
+  // gated by the device-side phase, so whole patterns are enqueued blindly: the expected number of outer
+  // iterations first, then one read-back; more patterns only if the state says the solve is not done.
+  const int J = std::max(1, std::min(a.tcg_hint, p.rtr_tcg_iterations));
+  auto pattern = [&]() {
+    launch_precond(c, sel, mn, PM_TCG_INIT_, B_X, 0, 0, sp, p.rtr_tcg_iterations, 0.0, 0, p.num_robots); sp ^= 1;
+    for (int q = 0; q < J; ++q) {
       launch_tcg_hv(c, sel, mn, sp, p.rtr_tcg_iterations); sp ^= 1;
       launch_precond(c, sel, mn, PM_TCG_STEP_, B_X, 0, 0, sp, p.rtr_tcg_iterations, 0.0, 0, p.num_robots); sp ^= 1;
     }
+    launch_retract(c, sel, mn, B_X, B_ETA, 1.0, B_X2, sp);
+    launch_rtr_eval2(c, sel, mn, sp);
+    launch_rtr_accept(c, sel, mn, sp, p.gradnorm_tol, p.rtr_iterations, p.rtr_max_radius); sp ^= 1;
   };
-  auto tcg_init = [&]() {
-    launch_precond(c, sel, mn, PM_TCG_INIT_, B_X, 0, 0, sp, p.rtr_tcg_iterations, 0.0, 0, p.num_robots); sp ^= 1;
-  };
-  tcg_init();
-  tcg_chunk();
-  if (read_state()) return DPGO_ERR;
-  int guard = 0;
-  while (!hs->outer_done && guard++ < 100000) {
-    if (hs->tcg_active) {
-      tcg_chunk();
-    } else {
-      launch_retract(c, sel, mn, B_X, B_ETA, 1.0, B_X2, sp);
-      launch_rtr_eval2(c, sel, mn, sp);
-      launch_rtr_accept(c, sel, mn, sp, p.gradnorm_tol, p.rtr_iterations, p.rtr_max_radius); sp ^= 1;
-      tcg_init();
-      tcg_chunk();
-    }
+  bool have_state = false;
+  if (a.outer_hint == 0) {  // the previous solve of this agent started below the gradient tolerance
     if (read_state()) return DPGO_ERR;
+    have_state = true;
   }
+  if (!have_state || !hs->outer_done) {
+    const int first = (a.outer_hint > 0) ? std::min(a.outer_hint, p.rtr_iterations) : p.rtr_iterations;
+    for (int o = 0; o < first; ++o) pattern();
+    if (read_state()) return DPGO_ERR;
+    int guard = 0;
+    while (!hs->outer_done && guard++ < 100000) {
+      pattern();
+      if (read_state()) return DPGO_ERR;
+    }
+  }
+  a.outer_hint = hs->outer_count;
+  if (hs->outer_count > 0) a.tcg_hint = std::max(2, std::min(8, (hs->tcg_total + hs->outer_count - 1) / hs->outer_count + 1));
   a.opt.success = 1;
   a.opt.f_init = hs->f_init; a.opt.gradnorm_init = hs->gn_init;
   a.opt.f_opt = hs->f1; a.opt.gradnorm_opt = hs->ngf;
