@@ -582,7 +582,7 @@ __global__ __launch_bounds__(64) void k_tcg_hv(const AgentDev *agents, const Tea
     if (blockIdx.x == 0 && lane == 0) ag.st[sp ^ 1] = S;
     return;
   }
-  const double theta = 1.0, kappa = 0.1;
+  const double kappa = 0.1;  // tCG stop: |r| <= |r0| min(|r0|^theta, kappa) with theta = 1
   const int npb = precond_blocks(ag.N4);
   const double zr_new = sum_partials(ag.part + PART_B, npb, PART_STRIDE, lane);
   const double rr_new = sum_partials(ag.part + PART_B + 1, npb, PART_STRIDE, lane);
@@ -593,7 +593,7 @@ __global__ __launch_bounds__(64) void k_tcg_hv(const AgentDev *agents, const Tea
     T.z_r = zr_new; T.d_Pd = zr_new; T.norm_r0 = sqrt(rr_new);
   } else {
     const double nr = sqrt(rr_new);
-    const double thr = pow(S.norm_r0, theta);
+    const double thr = S.norm_r0;
     bool stop = false;
     if (nr <= S.norm_r0 * (thr < kappa ? thr : kappa)) { T.tcg_status = (kappa < thr) ? 3 : 4; stop = true; }
     else if (S.tcg_j >= max_inner) { T.tcg_status = 0; stop = true; }

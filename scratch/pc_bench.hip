@@ -335,6 +335,130 @@ __global__ __launch_bounds__(256) void k_gemv11(const double* M, const double* V
   }
 }
 
+// V9a: staging kept, FMA loop replaced by a plain sum of m  (isolates the staging cost)
+__global__ __launch_bounds__(256) void k_gemv9a(const double* M, const double* V, double* out, int N4) {
+  __shared__ double vs[R * KC];
+  const int tid = threadIdx.x, cg = tid >> 5, kl = tid & 31;
+  const int col = 8 * blockIdx.x + cg;
+  const double* Mc = M + (size_t)col * N4;
+  {
+    double2 v[20];
+#pragma unroll
+    for (int u = 0; u < 20; ++u) { const int tt = 2 * (tid + 256 * u); v[u] = (tt < N4 * R) ? ld2(V + tt) : make_double2(0, 0); }
+#pragma unroll
+    for (int u = 0; u < 20; ++u) { const int tt = 2 * (tid + 256 * u); *(double2*)&vs[tt] = v[u]; }
+  }
+  __syncthreads();
+  double2 m[32];
+#pragma unroll
+  for (int q = 0; q < 32; ++q) { const int k = 2 * kl + 64 * q; m[q] = (k < N4) ? ld2_nt(Mc + k) : make_double2(0, 0); }
+  double s = vs[tid];
+#pragma unroll
+  for (int q = 0; q < 32; ++q) s += m[q].x + m[q].y;
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if (kl == 0) out[col] = s;
+}
+// V9b: no staging (LDS left uninitialised), FMA loop kept  (isolates the arithmetic + LDS reads)
+__global__ __launch_bounds__(256) void k_gemv9b(const double* M, const double* V, double* out, int N4) {
+  __shared__ double vs[R * KC];
+  const int tid = threadIdx.x, cg = tid >> 5, kl = tid & 31;
+  const int col = 8 * blockIdx.x + cg;
+  const double* Mc = M + (size_t)col * N4;
+  double2 m[32];
+#pragma unroll
+  for (int q = 0; q < 32; ++q) { const int k = 2 * kl + 64 * q; m[q] = (k < N4) ? ld2_nt(Mc + k) : make_double2(0, 0); }
+  double acc[R];
+#pragma unroll
+  for (int a = 0; a < R; ++a) acc[a] = 0;
+#pragma unroll
+  for (int q = 0; q < 32; ++q) {
+    const int k = 2 * kl + 64 * q;
+    double w[2 * R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) { const double2 t = *(const double2*)&vs[k * R + 2 * j]; w[2 * j] = t.x; w[2 * j + 1] = t.y; }
+#pragma unroll
+    for (int a = 0; a < R; ++a) acc[a] += w[a] * m[q].x + w[R + a] * m[q].y;
+  }
+#pragma unroll
+  for (int a = 0; a < R; ++a) {
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) acc[a] += __shfl_xor(acc[a], off, 64);
+  }
+  if (kl == 0) {
+#pragma unroll
+    for (int a = 0; a < R; ++a) out[(size_t)col * R + a] = acc[a];
+  }
+}
+// V0b: pure stream but with 80 KB of static LDS declared (occupancy / dispatch effect of the LDS footprint)
+__global__ __launch_bounds__(256) void k_stream_lds(const double* M, double* out, int N4) {
+  __shared__ double vs[R * KC];
+  const int tid = threadIdx.x, cg = tid >> 5, kl = tid & 31;
+  const int col = 8 * blockIdx.x + cg;
+  const double* Mc = M + (size_t)col * N4;
+  double2 m[32];
+#pragma unroll
+  for (int q = 0; q < 32; ++q) { const int k = 2 * kl + 64 * q; m[q] = (k < N4) ? ld2_nt(Mc + k) : make_double2(0, 0); }
+  vs[tid] = m[0].x;
+  double s = 0;
+#pragma unroll
+  for (int q = 0; q < 32; ++q) s += m[q].x + m[q].y;
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if (kl == 0) out[col] = s + vs[(tid + 7) & 255];
+}
+
+// V12<NT>: same as V9 with NT threads per workgroup (8 columns x NT/8 k-lanes), more waves per SIMD
+template <int NT>
+__global__ __launch_bounds__(NT) void k_gemv12(const double* M, const double* V, double* out, int N4) {
+  __shared__ double vs[R * KC];
+  __shared__ double red[NT / 64][8 * R];
+  constexpr int KL = NT / 8, NQ = KC / (2 * KL), NS = (KC * R / 2 + NT - 1) / NT;
+  const int tid = threadIdx.x, cg = tid / KL, kl = tid % KL;
+  const int col = 8 * blockIdx.x + cg;
+  const double* Mc = M + (size_t)col * N4;
+  {
+    double2 v[NS];
+#pragma unroll
+    for (int u = 0; u < NS; ++u) { const int tt = 2 * (tid + NT * u); v[u] = (tt < N4 * R) ? ld2(V + tt) : make_double2(0, 0); }
+#pragma unroll
+    for (int u = 0; u < NS; ++u) { const int tt = 2 * (tid + NT * u); if (tt < KC * R) *(double2*)&vs[tt] = v[u]; }
+  }
+  __syncthreads();
+  double2 m[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) { const int k = 2 * kl + 2 * KL * q; m[q] = (k < N4) ? ld2_nt(Mc + k) : make_double2(0, 0); }
+  double acc[R];
+#pragma unroll
+  for (int a = 0; a < R; ++a) acc[a] = 0;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int k = 2 * kl + 2 * KL * q;
+    double w[2 * R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) { const double2 t = *(const double2*)&vs[k * R + 2 * j]; w[2 * j] = t.x; w[2 * j + 1] = t.y; }
+#pragma unroll
+    for (int a = 0; a < R; ++a) acc[a] += w[a] * m[q].x + w[R + a] * m[q].y;
+  }
+  // reduce over the KL lanes of a column (KL = 64: one wave per column; KL = 128: two waves)
+#pragma unroll
+  for (int a = 0; a < R; ++a) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc[a] += __shfl_xor(acc[a], off, 64);
+  }
+  if ((tid & 63) == 0) {
+#pragma unroll
+    for (int a = 0; a < R; ++a) red[tid >> 6][a] = acc[a];
+  }
+  __syncthreads();
+  if (tid < 8 * R) {
+    const int c = tid / R, a = tid % R;
+    double s2 = 0;
+    for (int w = 0; w < KL / 64; ++w) s2 += red[c * (KL / 64) + w][a];
+    out[(size_t)(8 * blockIdx.x + c) * R + a] = s2;
+  }
+}
+
 __global__ void k_noop() {}
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
@@ -365,6 +489,11 @@ int main() {
   printf("gemv10 raw barrier %.2f us\n", timeit([&] { hipLaunchKernelGGL(k_gemv10, dim3(250), dim3(256), 0, s, Ms[(it++) % NAG], V, out, N4); }, 500, s));
   double* part; CK(hipMalloc(&part, sizeof(double) * 16 * N4 * R));
   printf("gemv11 2D split-k  %.2f us\n", timeit([&] { hipLaunchKernelGGL(k_gemv11, dim3(256), dim3(256), 0, s, Ms[(it++) % NAG], V, part, N4); }, 500, s));
+  printf("gemv9a stage only  %.2f us\n", timeit([&] { hipLaunchKernelGGL(k_gemv9a, dim3(250), dim3(256), 0, s, Ms[(it++) % NAG], V, out, N4); }, 500, s));
+  printf("gemv9b fma only    %.2f us\n", timeit([&] { hipLaunchKernelGGL(k_gemv9b, dim3(250), dim3(256), 0, s, Ms[(it++) % NAG], V, out, N4); }, 500, s));
+  printf("stream + 80KB LDS  %.2f us\n", timeit([&] { hipLaunchKernelGGL(k_stream_lds, dim3(250), dim3(256), 0, s, Ms[(it++) % NAG], out, N4); }, 500, s));
+  printf("gemv12 512 thr     %.2f us\n", timeit([&] { hipLaunchKernelGGL(k_gemv12<512>, dim3(250), dim3(512), 0, s, Ms[(it++) % NAG], V, out, N4); }, 500, s));
+  printf("gemv12 1024 thr    %.2f us\n", timeit([&] { hipLaunchKernelGGL(k_gemv12<1024>, dim3(250), dim3(1024), 0, s, Ms[(it++) % NAG], V, out, N4); }, 500, s));
   // graph of 20 launches
   hipGraph_t g; hipGraphExec_t ge;
   CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
