@@ -341,3 +341,68 @@ def test_asapp_style_seeded_random_order_on_tunnels():
     assert np.abs(th.global_X() - to.global_X()).max() < 1e-7
     assert abs(th.cost() - to.cost()) <= 1e-9 * abs(to.cost()) and to.cost() < f0
     th.close()
+
+
+def test_config2_sphere2500_eight_agents_rtr():
+    """BASELINE configs[2]: sphere2500 over 8 agents (7 x 312 + 316 poses), RTR 3/50/0.5 (launch/dpgo_demo.launch:33-35)."""
+    kw = dict(method=capi.METHOD_RTR, rtr_iterations=3, rtr_tcg_iterations=50, gradnorm_tol=0.5)
+    th, to, n = make_pair("sphere2500", 8, **kw)
+    assert [th.agents[k].n for k in range(8)] == [312] * 7 + [316]
+    th.run(16)
+    for _ in range(16):
+        to.iterate()
+    assert np.abs(th.global_X() - to.global_X()).max() < 1e-7
+    assert abs(th.cost() - to.cost()) <= 1e-9 * abs(to.cost())
+    for k in range(8):
+        rh, ro = th.agents[k].opt_result(), to.agents[k].opt_result()
+        assert rh.tcg_iters_total == ro.tcg_iters_total and rh.accepted == ro.accepted
+    th.close()
+
+
+def test_config3_torus_eight_agents_gnc_with_outliers():
+    """BASELINE configs[3] with the declared substitution (grid3D / rim are absent): torus3D split over
+    8 agents + seeded synthetic outlier loop closures, GNC_TLS barc 3, mu 1e-5 x2 (launch/dpgo_gnc_demo.launch:35-42)."""
+    from tests.util import add_outliers
+    N = 8
+    m, _, n = load("torus3D", 1)
+    mo = add_outliers(m, n, frac=0.02, seed=0)
+    mp = O.partition(mo, n, N)
+    T = O.odometry_init(mo, n)
+    kw = dict(method=capi.METHOD_RTR, gradnorm_tol=0.5, robust_cost_type=capi.COST_GNC_TLS, gnc_barc=3.0,
+              gnc_mu_step=2.0, gnc_init_mu=1e-5, robust_opt_num_weight_updates=3, robust_opt_inner_iters=8)
+    th, to = _pair_from(mp, n, N, T, **kw)
+    assert [th.agents[k].n for k in range(N)] == [625] * 8
+    for rnd in range(2):
+        th.run(8)
+        for _ in range(8):
+            to.iterate()
+        assert np.abs(th.global_X() - to.global_X()).max() < 1e-6, rnd
+        assert th.update_weights() == to.update_weights()
+        wh = np.concatenate([th.agents[a].measurements()["weight"] for a in range(N)])
+        wo = np.concatenate([to.agents[a].measurements()["weight"] for a in range(N)])
+        assert np.abs(wh - wo).max() < 1e-6
+    th.close()
+
+
+def test_full_size_properties_sphere2500():
+    """Size-independent properties at the bench workload's full size, HIP path only:
+    monotone descent of plain RBCD, iterates stay on the manifold, gauge invariance of the cost."""
+    m, mp, n = load("sphere2500", 5)
+    t = capi.Team.from_measurements(mp.view(capi.MEAS_DTYPE), capi.default_params(r=5, num_robots=5, method=capi.METHOD_RTR, gradnorm_tol=0.5))
+    t.set_initial(O.odometry_init(m, n), O.fixed_stiefel(5))
+    prev = t.cost()
+    for _ in range(25):
+        t.run(1)
+        c = t.cost()
+        assert c <= prev * (1 + 1e-12)
+        prev = c
+    X = t.global_X()
+    Y = X.reshape(n, 4, 5)[:, :3, :]
+    assert np.abs(np.einsum("nia,nja->nij", Y, Y) - np.eye(3)).max() < 1e-12
+    A, _ = np.linalg.qr(np.random.default_rng(0).standard_normal((5, 5)))
+    AX = (A @ X.reshape(4 * n, 5).T).T.reshape(-1)
+    for a in range(5):
+        t.agents[a].set_X(AX[5 * 4 * 500 * a:5 * 4 * 500 * (a + 1)])
+    t.exchange_all()
+    assert abs(t.cost() - prev) <= 1e-10 * prev
+    t.close()
