@@ -323,14 +323,17 @@ __global__ __launch_bounds__(64) void k_hess(const AgentDev *agents, const TeamD
 //   PM_TCG_STEP v = r_old + alpha Hd (on the fly), eta += alpha d, z = P(v M)   (tCG body, part 2)
 //   PM_RGD      v = gf; X <- Retr_X(-step z); [V <- proj(V + gamma (X - Y))]; partial [2] |X - XPrev|^2
 //               (the whole RGD step + Nesterov V update of the two poses this workgroup owns)
-constexpr int KC = 2048;       // scalars of the input vector staged per chunk (KC * R * 8 bytes of LDS)
-constexpr int MREG = KC / 64;  // double2 registers per thread per chunk
+// KC = rows of M (scalars of the input vector) handled per chunk: KC * R * 8 bytes of LDS and KC / 64
+// 16-byte registers per lane.  One 2048-row chunk covers a 500-pose agent in a single round trip with one
+// workgroup per CU; larger agents use 1024-row chunks so that 3 workgroups fit a CU and one workgroup's
+// arithmetic overlaps the others' streams.
 
-template <int R, int MODE>
+template <int R, int MODE, int KC>
 __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, const TeamDev *team, int sel, int xb, int vb,
                                                  int zb, int sp, int max_inner, double step, int accel,
                                                  int num_robots) {
   const AgentDev &ag = agents[sel_cur(team, sel)];
+  constexpr int MREG = KC / 64;
   __shared__ double vs[R * KC];
   __shared__ double zs[8 * R];
   __shared__ double Ysh[2 * 4 * R];
@@ -1158,9 +1161,14 @@ void launch_hess(const LaunchCtx &c, int sel, int max_n, int xb, int egb, int vb
 void launch_precond(const LaunchCtx &c, int sel, int max_n, int mode, int xb, int vb, int zb, int sp, int max_inner,
                     double step, int accel, int num_robots) {
   const int grid = (4 * max_n + 7) / 8;
-#define PC_CALL(M)                                                                                              \
-  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL((k_precond<R, M>), dim3(grid), dim3(256), 0, c.stream, c.agents, c.team, \
-                                          sel, xb, vb, zb, sp, max_inner, step, accel, num_robots))
+#define PC_CALL(M)                                                                                                  \
+  if (4 * max_n <= 2048) {                                                                                           \
+    DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL((k_precond<R, M, 2048>), dim3(grid), dim3(256), 0, c.stream, c.agents,   \
+                                            c.team, sel, xb, vb, zb, sp, max_inner, step, accel, num_robots));       \
+  } else {                                                                                                           \
+    DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL((k_precond<R, M, 1024>), dim3(grid), dim3(256), 0, c.stream, c.agents,   \
+                                            c.team, sel, xb, vb, zb, sp, max_inner, step, accel, num_robots));       \
+  }
   if (mode == PM_PLAIN_) { PC_CALL(PM_PLAIN_); }
   else if (mode == PM_TCG_INIT_) { PC_CALL(PM_TCG_INIT_); }
   else if (mode == PM_TCG_STEP_) { PC_CALL(PM_TCG_STEP_); }
