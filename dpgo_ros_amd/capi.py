@@ -75,7 +75,7 @@ dpgo_agent_get_G dpgo_project_manifold dpgo_tangent_project dpgo_retract dpgo_ag
 dpgo_agent_robust_weight dpgo_agent_update_measurement_weights dpgo_agent_set_measurement_weight
 dpgo_agent_get_measurements dpgo_agent_should_update_weights dpgo_agent_clear_data_matrices
 dpgo_error_threshold_at_quantile dpgo_team_set_schedule dpgo_team_set_initial dpgo_team_exchange_all
-dpgo_agent_pull_local dpgo_team_time_kernel dpgo_team_run dpgo_team_step_begin dpgo_team_step_end dpgo_team_iteration dpgo_team_cost dpgo_team_update_weights dpgo_team_get_counters""".split()
+dpgo_agent_pull_local dpgo_team_time_kernel dpgo_team_run dpgo_team_get_coloring dpgo_team_run_colored dpgo_team_step_begin dpgo_team_step_end dpgo_team_iteration dpgo_team_cost dpgo_team_update_weights dpgo_team_get_counters""".split()
 
 
 class DpgoError(RuntimeError):
@@ -378,6 +378,14 @@ class Team:
 
     def run(self, iters):
         _chk(lib().dpgo_team_run(self.h, iters), "team_run")
+
+    def coloring(self):
+        col = np.zeros(len(self.ids), dtype=np.int32)
+        nc = _chk(lib().dpgo_team_get_coloring(self.h, _d(col)), "get_coloring")
+        return nc, col
+
+    def run_colored(self, sweeps):
+        _chk(lib().dpgo_team_run_colored(self.h, sweeps), "run_colored")
 
     def step_begin(self, sel_id):
         _chk(lib().dpgo_team_step_begin(self.h, sel_id), "step_begin")

@@ -92,6 +92,10 @@ struct TeamDev {
   int cur_sel;       // agent selected in the running iteration (published by the first kernel)
   int pad;
   const int *sched;  // [sched_len] local agent index selected at iteration k % sched_len
+  const int *group_ptr;      // colour classes of the agent graph (CSR): agents of one class share no edge,
+  const int *group_members;  // so they may take their block update in the same launches (blockIdx.y)
 };
+
+constexpr int SEL_GROUP0 = -16;  // sel <= SEL_GROUP0 selects colour class (SEL_GROUP0 - sel), member blockIdx.y
 
 }  // namespace dpgo

@@ -10,6 +10,7 @@ struct LaunchCtx {
   hipStream_t stream;
   const AgentDev *agents;  // device array
   TeamDev *team;           // device
+  int ny = 1;              // grid.y of the per-agent kernels: members of the colour class being updated
 };
 
 // preconditioner kernel modes (see kernels.hip)
@@ -39,7 +40,7 @@ void launch_nest_pre(const LaunchCtx &c, int sel, int only_agent, int num_agents
 void launch_nest_post(const LaunchCtx &c, int sel, int max_n, int num_robots, int restart_interval);
 void launch_nest_reset(const LaunchCtx &c, int sel, int max_n);
 void launch_advance(const LaunchCtx &c, int only_agent, int num_agents, int accel, int num_robots, int restart_interval,
-                    int bump_team);
+                    int bump_team, int inc = 1);
 void launch_status(const LaunchCtx &c, int sel, int only_agent, int num_agents, int max_n);
 void launch_rtr_begin(const LaunchCtx &c, int sel, double Delta0, double tol, int max_outer);
 void launch_rtr_eval2(const LaunchCtx &c, int sel, int max_n, int sp);

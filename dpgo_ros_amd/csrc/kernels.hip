@@ -29,7 +29,11 @@ namespace dpgo {
 __device__ __forceinline__ int sel_sched(const TeamDev *team, int sel) {
   return sel >= 0 ? sel : team->sched[team->iter % team->sched_len];
 }
-__device__ __forceinline__ int sel_cur(const TeamDev *team, int sel) { return sel >= 0 ? sel : team->cur_sel; }
+__device__ __forceinline__ int sel_cur(const TeamDev *team, int sel) {
+  if (sel >= 0) return sel;
+  if (sel > SEL_GROUP0) return team->cur_sel;
+  return team->group_members[team->group_ptr[SEL_GROUP0 - sel] + blockIdx.y];  // colour-parallel update
+}
 
 template <int R>
 __device__ __forceinline__ int spmm_blocks(int n) { return (n + (64 / R) - 1) / (64 / R); }
@@ -155,7 +159,8 @@ __global__ void k_pull(const AgentDev *agents, int dst) {
 }
 
 // end of an iteration: advance gamma/alpha/iter of one agent
-__device__ __forceinline__ void advance_agent(const AgentDev &ag, int accel, int num_robots, int restart_interval) {
+__device__ __forceinline__ void advance_agent(const AgentDev &ag, int accel, int num_robots, int restart_interval,
+                                              int inc = 1) {
   NestState ns = *ag.nest;
   if (accel) {
     const double Nr = (double)num_robots;
@@ -166,7 +171,7 @@ __device__ __forceinline__ void advance_agent(const AgentDev &ag, int accel, int
       ns.alpha = 1.0 / (ns.gamma * Nr);
     }
   }
-  ns.iter += 1;
+  ns.iter += inc;
   *ag.nest = ns;
 }
 
@@ -868,11 +873,11 @@ __global__ void k_nest_reset(const AgentDev *agents, const TeamDev *team, int se
 
 // end of an iteration (unfused paths): advance gamma/alpha/iter of every agent, and the team counter
 __global__ void k_advance(const AgentDev *agents, TeamDev *team, int only_agent, int accel, int num_robots,
-                          int restart_interval, int bump_team) {
+                          int restart_interval, int bump_team, int inc) {
   const int ai = only_agent >= 0 ? only_agent : (int)blockIdx.x;
   if (threadIdx.x != 0) return;
-  advance_agent(agents[ai], accel, num_robots, restart_interval);
-  if (bump_team && ai == 0) team->iter += 1;
+  advance_agent(agents[ai], accel, num_robots, restart_interval, inc);
+  if (bump_team && ai == 0) team->iter += inc;
 }
 
 // PART_D partial [0] = |X - XPrev|_F^2 over a 64-pose tile (blockIdx.y = agent when sel == -3)
@@ -1141,7 +1146,7 @@ static inline int spmm_grid(int r, int n) { const int ppb = 64 / r; return (n + 
 
 void launch_buildG(const LaunchCtx &c, int sel, int max_npub, int aux, int pull) {
   if (max_npub <= 0) return;
-  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_buildG<R>, dim3(spmm_grid(c.r, max_npub)), dim3(64), 0, c.stream, c.agents,
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_buildG<R>, dim3(spmm_grid(c.r, max_npub), c.ny), dim3(64), 0, c.stream, c.agents,
                                           c.team, sel, aux, pull));
 }
 void launch_pull(const LaunchCtx &c, int dst, int nshared) {
@@ -1150,12 +1155,12 @@ void launch_pull(const LaunchCtx &c, int dst, int nshared) {
   DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_pull<R>, dim3((len + 255) / 256), dim3(256), 0, c.stream, c.agents, dst));
 }
 void launch_eval(const LaunchCtx &c, int sel, int max_n, int xb, int egb, int gfb, int poff, const EvalOpts &o) {
-  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_eval<R>, dim3(spmm_grid(c.r, max_n)), dim3(64), 0, c.stream, c.agents,
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_eval<R>, dim3(spmm_grid(c.r, max_n), c.ny), dim3(64), 0, c.stream, c.agents,
                                           c.team, sel, xb, egb, gfb, poff, o.gmode, o.aux, o.advance, o.accel,
                                           o.num_robots, o.restart_interval));
 }
 void launch_hess(const LaunchCtx &c, int sel, int max_n, int xb, int egb, int vb, int ob, int poff) {
-  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_hess<R>, dim3(spmm_grid(c.r, max_n)), dim3(64), 0, c.stream, c.agents,
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_hess<R>, dim3(spmm_grid(c.r, max_n), c.ny), dim3(64), 0, c.stream, c.agents,
                                           c.team, sel, xb, egb, vb, ob, poff));
 }
 void launch_precond(const LaunchCtx &c, int sel, int max_n, int mode, int xb, int vb, int zb, int sp, int max_inner,
@@ -1163,10 +1168,10 @@ void launch_precond(const LaunchCtx &c, int sel, int max_n, int mode, int xb, in
   const int grid = (4 * max_n + 7) / 8;
 #define PC_CALL(M)                                                                                                  \
   if (4 * max_n <= 2048) {                                                                                           \
-    DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL((k_precond<R, M, 2048>), dim3(grid), dim3(256), 0, c.stream, c.agents,   \
+    DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL((k_precond<R, M, 2048>), dim3(grid, c.ny), dim3(256), 0, c.stream, c.agents,   \
                                             c.team, sel, xb, vb, zb, sp, max_inner, step, accel, num_robots));       \
   } else {                                                                                                           \
-    DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL((k_precond<R, M, 1024>), dim3(grid), dim3(256), 0, c.stream, c.agents,   \
+    DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL((k_precond<R, M, 1024>), dim3(grid, c.ny), dim3(256), 0, c.stream, c.agents,   \
                                             c.team, sel, xb, vb, zb, sp, max_inner, step, accel, num_robots));       \
   }
   if (mode == PM_PLAIN_) { PC_CALL(PM_PLAIN_); }
@@ -1176,11 +1181,11 @@ void launch_precond(const LaunchCtx &c, int sel, int max_n, int mode, int xb, in
 #undef PC_CALL
 }
 void launch_tcg_hv(const LaunchCtx &c, int sel, int max_n, int sp, int max_inner) {
-  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_tcg_hv<R>, dim3(spmm_grid(c.r, max_n)), dim3(64), 0, c.stream, c.agents,
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_tcg_hv<R>, dim3(spmm_grid(c.r, max_n), c.ny), dim3(64), 0, c.stream, c.agents,
                                           c.team, sel, sp, max_inner));
 }
 void launch_retract(const LaunchCtx &c, int sel, int max_n, int xb, int eb, double scale, int ob, int guard_state) {
-  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_retract<R>, dim3((max_n + 63) / 64), dim3(64), 0, c.stream, c.agents,
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_retract<R>, dim3((max_n + 63) / 64, c.ny), dim3(64), 0, c.stream, c.agents,
                                           c.team, sel, xb, eb, scale, ob, guard_state));
 }
 void launch_project_raw(const LaunchCtx &c, const double *X, double *out, int n) {
@@ -1207,27 +1212,27 @@ void launch_nest_reset(const LaunchCtx &c, int sel, int max_n) {
   hipLaunchKernelGGL(k_nest_reset, dim3((len + 255) / 256), dim3(256), 0, c.stream, c.agents, c.team, sel, c.r);
 }
 void launch_advance(const LaunchCtx &c, int only_agent, int num_agents, int accel, int num_robots, int restart_interval,
-                    int bump_team) {
+                    int bump_team, int inc) {
   hipLaunchKernelGGL(k_advance, dim3(only_agent >= 0 ? 1 : num_agents), dim3(64), 0, c.stream, c.agents, c.team,
-                     only_agent, accel, num_robots, restart_interval, bump_team);
+                     only_agent, accel, num_robots, restart_interval, bump_team, inc);
 }
 void launch_status(const LaunchCtx &c, int sel, int only_agent, int num_agents, int max_n) {
   dim3 grid((max_n + 63) / 64, (sel == -3 && only_agent < 0) ? num_agents : 1);
   DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_status<R>, grid, dim3(64), 0, c.stream, c.agents, c.team, sel, only_agent));
 }
 void launch_rtr_begin(const LaunchCtx &c, int sel, double Delta0, double tol, int max_outer) {
-  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_rtr_begin<R>, dim3(1), dim3(64), 0, c.stream, c.agents, c.team, sel, Delta0,
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_rtr_begin<R>, dim3(1, c.ny), dim3(64), 0, c.stream, c.agents, c.team, sel, Delta0,
                                           tol, max_outer));
 }
 void launch_rtr_eval2(const LaunchCtx &c, int sel, int max_n, int sp) {
-  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_rtr_eval2<R>, dim3(spmm_grid(c.r, max_n)), dim3(64), 0, c.stream, c.agents,
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_rtr_eval2<R>, dim3(spmm_grid(c.r, max_n), c.ny), dim3(64), 0, c.stream, c.agents,
                                           c.team, sel, sp));
 }
 void launch_rtr_accept(const LaunchCtx &c, int sel, int max_n, int sp, double tol, int max_outer, double max_radius) {
   const int len = max_n * 4 * c.r;
   int grid = (len + 255) / 256;
   if (grid > 64) grid = 64;
-  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_rtr_accept<R>, dim3(grid), dim3(256), 0, c.stream, c.agents, c.team, sel,
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_rtr_accept<R>, dim3(grid, c.ny), dim3(256), 0, c.stream, c.agents, c.team, sel,
                                           sp, tol, max_outer, max_radius));
 }
 void launch_pack(const LaunchCtx &c, const double *X, const int *frames, int count, double *out) {

@@ -106,7 +106,10 @@ struct dpgo_team {
   std::map<int, int> id2local;
   DevBuf<AgentDev> d_agents;
   DevBuf<TeamDev> d_team;
-  DevBuf<int> d_sched;
+  DevBuf<int> d_sched, d_group_ptr, d_group_members;
+  std::vector<std::vector<int>> groups;  // colour classes (local agent indices), greedy colouring
+  std::vector<int> color_of;
+  RtrState *h_states = nullptr;          // pinned, one per local agent
   DevBuf<double> d_tmp;  // scratch for raw manifold ops / dense factorisation
   std::vector<int> sched;
   int iter = 0;
@@ -377,9 +380,29 @@ int sync_descs(dpgo_team *t) {
   if (t->d_agents.upload(descs, t->stream)) { set_err("descriptor upload failed"); return DPGO_ERR; }
   if (t->sched.empty()) for (size_t k = 0; k < t->ag.size(); ++k) t->sched.push_back((int)k);
   if (t->d_sched.upload(t->sched, t->stream) || t->d_team.alloc(1)) { set_err("schedule upload failed"); return DPGO_ERR; }
+  // greedy colouring of the (local) agent graph in index order: same colour = no shared edge
+  const int na_ = (int)t->ag.size();
+  t->color_of.assign(na_, -1);
+  t->groups.clear();
+  for (int k = 0; k < na_; ++k) {
+    std::vector<char> used(na_ + 1, 0);
+    for (int nb : t->ag[k]->neighbors) {
+      auto it = t->id2local.find(nb);
+      if (it != t->id2local.end() && t->color_of[it->second] >= 0) used[t->color_of[it->second]] = 1;
+    }
+    int col = 0;
+    while (used[col]) ++col;
+    t->color_of[k] = col;
+    if ((int)t->groups.size() <= col) t->groups.resize(col + 1);
+    t->groups[col].push_back(k);
+  }
+  std::vector<int> gptr(1, 0), gmem;
+  for (auto &g : t->groups) { gmem.insert(gmem.end(), g.begin(), g.end()); gptr.push_back((int)gmem.size()); }
+  if (t->d_group_ptr.upload(gptr, t->stream) || t->d_group_members.upload(gmem, t->stream)) { set_err("group upload failed"); return DPGO_ERR; }
   TeamDev td{};
   td.num_agents = (int)t->ag.size(); td.sched_len = (int)t->sched.size(); td.iter = t->iter;
   td.restart_interval = t->prm.restart_interval; td.sched = t->d_sched.p;
+  td.group_ptr = t->d_group_ptr.p; td.group_members = t->d_group_members.p;
   HIPC(hipMemcpyAsync(t->d_team.p, &td, sizeof td, hipMemcpyHostToDevice, t->stream));
   HIPC(hipStreamSynchronize(t->stream));
   t->descs_dirty = false;
@@ -607,7 +630,8 @@ dpgo_team_t *dpgo_team_create(int device, const dpgo_params_t *p, int num_local,
   t->device = device; t->prm = *p;
   if (stream) t->stream = (hipStream_t)stream;
   else { if (hipStreamCreate(&t->stream) != hipSuccess) { delete t; set_err("hipStreamCreate failed"); return nullptr; } t->own_stream = true; }
-  if (hipHostMalloc((void **)&t->h_state, sizeof(RtrState)) != hipSuccess ||
+  if (hipHostMalloc((void **)&t->h_states, sizeof(RtrState) * std::max(1, num_local)) != hipSuccess ||
+      hipHostMalloc((void **)&t->h_state, sizeof(RtrState)) != hipSuccess ||
       hipHostMalloc((void **)&t->h_scal, sizeof(double) * 16) != hipSuccess) {
     delete t; set_err("pinned allocation failed"); return nullptr;
   }
@@ -627,6 +651,7 @@ void dpgo_team_destroy(dpgo_team_t *t) {
   for (auto &g : t->graph) if (g) (void)hipGraphExecDestroy(g);
   t->ag.clear();
   if (t->h_state) (void)hipHostFree(t->h_state);
+  if (t->h_states) (void)hipHostFree(t->h_states);
   if (t->h_scal) (void)hipHostFree(t->h_scal);
   if (t->own_stream) (void)hipStreamDestroy(t->stream);
   delete t;
@@ -1213,6 +1238,109 @@ int dpgo_team_run(dpgo_team_t *t, int iters) {
     t->counters[4] += batch;
     k += batch;
   }
+  return 0;
+}
+
+// ---- colour-parallel sweeps: the agents of one colour class share no edge, so their block
+// updates commute; they run in the same launches (blockIdx.y = member) and the result equals the sequential
+// schedule that visits the classes in order.  Non-accelerated RBCD only (the Nesterov scalars advance per
+// global iteration and do not commute).
+static int enqueue_optimize_group(dpgo_team_t *t, int g) {
+  LaunchCtx c = t->ctx();
+  const dpgo_params_t &p = t->prm;
+  const std::vector<int> &mem = t->groups[g];
+  c.ny = (int)mem.size();
+  const int sel = SEL_GROUP0 - g;
+  int mn = 0;
+  for (int k : mem) mn = std::max(mn, t->ag[k]->n);
+  if (p.method == DPGO_METHOD_RGD) {
+    launch_eval(c, sel, mn, B_X, B_EGRAD, B_GF, PART_C, eval_opts(t, 2, 0, 0));
+    int dirb = B_GF;
+    if (p.rgd_use_preconditioner) { launch_precond(c, sel, mn, PM_PLAIN_, B_X, B_GF, B_Z, 0, 0, 0.0, 0, p.num_robots); dirb = B_Z; }
+    launch_retract(c, sel, mn, B_X, dirb, -p.rgd_stepsize, B_X, -1);
+    launch_eval(c, sel, mn, B_X, B_EGRAD, B_GF, PART_A, eval_opts(t, 0, 0, 0));
+    for (int k : mem) {
+      Agent &a = *t->ag[k];
+      const double N4 = 4.0 * a.n;
+      if (p.rgd_use_preconditioner) { t->counters[0] += 1; t->counters[1] += 8.0 * N4 * N4; }
+      t->counters[2] += 2; t->counters[3] += 2 * spmm_bytes_of(t, a);
+      a.opt_pending_rgd = true;
+    }
+    return 0;
+  }
+  launch_eval(c, sel, mn, B_X, B_EGRAD, B_GF, PART_A, eval_opts(t, 2, 0, 0));
+  launch_rtr_begin(c, sel, p.rtr_initial_radius, p.gradnorm_tol, p.rtr_iterations);
+  int sp = 0, J = 2;
+  for (int k : mem) J = std::max(J, t->ag[k]->tcg_hint);
+  J = std::min(J, p.rtr_tcg_iterations);
+  auto pattern = [&]() {
+    launch_precond(c, sel, mn, PM_TCG_INIT_, B_X, 0, 0, sp, p.rtr_tcg_iterations, 0.0, 0, p.num_robots); sp ^= 1;
+    for (int q = 0; q < J; ++q) {
+      launch_tcg_hv(c, sel, mn, sp, p.rtr_tcg_iterations); sp ^= 1;
+      launch_precond(c, sel, mn, PM_TCG_STEP_, B_X, 0, 0, sp, p.rtr_tcg_iterations, 0.0, 0, p.num_robots); sp ^= 1;
+    }
+    launch_retract(c, sel, mn, B_X, B_ETA, 1.0, B_X2, sp);
+    launch_rtr_eval2(c, sel, mn, sp);
+    launch_rtr_accept(c, sel, mn, sp, p.gradnorm_tol, p.rtr_iterations, p.rtr_max_radius); sp ^= 1;
+  };
+  auto read_states = [&](bool &all_done) -> int {
+    for (size_t q = 0; q < mem.size(); ++q)
+      HIPC(hipMemcpyAsync(t->h_states + q, t->ag[mem[q]]->dev.st + sp, sizeof(RtrState), hipMemcpyDeviceToHost, t->stream));
+    HIPC(hipStreamSynchronize(t->stream));
+    all_done = true;
+    for (size_t q = 0; q < mem.size(); ++q) all_done = all_done && t->h_states[q].outer_done;
+    return 0;
+  };
+  bool done = false;
+  for (int o = 0; o < p.rtr_iterations; ++o) pattern();
+  if (read_states(done)) return DPGO_ERR;
+  int guard = 0;
+  while (!done && guard++ < 100000) {
+    pattern();
+    if (read_states(done)) return DPGO_ERR;
+  }
+  for (size_t q = 0; q < mem.size(); ++q) {
+    Agent &a = *t->ag[mem[q]];
+    const RtrState &hs = t->h_states[q];
+    a.opt.success = 1;
+    a.opt.f_init = hs.f_init; a.opt.gradnorm_init = hs.gn_init; a.opt.f_opt = hs.f1; a.opt.gradnorm_opt = hs.ngf;
+    a.opt.rtr_outer_iters = hs.outer_count; a.opt.tcg_iters_total = hs.tcg_total;
+    a.opt.hessvec_count = hs.hv_count; a.opt.precond_count = hs.pc_count; a.opt.accepted = hs.accepted;
+    a.opt_pending_rgd = false;
+    if (hs.outer_count > 0) a.tcg_hint = std::max(2, std::min(8, (hs.tcg_total + hs.outer_count - 1) / hs.outer_count + 1));
+    const double N4 = 4.0 * a.n;
+    t->counters[0] += hs.pc_count; t->counters[1] += hs.pc_count * 8.0 * N4 * N4;
+    t->counters[2] += hs.hv_count + 1 + hs.outer_count;
+    t->counters[3] += (hs.hv_count + 1 + hs.outer_count) * spmm_bytes_of(t, a);
+  }
+  return 0;
+}
+
+int dpgo_team_get_coloring(dpgo_team_t *t, int *color_of_agent) {
+  if (sync_descs(t)) return DPGO_ERR;
+  for (size_t k = 0; k < t->ag.size(); ++k) color_of_agent[k] = t->color_of[k];
+  return (int)t->groups.size();
+}
+
+int dpgo_team_run_colored(dpgo_team_t *t, int sweeps) {
+  if (sync_descs(t)) return DPGO_ERR;
+  const dpgo_params_t &p = t->prm;
+  if (p.acceleration) { set_err("colour-parallel sweeps need acceleration = 0"); return DPGO_ERR; }
+  for (auto &a : t->ag) if (!a->has_X) { set_err("run_colored before set_initial"); return DPGO_NOT_READY; }
+  LaunchCtx c = t->ctx();
+  const int na = (int)t->ag.size();
+  for (int sw = 0; sw < sweeps; ++sw)
+    for (size_t g = 0; g < t->groups.size(); ++g) {
+      const int gs = (int)t->groups[g].size();
+      launch_copy(c, -3, -1, na, t->max_n, B_X, B_XPREV, 0);
+      const int rc = enqueue_optimize_group(t, (int)g);
+      if (rc) return rc;
+      launch_status(c, -3, -1, na, t->max_n);
+      launch_advance(c, -1, na, 0, p.num_robots, p.restart_interval, 1, gs);
+      for (auto &a : t->ag) { a->rel_src = 0; a->iter += gs; if (p.robust_cost_type != DPGO_COST_L2) a->robust_inner_iter += gs; }
+      t->iter += gs;
+      t->counters[4] += gs;
+    }
   return 0;
 }
 

@@ -158,6 +158,11 @@ int dpgo_team_run(dpgo_team_t *t, int iters);
  * of `sel_id` if it lives here + bookkeeping.  sel_id is a global robot id. */
 int dpgo_team_step_begin(dpgo_team_t *t, int sel_id);
 int dpgo_team_step_end(dpgo_team_t *t, int sel_id);
+/* colour-parallel sweeps: agents without a shared edge take their block update in the same
+ * launches; identical to the sequential schedule that visits the colour classes in order (class 0 first,
+ * members in id order).  One sweep = one block update of every agent.  Needs acceleration = 0. */
+int dpgo_team_get_coloring(dpgo_team_t *t, int *color_of_agent); /* returns the number of classes */
+int dpgo_team_run_colored(dpgo_team_t *t, int sweeps);
 int dpgo_team_iteration(dpgo_team_t *t);
 /* global cost of the concatenated iterate, evaluated on the device */
 int dpgo_team_cost(dpgo_team_t *t, double *f);

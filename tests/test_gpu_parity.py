@@ -406,3 +406,29 @@ def test_full_size_properties_sphere2500():
     t.exchange_all()
     assert abs(t.cost() - prev) <= 1e-10 * prev
     t.close()
+
+
+@pytest.mark.parametrize("dataset,N,method", [("sphere2500", 5, capi.METHOD_RTR), ("sphere2500", 8, capi.METHOD_RGD),
+                                               ("smallGrid3D", 3, capi.METHOD_RTR)])
+def test_colour_parallel_sweeps_equal_the_permuted_sequential_schedule(dataset, N, method):
+    """agents of one colour class update in the same launches; the result must equal the
+    sequential schedule [class 0 ..., class 1 ...] -- bitwise on the HIP path, to tolerance vs the oracle."""
+    kw = dict(method=method, acceleration=0, rgd_stepsize=0.2, gradnorm_tol=1e-2)
+    th, to, n = make_pair(dataset, N, **kw)
+    nc, col = th.coloring()
+    order = [a for c in range(nc) for a in range(N) if col[a] == c]
+    assert nc == 2 and sorted(order) == list(range(N))  # chain of agents: two colours
+    sweeps = 4
+    th.run_colored(sweeps)
+    to.set_schedule(order)
+    for _ in range(sweeps * N):
+        to.iterate()
+    assert np.abs(th.global_X() - to.global_X()).max() < 1e-7
+    assert abs(th.cost() - to.cost()) <= 1e-9 * abs(to.cost())
+    assert th.iteration() == sweeps * N
+    ts, _, _ = make_pair(dataset, N, **kw)
+    ts.set_schedule(order)
+    ts.run(sweeps * N)
+    assert np.array_equal(ts.global_X(), th.global_X())  # same kernels, same order of arithmetic per agent
+    ts.close()
+    th.close()
