@@ -75,7 +75,7 @@ dpgo_agent_get_G dpgo_project_manifold dpgo_tangent_project dpgo_retract dpgo_ag
 dpgo_agent_robust_weight dpgo_agent_update_measurement_weights dpgo_agent_set_measurement_weight
 dpgo_agent_get_measurements dpgo_agent_should_update_weights dpgo_agent_clear_data_matrices
 dpgo_error_threshold_at_quantile dpgo_team_set_schedule dpgo_team_set_initial dpgo_team_exchange_all
-dpgo_agent_pull_local dpgo_team_time_kernel dpgo_team_run dpgo_team_get_coloring dpgo_team_run_colored dpgo_team_step_begin dpgo_team_step_end dpgo_team_iteration dpgo_team_cost dpgo_team_update_weights dpgo_team_get_counters""".split()
+dpgo_agent_pull_local dpgo_team_time_kernel dpgo_team_run dpgo_team_get_coloring dpgo_team_run_colored dpgo_team_set_groups dpgo_team_run_group dpgo_team_step_begin dpgo_team_step_end dpgo_team_iteration dpgo_team_cost dpgo_team_update_weights dpgo_team_get_counters""".split()
 
 
 class DpgoError(RuntimeError):
@@ -386,6 +386,14 @@ class Team:
 
     def run_colored(self, sweeps):
         _chk(lib().dpgo_team_run_colored(self.h, sweeps), "run_colored")
+
+    def set_groups(self, groups):
+        ptr = np.cumsum([0] + [len(g) for g in groups]).astype(np.int32)
+        mem = np.array([a for g in groups for a in g], dtype=np.int32)
+        _chk(lib().dpgo_team_set_groups(self.h, len(groups), _d(ptr), _d(mem)), "set_groups")
+
+    def run_group(self, g, count):
+        _chk(lib().dpgo_team_run_group(self.h, g, count), "run_group")
 
     def step_begin(self, sel_id):
         _chk(lib().dpgo_team_step_begin(self.h, sel_id), "step_begin")

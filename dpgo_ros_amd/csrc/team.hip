@@ -109,6 +109,7 @@ struct dpgo_team {
   DevBuf<int> d_sched, d_group_ptr, d_group_members;
   std::vector<std::vector<int>> groups;  // colour classes (local agent indices), greedy colouring
   std::vector<int> color_of;
+  bool user_groups = false;              // groups supplied by dpgo_team_set_groups (global colouring)
   RtrState *h_states = nullptr;          // pinned, one per local agent
   DevBuf<double> d_tmp;  // scratch for raw manifold ops / dense factorisation
   std::vector<int> sched;
@@ -382,6 +383,7 @@ int sync_descs(dpgo_team *t) {
   if (t->d_sched.upload(t->sched, t->stream) || t->d_team.alloc(1)) { set_err("schedule upload failed"); return DPGO_ERR; }
   // greedy colouring of the (local) agent graph in index order: same colour = no shared edge
   const int na_ = (int)t->ag.size();
+  if (!t->user_groups) {
   t->color_of.assign(na_, -1);
   t->groups.clear();
   for (int k = 0; k < na_; ++k) {
@@ -395,6 +397,7 @@ int sync_descs(dpgo_team *t) {
     t->color_of[k] = col;
     if ((int)t->groups.size() <= col) t->groups.resize(col + 1);
     t->groups[col].push_back(k);
+  }
   }
   std::vector<int> gptr(1, 0), gmem;
   for (auto &g : t->groups) { gmem.insert(gmem.end(), g.begin(), g.end()); gptr.push_back((int)gmem.size()); }
@@ -1320,6 +1323,46 @@ int dpgo_team_get_coloring(dpgo_team_t *t, int *color_of_agent) {
   if (sync_descs(t)) return DPGO_ERR;
   for (size_t k = 0; k < t->ag.size(); ++k) color_of_agent[k] = t->color_of[k];
   return (int)t->groups.size();
+}
+
+// explicit colour classes (global robot ids; ids that are not local are ignored) for teams that hold only part
+// of the problem: the colouring must be global so that no two agents updated together share an edge
+int dpgo_team_set_groups(dpgo_team_t *t, int num_groups, const int *group_ptr, const int *member_ids) {
+  t->groups.assign(num_groups, {});
+  t->color_of.assign(t->ag.size(), -1);
+  for (int g = 0; g < num_groups; ++g)
+    for (int q = group_ptr[g]; q < group_ptr[g + 1]; ++q) {
+      auto it = t->id2local.find(member_ids[q]);
+      if (it == t->id2local.end()) continue;
+      t->groups[g].push_back(it->second);
+      t->color_of[it->second] = g;
+    }
+  t->user_groups = true;
+  t->descs_dirty = true;
+  return 0;
+}
+
+// one colour class: `count` block updates of the global schedule (count = global size of the class)
+int dpgo_team_run_group(dpgo_team_t *t, int g, int count) {
+  if (sync_descs(t)) return DPGO_ERR;
+  const dpgo_params_t &p = t->prm;
+  if (p.acceleration) { set_err("colour-parallel sweeps need acceleration = 0"); return DPGO_ERR; }
+  if (g < 0 || g >= (int)t->groups.size()) { set_err("bad group"); return DPGO_ERR; }
+  LaunchCtx c = t->ctx();
+  const int na = (int)t->ag.size();
+  if (na == 0) return 0;
+  launch_copy(c, -3, -1, na, t->max_n, B_X, B_XPREV, 0);
+  if (!t->groups[g].empty()) {
+    const int rc = enqueue_optimize_group(t, g);
+    if (rc) return rc;
+  }
+  launch_status(c, -3, -1, na, t->max_n);
+  launch_advance(c, -1, na, 0, p.num_robots, p.restart_interval, 1, count);
+  for (auto &a : t->ag) { a->rel_src = 0; a->iter += count; if (p.robust_cost_type != DPGO_COST_L2) a->robust_inner_iter += count; }
+  for (int k : t->groups[g]) t->ag[k]->publish_requested = true;
+  t->iter += count;
+  t->counters[4] += count;
+  return 0;
 }
 
 int dpgo_team_run_colored(dpgo_team_t *t, int sweeps) {

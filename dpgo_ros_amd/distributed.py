@@ -38,6 +38,19 @@ def owner_of(agent, world):
     return agent % world
 
 
+def greedy_coloring(nbrs, num_robots):
+    """colour classes of the agent graph (id order, smallest free colour): agents of a class share no edge"""
+    color = {}
+    for a in range(num_robots):
+        used = {color[b] for b in nbrs[a] if b in color}
+        c = 0
+        while c in used:
+            c += 1
+        color[a] = c
+    ncol = 1 + max(color.values())
+    return [[a for a in range(num_robots) if color[a] == c] for c in range(ncol)]
+
+
 class HipBackend:
     """local agents on this rank's GPU, through the C-ABI (dpgo_ros_amd.capi)."""
 
@@ -94,6 +107,14 @@ class HipBackend:
         self.team.agents[agent].pull_local()
 
     # batched form of the iteration (one launch for all local agents instead of one call per agent)
+    def set_groups(self, groups):
+        if self.team is not None:
+            self.team.set_groups(groups)
+
+    def run_group(self, g, members):
+        if self.team is not None:
+            self.team.run_group(g, len(members))
+
     def step_begin(self, sel):
         if self.team is not None:
             self.team.step_begin(sel)
@@ -176,6 +197,20 @@ class DistributedRBCD:
                     self.be.iterate(sel, True)
         self.k += 1
         return sel
+
+    def sweep_colored(self):
+        """one colour-parallel sweep of plain (non-accelerated) RBCD: for each colour class, every member
+        receives its neighbours' public poses, then all members -- on whatever ranks they live -- take
+        their block update concurrently.  Equals the sequential schedule [class 0 ..., class 1 ...]."""
+        if not hasattr(self, "groups"):
+            self.groups = greedy_coloring(self.nbrs, self.N)
+            self.be.set_groups(self.groups)
+        with self._ctx():
+            for g, members in enumerate(self.groups):
+                for a in members:
+                    self._exchange_to(a, (0,))
+                self.be.run_group(g, members)
+                self.k += len(members)
 
     def global_cost(self, torch_module, device):
         """f of the concatenated iterate: owned-edge partial sums, one 1-double all-reduce."""

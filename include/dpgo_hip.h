@@ -163,6 +163,9 @@ int dpgo_team_step_end(dpgo_team_t *t, int sel_id);
  * members in id order).  One sweep = one block update of every agent.  Needs acceleration = 0. */
 int dpgo_team_get_coloring(dpgo_team_t *t, int *color_of_agent); /* returns the number of classes */
 int dpgo_team_run_colored(dpgo_team_t *t, int sweeps);
+/* the same with an explicit (global) colouring, one class at a time, for one-process-per-GPU runs */
+int dpgo_team_set_groups(dpgo_team_t *t, int num_groups, const int *group_ptr, const int *member_ids);
+int dpgo_team_run_group(dpgo_team_t *t, int group, int count);
 int dpgo_team_iteration(dpgo_team_t *t);
 /* global cost of the concatenated iterate, evaluated on the device */
 int dpgo_team_cost(dpgo_team_t *t, double *f);

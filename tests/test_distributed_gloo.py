@@ -50,6 +50,15 @@ class OracleBackend:
                     ids, P = self.agents[b].get_public_poses(agent, aux)
                     ag.update_neighbor_poses(b, ids, P, aux)
 
+    def set_groups(self, groups):
+        self.groups = groups
+
+    def run_group(self, g, members):
+        # sequential equivalent: the members' block updates in id order; everyone else only counts
+        for m in members:
+            for a, ag in self.agents.items():
+                ag.iterate(a == m)
+
     def partial_cost(self):
         f = 0.0
         for a, ag in self.agents.items():
@@ -72,7 +81,7 @@ def _worker(rank, world, port, cfg, outdir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     ds, N, kw, iters = cfg
     m, mp, n = load(ds, N)
-    params = O.default_params(r=5, num_robots=N, **kw)
+    params = O.default_params(r=5, num_robots=N, **{k: v for k, v in kw.items() if k != "colored"})
     T, Y = O.odometry_init(m, n), O.fixed_stiefel(5)
     per = n // N
     offsets = {a: a * per for a in range(N)}
@@ -81,10 +90,15 @@ def _worker(rank, world, port, cfg, outdir):
     drv = DistributedRBCD(dist, be, mp, N, kw.get("acceleration", 0), rank, world)
     drv.exchange_all()
     costs = []
-    for k in range(iters):
-        drv.step()
-        if k % 3 == 2:
+    if kw.get("colored"):
+        for k in range(iters // N):
+            drv.sweep_colored()
             costs.append(drv.global_cost(torch, "cpu"))
+    else:
+        for k in range(iters):
+            drv.step()
+            if k % 3 == 2:
+                costs.append(drv.global_cost(torch, "cpu"))
     np.savez(os.path.join(outdir, "rank%d.npz" % rank), costs=np.array(costs),
              **{"X%d" % a: be.agents[a].get_X() for a in mine})
     dist.barrier()
@@ -95,6 +109,7 @@ CASES = [
     ("smallGrid3D", 3, dict(method=0, gradnorm_tol=1e-2), 9),
     ("smallGrid3D", 3, dict(method=1, acceleration=1, rgd_stepsize=0.2, restart_interval=4), 12),
     ("smallGrid3D", 2, dict(method=0, acceleration=1, restart_interval=5, gradnorm_tol=1e-2), 8),
+    ("smallGrid3D", 4, dict(method=0, gradnorm_tol=1e-2, colored=1), 12),
 ]
 
 
@@ -110,12 +125,16 @@ def test_two_rank_gloo_run_is_bitwise_the_single_process_schedule(cfg):
         outs = [np.load(os.path.join(d, "rank%d.npz" % r)) for r in range(2)]
         ds, N, kw, iters = cfg
         m, mp, n = load(ds, N)
-        ref = O.Team(mp, n, O.default_params(r=5, num_robots=N, **kw))
+        ref = O.Team(mp, n, O.default_params(r=5, num_robots=N, **{k: v for k, v in kw.items() if k != "colored"}))
         ref.set_initial(O.odometry_init(m, n), O.fixed_stiefel(5))
         costs = []
+        if kw.get("colored"):
+            from dpgo_ros_amd.distributed import greedy_coloring, topology
+            groups = greedy_coloring(topology(mp, N)[0], N)
+            ref.set_schedule([a for g in groups for a in g])
         for k in range(iters):
             ref.iterate()
-            if k % 3 == 2:
+            if (k % N == N - 1) if kw.get("colored") else (k % 3 == 2):
                 costs.append(ref.cost())
         for a in range(N):
             Xa = outs[a % 2]["X%d" % a]

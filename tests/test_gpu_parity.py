@@ -140,6 +140,56 @@ def test_team_run_matches_oracle(dataset, N, method, accel, iters):
     th.close()
 
 
+def _two_rank_colored_worker(rank, world, port, outdir):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    from dpgo_ros_amd.distributed import DistributedRBCD, HipBackend, owner_of
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    N, r = 4, 5
+    kw = dict(method=capi.METHOD_RTR, acceleration=0, gradnorm_tol=1e-2)
+    m, mp, n = load("smallGrid3D", N)
+    mine = [a for a in range(N) if owner_of(a, world) == rank]
+    be = HipBackend(mp.view(capi.MEAS_DTYPE), capi.default_params(r=r, num_robots=N, **kw), mine, 0, torch, host_staging=True)
+    per = n // N
+    be.team.set_initial(O.odometry_init(m, n), O.fixed_stiefel(r), offsets=np.array([a * per for a in mine], dtype=np.int32))
+    drv = DistributedRBCD(dist, be, mp, N, 0, rank, world)
+    drv.exchange_all()
+    for _ in range(3):
+        drv.sweep_colored()
+    cost = drv.global_cost(torch, "cpu")
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), cost=cost, groups=np.array([a for g in drv.groups for a in g]),
+             **{"X%d" % a: be.team.agents[a].get_X() for a in mine})
+    dist.barrier()
+    be.close()
+    dist.destroy_process_group()
+
+
+def test_two_processes_colour_parallel_sweeps():
+    """multi-process colour-parallel RBCD: members of a class on different ranks update concurrently."""
+    import socket
+    import tempfile
+    import torch.multiprocessing as mp_
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    with tempfile.TemporaryDirectory() as d:
+        mp_.spawn(_two_rank_colored_worker, args=(2, port, d), nprocs=2, join=True)
+        outs = [np.load(d + "/rank%d.npz" % r) for r in range(2)]
+    N = 4
+    m, mp, n = load("smallGrid3D", N)
+    ref = O.Team(mp, n, O.default_params(r=5, num_robots=N, method=O.METHOD_RTR, gradnorm_tol=1e-2))
+    ref.set_schedule(outs[0]["groups"])
+    ref.set_initial(O.odometry_init(m, n), O.fixed_stiefel(5))
+    for _ in range(3 * N):
+        ref.iterate()
+    for a in range(N):
+        assert np.abs(outs[a % 2]["X%d" % a] - ref.agents[a].get_X()).max() < 1e-8
+    assert abs(float(outs[0]["cost"]) - ref.cost()) <= 1e-9 * ref.cost()
+
+
 def _two_rank_worker(rank, world, port, outdir):
     import os
     import sys
