@@ -71,7 +71,7 @@ struct AgentDev {
   double *part;               // partial-sum scratch, [PART_STRIDE * MAX_PART]
   RtrState *st;               // [2]
   NestState *nest;            // [1]
-  double *scal;               // [16] misc scalars: 0 relchange^2, 1 f_opt, 2 gn_opt^2, 3 f_init, 4 gn_init^2
+  double *scal;               // [16] misc scalars: 5 owned-edge cost, 6 gamma' of the running iteration (published by k_nest_pre)
   double *resid;              // [nedges] residual scratch
 };
 
@@ -90,7 +90,7 @@ struct TeamDev {
   int iter;          // global iteration counter (device copy)
   int restart_interval;
   int cur_sel;       // agent selected in the running iteration (published by the first kernel)
-  int pad;
+  int stats_sel;     // agent whose final statistics are being evaluated on the side stream
   const int *sched;  // [sched_len] local agent index selected at iteration k % sched_len
   const int *group_ptr;      // colour classes of the agent graph (CSR): agents of one class share no edge,
   const int *group_members;  // so they may take their block update in the same launches (blockIdx.y)

@@ -31,6 +31,7 @@ __device__ __forceinline__ int sel_sched(const TeamDev *team, int sel) {
 }
 __device__ __forceinline__ int sel_cur(const TeamDev *team, int sel) {
   if (sel >= 0) return sel;
+  if (sel == -5) return team->stats_sel;
   if (sel > SEL_GROUP0) return team->cur_sel;
   return team->group_members[team->group_ptr[SEL_GROUP0 - sel] + blockIdx.y];  // colour-parallel update
 }
@@ -334,10 +335,18 @@ __global__ __launch_bounds__(64) void k_hess(const AgentDev *agents, const TeamD
 // arithmetic overlaps the others' streams.
 
 template <int R, int MODE, int KC>
-__global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, const TeamDev *team, int sel, int xb, int vb,
+__global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev *team, int sel, int xb, int vb,
                                                  int zb, int sp, int max_inner, double step, int accel,
-                                                 int num_robots) {
+                                                 int num_robots, int advance, int restart_interval) {
   const AgentDev &ag = agents[sel_cur(team, sel)];
+  if (MODE == PM_RGD_ && advance && blockIdx.x == 0 && threadIdx.x == 0) {
+    // end-of-iteration bookkeeping of the whole team, folded here: no workgroup of this kernel reads
+    // team->iter (they use cur_sel) or a NestState (gamma' comes from scal[6]), and the next kernel that
+    // does (k_nest_pre of the following iteration) is ordered behind this launch
+    for (int k = 0; k < team->num_agents; ++k) advance_agent(agents[k], accel, num_robots, restart_interval);
+    team->iter += 1;
+    team->stats_sel = team->cur_sel;
+  }
   constexpr int MREG = KC / 64;
   __shared__ double vs[R * KC];
   __shared__ double zs[8 * R];
@@ -423,7 +432,7 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, const T
       pre_p = ag.buf[B_XPREV][(size_t)col0 * R + tid];
     }
   }
-  if (MODE == PM_RGD_ && accel) nest_gamma = ag.nest->gamma;
+  if (MODE == PM_RGD_ && accel) nest_gamma = ag.scal[6];
 
   const int cg = tid >> 5, kl = tid & 31;
   const int col = col0 + cg;
@@ -517,12 +526,12 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, const T
 #pragma unroll
       for (int i = 0; i < 4 * R; ++i) {
         ag.buf[B_X][o + i] = x[i];
+        ag.buf[B_X2][o + i] = x[i];  // snapshot for the final-statistics evaluation (side stream)
         const double d = x[i] - Esh[2][lp * 4 * R + i];
         rel += d * d;
       }
       if (accel) {
-        const double Nr = (double)num_robots;
-        const double gamma = (1.0 + sqrt(1.0 + 4.0 * Nr * Nr * nest_gamma * nest_gamma)) / (2.0 * Nr);
+        const double gamma = nest_gamma;
         double v[4 * R];
 #pragma unroll
         for (int i = 0; i < 4 * R; ++i) v[i] = Esh[0][lp * 4 * R + i] + gamma * (x[i] - Esh[1][lp * 4 * R + i]);
@@ -781,6 +790,7 @@ __global__ __launch_bounds__(64) void k_nest_pre(const AgentDev *agents, TeamDev
   const double gamma = (1.0 + sqrt(1.0 + 4.0 * Nr * Nr * ns.gamma * ns.gamma)) / (2.0 * Nr);
   const double alpha = 1.0 / (gamma * Nr);
   const bool restart = ((ns.iter + 2) % restart_interval) == 0;  // iter is pre-increment: (iter+1)+1
+  if (blockIdx.x == 0 && tid == 0) ag.scal[6] = gamma;  // read by the fused RGD tail instead of the (mutable) NestState
   __shared__ Tile<R> TX, TV;
   tile_in<R>(TX, ag.buf[B_X], j0, cnt, tid);
   tile_in<R>(TV, ag.buf[B_V], j0, cnt, tid);
@@ -1164,15 +1174,17 @@ void launch_hess(const LaunchCtx &c, int sel, int max_n, int xb, int egb, int vb
                                           c.team, sel, xb, egb, vb, ob, poff));
 }
 void launch_precond(const LaunchCtx &c, int sel, int max_n, int mode, int xb, int vb, int zb, int sp, int max_inner,
-                    double step, int accel, int num_robots) {
+                    double step, int accel, int num_robots, int advance, int restart_interval) {
   const int grid = (4 * max_n + 7) / 8;
 #define PC_CALL(M)                                                                                                  \
   if (4 * max_n <= 2048) {                                                                                           \
     DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL((k_precond<R, M, 2048>), dim3(grid, c.ny), dim3(256), 0, c.stream, c.agents,   \
-                                            c.team, sel, xb, vb, zb, sp, max_inner, step, accel, num_robots));       \
+                                            c.team, sel, xb, vb, zb, sp, max_inner, step, accel, num_robots, advance,   \
+                                            restart_interval));                                                       \
   } else {                                                                                                           \
     DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL((k_precond<R, M, 1024>), dim3(grid, c.ny), dim3(256), 0, c.stream, c.agents,   \
-                                            c.team, sel, xb, vb, zb, sp, max_inner, step, accel, num_robots));       \
+                                            c.team, sel, xb, vb, zb, sp, max_inner, step, accel, num_robots, advance,   \
+                                            restart_interval));                                                       \
   }
   if (mode == PM_PLAIN_) { PC_CALL(PM_PLAIN_); }
   else if (mode == PM_TCG_INIT_) { PC_CALL(PM_TCG_INIT_); }
