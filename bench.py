@@ -101,10 +101,12 @@ def single_gpu(args):
 
     # ---- convergence leg (untimed): iterations to (f_k - f*)/f* <= 1e-6
     conv = {}
-    for name, cfg, cap in (("rgd_nesterov", RGD, 3000), ("rtr_nesterov", RTR, 1500)):
+    Tch = capi.chordal_init(m, n)  # GPU chordal relaxation of the whole graph
+    for name, cfg, cap, T0 in (("rgd_nesterov", RGD, 3000, T), ("rtr_nesterov", RTR, 1500, T),
+                               ("rtr_nesterov_chordal_init", RTR, 1500, Tch)):
         p2 = capi.default_params(r=WORKLOAD["r"], num_robots=WORKLOAD["num_robots"], **cfg)
         t2 = capi.Team.from_measurements(mp, p2, device=0)
-        t2.set_initial(T, Y)
+        t2.set_initial(T0, Y)
         hit, gap = None, None
         tt = 0.0
         for k in range(cap):

@@ -63,7 +63,7 @@ OK, NOT_READY, ERR = 0, 1, -1
 
 # every symbol include/dpgo_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = """dpgo_default_params dpgo_last_error dpgo_read_g2o dpgo_read_measurements_csv dpgo_partition
-dpgo_free dpgo_odometry_init dpgo_fixed_stiefel dpgo_lift dpgo_team_create dpgo_team_destroy
+dpgo_free dpgo_odometry_init dpgo_chordal_init dpgo_fixed_stiefel dpgo_lift dpgo_team_create dpgo_team_destroy
 dpgo_team_num_local dpgo_team_stream dpgo_team_synchronize dpgo_agent_add_measurements
 dpgo_agent_num_poses dpgo_agent_num_measurements dpgo_agent_get_neighbors dpgo_agent_public_pose_ids
 dpgo_agent_neighbor_pose_ids dpgo_agent_set_X dpgo_agent_get_X dpgo_agent_get_public_poses
@@ -148,6 +148,12 @@ def partition(m, num_poses, num_robots, weight_mode=WEIGHT_LIBRARY):
 def odometry_init(m, num_poses):
     T = np.zeros(12 * num_poses)
     lib().dpgo_odometry_init(_d(np.ascontiguousarray(m)), len(m), num_poses, _d(T))
+    return T
+
+
+def chordal_init(m, num_poses, device=0):
+    T = np.zeros(12 * num_poses)
+    _chk(lib().dpgo_chordal_init(device, _d(np.ascontiguousarray(m)), len(m), num_poses, _d(T)), "chordal_init")
     return T
 
 

@@ -5,7 +5,8 @@
 // directly (`class PGOAgentROS : public PGOAgent`, include/dpgo_ros/PGOAgentROS.h:121).  All
 // optimisation state lives in HBM behind the C-ABI; this class only keeps the host-side mirror the
 // wrapper touches (measurements with their mutable weights, neighbour pose dictionary, statuses).
-// Declared simplifications ("next"): local initialisation is odometry chaining;
+// Declared simplifications ("next"): local initialisation is odometry chaining or the GPU chordal
+// relaxation (InitializationMethod::GNC_TLS falls back to odometry);
 // the inter-robot frame alignment uses the first shared loop closure whose neighbour pose is known
 // (the reference averages robustly over all of them); robot 0 draws a fixed, not random, YLift.
 #pragma once
@@ -108,7 +109,14 @@ class PGOAgent {
       std::vector<dpgo_measurement_t> odo;
       for (const auto &m : mPoseGraph->odometry()) { dpgo_measurement_t c = m.toC(); c.r1 = c.r2 = 0; odo.push_back(c); }
       std::vector<double> Tl(12 * (size_t)n);
-      dpgo_odometry_init(odo.data(), (int)odo.size(), (int)n, Tl.data());
+      bool done = false;
+      if (mParams.localInitializationMethod == InitializationMethod::Chordal) {
+        // chordal relaxation of the local graph (odometry + private loop closures) on the GPU
+        std::vector<dpgo_measurement_t> loc = odo;
+        for (const auto &m : mPoseGraph->privateLoopClosures()) { dpgo_measurement_t c = m.toC(); c.r1 = c.r2 = 0; loc.push_back(c); }
+        done = dpgo_chordal_init(0, loc.data(), (int)loc.size(), (int)n, Tl.data()) == DPGO_OK;
+      }
+      if (!done) dpgo_odometry_init(odo.data(), (int)odo.size(), (int)n, Tl.data());
       Matrix M = Matrix::Zero(d, (d + 1) * n);
       for (unsigned i = 0; i < n; ++i) for (unsigned c = 0; c < 4; ++c) for (unsigned b = 0; b < 3; ++b) M(b, 4 * i + c) = Tl[12 * i + 3 * c + b];
       T.setData(M);

@@ -82,6 +82,9 @@ int dpgo_read_measurements_csv(const char *path, int weight_mode, dpgo_measureme
 void dpgo_partition(dpgo_measurement_t *m, int nm, int num_poses, int num_robots, int weight_mode);
 void dpgo_free(void *p);
 void dpgo_odometry_init(const dpgo_measurement_t *m, int nm, int num_poses, double *T /* 3x4 per pose */);
+/* two-stage chordal relaxation on the GPU (dense SPD solves), single-robot numbering; T as above.
+ * PGOAgent::initialize() with InitializationMethod::Chordal (src/PGOAgentROS.cpp:348, Node.cpp:106-112) */
+int dpgo_chordal_init(int device, const dpgo_measurement_t *m, int nm, int num_poses, double *T);
 void dpgo_fixed_stiefel(int r, double *YLift);
 void dpgo_lift(const double *T, int num_poses, const double *YLift, int r, double *X);
 

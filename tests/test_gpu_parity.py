@@ -482,3 +482,18 @@ def test_colour_parallel_sweeps_equal_the_permuted_sequential_schedule(dataset, 
     assert np.array_equal(ts.global_X(), th.global_X())  # same kernels, same order of arithmetic per agent
     ts.close()
     th.close()
+
+
+@pytest.mark.parametrize("dataset", ["tinyGrid3D", "smallGrid3D", "sphere2500"])
+def test_chordal_initialisation(dataset):
+    """8f-1: chordal relaxation on the GPU (dense SPD solves) vs the oracle's sparse-Cholesky version."""
+    m, _, n = load(dataset, 1)
+    Th = capi.chordal_init(m.view(capi.MEAS_DTYPE), n)
+    To = O.chordal_init(m, n)
+    assert np.abs(Th - To).max() < 1e-8 * max(1.0, np.abs(To).max())
+    R = Th.reshape(n, 4, 3)[:, :3, :]
+    assert np.abs(np.einsum("nia,nja->nij", R, R) - np.eye(3)).max() < 1e-12
+    assert np.all(np.linalg.det(R) > 0.999)
+    if dataset == "sphere2500":
+        c = 2 * O.measurement_cost(m, O.lift(Th, n, O.fixed_stiefel(5), 5), 5)
+        assert abs(c - 1971.175) < 0.01  # SE-Sync's chordal-initialisation cost for sphere2500
