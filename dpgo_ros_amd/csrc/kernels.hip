@@ -326,7 +326,7 @@ __global__ __launch_bounds__(64) void k_hess(const AgentDev *agents, const TeamD
 // round trip per 2048-row chunk.  The input vector is staged in LDS as SoA [a][k].  Modes:
 //   PM_PLAIN    v = buf[vb]                        -> buf[zb]            partials [0]<z,v> [1]<v,v>
 //   PM_TCG_INIT v = gf; r0 = gf; eta = 0; d0 = -z  (tCG set-up, RtrState ping-pong)
-//   PM_TCG_STEP v = r_old + alpha Hd (on the fly), eta += alpha d, z = P(v M)   (tCG body, part 2)
+//   PM_TCG_STEP stages Hd only: r += alpha Hd, eta += alpha d, z += alpha P(Hd M)   (tCG body, part 2)
 //   PM_RGD      v = gf; X <- Retr_X(-step z); [V <- proj(V + gamma (X - Y))]; partial [2] |X - XPrev|^2
 //               (the whole RGD step + Nesterov V update of the two poses this workgroup owns)
 // KC = rows of M (scalars of the input vector) handled per chunk: KC * R * 8 bytes of LDS and KC / 64
@@ -406,6 +406,11 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
   const double *Vin = (MODE == PM_PLAIN_) ? ag.buf[vb]
                       : ((MODE == PM_TCG_INIT_ || MODE == PM_RGD_) ? ag.buf[B_GF] : ag.buf[jpar ? B_R1 : B_R0]);
   const double *Hd = ag.buf[B_HD];
+  // tCG step: the preconditioned residual obeys the same recurrence as the residual,
+  //   r+ = r + alpha Hd   =>   z+ = P(r+ M) = z + alpha P(Hd M)      (P and M are linear),
+  // so only ONE vector (Hd) has to be pulled through every workgroup's LDS; r and z are updated in place by
+  // their owners.  (The oracle recomputes z from r+ directly; the two differ by round-off only.)
+  const double *Vstage = (MODE == PM_TCG_STEP_) ? Hd : Vin;
   const int col0 = 8 * blockIdx.x;
   const int npose = min(2, ag.n - 2 * (int)blockIdx.x);
 
@@ -457,17 +462,7 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
 #pragma unroll
       for (int u = 0; u < NSTG; ++u) {
         const int tt = 2 * (tid + 256 * u);  // kn * R is even
-        v[u] = (tt < kn * R) ? ld2(Vin + (size_t)k0 * R + tt) : make_double2(0.0, 0.0);
-      }
-      if (MODE == PM_TCG_STEP_) {
-#pragma unroll
-        for (int u = 0; u < NSTG; ++u) {
-          const int tt = 2 * (tid + 256 * u);
-          if (tt < kn * R) {
-            const double2 h = ld2(Hd + (size_t)k0 * R + tt);
-            v[u].x += alpha * h.x; v[u].y += alpha * h.y;
-          }
-        }
+        v[u] = (tt < kn * R) ? ld2(Vstage + (size_t)k0 * R + tt) : make_double2(0.0, 0.0);
       }
 #pragma unroll
       for (int u = 0; u < NSTG; ++u) {
@@ -562,6 +557,7 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
       if (MODE == PM_TCG_STEP_) {
         v += alpha * Hd[o + c * R + a];
         ag.buf[jpar ? B_R0 : B_R1][o + c * R + a] = v;  // r_new into the other half
+        z[c] = Z[o + c * R + a] + alpha * z[c];         // z_new = z_old + alpha P(Hd M)
       }
       if (MODE == PM_TCG_INIT_) {
         ag.buf[B_R0][o + c * R + a] = v;
