@@ -37,6 +37,7 @@ void launch_tangent_raw(const LaunchCtx &c, const double *X, const double *V, do
 void launch_retract_raw(const LaunchCtx &c, const double *X, const double *E, double *out, int n);
 void launch_nest_pre(const LaunchCtx &c, int sel, int only_agent, int num_agents, int max_n, int num_robots,
                      int restart_interval);
+void launch_stats_nest(const LaunchCtx &c, int num_agents, int max_n, int num_robots, int restart_interval);
 void launch_nest_post(const LaunchCtx &c, int sel, int max_n, int num_robots, int restart_interval);
 void launch_nest_reset(const LaunchCtx &c, int sel, int max_n);
 void launch_advance(const LaunchCtx &c, int only_agent, int num_agents, int accel, int num_robots, int restart_interval,

@@ -179,22 +179,15 @@ __device__ __forceinline__ void advance_agent(const AgentDev &ag, int accel, int
 // ------------------------------------------------------------------------------------------------
 // f, Euclidean gradient, Riemannian gradient (a3).  partials: [0] f, [1] |rgrad|^2
 // gmode: 0 G from the buffer, 1 assemble G from the slab, 2 assemble G pulling from co-resident
-// agents (both also store G).  advance: fold the end-of-iteration bookkeeping of the whole team
-// into workgroup 0 (this kernel reads neither team->iter nor the Nesterov state).
+// agents (both also store G).
 template <int R>
-__global__ __launch_bounds__(64) void k_eval(const AgentDev *agents, TeamDev *team, int sel, int xb, int egb, int gfb,
-                                             int poff, int gmode, int aux, int advance, int accel, int num_robots,
-                                             int restart_interval) {
+__device__ __forceinline__ void eval_body(const AgentDev *agents, const TeamDev *team, int sel, int xb, int egb, int gfb,
+                                          int poff, int gmode, int aux, int bx, double *Ysh, double *Wsh) {
   const AgentDev &ag = agents[sel_cur(team, sel)];
   constexpr int PPB = 64 / R;
-  __shared__ double Ysh[PPB * 4 * R], Wsh[PPB * 4 * R];
   const int lane = threadIdx.x, lp = lane / R, a = lane - lp * R;
-  const int j = blockIdx.x * PPB + lp;
-  if (advance && blockIdx.x == 0 && lane == 0) {
-    for (int k = 0; k < team->num_agents; ++k) advance_agent(agents[k], accel, num_robots, restart_interval);
-    team->iter += 1;
-  }
-  if (blockIdx.x * PPB >= ag.n) return;
+  const int j = bx * PPB + lp;
+  if (bx * PPB >= ag.n) return;
   const bool act = lp < PPB && j < ag.n;
   const double *X = ag.buf[xb];
   double fpart = 0, gpart = 0, eg3 = 0;
@@ -242,9 +235,17 @@ __global__ __launch_bounds__(64) void k_eval(const AgentDev *agents, TeamDev *te
   fpart = wave_sum(fpart);
   gpart = wave_sum(gpart);
   if (lane == 0) {
-    double *P = ag.part + poff + (size_t)blockIdx.x * PART_STRIDE;
+    double *P = ag.part + poff + (size_t)bx * PART_STRIDE;
     P[0] = fpart; P[1] = gpart;
   }
+}
+
+template <int R>
+__global__ __launch_bounds__(64) void k_eval(const AgentDev *agents, const TeamDev *team, int sel, int xb, int egb,
+                                             int gfb, int poff, int gmode, int aux) {
+  constexpr int PPB = 64 / R;
+  __shared__ double Ysh[PPB * 4 * R], Wsh[PPB * 4 * R];
+  eval_body<R>(agents, team, sel, xb, egb, gfb, poff, gmode, aux, (int)blockIdx.x, Ysh, Wsh);
 }
 
 // shared tail of every Hessian-vector product: curvature correction + tangent projection.
@@ -771,13 +772,14 @@ __global__ __launch_bounds__(64) void k_raw_op(const double *X, const double *V,
 // V = Y = X; partial [0] of PART_D = |X_new - XPrev|^2.  First kernel of an accelerated iteration:
 // publishes team->cur_sel.
 template <int R>
-__global__ __launch_bounds__(64) void k_nest_pre(const AgentDev *agents, TeamDev *team, int sel, int only_agent,
-                                                 int num_robots, int restart_interval) {
-  const int ai = only_agent >= 0 ? only_agent : (int)blockIdx.y;
+__device__ __forceinline__ void nest_pre_body(const AgentDev *agents, TeamDev *team, int sel, int only_agent,
+                                              int num_robots, int restart_interval, int bx, int by, Tile<R> &TX,
+                                              Tile<R> &TV) {
+  const int ai = only_agent >= 0 ? only_agent : by;
   const AgentDev &ag = agents[ai];
   const int selected = (sel == -2) ? -1 : sel_sched(team, sel);
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && sel == -1) team->cur_sel = selected;
-  const int j0 = blockIdx.x * 64, tid = threadIdx.x;
+  if (bx == 0 && by == 0 && threadIdx.x == 0 && sel == -1) team->cur_sel = selected;
+  const int j0 = bx * 64, tid = threadIdx.x;
   if (j0 >= ag.n) return;
   const int cnt = min(64, ag.n - j0);
   const bool optimizing = (ai == selected);
@@ -786,8 +788,7 @@ __global__ __launch_bounds__(64) void k_nest_pre(const AgentDev *agents, TeamDev
   const double gamma = (1.0 + sqrt(1.0 + 4.0 * Nr * Nr * ns.gamma * ns.gamma)) / (2.0 * Nr);
   const double alpha = 1.0 / (gamma * Nr);
   const bool restart = ((ns.iter + 2) % restart_interval) == 0;  // iter is pre-increment: (iter+1)+1
-  if (blockIdx.x == 0 && tid == 0) ag.scal[6] = gamma;  // read by the fused RGD tail instead of the (mutable) NestState
-  __shared__ Tile<R> TX, TV;
+  if (bx == 0 && tid == 0) ag.scal[6] = gamma;  // read by the fused RGD tail instead of the (mutable) NestState
   tile_in<R>(TX, ag.buf[B_X], j0, cnt, tid);
   tile_in<R>(TV, ag.buf[B_V], j0, cnt, tid);
   __syncthreads();
@@ -825,7 +826,32 @@ __global__ __launch_bounds__(64) void k_nest_pre(const AgentDev *agents, TeamDev
   }
   if (!optimizing) {
     rel = wave_sum(rel);
-    if (tid == 0) ag.part[PART_D + (size_t)blockIdx.x * PART_STRIDE] = rel;
+    if (tid == 0) ag.part[PART_D + (size_t)bx * PART_STRIDE] = rel;
+  }
+}
+
+template <int R>
+__global__ __launch_bounds__(64) void k_nest_pre(const AgentDev *agents, TeamDev *team, int sel, int only_agent,
+                                                 int num_robots, int restart_interval) {
+  __shared__ Tile<R> TX, TV;
+  nest_pre_body<R>(agents, team, sel, only_agent, num_robots, restart_interval, (int)blockIdx.x, (int)blockIdx.y, TX, TV);
+}
+
+// Heterogeneous launch that closes iteration k and opens iteration k+1 inside captured graphs: the first
+// nest_tiles * num_agents workgroups run the Nesterov step of every agent (k_nest_pre), the rest evaluate
+// f_opt / gradnorm_opt of the agent that just optimized on its snapshot B_X2 (k_eval, sel = stats_sel).
+// The two halves touch disjoint data: the statistics read B_X2 / G of agent a, the Nesterov step writes
+// X, Y, V, XPrev; one launch boundary per iteration disappears.
+template <int R>
+__global__ __launch_bounds__(64) void k_stats_nest(const AgentDev *agents, TeamDev *team, int nest_tiles, int num_agents,
+                                                   int num_robots, int restart_interval) {
+  __shared__ Tile<R> TX, TV;
+  const int nb_nest = nest_tiles * num_agents;
+  const int b = (int)blockIdx.x;
+  if (b < nb_nest) {
+    nest_pre_body<R>(agents, team, -1, -1, num_robots, restart_interval, b % nest_tiles, b / nest_tiles, TX, TV);
+  } else {
+    eval_body<R>(agents, team, -5, B_X2, B_EGRAD2, B_GF2, PART_A, 0, 0, b - nb_nest, TX.d, TV.d);
   }
 }
 
@@ -1162,8 +1188,7 @@ void launch_pull(const LaunchCtx &c, int dst, int nshared) {
 }
 void launch_eval(const LaunchCtx &c, int sel, int max_n, int xb, int egb, int gfb, int poff, const EvalOpts &o) {
   DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_eval<R>, dim3(spmm_grid(c.r, max_n), c.ny), dim3(64), 0, c.stream, c.agents,
-                                          c.team, sel, xb, egb, gfb, poff, o.gmode, o.aux, o.advance, o.accel,
-                                          o.num_robots, o.restart_interval));
+                                          c.team, sel, xb, egb, gfb, poff, o.gmode, o.aux));
 }
 void launch_hess(const LaunchCtx &c, int sel, int max_n, int xb, int egb, int vb, int ob, int poff) {
   DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_hess<R>, dim3(spmm_grid(c.r, max_n), c.ny), dim3(64), 0, c.stream, c.agents,
@@ -1210,6 +1235,12 @@ void launch_nest_pre(const LaunchCtx &c, int sel, int only_agent, int num_agents
   dim3 grid((max_n + 63) / 64, only_agent >= 0 ? 1 : num_agents);
   DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_nest_pre<R>, grid, dim3(64), 0, c.stream, c.agents, c.team, sel, only_agent,
                                           num_robots, restart_interval));
+}
+void launch_stats_nest(const LaunchCtx &c, int num_agents, int max_n, int num_robots, int restart_interval) {
+  const int nest_tiles = (max_n + 63) / 64;
+  const int grid = nest_tiles * num_agents + spmm_grid(c.r, max_n);
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_stats_nest<R>, dim3(grid), dim3(64), 0, c.stream, c.agents, c.team, nest_tiles,
+                                          num_agents, num_robots, restart_interval));
 }
 void launch_nest_post(const LaunchCtx &c, int sel, int max_n, int num_robots, int restart_interval) {
   DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_nest_post<R>, dim3((max_n + 63) / 64), dim3(64), 0, c.stream, c.agents,

@@ -1235,7 +1235,23 @@ int dpgo_team_run(dpgo_team_t *t, int iters) {
       HIPC(hipStreamBeginCapture(t->stream, hipStreamCaptureModeThreadLocal));
       int rc = 0;
       t->prev_side_ev = nullptr;
-      for (int rep = 0; rep < (1 << gi) && !rc; ++rep) rc = enqueue_team_iteration(t, true, false, -1, 0);
+      if (p.acceleration && !t->use_side) {
+        // 3 launches per iteration: [statistics of iteration k-1 + Nesterov step of iteration k] in one
+        // heterogeneous kernel, cost/gradient (+ G from the neighbours' Y), preconditioner + RGD step +
+        // Nesterov V + bookkeeping.  The first iteration has no statistics to close, the last one is closed
+        // by a plain evaluation.
+        LaunchCtx c = t->ctx();
+        const int na = (int)t->ag.size(), mn = t->max_n;
+        for (int rep = 0; rep < (1 << gi); ++rep) {
+          if (rep == 0) launch_nest_pre(c, -1, -1, na, mn, p.num_robots, p.restart_interval);
+          else launch_stats_nest(c, na, mn, p.num_robots, p.restart_interval);
+          launch_eval(c, -1, mn, B_X, B_EGRAD, B_GF, PART_C, eval_opts(t, 2, 1, 0));
+          launch_precond(c, -1, mn, PM_RGD_, B_X, B_GF, B_Z, 0, 0, p.rgd_stepsize, 1, p.num_robots, 1, p.restart_interval);
+        }
+        launch_eval(c, -5, mn, B_X2, B_EGRAD2, B_GF2, PART_A, eval_opts(t, 0, 0, 0));
+      } else {
+        for (int rep = 0; rep < (1 << gi) && !rc; ++rep) rc = enqueue_team_iteration(t, true, false, -1, 0);
+      }
       if (t->prev_side_ev) { HIPC(hipStreamWaitEvent(t->stream, t->prev_side_ev, 0)); t->prev_side_ev = nullptr; }  // join
       HIPC(hipStreamEndCapture(t->stream, &g));
       if (rc) { (void)hipGraphDestroy(g); return rc; }
