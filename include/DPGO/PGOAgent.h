@@ -13,9 +13,14 @@
 #include <cassert>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
+#include <chrono>
 #include <iostream>
 #include <memory>
+#include <mutex>
+#include <random>
 #include <set>
+#include <thread>
 
 #include "DPGO_robust.h"
 #include "DPGO_types.h"
@@ -71,7 +76,7 @@ class PGOAgent {
     }
     mTeamRobotActive[mID] = true;
   }
-  virtual ~PGOAgent() { destroyTeam(); }
+  virtual ~PGOAgent() { endOptimizationLoop(); destroyTeam(); }
   PGOAgent(const PGOAgent &) = delete;
   PGOAgent &operator=(const PGOAgent &) = delete;
 
@@ -89,7 +94,9 @@ class PGOAgent {
   }
 
   // ---- measurements
-  void addMeasurement(const RelativeSEMeasurement &m) {  // :277, :1307
+  void addMeasurement(const RelativeSEMeasurement &m) {
+    std::lock_guard<std::recursive_mutex> lock_(mMutex);
+  // :277, :1307
     if (mState != PGOAgentState::WAIT_FOR_DATA && mState != PGOAgentState::WAIT_FOR_INITIALIZATION && mPoseGraph->hasMeasurement(PoseID(m.r1, m.p1), PoseID(m.r2, m.p2))) return;
     mPoseGraph->addMeasurement(m);
   }
@@ -101,6 +108,8 @@ class PGOAgent {
 
   // ---- initialisation (:348, :353-360)
   void initialize(const PoseArray *TInitPtr = nullptr) {
+    std::lock_guard<std::recursive_mutex> lock_(mMutex);
+
     if (mPoseGraph->n() == 0) return;
     const unsigned n = mPoseGraph->n();
     PoseArray T(d, n);
@@ -125,6 +134,8 @@ class PGOAgent {
     mState = PGOAgentState::WAIT_FOR_INITIALIZATION;
   }
   void initializeInGlobalFrame(const Pose &T_world_robot) {
+    std::lock_guard<std::recursive_mutex> lock_(mMutex);
+
     DPGO_CHECK(YLift.has_value());
     if (!TLocalInit) initialize();
     DPGO_CHECK(TLocalInit.has_value());
@@ -139,6 +150,7 @@ class PGOAgent {
     mState = PGOAgentState::INITIALIZED;
     pushNeighborDict(false);
     pushNeighborDict(true);
+    if (mParams.asynchronous) startOptimizationLoop(mParams.asynchronousOptimizationRate);
   }
   void anchorFirstPose() {}  // :360 -- gauge fixing of the single-robot case; no-op for the lifted iterate
   bool isRobotInitialized(unsigned id) const {  // :451,468,1144
@@ -149,6 +161,8 @@ class PGOAgent {
 
   // ---- public pose exchange (:424, :666-668, :1276-1278)
   bool getSharedPose(unsigned index, Matrix &Mout) {
+    std::lock_guard<std::recursive_mutex> lock_(mMutex);
+
     if (mState != PGOAgentState::INITIALIZED || index >= num_poses()) return false;
     const Matrix X = fetchX(0);
     Mout = mat_block(X, 0, index * (d + 1), r, d + 1);
@@ -157,18 +171,24 @@ class PGOAgent {
   bool getSharedPoseDictWithNeighbor(PoseDict &map, unsigned neighborID) { return sharedDict(map, neighborID, 0); }
   bool getAuxSharedPoseDictWithNeighbor(PoseDict &map, unsigned neighborID) { return sharedDict(map, neighborID, 1); }
   void updateNeighborPoses(unsigned neighborID, const PoseDict &poseDict) {
+    std::lock_guard<std::recursive_mutex> lock_(mMutex);
+
     for (const auto &kv : poseDict) neighborPoseDict[kv.first] = kv.second;
     if (mState == PGOAgentState::WAIT_FOR_INITIALIZATION && TLocalInit && YLift && mParams.multirobotInitialization)
       tryAlignWithNeighbor(neighborID, poseDict);
     if (mState == PGOAgentState::INITIALIZED) pushDict(neighborID, poseDict, false);
   }
   void updateAuxNeighborPoses(unsigned neighborID, const PoseDict &poseDict) {
+    std::lock_guard<std::recursive_mutex> lock_(mMutex);
+
     for (const auto &kv : poseDict) neighborAuxPoseDict[kv.first] = kv.second;
     if (mState == PGOAgentState::INITIALIZED) pushDict(neighborID, poseDict, true);
   }
 
   // ---- the hot call (:160, :1185)
   bool iterate(bool doOptimization = true) {
+    std::lock_guard<std::recursive_mutex> lock_(mMutex);
+
     if (mState != PGOAgentState::INITIALIZED) { mIterationNumber++; return false; }
     syncMeasurements();
     if ((int)mIterationNumber != dpgo_agent_iteration_number(team_, (int)mID))
@@ -191,6 +211,8 @@ class PGOAgent {
     return rc == DPGO_OK;
   }
   virtual void reset() {  // :223 (overridden by PGOAgentROS::reset, which calls this first)
+    endOptimizationLoop();
+    std::lock_guard<std::recursive_mutex> lock_(mMutex);
     destroyTeam();
     mInstanceNumber++;
     mIterationNumber = 0; mWeightUpdateCount = 0; mRobustOptInnerIter = 0;
@@ -206,6 +228,32 @@ class PGOAgent {
     mTeamRobotActive[mID] = true;
     pushed_ = {0, 0, 0};
   }
+
+  // ---- asynchronous (ASAPP) mode: a library-owned thread calls iterate(true) at exponentially distributed
+  // intervals of mean 1/freq and raises mPublishAsynchronousRequested (src/PGOAgentROS.cpp:119-127); every entry
+  // point of this class serialises on mMutex, so the ROS thread may call update*NeighborPoses / get*SharedPoseDict
+  // / getStatus concurrently (SURVEY 3d, 8b "Threading")
+  void startOptimizationLoop(double freq) {
+    if (mOptimizationThread) return;
+    mEndLoopRequested = false;
+    mOptimizationThread.reset(new std::thread([this, freq]() {
+      std::mt19937 rng(1234u + mID);
+      std::exponential_distribution<double> gap(freq);
+      while (!mEndLoopRequested) {
+        std::this_thread::sleep_for(std::chrono::duration<double>(gap(rng)));
+        if (mEndLoopRequested) break;
+        std::lock_guard<std::recursive_mutex> lock_(mMutex);
+        if (mState == PGOAgentState::INITIALIZED && iterate(true)) mPublishAsynchronousRequested = true;
+      }
+    }));
+  }
+  void endOptimizationLoop() {
+    if (!mOptimizationThread) return;
+    mEndLoopRequested = true;
+    mOptimizationThread->join();
+    mOptimizationThread.reset();
+  }
+  bool isOptimizationRunning() const { return (bool)mOptimizationThread; }
 
   // ---- status / team bookkeeping (:616, :965, :1116-1121, :208-210)
   PGOAgentStatus getStatus() { mStatus.agentID = mID; mStatus.state = mState; mStatus.instanceNumber = mInstanceNumber; mStatus.iterationNumber = mIterationNumber; return mStatus; }
@@ -234,12 +282,16 @@ class PGOAgent {
 
   // ---- robust path (:1218, :1049, :1341)
   bool computeMeasurementResidual(const RelativeSEMeasurement &m, double *residual) {
+    std::lock_guard<std::recursive_mutex> lock_(mMutex);
+
     if (mState != PGOAgentState::INITIALIZED) return false;
     syncMeasurements();
     const dpgo_measurement_t c = m.toC();
     return dpgo_agent_compute_residual(team_, (int)mID, &c, residual) == DPGO_OK;
   }
   void updateMeasurementWeights() {
+    std::lock_guard<std::recursive_mutex> lock_(mMutex);
+
     for (auto *m : mPoseGraph->activeLoopClosures()) {
       if (m->fixedWeight) continue;
       if (m->r1 != m->r2) { const unsigned other = (m->r1 == mID) ? m->r2 : m->r1; if (other < mID) continue; }
@@ -252,6 +304,8 @@ class PGOAgent {
     mPoseGraph->clearDataMatrices();
   }
   bool setMeasurementWeight(const PoseID &src, const PoseID &dst, double weight, bool fixed_weight = false) {
+    std::lock_guard<std::recursive_mutex> lock_(mMutex);
+
     RelativeSEMeasurement *m = mPoseGraph->findMeasurement(src, dst);
     if (!m) return false;
     m->weight = weight; m->fixedWeight = fixed_weight;
@@ -260,6 +314,8 @@ class PGOAgent {
 
   // ---- rounding (:622-627, :774-812, :1395)
   bool getTrajectoryInGlobalFrame(PoseArray &Trajectory) {
+    std::lock_guard<std::recursive_mutex> lock_(mMutex);
+
     if (!globalAnchor || mState != PGOAgentState::INITIALIZED) return false;
     const Matrix X = fetchX(0);
     Trajectory = PoseArray(d, num_poses());
@@ -298,6 +354,9 @@ class PGOAgent {
   std::optional<LiftedPose> globalAnchor;
   std::optional<PoseArray> TLocalInit;
   PoseDict neighborPoseDict, neighborAuxPoseDict;
+  std::recursive_mutex mMutex;
+  std::unique_ptr<std::thread> mOptimizationThread;
+  std::atomic<bool> mEndLoopRequested{false};
 
  private:
   dpgo_team_t *team_ = nullptr;
@@ -355,6 +414,8 @@ class PGOAgent {
     return X;
   }
   bool sharedDict(PoseDict &map, unsigned nbr, int aux) {
+    std::lock_guard<std::recursive_mutex> lock_(mMutex);
+
     if (mState != PGOAgentState::INITIALIZED) return false;
     syncMeasurements();
     const int cnt = dpgo_agent_public_pose_ids(team_, (int)mID, (int)nbr, nullptr);

@@ -3,8 +3,10 @@
 // ROS is absent from this image, so this subclass stands in for `class PGOAgentROS : public PGOAgent`
 // and touches the same protected members (src/PGOAgentROS.cpp).
 // Usage: mock_wrapper <g2o> <num_robots> <iterations> [accel]   -> prints one cost line per iteration.
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <thread>
 #include <memory>
 #include <vector>
 
@@ -50,7 +52,8 @@ int main(int argc, char **argv) {
   if (argc < 4) return 1;
   const unsigned N = (unsigned)std::atoi(argv[2]);
   const int iters = std::atoi(argv[3]);
-  const bool accel = argc > 4 && std::atoi(argv[4]) != 0;
+  const int mode = argc > 4 ? std::atoi(argv[4]) : 0;  // 0 plain, 1 accelerated, 2 asynchronous (ASAPP)
+  const bool accel = mode == 1;
   size_t num_poses = 0;
   std::vector<RelativeSEMeasurement> dataset = read_g2o_file(argv[1], num_poses);
   PGOAgentParameters params(3, 5, N);
@@ -59,6 +62,12 @@ int main(int argc, char **argv) {
   params.acceleration = accel;
   params.restartInterval = 7;
   params.relChangeTol = 0.2;
+  if (mode == 2) {  // src/PGOAgentROSNode.cpp:86-93: asynchronous => RGD at asynchronous_rate; README.md:52 stepsize 0.2
+    params.asynchronous = true;
+    params.asynchronousOptimizationRate = 100.0;  // launch/asapp_demo.launch:25-26
+    params.localOptimizationParams.method = ROptParameters::ROptMethod::RGD;
+    params.localOptimizationParams.RGD_stepsize = 0.05;  // simultaneous (Jacobi-like) updates on this tightly coupled pair need a smaller step
+  }
   std::vector<std::unique_ptr<MockAgentROS>> team;
   for (unsigned k = 0; k < N; ++k) team.emplace_back(new MockAgentROS(k, params));
   // src/PGODatasetPublisherNode.cpp:84-135 partition; every robot ends with all edges incident to it
@@ -82,6 +91,20 @@ int main(int argc, char **argv) {
   if (!team[0]->getSharedPose(0, anchor)) return 5;
   for (auto &a : team) a->setGlobalAnchor(anchor);  // :431-438, :932-939
   std::printf("init cost %.12e\n", global_cost(team));
+  if (mode == 2) {
+    // runOnceAsynchronous (:119-127) + publishPublicPoses (:109-113) polled from this "ROS" thread
+    for (int k = 0; k < iters; ++k) {
+      std::this_thread::sleep_for(std::chrono::milliseconds(4));
+      for (unsigned b = 0; b < N; ++b) if (team[b]->publishRequested()) publish(team, b, false);
+      unsigned its = 0;
+      for (auto &a : team) its += a->iteration_number();
+      std::printf("async poll %d local_iterations %u cost %.12e\n", k + 1, its, global_cost(team));
+    }
+    for (auto &a : team) a->endOptimizationLoop();
+    for (unsigned b = 0; b < N; ++b) publish(team, b, false);  // consistent snapshot
+    std::printf("final cost %.12e\n", global_cost(team));
+    return 0;
+  }
   for (int k = 0; k < iters; ++k) {
     const unsigned sel = (unsigned)k % N;  // RoundRobin token (:464-473)
     for (unsigned b = 0; b < N; ++b)

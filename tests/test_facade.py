@@ -16,7 +16,7 @@ BIN = os.path.join(ROOT, "tests", "cpp", "mock_wrapper")
 
 def _compile():
     lib = os.path.join(ROOT, "dpgo_ros_amd")
-    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-pthread", "-I" + os.path.join(ROOT, "include"),
            os.path.join(ROOT, "tests", "cpp", "mock_wrapper.cpp"), "-o", BIN, "-L" + lib, "-ldpgo_hip", "-Wl,-rpath," + lib]
     subprocess.check_call(cmd)
 
@@ -95,3 +95,19 @@ def test_mock_wrapper_follows_the_oracle(accel):
         assert abs(costs[k] - ref.cost()) <= 1e-8 * ref.cost(), k
     defect = float(re.search(r"orthogonality_defect (\S+)", out).group(1))
     assert defect < 1e-9
+
+
+@pytest.mark.gpu
+def test_mock_wrapper_asynchronous_mode():
+    """ASAPP mode of the facade: library-owned optimisation threads (RGD, stepsize 0.2) race the polling
+    thread that relays public poses; nondeterministic by construction, so only progress is asserted."""
+    _compile()
+    out = subprocess.check_output([BIN, os.path.join(DATA, "smallGrid3D.g2o"), "2", "100", "2"], text=True, timeout=120)
+    init = float(re.search(r"init cost (\S+)", out).group(1))
+    rows = re.findall(r"async poll \d+ local_iterations (\d+) cost (\S+)", out)
+    assert len(rows) == 100
+    its = [int(r[0]) for r in rows]
+    costs = [float(r[1]) for r in rows]
+    assert its[-1] > 20 and its == sorted(its)
+    final = float(re.search(r"final cost (\S+)", out).group(1))
+    assert final < 0.5 * init, (init, final, costs[::10])
