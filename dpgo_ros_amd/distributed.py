@@ -11,8 +11,8 @@ sends the neighbour's current public poses (X, and the auxiliary Y sequence unde
 this equals the reference's staleness gate with maxDelayedIterations = 0 (:136-149).
 
 The module is transport + schedule only.  The compute backend is any object with
-    iterate(agent, do_opt), pack(agent, nbr, aux) -> tensor, unpack(agent, nbr, aux, tensor),
-    pull_local(agent), partial_cost() -> float
+    iterate(agent, do_opt), pack(agent, nbr, seqs, count) -> tensor, recv_buffer(agent, nbr, seqs, count),
+    unpack(agent, nbr, seqs, tensor), pull_local(agent), partial_cost() -> float
 (`HipBackend` below for the product; the CPU tests plug the oracle in through the same protocol).
 """
 import numpy as np
@@ -81,27 +81,33 @@ class HipBackend:
     def iterate(self, agent, do_opt):
         return self.team.agents[agent].iterate(do_opt)
 
-    def pack(self, agent, nbr, aux, count):
-        t = self.buffer(("s", agent, nbr, aux), count)
-        self.team.agents[agent].pack_public_poses_device(nbr, aux, t.data_ptr())
+    def pack(self, agent, nbr, seqs, count):
+        """one message per neighbour: the public poses of every requested sequence (0 = X, 1 = auxiliary Y)
+        packed back to back by the device kernels"""
+        n = count * 4 * self.r
+        t = self.buffer(("s", agent, nbr, len(seqs)), count * len(seqs))
+        for q, aux in enumerate(seqs):
+            self.team.agents[agent].pack_public_poses_device(nbr, aux, t.data_ptr() + 8 * n * q)
         if self.host_staging:
-            return t.cpu()  # synchronises the (current) stream the pack kernel ran on
+            return t.cpu()  # synchronises the (current) stream the pack kernels ran on
         return t
 
-    def recv_buffer(self, agent, nbr, aux, count):
+    def recv_buffer(self, agent, nbr, seqs, count):
         if self.host_staging:
-            key = ("rh", agent, nbr, aux)
+            key = ("rh", agent, nbr, len(seqs))
             if key not in self._buf:
-                self._buf[key] = self.torch.empty(count * 4 * self.r, dtype=self.torch.float64)
+                self._buf[key] = self.torch.empty(count * len(seqs) * 4 * self.r, dtype=self.torch.float64)
             return self._buf[key]
-        return self.buffer(("r", agent, nbr, aux), count)
+        return self.buffer(("r", agent, nbr, len(seqs)), count * len(seqs))
 
-    def unpack(self, agent, nbr, aux, tensor):
+    def unpack(self, agent, nbr, seqs, tensor):
+        n = tensor.numel() // len(seqs)
         if self.host_staging:
-            d = self.buffer(("r", agent, nbr, aux), tensor.numel() // (4 * self.r))
+            d = self.buffer(("r", agent, nbr, len(seqs)), tensor.numel() // (4 * self.r))
             d.copy_(tensor)
             tensor = d
-        self.team.agents[agent].unpack_neighbor_poses_device(nbr, aux, tensor.data_ptr())
+        for q, aux in enumerate(seqs):
+            self.team.agents[agent].unpack_neighbor_poses_device(nbr, aux, tensor.data_ptr() + 8 * n * q)
 
     def pull_local(self, agent):
         self.team.agents[agent].pull_local()
@@ -160,18 +166,17 @@ class DistributedRBCD:
             if rb == rs:
                 continue
             cnt = self.npub[(b, sel)]
-            for aux in seqs:
-                if self.rank == rb:
-                    ops.append(d.P2POp(d.isend, self.be.pack(b, sel, aux, cnt), rs))
-                if self.rank == rs:
-                    t = self.be.recv_buffer(sel, b, aux, cnt)
-                    ops.append(d.P2POp(d.irecv, t, rb))
-                    todo.append((b, aux, t))
+            if self.rank == rb:
+                ops.append(d.P2POp(d.isend, self.be.pack(b, sel, seqs, cnt), rs))
+            if self.rank == rs:
+                t = self.be.recv_buffer(sel, b, seqs, cnt)
+                ops.append(d.P2POp(d.irecv, t, rb))
+                todo.append((b, t))
         if ops:
             for w in d.batch_isend_irecv(ops):
                 w.wait()
-        for b, aux, t in todo:
-            self.be.unpack(sel, b, aux, t)
+        for b, t in todo:
+            self.be.unpack(sel, b, seqs, t)
         if self.rank == rs and pull:  # the batched step pulls co-resident poses inside the G-assembly kernel
             self.be.pull_local(sel)
 

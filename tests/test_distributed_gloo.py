@@ -30,17 +30,22 @@ class OracleBackend:
     def iterate(self, agent, do_opt):
         return self.agents[agent].iterate(do_opt)
 
-    def pack(self, agent, nbr, aux, count):
-        ids, P = self.agents[agent].get_public_poses(nbr, bool(aux))
-        assert len(ids) == count
-        return self.torch.from_numpy(P.copy())
+    def pack(self, agent, nbr, seqs, count):
+        parts = []
+        for aux in seqs:
+            ids, P = self.agents[agent].get_public_poses(nbr, bool(aux))
+            assert len(ids) == count
+            parts.append(P)
+        return self.torch.from_numpy(np.concatenate(parts))
 
-    def recv_buffer(self, agent, nbr, aux, count):
-        return self._buf.setdefault((agent, nbr, aux), self.torch.empty(count * 4 * self.r, dtype=self.torch.float64))
+    def recv_buffer(self, agent, nbr, seqs, count):
+        return self._buf.setdefault((agent, nbr, len(seqs)), self.torch.empty(count * len(seqs) * 4 * self.r, dtype=self.torch.float64))
 
-    def unpack(self, agent, nbr, aux, tensor):
+    def unpack(self, agent, nbr, seqs, tensor):
         ag = self.agents[agent]
-        ag.update_neighbor_poses(nbr, ag.neighbor_pose_ids(nbr), tensor.numpy(), bool(aux))
+        chunks = tensor.numpy().reshape(len(seqs), -1)
+        for q, aux in enumerate(seqs):
+            ag.update_neighbor_poses(nbr, ag.neighbor_pose_ids(nbr), chunks[q], bool(aux))
 
     def pull_local(self, agent):
         ag = self.agents[agent]
