@@ -216,11 +216,38 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-// sum of a short global array of partials, identical order in every wave that calls it
+// sum of a short global array of partials, identical order in every wave that calls it.  The loads of a
+// lane are issued as one batch (a runtime-bounded loop would wait for each cold load in turn).
 __device__ __forceinline__ double sum_partials(const double *p, int count, int stride, int lane) {
   double s = 0;
-  for (int i = lane; i < count; i += 64) s += p[(size_t)i * stride];
+  for (int base = 0; base < count; base += 512) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = base + lane + 64 * u;
+      v[u] = (i < count) ? p[(size_t)i * stride] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
   return wave_sum(s);
+}
+
+// two adjacent partials per entry (p[i*stride], p[i*stride + 1]) with one 16-byte load each
+__device__ __forceinline__ void sum_partials2(const double *p, int count, int stride, int lane, double &s0, double &s1) {
+  double a = 0, b = 0;
+  for (int base = 0; base < count; base += 512) {
+    double2 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = base + lane + 64 * u;
+      v[u] = (i < count) ? *reinterpret_cast<const double2 *>(p + (size_t)i * stride) : make_double2(0.0, 0.0);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { a += v[u].x; b += v[u].y; }
+  }
+  s0 = wave_sum(a);
+  s1 = wave_sum(b);
 }
 
 }  // namespace dpgo

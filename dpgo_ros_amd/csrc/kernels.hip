@@ -598,8 +598,8 @@ __global__ __launch_bounds__(64) void k_tcg_hv(const AgentDev *agents, const Tea
   }
   const double kappa = 0.1;  // tCG stop: |r| <= |r0| min(|r0|^theta, kappa) with theta = 1
   const int npb = precond_blocks(ag.N4);
-  const double zr_new = sum_partials(ag.part + PART_B, npb, PART_STRIDE, lane);
-  const double rr_new = sum_partials(ag.part + PART_B + 1, npb, PART_STRIDE, lane);
+  double zr_new, rr_new;
+  sum_partials2(ag.part + PART_B, npb, PART_STRIDE, lane, zr_new, rr_new);
   RtrState T = S;
   double beta = 0;
   const bool fresh = (S.tcg_j == 0);
