@@ -90,7 +90,7 @@ struct TeamDev {
   int iter;          // global iteration counter (device copy)
   int restart_interval;
   int cur_sel;       // agent selected in the running iteration (published by the first kernel)
-  int stats_sel;     // agent whose final statistics are being evaluated on the side stream
+  int stats_sel;     // agent of the iteration that just finished: its final statistics are evaluated by k_stats_nest
   const int *sched;  // [sched_len] local agent index selected at iteration k % sched_len
   const int *group_ptr;      // colour classes of the agent graph (CSR): agents of one class share no edge,
   const int *group_members;  // so they may take their block update in the same launches (blockIdx.y)

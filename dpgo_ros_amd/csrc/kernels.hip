@@ -452,7 +452,7 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
   // batch of 16-byte loads, (2) barrier, (3) the whole M slab of this workgroup is requested (32 x 16 B per
   // lane, non-temporal), (4) the FMA loop drains the slab in issue order, so arithmetic overlaps the
   // stream.  A lane reads the 2R contiguous doubles v[k][:], v[k+1][:] as R ds_read_b128 (16R-byte lane
-  // stride: conflict-free for R = 3, 5).  Measured (scratch/pc_bench.hip): ingest per CU, not HBM, is
+  // stride: conflict-free for R = 3, 5).  Measured (profiles/experiments/pc_bench.hip): ingest per CU, not HBM, is
   // the limit -- every workgroup has to pull the full 8*R*N4-byte vector through L2 next to its slab.
   constexpr int NSTG = (KC * R / 2 + 255) / 256;  // 16-byte pairs per lane per chunk
   for (int k0 = 0; k0 < N4; k0 += KC) {

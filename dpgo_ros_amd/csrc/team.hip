@@ -11,7 +11,6 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
-#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -112,11 +111,6 @@ struct dpgo_team {
   std::vector<int> color_of;
   bool user_groups = false;              // groups supplied by dpgo_team_set_groups (global colouring)
   RtrState *h_states = nullptr;          // pinned, one per local agent
-  hipStream_t side = nullptr;            // final-statistics evaluations run here, overlapped with the next iteration
-  std::vector<hipEvent_t> ev_pool;
-  size_t ev_next = 0;
-  hipEvent_t prev_side_ev = nullptr;
-  bool use_side = false;
   DevBuf<double> d_tmp;  // scratch for raw manifold ops / dense factorisation
   std::vector<int> sched;
   int iter = 0;
@@ -127,7 +121,6 @@ struct dpgo_team {
   static constexpr int NGRAPH = 5;       // graphs of 1, 2, 4, 8, 16 identical iterations
   hipGraphExec_t graph[NGRAPH] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   bool graph_valid = false;
-  int tcg_chunk = 4;
   double counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   LaunchCtx ctx() { return LaunchCtx{prm.r, stream, d_agents.p, d_team.p}; }
 };
@@ -430,7 +423,7 @@ bool neighbor_poses_ready(const Agent &a, int aux) {
 // device-side solver state.
 //   fused: the iteration's tail (Nesterov V update, |X - XPrev|^2, end-of-iteration bookkeeping)
 //          is folded into the RGD kernels (no restart in this iteration); `last` folds k_advance.
-struct OptFlags { int aux = 0, pull = 0; bool capture = false, fused = false, last_advances = false, side = false; };
+struct OptFlags { int aux = 0, pull = 0; bool capture = false, fused = false, last_advances = false; };
 
 EvalOpts eval_opts(const dpgo_team *t, int gmode, int aux, int advance) {
   EvalOpts o;
@@ -453,23 +446,10 @@ int enqueue_optimize(dpgo_team *t, int sel, const OptFlags &fl) {
     launch_eval(c, sel, mn, B_X, B_EGRAD, B_GF, PART_C, eval_opts(t, gmode, fl.aux, 0));
     if (fl.fused && p.rgd_use_preconditioner) {
       // K3: preconditioner + RGD step + Nesterov V + |dX|^2 (+ the team's end-of-iteration bookkeeping);
-      // K5: f_opt / gradnorm_opt on the snapshot B_X2 -- on the side stream when captured, so that it
-      // overlaps K1/K2 of the next iteration (it must be over before the next K3 republishes stats_sel)
-      if (fl.side && t->prev_side_ev) HIPC(hipStreamWaitEvent(t->stream, t->prev_side_ev, 0));
+      // K5: f_opt / gradnorm_opt on the snapshot B_X2 that K3 leaves behind
       launch_precond(c, sel, mn, PM_RGD_, B_X, B_GF, B_Z, 0, 0, p.rgd_stepsize, p.acceleration, p.num_robots,
                      fl.last_advances ? 1 : 0, p.restart_interval);
-      if (fl.side) {
-        hipEvent_t ef = t->ev_pool[t->ev_next++ % t->ev_pool.size()], ed = t->ev_pool[t->ev_next++ % t->ev_pool.size()];
-        HIPC(hipEventRecord(ef, t->stream));
-        HIPC(hipStreamWaitEvent(t->side, ef, 0));
-        LaunchCtx cs = c;
-        cs.stream = t->side;
-        launch_eval(cs, -5, mn, B_X2, B_EGRAD2, B_GF2, PART_A, eval_opts(t, 0, 0, 0));
-        HIPC(hipEventRecord(ed, t->side));
-        t->prev_side_ev = ed;
-      } else {
-        launch_eval(c, sel, mn, B_X2, B_EGRAD2, B_GF2, PART_A, eval_opts(t, 0, 0, 0));
-      }
+      launch_eval(c, sel, mn, B_X2, B_EGRAD2, B_GF2, PART_A, eval_opts(t, 0, 0, 0));
     } else {
       int dirb = B_GF;
       if (p.rgd_use_preconditioner) {
@@ -661,9 +641,6 @@ dpgo_team_t *dpgo_team_create(int device, const dpgo_params_t *p, int num_local,
       hipHostMalloc((void **)&t->h_scal, sizeof(double) * 16) != hipSuccess) {
     delete t; set_err("pinned allocation failed"); return nullptr;
   }
-  if (hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking) != hipSuccess) { delete t; set_err("side stream failed"); return nullptr; }
-  t->ev_pool.resize(64);
-  for (auto &e : t->ev_pool) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete t; set_err("event create failed"); return nullptr; }
   for (int k = 0; k < num_local; ++k) {
     auto a = std::make_unique<Agent>();
     a->id = agent_ids[k]; a->local = k; a->mu = p->gnc_init_mu;
@@ -682,8 +659,6 @@ void dpgo_team_destroy(dpgo_team_t *t) {
   if (t->h_state) (void)hipHostFree(t->h_state);
   if (t->h_states) (void)hipHostFree(t->h_states);
   if (t->h_scal) (void)hipHostFree(t->h_scal);
-  for (auto &e : t->ev_pool) if (e) (void)hipEventDestroy(e);
-  if (t->side) (void)hipStreamDestroy(t->side);
   if (t->own_stream) (void)hipStreamDestroy(t->stream);
   delete t;
 }
@@ -1152,7 +1127,6 @@ static int enqueue_team_iteration(dpgo_team_t *t, bool capture, bool restart, in
   const bool fused = p.method == DPGO_METHOD_RGD && p.rgd_use_preconditioner && !restart && sel != -2;
   OptFlags fl;
   fl.pull = 1; fl.capture = capture; fl.fused = fused; fl.last_advances = fused;
-  fl.side = capture && fused && t->use_side;
   int rc = 0;
   if (phase != 2) {
     if (p.acceleration) launch_nest_pre(c, sel, -1, na, mn, p.num_robots, p.restart_interval);  // K1 (+ publishes cur_sel)
@@ -1225,17 +1199,13 @@ int dpgo_team_run(dpgo_team_t *t, int iters) {
   for (auto &a : t->ag) if (!a->has_X) { set_err("team_run before set_initial"); return DPGO_NOT_READY; }
   const bool graphable = (p.method == DPGO_METHOD_RGD) && p.rgd_use_preconditioner;
   if (graphable && !t->graph_valid) {
-    // side-stream statistics need consecutive iterations to select different agents (G / snapshot buffers)
-    t->use_side = t->ag.size() > 1 && std::getenv("DPGO_SIDE_STREAM") != nullptr;  // measured slower (graph fork/join edges cost more than the 7 us they hide)
-    for (size_t q = 0; q < t->sched.size(); ++q) if (t->sched[q] == t->sched[(q + 1) % t->sched.size()]) t->use_side = false;
     // the schedule, the counters and the Nesterov scalars live on the device, so every iteration is
     // the same launch sequence: capture it 1/2/4/8/16 times to amortise the graph-launch gap
     for (int gi = 0; gi < dpgo_team::NGRAPH; ++gi) {
       hipGraph_t g = nullptr;
       HIPC(hipStreamBeginCapture(t->stream, hipStreamCaptureModeThreadLocal));
       int rc = 0;
-      t->prev_side_ev = nullptr;
-      if (p.acceleration && !t->use_side) {
+      if (p.acceleration) {
         // 3 launches per iteration: [statistics of iteration k-1 + Nesterov step of iteration k] in one
         // heterogeneous kernel, cost/gradient (+ G from the neighbours' Y), preconditioner + RGD step +
         // Nesterov V + bookkeeping.  The first iteration has no statistics to close, the last one is closed
@@ -1252,7 +1222,6 @@ int dpgo_team_run(dpgo_team_t *t, int iters) {
       } else {
         for (int rep = 0; rep < (1 << gi) && !rc; ++rep) rc = enqueue_team_iteration(t, true, false, -1, 0);
       }
-      if (t->prev_side_ev) { HIPC(hipStreamWaitEvent(t->stream, t->prev_side_ev, 0)); t->prev_side_ev = nullptr; }  // join
       HIPC(hipStreamEndCapture(t->stream, &g));
       if (rc) { (void)hipGraphDestroy(g); return rc; }
       if (t->graph[gi]) { (void)hipGraphExecDestroy(t->graph[gi]); t->graph[gi] = nullptr; }

@@ -1,8 +1,8 @@
 import sys, os
-sys.path.insert(0,'/root/repo')
+sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), '..', '..'))
 from dpgo_ros_amd import capi
 import numpy as np
-m,n=capi.read_g2o('/root/repo/data/sphere2500.g2o')
+m,n=capi.read_g2o('data/sphere2500.g2o')
 mp=capi.partition(m,n,5); T=capi.odometry_init(m,n); Y=capi.fixed_stiefel(5)
 t=capi.Team.from_measurements(mp, capi.default_params(r=5,num_robots=5,method=1,acceleration=1,rgd_stepsize=0.1))
 t.set_initial(T,Y)

@@ -1,7 +1,7 @@
 import sys, os, time
-sys.path.insert(0,'/root/repo')
+sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), '..', '..'))
 from dpgo_ros_amd import capi
-m,n=capi.read_g2o('/root/repo/data/sphere2500.g2o')
+m,n=capi.read_g2o('data/sphere2500.g2o')
 mp=capi.partition(m,n,5); T=capi.odometry_init(m,n); Y=capi.fixed_stiefel(5)
 t=capi.Team.from_measurements(mp, capi.default_params(r=5,num_robots=5,method=0,acceleration=1,rtr_iterations=3,rtr_tcg_iterations=50,gradnorm_tol=1e-2,restart_interval=50))
 t.set_initial(T,Y)

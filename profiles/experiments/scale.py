@@ -1,7 +1,7 @@
 import sys, os, time
-sys.path.insert(0,'/root/repo')
+sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), '..', '..'))
 from dpgo_ros_amd import capi
-m,n=capi.read_g2o('/root/repo/data/sphere2500.g2o')
+m,n=capi.read_g2o('data/sphere2500.g2o')
 T=capi.odometry_init(m,n); Y=capi.fixed_stiefel(5)
 print("| agents | poses/agent | M bytes | precond us/launch | GB/s | frac of 8 TB/s | eval us | eval GB/s |")
 print("|---|---|---|---|---|---|---|---|")
