@@ -1,0 +1,290 @@
+// assembly.hip -- measurement lists -> block-CSR / ELL structure, data matrices Q and G, the dense
+// preconditioner and the device descriptors of a team (PoseGraph of the reference: constructQ/constructG,
+// SURVEY 8a rows 'PoseGraph data matrices').
+#include "team_internal.h"
+
+using namespace dpgo;
+
+namespace dpgo_host {
+
+Agent *find_agent(dpgo_team *t, int id) {
+  auto it = t->id2local.find(id);
+  if (it == t->id2local.end()) { set_err("unknown agent id " + std::to_string(id)); return nullptr; }
+  return t->ag[it->second].get();
+}
+
+// 4x4 column-major blocks of one edge:  TO = T Omega, TOT = T Omega T^T, Om = Omega (x weight)
+void edge_blocks(const dpgo_measurement_t &m, double TO[16], double TOT[16], double Om[16]) {
+  const double w = m.weight, k = m.kappa, tau = m.tau;
+  std::fill(TO, TO + 16, 0.0); std::fill(TOT, TOT + 16, 0.0); std::fill(Om, Om + 16, 0.0);
+  for (int a = 0; a < 3; ++a) {
+    for (int b = 0; b < 3; ++b) {
+      TO[a + 4 * b] = w * k * m.R[3 * a + b];
+      TOT[a + 4 * b] = w * ((a == b ? k : 0.0) + tau * (m.t[a] * m.t[b]));
+    }
+    TO[a + 12] = w * tau * m.t[a];
+    TOT[a + 12] = w * tau * m.t[a];
+    TOT[3 + 4 * a] = w * tau * m.t[a];
+    Om[5 * a] = w * k;
+  }
+  TO[15] = TOT[15] = Om[15] = w * tau;
+}
+
+void rebuild_index(Agent &a) {
+  if (!a.index_dirty) return;
+  int n = 0;
+  auto upd = [&](int p) { n = std::max(n, p + 1); };
+  for (auto &m : a.odom) { upd(m.p1); upd(m.p2); }
+  for (auto &m : a.priv) { upd(m.p1); upd(m.p2); }
+  std::vector<std::pair<int, int>> np;
+  for (auto &m : a.shared) {
+    if (m.r1 == a.id) { upd(m.p1); np.emplace_back(m.r2, m.p2); }
+    else { upd(m.p2); np.emplace_back(m.r1, m.p1); }
+  }
+  std::sort(np.begin(), np.end());
+  np.erase(std::unique(np.begin(), np.end()), np.end());
+  a.np = np;
+  a.np_has[0].assign(np.size(), 0);
+  a.np_has[1].assign(np.size(), 0);
+  a.neighbors.clear();
+  for (auto &p : np) if (a.neighbors.empty() || a.neighbors.back() != p.first) a.neighbors.push_back(p.first);
+  a.n = n;
+  a.index_dirty = false;
+  a.data_dirty = true;
+}
+
+int find_np(const Agent &a, int robot, int frame) {
+  auto it = std::lower_bound(a.np.begin(), a.np.end(), std::make_pair(robot, frame));
+  if (it == a.np.end() || *it != std::make_pair(robot, frame)) return -1;
+  return int(it - a.np.begin());
+}
+
+std::vector<int> public_ids(const Agent &a, int nbr) {
+  std::vector<int> f;
+  for (auto &m : a.shared) {
+    if (m.r1 == a.id && m.r2 == nbr) f.push_back(m.p1);
+    else if (m.r2 == a.id && m.r1 == nbr) f.push_back(m.p2);
+  }
+  std::sort(f.begin(), f.end());
+  f.erase(std::unique(f.begin(), f.end()), f.end());
+  return f;
+}
+
+std::vector<int> neighbor_ids(const Agent &a, int nbr) {
+  std::vector<int> f;
+  for (auto &p : a.np) if (p.first == nbr) f.push_back(p.second);
+  return f;
+}
+
+// connection Laplacian in block-CSR (row j lists (i, Q_ij)); duplicates merged in insertion order
+void build_Q(Agent &a) {
+  std::vector<std::map<int, std::array<double, 16>>> rows(a.n);
+  auto add = [&](int row, int colm, const double *v, bool transpose, double sign) {
+    auto &blk = rows[row][colm];
+    for (int cp = 0; cp < 4; ++cp)
+      for (int c = 0; c < 4; ++c) blk[cp + 4 * c] += sign * (transpose ? v[c + 4 * cp] : v[cp + 4 * c]);
+  };
+  double TO[16], TOT[16], Om[16];
+  for (int i = 0; i < a.n; ++i) rows[i][i];  // every pose owns a diagonal block
+  for (int pass = 0; pass < 2; ++pass)
+    for (auto &m : (pass ? a.priv : a.odom)) {
+      edge_blocks(m, TO, TOT, Om);
+      add(m.p1, m.p1, TOT, false, 1.0);
+      add(m.p2, m.p2, Om, false, 1.0);
+      add(m.p2, m.p1, TO, false, -1.0);  // Q_ij stored in row j
+      add(m.p1, m.p2, TO, true, -1.0);   // Q_ji = Q_ij^T stored in row i
+    }
+  for (auto &m : a.shared) {
+    edge_blocks(m, TO, TOT, Om);
+    if (m.r1 == a.id) add(m.p1, m.p1, TOT, false, 1.0);
+    else add(m.p2, m.p2, Om, false, 1.0);
+  }
+  a.rowptr.assign(a.n + 1, 0);
+  a.col.clear(); a.qval.clear();
+  for (int j = 0; j < a.n; ++j) {
+    for (auto &kv : rows[j]) {
+      a.col.push_back(kv.first);
+      a.qval.insert(a.qval.end(), kv.second.begin(), kv.second.end());
+    }
+    a.rowptr[j + 1] = (int)a.col.size();
+  }
+}
+
+// upload structure + data matrices of one agent and (re)build the dense preconditioner
+int finalize_agent(dpgo_team *t, Agent &a) {
+  rebuild_index(a);
+  if (!a.data_dirty) return 0;
+  const int r = t->prm.r, n = a.n, N4 = 4 * n;
+  const size_t len = (size_t)r * 4 * n;
+  hipStream_t s = t->stream;
+  build_Q(a);
+  // shared edges sorted by local pose
+  struct SE { int lpose; SharedEdgeDev d; };
+  std::vector<SharedEdgeDev> se;
+  double TO[16], TOT[16], Om[16];
+  for (auto &m : a.shared) {
+    edge_blocks(m, TO, TOT, Om);
+    const bool out = (m.r1 == a.id);
+    SharedEdgeDev d{};
+    d.lpose = out ? m.p1 : m.p2;
+    const int nr = out ? m.r2 : m.r1, nf = out ? m.p2 : m.p1;
+    d.slot = find_np(a, nr, nf);
+    auto it = t->id2local.find(nr);
+    d.src_agent_local = (it == t->id2local.end()) ? -1 : it->second;
+    d.src_frame = nf;
+    for (int cp = 0; cp < 4; ++cp)
+      for (int c = 0; c < 4; ++c) d.coef[cp + 4 * c] = out ? TO[c + 4 * cp] : TO[cp + 4 * c];
+    se.push_back(d);
+  }
+  std::stable_sort(se.begin(), se.end(), [](const SharedEdgeDev &x, const SharedEdgeDev &y) { return x.lpose < y.lpose; });
+  std::vector<int> pub_pose, pub_ptr;
+  for (size_t e = 0; e < se.size(); ++e) {
+    if (e == 0 || se[e].lpose != se[e - 1].lpose) { pub_pose.push_back(se[e].lpose); pub_ptr.push_back((int)e); }
+  }
+  pub_ptr.push_back((int)se.size());
+  a.npub = (int)pub_pose.size();
+  // edge records for residual / cost evaluation
+  std::vector<EdgeDev> edges;
+  auto push_edge = [&](const dpgo_measurement_t &m) {
+    EdgeDev e{};
+    e.i_local = (m.r1 == a.id) ? m.p1 : -1;
+    e.j_local = (m.r2 == a.id) ? m.p2 : -1;
+    e.i_slot = (m.r1 == a.id) ? -1 : find_np(a, m.r1, m.p1);
+    e.j_slot = (m.r2 == a.id) ? -1 : find_np(a, m.r2, m.p2);
+    std::memcpy(e.R, m.R, sizeof e.R);
+    std::memcpy(e.t, m.t, sizeof e.t);
+    e.kappa = m.kappa; e.tau = m.tau; e.weight = m.weight;
+    e.count_in_cost = (m.r1 == m.r2) ? 1 : (std::min(m.r1, m.r2) == a.id);
+    edges.push_back(e);
+  };
+  for (auto &m : a.odom) push_edge(m);
+  for (auto &m : a.priv) push_edge(m);
+  for (auto &m : a.shared) push_edge(m);
+  a.nedges = (int)edges.size();
+
+  // ELL (slot-major, width <= 8) + CSR tail copy of Q for the SpMM kernels
+  int maxlen = 0;
+  for (int j = 0; j < n; ++j) maxlen = std::max(maxlen, a.rowptr[j + 1] - a.rowptr[j]);
+  const int EW = std::min(maxlen, 8);
+  std::vector<int> ell_col((size_t)EW * n), trowptr(n + 1, 0), tcol;
+  std::vector<double> ell_val((size_t)EW * n * 16, 0.0), tval;
+  for (int j = 0; j < n; ++j) {
+    const int p0 = a.rowptr[j], p1 = a.rowptr[j + 1];
+    for (int u = 0; u < EW; ++u) {
+      const int p = p0 + u;
+      ell_col[(size_t)u * n + j] = (p < p1) ? a.col[p] : j;
+      if (p < p1) std::copy(a.qval.begin() + (size_t)16 * p, a.qval.begin() + (size_t)16 * (p + 1), ell_val.begin() + ((size_t)u * n + j) * 16);
+    }
+    for (int p = p0 + EW; p < p1; ++p) { tcol.push_back(a.col[p]); tval.insert(tval.end(), a.qval.begin() + (size_t)16 * p, a.qval.begin() + (size_t)16 * (p + 1)); }
+    trowptr[j + 1] = (int)tcol.size();
+  }
+  std::vector<int> pub_index(n, -1);
+  for (size_t q = 0; q < pub_pose.size(); ++q) pub_index[pub_pose[q]] = (int)q;
+  if (a.d_ell_col.upload(ell_col, s) || a.d_ell_val.upload(ell_val, s) || a.d_trowptr.upload(trowptr, s) ||
+      a.d_tcol.upload(tcol, s) || a.d_tval.upload(tval, s) || a.d_pub_index.upload(pub_index, s)) {
+    set_err("device allocation/upload failed");
+    return DPGO_ERR;
+  }
+  const bool fresh_vec = a.d_vec.n < len * NBUF;
+  if (a.d_rowptr.upload(a.rowptr, s) || a.d_col.upload(a.col, s) || a.d_qval.upload(a.qval, s) ||
+      a.d_pub_pose.upload(pub_pose, s) || a.d_pub_ptr.upload(pub_ptr, s) || a.d_se.upload(se, s) ||
+      a.d_edges.upload(edges, s) || a.d_vec.alloc(len * NBUF) || a.d_nbr.alloc(2 * a.np.size() * 4 * r) ||
+      a.d_part.alloc(PART_TOTAL) || a.d_scal.alloc(16) || a.d_resid.alloc(edges.size()) || a.d_st.alloc(2) ||
+      a.d_nest.alloc(1) || a.d_M.alloc((size_t)N4 * N4)) {
+    set_err("device allocation/upload failed");
+    return DPGO_ERR;
+  }
+  if (fresh_vec) {
+    HIPC(hipMemsetAsync(a.d_vec.p, 0, sizeof(double) * len * NBUF, s));
+    HIPC(hipMemsetAsync(a.d_nbr.p, 0, sizeof(double) * a.d_nbr.n, s));
+    HIPC(hipMemsetAsync(a.d_scal.p, 0, sizeof(double) * 16, s));
+    HIPC(hipMemsetAsync(a.d_nest.p, 0, sizeof(NestState), s));
+    HIPC(hipMemsetAsync(a.d_st.p, 0, sizeof(RtrState) * 2, s));
+    HIPC(hipMemsetAsync(a.d_part.p, 0, sizeof(double) * PART_TOTAL, s));
+  }
+  // dense preconditioner  M = (Q + shift I)^-1
+  if (t->d_tmp.alloc(2 * (size_t)N4 * N4)) { set_err("scratch allocation failed"); return DPGO_ERR; }
+  double *A = t->d_tmp.p, *W = t->d_tmp.p + (size_t)N4 * N4;
+  launch_bsr_to_dense(s, a.d_rowptr.p, a.d_col.p, a.d_qval.p, n, t->prm.precond_shift, A);
+  const int fail = dense_spd_inverse(s, A, W, a.d_M.p, N4);
+  if (fail != 0) { set_err("dense Cholesky of Q + shift I failed at pivot " + std::to_string(fail)); return DPGO_ERR; }
+
+  // per-neighbour index tables for the packed-slab exchange (a7)
+  size_t max_xfer = 1;
+  for (int nb : a.neighbors) {
+    const std::vector<int> fr = public_ids(a, nb);
+    std::vector<int> slots;
+    for (size_t q = 0; q < a.np.size(); ++q) if (a.np[q].first == nb) slots.push_back((int)q);
+    auto &bf = a.d_pubframes[nb]; if (!bf) bf = std::make_unique<DevBuf<int>>();
+    auto &bs = a.d_nbrslots[nb]; if (!bs) bs = std::make_unique<DevBuf<int>>();
+    if (bf->upload(fr, s) || bs->upload(slots, s)) { set_err("index upload failed"); return DPGO_ERR; }
+    a.n_pubframes[nb] = (int)fr.size(); a.n_nbrslots[nb] = (int)slots.size();
+    max_xfer = std::max(max_xfer, std::max(fr.size(), slots.size()));
+  }
+  if (a.d_xfer.alloc(max_xfer * 4 * r)) { set_err("device allocation failed"); return DPGO_ERR; }
+
+  AgentDev &d = a.dev;
+  d.id = a.id; d.n = n; d.nb = (int)a.col.size(); d.N4 = N4;
+  d.npub = a.npub; d.nshared = (int)se.size(); d.nnp = (int)a.np.size(); d.nedges = a.nedges;
+  d.rowptr = a.d_rowptr.p; d.col = a.d_col.p; d.qval = a.d_qval.p; d.M = a.d_M.p;
+  d.ell_w = EW; d.ell_col = a.d_ell_col.p; d.ell_val = a.d_ell_val.p;
+  d.trowptr = a.d_trowptr.p; d.tcol = a.d_tcol.p; d.tval = a.d_tval.p; d.pub_index = a.d_pub_index.p;
+  d.pub_pose = a.d_pub_pose.p; d.pub_ptr = a.d_pub_ptr.p; d.se = a.d_se.p; d.edges = a.d_edges.p;
+  d.nbr[0] = a.d_nbr.p; d.nbr[1] = a.d_nbr.p + a.np.size() * 4 * r;
+  for (int b = 0; b < NBUF; ++b) d.buf[b] = a.d_vec.p + len * b;
+  d.part = a.d_part.p; d.st = a.d_st.p; d.nest = a.d_nest.p; d.scal = a.d_scal.p; d.resid = a.d_resid.p;
+  a.data_dirty = false;
+  t->descs_dirty = true;
+  t->graph_valid = false;
+  return 0;
+}
+
+int sync_descs(dpgo_team *t) {
+  for (auto &a : t->ag) {
+    const int rc = finalize_agent(t, *a);
+    if (rc) return rc;
+  }
+  if (!t->descs_dirty) return 0;
+  std::vector<AgentDev> descs;
+  t->max_n = 0; t->max_npub = 0;
+  for (auto &a : t->ag) {
+    descs.push_back(a->dev);
+    t->max_n = std::max(t->max_n, a->n);
+    t->max_npub = std::max(t->max_npub, a->npub);
+  }
+  if (t->d_agents.upload(descs, t->stream)) { set_err("descriptor upload failed"); return DPGO_ERR; }
+  if (t->sched.empty()) for (size_t k = 0; k < t->ag.size(); ++k) t->sched.push_back((int)k);
+  if (t->d_sched.upload(t->sched, t->stream) || t->d_team.alloc(1)) { set_err("schedule upload failed"); return DPGO_ERR; }
+  // greedy colouring of the (local) agent graph in index order: same colour = no shared edge
+  const int na_ = (int)t->ag.size();
+  if (!t->user_groups) {
+  t->color_of.assign(na_, -1);
+  t->groups.clear();
+  for (int k = 0; k < na_; ++k) {
+    std::vector<char> used(na_ + 1, 0);
+    for (int nb : t->ag[k]->neighbors) {
+      auto it = t->id2local.find(nb);
+      if (it != t->id2local.end() && t->color_of[it->second] >= 0) used[t->color_of[it->second]] = 1;
+    }
+    int col = 0;
+    while (used[col]) ++col;
+    t->color_of[k] = col;
+    if ((int)t->groups.size() <= col) t->groups.resize(col + 1);
+    t->groups[col].push_back(k);
+  }
+  }
+  std::vector<int> gptr(1, 0), gmem;
+  for (auto &g : t->groups) { gmem.insert(gmem.end(), g.begin(), g.end()); gptr.push_back((int)gmem.size()); }
+  if (t->d_group_ptr.upload(gptr, t->stream) || t->d_group_members.upload(gmem, t->stream)) { set_err("group upload failed"); return DPGO_ERR; }
+  TeamDev td{};
+  td.num_agents = (int)t->ag.size(); td.sched_len = (int)t->sched.size(); td.iter = t->iter;
+  td.restart_interval = t->prm.restart_interval; td.sched = t->d_sched.p;
+  td.group_ptr = t->d_group_ptr.p; td.group_members = t->d_group_members.p;
+  HIPC(hipMemcpyAsync(t->d_team.p, &td, sizeof td, hipMemcpyHostToDevice, t->stream));
+  HIPC(hipStreamSynchronize(t->stream));
+  t->descs_dirty = false;
+  t->graph_valid = false;
+  return 0;
+}
+
+}  // namespace dpgo_host

@@ -1,607 +1,8 @@
-// team.hip -- host runtime + C-ABI of libdpgo_hip.so (see include/dpgo_hip.h for the contract).
-//
-// Mirrors the DPGO::PGOAgent call surface consumed by src/PGOAgentROS.cpp:
-// addMeasurement, iterate, update(Aux)NeighborPoses, get(Aux)SharedPoseDictWithNeighbor,
-// getStatus, mLocalOptResult, updateMeasurementWeights, setMeasurementWeight, clearDataMatrices.
-// All state (X, XPrev, Y, V, Q, G, dense preconditioner, neighbour slabs, solver scalars) lives
-// in HBM; the host only sequences launches.  There is no CPU fallback: every entry point that
-// computes fails with DPGO_ERR when no HIP device is usable.
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <cmath>
-#include <cstdio>
-#include <cstring>
-#include <map>
-#include <memory>
-#include <string>
-#include <utility>
-#include <vector>
-
-#include "../../include/dpgo_hip.h"
-#include "dpgo_dev.h"
-#include "kernels.h"
+// capi.hip -- the extern "C" entry points of libdpgo_hip.so (contract: include/dpgo_hip.h).
+#include "team_internal.h"
 
 using namespace dpgo;
-
-namespace {
-
-thread_local std::string g_err;
-void set_err(const std::string &s) { g_err = s; }
-
-#define HIPC(expr)                                                                         \
-  do {                                                                                     \
-    hipError_t e_ = (expr);                                                                \
-    if (e_ != hipSuccess) {                                                                \
-      set_err(std::string(#expr) + ": " + hipGetErrorString(e_) + " @" + std::to_string(__LINE__)); \
-      return DPGO_ERR;                                                                     \
-    }                                                                                      \
-  } while (0)
-
-template <class T>
-struct DevBuf {
-  T *p = nullptr;
-  size_t n = 0;
-  ~DevBuf() { if (p) (void)hipFree(p); }
-  int alloc(size_t count) {
-    if (count <= n && p) return 0;
-    if (p) (void)hipFree(p);
-    p = nullptr; n = 0;
-    if (hipMalloc(&p, sizeof(T) * std::max<size_t>(count, 1)) != hipSuccess) return -1;
-    n = std::max<size_t>(count, 1);
-    return 0;
-  }
-  int upload(const std::vector<T> &v, hipStream_t s) {
-    if (alloc(v.size())) return -1;
-    if (v.empty()) return 0;
-    return hipMemcpyAsync(p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice, s) == hipSuccess ? 0 : -1;
-  }
-};
-
-struct Agent {
-  int id = 0, local = 0;
-  std::vector<dpgo_measurement_t> odom, priv, shared;
-  bool index_dirty = true, data_dirty = true;
-  int n = 0;
-  // neighbour pose dictionary (sorted (robot, frame)) and per-neighbour public ids
-  std::vector<std::pair<int, int>> np;
-  std::vector<char> np_has[2];
-  std::vector<int> neighbors;
-  int state = DPGO_WAIT_FOR_DATA;
-  int iter = 0, instance = 0;
-  bool publish_requested = false;
-  bool has_X = false;
-  double mu = 0;
-  int weight_update_count = 0, robust_inner_iter = 0;
-  dpgo_opt_result_t opt{};
-  bool opt_pending_rgd = false, last_success = true;
-  // host copies of the sparse structure
-  std::vector<int> rowptr, col;
-  std::vector<double> qval;
-  int npub = 0;
-  // device storage
-  DevBuf<int> d_rowptr, d_col, d_pub_pose, d_pub_ptr, d_idx, d_ell_col, d_trowptr, d_tcol, d_pub_index;
-  DevBuf<double> d_qval, d_M, d_vec, d_nbr, d_part, d_scal, d_resid, d_ell_val, d_tval;
-  std::map<int, std::unique_ptr<DevBuf<int>>> d_pubframes, d_nbrslots;  // per neighbour, cached on the device
-  std::map<int, int> n_pubframes, n_nbrslots;
-  DevBuf<double> d_xfer;
-  int tcg_hint = 4, outer_hint = -1;  // launch-pattern sizing from the previous solve of this agent
-  int rel_src = 0;  // where the last |X - XPrev|^2 partials live: 0 PART_D (per 64-pose tile), 1 PART_B[2] (fused RGD)
-  DevBuf<SharedEdgeDev> d_se;
-  DevBuf<EdgeDev> d_edges;
-  DevBuf<RtrState> d_st;
-  DevBuf<NestState> d_nest;
-  AgentDev dev{};
-  int nedges = 0;
-};
-
-}  // namespace
-
-struct dpgo_team {
-  int device = 0;
-  dpgo_params_t prm{};
-  hipStream_t stream = nullptr;
-  bool own_stream = false;
-  std::vector<std::unique_ptr<Agent>> ag;
-  std::map<int, int> id2local;
-  DevBuf<AgentDev> d_agents;
-  DevBuf<TeamDev> d_team;
-  DevBuf<int> d_sched, d_group_ptr, d_group_members;
-  std::vector<std::vector<int>> groups;  // colour classes (local agent indices), greedy colouring
-  std::vector<int> color_of;
-  bool user_groups = false;              // groups supplied by dpgo_team_set_groups (global colouring)
-  RtrState *h_states = nullptr;          // pinned, one per local agent
-  DevBuf<double> d_tmp;  // scratch for raw manifold ops / dense factorisation
-  std::vector<int> sched;
-  int iter = 0;
-  bool descs_dirty = true;
-  int max_n = 0, max_npub = 0;
-  RtrState *h_state = nullptr;  // pinned
-  double *h_scal = nullptr;     // pinned [16]
-  static constexpr int NGRAPH = 5;       // graphs of 1, 2, 4, 8, 16 identical iterations
-  hipGraphExec_t graph[NGRAPH] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  bool graph_valid = false;
-  double counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  LaunchCtx ctx() { return LaunchCtx{prm.r, stream, d_agents.p, d_team.p}; }
-};
-
-namespace {
-
-Agent *find_agent(dpgo_team *t, int id) {
-  auto it = t->id2local.find(id);
-  if (it == t->id2local.end()) { set_err("unknown agent id " + std::to_string(id)); return nullptr; }
-  return t->ag[it->second].get();
-}
-
-// 4x4 column-major blocks of one edge:  TO = T Omega, TOT = T Omega T^T, Om = Omega (x weight)
-void edge_blocks(const dpgo_measurement_t &m, double TO[16], double TOT[16], double Om[16]) {
-  const double w = m.weight, k = m.kappa, tau = m.tau;
-  std::fill(TO, TO + 16, 0.0); std::fill(TOT, TOT + 16, 0.0); std::fill(Om, Om + 16, 0.0);
-  for (int a = 0; a < 3; ++a) {
-    for (int b = 0; b < 3; ++b) {
-      TO[a + 4 * b] = w * k * m.R[3 * a + b];
-      TOT[a + 4 * b] = w * ((a == b ? k : 0.0) + tau * (m.t[a] * m.t[b]));
-    }
-    TO[a + 12] = w * tau * m.t[a];
-    TOT[a + 12] = w * tau * m.t[a];
-    TOT[3 + 4 * a] = w * tau * m.t[a];
-    Om[5 * a] = w * k;
-  }
-  TO[15] = TOT[15] = Om[15] = w * tau;
-}
-
-void rebuild_index(Agent &a) {
-  if (!a.index_dirty) return;
-  int n = 0;
-  auto upd = [&](int p) { n = std::max(n, p + 1); };
-  for (auto &m : a.odom) { upd(m.p1); upd(m.p2); }
-  for (auto &m : a.priv) { upd(m.p1); upd(m.p2); }
-  std::vector<std::pair<int, int>> np;
-  for (auto &m : a.shared) {
-    if (m.r1 == a.id) { upd(m.p1); np.emplace_back(m.r2, m.p2); }
-    else { upd(m.p2); np.emplace_back(m.r1, m.p1); }
-  }
-  std::sort(np.begin(), np.end());
-  np.erase(std::unique(np.begin(), np.end()), np.end());
-  a.np = np;
-  a.np_has[0].assign(np.size(), 0);
-  a.np_has[1].assign(np.size(), 0);
-  a.neighbors.clear();
-  for (auto &p : np) if (a.neighbors.empty() || a.neighbors.back() != p.first) a.neighbors.push_back(p.first);
-  a.n = n;
-  a.index_dirty = false;
-  a.data_dirty = true;
-}
-
-int find_np(const Agent &a, int robot, int frame) {
-  auto it = std::lower_bound(a.np.begin(), a.np.end(), std::make_pair(robot, frame));
-  if (it == a.np.end() || *it != std::make_pair(robot, frame)) return -1;
-  return int(it - a.np.begin());
-}
-
-std::vector<int> public_ids(const Agent &a, int nbr) {
-  std::vector<int> f;
-  for (auto &m : a.shared) {
-    if (m.r1 == a.id && m.r2 == nbr) f.push_back(m.p1);
-    else if (m.r2 == a.id && m.r1 == nbr) f.push_back(m.p2);
-  }
-  std::sort(f.begin(), f.end());
-  f.erase(std::unique(f.begin(), f.end()), f.end());
-  return f;
-}
-
-std::vector<int> neighbor_ids(const Agent &a, int nbr) {
-  std::vector<int> f;
-  for (auto &p : a.np) if (p.first == nbr) f.push_back(p.second);
-  return f;
-}
-
-// connection Laplacian in block-CSR (row j lists (i, Q_ij)); duplicates merged in insertion order
-void build_Q(Agent &a) {
-  std::vector<std::map<int, std::array<double, 16>>> rows(a.n);
-  auto add = [&](int row, int colm, const double *v, bool transpose, double sign) {
-    auto &blk = rows[row][colm];
-    for (int cp = 0; cp < 4; ++cp)
-      for (int c = 0; c < 4; ++c) blk[cp + 4 * c] += sign * (transpose ? v[c + 4 * cp] : v[cp + 4 * c]);
-  };
-  double TO[16], TOT[16], Om[16];
-  for (int i = 0; i < a.n; ++i) rows[i][i];  // every pose owns a diagonal block
-  for (int pass = 0; pass < 2; ++pass)
-    for (auto &m : (pass ? a.priv : a.odom)) {
-      edge_blocks(m, TO, TOT, Om);
-      add(m.p1, m.p1, TOT, false, 1.0);
-      add(m.p2, m.p2, Om, false, 1.0);
-      add(m.p2, m.p1, TO, false, -1.0);  // Q_ij stored in row j
-      add(m.p1, m.p2, TO, true, -1.0);   // Q_ji = Q_ij^T stored in row i
-    }
-  for (auto &m : a.shared) {
-    edge_blocks(m, TO, TOT, Om);
-    if (m.r1 == a.id) add(m.p1, m.p1, TOT, false, 1.0);
-    else add(m.p2, m.p2, Om, false, 1.0);
-  }
-  a.rowptr.assign(a.n + 1, 0);
-  a.col.clear(); a.qval.clear();
-  for (int j = 0; j < a.n; ++j) {
-    for (auto &kv : rows[j]) {
-      a.col.push_back(kv.first);
-      a.qval.insert(a.qval.end(), kv.second.begin(), kv.second.end());
-    }
-    a.rowptr[j + 1] = (int)a.col.size();
-  }
-}
-
-}  // namespace
-
-
-namespace {
-
-// upload structure + data matrices of one agent and (re)build the dense preconditioner
-int finalize_agent(dpgo_team *t, Agent &a) {
-  rebuild_index(a);
-  if (!a.data_dirty) return 0;
-  const int r = t->prm.r, n = a.n, N4 = 4 * n;
-  const size_t len = (size_t)r * 4 * n;
-  hipStream_t s = t->stream;
-  build_Q(a);
-  // shared edges sorted by local pose
-  struct SE { int lpose; SharedEdgeDev d; };
-  std::vector<SharedEdgeDev> se;
-  double TO[16], TOT[16], Om[16];
-  for (auto &m : a.shared) {
-    edge_blocks(m, TO, TOT, Om);
-    const bool out = (m.r1 == a.id);
-    SharedEdgeDev d{};
-    d.lpose = out ? m.p1 : m.p2;
-    const int nr = out ? m.r2 : m.r1, nf = out ? m.p2 : m.p1;
-    d.slot = find_np(a, nr, nf);
-    auto it = t->id2local.find(nr);
-    d.src_agent_local = (it == t->id2local.end()) ? -1 : it->second;
-    d.src_frame = nf;
-    for (int cp = 0; cp < 4; ++cp)
-      for (int c = 0; c < 4; ++c) d.coef[cp + 4 * c] = out ? TO[c + 4 * cp] : TO[cp + 4 * c];
-    se.push_back(d);
-  }
-  std::stable_sort(se.begin(), se.end(), [](const SharedEdgeDev &x, const SharedEdgeDev &y) { return x.lpose < y.lpose; });
-  std::vector<int> pub_pose, pub_ptr;
-  for (size_t e = 0; e < se.size(); ++e) {
-    if (e == 0 || se[e].lpose != se[e - 1].lpose) { pub_pose.push_back(se[e].lpose); pub_ptr.push_back((int)e); }
-  }
-  pub_ptr.push_back((int)se.size());
-  a.npub = (int)pub_pose.size();
-  // edge records for residual / cost evaluation
-  std::vector<EdgeDev> edges;
-  auto push_edge = [&](const dpgo_measurement_t &m) {
-    EdgeDev e{};
-    e.i_local = (m.r1 == a.id) ? m.p1 : -1;
-    e.j_local = (m.r2 == a.id) ? m.p2 : -1;
-    e.i_slot = (m.r1 == a.id) ? -1 : find_np(a, m.r1, m.p1);
-    e.j_slot = (m.r2 == a.id) ? -1 : find_np(a, m.r2, m.p2);
-    std::memcpy(e.R, m.R, sizeof e.R);
-    std::memcpy(e.t, m.t, sizeof e.t);
-    e.kappa = m.kappa; e.tau = m.tau; e.weight = m.weight;
-    e.count_in_cost = (m.r1 == m.r2) ? 1 : (std::min(m.r1, m.r2) == a.id);
-    edges.push_back(e);
-  };
-  for (auto &m : a.odom) push_edge(m);
-  for (auto &m : a.priv) push_edge(m);
-  for (auto &m : a.shared) push_edge(m);
-  a.nedges = (int)edges.size();
-
-  // ELL (slot-major, width <= 8) + CSR tail copy of Q for the SpMM kernels
-  int maxlen = 0;
-  for (int j = 0; j < n; ++j) maxlen = std::max(maxlen, a.rowptr[j + 1] - a.rowptr[j]);
-  const int EW = std::min(maxlen, 8);
-  std::vector<int> ell_col((size_t)EW * n), trowptr(n + 1, 0), tcol;
-  std::vector<double> ell_val((size_t)EW * n * 16, 0.0), tval;
-  for (int j = 0; j < n; ++j) {
-    const int p0 = a.rowptr[j], p1 = a.rowptr[j + 1];
-    for (int u = 0; u < EW; ++u) {
-      const int p = p0 + u;
-      ell_col[(size_t)u * n + j] = (p < p1) ? a.col[p] : j;
-      if (p < p1) std::copy(a.qval.begin() + (size_t)16 * p, a.qval.begin() + (size_t)16 * (p + 1), ell_val.begin() + ((size_t)u * n + j) * 16);
-    }
-    for (int p = p0 + EW; p < p1; ++p) { tcol.push_back(a.col[p]); tval.insert(tval.end(), a.qval.begin() + (size_t)16 * p, a.qval.begin() + (size_t)16 * (p + 1)); }
-    trowptr[j + 1] = (int)tcol.size();
-  }
-  std::vector<int> pub_index(n, -1);
-  for (size_t q = 0; q < pub_pose.size(); ++q) pub_index[pub_pose[q]] = (int)q;
-  if (a.d_ell_col.upload(ell_col, s) || a.d_ell_val.upload(ell_val, s) || a.d_trowptr.upload(trowptr, s) ||
-      a.d_tcol.upload(tcol, s) || a.d_tval.upload(tval, s) || a.d_pub_index.upload(pub_index, s)) {
-    set_err("device allocation/upload failed");
-    return DPGO_ERR;
-  }
-  const bool fresh_vec = a.d_vec.n < len * NBUF;
-  if (a.d_rowptr.upload(a.rowptr, s) || a.d_col.upload(a.col, s) || a.d_qval.upload(a.qval, s) ||
-      a.d_pub_pose.upload(pub_pose, s) || a.d_pub_ptr.upload(pub_ptr, s) || a.d_se.upload(se, s) ||
-      a.d_edges.upload(edges, s) || a.d_vec.alloc(len * NBUF) || a.d_nbr.alloc(2 * a.np.size() * 4 * r) ||
-      a.d_part.alloc(PART_TOTAL) || a.d_scal.alloc(16) || a.d_resid.alloc(edges.size()) || a.d_st.alloc(2) ||
-      a.d_nest.alloc(1) || a.d_M.alloc((size_t)N4 * N4)) {
-    set_err("device allocation/upload failed");
-    return DPGO_ERR;
-  }
-  if (fresh_vec) {
-    HIPC(hipMemsetAsync(a.d_vec.p, 0, sizeof(double) * len * NBUF, s));
-    HIPC(hipMemsetAsync(a.d_nbr.p, 0, sizeof(double) * a.d_nbr.n, s));
-    HIPC(hipMemsetAsync(a.d_scal.p, 0, sizeof(double) * 16, s));
-    HIPC(hipMemsetAsync(a.d_nest.p, 0, sizeof(NestState), s));
-    HIPC(hipMemsetAsync(a.d_st.p, 0, sizeof(RtrState) * 2, s));
-    HIPC(hipMemsetAsync(a.d_part.p, 0, sizeof(double) * PART_TOTAL, s));
-  }
-  // dense preconditioner  M = (Q + shift I)^-1
-  if (t->d_tmp.alloc(2 * (size_t)N4 * N4)) { set_err("scratch allocation failed"); return DPGO_ERR; }
-  double *A = t->d_tmp.p, *W = t->d_tmp.p + (size_t)N4 * N4;
-  launch_bsr_to_dense(s, a.d_rowptr.p, a.d_col.p, a.d_qval.p, n, t->prm.precond_shift, A);
-  const int fail = dense_spd_inverse(s, A, W, a.d_M.p, N4);
-  if (fail != 0) { set_err("dense Cholesky of Q + shift I failed at pivot " + std::to_string(fail)); return DPGO_ERR; }
-
-  // per-neighbour index tables for the packed-slab exchange (a7)
-  size_t max_xfer = 1;
-  for (int nb : a.neighbors) {
-    const std::vector<int> fr = public_ids(a, nb);
-    std::vector<int> slots;
-    for (size_t q = 0; q < a.np.size(); ++q) if (a.np[q].first == nb) slots.push_back((int)q);
-    auto &bf = a.d_pubframes[nb]; if (!bf) bf = std::make_unique<DevBuf<int>>();
-    auto &bs = a.d_nbrslots[nb]; if (!bs) bs = std::make_unique<DevBuf<int>>();
-    if (bf->upload(fr, s) || bs->upload(slots, s)) { set_err("index upload failed"); return DPGO_ERR; }
-    a.n_pubframes[nb] = (int)fr.size(); a.n_nbrslots[nb] = (int)slots.size();
-    max_xfer = std::max(max_xfer, std::max(fr.size(), slots.size()));
-  }
-  if (a.d_xfer.alloc(max_xfer * 4 * r)) { set_err("device allocation failed"); return DPGO_ERR; }
-
-  AgentDev &d = a.dev;
-  d.id = a.id; d.n = n; d.nb = (int)a.col.size(); d.N4 = N4;
-  d.npub = a.npub; d.nshared = (int)se.size(); d.nnp = (int)a.np.size(); d.nedges = a.nedges;
-  d.rowptr = a.d_rowptr.p; d.col = a.d_col.p; d.qval = a.d_qval.p; d.M = a.d_M.p;
-  d.ell_w = EW; d.ell_col = a.d_ell_col.p; d.ell_val = a.d_ell_val.p;
-  d.trowptr = a.d_trowptr.p; d.tcol = a.d_tcol.p; d.tval = a.d_tval.p; d.pub_index = a.d_pub_index.p;
-  d.pub_pose = a.d_pub_pose.p; d.pub_ptr = a.d_pub_ptr.p; d.se = a.d_se.p; d.edges = a.d_edges.p;
-  d.nbr[0] = a.d_nbr.p; d.nbr[1] = a.d_nbr.p + a.np.size() * 4 * r;
-  for (int b = 0; b < NBUF; ++b) d.buf[b] = a.d_vec.p + len * b;
-  d.part = a.d_part.p; d.st = a.d_st.p; d.nest = a.d_nest.p; d.scal = a.d_scal.p; d.resid = a.d_resid.p;
-  a.data_dirty = false;
-  t->descs_dirty = true;
-  t->graph_valid = false;
-  return 0;
-}
-
-int sync_descs(dpgo_team *t) {
-  for (auto &a : t->ag) {
-    const int rc = finalize_agent(t, *a);
-    if (rc) return rc;
-  }
-  if (!t->descs_dirty) return 0;
-  std::vector<AgentDev> descs;
-  t->max_n = 0; t->max_npub = 0;
-  for (auto &a : t->ag) {
-    descs.push_back(a->dev);
-    t->max_n = std::max(t->max_n, a->n);
-    t->max_npub = std::max(t->max_npub, a->npub);
-  }
-  if (t->d_agents.upload(descs, t->stream)) { set_err("descriptor upload failed"); return DPGO_ERR; }
-  if (t->sched.empty()) for (size_t k = 0; k < t->ag.size(); ++k) t->sched.push_back((int)k);
-  if (t->d_sched.upload(t->sched, t->stream) || t->d_team.alloc(1)) { set_err("schedule upload failed"); return DPGO_ERR; }
-  // greedy colouring of the (local) agent graph in index order: same colour = no shared edge
-  const int na_ = (int)t->ag.size();
-  if (!t->user_groups) {
-  t->color_of.assign(na_, -1);
-  t->groups.clear();
-  for (int k = 0; k < na_; ++k) {
-    std::vector<char> used(na_ + 1, 0);
-    for (int nb : t->ag[k]->neighbors) {
-      auto it = t->id2local.find(nb);
-      if (it != t->id2local.end() && t->color_of[it->second] >= 0) used[t->color_of[it->second]] = 1;
-    }
-    int col = 0;
-    while (used[col]) ++col;
-    t->color_of[k] = col;
-    if ((int)t->groups.size() <= col) t->groups.resize(col + 1);
-    t->groups[col].push_back(k);
-  }
-  }
-  std::vector<int> gptr(1, 0), gmem;
-  for (auto &g : t->groups) { gmem.insert(gmem.end(), g.begin(), g.end()); gptr.push_back((int)gmem.size()); }
-  if (t->d_group_ptr.upload(gptr, t->stream) || t->d_group_members.upload(gmem, t->stream)) { set_err("group upload failed"); return DPGO_ERR; }
-  TeamDev td{};
-  td.num_agents = (int)t->ag.size(); td.sched_len = (int)t->sched.size(); td.iter = t->iter;
-  td.restart_interval = t->prm.restart_interval; td.sched = t->d_sched.p;
-  td.group_ptr = t->d_group_ptr.p; td.group_members = t->d_group_members.p;
-  HIPC(hipMemcpyAsync(t->d_team.p, &td, sizeof td, hipMemcpyHostToDevice, t->stream));
-  HIPC(hipStreamSynchronize(t->stream));
-  t->descs_dirty = false;
-  t->graph_valid = false;
-  return 0;
-}
-
-bool neighbor_poses_ready(const Agent &a, int aux) {
-  for (char h : a.np_has[aux]) if (!h) return false;
-  return true;
-}
-
-// ---- the local solve (QuadraticOptimizer::optimize), enqueued on the team stream -------------
-// sel >= 0: that local agent (host-driven), sel == -1: device-selected (graph capture).
-// RGD returns after enqueueing; the RTR path synchronises once per tCG chunk to read the
-// device-side solver state.
-//   fused: the iteration's tail (Nesterov V update, |X - XPrev|^2, end-of-iteration bookkeeping)
-//          is folded into the RGD kernels (no restart in this iteration); `last` folds k_advance.
-struct OptFlags { int aux = 0, pull = 0; bool capture = false, fused = false, last_advances = false; };
-
-EvalOpts eval_opts(const dpgo_team *t, int gmode, int aux, int advance) {
-  EvalOpts o;
-  o.gmode = gmode; o.aux = aux; o.advance = advance;
-  o.accel = t->prm.acceleration; o.num_robots = t->prm.num_robots; o.restart_interval = t->prm.restart_interval;
-  return o;
-}
-
-double spmm_bytes_of(const dpgo_team *t, const Agent &a) {
-  return 8.0 * (16.0 * a.col.size() + 3.0 * t->prm.r * 4 * a.n) + 4.0 * (a.col.size() + a.n + 1);
-}
-
-int enqueue_optimize(dpgo_team *t, int sel, const OptFlags &fl) {
-  LaunchCtx c = t->ctx();
-  const dpgo_params_t &p = t->prm;
-  const int mn = (sel >= 0) ? t->ag[sel]->n : t->max_n;
-  const int N4 = 4 * mn;
-  const int gmode = fl.pull ? 2 : 1;
-  if (p.method == DPGO_METHOD_RGD) {
-    launch_eval(c, sel, mn, B_X, B_EGRAD, B_GF, PART_C, eval_opts(t, gmode, fl.aux, 0));
-    if (fl.fused && p.rgd_use_preconditioner) {
-      // K3: preconditioner + RGD step + Nesterov V + |dX|^2 (+ the team's end-of-iteration bookkeeping);
-      // K5: f_opt / gradnorm_opt on the snapshot B_X2 that K3 leaves behind
-      launch_precond(c, sel, mn, PM_RGD_, B_X, B_GF, B_Z, 0, 0, p.rgd_stepsize, p.acceleration, p.num_robots,
-                     fl.last_advances ? 1 : 0, p.restart_interval);
-      launch_eval(c, sel, mn, B_X2, B_EGRAD2, B_GF2, PART_A, eval_opts(t, 0, 0, 0));
-    } else {
-      int dirb = B_GF;
-      if (p.rgd_use_preconditioner) {
-        launch_precond(c, sel, mn, PM_PLAIN_, B_X, B_GF, B_Z, 0, 0, 0.0, 0, p.num_robots);
-        dirb = B_Z;
-      }
-      launch_retract(c, sel, mn, B_X, dirb, -p.rgd_stepsize, B_X, -1);
-      launch_eval(c, sel, mn, B_X, B_EGRAD, B_GF, PART_A, eval_opts(t, 0, 0, 0));
-    }
-    if (sel >= 0 && !fl.capture) {
-      Agent &a = *t->ag[sel];
-      if (p.rgd_use_preconditioner) { t->counters[0] += 1; t->counters[1] += 8.0 * N4 * (double)N4; }
-      t->counters[2] += 2; t->counters[3] += 2 * spmm_bytes_of(t, a);
-      a.opt_pending_rgd = true;
-    }
-    return 0;
-  }
-  if (fl.capture) { set_err("RTR cannot be captured"); return DPGO_ERR; }
-  // ---- RTR: trust-region Newton with truncated CG; scalars stay on the device
-  Agent &a = *t->ag[sel];
-  launch_eval(c, sel, mn, B_X, B_EGRAD, B_GF, PART_A, eval_opts(t, gmode, fl.aux, 0));
-  launch_rtr_begin(c, sel, p.rtr_initial_radius, p.gradnorm_tol, p.rtr_iterations);
-  int sp = 0;
-  RtrState *hs = t->h_state;
-  auto read_state = [&]() -> int {
-    HIPC(hipMemcpyAsync(hs, a.dev.st + sp, sizeof(RtrState), hipMemcpyDeviceToHost, t->stream));
-    HIPC(hipStreamSynchronize(t->stream));
-    return 0;
-  };
-  // One outer iteration = [tCG init, (Hess-vec, step) x J, retract, evaluate, accept].  Every kernel is
-  // gated by the device-side phase, so whole patterns are enqueued blindly: the expected number of outer
-  // iterations first, then one read-back; more patterns only if the state says the solve is not done.
-  const int J = std::max(1, std::min(a.tcg_hint, p.rtr_tcg_iterations));
-  auto pattern = [&]() {
-    launch_precond(c, sel, mn, PM_TCG_INIT_, B_X, 0, 0, sp, p.rtr_tcg_iterations, 0.0, 0, p.num_robots); sp ^= 1;
-    for (int q = 0; q < J; ++q) {
-      launch_tcg_hv(c, sel, mn, sp, p.rtr_tcg_iterations); sp ^= 1;
-      launch_precond(c, sel, mn, PM_TCG_STEP_, B_X, 0, 0, sp, p.rtr_tcg_iterations, 0.0, 0, p.num_robots); sp ^= 1;
-    }
-    launch_retract(c, sel, mn, B_X, B_ETA, 1.0, B_X2, sp);
-    launch_rtr_eval2(c, sel, mn, sp);
-    launch_rtr_accept(c, sel, mn, sp, p.gradnorm_tol, p.rtr_iterations, p.rtr_max_radius); sp ^= 1;
-  };
-  bool have_state = false;
-  if (a.outer_hint == 0) {  // the previous solve of this agent started below the gradient tolerance
-    if (read_state()) return DPGO_ERR;
-    have_state = true;
-  }
-  if (!have_state || !hs->outer_done) {
-    const int first = (a.outer_hint > 0) ? std::min(a.outer_hint, p.rtr_iterations) : p.rtr_iterations;
-    for (int o = 0; o < first; ++o) pattern();
-    if (read_state()) return DPGO_ERR;
-    int guard = 0;
-    while (!hs->outer_done && guard++ < 100000) {
-      pattern();
-      if (read_state()) return DPGO_ERR;
-    }
-  }
-  a.outer_hint = hs->outer_count;
-  if (hs->outer_count > 0) a.tcg_hint = std::max(2, std::min(8, (hs->tcg_total + hs->outer_count - 1) / hs->outer_count + 1));
-  a.opt.success = 1;
-  a.opt.f_init = hs->f_init; a.opt.gradnorm_init = hs->gn_init;
-  a.opt.f_opt = hs->f1; a.opt.gradnorm_opt = hs->ngf;
-  a.opt.rtr_outer_iters = hs->outer_count; a.opt.tcg_iters_total = hs->tcg_total;
-  a.opt.hessvec_count = hs->hv_count; a.opt.precond_count = hs->pc_count; a.opt.accepted = hs->accepted;
-  a.opt_pending_rgd = false;
-  t->counters[0] += hs->pc_count; t->counters[1] += hs->pc_count * 8.0 * N4 * (double)N4;
-  t->counters[2] += hs->hv_count + 1 + hs->outer_count;
-  t->counters[3] += (hs->hv_count + 1 + hs->outer_count) * spmm_bytes_of(t, a);
-  return 0;
-}
-
-// one PGOAgent::iterate for local agent `li` (host-driven variant used by the per-agent API)
-int enqueue_iterate(dpgo_team *t, int li, int do_opt) {
-  Agent &a = *t->ag[li];
-  LaunchCtx c = t->ctx();
-  const dpgo_params_t &p = t->prm;
-  const bool restart = p.acceleration && ((a.iter + 2) % p.restart_interval) == 0;
-  const bool fused = do_opt && p.method == DPGO_METHOD_RGD && p.rgd_use_preconditioner && !restart;
-  OptFlags fl;
-  fl.fused = fused;
-  int rc = 0;
-  a.rel_src = 0;
-  if (p.acceleration) {
-    launch_nest_pre(c, do_opt ? li : -2, li, 1, a.n, p.num_robots, p.restart_interval);
-    if (do_opt) {
-      fl.aux = 1;
-      rc = enqueue_optimize(t, li, fl);
-      if (rc) return rc;
-      if (!fused) launch_nest_post(c, li, a.n, p.num_robots, p.restart_interval);
-      if (restart) {
-        fl.aux = 0;
-        rc = enqueue_optimize(t, li, fl);
-        if (rc) return rc;
-        launch_nest_reset(c, li, a.n);
-      }
-      if (fused) a.rel_src = 1; else launch_status(c, li, li, 1, a.n);
-    }
-  } else {
-    launch_copy(c, li, li, 1, a.n, B_X, B_XPREV, 0);
-    if (do_opt) {
-      rc = enqueue_optimize(t, li, fl);
-      if (rc) return rc;
-    }
-    if (fused) a.rel_src = 1; else launch_status(c, li, li, 1, a.n);
-  }
-  launch_advance(c, li, 1, p.acceleration, p.num_robots, p.restart_interval, 0);
-  return 0;
-}
-
-int fetch_scal(dpgo_team *t, Agent &a) {
-  HIPC(hipMemcpyAsync(t->h_scal, a.dev.scal, sizeof(double) * 16, hipMemcpyDeviceToHost, t->stream));
-  HIPC(hipStreamSynchronize(t->stream));
-  return 0;
-}
-
-int refresh_rgd_result(dpgo_team *t, Agent &a) {
-  if (!a.opt_pending_rgd) return 0;
-  const int ppb = 64 / t->prm.r, nb = (a.n + ppb - 1) / ppb;
-  std::vector<double> pc((size_t)PART_STRIDE * nb), pa((size_t)PART_STRIDE * nb);
-  HIPC(hipStreamSynchronize(t->stream));
-  HIPC(hipMemcpy(pc.data(), a.dev.part + PART_C, sizeof(double) * pc.size(), hipMemcpyDeviceToHost));
-  HIPC(hipMemcpy(pa.data(), a.dev.part + PART_A, sizeof(double) * pa.size(), hipMemcpyDeviceToHost));
-  auto sum = [&](const std::vector<double> &p, int off) { double s = 0; for (int i = 0; i < nb; ++i) s += p[(size_t)i * PART_STRIDE + off]; return s; };
-  a.opt.success = 1;
-  a.opt.f_init = sum(pc, 0); a.opt.gradnorm_init = std::sqrt(sum(pc, 1));
-  a.opt.f_opt = sum(pa, 0); a.opt.gradnorm_opt = std::sqrt(sum(pa, 1));
-  a.opt.rtr_outer_iters = 0; a.opt.tcg_iters_total = 0; a.opt.hessvec_count = 0;
-  a.opt.precond_count = t->prm.rgd_use_preconditioner ? 1 : 0; a.opt.accepted = 1;
-  a.opt_pending_rgd = false;
-  return 0;
-}
-
-double robust_weight(const dpgo_params_t &p, double mu, double residual) {
-  if (p.robust_cost_type == DPGO_COST_L2) return 1.0;
-  const double r2 = residual * residual, b2 = p.gnc_barc * p.gnc_barc;
-  const double upper = (mu + 1.0) / mu * b2, lower = mu / (mu + 1.0) * b2;
-  if (r2 >= upper) return 0.0;
-  if (r2 <= lower) return 1.0;
-  return std::sqrt(b2 * mu * (mu + 1.0) / r2) - mu;
-}
-
-int compute_residuals(dpgo_team *t, Agent &a, std::vector<double> &res) {
-  LaunchCtx c = t->ctx();
-  launch_residuals(c, a.local, a.nedges);
-  res.resize(a.nedges);
-  if (a.nedges) HIPC(hipMemcpyAsync(res.data(), a.dev.resid, sizeof(double) * a.nedges, hipMemcpyDeviceToHost, t->stream));
-  HIPC(hipStreamSynchronize(t->stream));
-  return 0;
-}
-
-}  // namespace
+using namespace dpgo_host;
 
 // =================================================================================================
 extern "C" {
@@ -1114,64 +515,6 @@ int dpgo_team_exchange_all(dpgo_team_t *t) {
   return 0;
 }
 
-// One global RBCD iteration over the agents of this team.
-//   sel: local index of the agent that optimizes, -1 = device-selected (graph capture), -2 = the
-//        selected agent lives on another rank (every local agent runs iterate(false)).
-//   phase: 0 whole iteration; 1 = begin (everything before the neighbour exchange: Nesterov Y/X/V of all
-//          local agents); 2 = end (local solve of `sel` + bookkeeping).
-static int enqueue_team_iteration(dpgo_team_t *t, bool capture, bool restart, int sel, int phase) {
-  LaunchCtx c = t->ctx();
-  const dpgo_params_t &p = t->prm;
-  const int na = (int)t->ag.size();
-  const int mn = t->max_n;
-  const bool fused = p.method == DPGO_METHOD_RGD && p.rgd_use_preconditioner && !restart && sel != -2;
-  OptFlags fl;
-  fl.pull = 1; fl.capture = capture; fl.fused = fused; fl.last_advances = fused;
-  int rc = 0;
-  if (phase != 2) {
-    if (p.acceleration) launch_nest_pre(c, sel, -1, na, mn, p.num_robots, p.restart_interval);  // K1 (+ publishes cur_sel)
-    else launch_copy(c, -3, -1, na, mn, B_X, B_XPREV, capture ? 1 : 0);
-  }
-  if (phase == 1) return 0;
-  if (sel != -2) {
-    fl.aux = p.acceleration ? 1 : 0;
-    rc = enqueue_optimize(t, sel, fl);
-    if (rc) return rc;
-    if (!fused) {
-      const int ns = (sel >= 0) ? t->ag[sel]->n : mn;
-      if (p.acceleration) {
-        launch_nest_post(c, sel, ns, p.num_robots, p.restart_interval);
-        if (restart) {
-          fl.aux = 0;
-          rc = enqueue_optimize(t, sel, fl);
-          if (rc) return rc;
-          launch_nest_reset(c, sel, ns);
-        }
-      }
-      launch_status(c, sel, -1, 1, ns);
-    }
-  }
-  if (!fused) launch_advance(c, -1, na, p.acceleration, p.num_robots, p.restart_interval, 1);
-  return 0;
-}
-
-// host-side bookkeeping after one global iteration in which local agent `sel` (or nobody: -2) optimized
-static void account_iteration(dpgo_team_t *t, int sel, bool fused) {
-  const dpgo_params_t &p = t->prm;
-  for (auto &a : t->ag) {
-    a->rel_src = p.acceleration ? 0 : 2;  // non-accelerated iterate(false) leaves X untouched
-    a->iter += 1;
-    if (p.robust_cost_type != DPGO_COST_L2) a->robust_inner_iter += 1;
-    if (p.acceleration) a->publish_requested = true;
-  }
-  if (sel >= 0) {
-    t->ag[sel]->rel_src = fused ? 1 : 0;
-    t->ag[sel]->publish_requested = true;
-  }
-  t->iter += 1;
-  t->counters[4] += 1;
-}
-
 int dpgo_team_step_begin(dpgo_team_t *t, int sel_id) {
   if (sync_descs(t)) return DPGO_ERR;
   auto it = t->id2local.find(sel_id);
@@ -1268,81 +611,6 @@ int dpgo_team_run(dpgo_team_t *t, int iters) {
     for (auto &a : t->ag) { a->iter += batch; if (p.robust_cost_type != DPGO_COST_L2) a->robust_inner_iter += batch; }
     t->counters[4] += batch;
     k += batch;
-  }
-  return 0;
-}
-
-// ---- colour-parallel sweeps: the agents of one colour class share no edge, so their block
-// updates commute; they run in the same launches (blockIdx.y = member) and the result equals the sequential
-// schedule that visits the classes in order.  Non-accelerated RBCD only (the Nesterov scalars advance per
-// global iteration and do not commute).
-static int enqueue_optimize_group(dpgo_team_t *t, int g) {
-  LaunchCtx c = t->ctx();
-  const dpgo_params_t &p = t->prm;
-  const std::vector<int> &mem = t->groups[g];
-  c.ny = (int)mem.size();
-  const int sel = SEL_GROUP0 - g;
-  int mn = 0;
-  for (int k : mem) mn = std::max(mn, t->ag[k]->n);
-  if (p.method == DPGO_METHOD_RGD) {
-    launch_eval(c, sel, mn, B_X, B_EGRAD, B_GF, PART_C, eval_opts(t, 2, 0, 0));
-    int dirb = B_GF;
-    if (p.rgd_use_preconditioner) { launch_precond(c, sel, mn, PM_PLAIN_, B_X, B_GF, B_Z, 0, 0, 0.0, 0, p.num_robots); dirb = B_Z; }
-    launch_retract(c, sel, mn, B_X, dirb, -p.rgd_stepsize, B_X, -1);
-    launch_eval(c, sel, mn, B_X, B_EGRAD, B_GF, PART_A, eval_opts(t, 0, 0, 0));
-    for (int k : mem) {
-      Agent &a = *t->ag[k];
-      const double N4 = 4.0 * a.n;
-      if (p.rgd_use_preconditioner) { t->counters[0] += 1; t->counters[1] += 8.0 * N4 * N4; }
-      t->counters[2] += 2; t->counters[3] += 2 * spmm_bytes_of(t, a);
-      a.opt_pending_rgd = true;
-    }
-    return 0;
-  }
-  launch_eval(c, sel, mn, B_X, B_EGRAD, B_GF, PART_A, eval_opts(t, 2, 0, 0));
-  launch_rtr_begin(c, sel, p.rtr_initial_radius, p.gradnorm_tol, p.rtr_iterations);
-  int sp = 0, J = 2;
-  for (int k : mem) J = std::max(J, t->ag[k]->tcg_hint);
-  J = std::min(J, p.rtr_tcg_iterations);
-  auto pattern = [&]() {
-    launch_precond(c, sel, mn, PM_TCG_INIT_, B_X, 0, 0, sp, p.rtr_tcg_iterations, 0.0, 0, p.num_robots); sp ^= 1;
-    for (int q = 0; q < J; ++q) {
-      launch_tcg_hv(c, sel, mn, sp, p.rtr_tcg_iterations); sp ^= 1;
-      launch_precond(c, sel, mn, PM_TCG_STEP_, B_X, 0, 0, sp, p.rtr_tcg_iterations, 0.0, 0, p.num_robots); sp ^= 1;
-    }
-    launch_retract(c, sel, mn, B_X, B_ETA, 1.0, B_X2, sp);
-    launch_rtr_eval2(c, sel, mn, sp);
-    launch_rtr_accept(c, sel, mn, sp, p.gradnorm_tol, p.rtr_iterations, p.rtr_max_radius); sp ^= 1;
-  };
-  auto read_states = [&](bool &all_done) -> int {
-    for (size_t q = 0; q < mem.size(); ++q)
-      HIPC(hipMemcpyAsync(t->h_states + q, t->ag[mem[q]]->dev.st + sp, sizeof(RtrState), hipMemcpyDeviceToHost, t->stream));
-    HIPC(hipStreamSynchronize(t->stream));
-    all_done = true;
-    for (size_t q = 0; q < mem.size(); ++q) all_done = all_done && t->h_states[q].outer_done;
-    return 0;
-  };
-  bool done = false;
-  for (int o = 0; o < p.rtr_iterations; ++o) pattern();
-  if (read_states(done)) return DPGO_ERR;
-  int guard = 0;
-  while (!done && guard++ < 100000) {
-    pattern();
-    if (read_states(done)) return DPGO_ERR;
-  }
-  for (size_t q = 0; q < mem.size(); ++q) {
-    Agent &a = *t->ag[mem[q]];
-    const RtrState &hs = t->h_states[q];
-    a.opt.success = 1;
-    a.opt.f_init = hs.f_init; a.opt.gradnorm_init = hs.gn_init; a.opt.f_opt = hs.f1; a.opt.gradnorm_opt = hs.ngf;
-    a.opt.rtr_outer_iters = hs.outer_count; a.opt.tcg_iters_total = hs.tcg_total;
-    a.opt.hessvec_count = hs.hv_count; a.opt.precond_count = hs.pc_count; a.opt.accepted = hs.accepted;
-    a.opt_pending_rgd = false;
-    if (hs.outer_count > 0) a.tcg_hint = std::max(2, std::min(8, (hs.tcg_total + hs.outer_count - 1) / hs.outer_count + 1));
-    const double N4 = 4.0 * a.n;
-    t->counters[0] += hs.pc_count; t->counters[1] += hs.pc_count * 8.0 * N4 * N4;
-    t->counters[2] += hs.hv_count + 1 + hs.outer_count;
-    t->counters[3] += (hs.hv_count + 1 + hs.outer_count) * spmm_bytes_of(t, a);
   }
   return 0;
 }

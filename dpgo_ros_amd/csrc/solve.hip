@@ -1,0 +1,331 @@
+// solve.hip -- launch sequencing: one agent's local solve (RTR with tCG / fused RGD), PGOAgent::iterate,
+// the synchronous team iteration and the colour-parallel group update.  The host enqueues blind launch
+// patterns; every decision (accept/reject, tCG termination, schedule) is taken on the device.
+#include "team_internal.h"
+
+using namespace dpgo;
+
+namespace dpgo_host {
+
+bool neighbor_poses_ready(const Agent &a, int aux) {
+  for (char h : a.np_has[aux]) if (!h) return false;
+  return true;
+}
+
+// ---- the local solve (QuadraticOptimizer::optimize), enqueued on the team stream -------------
+// sel >= 0: that local agent (host-driven), sel == -1: device-selected (graph capture).
+// RGD returns after enqueueing; the RTR path synchronises once per tCG chunk to read the
+// device-side solver state.
+//   fused: the iteration's tail (Nesterov V update, |X - XPrev|^2, end-of-iteration bookkeeping)
+//          is folded into the RGD kernels (no restart in this iteration); `last` folds k_advance.
+
+EvalOpts eval_opts(const dpgo_team *t, int gmode, int aux, int advance) {
+  EvalOpts o;
+  o.gmode = gmode; o.aux = aux; o.advance = advance;
+  o.accel = t->prm.acceleration; o.num_robots = t->prm.num_robots; o.restart_interval = t->prm.restart_interval;
+  return o;
+}
+
+double spmm_bytes_of(const dpgo_team *t, const Agent &a) {
+  return 8.0 * (16.0 * a.col.size() + 3.0 * t->prm.r * 4 * a.n) + 4.0 * (a.col.size() + a.n + 1);
+}
+
+int enqueue_optimize(dpgo_team *t, int sel, const OptFlags &fl) {
+  LaunchCtx c = t->ctx();
+  const dpgo_params_t &p = t->prm;
+  const int mn = (sel >= 0) ? t->ag[sel]->n : t->max_n;
+  const int N4 = 4 * mn;
+  const int gmode = fl.pull ? 2 : 1;
+  if (p.method == DPGO_METHOD_RGD) {
+    launch_eval(c, sel, mn, B_X, B_EGRAD, B_GF, PART_C, eval_opts(t, gmode, fl.aux, 0));
+    if (fl.fused && p.rgd_use_preconditioner) {
+      // K3: preconditioner + RGD step + Nesterov V + |dX|^2 (+ the team's end-of-iteration bookkeeping);
+      // K5: f_opt / gradnorm_opt on the snapshot B_X2 that K3 leaves behind
+      launch_precond(c, sel, mn, PM_RGD_, B_X, B_GF, B_Z, 0, 0, p.rgd_stepsize, p.acceleration, p.num_robots,
+                     fl.last_advances ? 1 : 0, p.restart_interval);
+      launch_eval(c, sel, mn, B_X2, B_EGRAD2, B_GF2, PART_A, eval_opts(t, 0, 0, 0));
+    } else {
+      int dirb = B_GF;
+      if (p.rgd_use_preconditioner) {
+        launch_precond(c, sel, mn, PM_PLAIN_, B_X, B_GF, B_Z, 0, 0, 0.0, 0, p.num_robots);
+        dirb = B_Z;
+      }
+      launch_retract(c, sel, mn, B_X, dirb, -p.rgd_stepsize, B_X, -1);
+      launch_eval(c, sel, mn, B_X, B_EGRAD, B_GF, PART_A, eval_opts(t, 0, 0, 0));
+    }
+    if (sel >= 0 && !fl.capture) {
+      Agent &a = *t->ag[sel];
+      if (p.rgd_use_preconditioner) { t->counters[0] += 1; t->counters[1] += 8.0 * N4 * (double)N4; }
+      t->counters[2] += 2; t->counters[3] += 2 * spmm_bytes_of(t, a);
+      a.opt_pending_rgd = true;
+    }
+    return 0;
+  }
+  if (fl.capture) { set_err("RTR cannot be captured"); return DPGO_ERR; }
+  // ---- RTR: trust-region Newton with truncated CG; scalars stay on the device
+  Agent &a = *t->ag[sel];
+  launch_eval(c, sel, mn, B_X, B_EGRAD, B_GF, PART_A, eval_opts(t, gmode, fl.aux, 0));
+  launch_rtr_begin(c, sel, p.rtr_initial_radius, p.gradnorm_tol, p.rtr_iterations);
+  int sp = 0;
+  RtrState *hs = t->h_state;
+  auto read_state = [&]() -> int {
+    HIPC(hipMemcpyAsync(hs, a.dev.st + sp, sizeof(RtrState), hipMemcpyDeviceToHost, t->stream));
+    HIPC(hipStreamSynchronize(t->stream));
+    return 0;
+  };
+  // One outer iteration = [tCG init, (Hess-vec, step) x J, retract, evaluate, accept].  Every kernel is
+  // gated by the device-side phase, so whole patterns are enqueued blindly: the expected number of outer
+  // iterations first, then one read-back; more patterns only if the state says the solve is not done.
+  const int J = std::max(1, std::min(a.tcg_hint, p.rtr_tcg_iterations));
+  auto pattern = [&]() {
+    launch_precond(c, sel, mn, PM_TCG_INIT_, B_X, 0, 0, sp, p.rtr_tcg_iterations, 0.0, 0, p.num_robots); sp ^= 1;
+    for (int q = 0; q < J; ++q) {
+      launch_tcg_hv(c, sel, mn, sp, p.rtr_tcg_iterations); sp ^= 1;
+      launch_precond(c, sel, mn, PM_TCG_STEP_, B_X, 0, 0, sp, p.rtr_tcg_iterations, 0.0, 0, p.num_robots); sp ^= 1;
+    }
+    launch_retract(c, sel, mn, B_X, B_ETA, 1.0, B_X2, sp);
+    launch_rtr_eval2(c, sel, mn, sp);
+    launch_rtr_accept(c, sel, mn, sp, p.gradnorm_tol, p.rtr_iterations, p.rtr_max_radius); sp ^= 1;
+  };
+  bool have_state = false;
+  if (a.outer_hint == 0) {  // the previous solve of this agent started below the gradient tolerance
+    if (read_state()) return DPGO_ERR;
+    have_state = true;
+  }
+  if (!have_state || !hs->outer_done) {
+    const int first = (a.outer_hint > 0) ? std::min(a.outer_hint, p.rtr_iterations) : p.rtr_iterations;
+    for (int o = 0; o < first; ++o) pattern();
+    if (read_state()) return DPGO_ERR;
+    int guard = 0;
+    while (!hs->outer_done && guard++ < 100000) {
+      pattern();
+      if (read_state()) return DPGO_ERR;
+    }
+  }
+  a.outer_hint = hs->outer_count;
+  if (hs->outer_count > 0) a.tcg_hint = std::max(2, std::min(8, (hs->tcg_total + hs->outer_count - 1) / hs->outer_count + 1));
+  a.opt.success = 1;
+  a.opt.f_init = hs->f_init; a.opt.gradnorm_init = hs->gn_init;
+  a.opt.f_opt = hs->f1; a.opt.gradnorm_opt = hs->ngf;
+  a.opt.rtr_outer_iters = hs->outer_count; a.opt.tcg_iters_total = hs->tcg_total;
+  a.opt.hessvec_count = hs->hv_count; a.opt.precond_count = hs->pc_count; a.opt.accepted = hs->accepted;
+  a.opt_pending_rgd = false;
+  t->counters[0] += hs->pc_count; t->counters[1] += hs->pc_count * 8.0 * N4 * (double)N4;
+  t->counters[2] += hs->hv_count + 1 + hs->outer_count;
+  t->counters[3] += (hs->hv_count + 1 + hs->outer_count) * spmm_bytes_of(t, a);
+  return 0;
+}
+
+// one PGOAgent::iterate for local agent `li` (host-driven variant used by the per-agent API)
+int enqueue_iterate(dpgo_team *t, int li, int do_opt) {
+  Agent &a = *t->ag[li];
+  LaunchCtx c = t->ctx();
+  const dpgo_params_t &p = t->prm;
+  const bool restart = p.acceleration && ((a.iter + 2) % p.restart_interval) == 0;
+  const bool fused = do_opt && p.method == DPGO_METHOD_RGD && p.rgd_use_preconditioner && !restart;
+  OptFlags fl;
+  fl.fused = fused;
+  int rc = 0;
+  a.rel_src = 0;
+  if (p.acceleration) {
+    launch_nest_pre(c, do_opt ? li : -2, li, 1, a.n, p.num_robots, p.restart_interval);
+    if (do_opt) {
+      fl.aux = 1;
+      rc = enqueue_optimize(t, li, fl);
+      if (rc) return rc;
+      if (!fused) launch_nest_post(c, li, a.n, p.num_robots, p.restart_interval);
+      if (restart) {
+        fl.aux = 0;
+        rc = enqueue_optimize(t, li, fl);
+        if (rc) return rc;
+        launch_nest_reset(c, li, a.n);
+      }
+      if (fused) a.rel_src = 1; else launch_status(c, li, li, 1, a.n);
+    }
+  } else {
+    launch_copy(c, li, li, 1, a.n, B_X, B_XPREV, 0);
+    if (do_opt) {
+      rc = enqueue_optimize(t, li, fl);
+      if (rc) return rc;
+    }
+    if (fused) a.rel_src = 1; else launch_status(c, li, li, 1, a.n);
+  }
+  launch_advance(c, li, 1, p.acceleration, p.num_robots, p.restart_interval, 0);
+  return 0;
+}
+
+int fetch_scal(dpgo_team *t, Agent &a) {
+  HIPC(hipMemcpyAsync(t->h_scal, a.dev.scal, sizeof(double) * 16, hipMemcpyDeviceToHost, t->stream));
+  HIPC(hipStreamSynchronize(t->stream));
+  return 0;
+}
+
+int refresh_rgd_result(dpgo_team *t, Agent &a) {
+  if (!a.opt_pending_rgd) return 0;
+  const int ppb = 64 / t->prm.r, nb = (a.n + ppb - 1) / ppb;
+  std::vector<double> pc((size_t)PART_STRIDE * nb), pa((size_t)PART_STRIDE * nb);
+  HIPC(hipStreamSynchronize(t->stream));
+  HIPC(hipMemcpy(pc.data(), a.dev.part + PART_C, sizeof(double) * pc.size(), hipMemcpyDeviceToHost));
+  HIPC(hipMemcpy(pa.data(), a.dev.part + PART_A, sizeof(double) * pa.size(), hipMemcpyDeviceToHost));
+  auto sum = [&](const std::vector<double> &p, int off) { double s = 0; for (int i = 0; i < nb; ++i) s += p[(size_t)i * PART_STRIDE + off]; return s; };
+  a.opt.success = 1;
+  a.opt.f_init = sum(pc, 0); a.opt.gradnorm_init = std::sqrt(sum(pc, 1));
+  a.opt.f_opt = sum(pa, 0); a.opt.gradnorm_opt = std::sqrt(sum(pa, 1));
+  a.opt.rtr_outer_iters = 0; a.opt.tcg_iters_total = 0; a.opt.hessvec_count = 0;
+  a.opt.precond_count = t->prm.rgd_use_preconditioner ? 1 : 0; a.opt.accepted = 1;
+  a.opt_pending_rgd = false;
+  return 0;
+}
+
+double robust_weight(const dpgo_params_t &p, double mu, double residual) {
+  if (p.robust_cost_type == DPGO_COST_L2) return 1.0;
+  const double r2 = residual * residual, b2 = p.gnc_barc * p.gnc_barc;
+  const double upper = (mu + 1.0) / mu * b2, lower = mu / (mu + 1.0) * b2;
+  if (r2 >= upper) return 0.0;
+  if (r2 <= lower) return 1.0;
+  return std::sqrt(b2 * mu * (mu + 1.0) / r2) - mu;
+}
+
+int compute_residuals(dpgo_team *t, Agent &a, std::vector<double> &res) {
+  LaunchCtx c = t->ctx();
+  launch_residuals(c, a.local, a.nedges);
+  res.resize(a.nedges);
+  if (a.nedges) HIPC(hipMemcpyAsync(res.data(), a.dev.resid, sizeof(double) * a.nedges, hipMemcpyDeviceToHost, t->stream));
+  HIPC(hipStreamSynchronize(t->stream));
+  return 0;
+}
+
+// One global RBCD iteration over the agents of this team.
+//   sel: local index of the agent that optimizes, -1 = device-selected (graph capture), -2 = the
+//        selected agent lives on another rank (every local agent runs iterate(false)).
+//   phase: 0 whole iteration; 1 = begin (everything before the neighbour exchange: Nesterov Y/X/V of all
+//          local agents); 2 = end (local solve of `sel` + bookkeeping).
+int enqueue_team_iteration(dpgo_team *t, bool capture, bool restart, int sel, int phase) {
+  LaunchCtx c = t->ctx();
+  const dpgo_params_t &p = t->prm;
+  const int na = (int)t->ag.size();
+  const int mn = t->max_n;
+  const bool fused = p.method == DPGO_METHOD_RGD && p.rgd_use_preconditioner && !restart && sel != -2;
+  OptFlags fl;
+  fl.pull = 1; fl.capture = capture; fl.fused = fused; fl.last_advances = fused;
+  int rc = 0;
+  if (phase != 2) {
+    if (p.acceleration) launch_nest_pre(c, sel, -1, na, mn, p.num_robots, p.restart_interval);  // K1 (+ publishes cur_sel)
+    else launch_copy(c, -3, -1, na, mn, B_X, B_XPREV, capture ? 1 : 0);
+  }
+  if (phase == 1) return 0;
+  if (sel != -2) {
+    fl.aux = p.acceleration ? 1 : 0;
+    rc = enqueue_optimize(t, sel, fl);
+    if (rc) return rc;
+    if (!fused) {
+      const int ns = (sel >= 0) ? t->ag[sel]->n : mn;
+      if (p.acceleration) {
+        launch_nest_post(c, sel, ns, p.num_robots, p.restart_interval);
+        if (restart) {
+          fl.aux = 0;
+          rc = enqueue_optimize(t, sel, fl);
+          if (rc) return rc;
+          launch_nest_reset(c, sel, ns);
+        }
+      }
+      launch_status(c, sel, -1, 1, ns);
+    }
+  }
+  if (!fused) launch_advance(c, -1, na, p.acceleration, p.num_robots, p.restart_interval, 1);
+  return 0;
+}
+
+// host-side bookkeeping after one global iteration in which local agent `sel` (or nobody: -2) optimized
+void account_iteration(dpgo_team *t, int sel, bool fused) {
+  const dpgo_params_t &p = t->prm;
+  for (auto &a : t->ag) {
+    a->rel_src = p.acceleration ? 0 : 2;  // non-accelerated iterate(false) leaves X untouched
+    a->iter += 1;
+    if (p.robust_cost_type != DPGO_COST_L2) a->robust_inner_iter += 1;
+    if (p.acceleration) a->publish_requested = true;
+  }
+  if (sel >= 0) {
+    t->ag[sel]->rel_src = fused ? 1 : 0;
+    t->ag[sel]->publish_requested = true;
+  }
+  t->iter += 1;
+  t->counters[4] += 1;
+}
+
+// ---- colour-parallel sweeps: the agents of one colour class share no edge, so their block
+// updates commute; they run in the same launches (blockIdx.y = member) and the result equals the sequential
+// schedule that visits the classes in order.  Non-accelerated RBCD only (the Nesterov scalars advance per
+// global iteration and do not commute).
+int enqueue_optimize_group(dpgo_team *t, int g) {
+  LaunchCtx c = t->ctx();
+  const dpgo_params_t &p = t->prm;
+  const std::vector<int> &mem = t->groups[g];
+  c.ny = (int)mem.size();
+  const int sel = SEL_GROUP0 - g;
+  int mn = 0;
+  for (int k : mem) mn = std::max(mn, t->ag[k]->n);
+  if (p.method == DPGO_METHOD_RGD) {
+    launch_eval(c, sel, mn, B_X, B_EGRAD, B_GF, PART_C, eval_opts(t, 2, 0, 0));
+    int dirb = B_GF;
+    if (p.rgd_use_preconditioner) { launch_precond(c, sel, mn, PM_PLAIN_, B_X, B_GF, B_Z, 0, 0, 0.0, 0, p.num_robots); dirb = B_Z; }
+    launch_retract(c, sel, mn, B_X, dirb, -p.rgd_stepsize, B_X, -1);
+    launch_eval(c, sel, mn, B_X, B_EGRAD, B_GF, PART_A, eval_opts(t, 0, 0, 0));
+    for (int k : mem) {
+      Agent &a = *t->ag[k];
+      const double N4 = 4.0 * a.n;
+      if (p.rgd_use_preconditioner) { t->counters[0] += 1; t->counters[1] += 8.0 * N4 * N4; }
+      t->counters[2] += 2; t->counters[3] += 2 * spmm_bytes_of(t, a);
+      a.opt_pending_rgd = true;
+    }
+    return 0;
+  }
+  launch_eval(c, sel, mn, B_X, B_EGRAD, B_GF, PART_A, eval_opts(t, 2, 0, 0));
+  launch_rtr_begin(c, sel, p.rtr_initial_radius, p.gradnorm_tol, p.rtr_iterations);
+  int sp = 0, J = 2;
+  for (int k : mem) J = std::max(J, t->ag[k]->tcg_hint);
+  J = std::min(J, p.rtr_tcg_iterations);
+  auto pattern = [&]() {
+    launch_precond(c, sel, mn, PM_TCG_INIT_, B_X, 0, 0, sp, p.rtr_tcg_iterations, 0.0, 0, p.num_robots); sp ^= 1;
+    for (int q = 0; q < J; ++q) {
+      launch_tcg_hv(c, sel, mn, sp, p.rtr_tcg_iterations); sp ^= 1;
+      launch_precond(c, sel, mn, PM_TCG_STEP_, B_X, 0, 0, sp, p.rtr_tcg_iterations, 0.0, 0, p.num_robots); sp ^= 1;
+    }
+    launch_retract(c, sel, mn, B_X, B_ETA, 1.0, B_X2, sp);
+    launch_rtr_eval2(c, sel, mn, sp);
+    launch_rtr_accept(c, sel, mn, sp, p.gradnorm_tol, p.rtr_iterations, p.rtr_max_radius); sp ^= 1;
+  };
+  auto read_states = [&](bool &all_done) -> int {
+    for (size_t q = 0; q < mem.size(); ++q)
+      HIPC(hipMemcpyAsync(t->h_states + q, t->ag[mem[q]]->dev.st + sp, sizeof(RtrState), hipMemcpyDeviceToHost, t->stream));
+    HIPC(hipStreamSynchronize(t->stream));
+    all_done = true;
+    for (size_t q = 0; q < mem.size(); ++q) all_done = all_done && t->h_states[q].outer_done;
+    return 0;
+  };
+  bool done = false;
+  for (int o = 0; o < p.rtr_iterations; ++o) pattern();
+  if (read_states(done)) return DPGO_ERR;
+  int guard = 0;
+  while (!done && guard++ < 100000) {
+    pattern();
+    if (read_states(done)) return DPGO_ERR;
+  }
+  for (size_t q = 0; q < mem.size(); ++q) {
+    Agent &a = *t->ag[mem[q]];
+    const RtrState &hs = t->h_states[q];
+    a.opt.success = 1;
+    a.opt.f_init = hs.f_init; a.opt.gradnorm_init = hs.gn_init; a.opt.f_opt = hs.f1; a.opt.gradnorm_opt = hs.ngf;
+    a.opt.rtr_outer_iters = hs.outer_count; a.opt.tcg_iters_total = hs.tcg_total;
+    a.opt.hessvec_count = hs.hv_count; a.opt.precond_count = hs.pc_count; a.opt.accepted = hs.accepted;
+    a.opt_pending_rgd = false;
+    if (hs.outer_count > 0) a.tcg_hint = std::max(2, std::min(8, (hs.tcg_total + hs.outer_count - 1) / hs.outer_count + 1));
+    const double N4 = 4.0 * a.n;
+    t->counters[0] += hs.pc_count; t->counters[1] += hs.pc_count * 8.0 * N4 * N4;
+    t->counters[2] += hs.hv_count + 1 + hs.outer_count;
+    t->counters[3] += (hs.hv_count + 1 + hs.outer_count) * spmm_bytes_of(t, a);
+  }
+  return 0;
+}
+
+}  // namespace dpgo_host

@@ -1,0 +1,152 @@
+// team_internal.h -- host-side state of libdpgo_hip.so shared by assembly.hip (structure + data matrices),
+// solve.hip (launch sequencing of the local solves and the team schedule) and capi.hip (the C-ABI).
+// Mirrors the DPGO::PGOAgent call surface consumed by src/PGOAgentROS.cpp.  All state
+// (X, XPrev, Y, V, Q, G, dense preconditioner, neighbour slabs, solver scalars) lives in HBM; the host only
+// sequences launches.  There is no CPU fallback: every entry point that computes fails with DPGO_ERR when
+// no HIP device is usable.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/dpgo_hip.h"
+#include "dpgo_dev.h"
+#include "kernels.h"
+
+namespace dpgo_host {
+using namespace dpgo;
+
+inline thread_local std::string g_err;
+inline void set_err(const std::string &s) { g_err = s; }
+
+#define HIPC(expr)                                                                         \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess) {                                                                \
+      set_err(std::string(#expr) + ": " + hipGetErrorString(e_) + " @" + std::to_string(__LINE__)); \
+      return DPGO_ERR;                                                                     \
+    }                                                                                      \
+  } while (0)
+
+template <class T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  int alloc(size_t count) {
+    if (count <= n && p) return 0;
+    if (p) (void)hipFree(p);
+    p = nullptr; n = 0;
+    if (hipMalloc(&p, sizeof(T) * std::max<size_t>(count, 1)) != hipSuccess) return -1;
+    n = std::max<size_t>(count, 1);
+    return 0;
+  }
+  int upload(const std::vector<T> &v, hipStream_t s) {
+    if (alloc(v.size())) return -1;
+    if (v.empty()) return 0;
+    return hipMemcpyAsync(p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice, s) == hipSuccess ? 0 : -1;
+  }
+};
+
+struct Agent {
+  int id = 0, local = 0;
+  std::vector<dpgo_measurement_t> odom, priv, shared;
+  bool index_dirty = true, data_dirty = true;
+  int n = 0;
+  // neighbour pose dictionary (sorted (robot, frame)) and per-neighbour public ids
+  std::vector<std::pair<int, int>> np;
+  std::vector<char> np_has[2];
+  std::vector<int> neighbors;
+  int state = DPGO_WAIT_FOR_DATA;
+  int iter = 0, instance = 0;
+  bool publish_requested = false;
+  bool has_X = false;
+  double mu = 0;
+  int weight_update_count = 0, robust_inner_iter = 0;
+  dpgo_opt_result_t opt{};
+  bool opt_pending_rgd = false, last_success = true;
+  // host copies of the sparse structure
+  std::vector<int> rowptr, col;
+  std::vector<double> qval;
+  int npub = 0;
+  // device storage
+  DevBuf<int> d_rowptr, d_col, d_pub_pose, d_pub_ptr, d_idx, d_ell_col, d_trowptr, d_tcol, d_pub_index;
+  DevBuf<double> d_qval, d_M, d_vec, d_nbr, d_part, d_scal, d_resid, d_ell_val, d_tval;
+  std::map<int, std::unique_ptr<DevBuf<int>>> d_pubframes, d_nbrslots;  // per neighbour, cached on the device
+  std::map<int, int> n_pubframes, n_nbrslots;
+  DevBuf<double> d_xfer;
+  int tcg_hint = 4, outer_hint = -1;  // launch-pattern sizing from the previous solve of this agent
+  int rel_src = 0;  // where the last |X - XPrev|^2 partials live: 0 PART_D (per 64-pose tile), 1 PART_B[2] (fused RGD)
+  DevBuf<SharedEdgeDev> d_se;
+  DevBuf<EdgeDev> d_edges;
+  DevBuf<RtrState> d_st;
+  DevBuf<NestState> d_nest;
+  AgentDev dev{};
+  int nedges = 0;
+};
+
+}  // namespace dpgo_host
+
+struct dpgo_team {
+  int device = 0;
+  dpgo_params_t prm{};
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::vector<std::unique_ptr<dpgo_host::Agent>> ag;
+  std::map<int, int> id2local;
+  dpgo_host::DevBuf<dpgo::AgentDev> d_agents;
+  dpgo_host::DevBuf<dpgo::TeamDev> d_team;
+  dpgo_host::DevBuf<int> d_sched, d_group_ptr, d_group_members;
+  std::vector<std::vector<int>> groups;  // colour classes (local agent indices), greedy colouring
+  std::vector<int> color_of;
+  bool user_groups = false;              // groups supplied by dpgo_team_set_groups (global colouring)
+  dpgo::RtrState *h_states = nullptr;          // pinned, one per local agent
+  dpgo_host::DevBuf<double> d_tmp;  // scratch for raw manifold ops / dense factorisation
+  std::vector<int> sched;
+  int iter = 0;
+  bool descs_dirty = true;
+  int max_n = 0, max_npub = 0;
+  dpgo::RtrState *h_state = nullptr;  // pinned
+  double *h_scal = nullptr;     // pinned [16]
+  static constexpr int NGRAPH = 5;       // graphs of 1, 2, 4, 8, 16 identical iterations
+  hipGraphExec_t graph[NGRAPH] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  bool graph_valid = false;
+  double counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  dpgo::LaunchCtx ctx() { return dpgo::LaunchCtx{prm.r, stream, d_agents.p, d_team.p}; }
+};
+
+namespace dpgo_host {
+
+// ---- assembly.hip
+Agent *find_agent(dpgo_team *t, int id);
+void rebuild_index(Agent &a);
+int find_np(const Agent &a, int robot, int frame);
+std::vector<int> public_ids(const Agent &a, int nbr);
+std::vector<int> neighbor_ids(const Agent &a, int nbr);
+int finalize_agent(dpgo_team *t, Agent &a);
+int sync_descs(dpgo_team *t);
+
+// ---- solve.hip
+struct OptFlags { int aux = 0, pull = 0; bool capture = false, fused = false, last_advances = false; };
+bool neighbor_poses_ready(const Agent &a, int aux);
+EvalOpts eval_opts(const dpgo_team *t, int gmode, int aux, int advance);
+double spmm_bytes_of(const dpgo_team *t, const Agent &a);
+int enqueue_optimize(dpgo_team *t, int sel, const OptFlags &fl);
+int enqueue_iterate(dpgo_team *t, int li, int do_opt);
+int enqueue_team_iteration(dpgo_team *t, bool capture, bool restart, int sel, int phase);
+void account_iteration(dpgo_team *t, int sel, bool fused);
+int enqueue_optimize_group(dpgo_team *t, int g);
+int fetch_scal(dpgo_team *t, Agent &a);
+int refresh_rgd_result(dpgo_team *t, Agent &a);
+double robust_weight(const dpgo_params_t &p, double mu, double residual);
+int compute_residuals(dpgo_team *t, Agent &a, std::vector<double> &res);
+
+}  // namespace dpgo_host
