@@ -179,6 +179,11 @@ def multi_gpu(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     torch.cuda.set_device(local_rank)
     dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    # every rank takes part in one collective before the first point-to-point batch: the RCCL communicator of
+    # the whole group exists before any subset of ranks starts exchanging slabs
+    warm = torch.zeros(1, device="cuda")
+    dist.all_reduce(warm)
+    torch.cuda.synchronize()
     NA, r = WORKLOAD["num_robots"], WORKLOAD["r"]
     m, mp, n, T, Y = load_problem(capi)
     mine = [a for a in range(NA) if owner_of(a, world) == rank]

@@ -75,7 +75,8 @@ dpgo_agent_get_G dpgo_project_manifold dpgo_tangent_project dpgo_retract dpgo_ag
 dpgo_agent_robust_weight dpgo_agent_update_measurement_weights dpgo_agent_set_measurement_weight
 dpgo_agent_get_measurements dpgo_agent_should_update_weights dpgo_agent_clear_data_matrices
 dpgo_error_threshold_at_quantile dpgo_team_set_schedule dpgo_team_set_initial dpgo_team_exchange_all
-dpgo_agent_pull_local dpgo_team_time_kernel dpgo_team_run dpgo_team_get_coloring dpgo_team_run_colored dpgo_team_set_groups dpgo_team_run_group dpgo_team_step_begin dpgo_team_step_end dpgo_team_iteration dpgo_team_cost dpgo_team_update_weights dpgo_team_get_counters""".split()
+dpgo_agent_pull_local dpgo_team_time_kernel dpgo_team_run dpgo_team_get_coloring dpgo_team_run_colored dpgo_team_set_groups dpgo_team_run_group dpgo_team_step_begin dpgo_team_step_end dpgo_team_iteration dpgo_team_cost dpgo_team_update_weights dpgo_team_get_counters
+dpgo_write_measurements_csv dpgo_write_g2o dpgo_write_trajectory_csv dpgo_robust_frame_alignment""".split()
 
 
 class DpgoError(RuntimeError):
@@ -137,6 +138,61 @@ def read_csv(path, weight_mode=WEIGHT_LIBRARY):
     raw = C.string_at(out, nm * MEAS_DTYPE.itemsize)
     lib().dpgo_free(out)
     return np.frombuffer(raw, dtype=MEAS_DTYPE).copy()
+
+
+def robust_frame_alignment(Tc, max_rotation_error_rad=0.5, max_translation_error=1.0, min_inliers=2):
+    """Tc: n x 12 candidate transforms (3x4 column-major).  Returns (T, inlier mask) or None when fewer than
+    min_inliers candidates agree."""
+    Tc = np.ascontiguousarray(Tc, dtype=np.float64).reshape(-1, 12)
+    T, inl = np.zeros(12), np.zeros(len(Tc), dtype=np.int32)
+    rc = lib().dpgo_robust_frame_alignment(_d(Tc), len(Tc), C.c_double(max_rotation_error_rad),
+                                           C.c_double(max_translation_error), min_inliers, _d(T), _d(inl))
+    return (T, inl.astype(bool)) if rc == OK else None
+
+
+def write_csv(path, m):
+    """measurement list -> the CSV that read_csv / PGOLogger::loadMeasurements reads (weights included)"""
+    m = np.ascontiguousarray(m)
+    if lib().dpgo_write_measurements_csv(str(path).encode(), _d(m), len(m)) < 0:
+        raise OSError("cannot write %s" % path)
+
+
+def write_g2o(path, m, T=None, num_poses=0, robot_offsets=None):
+    m = np.ascontiguousarray(m)
+    Tp = _d(np.ascontiguousarray(T, dtype=np.float64)) if T is not None else None
+    off = np.ascontiguousarray(robot_offsets, dtype=np.int32) if robot_offsets is not None else None
+    if lib().dpgo_write_g2o(str(path).encode(), _d(m), len(m), Tp, num_poses if T is not None else 0,
+                            _d(off) if off is not None else None) < 0:
+        raise OSError("cannot write %s" % path)
+
+
+def write_trajectory_csv(path, T, num_poses):
+    T = np.ascontiguousarray(T, dtype=np.float64)
+    if lib().dpgo_write_trajectory_csv(str(path).encode(), _d(T), num_poses) < 0:
+        raise OSError("cannot write %s" % path)
+
+
+class IterationLog:
+    """per-iteration CSV in the column order of the reference's log (src/PGOAgentROS.cpp:863-864, 883-891),
+    followed by the global-cost column the reference does not have."""
+    HEADER = ("robot_id, cluster_id, num_active_robots, iteration, num_poses, bytes_received, "
+              "iter_time_sec, total_time_sec, rel_change, global_cost \n")
+
+    def __init__(self, path):
+        self.f = open(path, "w")
+        self.f.write(self.HEADER)
+
+    def log(self, robot_id, cluster_id, num_active_robots, iteration, num_poses, bytes_received, iter_time_sec,
+            total_time_sec, rel_change, global_cost=float("nan")):
+        self.f.write("%d,%d,%d,%d,%d,%d,%.9g,%.9g,%.17g,%.17g\n" % (robot_id, cluster_id, num_active_robots, iteration,
+                                                                     num_poses, bytes_received, iter_time_sec,
+                                                                     total_time_sec, rel_change, global_cost))
+
+    def log_string(self, s):  # "TERMINATE", "UPDATE_WEIGHT", ... (src/PGOAgentROS.cpp:896-909)
+        self.f.write(s + "\n")
+
+    def close(self):
+        self.f.close()
 
 
 def partition(m, num_poses, num_robots, weight_mode=WEIGHT_LIBRARY):

@@ -5,6 +5,8 @@
 //   PGOLogger::loadMeasurements(file, false)     src/PGODatasetPublisherNode.cpp:168
 //   contiguous-block partition + classification  src/PGODatasetPublisherNode.cpp:84-135
 //   wrapper weighting kappa=1e4 / tau=1e2, odometry => fixedWeight   src/utils.cpp:141-149
+// and writes the same formats back (PGOLogger::logMeasurements / logTrajectory analogue, so that
+// GNC weights and rounded trajectories round-trip through loadMeasurements / read_g2o_file).
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -24,6 +26,27 @@ void quat_to_rot(double qx, double qy, double qz, double qw, double R[9]) {
   R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * w);     R[2] = 2 * (x * z + y * w);
   R[3] = 2 * (x * y + z * w);     R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * w);
   R[6] = 2 * (x * z - y * w);     R[7] = 2 * (y * z + x * w);     R[8] = 1 - 2 * (x * x + y * y);
+}
+
+// unit quaternion (x, y, z, w), w >= 0, of a row-major rotation (Shepperd's branch on the largest pivot)
+void rot_to_quat(const double R[9], double q[4]) {
+  const double tr = R[0] + R[4] + R[8];
+  if (tr > 0) {
+    const double s = 2.0 * std::sqrt(1.0 + tr);
+    q[3] = 0.25 * s; q[0] = (R[7] - R[5]) / s; q[1] = (R[2] - R[6]) / s; q[2] = (R[3] - R[1]) / s;
+  } else if (R[0] > R[4] && R[0] > R[8]) {
+    const double s = 2.0 * std::sqrt(1.0 + R[0] - R[4] - R[8]);
+    q[3] = (R[7] - R[5]) / s; q[0] = 0.25 * s; q[1] = (R[1] + R[3]) / s; q[2] = (R[2] + R[6]) / s;
+  } else if (R[4] > R[8]) {
+    const double s = 2.0 * std::sqrt(1.0 + R[4] - R[0] - R[8]);
+    q[3] = (R[2] - R[6]) / s; q[0] = (R[1] + R[3]) / s; q[1] = 0.25 * s; q[2] = (R[5] + R[7]) / s;
+  } else {
+    const double s = 2.0 * std::sqrt(1.0 + R[8] - R[0] - R[4]);
+    q[3] = (R[3] - R[1]) / s; q[0] = (R[2] + R[6]) / s; q[1] = (R[5] + R[7]) / s; q[2] = 0.25 * s;
+  }
+  const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  const double sg = q[3] < 0 ? -1.0 : 1.0;
+  for (int k = 0; k < 4; ++k) q[k] = sg * q[k] / n;
 }
 
 // tr(S^-1) of the symmetric 3x3 [a b c; b d e; c e f]
@@ -111,6 +134,63 @@ int dpgo_read_measurements_csv(const char *path, int weight_mode, dpgo_measureme
   }
   *out = to_c_array(ms);
   return static_cast<int>(ms.size());
+}
+
+int dpgo_write_measurements_csv(const char *path, const dpgo_measurement_t *m, int nm) {
+  FILE *f = std::fopen(path, "w");
+  if (!f) return -1;
+  std::fprintf(f, "robot_src,pose_src,robot_dst,pose_dst,qx,qy,qz,qw,tx,ty,tz,kappa,tau,is_known_inlier,weight\n");
+  for (int k = 0; k < nm; ++k) {
+    double q[4];
+    rot_to_quat(m[k].R, q);
+    std::fprintf(f, "%d,%d,%d,%d,%.17g,%.17g,%.17g,%.17g,%.17g,%.17g,%.17g,%.17g,%.17g,%d,%.17g\n", m[k].r1, m[k].p1,
+                 m[k].r2, m[k].p2, q[0], q[1], q[2], q[3], m[k].t[0], m[k].t[1], m[k].t[2], m[k].kappa, m[k].tau,
+                 m[k].is_known_inlier ? 1 : 0, m[k].weight);
+  }
+  return std::fclose(f) == 0 ? nm : -1;
+}
+
+int dpgo_write_g2o(const char *path, const dpgo_measurement_t *m, int nm, const double *T, int num_poses,
+                   const int *robot_offsets) {
+  FILE *f = std::fopen(path, "w");
+  if (!f) return -1;
+  for (int i = 0; T && i < num_poses; ++i) {
+    const double *Ti = T + (size_t)12 * i;  // column-major 3x4
+    const double Rm[9] = {Ti[0], Ti[3], Ti[6], Ti[1], Ti[4], Ti[7], Ti[2], Ti[5], Ti[8]};
+    double q[4];
+    rot_to_quat(Rm, q);
+    std::fprintf(f, "VERTEX_SE3:QUAT %d %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", i, Ti[9], Ti[10], Ti[11], q[0], q[1],
+                 q[2], q[3]);
+  }
+  for (int k = 0; k < nm; ++k) {
+    const int i = m[k].p1 + (robot_offsets ? robot_offsets[m[k].r1] : 0);
+    const int j = m[k].p2 + (robot_offsets ? robot_offsets[m[k].r2] : 0);
+    double q[4];
+    rot_to_quat(m[k].R, q);
+    std::fprintf(f, "EDGE_SE3:QUAT %d %d %.17g %.17g %.17g %.17g %.17g %.17g %.17g", i, j, m[k].t[0], m[k].t[1], m[k].t[2],
+                 q[0], q[1], q[2], q[3]);
+    // isotropic information: translation block tau I, rotation block 2 kappa I (inverse of the reader's
+    // tau = 3 / tr(I_t^-1), kappa = 3 / (2 tr(I_R^-1)))
+    const double d[6] = {m[k].tau, m[k].tau, m[k].tau, 2 * m[k].kappa, 2 * m[k].kappa, 2 * m[k].kappa};
+    for (int a = 0; a < 6; ++a)
+      for (int b = a; b < 6; ++b) std::fprintf(f, " %.17g", a == b ? d[a] : 0.0);
+    std::fprintf(f, "\n");
+  }
+  return std::fclose(f) == 0 ? nm : -1;
+}
+
+int dpgo_write_trajectory_csv(const char *path, const double *T, int num_poses) {
+  FILE *f = std::fopen(path, "w");
+  if (!f) return -1;
+  std::fprintf(f, "pose_index,qx,qy,qz,qw,tx,ty,tz\n");
+  for (int i = 0; i < num_poses; ++i) {
+    const double *Ti = T + (size_t)12 * i;
+    const double Rm[9] = {Ti[0], Ti[3], Ti[6], Ti[1], Ti[4], Ti[7], Ti[2], Ti[5], Ti[8]};
+    double q[4];
+    rot_to_quat(Rm, q);
+    std::fprintf(f, "%d,%.17g,%.17g,%.17g,%.17g,%.17g,%.17g,%.17g\n", i, q[0], q[1], q[2], q[3], Ti[9], Ti[10], Ti[11]);
+  }
+  return std::fclose(f) == 0 ? num_poses : -1;
 }
 
 void dpgo_partition(dpgo_measurement_t *m, int nm, int num_poses, int num_robots, int weight_mode) {

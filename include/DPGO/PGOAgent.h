@@ -8,7 +8,7 @@
 // Declared simplifications ("next"): local initialisation is odometry chaining or the GPU chordal
 // relaxation (InitializationMethod::GNC_TLS falls back to odometry);
 // the inter-robot frame alignment uses the first shared loop closure whose neighbour pose is known
-// (the reference averages robustly over all of them); robot 0 draws a fixed, not random, YLift.
+// (L2 cost) or GNC-TLS two-stage averaging over all of them (robust cost); robot 0 draws a fixed, not random, YLift.
 #pragma once
 #include <cassert>
 #include <cstdio>
@@ -44,6 +44,8 @@ class PGOAgentParameters {  // fields written by src/PGOAgentROSNode.cpp:80-231
   unsigned robustOptNumWeightUpdates = 4, robustOptNumResets = 0, robustOptInnerIters = 30;
   double robustOptMinConvergenceRatio = 0.8;
   unsigned robustInitMinInliers = 2;
+  double robustInitMaxRotationError = 0.5;     // rad: candidates further than this from the consensus are outliers
+  double robustInitMaxTranslationError = 1.0;  // same unit as the measurements' translations
   unsigned maxNumIters = 1000;
   double relChangeTol = 5e-3;
   bool verbose = false, logData = false;
@@ -469,7 +471,11 @@ class PGOAgent {
     mat_set_block(T, 0, d, t);
     return T;
   }
+  // One candidate for T_world_robot per shared loop closure whose neighbour pose is in `dict`.  L2 cost: the
+  // first candidate initialises the frame; robust cost: GNC-TLS two-stage averaging over all of them
+  // (dpgo_robust_frame_alignment), and the agent stays uninitialised until robustInitMinInliers agree.
   void tryAlignWithNeighbor(unsigned nbr, const PoseDict &dict) {
+    std::vector<double> cand;
     for (const auto &m : mPoseGraph->sharedLoopClosures()) {
       const bool out = (m.r1 == mID);
       if ((out ? m.r2 : m.r1) != nbr) continue;
@@ -484,9 +490,22 @@ class PGOAgent {
       const Pose T_world_nbr(Tn), T_meas(Tm);
       const Pose T_world_mine = out ? T_world_nbr * T_meas.inverse() : T_world_nbr * T_meas;
       const Pose T_local(TLocalInit->pose((unsigned)(out ? m.p1 : m.p2)));
-      initializeInGlobalFrame(T_world_mine * T_local.inverse());
-      return;
+      const Pose T_world_robot = T_world_mine * T_local.inverse();
+      if (mParams.robustCostParams.costType == RobustCostParameters::Type::L2) {
+        initializeInGlobalFrame(T_world_robot);
+        return;
+      }
+      const Matrix &Tc = T_world_robot.getData();
+      for (unsigned c = 0; c < d + 1; ++c) for (unsigned a = 0; a < d; ++a) cand.push_back(Tc(a, c));
     }
+    const int n = (int)(cand.size() / 12);
+    if (n == 0) return;
+    double Tout[12];
+    if (dpgo_robust_frame_alignment(cand.data(), n, mParams.robustInitMaxRotationError, mParams.robustInitMaxTranslationError,
+                                    (int)mParams.robustInitMinInliers, Tout, nullptr) != DPGO_OK) return;
+    Matrix T = Matrix::Zero(d, d + 1);
+    for (unsigned c = 0; c < d + 1; ++c) for (unsigned a = 0; a < d; ++a) T(a, c) = Tout[3 * c + a];
+    initializeInGlobalFrame(Pose(T));
   }
 };
 

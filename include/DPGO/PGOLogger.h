@@ -1,4 +1,5 @@
-// PGOLogger::loadMeasurements(file, bool)  (src/PGODatasetPublisherNode.cpp:168)
+// PGOLogger::loadMeasurements(file, bool)  (src/PGODatasetPublisherNode.cpp:168) and the writers that
+// round-trip through it: logMeasurements, logTrajectory (files land in the logger's directory).
 #pragma once
 #include <stdexcept>
 #include "RelativeSEMeasurement.h"
@@ -21,6 +22,22 @@ class PGOLogger {
     }
     dpgo_free(raw);
     return out;
+  }
+  // measurement list (weights and inlier flags included) in the loadMeasurements format
+  bool logMeasurements(const std::vector<RelativeSEMeasurement> &measurements, const std::string &filename) const {
+    std::vector<dpgo_measurement_t> raw;
+    raw.reserve(measurements.size());
+    for (const auto &m : measurements) raw.push_back(m.toC());
+    return dpgo_write_measurements_csv((dir_ + filename).c_str(), raw.data(), (int)raw.size()) >= 0;
+  }
+  // T = d x (d+1)n trajectory [R_0 t_0 | R_1 t_1 | ...] as returned by getTrajectoryInGlobalFrame
+  bool logTrajectory(unsigned d, unsigned n, const Matrix &T, const std::string &filename) const {
+    if (d != 3) return false;
+    std::vector<double> flat((size_t)12 * n);
+    for (unsigned i = 0; i < n; ++i)
+      for (unsigned c = 0; c < 4; ++c)
+        for (unsigned a = 0; a < 3; ++a) flat[(size_t)12 * i + 3 * c + a] = T(a, 4 * i + c);
+    return dpgo_write_trajectory_csv((dir_ + filename).c_str(), flat.data(), (int)n) >= 0;
   }
  private:
   std::string dir_;

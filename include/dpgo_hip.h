@@ -79,6 +79,23 @@ const char *dpgo_last_error(void);
  *      PGOLogger::loadMeasurements (:168), contiguous partition (:84-135) ---- */
 int dpgo_read_g2o(const char *path, int weight_mode, dpgo_measurement_t **out, int *num_poses);
 int dpgo_read_measurements_csv(const char *path, int weight_mode, dpgo_measurement_t **out);
+/* robust inter-robot frame alignment: n candidate transforms T_world_robot (3x4 column-major
+ * each, one per shared loop closure with an initialised neighbour; updateNeighborPoses ->
+ * initializeInGlobalFrame, src/PGOAgentROS.cpp:1276, 353-358) -> GNC-TLS rotation averaging (chordal metric,
+ * threshold = chord of max_rotation_error_rad) then GNC-TLS translation averaging on the rotation inliers.
+ * DPGO_OK, or DPGO_NOT_READY when fewer than min_inliers (robustInitMinInliers, Node.cpp:150) agree.
+ * inlier: n flags or NULL.  Host arithmetic only. */
+int dpgo_robust_frame_alignment(const double *T_candidates, int n, double max_rotation_error_rad,
+                                double max_translation_error, int min_inliers, double *T_out, int *inlier);
+/* writers (the PGOLogger::logMeasurements / logTrajectory role): the CSV of loadMeasurements
+ * (data/tunnels/robot0/measurements.csv:1, weights and inlier flags included so GNC results round-trip), g2o
+ * with isotropic information blocks (global index = robot_offsets[robot] + frame; NULL = single robot; T =
+ * 3x4 column-major poses or NULL for edges only), and a trajectory CSV "pose_index,qx,qy,qz,qw,tx,ty,tz".
+ * Return the number of records written, -1 on I/O failure. */
+int dpgo_write_measurements_csv(const char *path, const dpgo_measurement_t *m, int nm);
+int dpgo_write_g2o(const char *path, const dpgo_measurement_t *m, int nm, const double *T, int num_poses,
+                   const int *robot_offsets);
+int dpgo_write_trajectory_csv(const char *path, const double *T, int num_poses);
 void dpgo_partition(dpgo_measurement_t *m, int nm, int num_poses, int num_robots, int weight_mode);
 void dpgo_free(void *p);
 void dpgo_odometry_init(const dpgo_measurement_t *m, int nm, int num_poses, double *T /* 3x4 per pose */);

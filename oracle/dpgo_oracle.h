@@ -157,6 +157,9 @@ int orc_chordal_init(const orc_meas_t *m, int nm, int num_poses, double *T);
 void orc_lift(const double *T, int num_poses, const double *YLift, int r, double *X);
 void orc_fixed_stiefel(int r, double *YLift); /* deterministic r x 3 Stiefel point */
 double orc_measurement_cost(const orc_meas_t *m, int nm, const double *X, int r); /* single-robot ids */
+/* robust frame alignment from n candidate transforms (3x4 column-major each): 0 ok, 1 not enough inliers */
+int orc_robust_frame_alignment(const double *Tc, int n, double max_rot_rad, double max_trans, int min_inliers,
+                               double *T_out, int *inlier /* nullable */);
 
 #ifdef __cplusplus
 }

@@ -140,6 +140,14 @@ def chordal_init(m, num_poses):
     return T
 
 
+def robust_frame_alignment(Tc, max_rotation_error_rad=0.5, max_translation_error=1.0, min_inliers=2):
+    Tc = np.ascontiguousarray(Tc, dtype=np.float64).reshape(-1, 12)
+    T, inl = np.zeros(12), np.zeros(len(Tc), dtype=np.int32)
+    rc = lib().orc_robust_frame_alignment(_d(Tc), len(Tc), C.c_double(max_rotation_error_rad),
+                                          C.c_double(max_translation_error), min_inliers, _d(T), _d(inl))
+    return (T, inl.astype(bool)) if rc == 0 else None
+
+
 def fixed_stiefel(r):
     Y = np.zeros(3 * r)
     lib().orc_fixed_stiefel(r, _d(Y))

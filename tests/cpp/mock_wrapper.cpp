@@ -52,7 +52,7 @@ int main(int argc, char **argv) {
   if (argc < 4) return 1;
   const unsigned N = (unsigned)std::atoi(argv[2]);
   const int iters = std::atoi(argv[3]);
-  const int mode = argc > 4 ? std::atoi(argv[4]) : 0;  // 0 plain, 1 accelerated, 2 asynchronous (ASAPP)
+  const int mode = argc > 4 ? std::atoi(argv[4]) : 0;  // 0 plain, 1 accelerated, 2 asynchronous (ASAPP), 3 robust cost (GNC-TLS frame alignment)
   const bool accel = mode == 1;
   size_t num_poses = 0;
   std::vector<RelativeSEMeasurement> dataset = read_g2o_file(argv[1], num_poses);
@@ -67,6 +67,11 @@ int main(int argc, char **argv) {
     params.asynchronousOptimizationRate = 100.0;  // launch/asapp_demo.launch:25-26
     params.localOptimizationParams.method = ROptParameters::ROptMethod::RGD;
     params.localOptimizationParams.RGD_stepsize = 0.05;  // simultaneous (Jacobi-like) updates on this tightly coupled pair need a smaller step
+  }
+  if (mode == 3) {  // launch/dpgo_gnc_demo.launch:35-42; frame alignment averages robustly over every shared loop closure
+    params.robustCostParams.costType = RobustCostParameters::Type::GNC_TLS;
+    params.robustOptInnerIters = 1000000;  // no weight update inside this short run
+    params.robustInitMinInliers = 2;
   }
   std::vector<std::unique_ptr<MockAgentROS>> team;
   for (unsigned k = 0; k < N; ++k) team.emplace_back(new MockAgentROS(k, params));

@@ -37,7 +37,7 @@ def test_facade_compiles_against_the_c_abi():
         assert re.search(r"\b%s\b" % name, hdr), name  # SURVEY App. A surface
 
 
-def _replicated_initial_guess(m, mp, n, N):
+def _replicated_initial_guess(m, mp, n, N, robust=False):
     """the facade's initialisation: per-robot odometry chains, robot 0 = world frame, robot k aligned
     through its first shared loop closure with an already initialised neighbour (chain order)."""
     per = n // N
@@ -59,6 +59,7 @@ def _replicated_initial_guess(m, mp, n, N):
             if k in world:
                 continue
             sh = mp[((mp["r1"] == k) | (mp["r2"] == k)) & (mp["r1"] != mp["r2"])]
+            cand = {}
             for e in sh:
                 out = e["r1"] == k
                 nb = int(e["r2"] if out else e["r1"])
@@ -67,8 +68,17 @@ def _replicated_initial_guess(m, mp, n, N):
                 Tm = np.hstack([e["R"].reshape(3, 3), e["t"].reshape(3, 1)])
                 Tn = compose(world[nb], local[nb][int(e["p2"] if out else e["p1"])])
                 Tmine = compose(Tn, inv(Tm)) if out else compose(Tn, Tm)
-                world[k] = compose(Tmine, inv(local[k][int(e["p1"] if out else e["p2"])]))
+                Tw = compose(Tmine, inv(local[k][int(e["p1"] if out else e["p2"])]))
+                if robust:  # robust cost: one candidate per shared loop closure, per neighbour, in measurement order
+                    cand.setdefault(nb, []).append(Tw.T.reshape(-1))
+                    continue
+                world[k] = Tw
                 break
+            for nb in sorted(cand):  # the facade aligns on the first neighbour message that yields a consensus
+                got = O.robust_frame_alignment(np.array(cand[nb]), 0.5, 1.0, 2)
+                if got is not None:
+                    world[k] = got[0].reshape(4, 3).T
+                    break
     for k in range(N):
         for i in range(start[k + 1] - start[k]):
             T[start[k] + i] = compose(world[k], local[k][i])
@@ -95,6 +105,28 @@ def test_mock_wrapper_follows_the_oracle(accel):
         assert abs(costs[k] - ref.cost()) <= 1e-8 * ref.cost(), k
     defect = float(re.search(r"orthogonality_defect (\S+)", out).group(1))
     assert defect < 1e-9
+
+
+@pytest.mark.gpu
+def test_mock_wrapper_robust_frame_alignment():
+    """robust cost => the facade initialises each robot's frame by GNC-TLS averaging over all shared loop closures
+    (dpgo_robust_frame_alignment); the oracle run starts from the same averaged frames"""
+    _compile()
+    N, iters = 3, 6
+    out = subprocess.check_output([BIN, os.path.join(DATA, "smallGrid3D.g2o"), str(N), str(iters), "3"], text=True)
+    init = float(re.search(r"init cost (\S+)", out).group(1))
+    costs = [float(x) for x in re.findall(r"iter \d+ robot \d+ cost (\S+)", out)]
+    m, mp, n = load("smallGrid3D", N)
+    T = _replicated_initial_guess(m, mp, n, N, robust=True)
+    T_first = _replicated_initial_guess(m, mp, n, N, robust=False)
+    assert np.abs(T - T_first).max() > 1e-3          # the averaged frames are not the single-loop-closure ones
+    ref = O.Team(mp, n, O.default_params(r=5, num_robots=N, method=O.METHOD_RTR, gradnorm_tol=1e-2, acceleration=0,
+                                         restart_interval=7, rel_change_tol=0.2, rtr_max_radius=500.0))
+    ref.set_initial(T, O.fixed_stiefel(5))
+    assert abs(init - ref.cost()) <= 1e-9 * ref.cost()
+    for k in range(iters):
+        ref.iterate()
+        assert abs(costs[k] - ref.cost()) <= 1e-8 * ref.cost(), k
 
 
 @pytest.mark.gpu
