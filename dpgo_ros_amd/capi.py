@@ -76,7 +76,7 @@ dpgo_agent_robust_weight dpgo_agent_update_measurement_weights dpgo_agent_set_me
 dpgo_agent_get_measurements dpgo_agent_should_update_weights dpgo_agent_clear_data_matrices
 dpgo_error_threshold_at_quantile dpgo_team_set_schedule dpgo_team_set_initial dpgo_team_exchange_all
 dpgo_agent_pull_local dpgo_team_time_kernel dpgo_team_run dpgo_team_get_coloring dpgo_team_run_colored dpgo_team_set_groups dpgo_team_run_group dpgo_team_step_begin dpgo_team_step_end dpgo_team_iteration dpgo_team_cost dpgo_team_update_weights dpgo_team_get_counters
-dpgo_write_measurements_csv dpgo_write_g2o dpgo_write_trajectory_csv dpgo_robust_frame_alignment""".split()
+dpgo_write_measurements_csv dpgo_write_g2o dpgo_write_trajectory_csv dpgo_robust_frame_alignment dpgo_robust_local_init""".split()
 
 
 class DpgoError(RuntimeError):
@@ -138,6 +138,14 @@ def read_csv(path, weight_mode=WEIGHT_LIBRARY):
     raw = C.string_at(out, nm * MEAS_DTYPE.itemsize)
     lib().dpgo_free(out)
     return np.frombuffer(raw, dtype=MEAS_DTYPE).copy()
+
+
+def robust_local_init(m, num_poses, params, device=0):
+    """single-robot GNC-TLS solve on the device -> (T [12 n], final weights in input order)"""
+    m = np.ascontiguousarray(m)
+    T, w = np.zeros(12 * num_poses), np.zeros(len(m))
+    _chk(lib().dpgo_robust_local_init(device, _d(m), len(m), num_poses, C.byref(params), _d(T), _d(w)), "robust_local_init")
+    return T, w
 
 
 def robust_frame_alignment(Tc, max_rotation_error_rad=0.5, max_translation_error=1.0, min_inliers=2):

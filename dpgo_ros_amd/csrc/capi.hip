@@ -450,6 +450,58 @@ int dpgo_agent_get_measurements(dpgo_team_t *t, int id, dpgo_measurement_t *out)
   return c;
 }
 
+// Robust local initialisation (InitializationMethod::GNC_TLS, src/PGOAgentROSNode.cpp:111-112): a single-robot
+// GNC-TLS pose-graph solve on the device.  Odometry is trusted (fixed weight 1) and supplies the initial guess;
+// the private loop closures are re-weighted between blocks of RTR iterations on the un-lifted problem (r = d = 3).
+int dpgo_robust_local_init(int device, const dpgo_measurement_t *m, int nm, int num_poses, const dpgo_params_t *gnc,
+                           double *T_out, double *weights_out) {
+  if (!m || nm <= 0 || num_poses <= 0 || !gnc || !T_out) { set_err("robust_local_init: bad arguments"); return DPGO_ERR; }
+  dpgo_params_t prm = *gnc;
+  prm.d = 3; prm.r = 3; prm.num_robots = 1;
+  prm.method = DPGO_METHOD_RTR;
+  prm.acceleration = 0;
+  prm.robust_cost_type = DPGO_COST_GNC_TLS;
+  std::vector<dpgo_measurement_t> loc(m, m + nm);
+  for (auto &e : loc) {
+    if (e.r1 != e.r2) { set_err("robust_local_init: single-robot measurements expected"); return DPGO_ERR; }
+    e.r1 = e.r2 = 0;
+    if (e.p1 + 1 == e.p2) { e.fixed_weight = 1; e.weight = 1.0; }
+    else if (!e.fixed_weight) e.weight = 1.0;
+  }
+  const int id = 0;
+  dpgo_team_t *t = dpgo_team_create(device, &prm, 1, &id, nullptr);
+  if (!t) return DPGO_ERR;
+  int rc = DPGO_ERR;
+  do {
+    if (dpgo_agent_add_measurements(t, id, loc.data(), nm)) break;
+    std::vector<double> T0((size_t)12 * num_poses);
+    dpgo_odometry_init(loc.data(), nm, num_poses, T0.data());
+    if (dpgo_agent_num_poses(t, id) != num_poses) { set_err("robust_local_init: pose count mismatch"); break; }
+    if (dpgo_agent_set_X(t, id, T0.data())) break;  // r = 3: the lifted iterate IS the 3 x 4n trajectory
+    bool failed = false;
+    for (int u = 0; u <= prm.robust_opt_num_weight_updates && !failed; ++u) {
+      for (int k = 0; k < prm.robust_opt_inner_iters; ++k) {
+        // a weighting that is already solved costs one gradient evaluation per call (RTR stops at its first test)
+        if (dpgo_agent_iterate(t, id, 1) < 0) { failed = true; break; }
+      }
+      if (!failed && u < prm.robust_opt_num_weight_updates && dpgo_agent_update_measurement_weights(t, id)) failed = true;
+    }
+    if (failed) break;
+    if (dpgo_agent_get_X(t, id, 0, T_out)) break;
+    if (weights_out) {
+      std::vector<dpgo_measurement_t> cur(nm);
+      if (dpgo_agent_get_measurements(t, id, cur.data()) != nm) break;
+      // stored as [odometry..., private...] in insertion order within each class
+      int io = 0, ip = 0, nodo = 0;
+      for (int k = 0; k < nm; ++k) nodo += (loc[k].p1 + 1 == loc[k].p2);
+      for (int k = 0; k < nm; ++k) weights_out[k] = (loc[k].p1 + 1 == loc[k].p2) ? cur[io++].weight : cur[nodo + ip++].weight;
+    }
+    rc = DPGO_OK;
+  } while (false);
+  dpgo_team_destroy(t);
+  return rc;
+}
+
 int dpgo_agent_should_update_weights(dpgo_team_t *t, int id) {
   Agent *a = find_agent(t, id);
   if (!a) return DPGO_ERR;

@@ -6,7 +6,7 @@
 // optimisation state lives in HBM behind the C-ABI; this class only keeps the host-side mirror the
 // wrapper touches (measurements with their mutable weights, neighbour pose dictionary, statuses).
 // Declared simplifications ("next"): local initialisation is odometry chaining or the GPU chordal
-// relaxation (InitializationMethod::GNC_TLS falls back to odometry);
+// relaxation or the GPU single-robot GNC-TLS solve (dpgo_robust_local_init);
 // the inter-robot frame alignment uses the first shared loop closure whose neighbour pose is known
 // (L2 cost) or GNC-TLS two-stage averaging over all of them (robust cost); robot 0 draws a fixed, not random, YLift.
 #pragma once
@@ -126,6 +126,13 @@ class PGOAgent {
         std::vector<dpgo_measurement_t> loc = odo;
         for (const auto &m : mPoseGraph->privateLoopClosures()) { dpgo_measurement_t c = m.toC(); c.r1 = c.r2 = 0; loc.push_back(c); }
         done = dpgo_chordal_init(0, loc.data(), (int)loc.size(), (int)n, Tl.data()) == DPGO_OK;
+      }
+      if (mParams.localInitializationMethod == InitializationMethod::GNC_TLS) {
+        // robust single-robot solve on the GPU: odometry fixed, private loop closures re-weighted by GNC-TLS
+        std::vector<dpgo_measurement_t> loc = odo;
+        for (const auto &m : mPoseGraph->privateLoopClosures()) { dpgo_measurement_t c = m.toC(); c.r1 = c.r2 = 0; loc.push_back(c); }
+        dpgo_params_t c = toC(mParams);
+        done = dpgo_robust_local_init(0, loc.data(), (int)loc.size(), (int)n, &c, Tl.data(), nullptr) == DPGO_OK;
       }
       if (!done) dpgo_odometry_init(odo.data(), (int)odo.size(), (int)n, Tl.data());
       Matrix M = Matrix::Zero(d, (d + 1) * n);

@@ -87,6 +87,13 @@ int dpgo_read_measurements_csv(const char *path, int weight_mode, dpgo_measureme
  * inlier: n flags or NULL.  Host arithmetic only. */
 int dpgo_robust_frame_alignment(const double *T_candidates, int n, double max_rotation_error_rad,
                                 double max_translation_error, int min_inliers, double *T_out, int *inlier);
+/* robust local initialisation (InitializationMethod::GNC_TLS, src/PGOAgentROSNode.cpp:111-112): single-robot
+ * GNC-TLS solve on the device with r = d = 3 -- odometry chain as the initial guess and fixed at weight 1,
+ * loop closures re-weighted robust_opt_num_weight_updates times, robust_opt_inner_iters RTR iterations
+ * per weighting (gnc_*, rtr_*, gradnorm_tol of `gnc` are used; r / num_robots / method / acceleration are
+ * overridden).  T_out: 3x4 column-major per pose; weights_out: nm final weights in input order, or NULL. */
+int dpgo_robust_local_init(int device, const dpgo_measurement_t *m, int nm, int num_poses, const dpgo_params_t *gnc,
+                           double *T_out, double *weights_out);
 /* writers (the PGOLogger::logMeasurements / logTrajectory role): the CSV of loadMeasurements
  * (data/tunnels/robot0/measurements.csv:1, weights and inlier flags included so GNC results round-trip), g2o
  * with isotropic information blocks (global index = robot_offsets[robot] + frame; NULL = single robot; T =

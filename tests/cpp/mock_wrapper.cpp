@@ -52,7 +52,8 @@ int main(int argc, char **argv) {
   if (argc < 4) return 1;
   const unsigned N = (unsigned)std::atoi(argv[2]);
   const int iters = std::atoi(argv[3]);
-  const int mode = argc > 4 ? std::atoi(argv[4]) : 0;  // 0 plain, 1 accelerated, 2 asynchronous (ASAPP), 3 robust cost (GNC-TLS frame alignment)
+  const int mode = argc > 4 ? std::atoi(argv[4]) : 0;  // 0 plain, 1 accelerated, 2 asynchronous (ASAPP), 3 robust cost (GNC-TLS frame alignment),
+                                                       // 4 local_initialization_method = GNC_TLS
   const bool accel = mode == 1;
   size_t num_poses = 0;
   std::vector<RelativeSEMeasurement> dataset = read_g2o_file(argv[1], num_poses);
@@ -72,6 +73,12 @@ int main(int argc, char **argv) {
     params.robustCostParams.costType = RobustCostParameters::Type::GNC_TLS;
     params.robustOptInnerIters = 1000000;  // no weight update inside this short run
     params.robustInitMinInliers = 2;
+  }
+  if (mode == 4) {  // src/PGOAgentROSNode.cpp:111-112
+    params.localInitializationMethod = InitializationMethod::GNC_TLS;
+    params.robustCostParams.GNCBarc = 5.0;
+    params.robustOptNumWeightUpdates = 4;
+    params.robustOptInnerIters = 5;
   }
   std::vector<std::unique_ptr<MockAgentROS>> team;
   for (unsigned k = 0; k < N; ++k) team.emplace_back(new MockAgentROS(k, params));

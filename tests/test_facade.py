@@ -130,6 +130,20 @@ def test_mock_wrapper_robust_frame_alignment():
 
 
 @pytest.mark.gpu
+def test_mock_wrapper_gnc_tls_local_initialization():
+    """local_initialization_method = GNC_TLS: each robot's local trajectory comes from the GPU single-robot robust
+    solve (odometry + private loop closures) instead of the odometry chain, so the team starts lower and descends"""
+    _compile()
+    args = [BIN, os.path.join(DATA, "smallGrid3D.g2o"), "2", "4"]
+    base = float(re.search(r"init cost (\S+)", subprocess.check_output(args + ["0"], text=True)).group(1))
+    out = subprocess.check_output(args + ["4"], text=True)
+    init = float(re.search(r"init cost (\S+)", out).group(1))
+    costs = [float(x) for x in re.findall(r"iter \d+ robot \d+ cost (\S+)", out)]
+    assert init < 0.5 * base
+    assert len(costs) == 4 and all(b <= a * (1 + 1e-12) for a, b in zip([init] + costs, costs))
+
+
+@pytest.mark.gpu
 def test_mock_wrapper_asynchronous_mode():
     """ASAPP mode of the facade: library-owned optimisation threads (RGD, stepsize 0.2) race the polling
     thread that relays public poses; nondeterministic by construction, so only progress is asserted."""

@@ -497,3 +497,54 @@ def test_chordal_initialisation(dataset):
     if dataset == "sphere2500":
         c = 2 * O.measurement_cost(m, O.lift(Th, n, O.fixed_stiefel(5), 5), 5)
         assert abs(c - 1971.175) < 0.01  # SE-Sync's chordal-initialisation cost for sphere2500
+
+
+def _oracle_robust_local_init(mo, n, kw):
+    loc = mo.copy()
+    odo = loc["p1"] + 1 == loc["p2"]
+    loc["fixed_weight"][odo] = 1
+    ag = O.Agent(0, O.default_params(r=3, num_robots=1, acceleration=0, **kw))
+    ag.add_measurements(loc)
+    ag.set_X(O.odometry_init(loc, n))
+    for u in range(kw["robust_opt_num_weight_updates"] + 1):
+        for _ in range(kw["robust_opt_inner_iters"]):
+            ag.iterate(True)
+        if u < kw["robust_opt_num_weight_updates"]:
+            ag.update_measurement_weights()
+    mw = ag.measurements()  # [odometry..., private...]
+    w = np.zeros(len(mo))
+    w[odo], w[~odo] = mw["weight"][:odo.sum()], mw["weight"][odo.sum():]
+    return ag.get_X(), w, ag
+
+
+def test_robust_local_initialization():
+    """f-1: InitializationMethod::GNC_TLS -- single-robot GNC-TLS solve on the device (r = d = 3, odometry fixed)
+    against the same sequence driven through the oracle's agent."""
+    from tests.util import add_outliers
+    m, _, n = load("smallGrid3D", 1)
+    mo = add_outliers(m, n, frac=0.1, seed=3)
+    nout = len(mo) - len(m)
+    kw = dict(method=capi.METHOD_RTR, gradnorm_tol=1e-3, robust_cost_type=capi.COST_GNC_TLS, gnc_barc=3.0,
+              gnc_mu_step=2.0, gnc_init_mu=1e-3, robust_opt_num_weight_updates=2, robust_opt_inner_iters=3,
+              rtr_max_radius=500.0)
+    # (A) iterate parity over two re-weightings (9 RTR iterations, tCG counts equal): 1e-7.  Longer schedules hit
+    # borderline tCG terminations (one extra inner iteration out of ~60 in one run) after which the two
+    # trajectories differ at the 1e-3 level while solving the same weighting -- compared in (B).
+    T, w = capi.robust_local_init(mo, n, capi.default_params(r=5, num_robots=4, acceleration=1, **kw))
+    To, wo, _ = _oracle_robust_local_init(mo, n, kw)
+    assert np.abs(w - wo).max() < 1e-7 and ((wo > 0) & (wo < 1)).any()
+    assert np.abs(T - To).max() < 1e-7
+    # (B) the full schedule: planted outliers end at weight 0, everything else at 1; trajectories agree to the
+    # solve tolerance, costs under the final weights tightly.
+    kw.update(robust_opt_num_weight_updates=12, robust_opt_inner_iters=8, gnc_barc=5.0)  # chi(6 dof): P(res > 5) ~ 2e-4
+    T, w = capi.robust_local_init(mo, n, capi.default_params(r=3, num_robots=1, **kw))
+    To, wo, ag = _oracle_robust_local_init(mo, n, kw)
+    assert np.abs(w - wo).max() < 1e-6
+    genuine = w[:len(m)]
+    assert (w[-nout:] < 1e-3).all() and (genuine > 0.99).mean() > 0.97 and (genuine[m["p1"] + 1 == m["p2"]] == 1).all()
+    assert np.abs(T - To).max() < 5e-3
+    fh, fo = ag.eval(T)[0], ag.eval(To)[0]
+    assert abs(fh - fo) <= 1e-6 * abs(fo)
+    R = T.reshape(n, 4, 3)[:, :3, :]
+    assert np.abs(np.einsum("nij,nkj->nik", R, R) - np.eye(3)).max() < 1e-12
+    assert (np.linalg.det(R) > 0).all()
