@@ -280,6 +280,10 @@ int sync_descs(dpgo_team *t) {
   td.num_agents = (int)t->ag.size(); td.sched_len = (int)t->sched.size(); td.iter = t->iter;
   td.restart_interval = t->prm.restart_interval; td.sched = t->d_sched.p;
   td.group_ptr = t->d_group_ptr.p; td.group_members = t->d_group_members.p;
+  for (int k = 0, acc = 0; k <= LOOKAHEAD_MAX_AGENTS; ++k) {
+    td.pose_prefix[k] = acc;
+    if (k < (int)t->ag.size()) acc += t->ag[k]->n;
+  }
   HIPC(hipMemcpyAsync(t->d_team.p, &td, sizeof td, hipMemcpyHostToDevice, t->stream));
   HIPC(hipStreamSynchronize(t->stream));
   t->descs_dirty = false;

@@ -55,7 +55,7 @@ void dpgo_team_destroy(dpgo_team_t *t) {
   if (!t) return;
   (void)hipSetDevice(t->device);
   (void)hipStreamSynchronize(t->stream);
-  for (auto &g : t->graph) if (g) (void)hipGraphExecDestroy(g);
+  for (auto &kv : t->graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);
   t->ag.clear();
   if (t->h_state) (void)hipHostFree(t->h_state);
   if (t->h_states) (void)hipHostFree(t->h_states);
@@ -233,14 +233,15 @@ int dpgo_agent_get_status(dpgo_team_t *t, int id, dpgo_status_t *s) {
   s->relative_change = 0; s->ready_to_terminate = 0;
   if (!a->has_X || a->iter == 0 || a->rel_src == 2) { s->ready_to_terminate = a->has_X && a->iter > 0 && a->last_success; return DPGO_OK; }
   // |X - XPrev|^2 partials were left by the last kernel that moved X (fixed summation order)
-  const int cnt = a->rel_src ? (4 * a->n + 7) / 8 : (a->n + 63) / 64;
-  const int off = a->rel_src ? PART_B + 2 : PART_D;
-  std::vector<double> part((size_t)cnt * PART_STRIDE);
-  HIPC(hipMemcpyAsync(part.data(), a->dev.part + off, sizeof(double) * ((size_t)(cnt - 1) * PART_STRIDE + 1),
+  const int cnt = a->rel_src == 4 ? a->n : (a->rel_src ? (4 * a->n + 7) / 8 : (a->n + 63) / 64);
+  const int stride = a->rel_src == 4 ? 1 : PART_STRIDE;
+  const int off = a->rel_src == 1 ? PART_B + 2 : PART_D;
+  std::vector<double> part((size_t)cnt * stride);
+  HIPC(hipMemcpyAsync(part.data(), a->dev.part + off, sizeof(double) * ((size_t)(cnt - 1) * stride + 1),
                       hipMemcpyDeviceToHost, t->stream));
   HIPC(hipStreamSynchronize(t->stream));
   double sum = 0;
-  for (int k = 0; k < cnt; ++k) sum += part[(size_t)k * PART_STRIDE];
+  for (int k = 0; k < cnt; ++k) sum += part[(size_t)k * stride];
   s->relative_change = std::sqrt(sum / a->n);
   s->ready_to_terminate = a->last_success && (s->relative_change <= t->prm.rel_change_tol);
   return DPGO_OK;
@@ -594,37 +595,73 @@ int dpgo_team_run(dpgo_team_t *t, int iters) {
   for (auto &a : t->ag) if (!a->has_X) { set_err("team_run before set_initial"); return DPGO_NOT_READY; }
   const bool graphable = (p.method == DPGO_METHOD_RGD) && p.rgd_use_preconditioner;
   if (graphable && !t->graph_valid) {
-    // the schedule, the counters and the Nesterov scalars live on the device, so every iteration is
-    // the same launch sequence: capture it 1/2/4/8/16 times to amortise the graph-launch gap
-    for (int gi = 0; gi < dpgo_team::NGRAPH; ++gi) {
-      hipGraph_t g = nullptr;
-      HIPC(hipStreamBeginCapture(t->stream, hipStreamCaptureModeThreadLocal));
-      int rc = 0;
-      if (p.acceleration) {
-        // 3 launches per iteration: [statistics of iteration k-1 + Nesterov step of iteration k] in one
-        // heterogeneous kernel, cost/gradient (+ G from the neighbours' Y), preconditioner + RGD step +
-        // Nesterov V + bookkeeping.  The first iteration has no statistics to close, the last one is closed
-        // by a plain evaluation.
-        LaunchCtx c = t->ctx();
-        const int na = (int)t->ag.size(), mn = t->max_n;
-        for (int rep = 0; rep < (1 << gi); ++rep) {
-          if (rep == 0) launch_nest_pre(c, -1, -1, na, mn, p.num_robots, p.restart_interval);
-          else launch_stats_nest(c, na, mn, p.num_robots, p.restart_interval);
-          launch_eval(c, -1, mn, B_X, B_EGRAD, B_GF, PART_C, eval_opts(t, 2, 1, 0));
-          launch_precond(c, -1, mn, PM_RGD_, B_X, B_GF, B_Z, 0, 0, p.rgd_stepsize, 1, p.num_robots, 1, p.restart_interval);
-        }
-        launch_eval(c, -5, mn, B_X2, B_EGRAD2, B_GF2, PART_A, eval_opts(t, 0, 0, 0));
-      } else {
-        for (int rep = 0; rep < (1 << gi) && !rc; ++rep) rc = enqueue_team_iteration(t, true, false, -1, 0);
-      }
-      HIPC(hipStreamEndCapture(t->stream, &g));
-      if (rc) { (void)hipGraphDestroy(g); return rc; }
-      if (t->graph[gi]) { (void)hipGraphExecDestroy(t->graph[gi]); t->graph[gi] = nullptr; }
-      HIPC(hipGraphInstantiate(&t->graph[gi], g, nullptr, nullptr, 0));
-      (void)hipGraphDestroy(g);
-    }
+    for (auto &kv : t->graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);
+    t->graphs.clear();
+    t->graph_flip.clear();
     t->graph_valid = true;
   }
+  // look-ahead Nesterov steps need every workgroup's share of the other agents' poses to fit one wave, and one
+  // double per pose in the PART_D region
+  bool pipelined = p.acceleration != 0 && (int)t->ag.size() <= LOOKAHEAD_MAX_AGENTS;
+  {
+    int total = 0;
+    for (auto &a : t->ag) total += a->n;
+    for (auto &a : t->ag) {
+      const int nblk = (4 * a->n + 7) / 8;
+      if ((total - a->n + nblk - 1) / nblk > 64 || a->n > MAX_PART * PART_STRIDE) pipelined = false;
+    }
+  }
+  // the schedule, the counters and the Nesterov scalars live on the device, so a run of B iterations is one
+  // fixed launch sequence: captured once per B and replayed
+  // lead: the window opens with a restart iteration (un-fused kernels, same launch sequence every time); B: fused
+  // iterations that follow.  Two instances per key alternate, so that a launch never has to wait for the previous
+  // replay of the same executable graph.
+  auto graph_for = [&](bool lead, int B, hipGraphExec_t *out) -> int {
+    const int base = ((lead ? 1 : 0) + 2 * B) * 2;
+    const int key = base + (t->graph_flip[base / 2] ^= 1);
+    auto it = t->graphs.find(key);
+    if (it != t->graphs.end()) { *out = it->second; return 0; }
+    hipGraph_t g = nullptr;
+    HIPC(hipStreamBeginCapture(t->stream, hipStreamCaptureModeThreadLocal));
+    int rc = 0;
+    if (lead) rc = enqueue_team_iteration(t, true, true, -1, 0);
+    if (rc == 0 && B > 0 && p.acceleration && pipelined) {
+      // pipelined: 2 launches per iteration (see k_eval_stats).  The Nesterov step of the first iteration is a
+      // launch of its own, the last iteration does not look ahead, and its statistics / bookkeeping close the run.
+      LaunchCtx c = t->ctx();
+      const int na = (int)t->ag.size(), mn = t->max_n;
+      launch_nest_pre(c, -1, -1, na, mn, p.num_robots, p.restart_interval);
+      for (int rep = 0; rep < B; ++rep) {
+        launch_eval_stats(c, mn, rep == 0, 1, rep > 0, p.num_robots, p.restart_interval);
+        launch_precond(c, -1, mn, PM_RGD_, B_X, B_GF, B_Z, 0, 0, p.rgd_stepsize, 1, p.num_robots, 2, p.restart_interval,
+                       rep + 1 < B ? 3 : 0);
+      }
+      launch_eval_stats(c, mn, 0, 0, 1, p.num_robots, p.restart_interval);
+    } else if (rc == 0 && B > 0 && p.acceleration) {
+      // 3 launches per iteration: [statistics of iteration k-1 + Nesterov step of iteration k] in one
+      // heterogeneous kernel, cost/gradient (+ G from the neighbours' Y), preconditioner + RGD step +
+      // Nesterov V + bookkeeping
+      LaunchCtx c = t->ctx();
+      const int na = (int)t->ag.size(), mn = t->max_n;
+      for (int rep = 0; rep < B; ++rep) {
+        if (rep == 0) launch_nest_pre(c, -1, -1, na, mn, p.num_robots, p.restart_interval);
+        else launch_stats_nest(c, na, mn, p.num_robots, p.restart_interval);
+        launch_eval(c, -1, mn, B_X, B_EGRAD, B_GF, PART_C, eval_opts(t, 2, 1, 0));
+        launch_precond(c, -1, mn, PM_RGD_, B_X, B_GF, B_Z, 0, 0, p.rgd_stepsize, 1, p.num_robots, 1, p.restart_interval);
+      }
+      launch_eval(c, -5, mn, B_X2, B_EGRAD2, B_GF2, PART_A, eval_opts(t, 0, 0, 0));
+    } else if (rc == 0) {
+      for (int rep = 0; rep < B && !rc; ++rep) rc = enqueue_team_iteration(t, true, false, -1, 0);
+    }
+    HIPC(hipStreamEndCapture(t->stream, &g));
+    if (rc) { (void)hipGraphDestroy(g); return rc; }
+    hipGraphExec_t ge = nullptr;
+    HIPC(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(g);
+    t->graphs[key] = ge;
+    *out = ge;
+    return 0;
+  };
   auto account = [&](int sel) {
     const int n = t->ag[sel]->n, N4 = 4 * n;
     t->counters[0] += 1; t->counters[1] += 8.0 * N4 * (double)N4;
@@ -634,30 +671,37 @@ int dpgo_team_run(dpgo_team_t *t, int iters) {
   while (k < iters) {
     const bool restart = p.acceleration && ((t->iter + 2) % p.restart_interval) == 0;
     int batch = 1;
-    if (graphable && !restart) {
-      // iterations until the next restart iteration (which runs un-captured)
-      int until = iters - k;
+    if (graphable) {
+      // one graph per window: [the restart iteration, if the window opens with one] + the fused iterations up to
+      // the next restart iteration
+      int fusedn = iters - k - (restart ? 1 : 0);
       if (p.acceleration) {
-        const int to_restart = (p.restart_interval - ((t->iter + 2) % p.restart_interval)) % p.restart_interval;
-        until = std::min(until, to_restart == 0 ? 1 : to_restart);
+        const int it0 = t->iter + (restart ? 1 : 0);
+        const int to_restart = (p.restart_interval - ((it0 + 2) % p.restart_interval)) % p.restart_interval;
+        fusedn = std::min(fusedn, to_restart);
       }
-      int gi = 0;
-      while (gi + 1 < dpgo_team::NGRAPH && (2 << gi) <= until) ++gi;
-      batch = 1 << gi;
-      HIPC(hipGraphLaunch(t->graph[gi], t->stream));
-      for (auto &a : t->ag) a->rel_src = p.acceleration ? 0 : 2;
+      fusedn = std::max(0, std::min(fusedn, dpgo_team::MAX_GRAPH_ITERS));
+      batch = fusedn + (restart ? 1 : 0);
+      hipGraphExec_t ge = nullptr;
+      const int grc = graph_for(restart, fusedn, &ge);
+      if (grc) return grc;
+      HIPC(hipGraphLaunch(ge, t->stream));
+      // after >= 2 pipelined iterations every agent took its last Nesterov step as a look-ahead (per-pose partials)
+      for (auto &a : t->ag) a->rel_src = p.acceleration ? ((pipelined && fusedn >= 2) ? 4 : 0) : 2;
       for (int q = 0; q < batch; ++q) {
         const int sel = t->sched[(t->iter + q) % t->sched.size()];
         account(sel);
-        if (q == batch - 1) { t->ag[sel]->opt_pending_rgd = true; t->ag[sel]->rel_src = 1; }
+        if (restart && q == 0) account(sel);  // the restart iteration solves twice (from Y, then from XPrev)
+        if (q == batch - 1) {
+          t->ag[sel]->opt_pending_rgd = true;
+          t->ag[sel]->rel_src = (fusedn > 0) ? 1 : 0;  // a lone restart iteration ends with k_status (PART_D tiles)
+        }
       }
     } else {
       const int sel = t->sched[t->iter % t->sched.size()];
       for (auto &a : t->ag) a->rel_src = p.acceleration ? 0 : 2;
       const int rc = enqueue_team_iteration(t, false, restart, sel, 0);
       if (rc) return rc;
-      const bool fused = p.method == DPGO_METHOD_RGD && p.rgd_use_preconditioner && !restart;
-      if (fused) t->ag[sel]->rel_src = 1;
     }
     t->iter += batch;
     for (auto &a : t->ag) { a->iter += batch; if (p.robust_cost_type != DPGO_COST_L2) a->robust_inner_iter += batch; }

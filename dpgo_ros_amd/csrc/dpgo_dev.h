@@ -79,10 +79,13 @@ constexpr int PART_STRIDE = 8;   // doubles per block of partials
 constexpr int MAX_PART = 4096;   // max blocks contributing partials
 // regions of AgentDev::part (each MAX_PART * PART_STRIDE doubles)
 constexpr int PART_A = 0;                             // SpMM-type kernels (eval / Hess-vec)
-constexpr int PART_B = MAX_PART * PART_STRIDE;        // preconditioner-type kernels
+constexpr int PART_B = MAX_PART * PART_STRIDE;        // preconditioner-type kernels ([2] |X - XPrev|^2 of the fused RGD step)
 constexpr int PART_C = 2 * MAX_PART * PART_STRIDE;    // outer-step / initial evaluation
-constexpr int PART_D = 3 * MAX_PART * PART_STRIDE;    // per-pose kernels: |X - XPrev|^2 partials
+constexpr int PART_D = 3 * MAX_PART * PART_STRIDE;    // per-pose kernels: |X - XPrev|^2 partials (per 64-pose tile; one double per
+                                                      // pose after a look-ahead Nesterov step)
 constexpr int PART_TOTAL = 4 * MAX_PART * PART_STRIDE;
+
+constexpr int LOOKAHEAD_MAX_AGENTS = 8;  // look-ahead Nesterov steps locate a pose's agent with one 9-int fetch
 
 struct TeamDev {
   int num_agents;
@@ -91,6 +94,10 @@ struct TeamDev {
   int restart_interval;
   int cur_sel;       // agent selected in the running iteration (published by the first kernel)
   int stats_sel;     // agent of the iteration that just finished: its final statistics are evaluated by k_stats_nest
+  int next_sel;      // pipelined RGD iterations: agent of iteration k+1, published by the step kernel of iteration k
+  int pad0;
+  int pose_prefix[LOOKAHEAD_MAX_AGENTS + 1];  // exclusive prefix sums of the agents' pose counts (teams of <= 8 agents)
+  int pad1;
   const int *sched;  // [sched_len] local agent index selected at iteration k % sched_len
   const int *group_ptr;      // colour classes of the agent graph (CSR): agents of one class share no edge,
   const int *group_members;  // so they may take their block update in the same launches (blockIdx.y)

@@ -32,6 +32,7 @@ __device__ __forceinline__ int sel_sched(const TeamDev *team, int sel) {
 __device__ __forceinline__ int sel_cur(const TeamDev *team, int sel) {
   if (sel >= 0) return sel;
   if (sel == -5) return team->stats_sel;
+  if (sel == -6) return team->next_sel;
   if (sel > SEL_GROUP0) return team->cur_sel;
   return team->group_members[team->group_ptr[SEL_GROUP0 - sel] + blockIdx.y];  // colour-parallel update
 }
@@ -320,6 +321,122 @@ __global__ __launch_bounds__(64) void k_hess(const AgentDev *agents, const TeamD
 }
 
 // ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+// per-pose kernels: one lane per pose with the whole pose in registers.  A 64-pose tile (64 * 4R
+// contiguous doubles) moves between HBM and registers through LDS so that every global access is a
+// fully coalesced 512-byte wave transaction instead of 64 strided 8-byte ones.
+template <int R>
+struct Tile {
+  static constexpr int P = 4 * R + 1;  // odd pitch: conflict-free row access
+  double d[64 * P];
+};
+// 64 lanes x 4R elements = exactly one tile: fixed trip count, every load issued before the first
+// LDS store (a runtime-bounded loop makes the compiler wait for each load in turn)
+template <int R>
+__device__ __forceinline__ void tile_in(Tile<R> &t, const double *g, int j0, int cnt, int tid) {
+  const double *src = g + (size_t)j0 * 4 * R;
+  const int total = cnt * 4 * R;
+  double tmp[4 * R];
+#pragma unroll
+  for (int k = 0; k < 4 * R; ++k) {
+    const int e = tid + 64 * k;
+    tmp[k] = (e < total) ? src[e] : 0.0;
+  }
+#pragma unroll
+  for (int k = 0; k < 4 * R; ++k) {
+    const int e = tid + 64 * k;
+    t.d[(e / (4 * R)) * Tile<R>::P + e % (4 * R)] = tmp[k];
+  }
+}
+template <int R>
+__device__ __forceinline__ void tile_out(const Tile<R> &t, double *g, int j0, int cnt, int tid) {
+  double *dst = g + (size_t)j0 * 4 * R;
+  const int total = cnt * 4 * R;
+#pragma unroll
+  for (int k = 0; k < 4 * R; ++k) {
+    const int e = tid + 64 * k;
+    if (e < total) dst[e] = t.d[(e / (4 * R)) * Tile<R>::P + e % (4 * R)];
+  }
+}
+template <int R>
+__device__ __forceinline__ void tile_get(const Tile<R> &t, int row, double *v) {
+#pragma unroll
+  for (int i = 0; i < 4 * R; ++i) v[i] = t.d[row * Tile<R>::P + i];
+}
+template <int R>
+__device__ __forceinline__ void tile_put(Tile<R> &t, int row, const double *v) {
+#pragma unroll
+  for (int i = 0; i < 4 * R; ++i) t.d[row * Tile<R>::P + i] = v[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Nesterov sequences (a6).  blockIdx.y = local agent.  For every agent:
+//   XPrev = X;  gamma' = (1 + sqrt(1 + 4 N^2 gamma^2)) / 2N;  alpha = 1 / (gamma' N)
+//   Y = proj((1 - alpha) X + alpha V);  X = Y
+// and for the agents that do NOT optimize this iteration (everything but `sel`, or all when
+// sel == -2):  V = proj(V)  [= proj(V + gamma (X - Y))], then the periodic restart X = XPrev,
+// V = Y = X; partial [0] of PART_D = |X_new - XPrev|^2.  First kernel of an accelerated iteration:
+// publishes team->cur_sel.
+template <int R>
+__device__ __forceinline__ void nest_pre_body(const AgentDev *agents, TeamDev *team, int sel, int only_agent,
+                                              int num_robots, int restart_interval, int bx, int by, Tile<R> &TX,
+                                              Tile<R> &TV) {
+  const int ai = only_agent >= 0 ? only_agent : by;
+  const AgentDev &ag = agents[ai];
+  const int selected = (sel == -2) ? -1 : sel_sched(team, sel);
+  if (bx == 0 && by == 0 && threadIdx.x == 0 && sel == -1) team->cur_sel = selected;
+  const int j0 = bx * 64, tid = threadIdx.x;
+  if (j0 >= ag.n) return;
+  const int cnt = min(64, ag.n - j0);
+  const bool optimizing = (ai == selected);
+  const NestState ns = *ag.nest;
+  const double Nr = (double)num_robots;
+  const double gamma = (1.0 + sqrt(1.0 + 4.0 * Nr * Nr * ns.gamma * ns.gamma)) / (2.0 * Nr);
+  const double alpha = 1.0 / (gamma * Nr);
+  const bool restart = ((ns.iter + 2) % restart_interval) == 0;  // iter is pre-increment: (iter+1)+1
+  if (bx == 0 && tid == 0) ag.scal[6] = gamma;  // read by the fused RGD tail instead of the (mutable) NestState
+  tile_in<R>(TX, ag.buf[B_X], j0, cnt, tid);
+  tile_in<R>(TV, ag.buf[B_V], j0, cnt, tid);
+  __syncthreads();
+  tile_out<R>(TX, ag.buf[B_XPREV], j0, cnt, tid);
+  double x[4 * R], v[4 * R], y[4 * R];
+  double rel = 0;
+  if (tid < cnt) {
+    tile_get<R>(TX, tid, x);
+    tile_get<R>(TV, tid, v);
+#pragma unroll
+    for (int i = 0; i < 4 * R; ++i) y[i] = (1.0 - alpha) * x[i] + alpha * v[i];
+    polar_inplace<R>(y);
+    if (!optimizing && !restart) {
+      polar_inplace<R>(v);
+#pragma unroll
+      for (int i = 0; i < 4 * R; ++i) { const double d = y[i] - x[i]; rel += d * d; }
+    }
+  }
+  __syncthreads();
+  if (tid < cnt) {
+    if (optimizing || !restart) { tile_put<R>(TX, tid, y); tile_put<R>(TV, tid, v); }
+    // restart of a non-optimizing agent: X = XPrev (tile still holds x); V = Y = X
+  }
+  __syncthreads();
+  if (optimizing) {
+    tile_out<R>(TX, ag.buf[B_Y], j0, cnt, tid);
+    tile_out<R>(TX, ag.buf[B_X], j0, cnt, tid);  // the local solve starts from Y, in place on X
+  } else if (restart) {
+    tile_out<R>(TX, ag.buf[B_Y], j0, cnt, tid);
+    tile_out<R>(TX, ag.buf[B_V], j0, cnt, tid);
+  } else {
+    tile_out<R>(TX, ag.buf[B_Y], j0, cnt, tid);
+    tile_out<R>(TX, ag.buf[B_X], j0, cnt, tid);
+    tile_out<R>(TV, ag.buf[B_V], j0, cnt, tid);
+  }
+  if (!optimizing) {
+    rel = wave_sum(rel);
+    if (tid == 0) ag.part[PART_D + (size_t)bx * PART_STRIDE] = rel;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Dense preconditioner apply  z = P_X( v (Q + shift I)^-1 )  (a3 PreConditioner).
 // Workgroup = 256 threads = 8 scalar columns (2 poses) x 32 k-lanes.  M (the only large operand,
 // N4^2 doubles, streamed exactly once, non-temporal so it does not evict the small operands from
@@ -330,6 +447,10 @@ __global__ __launch_bounds__(64) void k_hess(const AgentDev *agents, const TeamD
 //   PM_TCG_STEP stages Hd only: r += alpha Hd, eta += alpha d, z += alpha P(Hd M)   (tCG body, part 2)
 //   PM_RGD      v = gf; X <- Retr_X(-step z); [V <- proj(V + gamma (X - Y))]; partial [2] |X - XPrev|^2
 //               (the whole RGD step + Nesterov V update of the two poses this workgroup owns)
+//               ahead (pipelined iterations, see k_eval_stats): bit 0 = the first wave also takes the Nesterov step of
+//               iteration k+1 of its two poses, bit 1 = the second wave takes it for the workgroup's share of the
+//               other agents' poses; advance: 1 = end-of-iteration bookkeeping here, 2 = pipelined (publishes
+//               stats_sel / next_sel only)
 // KC = rows of M (scalars of the input vector) handled per chunk: KC * R * 8 bytes of LDS and KC / 64
 // 16-byte registers per lane.  One 2048-row chunk covers a 500-pose agent in a single round trip with one
 // workgroup per CU; larger agents use 1024-row chunks so that 3 workgroups fit a CU and one workgroup's
@@ -338,9 +459,15 @@ __global__ __launch_bounds__(64) void k_hess(const AgentDev *agents, const TeamD
 template <int R, int MODE, int KC>
 __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev *team, int sel, int xb, int vb,
                                                  int zb, int sp, int max_inner, double step, int accel,
-                                                 int num_robots, int advance, int restart_interval) {
+                                                 int num_robots, int advance, int restart_interval, int ahead) {
   const AgentDev &ag = agents[sel_cur(team, sel)];
-  if (MODE == PM_RGD_ && advance && blockIdx.x == 0 && threadIdx.x == 0) {
+  if (MODE == PM_RGD_ && advance == 2 && blockIdx.x == 0 && threadIdx.x == 0) {
+    // pipelined iterations: nothing that a workgroup of THIS launch reads is written here (cur_sel, iter and the
+    // NestStates move in the next k_eval_stats); the next launch finds its statistics agent and its own agent
+    team->stats_sel = team->cur_sel;
+    team->next_sel = team->sched[(team->iter + 1) % team->sched_len];
+  }
+  if (MODE == PM_RGD_ && advance == 1 && blockIdx.x == 0 && threadIdx.x == 0) {
     // end-of-iteration bookkeeping of the whole team, folded here: no workgroup of this kernel reads
     // team->iter (they use cur_sel) or a NestState (gamma' comes from scal[6]), and the next kernel that
     // does (k_nest_pre of the following iteration) is ordered behind this launch
@@ -438,8 +565,32 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
       pre_p = ag.buf[B_XPREV][(size_t)col0 * R + tid];
     }
   }
-  if (MODE == PM_RGD_ && accel) nest_gamma = ag.scal[6];
-
+  double ahead_alpha = 0;
+  bool ahead_opt = false;
+  if (MODE == PM_RGD_ && accel) {
+    if (advance == 2) {
+      // the NestState describes iteration k-1 (it is advanced by the next k_eval_stats): gamma of this iteration,
+      // and gamma / alpha / selected agent of iteration k+1 for the look-ahead Nesterov step of the epilogue
+      const NestState ns = *ag.nest;
+      const double Nr = (double)num_robots;
+      nest_gamma = (1.0 + sqrt(1.0 + 4.0 * Nr * Nr * ns.gamma * ns.gamma)) / (2.0 * Nr);
+      const double g2 = (1.0 + sqrt(1.0 + 4.0 * Nr * Nr * nest_gamma * nest_gamma)) / (2.0 * Nr);
+      ahead_alpha = 1.0 / (g2 * Nr);
+      ahead_opt = team->sched[(team->iter + 1) % team->sched_len] == sel_cur(team, sel);
+    } else {
+      nest_gamma = ag.scal[6];
+    }
+  }
+  // Look-ahead, other agents (pipelined iterations): while the first wave finishes the step of this workgroup's
+  // two poses, the second wave takes the Nesterov step of iteration k+1 (what k_nest_pre would do next) for this
+  // workgroup's share of the poses of every OTHER agent -- one lane per pose, straight from / to global memory:
+  // XPrev = X; Y = proj((1 - alpha') X + alpha' V); X = Y; and for the agents that do not optimize at k+1:
+  // V = proj(V), |Y - X|^2 per pose into PART_D.  Disjoint data: this launch reads nothing else of those agents.
+  // The operands are requested next to the vector stage so that they arrive under the stream.  (The NestStates of
+  // all agents advance in lockstep, so alpha' is the one computed above.)
+  bool la_act = false, la_opt = false;
+  int la_agent = 0, la_pose = 0;
+  double la_x[4 * R], la_v[4 * R];
   const int cg = tid >> 5, kl = tid & 31;
   const int col = col0 + cg;
   const bool cact = col < N4;
@@ -478,6 +629,42 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
       const int k = 2 * kl + 64 * m;
       mreg[m] = (cact && k < kn) ? ld2_nt(Mc + k0 + k) : make_double2(0.0, 0.0);
     }
+    if (k0 == 0 && MODE == PM_RGD_ && (ahead & 2)) {
+      // look-ahead operands of the second wave, requested right behind the M slab: they arrive under the stream.
+      // Every address comes from wave-uniform (scalar) loads -- a per-lane fetch of agents[a].buf would queue
+      // behind the vector stream and stall the wave.
+      const int self = sel_cur(team, sel);
+      int pre[LOOKAHEAD_MAX_AGENTS + 1];
+      const double *px[LOOKAHEAD_MAX_AGENTS], *pv[LOOKAHEAD_MAX_AGENTS];
+#pragma unroll
+      for (int k = 0; k <= LOOKAHEAD_MAX_AGENTS; ++k) pre[k] = team->pose_prefix[k];
+      const int na = team->num_agents;
+#pragma unroll
+      for (int k = 0; k < LOOKAHEAD_MAX_AGENTS; ++k) {
+        px[k] = (k < na) ? agents[k].buf[B_X] : nullptr;
+        pv[k] = (k < na) ? agents[k].buf[B_V] : nullptr;
+      }
+      const int total = pre[LOOKAHEAD_MAX_AGENTS] - ag.n;
+      const int per = (total + nblk - 1) / nblk;  // <= 64, checked by the host
+      const int l1 = tid - 64;
+      const int q = (int)blockIdx.x * per + l1;   // index among the poses of the other agents
+      if (l1 >= 0 && l1 < per && q < total) {
+        int self_lo = 0;
+#pragma unroll
+        for (int k = 0; k < LOOKAHEAD_MAX_AGENTS; ++k) if (k == self) self_lo = pre[k];
+        const int g = q < self_lo ? q : q + ag.n;  // index among all poses of the team
+        int a = 0, lo = 0;
+        const double *xa = px[0], *va = pv[0];
+#pragma unroll
+        for (int k = 1; k < LOOKAHEAD_MAX_AGENTS; ++k)
+          if (k < na && g >= pre[k]) { a = k; lo = pre[k]; xa = px[k]; va = pv[k]; }
+        la_act = true; la_agent = a; la_pose = g - lo;
+        la_opt = team->sched[(team->iter + 1) % team->sched_len] == a;
+        const size_t o = (size_t)la_pose * 4 * R;
+#pragma unroll
+        for (int i = 0; i < 4 * R; ++i) { la_x[i] = xa[o + i]; la_v[i] = va[o + i]; }
+      }
+    }
 #pragma unroll
     for (int m = 0; m < MREG; ++m) {
       const int k = 2 * kl + 64 * m;
@@ -506,6 +693,32 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
   }
   __syncthreads();
 
+  if (MODE == PM_RGD_ && (ahead & 2) && tid >= 64 && tid < 128) {
+    // look-ahead of the other agents' poses on the second wave (operands prefetched in the prologue)
+    if (la_act) {
+      const AgentDev &oa = agents[la_agent];
+      const size_t o = (size_t)la_pose * 4 * R;
+      double y[4 * R];
+#pragma unroll
+      for (int i = 0; i < 4 * R; ++i) y[i] = (1.0 - ahead_alpha) * la_x[i] + ahead_alpha * la_v[i];
+      polar_inplace<R>(y);
+      if (!la_opt) {
+        polar_inplace<R>(la_v);
+        double r2 = 0;
+#pragma unroll
+        for (int i = 0; i < 4 * R; ++i) { const double d = y[i] - la_x[i]; r2 += d * d; }
+        oa.part[PART_D + la_pose] = r2;
+      }
+#pragma unroll
+      for (int i = 0; i < 4 * R; ++i) {
+        oa.buf[B_XPREV][o + i] = la_x[i];
+        oa.buf[B_Y][o + i] = y[i];
+        oa.buf[B_X][o + i] = y[i];
+        if (!la_opt) oa.buf[B_V][o + i] = la_v[i];
+      }
+    }
+    return;
+  }
   if (MODE == PM_RGD_) {
     // one lane per pose finishes the step in registers: z = P(zs), X = qf(X - step z), V update
     double rel = 0;
@@ -521,17 +734,40 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
       qf_inplace<R>(x);
 #pragma unroll
       for (int i = 0; i < 4 * R; ++i) {
-        ag.buf[B_X][o + i] = x[i];
-        ag.buf[B_X2][o + i] = x[i];  // snapshot for the final-statistics evaluation (side stream)
+        if (!(ahead & 1)) ag.buf[B_X][o + i] = x[i];
+        ag.buf[B_X2][o + i] = x[i];  // snapshot for the final-statistics evaluation of this iteration
         const double d = x[i] - Esh[2][lp * 4 * R + i];
         rel += d * d;
       }
+      double v[4 * R];
       if (accel) {
         const double gamma = nest_gamma;
-        double v[4 * R];
 #pragma unroll
         for (int i = 0; i < 4 * R; ++i) v[i] = Esh[0][lp * 4 * R + i] + gamma * (x[i] - Esh[1][lp * 4 * R + i]);
         polar_inplace<R>(v);
+      }
+      if (accel && (ahead & 1)) {
+        // Nesterov step of iteration k+1 for this pose (what k_nest_pre would do next): XPrev = X,
+        // Y = proj((1 - alpha') X + alpha' V), X = Y, and V = proj(V) unless this agent is selected again
+        double y[4 * R];
+#pragma unroll
+        for (int i = 0; i < 4 * R; ++i) y[i] = (1.0 - ahead_alpha) * x[i] + ahead_alpha * v[i];
+        polar_inplace<R>(y);
+        if (!ahead_opt) {
+          polar_inplace<R>(v);
+          double rel2 = 0;
+#pragma unroll
+          for (int i = 0; i < 4 * R; ++i) { const double d = y[i] - x[i]; rel2 += d * d; }
+          ag.part[PART_D + 2 * blockIdx.x + lp] = rel2;  // look-ahead steps leave |Y' - X|^2 per pose
+        }
+#pragma unroll
+        for (int i = 0; i < 4 * R; ++i) {
+          ag.buf[B_XPREV][o + i] = x[i];
+          ag.buf[B_Y][o + i] = y[i];
+          ag.buf[B_X][o + i] = y[i];
+        }
+      }
+      if (accel) {
 #pragma unroll
         for (int i = 0; i < 4 * R; ++i) ag.buf[B_V][o + i] = v[i];
       }
@@ -660,54 +896,6 @@ __global__ __launch_bounds__(64) void k_tcg_hv(const AgentDev *agents, const Tea
   if (lane == 0) ag.part[PART_A + (size_t)blockIdx.x * PART_STRIDE] = d;
 }
 
-// ------------------------------------------------------------------------------------------------
-// per-pose kernels: one lane per pose with the whole pose in registers.  A 64-pose tile (64 * 4R
-// contiguous doubles) moves between HBM and registers through LDS so that every global access is a
-// fully coalesced 512-byte wave transaction instead of 64 strided 8-byte ones.
-template <int R>
-struct Tile {
-  static constexpr int P = 4 * R + 1;  // odd pitch: conflict-free row access
-  double d[64 * P];
-};
-// 64 lanes x 4R elements = exactly one tile: fixed trip count, every load issued before the first
-// LDS store (a runtime-bounded loop makes the compiler wait for each load in turn)
-template <int R>
-__device__ __forceinline__ void tile_in(Tile<R> &t, const double *g, int j0, int cnt, int tid) {
-  const double *src = g + (size_t)j0 * 4 * R;
-  const int total = cnt * 4 * R;
-  double tmp[4 * R];
-#pragma unroll
-  for (int k = 0; k < 4 * R; ++k) {
-    const int e = tid + 64 * k;
-    tmp[k] = (e < total) ? src[e] : 0.0;
-  }
-#pragma unroll
-  for (int k = 0; k < 4 * R; ++k) {
-    const int e = tid + 64 * k;
-    t.d[(e / (4 * R)) * Tile<R>::P + e % (4 * R)] = tmp[k];
-  }
-}
-template <int R>
-__device__ __forceinline__ void tile_out(const Tile<R> &t, double *g, int j0, int cnt, int tid) {
-  double *dst = g + (size_t)j0 * 4 * R;
-  const int total = cnt * 4 * R;
-#pragma unroll
-  for (int k = 0; k < 4 * R; ++k) {
-    const int e = tid + 64 * k;
-    if (e < total) dst[e] = t.d[(e / (4 * R)) * Tile<R>::P + e % (4 * R)];
-  }
-}
-template <int R>
-__device__ __forceinline__ void tile_get(const Tile<R> &t, int row, double *v) {
-#pragma unroll
-  for (int i = 0; i < 4 * R; ++i) v[i] = t.d[row * Tile<R>::P + i];
-}
-template <int R>
-__device__ __forceinline__ void tile_put(Tile<R> &t, int row, const double *v) {
-#pragma unroll
-  for (int i = 0; i < 4 * R; ++i) t.d[row * Tile<R>::P + i] = v[i];
-}
-
 // out = Retr_x(scale * eta).  guard_state >= 0: skip when the trust-region state says done.
 template <int R>
 __global__ __launch_bounds__(64) void k_retract(const AgentDev *agents, const TeamDev *team, int sel, int xb, int eb,
@@ -763,73 +951,6 @@ __global__ __launch_bounds__(64) void k_raw_op(const double *X, const double *V,
   tile_out<R>(TA, out, j0, cnt, tid);
 }
 
-// ------------------------------------------------------------------------------------------------
-// Nesterov sequences (a6).  blockIdx.y = local agent.  For every agent:
-//   XPrev = X;  gamma' = (1 + sqrt(1 + 4 N^2 gamma^2)) / 2N;  alpha = 1 / (gamma' N)
-//   Y = proj((1 - alpha) X + alpha V);  X = Y
-// and for the agents that do NOT optimize this iteration (everything but `sel`, or all when
-// sel == -2):  V = proj(V)  [= proj(V + gamma (X - Y))], then the periodic restart X = XPrev,
-// V = Y = X; partial [0] of PART_D = |X_new - XPrev|^2.  First kernel of an accelerated iteration:
-// publishes team->cur_sel.
-template <int R>
-__device__ __forceinline__ void nest_pre_body(const AgentDev *agents, TeamDev *team, int sel, int only_agent,
-                                              int num_robots, int restart_interval, int bx, int by, Tile<R> &TX,
-                                              Tile<R> &TV) {
-  const int ai = only_agent >= 0 ? only_agent : by;
-  const AgentDev &ag = agents[ai];
-  const int selected = (sel == -2) ? -1 : sel_sched(team, sel);
-  if (bx == 0 && by == 0 && threadIdx.x == 0 && sel == -1) team->cur_sel = selected;
-  const int j0 = bx * 64, tid = threadIdx.x;
-  if (j0 >= ag.n) return;
-  const int cnt = min(64, ag.n - j0);
-  const bool optimizing = (ai == selected);
-  const NestState ns = *ag.nest;
-  const double Nr = (double)num_robots;
-  const double gamma = (1.0 + sqrt(1.0 + 4.0 * Nr * Nr * ns.gamma * ns.gamma)) / (2.0 * Nr);
-  const double alpha = 1.0 / (gamma * Nr);
-  const bool restart = ((ns.iter + 2) % restart_interval) == 0;  // iter is pre-increment: (iter+1)+1
-  if (bx == 0 && tid == 0) ag.scal[6] = gamma;  // read by the fused RGD tail instead of the (mutable) NestState
-  tile_in<R>(TX, ag.buf[B_X], j0, cnt, tid);
-  tile_in<R>(TV, ag.buf[B_V], j0, cnt, tid);
-  __syncthreads();
-  tile_out<R>(TX, ag.buf[B_XPREV], j0, cnt, tid);
-  double x[4 * R], v[4 * R], y[4 * R];
-  double rel = 0;
-  if (tid < cnt) {
-    tile_get<R>(TX, tid, x);
-    tile_get<R>(TV, tid, v);
-#pragma unroll
-    for (int i = 0; i < 4 * R; ++i) y[i] = (1.0 - alpha) * x[i] + alpha * v[i];
-    polar_inplace<R>(y);
-    if (!optimizing && !restart) {
-      polar_inplace<R>(v);
-#pragma unroll
-      for (int i = 0; i < 4 * R; ++i) { const double d = y[i] - x[i]; rel += d * d; }
-    }
-  }
-  __syncthreads();
-  if (tid < cnt) {
-    if (optimizing || !restart) { tile_put<R>(TX, tid, y); tile_put<R>(TV, tid, v); }
-    // restart of a non-optimizing agent: X = XPrev (tile still holds x); V = Y = X
-  }
-  __syncthreads();
-  if (optimizing) {
-    tile_out<R>(TX, ag.buf[B_Y], j0, cnt, tid);
-    tile_out<R>(TX, ag.buf[B_X], j0, cnt, tid);  // the local solve starts from Y, in place on X
-  } else if (restart) {
-    tile_out<R>(TX, ag.buf[B_Y], j0, cnt, tid);
-    tile_out<R>(TX, ag.buf[B_V], j0, cnt, tid);
-  } else {
-    tile_out<R>(TX, ag.buf[B_Y], j0, cnt, tid);
-    tile_out<R>(TX, ag.buf[B_X], j0, cnt, tid);
-    tile_out<R>(TV, ag.buf[B_V], j0, cnt, tid);
-  }
-  if (!optimizing) {
-    rel = wave_sum(rel);
-    if (tid == 0) ag.part[PART_D + (size_t)bx * PART_STRIDE] = rel;
-  }
-}
-
 template <int R>
 __global__ __launch_bounds__(64) void k_nest_pre(const AgentDev *agents, TeamDev *team, int sel, int only_agent,
                                                  int num_robots, int restart_interval) {
@@ -852,6 +973,36 @@ __global__ __launch_bounds__(64) void k_stats_nest(const AgentDev *agents, TeamD
     nest_pre_body<R>(agents, team, -1, -1, num_robots, restart_interval, b % nest_tiles, b / nest_tiles, TX, TV);
   } else {
     eval_body<R>(agents, team, -5, B_X2, B_EGRAD2, B_GF2, PART_A, 0, 0, b - nb_nest, TX.d, TV.d);
+  }
+}
+
+// Pipelined accelerated RGD iterations (dpgo_team_run): two launches per iteration.
+//   k_eval_stats      cost / gradient of the agent of iteration k (G from the neighbours' Y)  ||  final statistics of
+//                     iteration k-1 on its snapshot  ||  end-of-iteration bookkeeping of k-1 (workgroup 0)
+//   k_precond<PM_RGD> preconditioned step + Nesterov V of iteration k and the Nesterov step of iteration k+1 of the same
+//                     poses (first wave of each workgroup)  ||  the Nesterov step of iteration k+1 of the workgroup's
+//                     share of every other agent's poses (second wave)
+// No workgroup reads what another workgroup of the same launch writes: this kernel's workgroups read next_sel /
+// stats_sel (written by the previous step kernel) while workgroup 0 moves iter, cur_sel and the NestStates, which
+// only the step kernel reads.
+template <int R>
+__global__ __launch_bounds__(64) void k_eval_stats(const AgentDev *agents, TeamDev *team, int nb_eval, int first,
+                                                   int has_eval, int has_stats, int num_robots, int restart_interval) {
+  constexpr int PPB = 64 / R;
+  __shared__ double Ysh[PPB * 4 * R], Wsh[PPB * 4 * R];
+  const int b = (int)blockIdx.x;
+  if (b == (int)gridDim.x - 1) {  // the extra workgroup: bookkeeping only, so that no evaluation waits for it
+    if (!first && threadIdx.x == 0) {
+      for (int k = 0; k < team->num_agents; ++k) advance_agent(agents[k], 1, num_robots, restart_interval);
+      team->iter += 1;
+      if (has_eval) team->cur_sel = team->next_sel;
+    }
+    return;
+  }
+  if (has_eval && b < nb_eval) {
+    eval_body<R>(agents, team, first ? -1 : -6, B_X, B_EGRAD, B_GF, PART_C, 2, 1, b, Ysh, Wsh);
+  } else if (has_stats) {
+    eval_body<R>(agents, team, -5, B_X2, B_EGRAD2, B_GF2, PART_A, 0, 0, b - (has_eval ? nb_eval : 0), Ysh, Wsh);
   }
 }
 
@@ -1195,23 +1346,30 @@ void launch_hess(const LaunchCtx &c, int sel, int max_n, int xb, int egb, int vb
                                           c.team, sel, xb, egb, vb, ob, poff));
 }
 void launch_precond(const LaunchCtx &c, int sel, int max_n, int mode, int xb, int vb, int zb, int sp, int max_inner,
-                    double step, int accel, int num_robots, int advance, int restart_interval) {
+                    double step, int accel, int num_robots, int advance, int restart_interval, int ahead) {
   const int grid = (4 * max_n + 7) / 8;
 #define PC_CALL(M)                                                                                                  \
   if (4 * max_n <= 2048) {                                                                                           \
     DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL((k_precond<R, M, 2048>), dim3(grid, c.ny), dim3(256), 0, c.stream, c.agents,   \
                                             c.team, sel, xb, vb, zb, sp, max_inner, step, accel, num_robots, advance,   \
-                                            restart_interval));                                                       \
+                                            restart_interval, ahead));                                                \
   } else {                                                                                                           \
     DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL((k_precond<R, M, 1024>), dim3(grid, c.ny), dim3(256), 0, c.stream, c.agents,   \
                                             c.team, sel, xb, vb, zb, sp, max_inner, step, accel, num_robots, advance,   \
-                                            restart_interval));                                                       \
+                                            restart_interval, ahead));                                                \
   }
   if (mode == PM_PLAIN_) { PC_CALL(PM_PLAIN_); }
   else if (mode == PM_TCG_INIT_) { PC_CALL(PM_TCG_INIT_); }
   else if (mode == PM_TCG_STEP_) { PC_CALL(PM_TCG_STEP_); }
   else { PC_CALL(PM_RGD_); }
 #undef PC_CALL
+}
+void launch_eval_stats(const LaunchCtx &c, int max_n, int first, int has_eval, int has_stats, int num_robots,
+                       int restart_interval) {
+  const int nb = spmm_grid(c.r, max_n);
+  const int grid = nb * ((has_eval ? 1 : 0) + (has_stats ? 1 : 0)) + 1;
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_eval_stats<R>, dim3(grid), dim3(64), 0, c.stream, c.agents, c.team, nb, first,
+                                          has_eval, has_stats, num_robots, restart_interval));
 }
 void launch_tcg_hv(const LaunchCtx &c, int sel, int max_n, int sp, int max_inner) {
   DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_tcg_hv<R>, dim3(spmm_grid(c.r, max_n), c.ny), dim3(64), 0, c.stream, c.agents,

@@ -84,7 +84,8 @@ struct Agent {
   std::map<int, int> n_pubframes, n_nbrslots;
   DevBuf<double> d_xfer;
   int tcg_hint = 4, outer_hint = -1;  // launch-pattern sizing from the previous solve of this agent
-  int rel_src = 0;  // where the last |X - XPrev|^2 partials live: 0 PART_D (per 64-pose tile), 1 PART_B[2] (fused RGD)
+  int rel_src = 0;  // where the last |X - XPrev|^2 partials live: 0 PART_D (per 64-pose tile), 1 PART_B[2] (fused RGD),
+                    // 2 none (X untouched), 4 PART_D one double per pose (look-ahead Nesterov step)
   DevBuf<SharedEdgeDev> d_se;
   DevBuf<EdgeDev> d_edges;
   DevBuf<RtrState> d_st;
@@ -116,8 +117,9 @@ struct dpgo_team {
   int max_n = 0, max_npub = 0;
   dpgo::RtrState *h_state = nullptr;  // pinned
   double *h_scal = nullptr;     // pinned [16]
-  static constexpr int NGRAPH = 5;       // graphs of 1, 2, 4, 8, 16 identical iterations
-  hipGraphExec_t graph[NGRAPH] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  static constexpr int MAX_GRAPH_ITERS = 64;       // iterations captured in one graph (one graph per distinct count)
+  std::map<int, hipGraphExec_t> graphs;            // key: see dpgo_team_run
+  std::map<int, int> graph_flip;
   bool graph_valid = false;
   double counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   dpgo::LaunchCtx ctx() { return dpgo::LaunchCtx{prm.r, stream, d_agents.p, d_team.p}; }

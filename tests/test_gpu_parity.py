@@ -140,6 +140,43 @@ def test_team_run_matches_oracle(dataset, N, method, accel, iters):
     th.close()
 
 
+@pytest.mark.parametrize("N,restart,schedule,splits", [
+    (3, 25, None, (40,)),                 # one long window, look-ahead on every iteration but the last
+    (3, 4, None, (1, 2, 3, 7, 11)),       # windows of 3 fused iterations between restarts, ragged run() calls
+    (3, 6, [0, 0, 1, 2, 2, 1], (5, 19)),  # an agent selected twice in a row: its look-ahead step keeps V
+    (2, 5, [1], (9,)),                    # the same agent every time
+])
+def test_pipelined_rgd_windows(N, restart, schedule, splits):
+    """dpgo_team_run for accelerated RGD: [restart iteration] + fused iterations in one graph per window, two
+    launches per fused iteration with the Nesterov step of k+1 taken inside the step kernel of k.  Iterates,
+    per-agent status (relative change from the look-ahead partials) and optimisation results after every run()
+    call against the oracle's one-iteration-at-a-time schedule."""
+    kw = dict(method=capi.METHOD_RGD, acceleration=1, rgd_stepsize=0.1, restart_interval=restart)
+    th, to, n = make_pair("smallGrid3D", N, **kw)
+    if schedule is not None:
+        th.set_schedule(schedule)
+        to.set_schedule(schedule)
+    done = 0
+    for cnt in splits:
+        th.run(cnt)
+        sel = None
+        for _ in range(cnt):
+            sel = to.iterate()
+        done += cnt
+        assert np.abs(th.global_X() - to.global_X()).max() < 1e-8, done
+        for a in range(N):
+            sh, so = th.agents[a].status(), to.agents[a].status()
+            assert sh.iteration_number == so.iteration_number == done
+            assert abs(sh.relative_change - so.relative_change) < 1e-8, (done, a)
+            for which in ("get_Y", "get_V"):
+                assert np.abs(getattr(th.agents[a], which)() - getattr(to.agents[a], which)()).max() < 1e-8, (done, a, which)
+        rh, ro = th.agents[sel].opt_result(), to.agents[sel].opt_result()
+        assert abs(rh.f_init - ro.f_init) <= 1e-9 * abs(ro.f_init) and abs(rh.f_opt - ro.f_opt) <= 1e-9 * abs(ro.f_opt)
+        assert abs(rh.gradnorm_opt - ro.gradnorm_opt) <= 1e-7 * max(1.0, ro.gradnorm_opt)
+    assert abs(th.cost() - to.cost()) <= 1e-9 * abs(to.cost())
+    th.close()
+
+
 def _two_rank_colored_worker(rank, world, port, outdir):
     import os
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
