@@ -460,14 +460,19 @@ template <int R, int MODE, int KC>
 __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev *team, int sel, int xb, int vb,
                                                  int zb, int sp, int max_inner, double step, int accel,
                                                  int num_robots, int advance, int restart_interval, int ahead) {
+  // XCD-aware block order: hardware workgroup h runs on XCD h % 8 (each with its own L2).  Logical block
+  // (h % 8) * (grid / 8) + h / 8 gives every XCD one contiguous range of poses, so that the cache lines shared by
+  // neighbouring poses (a pose is 4R doubles, not a multiple of a line) are written inside one L2 instead of
+  // being split between two.  The grid is padded to a multiple of 8; padding blocks fall out at the nblk test.
+  const int bx = ((int)blockIdx.x % 8) * ((int)gridDim.x / 8) + (int)blockIdx.x / 8;
   const AgentDev &ag = agents[sel_cur(team, sel)];
-  if (MODE == PM_RGD_ && advance == 2 && blockIdx.x == 0 && threadIdx.x == 0) {
+  if (MODE == PM_RGD_ && advance == 2 && bx == 0 && threadIdx.x == 0) {
     // pipelined iterations: nothing that a workgroup of THIS launch reads is written here (cur_sel, iter and the
     // NestStates move in the next k_eval_stats); the next launch finds its statistics agent and its own agent
     team->stats_sel = team->cur_sel;
     team->next_sel = team->sched[(team->iter + 1) % team->sched_len];
   }
-  if (MODE == PM_RGD_ && advance == 1 && blockIdx.x == 0 && threadIdx.x == 0) {
+  if (MODE == PM_RGD_ && advance == 1 && bx == 0 && threadIdx.x == 0) {
     // end-of-iteration bookkeeping of the whole team, folded here: no workgroup of this kernel reads
     // team->iter (they use cur_sel) or a NestState (gamma' comes from scal[6]), and the next kernel that
     // does (k_nest_pre of the following iteration) is ordered behind this launch
@@ -483,7 +488,7 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
   const int tid = threadIdx.x, lane = tid & 63;
   const int N4 = ag.N4;
   const int nblk = precond_blocks(N4);
-  if ((int)blockIdx.x >= nblk) return;
+  if (bx >= nblk) return;
 
   // ---- scalar prologue (identical in every workgroup)
   double alpha = 0, tau = 0;
@@ -496,7 +501,7 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
     // a kernel whose phase is not due forwards the state and returns
     const bool idle = S.outer_done || (MODE == PM_TCG_STEP_ && !S.tcg_active) || (MODE == PM_TCG_INIT_ && !S.need_init);
     if (idle) {
-      if (blockIdx.x == 0 && tid == 0) ag.st[sp ^ 1] = S;
+      if (bx == 0 && tid == 0) ag.st[sp ^ 1] = S;
       return;
     }
     if (MODE == PM_TCG_STEP_) {
@@ -507,13 +512,13 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
       if (d_Hd <= 0 || e_Pe_new >= S.Delta * S.Delta) {
         boundary = true;
         tau = (-S.e_Pd + sqrt(S.e_Pd * S.e_Pd + S.d_Pd * (S.Delta * S.Delta - S.e_Pe))) / S.d_Pd;
-        if (blockIdx.x == 0 && tid == 0) {
+        if (bx == 0 && tid == 0) {
           RtrState T = S;
           T.tcg_active = 0;
           T.tcg_status = (d_Hd <= 0) ? 1 : 2;
           ag.st[sp ^ 1] = T;
         }
-      } else if (blockIdx.x == 0 && tid == 0) {
+      } else if (bx == 0 && tid == 0) {
         RtrState T = S;
         T.e_Pe = e_Pe_new;
         T.alpha = alpha;
@@ -521,7 +526,7 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
         T.pc_count = S.pc_count + 1;
         ag.st[sp ^ 1] = T;
       }
-    } else if (blockIdx.x == 0 && tid == 0) {
+    } else if (bx == 0 && tid == 0) {
       RtrState T = S;
       T.tcg_active = 1; T.tcg_j = 0; T.tcg_status = 0; T.need_init = 0;
       T.e_Pd = 0; T.e_Pe = 0; T.alpha = 0;
@@ -539,8 +544,8 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
   // so only ONE vector (Hd) has to be pulled through every workgroup's LDS; r and z are updated in place by
   // their owners.  (The oracle recomputes z from r+ directly; the two differ by round-off only.)
   const double *Vstage = (MODE == PM_TCG_STEP_) ? Hd : Vin;
-  const int col0 = 8 * blockIdx.x;
-  const int npose = min(2, ag.n - 2 * (int)blockIdx.x);
+  const int col0 = 8 * bx;
+  const int npose = min(2, ag.n - 2 * bx);
 
   if (MODE == PM_TCG_STEP_) {
     // eta += (alpha | tau) * delta on the two poses owned by this workgroup
@@ -647,7 +652,7 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
       const int total = pre[LOOKAHEAD_MAX_AGENTS] - ag.n;
       const int per = (total + nblk - 1) / nblk;  // <= 64, checked by the host
       const int l1 = tid - 64;
-      const int q = (int)blockIdx.x * per + l1;   // index among the poses of the other agents
+      const int q = bx * per + l1;   // index among the poses of the other agents
       if (l1 >= 0 && l1 < per && q < total) {
         int self_lo = 0;
 #pragma unroll
@@ -724,7 +729,7 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
     double rel = 0;
     if (tid < npose) {
       const int lp = tid;
-      const size_t o = (size_t)(2 * blockIdx.x + lp) * 4 * R;
+      const size_t o = (size_t)(2 * bx + lp) * 4 * R;
       double x[4 * R], z[4 * R];
 #pragma unroll
       for (int i = 0; i < 4 * R; ++i) { x[i] = Ysh[lp * 4 * R + i]; z[i] = zs[lp * 4 * R + i]; }
@@ -758,7 +763,7 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
           double rel2 = 0;
 #pragma unroll
           for (int i = 0; i < 4 * R; ++i) { const double d = y[i] - x[i]; rel2 += d * d; }
-          ag.part[PART_D + 2 * blockIdx.x + lp] = rel2;  // look-ahead steps leave |Y' - X|^2 per pose
+          ag.part[PART_D + 2 * bx + lp] = rel2;  // look-ahead steps leave |Y' - X|^2 per pose
         }
 #pragma unroll
         for (int i = 0; i < 4 * R; ++i) {
@@ -774,7 +779,7 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
     }
     if (tid < 64) {
       rel = wave_sum(rel);
-      if (tid == 0) ag.part[PART_B + (size_t)blockIdx.x * PART_STRIDE + 2] = rel;
+      if (tid == 0) ag.part[PART_B + (size_t)bx * PART_STRIDE + 2] = rel;
     }
     return;
   }
@@ -783,7 +788,7 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
   double zr = 0, rr = 0;
   if (tid < npose * R) {
     const int lp = tid / R, a = tid - lp * R;
-    const size_t o = (size_t)(2 * blockIdx.x + lp) * 4 * R;
+    const size_t o = (size_t)(2 * bx + lp) * 4 * R;
     double z[4];
     tangent_row<R>(Ysh + lp * 4 * R, zs + lp * 4 * R, a, z);
     z[3] = zs[lp * 4 * R + 3 * R + a];
@@ -810,7 +815,7 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
     zr = wave_sum(zr);
     rr = wave_sum(rr);
     if (tid == 0) {
-      double *P = ag.part + PART_B + (size_t)blockIdx.x * PART_STRIDE;
+      double *P = ag.part + PART_B + (size_t)bx * PART_STRIDE;
       P[0] = zr; P[1] = rr;
     }
   }
@@ -1347,7 +1352,7 @@ void launch_hess(const LaunchCtx &c, int sel, int max_n, int xb, int egb, int vb
 }
 void launch_precond(const LaunchCtx &c, int sel, int max_n, int mode, int xb, int vb, int zb, int sp, int max_inner,
                     double step, int accel, int num_robots, int advance, int restart_interval, int ahead) {
-  const int grid = (4 * max_n + 7) / 8;
+  const int grid = (((4 * max_n + 7) / 8) + 7) / 8 * 8;  // multiple of 8: see the XCD-aware block order in k_precond
 #define PC_CALL(M)                                                                                                  \
   if (4 * max_n <= 2048) {                                                                                           \
     DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL((k_precond<R, M, 2048>), dim3(grid, c.ny), dim3(256), 0, c.stream, c.agents,   \
