@@ -74,8 +74,8 @@ def single_gpu(args):
             "peak": 8000.0, "unit": "GB/s",
             # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and
             # --pmc WRITE_SIZE in separate runs; FETCH_SIZE doubled per the gfx950 correction):
-            # 2 x 16076.9 KB + 85.9 KB.  Not collectable live; re-measure with profiles/collect.sh.
-            "traffic": (2 * 16076.9 + 85.9) * 1024, "traffic_source": "profiles/r01_pmc_fetch.md, profiles/r01_pmc_write.md",
+            # 2 x 16076.0 KB + 85.9 KB.  Not collectable live; re-measure with profiles/collect.sh.
+            "traffic": (2 * 16076.0 + 85.9) * 1024, "traffic_source": "profiles/r01_pmc_fetch.md, profiles/r01_pmc_write.md",
             "bytes_per_launch": k_bytes, "us_per_launch": k_ms * 1e3,
             "spmm_eval": {"kernel": "k_eval<5>", "bytes_per_launch": s_bytes, "us_per_launch": s_ms * 1e3,
                           "achieved": s_bytes / (s_ms * 1e-3) / 1e9}}
