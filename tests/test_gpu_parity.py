@@ -353,6 +353,19 @@ def test_tunnels_eight_agents(mode, accel):
     assert np.abs(th.global_X() - to.global_X()).max() < 1e-6
     assert abs(th.cost() - to.cost()) <= 1e-8 * abs(to.cost()) and to.cost() < f0
     th.close()
+    if accel:
+        # the same inputs through the pipelined accelerated-RGD windows: 8 agents of 105..191 poses, so a
+        # workgroup's look-ahead share (up to 22 poses) straddles agents
+        kw = dict(method=capi.METHOD_RGD, rgd_stepsize=0.05, acceleration=1, restart_interval=9)
+        th, to = _pair_from(m, sum(nk), N, T, **kw)
+        for cnt in (13, 20):
+            th.run(cnt)
+            for _ in range(cnt):
+                to.iterate()
+            assert np.abs(th.global_X() - to.global_X()).max() < 1e-7
+            for k in range(N):
+                assert abs(th.agents[k].status().relative_change - to.agents[k].status().relative_change) < 1e-8
+        th.close()
 
 
 def test_long_rows_take_the_csr_tail():
