@@ -147,7 +147,78 @@ def single_gpu(args):
         t4.close()
     cp["classes"] = int(nc)
     conv["plain_rtr"] = cp
+    conv["asapp_tunnels"] = asapp_leg(capi)
     return ms, roof, conv, cpu, counters
+
+
+def load_tunnels(mod, weight_mode):
+    """the 8 per-robot CSVs of BASELINE configs[4] merged (a shared edge listed by both robots kept once) and the
+    per-robot odometry chains as the common initial guess"""
+    rows, seen = [], set()
+    for k in range(8):
+        for e in mod.read_csv(os.path.join(ROOT, "data", "tunnels", "robot%d" % k, "measurements.csv"), weight_mode):
+            key = (int(e["r1"]), int(e["p1"]), int(e["r2"]), int(e["p2"]))
+            if key not in seen:
+                seen.add(key)
+                rows.append(e)
+    m = np.array(rows, dtype=mod.MEAS_DTYPE)
+    nk = [0] * 8
+    for e in m:
+        nk[e["r1"]] = max(nk[e["r1"]], int(e["p1"]) + 1)
+        nk[e["r2"]] = max(nk[e["r2"]], int(e["p2"]) + 1)
+    Ts = []
+    for k in range(8):
+        odo = m[(m["r1"] == k) & (m["r2"] == k) & (m["p1"] + 1 == m["p2"])].copy()
+        odo["r1"] = 0
+        odo["r2"] = 0
+        Ts.append(mod.odometry_init(odo, nk[k]))
+    return m, nk, np.concatenate(Ts)
+
+
+def asapp_leg(capi):
+    """BASELINE configs[4]: MIT tunnels, 8 robots, asynchronous (ASAPP) RGD with stepsize 0.2 and the preconditioner.
+    The asynchronous schedule is nondeterministic in the reference (Poisson clocks); measured here is its
+    deterministic lockstep instance -- every robot takes one RGD step per tick from the neighbour poses of the
+    tick's start, all 8 in the same launches on one GPU -- next to the CPU restatement doing the same with one thread
+    per robot (the structure of the reference: one process per robot)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as O
+    kw = dict(method=1, rgd_stepsize=0.2, acceleration=0)
+    m, nk, T = load_tunnels(capi, 1)
+    Y = capi.fixed_stiefel(5)
+    t = capi.Team.from_measurements(m, capi.default_params(r=5, num_robots=8, **kw), device=0)
+    t.set_initial(T, Y)
+    c0 = t.cost()
+    t.run_simultaneous(64)
+    t.synchronize()
+    a0 = time.perf_counter()
+    t.run_simultaneous(1280)
+    t.synchronize()
+    gpu_ms = (time.perf_counter() - a0) / 1280 * 1e3
+    c1 = t.cost()
+    t.close()
+    mo, _, To = load_tunnels(O, 1)
+    to = O.Team(mo, sum(nk), O.default_params(r=5, num_robots=8, **kw))
+    to.set_initial(To, O.fixed_stiefel(5))
+    threads = min(8, os.cpu_count() or 1)
+    ticks = 0
+    with ThreadPoolExecutor(threads) as pool:
+        def tick():
+            to.exchange_all()
+            list(pool.map(lambda a: a.iterate(True), to.agents))
+        for _ in range(5):
+            tick()
+        b0 = time.perf_counter()
+        while time.perf_counter() - b0 < 4.0:
+            for _ in range(20):
+                tick()
+            ticks += 20
+        cpu_ms = (time.perf_counter() - b0) / ticks * 1e3
+    return {"workload": "data/tunnels (8 robots, %d poses, %d edges), RGD stepsize 0.2 + preconditioner, wrapper weighting, "
+                        "lockstep ticks" % (sum(nk), len(m)),
+            "ms_per_tick": gpu_ms, "ms_per_robot_update": gpu_ms / 8, "cost_initial": c0, "cost_after_1344_ticks": c1,
+            "cpu": {"ms_per_tick": cpu_ms, "threads": threads, "kind": "port",
+                    "sample": "%d ticks (~4 s), one oracle agent per thread" % ticks}}
 
 
 def cpu_baseline(mp, n, T, Y):

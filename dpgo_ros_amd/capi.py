@@ -76,7 +76,7 @@ dpgo_agent_robust_weight dpgo_agent_update_measurement_weights dpgo_agent_set_me
 dpgo_agent_get_measurements dpgo_agent_should_update_weights dpgo_agent_clear_data_matrices
 dpgo_error_threshold_at_quantile dpgo_team_set_schedule dpgo_team_set_initial dpgo_team_exchange_all
 dpgo_agent_pull_local dpgo_team_time_kernel dpgo_team_run dpgo_team_get_coloring dpgo_team_run_colored dpgo_team_set_groups dpgo_team_run_group dpgo_team_step_begin dpgo_team_step_end dpgo_team_iteration dpgo_team_cost dpgo_team_update_weights dpgo_team_get_counters
-dpgo_write_measurements_csv dpgo_write_g2o dpgo_write_trajectory_csv dpgo_robust_frame_alignment dpgo_robust_local_init""".split()
+dpgo_write_measurements_csv dpgo_write_g2o dpgo_write_trajectory_csv dpgo_robust_frame_alignment dpgo_robust_local_init dpgo_team_run_simultaneous""".split()
 
 
 class DpgoError(RuntimeError):
@@ -453,6 +453,10 @@ class Team:
         col = np.zeros(len(self.ids), dtype=np.int32)
         nc = _chk(lib().dpgo_team_get_coloring(self.h, _d(col)), "get_coloring")
         return nc, col
+
+    def run_simultaneous(self, ticks):
+        """every agent takes `ticks` RGD steps, all agents per tick in the same launches (ASAPP, clocks in lockstep)"""
+        _chk(lib().dpgo_team_run_simultaneous(self.h, ticks), "run_simultaneous")
 
     def run_colored(self, sweeps):
         _chk(lib().dpgo_team_run_colored(self.h, sweeps), "run_colored")

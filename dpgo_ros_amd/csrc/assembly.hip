@@ -275,6 +275,10 @@ int sync_descs(dpgo_team *t) {
   }
   std::vector<int> gptr(1, 0), gmem;
   for (auto &g : t->groups) { gmem.insert(gmem.end(), g.begin(), g.end()); gptr.push_back((int)gmem.size()); }
+  // one more class behind the colouring: every local agent (simultaneous updates, dpgo_team_run_simultaneous)
+  t->all_group = (int)t->groups.size();
+  for (int k = 0; k < na_; ++k) gmem.push_back(k);
+  gptr.push_back((int)gmem.size());
   if (t->d_group_ptr.upload(gptr, t->stream) || t->d_group_members.upload(gmem, t->stream)) { set_err("group upload failed"); return DPGO_ERR; }
   TeamDev td{};
   td.num_agents = (int)t->ag.size(); td.sched_len = (int)t->sched.size(); td.iter = t->iter;

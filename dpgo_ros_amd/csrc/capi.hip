@@ -757,6 +757,71 @@ int dpgo_team_run_group(dpgo_team_t *t, int g, int count) {
   return 0;
 }
 
+// Simultaneous updates: every local agent takes one preconditioned RGD step per tick, all in the same launches
+// (blockIdx.y = agent), each from the neighbour poses as they were when the tick began.  This is the deterministic
+// instance of the asynchronous (ASAPP) mode in which all Poisson clocks fire together (src/PGOAgentROS.cpp:119-127
+// runs the same RGD step from whatever neighbour poses have arrived); one graph replay per call.
+int dpgo_team_run_simultaneous(dpgo_team_t *t, int ticks) {
+  if (sync_descs(t)) return DPGO_ERR;
+  const dpgo_params_t &p = t->prm;
+  if (p.method != DPGO_METHOD_RGD || !p.rgd_use_preconditioner || p.acceleration) {
+    set_err("simultaneous updates: preconditioned RGD without acceleration (the ASAPP configuration)");
+    return DPGO_ERR;
+  }
+  for (auto &a : t->ag) if (!a->has_X) { set_err("run_simultaneous before set_initial"); return DPGO_NOT_READY; }
+  const int na = (int)t->ag.size();
+  if (na == 0 || ticks <= 0) return 0;
+  if (!t->graph_valid) {
+    for (auto &kv : t->graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);
+    t->graphs.clear();
+    t->graph_flip.clear();
+    t->graph_valid = true;
+  }
+  LaunchCtx c = t->ctx();
+  c.ny = na;
+  const int sel = SEL_GROUP0 - t->all_group, mn = t->max_n;
+  auto body = [&](int reps) {
+    for (int rep = 0; rep < reps; ++rep) {
+      launch_copy(c, -3, -1, na, mn, B_X, B_XPREV, 0);
+      launch_eval(c, sel, mn, B_X, B_EGRAD, B_GF, PART_C, eval_opts(t, 2, 0, 0));
+      launch_precond(c, sel, mn, PM_RGD_, B_X, B_GF, B_Z, 0, 0, p.rgd_stepsize, 0, p.num_robots, 0, p.restart_interval);
+    }
+  };
+  int left = ticks;
+  while (left > 0) {
+    const int B = std::min(left, dpgo_team::MAX_GRAPH_ITERS);
+    const int key = -(B + 1);  // negative keys: simultaneous-update graphs
+    hipGraphExec_t ge = nullptr;
+    auto it = t->graphs.find(key);
+    if (it != t->graphs.end()) ge = it->second;
+    else {
+      hipGraph_t g = nullptr;
+      HIPC(hipStreamBeginCapture(t->stream, hipStreamCaptureModeThreadLocal));
+      body(B);
+      HIPC(hipStreamEndCapture(t->stream, &g));
+      HIPC(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+      (void)hipGraphDestroy(g);
+      t->graphs[key] = ge;
+    }
+    HIPC(hipGraphLaunch(ge, t->stream));
+    left -= B;
+  }
+  // f_opt / gradnorm_opt of every agent on the snapshot of its last step, then the counters
+  launch_eval(c, sel, mn, B_X2, B_EGRAD2, B_GF2, PART_A, eval_opts(t, 0, 0, 0));
+  LaunchCtx c1 = t->ctx();
+  launch_advance(c1, -1, na, 0, p.num_robots, p.restart_interval, 1, ticks, ticks * na);
+  for (auto &a : t->ag) {
+    const double N4 = 4.0 * a->n;
+    t->counters[0] += ticks; t->counters[1] += ticks * 8.0 * N4 * N4;
+    t->counters[2] += ticks + 1; t->counters[3] += (ticks + 1) * spmm_bytes_of(t, *a);
+    a->rel_src = 1; a->iter += ticks; a->opt_pending_rgd = true; a->publish_requested = true;
+    if (p.robust_cost_type != DPGO_COST_L2) a->robust_inner_iter += ticks;
+  }
+  t->iter += ticks * na;
+  t->counters[4] += ticks * na;
+  return 0;
+}
+
 int dpgo_team_run_colored(dpgo_team_t *t, int sweeps) {
   if (sync_descs(t)) return DPGO_ERR;
   const dpgo_params_t &p = t->prm;

@@ -44,7 +44,7 @@ void launch_stats_nest(const LaunchCtx &c, int num_agents, int max_n, int num_ro
 void launch_nest_post(const LaunchCtx &c, int sel, int max_n, int num_robots, int restart_interval);
 void launch_nest_reset(const LaunchCtx &c, int sel, int max_n);
 void launch_advance(const LaunchCtx &c, int only_agent, int num_agents, int accel, int num_robots, int restart_interval,
-                    int bump_team, int inc = 1);
+                    int bump_team, int inc = 1, int team_inc = -1 /* = inc */);
 void launch_status(const LaunchCtx &c, int sel, int only_agent, int num_agents, int max_n);
 void launch_rtr_begin(const LaunchCtx &c, int sel, double Delta0, double tol, int max_outer);
 void launch_rtr_eval2(const LaunchCtx &c, int sel, int max_n, int sp);

@@ -1061,11 +1061,11 @@ __global__ void k_nest_reset(const AgentDev *agents, const TeamDev *team, int se
 
 // end of an iteration (unfused paths): advance gamma/alpha/iter of every agent, and the team counter
 __global__ void k_advance(const AgentDev *agents, TeamDev *team, int only_agent, int accel, int num_robots,
-                          int restart_interval, int bump_team, int inc) {
+                          int restart_interval, int bump_team, int inc, int team_inc) {
   const int ai = only_agent >= 0 ? only_agent : (int)blockIdx.x;
   if (threadIdx.x != 0) return;
   advance_agent(agents[ai], accel, num_robots, restart_interval, inc);
-  if (bump_team && ai == 0) team->iter += inc;
+  if (bump_team && ai == 0) team->iter += team_inc;
 }
 
 // PART_D partial [0] = |X - XPrev|_F^2 over a 64-pose tile (blockIdx.y = agent when sel == -3)
@@ -1354,7 +1354,7 @@ void launch_precond(const LaunchCtx &c, int sel, int max_n, int mode, int xb, in
                     double step, int accel, int num_robots, int advance, int restart_interval, int ahead) {
   const int grid = (((4 * max_n + 7) / 8) + 7) / 8 * 8;  // multiple of 8: see the XCD-aware block order in k_precond
 #define PC_CALL(M)                                                                                                  \
-  if (4 * max_n <= 2048) {                                                                                           \
+  if (4 * max_n > 1024 && 4 * max_n <= 2048) {                                                                       \
     DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL((k_precond<R, M, 2048>), dim3(grid, c.ny), dim3(256), 0, c.stream, c.agents,   \
                                             c.team, sel, xb, vb, zb, sp, max_inner, step, accel, num_robots, advance,   \
                                             restart_interval, ahead));                                                \
@@ -1414,9 +1414,9 @@ void launch_nest_reset(const LaunchCtx &c, int sel, int max_n) {
   hipLaunchKernelGGL(k_nest_reset, dim3((len + 255) / 256), dim3(256), 0, c.stream, c.agents, c.team, sel, c.r);
 }
 void launch_advance(const LaunchCtx &c, int only_agent, int num_agents, int accel, int num_robots, int restart_interval,
-                    int bump_team, int inc) {
+                    int bump_team, int inc, int team_inc) {
   hipLaunchKernelGGL(k_advance, dim3(only_agent >= 0 ? 1 : num_agents), dim3(64), 0, c.stream, c.agents, c.team,
-                     only_agent, accel, num_robots, restart_interval, bump_team, inc);
+                     only_agent, accel, num_robots, restart_interval, bump_team, inc, team_inc < 0 ? inc : team_inc);
 }
 void launch_status(const LaunchCtx &c, int sel, int only_agent, int num_agents, int max_n) {
   dim3 grid((max_n + 63) / 64, (sel == -3 && only_agent < 0) ? num_agents : 1);

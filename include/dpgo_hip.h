@@ -189,6 +189,11 @@ int dpgo_team_step_end(dpgo_team_t *t, int sel_id);
  * launches; identical to the sequential schedule that visits the colour classes in order (class 0 first,
  * members in id order).  One sweep = one block update of every agent.  Needs acceleration = 0. */
 int dpgo_team_get_coloring(dpgo_team_t *t, int *color_of_agent); /* returns the number of classes */
+/* simultaneous updates (the ASAPP configuration: preconditioned RGD, no acceleration): every local agent takes
+ * one RGD step per tick in the same launches, from the neighbour poses as of the beginning of the tick -- the
+ * deterministic instance of the asynchronous mode (src/PGOAgentROS.cpp:119-127) in which all clocks fire together.
+ * Each agent's iteration number advances by `ticks`. */
+int dpgo_team_run_simultaneous(dpgo_team_t *t, int ticks);
 int dpgo_team_run_colored(dpgo_team_t *t, int sweeps);
 /* the same with an explicit (global) colouring, one class at a time, for one-process-per-GPU runs */
 int dpgo_team_set_groups(dpgo_team_t *t, int num_groups, const int *group_ptr, const int *member_ids);

@@ -346,6 +346,9 @@ class Team:
     def iterate(self):
         return lib().orc_team_iterate(self.h)
 
+    def exchange_all(self):
+        lib().orc_team_exchange_all(self.h)
+
     def cost(self):
         return lib().orc_team_cost(self.h)
 

@@ -598,3 +598,55 @@ def test_robust_local_initialization():
     R = T.reshape(n, 4, 3)[:, :3, :]
     assert np.abs(np.einsum("nij,nkj->nik", R, R) - np.eye(3)).max() < 1e-12
     assert (np.linalg.det(R) > 0).all()
+
+
+def _oracle_simultaneous(to, N, ticks):
+    """all agents step from the neighbour poses of the beginning of the tick (oracle, per-agent API)"""
+    for _ in range(ticks):
+        snap = {}
+        for b in range(N):
+            for c in to.agents[b].neighbors():
+                snap[(b, c)] = to.agents[b].get_public_poses(c, False)
+        for (b, c), (ids, P) in snap.items():
+            to.agents[c].update_neighbor_poses(b, ids, P, False)
+        for b in range(N):
+            assert to.agents[b].iterate(True)
+
+
+@pytest.mark.parametrize("dataset,N", [("smallGrid3D", 3), ("tunnels", 8)])
+def test_simultaneous_updates(dataset, N):
+    """ASAPP with all clocks in lockstep (dpgo_team_run_simultaneous): every agent takes an RGD step per tick in
+    the same launches; equals the oracle's agents stepping one by one from poses frozen at the tick's start."""
+    kw = dict(method=capi.METHOD_RGD, rgd_stepsize=0.05, acceleration=0)
+    if dataset == "tunnels":
+        from tests.util import load_tunnels
+        m = load_tunnels(capi.WEIGHT_WRAPPER)
+        nk = [0] * N
+        for e in m:
+            nk[e["r1"]] = max(nk[e["r1"]], int(e["p1"]) + 1)
+            nk[e["r2"]] = max(nk[e["r2"]], int(e["p2"]) + 1)
+        Ts = []
+        for k in range(N):
+            odo = m[(m["r1"] == k) & (m["r2"] == k) & (m["p1"] + 1 == m["p2"])].copy()
+            odo["r1"] = 0; odo["r2"] = 0
+            Ts.append(O.odometry_init(odo, nk[k]))
+        th, to = _pair_from(m, sum(nk), N, np.concatenate(Ts), **kw)
+    else:
+        th, to, n = make_pair(dataset, N, **kw)
+    f0 = to.cost()
+    done = 0
+    for ticks in (1, 5, 70):   # 70 > one graph of 64 ticks
+        th.run_simultaneous(ticks)
+        _oracle_simultaneous(to, N, ticks)
+        done += ticks
+        assert np.abs(th.global_X() - to.global_X()).max() < 1e-8, done
+        for a in range(N):
+            sh, so = th.agents[a].status(), to.agents[a].status()
+            assert sh.iteration_number == so.iteration_number == done
+            assert abs(sh.relative_change - so.relative_change) < 1e-8
+            rh, ro = th.agents[a].opt_result(), to.agents[a].opt_result()
+            assert abs(rh.f_opt - ro.f_opt) <= 1e-9 * max(1.0, abs(ro.f_opt))
+    assert abs(th.cost() - to.cost()) <= 1e-9 * abs(to.cost()) and to.cost() < f0
+    # the sequential schedule still works afterwards (team counter advanced by ticks * N)
+    th.run(4)
+    th.close()
