@@ -67,19 +67,7 @@ def single_gpu(args):
     iter_bytes = (c_timed[1] + c_timed[3]) / max(c_timed[4], 1)   # algorithmic bytes per RBCD iteration
 
     fstar = F_STAR[WORKLOAD["dataset"]]
-    # ---- roofline leg: dominant kernel = dense preconditioner apply, HIP events on the team stream
-    k_ms, k_bytes = team.time_kernel(1, 0, reps=500)
-    s_ms, s_bytes = team.time_kernel(1, 1, reps=500)
-    roof = {"kernel": "k_precond<5,PM_PLAIN>", "bound": "hbm", "achieved": k_bytes / (k_ms * 1e-3) / 1e9,
-            "peak": 8000.0, "unit": "GB/s",
-            # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and
-            # --pmc WRITE_SIZE in separate runs; FETCH_SIZE doubled per the gfx950 correction):
-            # 2 x 16076.0 KB + 85.9 KB.  Not collectable live; re-measure with profiles/collect.sh.
-            "traffic": (2 * 16076.0 + 85.9) * 1024, "traffic_source": "profiles/r01_pmc_fetch.md, profiles/r01_pmc_write.md",
-            "bytes_per_launch": k_bytes, "us_per_launch": k_ms * 1e3,
-            "spmm_eval": {"kernel": "k_eval<5>", "bytes_per_launch": s_bytes, "us_per_launch": s_ms * 1e3,
-                          "achieved": s_bytes / (s_ms * 1e-3) / 1e9}}
-    roof["frac"] = roof["achieved"] / roof["peak"]
+    roof = roofline_leg(team, 1)
     roof["iteration"] = {"algorithmic_bytes": iter_bytes, "achieved": iter_bytes / (ms * 1e-3) / 1e9, "unit": "GB/s",
                          "note": "B_iter = #precond x B_P + #eval x B from the run's own counters, / ms per iteration"}
 
@@ -149,6 +137,24 @@ def single_gpu(args):
     conv["plain_rtr"] = cp
     conv["asapp_tunnels"] = asapp_leg(capi)
     return ms, roof, conv, cpu, counters
+
+
+def roofline_leg(team, agent_id):
+    """dominant kernel = dense preconditioner apply of one agent, HIP events on the team stream (back-to-back
+    launches of the plain mode), plus the SpMM evaluation the same way"""
+    k_ms, k_bytes = team.time_kernel(agent_id, 0, reps=500)
+    s_ms, s_bytes = team.time_kernel(agent_id, 1, reps=500)
+    roof = {"kernel": "k_precond<5,PM_PLAIN>", "bound": "hbm", "achieved": k_bytes / (k_ms * 1e-3) / 1e9,
+            "peak": 8000.0, "unit": "GB/s",
+            # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and
+            # --pmc WRITE_SIZE in separate runs; FETCH_SIZE doubled per the gfx950 correction):
+            # 2 x 16076.0 KB + 85.9 KB.  Not collectable live; re-measure with profiles/collect.sh.
+            "traffic": (2 * 16076.0 + 85.9) * 1024, "traffic_source": "profiles/r01_pmc_fetch.md, profiles/r01_pmc_write.md",
+            "bytes_per_launch": k_bytes, "us_per_launch": k_ms * 1e3,
+            "spmm_eval": {"kernel": "k_eval<5>", "bytes_per_launch": s_bytes, "us_per_launch": s_ms * 1e3,
+                          "achieved": s_bytes / (s_ms * 1e-3) / 1e9}}
+    roof["frac"] = roof["achieved"] / roof["peak"]
+    return roof
 
 
 def load_tunnels(mod, weight_mode):
@@ -281,6 +287,10 @@ def multi_gpu(args):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         ms = tmax.item() / args.steps * 1e3
     cost = drv.global_cost(torch, "cuda")
+    roof = None
+    if rank == 0 and be.team is not None:  # the same kernel-level leg as at N = 1, on rank 0's first agent
+        with be.stream_context():
+            roof = roofline_leg(be.team, mine[0])
     dist.barrier()
     be.close()
 
@@ -311,7 +321,7 @@ def multi_gpu(args):
     dist.barrier()
     be2.close()
     dist.destroy_process_group()
-    return rank, ms, cost, {"ms_per_block_update": cp_ms, "classes": len(drv2.groups),
+    return rank, ms, cost, roof, {"ms_per_block_update": cp_ms, "classes": len(drv2.groups),
                             "relcost_after_45_sweeps": (cp_cost - F_STAR[WORKLOAD["dataset"]]) / F_STAR[WORKLOAD["dataset"]]}
 
 
@@ -337,10 +347,10 @@ def main():
                                  "spmm_launches": counters[2], "spmm_bytes": counters[3], "iterations": counters[4]}})
         print(json.dumps(out))
     else:
-        rank, ms, cost, cp = multi_gpu(args)
+        rank, ms, cost, roof, cp = multi_gpu(args)
         if rank == 0:
             fstar = F_STAR[WORKLOAD["dataset"]]
-            out.update({"value": ms, "ms_per_step": ms, "roofline": None, "cpu_baseline": None,
+            out.update({"value": ms, "ms_per_step": ms, "roofline": roof, "cpu_baseline": None,
                         "relcost_after_run": (cost - fstar) / fstar, "colour_parallel_plain_rtr": cp,
                         "exchange": "RCCL isend/irecv of packed public-pose slabs (X and Y), pull-before-use"})
             print(json.dumps(out))
