@@ -90,24 +90,27 @@ def single_gpu(args):
     # ---- convergence leg (untimed): iterations to (f_k - f*)/f* <= 1e-6
     conv = {}
     Tch = capi.chordal_init(m, n)  # GPU chordal relaxation of the whole graph
-    for name, cfg, cap, T0 in (("rgd_nesterov", RGD, 3000, T), ("rtr_nesterov", RTR, 1500, T),
-                               ("rtr_nesterov_chordal_init", RTR, 1500, Tch)):
+    # RGD legs: the gap is checked every 100 iterations until it is below 3e-6, then after every iteration
+    for name, cfg, cap, T0, coarse in (("rgd_nesterov", RGD, 20000, T, 100), ("rgd_nesterov_chordal_init", RGD, 20000, Tch, 100),
+                                       ("rtr_nesterov", RTR, 1500, T, 1), ("rtr_nesterov_chordal_init", RTR, 1500, Tch, 1)):
         p2 = capi.default_params(r=WORKLOAD["r"], num_robots=WORKLOAD["num_robots"], **cfg)
         t2 = capi.Team.from_measurements(mp, p2, device=0)
         t2.set_initial(T0, Y)
-        hit, gap = None, None
+        hit, gap, k = None, float("inf"), 0
         tt = 0.0
-        for k in range(cap):
+        while k < cap:
+            chunk = coarse if gap > 3e-6 else 1
             a0 = time.perf_counter()
-            t2.run(1)
+            t2.run(chunk)
             t2.synchronize()
             tt += time.perf_counter() - a0
+            k += chunk
             gap = (t2.cost() - fstar) / fstar
             if gap <= 1e-6:
-                hit = k + 1
+                hit = k
                 break
-        conv[name] = {"iters_to_relcost_1e-6": hit, "relcost_at_stop": gap, "iters_run": k + 1,
-                      "ms_per_iter_synced": tt / (k + 1) * 1e3}
+        conv[name] = {"iters_to_relcost_1e-6": hit, "relcost_at_stop": gap, "iters_run": k,
+                      "ms_per_iter_synced": tt / k * 1e3}
         t2.close()
 
     cpu = cpu_baseline(mp, n, T, Y)
