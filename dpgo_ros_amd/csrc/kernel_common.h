@@ -1,0 +1,385 @@
+// kernel_common.h -- device-side helpers shared by the hand-written HIP kernels (gfx950 / CDNA4, wave64) of the
+// RBCD hot path: spmm.hip (block-sparse evaluations), precond.hip (dense preconditioner apply and the solver steps
+// fused into it), pose_ops.hip (per-pose manifold operations, scalar state machines, exchange and cost kernels).
+//
+// SURVEY 8a rows served here (call sites in /root/reference, bodies external):
+//   a2  G assembly from neighbour public poses           (src/PGOAgentROS.cpp:1276,1278 feed it)
+//   a3  QuadraticProblem f / EucGrad / RieGrad / Hess-vec / PreConditioner  (:169-172)
+//   a4  RTR (Steihaug tCG) state machine + RGD step      (src/PGOAgentROSNode.cpp:85,90,96-100)
+//   a5  tangent projection / QF retraction / polar projection (:1420-1422)
+//   a6  Nesterov gamma/alpha/Y/V sequences + restart     (src/PGOAgentROSNode.cpp:126-130)
+//   a7  pack/unpack of public-pose slabs                 (:662-690, :1255-1284)
+//   a8  per-edge residuals                               (:1049)
+//
+// Layout: X is r x 4n column-major (pose = 4r contiguous doubles).  Q is stored twice: block-CSR
+// (row j lists (i, Q_ij), (XQ)_j = sum_i X_i Q_ij) for assembly/read-back, and slot-major ELL
+// (+ CSR tail for long rows) for the SpMM kernels, so that the column indices and the 4x4 blocks of
+// a row are fetched with loads that do not depend on each other (the operands are L2/MALL resident;
+// what bounds these kernels is the number of dependent round trips, not bytes).  One lane owns one
+// (pose, row a) pair: a 64-wide wave covers floor(64/R) poses.
+// Scalars of the inner solve (dots, alpha, beta, rho, radius) never visit the host: every
+// workgroup re-derives them from the same per-block partial sums in the same order, and
+// workgroup 0 publishes the next state into the other half of a ping-pong pair.
+#pragma once
+#include "device_math.h"
+#include "dpgo_dev.h"
+#include "kernels.h"
+
+namespace dpgo {
+
+// agent selection.  First kernel of an iteration: from the device-side schedule (and it publishes
+// team->cur_sel); every later kernel: team->cur_sel, so that the last kernel may advance team->iter.
+__device__ __forceinline__ int sel_sched(const TeamDev *team, int sel) {
+  return sel >= 0 ? sel : team->sched[team->iter % team->sched_len];
+}
+
+__device__ __forceinline__ int sel_cur(const TeamDev *team, int sel) {
+  if (sel >= 0) return sel;
+  if (sel == -5) return team->stats_sel;
+  if (sel == -6) return team->next_sel;
+  if (sel > SEL_GROUP0) return team->cur_sel;
+  return team->group_members[team->group_ptr[SEL_GROUP0 - sel] + blockIdx.y];  // colour-parallel update
+}
+
+template <int R>
+__device__ __forceinline__ int spmm_blocks(int n) { return (n + (64 / R) - 1) / (64 / R); }
+
+__device__ __forceinline__ int precond_blocks(int N4) { return (N4 + 7) / 8; }
+
+__device__ __forceinline__ double2 ld2(const double *p) { return *reinterpret_cast<const double2 *>(p); }
+
+typedef double v2d_t __attribute__((ext_vector_type(2)));
+
+#ifndef DPGO_M_NT
+#define DPGO_M_NT 1
+#endif
+
+__device__ __forceinline__ double2 ld2_nt(const double *p) {
+#if DPGO_M_NT
+  const v2d_t v = __builtin_nontemporal_load(reinterpret_cast<const v2d_t *>(p));
+  return make_double2(v.x, v.y);
+#else
+  return *reinterpret_cast<const double2 *>(p);
+#endif
+}
+
+// one group of up to 4 ELL slots: every index/block load is issued before the first use
+template <int R, int NV, class Src>
+__device__ __forceinline__ void ell_group(const AgentDev &ag, int j, int slot0, Src src, double (*acc)[4]) {
+  const int W = ag.ell_w, n = ag.n;
+  int idx[4];
+  double2 B[4][8];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const bool valid = slot0 + u < W;
+    idx[u] = valid ? ag.ell_col[(size_t)(slot0 + u) * n + j] : j;
+    const double *bp = ag.ell_val + ((size_t)(valid ? slot0 + u : 0) * n + j) * 16;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) B[u][q] = valid ? ld2(bp + 2 * q) : make_double2(0.0, 0.0);
+  }
+  double x[4][NV][4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) src(idx[u], x[u]);
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        acc[v][c] += x[u][v][0] * B[u][2 * c].x + x[u][v][1] * B[u][2 * c].y + x[u][v][2] * B[u][2 * c + 1].x +
+                     x[u][v][3] * B[u][2 * c + 1].y;
+}
+
+// acc[v][c] += sum_i sum_cp src_v(i, cp) * Q_ij[cp, c]   for output pose j, row a; NV vectors at once
+template <int R, int NV, class Src>
+__device__ __forceinline__ void spmm_row(const AgentDev &ag, int j, Src src, double (*acc)[4]) {
+  ell_group<R, NV>(ag, j, 0, src, acc);
+  if (ag.ell_w > 4) ell_group<R, NV>(ag, j, 4, src, acc);
+  const int p0 = ag.trowptr[j], p1 = ag.trowptr[j + 1];
+  for (int p = p0; p < p1; ++p) {
+    const int i = ag.tcol[p];
+    const double *bp = ag.tval + (size_t)16 * p;
+    double x[NV][4];
+    src(i, x);
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const double2 b01 = ld2(bp + 4 * c), b23 = ld2(bp + 4 * c + 2);
+        acc[v][c] += x[v][0] * b01.x + x[v][1] * b01.y + x[v][2] * b23.x + x[v][3] * b23.y;
+      }
+  }
+}
+
+// G_j row a from the shared edges of public pose index q (a2)
+template <int R>
+__device__ __forceinline__ void g_row(const AgentDev *agents, const AgentDev &ag, int q, int a, int aux, int pull,
+                                      double g[4]) {
+  g[0] = g[1] = g[2] = g[3] = 0.0;
+  for (int e = ag.pub_ptr[q]; e < ag.pub_ptr[q + 1]; ++e) {
+    const SharedEdgeDev &se = ag.se[e];
+    double *slab = ag.nbr[aux] + (size_t)se.slot * 4 * R;
+    double x[4];
+    if (pull && se.src_agent_local >= 0) {
+      const double *src = agents[se.src_agent_local].buf[aux ? B_Y : B_X] + (size_t)se.src_frame * 4 * R;
+#pragma unroll
+      for (int cp = 0; cp < 4; ++cp) { x[cp] = src[cp * R + a]; slab[cp * R + a] = x[cp]; }
+    } else {
+#pragma unroll
+      for (int cp = 0; cp < 4; ++cp) x[cp] = slab[cp * R + a];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int cp = 0; cp < 4; ++cp) g[c] -= x[cp] * se.coef[cp + 4 * c];
+  }
+}
+
+// end of an iteration: advance gamma/alpha/iter of one agent
+__device__ __forceinline__ void advance_agent(const AgentDev &ag, int accel, int num_robots, int restart_interval,
+                                              int inc = 1) {
+  NestState ns = *ag.nest;
+  if (accel) {
+    const double Nr = (double)num_robots;
+    const bool restart = ((ns.iter + 2) % restart_interval) == 0;
+    if (restart) { ns.gamma = 0; ns.alpha = 0; }
+    else {
+      ns.gamma = (1.0 + sqrt(1.0 + 4.0 * Nr * Nr * ns.gamma * ns.gamma)) / (2.0 * Nr);
+      ns.alpha = 1.0 / (ns.gamma * Nr);
+    }
+  }
+  ns.iter += inc;
+  *ag.nest = ns;
+}
+
+// ------------------------------------------------------------------------------------------------
+// f, Euclidean gradient, Riemannian gradient (a3).  partials: [0] f, [1] |rgrad|^2
+// gmode: 0 G from the buffer, 1 assemble G from the slab, 2 assemble G pulling from co-resident
+// agents (both also store G).
+template <int R>
+__device__ __forceinline__ void eval_body(const AgentDev *agents, const TeamDev *team, int sel, int xb, int egb, int gfb,
+                                          int poff, int gmode, int aux, int bx, double *Ysh, double *Wsh) {
+  const AgentDev &ag = agents[sel_cur(team, sel)];
+  constexpr int PPB = 64 / R;
+  const int lane = threadIdx.x, lp = lane / R, a = lane - lp * R;
+  const int j = bx * PPB + lp;
+  if (bx * PPB >= ag.n) return;
+  const bool act = lp < PPB && j < ag.n;
+  const double *X = ag.buf[xb];
+  double fpart = 0, gpart = 0, eg3 = 0;
+  if (act) {
+    double acc[1][4] = {{0, 0, 0, 0}};
+    spmm_row<R, 1>(ag, j, [&](int i, double(*x)[4]) {
+#pragma unroll
+      for (int cp = 0; cp < 4; ++cp) x[0][cp] = X[((size_t)4 * i + cp) * R + a];
+    }, acc);
+    double g[4] = {0, 0, 0, 0};
+    const int q = ag.pub_index[j];
+    double *Gj = ag.buf[B_G] + (size_t)j * 4 * R;
+    if (q >= 0) {
+      if (gmode == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) g[c] = Gj[c * R + a];
+      } else {
+        g_row<R>(agents, ag, q, a, aux, gmode == 2, g);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) Gj[c * R + a] = g[c];
+      }
+    }
+    double *EG = ag.buf[egb] + (size_t)j * 4 * R;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const double xr = X[((size_t)4 * j + c) * R + a];
+      fpart += (0.5 * acc[0][c] + g[c]) * xr;
+      const double eg = acc[0][c] + g[c];
+      EG[c * R + a] = eg;
+      Ysh[lp * 4 * R + c * R + a] = xr;
+      Wsh[lp * 4 * R + c * R + a] = eg;
+      if (c == 3) eg3 = eg;
+    }
+  }
+  __syncthreads();
+  if (act) {
+    double o[3];
+    tangent_row<R>(Ysh + lp * 4 * R, Wsh + lp * 4 * R, a, o);
+    double *GF = ag.buf[gfb] + (size_t)j * 4 * R;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { GF[c * R + a] = o[c]; gpart += o[c] * o[c]; }
+    GF[3 * R + a] = eg3;
+    gpart += eg3 * eg3;
+  }
+  fpart = wave_sum(fpart);
+  gpart = wave_sum(gpart);
+  if (lane == 0) {
+    double *P = ag.part + poff + (size_t)bx * PART_STRIDE;
+    P[0] = fpart; P[1] = gpart;
+  }
+}
+
+// shared tail of every Hessian-vector product: curvature correction + tangent projection.
+// in : wrow[4] = (V Q)_j row a, vrow[4] = V_j row a, Ysh/Esh = full Y_j / egrad_j staged in LDS
+// out: hrow[4] = Hess f[V]_j row a ;  Wsh used as scratch
+template <int R>
+__device__ __forceinline__ void hess_tail(const double *Ysh, const double *Esh, double *Wsh, int a,
+                                          const double wrow[4], const double vrow[4], double hrow[4], bool act) {
+  if (act) {
+    double S[9];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        double s = 0;
+#pragma unroll
+        for (int b = 0; b < R; ++b) s += Ysh[p * R + b] * Esh[q * R + b];
+        S[3 * p + q] = s;
+      }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      double s = wrow[q];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) s -= vrow[p] * 0.5 * (S[3 * p + q] + S[3 * q + p]);
+      Wsh[q * R + a] = s;
+    }
+  }
+  __syncthreads();
+  if (act) {
+    double o[3];
+    tangent_row<R>(Ysh, Wsh, a, o);
+    hrow[0] = o[0]; hrow[1] = o[1]; hrow[2] = o[2]; hrow[3] = wrow[3];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+// per-pose kernels: one lane per pose with the whole pose in registers.  A 64-pose tile (64 * 4R
+// contiguous doubles) moves between HBM and registers through LDS so that every global access is a
+// fully coalesced 512-byte wave transaction instead of 64 strided 8-byte ones.
+template <int R>
+struct Tile {
+  static constexpr int P = 4 * R + 1;  // odd pitch: conflict-free row access
+  double d[64 * P];
+};
+
+// 64 lanes x 4R elements = exactly one tile: fixed trip count, every load issued before the first
+// LDS store (a runtime-bounded loop makes the compiler wait for each load in turn)
+template <int R>
+__device__ __forceinline__ void tile_in(Tile<R> &t, const double *g, int j0, int cnt, int tid) {
+  const double *src = g + (size_t)j0 * 4 * R;
+  const int total = cnt * 4 * R;
+  double tmp[4 * R];
+#pragma unroll
+  for (int k = 0; k < 4 * R; ++k) {
+    const int e = tid + 64 * k;
+    tmp[k] = (e < total) ? src[e] : 0.0;
+  }
+#pragma unroll
+  for (int k = 0; k < 4 * R; ++k) {
+    const int e = tid + 64 * k;
+    t.d[(e / (4 * R)) * Tile<R>::P + e % (4 * R)] = tmp[k];
+  }
+}
+
+template <int R>
+__device__ __forceinline__ void tile_out(const Tile<R> &t, double *g, int j0, int cnt, int tid) {
+  double *dst = g + (size_t)j0 * 4 * R;
+  const int total = cnt * 4 * R;
+#pragma unroll
+  for (int k = 0; k < 4 * R; ++k) {
+    const int e = tid + 64 * k;
+    if (e < total) dst[e] = t.d[(e / (4 * R)) * Tile<R>::P + e % (4 * R)];
+  }
+}
+
+template <int R>
+__device__ __forceinline__ void tile_get(const Tile<R> &t, int row, double *v) {
+#pragma unroll
+  for (int i = 0; i < 4 * R; ++i) v[i] = t.d[row * Tile<R>::P + i];
+}
+
+template <int R>
+__device__ __forceinline__ void tile_put(Tile<R> &t, int row, const double *v) {
+#pragma unroll
+  for (int i = 0; i < 4 * R; ++i) t.d[row * Tile<R>::P + i] = v[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Nesterov sequences (a6).  blockIdx.y = local agent.  For every agent:
+//   XPrev = X;  gamma' = (1 + sqrt(1 + 4 N^2 gamma^2)) / 2N;  alpha = 1 / (gamma' N)
+//   Y = proj((1 - alpha) X + alpha V);  X = Y
+// and for the agents that do NOT optimize this iteration (everything but `sel`, or all when
+// sel == -2):  V = proj(V)  [= proj(V + gamma (X - Y))], then the periodic restart X = XPrev,
+// V = Y = X; partial [0] of PART_D = |X_new - XPrev|^2.  First kernel of an accelerated iteration:
+// publishes team->cur_sel.
+template <int R>
+__device__ __forceinline__ void nest_pre_body(const AgentDev *agents, TeamDev *team, int sel, int only_agent,
+                                              int num_robots, int restart_interval, int bx, int by, Tile<R> &TX,
+                                              Tile<R> &TV) {
+  const int ai = only_agent >= 0 ? only_agent : by;
+  const AgentDev &ag = agents[ai];
+  const int selected = (sel == -2) ? -1 : sel_sched(team, sel);
+  if (bx == 0 && by == 0 && threadIdx.x == 0 && sel == -1) team->cur_sel = selected;
+  const int j0 = bx * 64, tid = threadIdx.x;
+  if (j0 >= ag.n) return;
+  const int cnt = min(64, ag.n - j0);
+  const bool optimizing = (ai == selected);
+  const NestState ns = *ag.nest;
+  const double Nr = (double)num_robots;
+  const double gamma = (1.0 + sqrt(1.0 + 4.0 * Nr * Nr * ns.gamma * ns.gamma)) / (2.0 * Nr);
+  const double alpha = 1.0 / (gamma * Nr);
+  const bool restart = ((ns.iter + 2) % restart_interval) == 0;  // iter is pre-increment: (iter+1)+1
+  if (bx == 0 && tid == 0) ag.scal[6] = gamma;  // read by the fused RGD tail instead of the (mutable) NestState
+  tile_in<R>(TX, ag.buf[B_X], j0, cnt, tid);
+  tile_in<R>(TV, ag.buf[B_V], j0, cnt, tid);
+  __syncthreads();
+  tile_out<R>(TX, ag.buf[B_XPREV], j0, cnt, tid);
+  double x[4 * R], v[4 * R], y[4 * R];
+  double rel = 0;
+  if (tid < cnt) {
+    tile_get<R>(TX, tid, x);
+    tile_get<R>(TV, tid, v);
+#pragma unroll
+    for (int i = 0; i < 4 * R; ++i) y[i] = (1.0 - alpha) * x[i] + alpha * v[i];
+    polar_inplace<R>(y);
+    if (!optimizing && !restart) {
+      polar_inplace<R>(v);
+#pragma unroll
+      for (int i = 0; i < 4 * R; ++i) { const double d = y[i] - x[i]; rel += d * d; }
+    }
+  }
+  __syncthreads();
+  if (tid < cnt) {
+    if (optimizing || !restart) { tile_put<R>(TX, tid, y); tile_put<R>(TV, tid, v); }
+    // restart of a non-optimizing agent: X = XPrev (tile still holds x); V = Y = X
+  }
+  __syncthreads();
+  if (optimizing) {
+    tile_out<R>(TX, ag.buf[B_Y], j0, cnt, tid);
+    tile_out<R>(TX, ag.buf[B_X], j0, cnt, tid);  // the local solve starts from Y, in place on X
+  } else if (restart) {
+    tile_out<R>(TX, ag.buf[B_Y], j0, cnt, tid);
+    tile_out<R>(TX, ag.buf[B_V], j0, cnt, tid);
+  } else {
+    tile_out<R>(TX, ag.buf[B_Y], j0, cnt, tid);
+    tile_out<R>(TX, ag.buf[B_X], j0, cnt, tid);
+    tile_out<R>(TV, ag.buf[B_V], j0, cnt, tid);
+  }
+  if (!optimizing) {
+    rel = wave_sum(rel);
+    if (tid == 0) ag.part[PART_D + (size_t)bx * PART_STRIDE] = rel;
+  }
+}
+
+#define DPGO_DISPATCH_R(R_, CALL)            \
+  switch (R_) {                              \
+    case 3: { constexpr int R = 3; CALL; } break; \
+    case 4: { constexpr int R = 4; CALL; } break; \
+    case 5: { constexpr int R = 5; CALL; } break; \
+    case 6: { constexpr int R = 6; CALL; } break; \
+    case 7: { constexpr int R = 7; CALL; } break; \
+    case 8: { constexpr int R = 8; CALL; } break; \
+    default: break;                          \
+  }
+
+static inline int spmm_grid(int r, int n) { const int ppb = 64 / r; return (n + ppb - 1) / ppb; }
+
+}  // namespace dpgo

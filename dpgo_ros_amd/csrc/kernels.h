@@ -1,4 +1,4 @@
-// kernels.h -- host-callable launch wrappers of kernels.hip / dense_inverse.hip
+// kernels.h -- host-callable launch wrappers of spmm.hip / precond.hip / pose_ops.hip / dense_inverse.hip
 #pragma once
 #include <hip/hip_runtime.h>
 #include "dpgo_dev.h"
@@ -13,7 +13,7 @@ struct LaunchCtx {
   int ny = 1;              // grid.y of the per-agent kernels: members of the colour class being updated
 };
 
-// preconditioner kernel modes (see kernels.hip)
+// preconditioner kernel modes (see precond.hip)
 constexpr int PM_PLAIN_ = 0, PM_TCG_INIT_ = 1, PM_TCG_STEP_ = 2, PM_RGD_ = 3;
 
 struct EvalOpts {

@@ -1,0 +1,396 @@
+// pose_ops.hip -- per-pose manifold kernels (retraction, raw manifold operations, Nesterov sequences; SURVEY 8a rows
+// a5, a6), status partials, the scalar trust-region state machine (a4), public-pose pack / unpack (a7), per-edge
+// residuals and the global cost (a8), dense assembly of Q + shift I.
+#include "kernel_common.h"
+
+namespace dpgo {
+
+// out = Retr_x(scale * eta).  guard_state >= 0: skip when the trust-region state says done.
+template <int R>
+__global__ __launch_bounds__(64) void k_retract(const AgentDev *agents, const TeamDev *team, int sel, int xb, int eb,
+                                                double scale, int ob, int guard_state) {
+  const AgentDev &ag = agents[sel_cur(team, sel)];
+  if (guard_state >= 0) {
+    const RtrState S = ag.st[guard_state];
+    if (S.outer_done || S.tcg_active || S.need_init) return;  // only between the end of tCG and the accept step
+  }
+  const int j0 = blockIdx.x * 64, tid = threadIdx.x;
+  if (j0 >= ag.n) return;
+  const int cnt = min(64, ag.n - j0);
+  __shared__ Tile<R> TA, TB;
+  tile_in<R>(TA, ag.buf[xb], j0, cnt, tid);
+  tile_in<R>(TB, ag.buf[eb], j0, cnt, tid);
+  __syncthreads();
+  if (tid < cnt) {
+    double x[4 * R], e[4 * R];
+    tile_get<R>(TA, tid, x);
+    tile_get<R>(TB, tid, e);
+#pragma unroll
+    for (int i = 0; i < 4 * R; ++i) x[i] += scale * e[i];
+    qf_inplace<R>(x);
+    tile_put<R>(TA, tid, x);
+  }
+  __syncthreads();
+  tile_out<R>(TA, ag.buf[ob], j0, cnt, tid);
+}
+
+// raw-pointer manifold ops (unit parity + set-up): OP 0 polar projection, 1 tangent projection, 2 retraction
+template <int R, int OP>
+__global__ __launch_bounds__(64) void k_raw_op(const double *X, const double *V, double *out, int n) {
+  const int j0 = blockIdx.x * 64, tid = threadIdx.x;
+  const int cnt = min(64, n - j0);
+  __shared__ Tile<R> TA, TB;
+  tile_in<R>(TA, X, j0, cnt, tid);
+  if (OP != 0) tile_in<R>(TB, V, j0, cnt, tid);
+  __syncthreads();
+  if (tid < cnt) {
+    double x[4 * R], v[4 * R];
+    tile_get<R>(TA, tid, x);
+    if (OP == 0) { polar_inplace<R>(x); tile_put<R>(TA, tid, x); }
+    if (OP == 1) { tile_get<R>(TB, tid, v); tangent_inplace<R>(x, v); tile_put<R>(TA, tid, v); }
+    if (OP == 2) {
+      tile_get<R>(TB, tid, v);
+#pragma unroll
+      for (int i = 0; i < 4 * R; ++i) x[i] += v[i];
+      qf_inplace<R>(x);
+      tile_put<R>(TA, tid, x);
+    }
+  }
+  __syncthreads();
+  tile_out<R>(TA, out, j0, cnt, tid);
+}
+
+template <int R>
+__global__ __launch_bounds__(64) void k_nest_pre(const AgentDev *agents, TeamDev *team, int sel, int only_agent,
+                                                 int num_robots, int restart_interval) {
+  __shared__ Tile<R> TX, TV;
+  nest_pre_body<R>(agents, team, sel, only_agent, num_robots, restart_interval, (int)blockIdx.x, (int)blockIdx.y, TX, TV);
+}
+
+// after the selected agent's local solve (unfused path):  V = proj(V + gamma' (X - Y)); on restart
+// X = XPrev (the host then re-optimizes from XPrev and calls k_nest_reset).
+template <int R>
+__global__ __launch_bounds__(64) void k_nest_post(const AgentDev *agents, const TeamDev *team, int sel, int num_robots,
+                                                  int restart_interval) {
+  const AgentDev &ag = agents[sel_cur(team, sel)];
+  const int j0 = blockIdx.x * 64, tid = threadIdx.x;
+  if (j0 >= ag.n) return;
+  const int cnt = min(64, ag.n - j0);
+  const NestState ns = *ag.nest;
+  const double Nr = (double)num_robots;
+  const double gamma = (1.0 + sqrt(1.0 + 4.0 * Nr * Nr * ns.gamma * ns.gamma)) / (2.0 * Nr);
+  const bool restart = ((ns.iter + 2) % restart_interval) == 0;
+  __shared__ Tile<R> TX, TV, TY;
+  if (restart) {
+    tile_in<R>(TX, ag.buf[B_XPREV], j0, cnt, tid);
+    __syncthreads();
+    tile_out<R>(TX, ag.buf[B_X], j0, cnt, tid);
+    return;
+  }
+  tile_in<R>(TX, ag.buf[B_X], j0, cnt, tid);
+  tile_in<R>(TV, ag.buf[B_V], j0, cnt, tid);
+  tile_in<R>(TY, ag.buf[B_Y], j0, cnt, tid);
+  __syncthreads();
+  if (tid < cnt) {
+    double x[4 * R], v[4 * R], y[4 * R];
+    tile_get<R>(TX, tid, x);
+    tile_get<R>(TV, tid, v);
+    tile_get<R>(TY, tid, y);
+#pragma unroll
+    for (int i = 0; i < 4 * R; ++i) v[i] += gamma * (x[i] - y[i]);
+    polar_inplace<R>(v);
+    tile_put<R>(TV, tid, v);
+  }
+  __syncthreads();
+  tile_out<R>(TV, ag.buf[B_V], j0, cnt, tid);
+}
+
+// V = X; Y = X  (restart tail / weight update)
+__global__ void k_nest_reset(const AgentDev *agents, const TeamDev *team, int sel, int r) {
+  const AgentDev &ag = agents[sel_cur(team, sel)];
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ag.N4 * r) return;
+  const double x = ag.buf[B_X][t];
+  ag.buf[B_V][t] = x;
+  ag.buf[B_Y][t] = x;
+}
+
+// end of an iteration (unfused paths): advance gamma/alpha/iter of every agent, and the team counter
+__global__ void k_advance(const AgentDev *agents, TeamDev *team, int only_agent, int accel, int num_robots,
+                          int restart_interval, int bump_team, int inc, int team_inc) {
+  const int ai = only_agent >= 0 ? only_agent : (int)blockIdx.x;
+  if (threadIdx.x != 0) return;
+  advance_agent(agents[ai], accel, num_robots, restart_interval, inc);
+  if (bump_team && ai == 0) team->iter += team_inc;
+}
+
+// PART_D partial [0] = |X - XPrev|_F^2 over a 64-pose tile (blockIdx.y = agent when sel == -3)
+template <int R>
+__global__ __launch_bounds__(64) void k_status(const AgentDev *agents, const TeamDev *team, int sel, int only_agent) {
+  const int ai = only_agent >= 0 ? only_agent : (sel == -3 ? (int)blockIdx.y : sel_cur(team, sel));
+  const AgentDev &ag = agents[ai];
+  const int j0 = blockIdx.x * 64, tid = threadIdx.x;
+  if (j0 >= ag.n) return;
+  const size_t lo = (size_t)j0 * 4 * R, hi = (size_t)min(ag.n, j0 + 64) * 4 * R;
+  double s = 0, xa[4 * R], xb[4 * R];
+#pragma unroll
+  for (int k = 0; k < 4 * R; ++k) {
+    const size_t t = lo + tid + 64 * k;
+    xa[k] = (t < hi) ? ag.buf[B_X][t] : 0.0;
+    xb[k] = (t < hi) ? ag.buf[B_XPREV][t] : 0.0;
+  }
+#pragma unroll
+  for (int k = 0; k < 4 * R; ++k) { const double d = xa[k] - xb[k]; s += d * d; }
+  s = wave_sum(s);
+  if (tid == 0) ag.part[PART_D + (size_t)blockIdx.x * PART_STRIDE] = s;
+}
+
+// buf[to] = buf[from] for one agent or (sel == -3) every agent (blockIdx.y).  As the first kernel of a
+// non-accelerated iteration (publish != 0) it also publishes team->cur_sel.
+__global__ void k_copy(const AgentDev *agents, TeamDev *team, int sel, int only_agent, int r, int from, int to,
+                       int publish) {
+  const int ai = only_agent >= 0 ? only_agent : (sel == -3 ? (int)blockIdx.y : sel_cur(team, sel));
+  if (publish && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+    team->cur_sel = team->sched[team->iter % team->sched_len];
+  const AgentDev &ag = agents[ai];
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ag.N4 * r) return;
+  ag.buf[to][t] = ag.buf[from][t];
+}
+
+// trust-region set-up from the initial evaluation partials
+template <int R>
+__global__ void k_rtr_begin(const AgentDev *agents, const TeamDev *team, int sel, double Delta0, double tol,
+                            int max_outer) {
+  const AgentDev &ag = agents[sel_cur(team, sel)];
+  const int lane = threadIdx.x;
+  const int nb = spmm_blocks<R>(ag.n);
+  const double f = sum_partials(ag.part + PART_A, nb, PART_STRIDE, lane);
+  const double g = sum_partials(ag.part + PART_A + 1, nb, PART_STRIDE, lane);
+  if (lane != 0) return;
+  RtrState S = {};
+  S.f1 = f; S.ngf = sqrt(g); S.Delta = Delta0;
+  S.f_init = f; S.gn_init = S.ngf;
+  S.outer_done = (S.ngf < tol) || (max_outer <= 0);
+  S.need_init = 1;
+  ag.st[0] = S;
+  ag.st[1] = S;
+}
+
+// outer step, acceptance test + radius update (ROPTLIB SolversTR constants: accept rho > 0.1,
+// grow x2 when rho > 0.75 at the boundary, shrink x0.25 when rho < 0.25)
+template <int R>
+__global__ void k_rtr_accept(const AgentDev *agents, const TeamDev *team, int sel, int sp, double tol, int max_outer,
+                             double max_radius) {
+  const AgentDev &ag = agents[sel_cur(team, sel)];
+  const RtrState S = ag.st[sp];
+  if (S.outer_done || S.tcg_active || S.need_init) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) ag.st[sp ^ 1] = S;
+    return;
+  }
+  const int lane = threadIdx.x & 63;
+  const int nb = spmm_blocks<R>(ag.n);
+  const double f2 = sum_partials(ag.part + PART_C, nb, PART_STRIDE, lane);
+  const double g2 = sum_partials(ag.part + PART_C + 1, nb, PART_STRIDE, lane);
+  const double ge = sum_partials(ag.part + PART_C + 2, nb, PART_STRIDE, lane);
+  const double eh = sum_partials(ag.part + PART_C + 3, nb, PART_STRIDE, lane);
+  const double rho = (S.f1 - f2) / (-ge - 0.5 * eh);
+  const bool accept = rho > 0.1;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    RtrState T = S;
+    if (rho > 0.75) {
+      if (S.tcg_status == 1 || S.tcg_status == 2) T.Delta = fmin(2.0 * S.Delta, max_radius);
+    } else if (rho < 0.25) {
+      T.Delta = 0.25 * S.Delta;
+    }
+    if (accept) { T.f1 = f2; T.ngf = sqrt(g2); T.accepted = S.accepted + 1; }
+    T.hv_count = S.hv_count + 1;
+    T.outer_it = S.outer_it + 1;
+    T.outer_done = (T.outer_it >= max_outer) || (T.ngf < tol);
+    T.tcg_active = 0;
+    T.need_init = 1;
+    ag.st[sp ^ 1] = T;
+  }
+  if (!accept) return;
+  const size_t len = (size_t)ag.n * 4 * R;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < len; t += (size_t)gridDim.x * blockDim.x) {
+    ag.buf[B_X][t] = ag.buf[B_X2][t];
+    ag.buf[B_EGRAD][t] = ag.buf[B_EGRAD2][t];
+    ag.buf[B_GF][t] = ag.buf[B_GF2][t];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// exchange (a7): packed slabs in public_pose_ids / neighbor_pose_ids order
+template <int R>
+__global__ void k_pack(const double *X, const int *frames, int count, double *out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= count * 4 * R) return;
+  const int q = t / (4 * R), k = t - q * 4 * R;
+  out[t] = X[(size_t)frames[q] * 4 * R + k];
+}
+
+template <int R>
+__global__ void k_unpack(double *slab, const int *slots, int count, const double *in) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= count * 4 * R) return;
+  const int q = t / (4 * R), k = t - q * 4 * R;
+  slab[(size_t)slots[q] * 4 * R + k] = in[t];
+}
+
+// per-edge residual sqrt(kappa |Y_j - Y_i R|^2 + tau |p_j - p_i - Y_i t|^2) (a8) and cost partials
+template <int R>
+__global__ void k_residuals(const AgentDev *agents, int ai) {
+  const AgentDev &ag = agents[ai];
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= ag.nedges) return;
+  const EdgeDev &m = ag.edges[e];
+  const double *Xi = m.i_local >= 0 ? ag.buf[B_X] + (size_t)m.i_local * 4 * R : ag.nbr[0] + (size_t)m.i_slot * 4 * R;
+  const double *Xj = m.j_local >= 0 ? ag.buf[B_X] + (size_t)m.j_local * 4 * R : ag.nbr[0] + (size_t)m.j_slot * 4 * R;
+  double sr = 0, st = 0;
+#pragma unroll
+  for (int x = 0; x < R; ++x) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      double v = Xj[c * R + x];
+#pragma unroll
+      for (int b = 0; b < 3; ++b) v -= Xi[b * R + x] * m.R[3 * b + c];
+      sr += v * v;
+    }
+    double v = Xj[3 * R + x] - Xi[3 * R + x];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) v -= Xi[b * R + x] * m.t[b];
+    st += v * v;
+  }
+  ag.resid[e] = sqrt(m.kappa * sr + m.tau * st);
+}
+
+// scal[5] = sum over owned edges of w/2 * residual^2   (single workgroup, fixed order)
+__global__ __launch_bounds__(256) void k_cost(const AgentDev *agents, int ai) {
+  const AgentDev &ag = agents[ai];
+  __shared__ double red[4];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  double s = 0;
+  for (int e = tid; e < ag.nedges; e += 256) {
+    const EdgeDev &m = ag.edges[e];
+    if (m.count_in_cost) s += 0.5 * m.weight * ag.resid[e] * ag.resid[e];
+  }
+  s = wave_sum(s);
+  if (lane == 0) red[w] = s;
+  __syncthreads();
+  if (tid == 0) ag.scal[5] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ void k_noop(const AgentDev *agents, int ai) { (void)agents; (void)ai; }
+
+// dense A = Q + shift I from the block-CSR (column-major N4 x N4; A must be zeroed first)
+__global__ void k_bsr_to_dense(const int *rowptr, const int *col, const double *qval, int n, double shift, double *A) {
+  const int j = blockIdx.x;  // block row = output pose = column block of A
+  const int N4 = 4 * n;
+  for (int p = rowptr[j] + threadIdx.x / 16; p < rowptr[j + 1]; p += blockDim.x / 16) {
+    const int e = threadIdx.x % 16, cp = e % 4, c = e / 4;
+    const int i = col[p];
+    double v = qval[(size_t)16 * p + e];
+    if (i == j && cp == c) v += shift;
+    A[(size_t)(4 * j + c) * N4 + 4 * i + cp] = v;
+  }
+}
+
+void launch_retract(const LaunchCtx &c, int sel, int max_n, int xb, int eb, double scale, int ob, int guard_state) {
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_retract<R>, dim3((max_n + 63) / 64, c.ny), dim3(64), 0, c.stream, c.agents,
+                                          c.team, sel, xb, eb, scale, ob, guard_state));
+}
+
+void launch_project_raw(const LaunchCtx &c, const double *X, double *out, int n) {
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL((k_raw_op<R, 0>), dim3((n + 63) / 64), dim3(64), 0, c.stream, X, X, out, n));
+}
+
+void launch_tangent_raw(const LaunchCtx &c, const double *X, const double *V, double *out, int n) {
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL((k_raw_op<R, 1>), dim3((n + 63) / 64), dim3(64), 0, c.stream, X, V, out, n));
+}
+
+void launch_retract_raw(const LaunchCtx &c, const double *X, const double *E, double *out, int n) {
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL((k_raw_op<R, 2>), dim3((n + 63) / 64), dim3(64), 0, c.stream, X, E, out, n));
+}
+
+void launch_nest_pre(const LaunchCtx &c, int sel, int only_agent, int num_agents, int max_n, int num_robots,
+                     int restart_interval) {
+  dim3 grid((max_n + 63) / 64, only_agent >= 0 ? 1 : num_agents);
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_nest_pre<R>, grid, dim3(64), 0, c.stream, c.agents, c.team, sel, only_agent,
+                                          num_robots, restart_interval));
+}
+
+void launch_nest_post(const LaunchCtx &c, int sel, int max_n, int num_robots, int restart_interval) {
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_nest_post<R>, dim3((max_n + 63) / 64), dim3(64), 0, c.stream, c.agents,
+                                          c.team, sel, num_robots, restart_interval));
+}
+
+void launch_nest_reset(const LaunchCtx &c, int sel, int max_n) {
+  const int len = max_n * 4 * c.r;
+  hipLaunchKernelGGL(k_nest_reset, dim3((len + 255) / 256), dim3(256), 0, c.stream, c.agents, c.team, sel, c.r);
+}
+
+void launch_advance(const LaunchCtx &c, int only_agent, int num_agents, int accel, int num_robots, int restart_interval,
+                    int bump_team, int inc, int team_inc) {
+  hipLaunchKernelGGL(k_advance, dim3(only_agent >= 0 ? 1 : num_agents), dim3(64), 0, c.stream, c.agents, c.team,
+                     only_agent, accel, num_robots, restart_interval, bump_team, inc, team_inc < 0 ? inc : team_inc);
+}
+
+void launch_status(const LaunchCtx &c, int sel, int only_agent, int num_agents, int max_n) {
+  dim3 grid((max_n + 63) / 64, (sel == -3 && only_agent < 0) ? num_agents : 1);
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_status<R>, grid, dim3(64), 0, c.stream, c.agents, c.team, sel, only_agent));
+}
+
+void launch_rtr_begin(const LaunchCtx &c, int sel, double Delta0, double tol, int max_outer) {
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_rtr_begin<R>, dim3(1, c.ny), dim3(64), 0, c.stream, c.agents, c.team, sel, Delta0,
+                                          tol, max_outer));
+}
+
+void launch_rtr_accept(const LaunchCtx &c, int sel, int max_n, int sp, double tol, int max_outer, double max_radius) {
+  const int len = max_n * 4 * c.r;
+  int grid = (len + 255) / 256;
+  if (grid > 64) grid = 64;
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_rtr_accept<R>, dim3(grid, c.ny), dim3(256), 0, c.stream, c.agents, c.team, sel,
+                                          sp, tol, max_outer, max_radius));
+}
+
+void launch_pack(const LaunchCtx &c, const double *X, const int *frames, int count, double *out) {
+  if (count <= 0) return;
+  const int len = count * 4 * c.r;
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_pack<R>, dim3((len + 255) / 256), dim3(256), 0, c.stream, X, frames, count,
+                                          out));
+}
+
+void launch_unpack(const LaunchCtx &c, double *slab, const int *slots, int count, const double *in) {
+  if (count <= 0) return;
+  const int len = count * 4 * c.r;
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_unpack<R>, dim3((len + 255) / 256), dim3(256), 0, c.stream, slab, slots,
+                                          count, in));
+}
+
+void launch_residuals(const LaunchCtx &c, int ai, int nedges) {
+  if (nedges <= 0) return;
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_residuals<R>, dim3((nedges + 63) / 64), dim3(64), 0, c.stream, c.agents, ai));
+}
+
+void launch_noop(const LaunchCtx &c, int grid, int block) {
+  hipLaunchKernelGGL(k_noop, dim3(grid), dim3(block), 0, c.stream, c.agents, 0);
+}
+
+void launch_cost(const LaunchCtx &c, int ai) {
+  hipLaunchKernelGGL(k_cost, dim3(1), dim3(256), 0, c.stream, c.agents, ai);
+}
+
+void launch_copy(const LaunchCtx &c, int sel, int only_agent, int num_agents, int max_n, int from, int to, int publish) {
+  const int len = max_n * 4 * c.r;
+  dim3 grid((len + 255) / 256, (sel == -3 && only_agent < 0) ? num_agents : 1);
+  hipLaunchKernelGGL(k_copy, grid, dim3(256), 0, c.stream, c.agents, c.team, sel, only_agent, c.r, from, to, publish);
+}
+
+void launch_bsr_to_dense(hipStream_t s, const int *rowptr, const int *col, const double *qval, int n, double shift,
+                         double *A) {
+  (void)hipMemsetAsync(A, 0, sizeof(double) * (size_t)16 * n * n, s);
+  hipLaunchKernelGGL(k_bsr_to_dense, dim3(n), dim3(64), 0, s, rowptr, col, qval, n, shift, A);
+}
+
+}  // namespace dpgo

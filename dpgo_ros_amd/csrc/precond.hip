@@ -1,0 +1,413 @@
+// precond.hip -- the dense preconditioner apply z = P_X(v (Q + shift I)^-1) (PreConditioner) and the
+// solver steps fused into it: tCG set-up and step (a4), the RGD step with the Nesterov V update and the look-ahead
+// Nesterov step of the pipelined iteration (a4, a6).  The one kernel of the path that streams HBM.
+#include "kernel_common.h"
+
+namespace dpgo {
+
+// ------------------------------------------------------------------------------------------------
+// Dense preconditioner apply  z = P_X( v (Q + shift I)^-1 )  (a3 PreConditioner).
+// Workgroup = 256 threads = 8 scalar columns (2 poses) x 32 k-lanes.  M (the only large operand,
+// N4^2 doubles, streamed exactly once, non-temporal so it does not evict the small operands from
+// L2) is fetched with 16-byte coalesced loads that are ALL issued before the first use: one memory
+// round trip per 2048-row chunk.  The input vector is staged in LDS as SoA [a][k].  Modes:
+//   PM_PLAIN    v = buf[vb]                        -> buf[zb]            partials [0]<z,v> [1]<v,v>
+//   PM_TCG_INIT v = gf; r0 = gf; eta = 0; d0 = -z  (tCG set-up, RtrState ping-pong)
+//   PM_TCG_STEP stages Hd only: r += alpha Hd, eta += alpha d, z += alpha P(Hd M)   (tCG body, part 2)
+//   PM_RGD      v = gf; X <- Retr_X(-step z); [V <- proj(V + gamma (X - Y))]; partial [2] |X - XPrev|^2
+//               (the whole RGD step + Nesterov V update of the two poses this workgroup owns)
+//               ahead (pipelined iterations, see k_eval_stats): bit 0 = the first wave also takes the Nesterov step of
+//               iteration k+1 of its two poses, bit 1 = the second wave takes it for the workgroup's share of the
+//               other agents' poses; advance: 1 = end-of-iteration bookkeeping here, 2 = pipelined (publishes
+//               stats_sel / next_sel only)
+// KC = rows of M (scalars of the input vector) handled per chunk: KC * R * 8 bytes of LDS and KC / 64
+// 16-byte registers per lane.  One 2048-row chunk covers a 500-pose agent in a single round trip with one
+// workgroup per CU; larger agents use 1024-row chunks so that 3 workgroups fit a CU and one workgroup's
+// arithmetic overlaps the others' streams.
+
+template <int R, int MODE, int KC>
+__global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev *team, int sel, int xb, int vb,
+                                                 int zb, int sp, int max_inner, double step, int accel,
+                                                 int num_robots, int advance, int restart_interval, int ahead) {
+  // XCD-aware block order: hardware workgroup h runs on XCD h % 8 (each with its own L2).  Logical block
+  // (h % 8) * (grid / 8) + h / 8 gives every XCD one contiguous range of poses, so that the cache lines shared by
+  // neighbouring poses (a pose is 4R doubles, not a multiple of a line) are written inside one L2 instead of
+  // being split between two.  The grid is padded to a multiple of 8; padding blocks fall out at the nblk test.
+  const int bx = ((int)blockIdx.x % 8) * ((int)gridDim.x / 8) + (int)blockIdx.x / 8;
+  const AgentDev &ag = agents[sel_cur(team, sel)];
+  if (MODE == PM_RGD_ && advance == 2 && bx == 0 && threadIdx.x == 0) {
+    // pipelined iterations: nothing that a workgroup of THIS launch reads is written here (cur_sel, iter and the
+    // NestStates move in the next k_eval_stats); the next launch finds its statistics agent and its own agent
+    team->stats_sel = team->cur_sel;
+    team->next_sel = team->sched[(team->iter + 1) % team->sched_len];
+  }
+  if (MODE == PM_RGD_ && advance == 1 && bx == 0 && threadIdx.x == 0) {
+    // end-of-iteration bookkeeping of the whole team, folded here: no workgroup of this kernel reads
+    // team->iter (they use cur_sel) or a NestState (gamma' comes from scal[6]), and the next kernel that
+    // does (k_nest_pre of the following iteration) is ordered behind this launch
+    for (int k = 0; k < team->num_agents; ++k) advance_agent(agents[k], accel, num_robots, restart_interval);
+    team->iter += 1;
+    team->stats_sel = team->cur_sel;
+  }
+  constexpr int MREG = KC / 64;
+  __shared__ double vs[R * KC];
+  __shared__ double zs[8 * R];
+  __shared__ double Ysh[2 * 4 * R];
+  __shared__ double Esh[3][2 * 4 * R];  // PM_RGD: V, Yaux, XPrev of the two poses
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int N4 = ag.N4;
+  const int nblk = precond_blocks(N4);
+  if (bx >= nblk) return;
+
+  // ---- scalar prologue (identical in every workgroup)
+  double alpha = 0, tau = 0;
+  int jpar = 0;
+  bool boundary = false;
+  RtrState S;
+  if (MODE == PM_TCG_INIT_ || MODE == PM_TCG_STEP_) {
+    S = ag.st[sp];
+    // phase gating: the host enqueues [init, (hv, step) x J, retract, eval2, accept] patterns blindly;
+    // a kernel whose phase is not due forwards the state and returns
+    const bool idle = S.outer_done || (MODE == PM_TCG_STEP_ && !S.tcg_active) || (MODE == PM_TCG_INIT_ && !S.need_init);
+    if (idle) {
+      if (bx == 0 && tid == 0) ag.st[sp ^ 1] = S;
+      return;
+    }
+    if (MODE == PM_TCG_STEP_) {
+      const double d_Hd = sum_partials(ag.part + PART_A, spmm_blocks<R>(ag.n), PART_STRIDE, lane);
+      alpha = S.z_r / d_Hd;
+      const double e_Pe_new = S.e_Pe + 2.0 * alpha * S.e_Pd + alpha * alpha * S.d_Pd;
+      jpar = S.tcg_j & 1;
+      if (d_Hd <= 0 || e_Pe_new >= S.Delta * S.Delta) {
+        boundary = true;
+        tau = (-S.e_Pd + sqrt(S.e_Pd * S.e_Pd + S.d_Pd * (S.Delta * S.Delta - S.e_Pe))) / S.d_Pd;
+        if (bx == 0 && tid == 0) {
+          RtrState T = S;
+          T.tcg_active = 0;
+          T.tcg_status = (d_Hd <= 0) ? 1 : 2;
+          ag.st[sp ^ 1] = T;
+        }
+      } else if (bx == 0 && tid == 0) {
+        RtrState T = S;
+        T.e_Pe = e_Pe_new;
+        T.alpha = alpha;
+        T.tcg_j = S.tcg_j + 1;
+        T.pc_count = S.pc_count + 1;
+        ag.st[sp ^ 1] = T;
+      }
+    } else if (bx == 0 && tid == 0) {
+      RtrState T = S;
+      T.tcg_active = 1; T.tcg_j = 0; T.tcg_status = 0; T.need_init = 0;
+      T.e_Pd = 0; T.e_Pe = 0; T.alpha = 0;
+      T.pc_count = S.pc_count + 1;
+      T.outer_count = S.outer_count + 1;
+      ag.st[sp ^ 1] = T;
+    }
+  }
+
+  const double *Vin = (MODE == PM_PLAIN_) ? ag.buf[vb]
+                      : ((MODE == PM_TCG_INIT_ || MODE == PM_RGD_) ? ag.buf[B_GF] : ag.buf[jpar ? B_R1 : B_R0]);
+  const double *Hd = ag.buf[B_HD];
+  // tCG step: the preconditioned residual obeys the same recurrence as the residual,
+  //   r+ = r + alpha Hd   =>   z+ = P(r+ M) = z + alpha P(Hd M)      (P and M are linear),
+  // so only ONE vector (Hd) has to be pulled through every workgroup's LDS; r and z are updated in place by
+  // their owners.  (The oracle recomputes z from r+ directly; the two differ by round-off only.)
+  const double *Vstage = (MODE == PM_TCG_STEP_) ? Hd : Vin;
+  const int col0 = 8 * bx;
+  const int npose = min(2, ag.n - 2 * bx);
+
+  if (MODE == PM_TCG_STEP_) {
+    // eta += (alpha | tau) * delta on the two poses owned by this workgroup
+    const double *D = ag.buf[jpar ? B_D1 : B_D0];
+    double *E = ag.buf[B_ETA];
+    const double stepc = boundary ? tau : alpha;
+    if (tid < npose * 4 * R) {
+      const size_t o = (size_t)col0 * R + tid;
+      E[o] += stepc * D[o];
+    }
+    if (boundary) return;
+  }
+
+  // epilogue operands of the two poses this workgroup owns: requested now, consumed after the M stream
+  double pre_x = 0, pre_v = 0, pre_y = 0, pre_p = 0;
+  double nest_gamma = 0;
+  if (tid < npose * 4 * R) {
+    pre_x = ag.buf[xb][(size_t)col0 * R + tid];
+    if (MODE == PM_RGD_) {
+      pre_v = ag.buf[B_V][(size_t)col0 * R + tid];
+      pre_y = ag.buf[B_Y][(size_t)col0 * R + tid];
+      pre_p = ag.buf[B_XPREV][(size_t)col0 * R + tid];
+    }
+  }
+  double ahead_alpha = 0;
+  bool ahead_opt = false;
+  if (MODE == PM_RGD_ && accel) {
+    if (advance == 2) {
+      // the NestState describes iteration k-1 (it is advanced by the next k_eval_stats): gamma of this iteration,
+      // and gamma / alpha / selected agent of iteration k+1 for the look-ahead Nesterov step of the epilogue
+      const NestState ns = *ag.nest;
+      const double Nr = (double)num_robots;
+      nest_gamma = (1.0 + sqrt(1.0 + 4.0 * Nr * Nr * ns.gamma * ns.gamma)) / (2.0 * Nr);
+      const double g2 = (1.0 + sqrt(1.0 + 4.0 * Nr * Nr * nest_gamma * nest_gamma)) / (2.0 * Nr);
+      ahead_alpha = 1.0 / (g2 * Nr);
+      ahead_opt = team->sched[(team->iter + 1) % team->sched_len] == sel_cur(team, sel);
+    } else {
+      nest_gamma = ag.scal[6];
+    }
+  }
+  // Look-ahead, other agents (pipelined iterations): while the first wave finishes the step of this workgroup's
+  // two poses, the second wave takes the Nesterov step of iteration k+1 (what k_nest_pre would do next) for this
+  // workgroup's share of the poses of every OTHER agent -- one lane per pose, straight from / to global memory:
+  // XPrev = X; Y = proj((1 - alpha') X + alpha' V); X = Y; and for the agents that do not optimize at k+1:
+  // V = proj(V), |Y - X|^2 per pose into PART_D.  Disjoint data: this launch reads nothing else of those agents.
+  // The operands are requested next to the vector stage so that they arrive under the stream.  (The NestStates of
+  // all agents advance in lockstep, so alpha' is the one computed above.)
+  bool la_act = false, la_opt = false;
+  int la_agent = 0, la_pose = 0;
+  double la_x[4 * R], la_v[4 * R];
+  const int cg = tid >> 5, kl = tid & 31;
+  const int col = col0 + cg;
+  const bool cact = col < N4;
+  const double *Mc = ag.M + (size_t)(cact ? col : 0) * N4;
+  double acc[R];
+#pragma unroll
+  for (int a = 0; a < R; ++a) acc[a] = 0;
+
+  // Per chunk of KC rows: (1) the input vector is copied into LDS in its native [k][a] layout with one
+  // batch of 16-byte loads, (2) barrier, (3) the whole M slab of this workgroup is requested (32 x 16 B per
+  // lane, non-temporal), (4) the FMA loop drains the slab in issue order, so arithmetic overlaps the
+  // stream.  A lane reads the 2R contiguous doubles v[k][:], v[k+1][:] as R ds_read_b128 (16R-byte lane
+  // stride: conflict-free for R = 3, 5).  Measured (profiles/experiments/pc_bench.hip): ingest per CU, not HBM, is
+  // the limit -- every workgroup has to pull the full 8*R*N4-byte vector through L2 next to its slab.
+  constexpr int NSTG = (KC * R / 2 + 255) / 256;  // 16-byte pairs per lane per chunk
+  for (int k0 = 0; k0 < N4; k0 += KC) {
+    const int kn = min(KC, N4 - k0);
+    if (k0 > 0) __syncthreads();
+    {
+      double2 v[NSTG];
+#pragma unroll
+      for (int u = 0; u < NSTG; ++u) {
+        const int tt = 2 * (tid + 256 * u);  // kn * R is even
+        v[u] = (tt < kn * R) ? ld2(Vstage + (size_t)k0 * R + tt) : make_double2(0.0, 0.0);
+      }
+#pragma unroll
+      for (int u = 0; u < NSTG; ++u) {
+        const int tt = 2 * (tid + 256 * u);
+        if (tt < KC * R) *reinterpret_cast<double2 *>(&vs[tt]) = v[u];
+      }
+    }
+    __syncthreads();
+    double2 mreg[MREG];
+#pragma unroll
+    for (int m = 0; m < MREG; ++m) {
+      const int k = 2 * kl + 64 * m;
+      mreg[m] = (cact && k < kn) ? ld2_nt(Mc + k0 + k) : make_double2(0.0, 0.0);
+    }
+    if (k0 == 0 && MODE == PM_RGD_ && (ahead & 2)) {
+      // look-ahead operands of the second wave, requested right behind the M slab: they arrive under the stream.
+      // Every address comes from wave-uniform (scalar) loads -- a per-lane fetch of agents[a].buf would queue
+      // behind the vector stream and stall the wave.
+      const int self = sel_cur(team, sel);
+      int pre[LOOKAHEAD_MAX_AGENTS + 1];
+      const double *px[LOOKAHEAD_MAX_AGENTS], *pv[LOOKAHEAD_MAX_AGENTS];
+#pragma unroll
+      for (int k = 0; k <= LOOKAHEAD_MAX_AGENTS; ++k) pre[k] = team->pose_prefix[k];
+      const int na = team->num_agents;
+#pragma unroll
+      for (int k = 0; k < LOOKAHEAD_MAX_AGENTS; ++k) {
+        px[k] = (k < na) ? agents[k].buf[B_X] : nullptr;
+        pv[k] = (k < na) ? agents[k].buf[B_V] : nullptr;
+      }
+      const int total = pre[LOOKAHEAD_MAX_AGENTS] - ag.n;
+      const int per = (total + nblk - 1) / nblk;  // <= 64, checked by the host
+      const int l1 = tid - 64;
+      const int q = bx * per + l1;   // index among the poses of the other agents
+      if (l1 >= 0 && l1 < per && q < total) {
+        int self_lo = 0;
+#pragma unroll
+        for (int k = 0; k < LOOKAHEAD_MAX_AGENTS; ++k) if (k == self) self_lo = pre[k];
+        const int g = q < self_lo ? q : q + ag.n;  // index among all poses of the team
+        int a = 0, lo = 0;
+        const double *xa = px[0], *va = pv[0];
+#pragma unroll
+        for (int k = 1; k < LOOKAHEAD_MAX_AGENTS; ++k)
+          if (k < na && g >= pre[k]) { a = k; lo = pre[k]; xa = px[k]; va = pv[k]; }
+        la_act = true; la_agent = a; la_pose = g - lo;
+        la_opt = team->sched[(team->iter + 1) % team->sched_len] == a;
+        const size_t o = (size_t)la_pose * 4 * R;
+#pragma unroll
+        for (int i = 0; i < 4 * R; ++i) { la_x[i] = xa[o + i]; la_v[i] = va[o + i]; }
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < MREG; ++m) {
+      const int k = 2 * kl + 64 * m;
+      double w[2 * R];
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        const double2 t2 = *reinterpret_cast<const double2 *>(&vs[k * R + 2 * j]);
+        w[2 * j] = t2.x; w[2 * j + 1] = t2.y;
+      }
+#pragma unroll
+      for (int a = 0; a < R; ++a) acc[a] += w[a] * mreg[m].x + w[R + a] * mreg[m].y;
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < R; ++a) {
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) acc[a] += __shfl_xor(acc[a], off, 64);
+  }
+  if (kl == 0) {
+#pragma unroll
+    for (int a = 0; a < R; ++a) zs[cg * R + a] = acc[a];
+  }
+  if (tid < npose * 4 * R) {
+    Ysh[tid] = pre_x;
+    if (MODE == PM_RGD_) { Esh[0][tid] = pre_v; Esh[1][tid] = pre_y; Esh[2][tid] = pre_p; }
+  }
+  __syncthreads();
+
+  if (MODE == PM_RGD_ && (ahead & 2) && tid >= 64 && tid < 128) {
+    // look-ahead of the other agents' poses on the second wave (operands prefetched in the prologue)
+    if (la_act) {
+      const AgentDev &oa = agents[la_agent];
+      const size_t o = (size_t)la_pose * 4 * R;
+      double y[4 * R];
+#pragma unroll
+      for (int i = 0; i < 4 * R; ++i) y[i] = (1.0 - ahead_alpha) * la_x[i] + ahead_alpha * la_v[i];
+      polar_inplace<R>(y);
+      if (!la_opt) {
+        polar_inplace<R>(la_v);
+        double r2 = 0;
+#pragma unroll
+        for (int i = 0; i < 4 * R; ++i) { const double d = y[i] - la_x[i]; r2 += d * d; }
+        oa.part[PART_D + la_pose] = r2;
+      }
+#pragma unroll
+      for (int i = 0; i < 4 * R; ++i) {
+        oa.buf[B_XPREV][o + i] = la_x[i];
+        oa.buf[B_Y][o + i] = y[i];
+        oa.buf[B_X][o + i] = y[i];
+        if (!la_opt) oa.buf[B_V][o + i] = la_v[i];
+      }
+    }
+    return;
+  }
+  if (MODE == PM_RGD_) {
+    // one lane per pose finishes the step in registers: z = P(zs), X = qf(X - step z), V update
+    double rel = 0;
+    if (tid < npose) {
+      const int lp = tid;
+      const size_t o = (size_t)(2 * bx + lp) * 4 * R;
+      double x[4 * R], z[4 * R];
+#pragma unroll
+      for (int i = 0; i < 4 * R; ++i) { x[i] = Ysh[lp * 4 * R + i]; z[i] = zs[lp * 4 * R + i]; }
+      tangent_inplace<R>(x, z);
+#pragma unroll
+      for (int i = 0; i < 4 * R; ++i) x[i] -= step * z[i];
+      qf_inplace<R>(x);
+#pragma unroll
+      for (int i = 0; i < 4 * R; ++i) {
+        if (!(ahead & 1)) ag.buf[B_X][o + i] = x[i];
+        ag.buf[B_X2][o + i] = x[i];  // snapshot for the final-statistics evaluation of this iteration
+        const double d = x[i] - Esh[2][lp * 4 * R + i];
+        rel += d * d;
+      }
+      double v[4 * R];
+      if (accel) {
+        const double gamma = nest_gamma;
+#pragma unroll
+        for (int i = 0; i < 4 * R; ++i) v[i] = Esh[0][lp * 4 * R + i] + gamma * (x[i] - Esh[1][lp * 4 * R + i]);
+        polar_inplace<R>(v);
+      }
+      if (accel && (ahead & 1)) {
+        // Nesterov step of iteration k+1 for this pose (what k_nest_pre would do next): XPrev = X,
+        // Y = proj((1 - alpha') X + alpha' V), X = Y, and V = proj(V) unless this agent is selected again
+        double y[4 * R];
+#pragma unroll
+        for (int i = 0; i < 4 * R; ++i) y[i] = (1.0 - ahead_alpha) * x[i] + ahead_alpha * v[i];
+        polar_inplace<R>(y);
+        if (!ahead_opt) {
+          polar_inplace<R>(v);
+          double rel2 = 0;
+#pragma unroll
+          for (int i = 0; i < 4 * R; ++i) { const double d = y[i] - x[i]; rel2 += d * d; }
+          ag.part[PART_D + 2 * bx + lp] = rel2;  // look-ahead steps leave |Y' - X|^2 per pose
+        }
+#pragma unroll
+        for (int i = 0; i < 4 * R; ++i) {
+          ag.buf[B_XPREV][o + i] = x[i];
+          ag.buf[B_Y][o + i] = y[i];
+          ag.buf[B_X][o + i] = y[i];
+        }
+      }
+      if (accel) {
+#pragma unroll
+        for (int i = 0; i < 4 * R; ++i) ag.buf[B_V][o + i] = v[i];
+      }
+    }
+    if (tid < 64) {
+      rel = wave_sum(rel);
+      if (tid == 0) ag.part[PART_B + (size_t)bx * PART_STRIDE + 2] = rel;
+    }
+    return;
+  }
+
+  // ---- epilogue: tangent projection of the two poses, dots, mode-specific stores
+  double zr = 0, rr = 0;
+  if (tid < npose * R) {
+    const int lp = tid / R, a = tid - lp * R;
+    const size_t o = (size_t)(2 * bx + lp) * 4 * R;
+    double z[4];
+    tangent_row<R>(Ysh + lp * 4 * R, zs + lp * 4 * R, a, z);
+    z[3] = zs[lp * 4 * R + 3 * R + a];
+    double *Z = ag.buf[(MODE == PM_PLAIN_) ? zb : B_Z];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      double v = Vin[o + c * R + a];
+      if (MODE == PM_TCG_STEP_) {
+        v += alpha * Hd[o + c * R + a];
+        ag.buf[jpar ? B_R0 : B_R1][o + c * R + a] = v;  // r_new into the other half
+        z[c] = Z[o + c * R + a] + alpha * z[c];         // z_new = z_old + alpha P(Hd M)
+      }
+      if (MODE == PM_TCG_INIT_) {
+        ag.buf[B_R0][o + c * R + a] = v;
+        ag.buf[B_ETA][o + c * R + a] = 0.0;
+        ag.buf[B_D0][o + c * R + a] = -z[c];
+      }
+      Z[o + c * R + a] = z[c];
+      zr += z[c] * v;
+      rr += v * v;
+    }
+  }
+  if (tid < 64) {
+    zr = wave_sum(zr);
+    rr = wave_sum(rr);
+    if (tid == 0) {
+      double *P = ag.part + PART_B + (size_t)bx * PART_STRIDE;
+      P[0] = zr; P[1] = rr;
+    }
+  }
+}
+
+void launch_precond(const LaunchCtx &c, int sel, int max_n, int mode, int xb, int vb, int zb, int sp, int max_inner,
+                    double step, int accel, int num_robots, int advance, int restart_interval, int ahead) {
+  const int grid = (((4 * max_n + 7) / 8) + 7) / 8 * 8;  // multiple of 8: see the XCD-aware block order in k_precond
+#define PC_CALL(M)                                                                                                  \
+  if (4 * max_n > 1024 && 4 * max_n <= 2048) {                                                                       \
+    DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL((k_precond<R, M, 2048>), dim3(grid, c.ny), dim3(256), 0, c.stream, c.agents,   \
+                                            c.team, sel, xb, vb, zb, sp, max_inner, step, accel, num_robots, advance,   \
+                                            restart_interval, ahead));                                                \
+  } else {                                                                                                           \
+    DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL((k_precond<R, M, 1024>), dim3(grid, c.ny), dim3(256), 0, c.stream, c.agents,   \
+                                            c.team, sel, xb, vb, zb, sp, max_inner, step, accel, num_robots, advance,   \
+                                            restart_interval, ahead));                                                \
+  }
+  if (mode == PM_PLAIN_) { PC_CALL(PM_PLAIN_); }
+  else if (mode == PM_TCG_INIT_) { PC_CALL(PM_TCG_INIT_); }
+  else if (mode == PM_TCG_STEP_) { PC_CALL(PM_TCG_STEP_); }
+  else { PC_CALL(PM_RGD_); }
+#undef PC_CALL
+}
+
+}  // namespace dpgo

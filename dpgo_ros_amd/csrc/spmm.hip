@@ -1,0 +1,340 @@
+// spmm.hip -- block-sparse kernels: G assembly, cost / gradient, Hessian-vector products, the tCG Hessian step,
+// the trust-region trial evaluation and the heterogeneous evaluation launches of the fused RGD iteration
+// (SURVEY 8a rows a2, a3, a4).  One lane owns one (pose, row) pair; see kernel_common.h for the layout.
+#include "kernel_common.h"
+
+namespace dpgo {
+
+// ------------------------------------------------------------------------------------------------
+// stand-alone G assembly.  One lane per (public pose, row a).  pull != 0: read the neighbour's pose
+// straight from the neighbour agent's X / Y array on this GPU (device-to-device exchange that
+// replaces the PublicPoses topic) and refresh the slab; else read the slab filled by unpack.
+template <int R>
+__global__ __launch_bounds__(64) void k_buildG(const AgentDev *agents, const TeamDev *team, int sel, int aux,
+                                               int pull) {
+  const AgentDev &ag = agents[sel_cur(team, sel)];
+  constexpr int PPB = 64 / R;
+  const int lane = threadIdx.x, lp = lane / R, a = lane - lp * R;
+  const int q = blockIdx.x * PPB + lp;
+  if (lp >= PPB || q >= ag.npub) return;
+  double g[4];
+  g_row<R>(agents, ag, q, a, aux, pull, g);
+  double *G = ag.buf[B_G] + (size_t)ag.pub_pose[q] * 4 * R;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) G[c * R + a] = g[c];
+}
+
+// refresh every slab entry of one agent from co-resident neighbours (both sequences)
+template <int R>
+__global__ void k_pull(const AgentDev *agents, int dst) {
+  const AgentDev &ag = agents[dst];
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ag.nshared * 4 * R) return;
+  const int e = t / (4 * R), k = t - e * 4 * R;
+  const SharedEdgeDev &se = ag.se[e];
+  if (se.src_agent_local < 0) return;
+  const AgentDev &sa = agents[se.src_agent_local];
+  ag.nbr[0][(size_t)se.slot * 4 * R + k] = sa.buf[B_X][(size_t)se.src_frame * 4 * R + k];
+  ag.nbr[1][(size_t)se.slot * 4 * R + k] = sa.buf[B_Y][(size_t)se.src_frame * 4 * R + k];
+}
+
+template <int R>
+__global__ __launch_bounds__(64) void k_eval(const AgentDev *agents, const TeamDev *team, int sel, int xb, int egb,
+                                             int gfb, int poff, int gmode, int aux) {
+  constexpr int PPB = 64 / R;
+  __shared__ double Ysh[PPB * 4 * R], Wsh[PPB * 4 * R];
+  eval_body<R>(agents, team, sel, xb, egb, gfb, poff, gmode, aux, (int)blockIdx.x, Ysh, Wsh);
+}
+
+// generic Riemannian Hessian-vector product at point xb with Euclidean gradient egb:  ob = Hess[vb]
+// partials: [0] <v, Hv>
+template <int R>
+__global__ __launch_bounds__(64) void k_hess(const AgentDev *agents, const TeamDev *team, int sel, int xb, int egb,
+                                             int vb, int ob, int poff) {
+  const AgentDev &ag = agents[sel_cur(team, sel)];
+  constexpr int PPB = 64 / R;
+  __shared__ double Ysh[PPB * 4 * R], Esh[PPB * 4 * R], Wsh[PPB * 4 * R];
+  const int lane = threadIdx.x, lp = lane / R, a = lane - lp * R;
+  const int j = blockIdx.x * PPB + lp;
+  if (blockIdx.x * PPB >= ag.n) return;
+  const bool act = lp < PPB && j < ag.n;
+  const double *V = ag.buf[vb];
+  double w[1][4] = {{0, 0, 0, 0}}, vrow[4] = {0, 0, 0, 0}, hrow[4];
+  if (act) {
+    spmm_row<R, 1>(ag, j, [&](int i, double(*x)[4]) {
+#pragma unroll
+      for (int cp = 0; cp < 4; ++cp) x[0][cp] = V[((size_t)4 * i + cp) * R + a];
+    }, w);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      vrow[c] = V[((size_t)4 * j + c) * R + a];
+      Ysh[lp * 4 * R + c * R + a] = ag.buf[xb][((size_t)4 * j + c) * R + a];
+      Esh[lp * 4 * R + c * R + a] = ag.buf[egb][((size_t)4 * j + c) * R + a];
+    }
+  }
+  __syncthreads();
+  hess_tail<R>(Ysh + lp * 4 * R, Esh + lp * 4 * R, Wsh + lp * 4 * R, a, w[0], vrow, hrow, act);
+  double d = 0;
+  if (act) {
+    double *O = ag.buf[ob] + (size_t)j * 4 * R;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { O[c * R + a] = hrow[c]; d += vrow[c] * hrow[c]; }
+  }
+  d = wave_sum(d);
+  if (lane == 0) ag.part[poff + (size_t)blockIdx.x * PART_STRIDE] = d;
+}
+
+// ------------------------------------------------------------------------------------------------
+// tCG body, part 1:  delta <- -z + beta delta (on the fly), Hd = Hess[delta], partial <delta, Hd>.
+template <int R>
+__global__ __launch_bounds__(64) void k_tcg_hv(const AgentDev *agents, const TeamDev *team, int sel, int sp,
+                                               int max_inner) {
+  const AgentDev &ag = agents[sel_cur(team, sel)];
+  constexpr int PPB = 64 / R;
+  __shared__ double Ysh[PPB * 4 * R], Esh[PPB * 4 * R], Wsh[PPB * 4 * R];
+  const int lane = threadIdx.x, lp = lane / R, a = lane - lp * R;
+  const int j = blockIdx.x * PPB + lp;
+  if (blockIdx.x * PPB >= ag.n) return;
+  const RtrState S = ag.st[sp];
+  if (S.outer_done || !S.tcg_active) {
+    if (blockIdx.x == 0 && lane == 0) ag.st[sp ^ 1] = S;
+    return;
+  }
+  const double kappa = 0.1;  // tCG stop: |r| <= |r0| min(|r0|^theta, kappa) with theta = 1
+  const int npb = precond_blocks(ag.N4);
+  double zr_new, rr_new;
+  sum_partials2(ag.part + PART_B, npb, PART_STRIDE, lane, zr_new, rr_new);
+  RtrState T = S;
+  double beta = 0;
+  const bool fresh = (S.tcg_j == 0);
+  if (fresh) {
+    T.z_r = zr_new; T.d_Pd = zr_new; T.norm_r0 = sqrt(rr_new);
+  } else {
+    const double nr = sqrt(rr_new);
+    const double thr = S.norm_r0;
+    bool stop = false;
+    if (nr <= S.norm_r0 * (thr < kappa ? thr : kappa)) { T.tcg_status = (kappa < thr) ? 3 : 4; stop = true; }
+    else if (S.tcg_j >= max_inner) { T.tcg_status = 0; stop = true; }
+    if (stop) {
+      T.tcg_active = 0;
+      if (blockIdx.x == 0 && lane == 0) ag.st[sp ^ 1] = T;
+      return;
+    }
+    beta = zr_new / S.z_r;
+    T.e_Pd = beta * (S.e_Pd + S.alpha * S.d_Pd);
+    T.d_Pd = zr_new + beta * beta * S.d_Pd;
+    T.z_r = zr_new;
+  }
+  T.hv_count = S.hv_count + 1;
+  T.tcg_total = S.tcg_total + 1;
+  if (blockIdx.x == 0 && lane == 0) ag.st[sp ^ 1] = T;
+
+  const bool act = lp < PPB && j < ag.n;
+  const int jp = S.tcg_j & 1;
+  const double *Dold = ag.buf[jp ? B_D0 : B_D1];  // delta of iteration j-1
+  double *Dnew = ag.buf[jp ? B_D1 : B_D0];        // delta of iteration j (T0 wrote D0 for j = 0)
+  const double *Z = ag.buf[B_Z];
+  double w[1][4] = {{0, 0, 0, 0}}, vrow[4] = {0, 0, 0, 0}, hrow[4];
+  if (act) {
+    spmm_row<R, 1>(ag, j, [&](int i, double(*x)[4]) {
+#pragma unroll
+      for (int cp = 0; cp < 4; ++cp) {
+        const size_t o = ((size_t)4 * i + cp) * R + a;
+        x[0][cp] = fresh ? Dnew[o] : (-Z[o] + beta * Dold[o]);
+      }
+    }, w);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const size_t o = ((size_t)4 * j + c) * R + a;
+      vrow[c] = fresh ? Dnew[o] : (-Z[o] + beta * Dold[o]);
+      if (!fresh) Dnew[o] = vrow[c];
+      Ysh[lp * 4 * R + c * R + a] = ag.buf[B_X][o];
+      Esh[lp * 4 * R + c * R + a] = ag.buf[B_EGRAD][o];
+    }
+  }
+  __syncthreads();
+  hess_tail<R>(Ysh + lp * 4 * R, Esh + lp * 4 * R, Wsh + lp * 4 * R, a, w[0], vrow, hrow, act);
+  double d = 0;
+  if (act) {
+    double *O = ag.buf[B_HD] + (size_t)j * 4 * R;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { O[c * R + a] = hrow[c]; d += vrow[c] * hrow[c]; }
+  }
+  d = wave_sum(d);
+  if (lane == 0) ag.part[PART_A + (size_t)blockIdx.x * PART_STRIDE] = d;
+}
+
+// Heterogeneous launch that closes iteration k and opens iteration k+1 inside captured graphs: the first
+// nest_tiles * num_agents workgroups run the Nesterov step of every agent (k_nest_pre), the rest evaluate
+// f_opt / gradnorm_opt of the agent that just optimized on its snapshot B_X2 (k_eval, sel = stats_sel).
+// The two halves touch disjoint data: the statistics read B_X2 / G of agent a, the Nesterov step writes
+// X, Y, V, XPrev; one launch boundary per iteration disappears.
+template <int R>
+__global__ __launch_bounds__(64) void k_stats_nest(const AgentDev *agents, TeamDev *team, int nest_tiles, int num_agents,
+                                                   int num_robots, int restart_interval) {
+  __shared__ Tile<R> TX, TV;
+  const int nb_nest = nest_tiles * num_agents;
+  const int b = (int)blockIdx.x;
+  if (b < nb_nest) {
+    nest_pre_body<R>(agents, team, -1, -1, num_robots, restart_interval, b % nest_tiles, b / nest_tiles, TX, TV);
+  } else {
+    eval_body<R>(agents, team, -5, B_X2, B_EGRAD2, B_GF2, PART_A, 0, 0, b - nb_nest, TX.d, TV.d);
+  }
+}
+
+// Pipelined accelerated RGD iterations (dpgo_team_run): two launches per iteration.
+//   k_eval_stats      cost / gradient of the agent of iteration k (G from the neighbours' Y)  ||  final statistics of
+//                     iteration k-1 on its snapshot  ||  end-of-iteration bookkeeping of k-1 (workgroup 0)
+//   k_precond<PM_RGD> preconditioned step + Nesterov V of iteration k and the Nesterov step of iteration k+1 of the same
+//                     poses (first wave of each workgroup)  ||  the Nesterov step of iteration k+1 of the workgroup's
+//                     share of every other agent's poses (second wave)
+// No workgroup reads what another workgroup of the same launch writes: this kernel's workgroups read next_sel /
+// stats_sel (written by the previous step kernel) while workgroup 0 moves iter, cur_sel and the NestStates, which
+// only the step kernel reads.
+template <int R>
+__global__ __launch_bounds__(64) void k_eval_stats(const AgentDev *agents, TeamDev *team, int nb_eval, int first,
+                                                   int has_eval, int has_stats, int num_robots, int restart_interval) {
+  constexpr int PPB = 64 / R;
+  __shared__ double Ysh[PPB * 4 * R], Wsh[PPB * 4 * R];
+  const int b = (int)blockIdx.x;
+  if (b == (int)gridDim.x - 1) {  // the extra workgroup: bookkeeping only, so that no evaluation waits for it
+    if (!first && threadIdx.x == 0) {
+      for (int k = 0; k < team->num_agents; ++k) advance_agent(agents[k], 1, num_robots, restart_interval);
+      team->iter += 1;
+      if (has_eval) team->cur_sel = team->next_sel;
+    }
+    return;
+  }
+  if (has_eval && b < nb_eval) {
+    eval_body<R>(agents, team, first ? -1 : -6, B_X, B_EGRAD, B_GF, PART_C, 2, 1, b, Ysh, Wsh);
+  } else if (has_stats) {
+    eval_body<R>(agents, team, -5, B_X2, B_EGRAD2, B_GF2, PART_A, 0, 0, b - (has_eval ? nb_eval : 0), Ysh, Wsh);
+  }
+}
+
+// outer step, evaluation at the candidate x2 = Retr_x1(eta):
+//   egrad2 = x2 Q + G, rgrad2, Heta = Hess_x1[eta];  partials [0] f2 [1] |rgrad2|^2 [2] <gf,eta> [3] <eta,Heta>
+// (both SpMM rows share every Q block load)
+template <int R>
+__global__ __launch_bounds__(64) void k_rtr_eval2(const AgentDev *agents, const TeamDev *team, int sel, int sp) {
+  const AgentDev &ag = agents[sel_cur(team, sel)];
+  constexpr int PPB = 64 / R;
+  __shared__ double Ysh[PPB * 4 * R], Esh[PPB * 4 * R], Wsh[PPB * 4 * R];
+  const int lane = threadIdx.x, lp = lane / R, a = lane - lp * R;
+  const int j = blockIdx.x * PPB + lp;
+  if (blockIdx.x * PPB >= ag.n) return;
+  {
+    const RtrState S = ag.st[sp];
+    if (S.outer_done || S.tcg_active || S.need_init) return;
+  }
+  const bool act = lp < PPB && j < ag.n;
+  const double *X2 = ag.buf[B_X2], *ETA = ag.buf[B_ETA];
+  double fpart = 0, gpart = 0, ge = 0, eh = 0;
+  double acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, vrow[4] = {0, 0, 0, 0}, hrow[4], eg[4] = {0, 0, 0, 0};
+  if (act) {
+    spmm_row<R, 2>(ag, j, [&](int i, double(*x)[4]) {
+#pragma unroll
+      for (int cp = 0; cp < 4; ++cp) {
+        x[0][cp] = X2[((size_t)4 * i + cp) * R + a];
+        x[1][cp] = ETA[((size_t)4 * i + cp) * R + a];
+      }
+    }, acc);
+    const bool pub = ag.pub_index[j] >= 0;
+    const double *G = ag.buf[B_G] + (size_t)j * 4 * R;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const size_t o = ((size_t)4 * j + c) * R + a;
+      const double xr = X2[o], g = pub ? G[c * R + a] : 0.0;
+      fpart += (0.5 * acc[0][c] + g) * xr;
+      eg[c] = acc[0][c] + g;
+      ag.buf[B_EGRAD2][o] = eg[c];
+      Ysh[lp * 4 * R + c * R + a] = xr;
+      Wsh[lp * 4 * R + c * R + a] = eg[c];
+    }
+  }
+  __syncthreads();
+  if (act) {
+    double o3[3];
+    tangent_row<R>(Ysh + lp * 4 * R, Wsh + lp * 4 * R, a, o3);
+    double *GF2 = ag.buf[B_GF2] + (size_t)j * 4 * R;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { GF2[c * R + a] = o3[c]; gpart += o3[c] * o3[c]; }
+    GF2[3 * R + a] = eg[3];
+    gpart += eg[3] * eg[3];
+  }
+  __syncthreads();
+  if (act) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const size_t o = ((size_t)4 * j + c) * R + a;
+      vrow[c] = ETA[o];
+      Ysh[lp * 4 * R + c * R + a] = ag.buf[B_X][o];
+      Esh[lp * 4 * R + c * R + a] = ag.buf[B_EGRAD][o];
+    }
+  }
+  __syncthreads();
+  hess_tail<R>(Ysh + lp * 4 * R, Esh + lp * 4 * R, Wsh + lp * 4 * R, a, acc[1], vrow, hrow, act);
+  if (act) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const size_t o = ((size_t)4 * j + c) * R + a;
+      ag.buf[B_HETA][o] = hrow[c];
+      ge += ag.buf[B_GF][o] * vrow[c];
+      eh += vrow[c] * hrow[c];
+    }
+  }
+  fpart = wave_sum(fpart); gpart = wave_sum(gpart); ge = wave_sum(ge); eh = wave_sum(eh);
+  if (lane == 0) {
+    double *P = ag.part + PART_C + (size_t)blockIdx.x * PART_STRIDE;
+    P[0] = fpart; P[1] = gpart; P[2] = ge; P[3] = eh;
+  }
+}
+
+void launch_buildG(const LaunchCtx &c, int sel, int max_npub, int aux, int pull) {
+  if (max_npub <= 0) return;
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_buildG<R>, dim3(spmm_grid(c.r, max_npub), c.ny), dim3(64), 0, c.stream, c.agents,
+                                          c.team, sel, aux, pull));
+}
+
+void launch_pull(const LaunchCtx &c, int dst, int nshared) {
+  if (nshared <= 0) return;
+  const int len = nshared * 4 * c.r;
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_pull<R>, dim3((len + 255) / 256), dim3(256), 0, c.stream, c.agents, dst));
+}
+
+void launch_eval(const LaunchCtx &c, int sel, int max_n, int xb, int egb, int gfb, int poff, const EvalOpts &o) {
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_eval<R>, dim3(spmm_grid(c.r, max_n), c.ny), dim3(64), 0, c.stream, c.agents,
+                                          c.team, sel, xb, egb, gfb, poff, o.gmode, o.aux));
+}
+
+void launch_hess(const LaunchCtx &c, int sel, int max_n, int xb, int egb, int vb, int ob, int poff) {
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_hess<R>, dim3(spmm_grid(c.r, max_n), c.ny), dim3(64), 0, c.stream, c.agents,
+                                          c.team, sel, xb, egb, vb, ob, poff));
+}
+
+void launch_eval_stats(const LaunchCtx &c, int max_n, int first, int has_eval, int has_stats, int num_robots,
+                       int restart_interval) {
+  const int nb = spmm_grid(c.r, max_n);
+  const int grid = nb * ((has_eval ? 1 : 0) + (has_stats ? 1 : 0)) + 1;
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_eval_stats<R>, dim3(grid), dim3(64), 0, c.stream, c.agents, c.team, nb, first,
+                                          has_eval, has_stats, num_robots, restart_interval));
+}
+
+void launch_tcg_hv(const LaunchCtx &c, int sel, int max_n, int sp, int max_inner) {
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_tcg_hv<R>, dim3(spmm_grid(c.r, max_n), c.ny), dim3(64), 0, c.stream, c.agents,
+                                          c.team, sel, sp, max_inner));
+}
+
+void launch_stats_nest(const LaunchCtx &c, int num_agents, int max_n, int num_robots, int restart_interval) {
+  const int nest_tiles = (max_n + 63) / 64;
+  const int grid = nest_tiles * num_agents + spmm_grid(c.r, max_n);
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_stats_nest<R>, dim3(grid), dim3(64), 0, c.stream, c.agents, c.team, nest_tiles,
+                                          num_agents, num_robots, restart_interval));
+}
+
+void launch_rtr_eval2(const LaunchCtx &c, int sel, int max_n, int sp) {
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_rtr_eval2<R>, dim3(spmm_grid(c.r, max_n), c.ny), dim3(64), 0, c.stream, c.agents,
+                                          c.team, sel, sp));
+}
+
+}  // namespace dpgo
