@@ -914,9 +914,19 @@ int dpgo_team_time_kernel(dpgo_team_t *t, int id, int which, int reps, double *a
     else if (which == 5) launch_noop(c, 1, 64);
     else if (which == 6) launch_noop(c, 256, 256);
     else if (which == 7) launch_status(c, -3, -1, (int)t->ag.size(), t->max_n);
+    else if (which == 9)  // the fused step kernel exactly as the pipelined accelerated-RGD loop launches it (state is consumed)
+      launch_precond(c, a->local, n, PM_RGD_, B_X, B_GF, B_Z, 0, 0, t->prm.rgd_stepsize, 1, t->prm.num_robots, 2,
+                     t->prm.restart_interval, 3);
     else launch_copy(c, -3, -1, (int)t->ag.size(), t->max_n, B_X, B_XPREV, 0);
   };
   if (which == 0) *algorithmic_bytes = 8.0 * N4 * N4 + 3.0 * vec;          // M once, v + X in, z out
+  else if (which == 9) {
+    // M once; gradient, X, V, Y, XPrev in and X2, XPrev, Y, X, V out for this agent; X, V in and XPrev, Y, X, V out
+    // for the look-ahead Nesterov step of every other agent
+    double others = 0;
+    for (auto &b : t->ag) if (b.get() != a) others += 8.0 * r * 4 * b->n;
+    *algorithmic_bytes = 8.0 * N4 * N4 + 10.0 * vec + 6.0 * others;
+  }
   else *algorithmic_bytes = 8.0 * (16.0 * a->col.size() + 3.0 * r * 4 * n) + 4.0 * (a->col.size() + n + 1);
   hipEvent_t e0, e1;
   HIPC(hipEventCreate(&e0)); HIPC(hipEventCreate(&e1));
