@@ -143,23 +143,25 @@ def single_gpu(args):
 
 
 def roofline_leg(team, agent_id):
-    """HIP events on the team stream around back-to-back launches.  Top level: the dominant kernel of the timed loop,
-    k_precond<5,PM_RGD> launched exactly as the pipelined iteration launches it (preconditioner stream + RGD step +
-    Nesterov V + look-ahead Nesterov step of all agents; consumes the team's state, so this runs after the timed
-    loop).  apply_only: the same kernel's plain mode, i.e. the bare preconditioner apply.  spmm_eval: k_eval."""
+    """HIP events on the team stream.  Top level: the dominant kernel of the timed loop, k_precond<5,PM_RGD>
+    (preconditioner stream + RGD step + Nesterov V + look-ahead Nesterov step of all agents), timed inside the running
+    pipelined iteration with an event pair around every launch (the sequence consumes the team's state, so this runs
+    after the timed loop).  apply_only: the same kernel's plain mode, i.e. the bare preconditioner apply, back to back.
+    spmm_eval: k_eval back to back."""
     p_ms, p_bytes = team.time_kernel(agent_id, 0, reps=500)
     s_ms, s_bytes = team.time_kernel(agent_id, 1, reps=500)
-    f_ms, f_bytes = team.time_kernel(agent_id, 9, reps=500)
+    f_ms, f_bytes = team.time_kernel(agent_id, 10, reps=500)   # inside the running iteration (event pair per launch)
+    b_ms, _ = team.time_kernel(agent_id, 9, reps=500)          # the same kernel back to back (warm operands)
     # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and --pmc
     # WRITE_SIZE in separate runs; FETCH_SIZE doubled per the gfx950 correction).  Not collectable live; re-measure
     # with profiles/collect.sh.
     roof = {"kernel": "k_precond<5,PM_RGD> (fused step kernel of the timed loop)", "bound": "hbm",
             "achieved": f_bytes / (f_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-            "traffic": (2 * 16327.4 + 328.3) * 1024, "traffic_source": "profiles/r01_pmc_fetch.md, profiles/r01_pmc_write.md",
-            "bytes_per_launch": f_bytes, "us_per_launch": f_ms * 1e3,
+            "traffic": (2 * 16638.2 + 1413.4) * 1024, "traffic_source": "profiles/r01_pmc_fetch.md, profiles/r01_pmc_write.md",
+            "bytes_per_launch": f_bytes, "us_per_launch": f_ms * 1e3, "us_per_launch_back_to_back": b_ms * 1e3,
             "apply_only": {"kernel": "k_precond<5,PM_PLAIN>", "bytes_per_launch": p_bytes, "us_per_launch": p_ms * 1e3,
                            "achieved": p_bytes / (p_ms * 1e-3) / 1e9, "frac": p_bytes / (p_ms * 1e-3) / 1e9 / 8000.0,
-                           "traffic": (2 * 16076.0 + 85.9) * 1024},
+                           "traffic": (2 * 16076.3 + 85.9) * 1024},
             "spmm_eval": {"kernel": "k_eval<5>", "bytes_per_launch": s_bytes, "us_per_launch": s_ms * 1e3,
                           "achieved": s_bytes / (s_ms * 1e-3) / 1e9}}
     roof["frac"] = roof["achieved"] / roof["peak"]

@@ -928,6 +928,34 @@ int dpgo_team_time_kernel(dpgo_team_t *t, int id, int which, int reps, double *a
     *algorithmic_bytes = 8.0 * N4 * N4 + 10.0 * vec + 6.0 * others;
   }
   else *algorithmic_bytes = 8.0 * (16.0 * a->col.size() + 3.0 * r * 4 * n) + 4.0 * (a->col.size() + n + 1);
+  if (which == 10) {
+    // the fused step kernel inside the running iteration: the pipelined accelerated-RGD sequence launched eagerly
+    // (k_eval_stats, k_precond<PM_RGD>) x reps with an event pair around every step kernel, so that it is timed
+    // with the operands its predecessor just produced (state is consumed; restarts are not honoured).  Events
+    // recorded inside a captured graph cannot be timed (hipEventElapsedTime: invalid resource handle), hence eager:
+    // each pair includes one eager launch gap (~2.5 us) on top of the kernel's own duration.
+    const dpgo_params_t &p = t->prm;
+    const int na = (int)t->ag.size(), mn = t->max_n;
+    double others = 0;
+    for (auto &b : t->ag) if (b.get() != a) others += 8.0 * r * 4 * b->n;
+    *algorithmic_bytes = 8.0 * N4 * N4 + 10.0 * vec + 6.0 * others;
+    std::vector<hipEvent_t> ev(2 * (size_t)reps);
+    for (auto &e : ev) HIPC(hipEventCreate(&e));
+    LaunchCtx cc = t->ctx();
+    launch_nest_pre(cc, -1, -1, na, mn, p.num_robots, p.restart_interval);
+    for (int k = 0; k < reps; ++k) {
+      launch_eval_stats(cc, mn, k == 0, 1, k > 0, p.num_robots, p.restart_interval);
+      HIPC(hipEventRecord(ev[2 * k], t->stream));
+      launch_precond(cc, -1, mn, PM_RGD_, B_X, B_GF, B_Z, 0, 0, p.rgd_stepsize, 1, p.num_robots, 2, p.restart_interval, 3);
+      HIPC(hipEventRecord(ev[2 * k + 1], t->stream));
+    }
+    HIPC(hipStreamSynchronize(t->stream));
+    double tot = 0;
+    for (int k = 0; k < reps; ++k) { float ms1 = 0; HIPC(hipEventElapsedTime(&ms1, ev[2 * k], ev[2 * k + 1])); tot += ms1; }
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    *avg_ms = tot / reps;
+    return 0;
+  }
   hipEvent_t e0, e1;
   HIPC(hipEventCreate(&e0)); HIPC(hipEventCreate(&e1));
   for (int k = 0; k < 3; ++k) launch();
