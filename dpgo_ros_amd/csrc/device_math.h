@@ -130,15 +130,46 @@ __device__ __forceinline__ void polar_inplace(double *A) {
       for (int a = 0; a < R; ++a) B[j * R + a] = A[a] * T[j] + A[R + a] * T[3 + j] + A[2 * R + a] * T[6 + j];
 #pragma unroll
     for (int i = 0; i < 3 * R; ++i) A[i] = B[i];
+    // E' = (3 E^2 + E^3) / 4  =>  |E'|_F^2 <= d^2: a step taken from d <= 3e-16 needs no check
+    if (d * d <= 1e-31) break;
     gram3<R>(A, S);
     const double f0 = 1.0 - S[0], f1 = 1.0 - S[4], f2 = 1.0 - S[8];
     d = f0 * f0 + f1 * f1 + f2 * f2 + 2.0 * (S[1] * S[1] + S[2] * S[2] + S[5] * S[5]);
   }
 }
 
-// Q factor (positive diagonal R) of the R x 3 block A in place, modified Gram-Schmidt
+// Q factor (positive diagonal R) of the R x 3 block A in place.
+// The retraction is applied to Y + eta with Y on the manifold and eta tangent, i.e. to a block whose Gram matrix is
+// I + eta^T eta: close to the identity whenever the step is small (the steady state of the iteration).  There the
+// factor comes from the Cholesky factor of the Gram matrix (A = Q R  <=>  A^T A = R^T R, same positive-diagonal R):
+// 6 short independent dot products, 3 reciprocal square roots and one triangular solve per row -- no column-by-column
+// dependency chain and no divisions; its orthogonality error is eps * cond(A)^2, hence the guard.  Blocks further from
+// orthonormal go through modified Gram-Schmidt (error eps * cond(A)).
 template <int R>
 __device__ __forceinline__ void qf_inplace(double *A) {
+  double g00 = 0, g01 = 0, g02 = 0, g11 = 0, g12 = 0, g22 = 0;
+#pragma unroll
+  for (int a = 0; a < R; ++a) {
+    g00 += A[a] * A[a]; g01 += A[a] * A[R + a]; g02 += A[a] * A[2 * R + a];
+    g11 += A[R + a] * A[R + a]; g12 += A[R + a] * A[2 * R + a]; g22 += A[2 * R + a] * A[2 * R + a];
+  }
+  const double e0 = 1.0 - g00, e1 = 1.0 - g11, e2 = 1.0 - g22;
+  const double dev = e0 * e0 + e1 * e1 + e2 * e2 + 2.0 * (g01 * g01 + g02 * g02 + g12 * g12);
+  if (dev < 0.05) {
+    const double i0 = rsqrt(g00);
+    const double r01 = g01 * i0, r02 = g02 * i0;
+    const double i1 = rsqrt(g11 - r01 * r01);
+    const double r12 = (g12 - r01 * r02) * i1;
+    const double i2 = rsqrt(g22 - r02 * r02 - r12 * r12);
+#pragma unroll
+    for (int a = 0; a < R; ++a) {
+      const double q0 = A[a] * i0;
+      const double q1 = (A[R + a] - r01 * q0) * i1;
+      const double q2 = (A[2 * R + a] - r02 * q0 - r12 * q1) * i2;
+      A[a] = q0; A[R + a] = q1; A[2 * R + a] = q2;
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
 #pragma unroll
