@@ -614,7 +614,8 @@ int dpgo_team_run(dpgo_team_t *t, int iters) {
   // the schedule, the counters and the Nesterov scalars live on the device, so a run of B iterations is one
   // fixed launch sequence: captured once per B and replayed
   // lead: the window opens with a restart iteration (un-fused kernels, same launch sequence every time); B: fused
-  // iterations that follow.  Two instances per key alternate, so that a launch never has to wait for the previous
+  // iterations that follow.  Pipelined teams have no windows: restart iterations are part of the uniform sequence
+  // (lead is never set).  Two instances per key alternate, so that a launch never has to wait for the previous
   // replay of the same executable graph.
   auto graph_for = [&](bool lead, int B, hipGraphExec_t *out) -> int {
     const int base = ((lead ? 1 : 0) + 2 * B) * 2;
@@ -626,11 +627,12 @@ int dpgo_team_run(dpgo_team_t *t, int iters) {
     int rc = 0;
     if (lead) rc = enqueue_team_iteration(t, true, true, -1, 0);
     if (rc == 0 && B > 0 && p.acceleration && pipelined) {
-      // pipelined: 2 launches per iteration (see k_eval_stats).  The Nesterov step of the first iteration is a
-      // launch of its own, the last iteration does not look ahead, and its statistics / bookkeeping close the run.
+      // pipelined: 2 launches per iteration (see k_eval_stats), restart iterations included.  The Nesterov step of
+      // the first iteration is a launch of its own, the last iteration does not look ahead, and its statistics /
+      // bookkeeping close the run.
       LaunchCtx c = t->ctx();
       const int na = (int)t->ag.size(), mn = t->max_n;
-      launch_nest_pre(c, -1, -1, na, mn, p.num_robots, p.restart_interval);
+      launch_nest_pre(c, -1, -1, na, mn, p.num_robots, p.restart_interval, 1);
       for (int rep = 0; rep < B; ++rep) {
         launch_eval_stats(c, mn, rep == 0, 1, rep > 0, p.num_robots, p.restart_interval);
         launch_precond(c, -1, mn, PM_RGD_, B_X, B_GF, B_Z, 0, 0, p.rgd_stepsize, 1, p.num_robots, 2, p.restart_interval,
@@ -669,13 +671,14 @@ int dpgo_team_run(dpgo_team_t *t, int iters) {
   };
   int k = 0;
   while (k < iters) {
-    const bool restart = p.acceleration && ((t->iter + 2) % p.restart_interval) == 0;
+    const bool uniform = graphable && p.acceleration && pipelined;  // restart iterations are ordinary iterations of the sequence
+    const bool restart = !uniform && p.acceleration && ((t->iter + 2) % p.restart_interval) == 0;
     int batch = 1;
     if (graphable) {
       // one graph per window: [the restart iteration, if the window opens with one] + the fused iterations up to
       // the next restart iteration
       int fusedn = iters - k - (restart ? 1 : 0);
-      if (p.acceleration) {
+      if (p.acceleration && !uniform) {
         const int it0 = t->iter + (restart ? 1 : 0);
         const int to_restart = (p.restart_interval - ((it0 + 2) % p.restart_interval)) % p.restart_interval;
         fusedn = std::min(fusedn, to_restart);

@@ -313,7 +313,9 @@ __device__ __forceinline__ void tile_put(Tile<R> &t, int row, const double *v) {
 template <int R>
 __device__ __forceinline__ void nest_pre_body(const AgentDev *agents, TeamDev *team, int sel, int only_agent,
                                               int num_robots, int restart_interval, int bx, int by, Tile<R> &TX,
-                                              Tile<R> &TV) {
+                                              Tile<R> &TV, int fused_restart = 0) {
+  // fused_restart: the pipelined RGD sequence takes a restart iteration as one plain step from X (the accelerated
+  // solve that the un-fused path runs first, and discards, is skipped), so the selected agent only saves XPrev
   const int ai = only_agent >= 0 ? only_agent : by;
   const AgentDev &ag = agents[ai];
   const int selected = (sel == -2) ? -1 : sel_sched(team, sel);
@@ -332,6 +334,7 @@ __device__ __forceinline__ void nest_pre_body(const AgentDev *agents, TeamDev *t
   tile_in<R>(TV, ag.buf[B_V], j0, cnt, tid);
   __syncthreads();
   tile_out<R>(TX, ag.buf[B_XPREV], j0, cnt, tid);
+  if (fused_restart && optimizing && restart) return;
   double x[4 * R], v[4 * R], y[4 * R];
   double rel = 0;
   if (tid < cnt) {

@@ -39,7 +39,7 @@ void launch_project_raw(const LaunchCtx &c, const double *X, double *out, int n)
 void launch_tangent_raw(const LaunchCtx &c, const double *X, const double *V, double *out, int n);
 void launch_retract_raw(const LaunchCtx &c, const double *X, const double *E, double *out, int n);
 void launch_nest_pre(const LaunchCtx &c, int sel, int only_agent, int num_agents, int max_n, int num_robots,
-                     int restart_interval);
+                     int restart_interval, int fused_restart = 0);
 void launch_stats_nest(const LaunchCtx &c, int num_agents, int max_n, int num_robots, int restart_interval);
 void launch_nest_post(const LaunchCtx &c, int sel, int max_n, int num_robots, int restart_interval);
 void launch_nest_reset(const LaunchCtx &c, int sel, int max_n);

@@ -62,9 +62,10 @@ __global__ __launch_bounds__(64) void k_raw_op(const double *X, const double *V,
 
 template <int R>
 __global__ __launch_bounds__(64) void k_nest_pre(const AgentDev *agents, TeamDev *team, int sel, int only_agent,
-                                                 int num_robots, int restart_interval) {
+                                                 int num_robots, int restart_interval, int fused_restart) {
   __shared__ Tile<R> TX, TV;
-  nest_pre_body<R>(agents, team, sel, only_agent, num_robots, restart_interval, (int)blockIdx.x, (int)blockIdx.y, TX, TV);
+  nest_pre_body<R>(agents, team, sel, only_agent, num_robots, restart_interval, (int)blockIdx.x, (int)blockIdx.y, TX, TV,
+                   fused_restart);
 }
 
 // after the selected agent's local solve (unfused path):  V = proj(V + gamma' (X - Y)); on restart
@@ -314,10 +315,10 @@ void launch_retract_raw(const LaunchCtx &c, const double *X, const double *E, do
 }
 
 void launch_nest_pre(const LaunchCtx &c, int sel, int only_agent, int num_agents, int max_n, int num_robots,
-                     int restart_interval) {
+                     int restart_interval, int fused_restart) {
   dim3 grid((max_n + 63) / 64, only_agent >= 0 ? 1 : num_agents);
   DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_nest_pre<R>, grid, dim3(64), 0, c.stream, c.agents, c.team, sel, only_agent,
-                                          num_robots, restart_interval));
+                                          num_robots, restart_interval, fused_restart));
 }
 
 void launch_nest_post(const LaunchCtx &c, int sel, int max_n, int num_robots, int restart_interval) {

@@ -140,14 +140,20 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
     }
   }
   double ahead_alpha = 0;
-  bool ahead_opt = false;
+  bool ahead_opt = false, restart_now = false, restart_next = false;
   if (MODE == PM_RGD_ && accel) {
     if (advance == 2) {
       // the NestState describes iteration k-1 (it is advanced by the next k_eval_stats): gamma of this iteration,
       // and gamma / alpha / selected agent of iteration k+1 for the look-ahead Nesterov step of the epilogue
       const NestState ns = *ag.nest;
       const double Nr = (double)num_robots;
-      nest_gamma = (1.0 + sqrt(1.0 + 4.0 * Nr * Nr * ns.gamma * ns.gamma)) / (2.0 * Nr);
+      // restart iterations are part of the uniform sequence: iteration k restarts when (iter + 2) % interval == 0
+      // (the test of k_nest_pre / advance_agent); its step is a plain RGD step from X with V = Y = X afterwards
+      // and gamma = 0 for what follows.  (The reference also runs -- and discards -- an accelerated solve first; it
+      // has no observable effect and is skipped here.)
+      restart_now = ((ns.iter + 2) % restart_interval) == 0;
+      restart_next = ((ns.iter + 3) % restart_interval) == 0;
+      nest_gamma = restart_now ? 0.0 : (1.0 + sqrt(1.0 + 4.0 * Nr * Nr * ns.gamma * ns.gamma)) / (2.0 * Nr);
       const double g2 = (1.0 + sqrt(1.0 + 4.0 * Nr * Nr * nest_gamma * nest_gamma)) / (2.0 * Nr);
       ahead_alpha = 1.0 / (g2 * Nr);
       ahead_opt = team->sched[(team->iter + 1) % team->sched_len] == sel_cur(team, sel);
@@ -272,23 +278,33 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
     if (la_act) {
       const AgentDev &oa = agents[la_agent];
       const size_t o = (size_t)la_pose * 4 * R;
-      double y[4 * R];
+      if (restart_next) {
+        // iteration k+1 restarts: XPrev = X, and V = Y = X for the agents that do not optimize (X does not move)
 #pragma unroll
-      for (int i = 0; i < 4 * R; ++i) y[i] = (1.0 - ahead_alpha) * la_x[i] + ahead_alpha * la_v[i];
-      polar_inplace<R>(y);
-      if (!la_opt) {
-        polar_inplace<R>(la_v);
-        double r2 = 0;
+        for (int i = 0; i < 4 * R; ++i) {
+          oa.buf[B_XPREV][o + i] = la_x[i];
+          if (!la_opt) { oa.buf[B_Y][o + i] = la_x[i]; oa.buf[B_V][o + i] = la_x[i]; }
+        }
+        if (!la_opt) oa.part[PART_D + la_pose] = 0.0;
+      } else {
+        double y[4 * R];
 #pragma unroll
-        for (int i = 0; i < 4 * R; ++i) { const double d = y[i] - la_x[i]; r2 += d * d; }
-        oa.part[PART_D + la_pose] = r2;
-      }
+        for (int i = 0; i < 4 * R; ++i) y[i] = (1.0 - ahead_alpha) * la_x[i] + ahead_alpha * la_v[i];
+        polar_inplace<R>(y);
+        if (!la_opt) {
+          polar_inplace<R>(la_v);
+          double r2 = 0;
 #pragma unroll
-      for (int i = 0; i < 4 * R; ++i) {
-        oa.buf[B_XPREV][o + i] = la_x[i];
-        oa.buf[B_Y][o + i] = y[i];
-        oa.buf[B_X][o + i] = y[i];
-        if (!la_opt) oa.buf[B_V][o + i] = la_v[i];
+          for (int i = 0; i < 4 * R; ++i) { const double d = y[i] - la_x[i]; r2 += d * d; }
+          oa.part[PART_D + la_pose] = r2;
+        }
+#pragma unroll
+        for (int i = 0; i < 4 * R; ++i) {
+          oa.buf[B_XPREV][o + i] = la_x[i];
+          oa.buf[B_Y][o + i] = y[i];
+          oa.buf[B_X][o + i] = y[i];
+          if (!la_opt) oa.buf[B_V][o + i] = la_v[i];
+        }
       }
     }
     return;
@@ -308,38 +324,56 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
       qf_inplace<R>(x);
 #pragma unroll
       for (int i = 0; i < 4 * R; ++i) {
-        if (!(ahead & 1)) ag.buf[B_X][o + i] = x[i];
         ag.buf[B_X2][o + i] = x[i];  // snapshot for the final-statistics evaluation of this iteration
         const double d = x[i] - Esh[2][lp * 4 * R + i];
         rel += d * d;
       }
+      // results are stored as soon as they exist: the per-pose arrays of this tail do not fit the register file
+      // together (they spill to AGPRs, which costs more than the stores)
+      const bool reset = accel && advance == 2 && restart_now;  // restart iteration: V = Y = X (k_nest_reset)
       double v[4 * R];
       if (accel) {
-        const double gamma = nest_gamma;
+        if (reset) {
 #pragma unroll
-        for (int i = 0; i < 4 * R; ++i) v[i] = Esh[0][lp * 4 * R + i] + gamma * (x[i] - Esh[1][lp * 4 * R + i]);
-        polar_inplace<R>(v);
+          for (int i = 0; i < 4 * R; ++i) v[i] = x[i];
+        } else {
+          const double gamma = nest_gamma;
+#pragma unroll
+          for (int i = 0; i < 4 * R; ++i) v[i] = Esh[0][lp * 4 * R + i] + gamma * (x[i] - Esh[1][lp * 4 * R + i]);
+          polar_inplace<R>(v);
+        }
       }
       if (accel && (ahead & 1)) {
-        // Nesterov step of iteration k+1 for this pose (what k_nest_pre would do next): XPrev = X,
-        // Y = proj((1 - alpha') X + alpha' V), X = Y, and V = proj(V) unless this agent is selected again
-        double y[4 * R];
+        // Nesterov step of iteration k+1 for this pose (what k_nest_pre would do next): XPrev = X, then
+        //   k+1 regular:  Y = proj((1 - alpha') X + alpha' V), X = Y, and V = proj(V) unless this agent is selected again
+        //   k+1 restarts: V = Y = X unless this agent is selected again (X does not move)
 #pragma unroll
-        for (int i = 0; i < 4 * R; ++i) y[i] = (1.0 - ahead_alpha) * x[i] + ahead_alpha * v[i];
-        polar_inplace<R>(y);
-        if (!ahead_opt) {
-          polar_inplace<R>(v);
-          double rel2 = 0;
+        for (int i = 0; i < 4 * R; ++i) ag.buf[B_XPREV][o + i] = x[i];
+        if (restart_next) {
 #pragma unroll
-          for (int i = 0; i < 4 * R; ++i) { const double d = y[i] - x[i]; rel2 += d * d; }
-          ag.part[PART_D + 2 * bx + lp] = rel2;  // look-ahead steps leave |Y' - X|^2 per pose
+          for (int i = 0; i < 4 * R; ++i) {
+            ag.buf[B_X][o + i] = x[i];
+            if (!ahead_opt) { ag.buf[B_Y][o + i] = x[i]; v[i] = x[i]; } else if (reset) ag.buf[B_Y][o + i] = x[i];
+          }
+          if (!ahead_opt) ag.part[PART_D + 2 * bx + lp] = 0.0;
+        } else {
+          double y[4 * R];
+#pragma unroll
+          for (int i = 0; i < 4 * R; ++i) y[i] = (1.0 - ahead_alpha) * x[i] + ahead_alpha * v[i];
+          polar_inplace<R>(y);
+#pragma unroll
+          for (int i = 0; i < 4 * R; ++i) { ag.buf[B_Y][o + i] = y[i]; ag.buf[B_X][o + i] = y[i]; }
+          if (!ahead_opt) {
+            polar_inplace<R>(v);
+            double rel2 = 0;
+#pragma unroll
+            for (int i = 0; i < 4 * R; ++i) { const double d = y[i] - x[i]; rel2 += d * d; }
+            ag.part[PART_D + 2 * bx + lp] = rel2;  // look-ahead steps leave |Y' - X|^2 per pose
+          }
         }
+      } else {
 #pragma unroll
-        for (int i = 0; i < 4 * R; ++i) {
-          ag.buf[B_XPREV][o + i] = x[i];
-          ag.buf[B_Y][o + i] = y[i];
-          ag.buf[B_X][o + i] = y[i];
-        }
+        for (int i = 0; i < 4 * R; ++i) { ag.buf[B_X][o + i] = x[i]; if (reset) ag.buf[B_Y][o + i] = x[i]; }
       }
       if (accel) {
 #pragma unroll
