@@ -209,42 +209,6 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
       const int k = 2 * kl + 64 * m;
       mreg[m] = (cact && k < kn) ? ld2_nt(Mc + k0 + k) : make_double2(0.0, 0.0);
     }
-    if (k0 == 0 && MODE == PM_RGD_ && (ahead & 2)) {
-      // look-ahead operands of the second wave, requested right behind the M slab: they arrive under the stream.
-      // Every address comes from wave-uniform (scalar) loads -- a per-lane fetch of agents[a].buf would queue
-      // behind the vector stream and stall the wave.
-      const int self = sel_cur(team, sel);
-      int pre[LOOKAHEAD_MAX_AGENTS + 1];
-      const double *px[LOOKAHEAD_MAX_AGENTS], *pv[LOOKAHEAD_MAX_AGENTS];
-#pragma unroll
-      for (int k = 0; k <= LOOKAHEAD_MAX_AGENTS; ++k) pre[k] = team->pose_prefix[k];
-      const int na = team->num_agents;
-#pragma unroll
-      for (int k = 0; k < LOOKAHEAD_MAX_AGENTS; ++k) {
-        px[k] = (k < na) ? agents[k].buf[B_X] : nullptr;
-        pv[k] = (k < na) ? agents[k].buf[B_V] : nullptr;
-      }
-      const int total = pre[LOOKAHEAD_MAX_AGENTS] - ag.n;
-      const int per = (total + nblk - 1) / nblk;  // <= 64, checked by the host
-      const int l1 = tid - 64;
-      const int q = bx * per + l1;   // index among the poses of the other agents
-      if (l1 >= 0 && l1 < per && q < total) {
-        int self_lo = 0;
-#pragma unroll
-        for (int k = 0; k < LOOKAHEAD_MAX_AGENTS; ++k) if (k == self) self_lo = pre[k];
-        const int g = q < self_lo ? q : q + ag.n;  // index among all poses of the team
-        int a = 0, lo = 0;
-        const double *xa = px[0], *va = pv[0];
-#pragma unroll
-        for (int k = 1; k < LOOKAHEAD_MAX_AGENTS; ++k)
-          if (k < na && g >= pre[k]) { a = k; lo = pre[k]; xa = px[k]; va = pv[k]; }
-        la_act = true; la_agent = a; la_pose = g - lo;
-        la_opt = team->sched[(team->iter + 1) % team->sched_len] == a;
-        const size_t o = (size_t)la_pose * 4 * R;
-#pragma unroll
-        for (int i = 0; i < 4 * R; ++i) { la_x[i] = xa[o + i]; la_v[i] = va[o + i]; }
-      }
-    }
 #pragma unroll
     for (int m = 0; m < MREG; ++m) {
       const int k = 2 * kl + 64 * m;
@@ -256,6 +220,44 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
       }
 #pragma unroll
       for (int a = 0; a < R; ++a) acc[a] += w[a] * mreg[m].x + w[R + a] * mreg[m].y;
+    }
+  }
+  if (MODE == PM_RGD_ && (ahead & 2)) {
+    // look-ahead operands of the second wave, requested once its share of the stream is consumed: they arrive while
+    // the partial sums are reduced and the first wave starts its tail, and they do not occupy registers during the
+    // stream (the tail is register-bound).
+    // Every address comes from wave-uniform (scalar) loads -- a per-lane fetch of agents[a].buf would queue
+    // behind the vector stream and stall the wave.
+    const int self = sel_cur(team, sel);
+    int pre[LOOKAHEAD_MAX_AGENTS + 1];
+    const double *px[LOOKAHEAD_MAX_AGENTS], *pv[LOOKAHEAD_MAX_AGENTS];
+#pragma unroll
+    for (int k = 0; k <= LOOKAHEAD_MAX_AGENTS; ++k) pre[k] = team->pose_prefix[k];
+    const int na = team->num_agents;
+#pragma unroll
+    for (int k = 0; k < LOOKAHEAD_MAX_AGENTS; ++k) {
+      px[k] = (k < na) ? agents[k].buf[B_X] : nullptr;
+      pv[k] = (k < na) ? agents[k].buf[B_V] : nullptr;
+    }
+    const int total = pre[LOOKAHEAD_MAX_AGENTS] - ag.n;
+    const int per = (total + nblk - 1) / nblk;  // <= 64, checked by the host
+    const int l1 = tid - 64;
+    const int q = bx * per + l1;   // index among the poses of the other agents
+    if (l1 >= 0 && l1 < per && q < total) {
+      int self_lo = 0;
+#pragma unroll
+      for (int k = 0; k < LOOKAHEAD_MAX_AGENTS; ++k) if (k == self) self_lo = pre[k];
+      const int g = q < self_lo ? q : q + ag.n;  // index among all poses of the team
+      int a = 0, lo = 0;
+      const double *xa = px[0], *va = pv[0];
+#pragma unroll
+      for (int k = 1; k < LOOKAHEAD_MAX_AGENTS; ++k)
+        if (k < na && g >= pre[k]) { a = k; lo = pre[k]; xa = px[k]; va = pv[k]; }
+      la_act = true; la_agent = a; la_pose = g - lo;
+      la_opt = team->sched[(team->iter + 1) % team->sched_len] == a;
+      const size_t o = (size_t)la_pose * 4 * R;
+#pragma unroll
+      for (int i = 0; i < 4 * R; ++i) { la_x[i] = xa[o + i]; la_v[i] = va[o + i]; }
     }
   }
 #pragma unroll
