@@ -177,6 +177,24 @@ def test_pipelined_rgd_windows(N, restart, schedule, splits):
     th.close()
 
 
+def test_accelerated_rgd_beyond_the_lookahead_limit():
+    """teams of more than 8 agents keep the 3-launch iteration and the per-window graphs ([restart iteration] +
+    fused iterations up to the next restart): torus3D over 10 agents, restart every 7 iterations"""
+    kw = dict(method=capi.METHOD_RGD, acceleration=1, rgd_stepsize=0.05, restart_interval=7)
+    th, to, n = make_pair("torus3D", 10, **kw)
+    done = 0
+    for cnt in (3, 22):
+        th.run(cnt)
+        for _ in range(cnt):
+            to.iterate()
+        done += cnt
+        assert np.abs(th.global_X() - to.global_X()).max() < 1e-7, done
+        for a in range(10):
+            assert abs(th.agents[a].status().relative_change - to.agents[a].status().relative_change) < 1e-8
+    assert abs(th.cost() - to.cost()) <= 1e-9 * abs(to.cost())
+    th.close()
+
+
 def _two_rank_colored_worker(rank, world, port, outdir):
     import os
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
