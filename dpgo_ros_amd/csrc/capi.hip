@@ -634,9 +634,11 @@ int dpgo_team_run(dpgo_team_t *t, int iters) {
       const int na = (int)t->ag.size(), mn = t->max_n;
       launch_nest_pre(c, -1, -1, na, mn, p.num_robots, p.restart_interval, 1);
       for (int rep = 0; rep < B; ++rep) {
-        launch_eval_stats(c, mn, rep == 0, 1, rep > 0, p.num_robots, p.restart_interval);
+        // statistics (X2 snapshot, |X - XPrev|^2) only from the last step, status data (XPrev, |Y' - X|^2) only from
+        // the last look-ahead: nothing reads them in between
+        launch_eval_stats(c, mn, rep == 0, 1, 0, p.num_robots, p.restart_interval);
         launch_precond(c, -1, mn, PM_RGD_, B_X, B_GF, B_Z, 0, 0, p.rgd_stepsize, 1, p.num_robots, 2, p.restart_interval,
-                       rep + 1 < B ? 3 : 0);
+                       rep + 1 < B ? (rep + 2 == B ? 7 : 3) : 8);
       }
       launch_eval_stats(c, mn, 0, 0, 1, p.num_robots, p.restart_interval);
     } else if (rc == 0 && B > 0 && p.acceleration) {
@@ -924,11 +926,12 @@ int dpgo_team_time_kernel(dpgo_team_t *t, int id, int which, int reps, double *a
   };
   if (which == 0) *algorithmic_bytes = 8.0 * N4 * N4 + 3.0 * vec;          // M once, v + X in, z out
   else if (which == 9) {
-    // M once; gradient, X, V, Y, XPrev in and X2, XPrev, Y, X, V out for this agent; X, V in and XPrev, Y, X, V out
-    // for the look-ahead Nesterov step of every other agent
+    // a mid-run iteration: M once; gradient, X, V, Y in and Y, X, V out for this agent; X, V in and Y, X out for the
+    // look-ahead Nesterov step of every other agent (XPrev, the X2 snapshot and the status partials only move in the
+    // last two iterations of a run)
     double others = 0;
     for (auto &b : t->ag) if (b.get() != a) others += 8.0 * r * 4 * b->n;
-    *algorithmic_bytes = 8.0 * N4 * N4 + 10.0 * vec + 6.0 * others;
+    *algorithmic_bytes = 8.0 * N4 * N4 + 7.0 * vec + 4.0 * others;
   }
   else *algorithmic_bytes = 8.0 * (16.0 * a->col.size() + 3.0 * r * 4 * n) + 4.0 * (a->col.size() + n + 1);
   if (which == 10) {
@@ -941,7 +944,7 @@ int dpgo_team_time_kernel(dpgo_team_t *t, int id, int which, int reps, double *a
     const int na = (int)t->ag.size(), mn = t->max_n;
     double others = 0;
     for (auto &b : t->ag) if (b.get() != a) others += 8.0 * r * 4 * b->n;
-    *algorithmic_bytes = 8.0 * N4 * N4 + 10.0 * vec + 6.0 * others;
+    *algorithmic_bytes = 8.0 * N4 * N4 + 7.0 * vec + 4.0 * others;  // as for which == 9
     std::vector<hipEvent_t> ev(2 * (size_t)reps);
     for (auto &e : ev) HIPC(hipEventCreate(&e));
     LaunchCtx cc = t->ctx();

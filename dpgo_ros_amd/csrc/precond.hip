@@ -129,6 +129,10 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
   }
 
   // epilogue operands of the two poses this workgroup owns: requested now, consumed after the M stream
+  // ahead bits: 1 look-ahead of this workgroup's poses, 2 look-ahead of the other agents' poses, 4 the look-ahead also
+  // leaves what a status query needs (XPrev, |Y' - X|^2 per pose), 8 this step leaves its statistics (X2 snapshot,
+  // |X - XPrev|^2).  Only the last two iterations of a run set 4 / 8: nothing reads those values in between.
+  const bool la_status = (ahead & 4) != 0, want_stats = (MODE != PM_RGD_) || advance != 2 || (ahead & 8) != 0;
   double pre_x = 0, pre_v = 0, pre_y = 0, pre_p = 0;
   double nest_gamma = 0;
   if (tid < npose * 4 * R) {
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
     if (MODE == PM_RGD_) {
       pre_v = ag.buf[B_V][(size_t)col0 * R + tid];
       pre_y = ag.buf[B_Y][(size_t)col0 * R + tid];
-      pre_p = ag.buf[B_XPREV][(size_t)col0 * R + tid];
+      if (want_stats) pre_p = ag.buf[B_XPREV][(size_t)col0 * R + tid];
     }
   }
   double ahead_alpha = 0;
@@ -284,17 +288,18 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
         // iteration k+1 restarts: XPrev = X, and V = Y = X for the agents that do not optimize (X does not move)
 #pragma unroll
         for (int i = 0; i < 4 * R; ++i) {
-          oa.buf[B_XPREV][o + i] = la_x[i];
+          if (la_status) oa.buf[B_XPREV][o + i] = la_x[i];
           if (!la_opt) { oa.buf[B_Y][o + i] = la_x[i]; oa.buf[B_V][o + i] = la_x[i]; }
         }
-        if (!la_opt) oa.part[PART_D + la_pose] = 0.0;
+        if (la_status && !la_opt) oa.part[PART_D + la_pose] = 0.0;
       } else {
+        // V of an agent that does not optimize is re-projected by the reference (V = proj(V)); V left its last update
+        // as a polar factor, so the projection is the identity up to round-off and V is neither read nor written here
         double y[4 * R];
 #pragma unroll
         for (int i = 0; i < 4 * R; ++i) y[i] = (1.0 - ahead_alpha) * la_x[i] + ahead_alpha * la_v[i];
         polar_inplace<R>(y);
-        if (!la_opt) {
-          polar_inplace<R>(la_v);
+        if (la_status && !la_opt) {
           double r2 = 0;
 #pragma unroll
           for (int i = 0; i < 4 * R; ++i) { const double d = y[i] - la_x[i]; r2 += d * d; }
@@ -302,10 +307,9 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
         }
 #pragma unroll
         for (int i = 0; i < 4 * R; ++i) {
-          oa.buf[B_XPREV][o + i] = la_x[i];
+          if (la_status) oa.buf[B_XPREV][o + i] = la_x[i];
           oa.buf[B_Y][o + i] = y[i];
           oa.buf[B_X][o + i] = y[i];
-          if (!la_opt) oa.buf[B_V][o + i] = la_v[i];
         }
       }
     }
@@ -324,11 +328,13 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
 #pragma unroll
       for (int i = 0; i < 4 * R; ++i) x[i] -= step * z[i];
       qf_inplace<R>(x);
+      if (want_stats) {
 #pragma unroll
-      for (int i = 0; i < 4 * R; ++i) {
-        ag.buf[B_X2][o + i] = x[i];  // snapshot for the final-statistics evaluation of this iteration
-        const double d = x[i] - Esh[2][lp * 4 * R + i];
-        rel += d * d;
+        for (int i = 0; i < 4 * R; ++i) {
+          ag.buf[B_X2][o + i] = x[i];  // snapshot for the final-statistics evaluation of this iteration
+          const double d = x[i] - Esh[2][lp * 4 * R + i];
+          rel += d * d;
+        }
       }
       // results are stored as soon as they exist: the per-pose arrays of this tail do not fit the register file
       // together (they spill to AGPRs, which costs more than the stores)
@@ -347,17 +353,19 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
       }
       if (accel && (ahead & 1)) {
         // Nesterov step of iteration k+1 for this pose (what k_nest_pre would do next): XPrev = X, then
-        //   k+1 regular:  Y = proj((1 - alpha') X + alpha' V), X = Y, and V = proj(V) unless this agent is selected again
+        //   k+1 regular:  Y = proj((1 - alpha') X + alpha' V), X = Y (V = proj(V) is the identity: V was just projected)
         //   k+1 restarts: V = Y = X unless this agent is selected again (X does not move)
+        if (la_status) {
 #pragma unroll
-        for (int i = 0; i < 4 * R; ++i) ag.buf[B_XPREV][o + i] = x[i];
+          for (int i = 0; i < 4 * R; ++i) ag.buf[B_XPREV][o + i] = x[i];
+        }
         if (restart_next) {
 #pragma unroll
           for (int i = 0; i < 4 * R; ++i) {
             ag.buf[B_X][o + i] = x[i];
             if (!ahead_opt) { ag.buf[B_Y][o + i] = x[i]; v[i] = x[i]; } else if (reset) ag.buf[B_Y][o + i] = x[i];
           }
-          if (!ahead_opt) ag.part[PART_D + 2 * bx + lp] = 0.0;
+          if (la_status && !ahead_opt) ag.part[PART_D + 2 * bx + lp] = 0.0;
         } else {
           double y[4 * R];
 #pragma unroll
@@ -365,8 +373,7 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
           polar_inplace<R>(y);
 #pragma unroll
           for (int i = 0; i < 4 * R; ++i) { ag.buf[B_Y][o + i] = y[i]; ag.buf[B_X][o + i] = y[i]; }
-          if (!ahead_opt) {
-            polar_inplace<R>(v);
+          if (la_status && !ahead_opt) {
             double rel2 = 0;
 #pragma unroll
             for (int i = 0; i < 4 * R; ++i) { const double d = y[i] - x[i]; rel2 += d * d; }
