@@ -465,6 +465,7 @@ int dpgo_robust_local_init(int device, const dpgo_measurement_t *m, int nm, int 
   std::vector<dpgo_measurement_t> loc(m, m + nm);
   for (auto &e : loc) {
     if (e.r1 != e.r2) { set_err("robust_local_init: single-robot measurements expected"); return DPGO_ERR; }
+    if (e.p1 < 0 || e.p1 >= num_poses || e.p2 < 0 || e.p2 >= num_poses) { set_err("robust_local_init: pose index out of range"); return DPGO_ERR; }
     e.r1 = e.r2 = 0;
     if (e.p1 + 1 == e.p2) { e.fixed_weight = 1; e.weight = 1.0; }
     else if (!e.fixed_weight) e.weight = 1.0;

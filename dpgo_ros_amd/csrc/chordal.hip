@@ -124,6 +124,9 @@ int dense_solve(hipStream_t s, const std::map<std::pair<int, int>, double> &A, i
 }  // namespace
 
 extern "C" int dpgo_chordal_init(int device, const dpgo_measurement_t *m, int nm, int num_poses, double *T) {
+  if (!m || nm < 0 || num_poses <= 0 || !T) return DPGO_ERR;
+  for (int e = 0; e < nm; ++e)  // single-robot numbering: every endpoint inside [0, num_poses)
+    if (m[e].p1 < 0 || m[e].p1 >= num_poses || m[e].p2 < 0 || m[e].p2 >= num_poses) return DPGO_ERR;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || hipSetDevice(device) != hipSuccess) return DPGO_ERR;
   hipStream_t s;

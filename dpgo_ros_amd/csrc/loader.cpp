@@ -207,7 +207,7 @@ void dpgo_partition(dpgo_measurement_t *m, int nm, int num_poses, int num_robots
 void dpgo_odometry_init(const dpgo_measurement_t *m, int nm, int num_poses, double *T) {
   std::vector<const dpgo_measurement_t *> odo(num_poses, nullptr);
   for (int e = 0; e < nm; ++e)
-    if (m[e].r1 == m[e].r2 && m[e].p2 == m[e].p1 + 1 && !odo[m[e].p1]) odo[m[e].p1] = &m[e];
+    if (m[e].r1 == m[e].r2 && m[e].p2 == m[e].p1 + 1 && m[e].p1 >= 0 && m[e].p2 < num_poses && !odo[m[e].p1]) odo[m[e].p1] = &m[e];
   std::memset(T, 0, sizeof(double) * 12 * (size_t)num_poses);
   T[0] = T[4] = T[8] = 1.0;
   for (int i = 0; i + 1 < num_poses; ++i) {

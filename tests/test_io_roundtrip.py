@@ -148,3 +148,12 @@ def test_robust_frame_alignment_min_inliers():
     assert capi.robust_frame_alignment(Tc, min_inliers=3) is None
     assert oracle.robust_frame_alignment(Tc, min_inliers=3) is None
     assert capi.robust_frame_alignment(np.zeros((0, 12))) is None
+
+
+def test_out_of_range_pose_indices_are_rejected():
+    """host-side validation: a measurement that names a pose outside [0, n) must fail cleanly, not crash"""
+    m, n = capi.read_g2o(os.path.join(DATA, "tinyGrid3D.g2o"))
+    T = capi.odometry_init(m, n - 3)          # edges beyond the range are skipped
+    assert np.isfinite(T).all() and T.shape == (12 * (n - 3),)
+    with pytest.raises(capi.DpgoError):
+        capi.chordal_init(m, n - 3)           # validated before any device work
