@@ -14,57 +14,85 @@ namespace dpgo {
 constexpr int NB = 32;
 
 // factor the nb x nb diagonal block at (k0,k0) in place and write its inverse (lower, dense NB x NB
-// column-major, zero padded) to Linv.  One workgroup of NB x NB threads.
-__global__ __launch_bounds__(1024) void k_potrf_diag(double *A, int N, int k0, int nb, double *Linv, int *fail) {
-  __shared__ double L[NB][NB + 1];
-  __shared__ double Wi[NB][NB + 1];
-  const int i = threadIdx.x % NB, j = threadIdx.x / NB;
-  L[i][j] = (i < nb && j < nb && i >= j) ? A[(size_t)(k0 + j) * N + k0 + i] : (i == j ? 1.0 : 0.0);
-  Wi[i][j] = (i == j) ? 1.0 : 0.0;
-  __syncthreads();
+// column-major, zero padded) to Linv.  One wave: lane i < NB keeps row i of the block in registers; the column that
+// every step produces is exchanged through LDS (broadcast reads), so there is no workgroup barrier in the 2 x NB
+// dependent steps (1024 threads with three barriers per step took 26 us, this takes about 5).
+__global__ __launch_bounds__(64) void k_potrf_diag(double *A, int N, int k0, int nb, double *Linv, int *fail) {
+  __shared__ double Ls[NB][NB + 1];  // the factor, row-major, for the broadcast reads of the inverse
+  __shared__ double col[NB], idiag[NB];
+  const int lane = threadIdx.x;
+  const bool own = lane < NB;
+  double row[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j)
+    row[j] = (own && lane < nb && j < nb && j <= lane) ? A[(size_t)(k0 + j) * N + k0 + lane] : ((own && j == lane) ? 1.0 : 0.0);
+#pragma unroll
   for (int k = 0; k < NB; ++k) {
-    if (i == k && j == k) {
-      const double d = L[k][k];
-      if (!(d > 0.0)) { *fail = k0 + k + 1; L[k][k] = 1.0; } else L[k][k] = sqrt(d);
+    // pivot: lane k holds L[k][k] after the updates of the previous steps
+    double d = __shfl(row[k], k, 64);
+    if (!(d > 0.0)) { if (lane == 0) *fail = k0 + k + 1; d = 1.0; }
+    const double inv = 1.0 / sqrt(d);  // one division per step; the column and the inverse below only multiply
+    double lik = 0.0;
+    if (own && lane >= k) { lik = (lane == k) ? d * inv : row[k] * inv; row[k] = lik; }
+    if (own) col[lane] = (lane >= k) ? lik : 0.0;
+    if (lane == k) idiag[k] = inv;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (own && lane > k) {
+#pragma unroll
+      for (int j = k + 1; j < NB; ++j)
+        if (j <= lane) row[j] -= lik * col[j];
     }
-    __syncthreads();
-    if (j == k && i > k) L[i][k] /= L[k][k];
-    __syncthreads();
-    if (j > k && i >= j) L[i][j] -= L[i][k] * L[j][k];
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
-  // forward substitution on the identity: column j of Wi solves L w = e_j
-  for (int k = 0; k < NB; ++k) {
-    if (i == k) Wi[k][j] /= L[k][k];
-    __syncthreads();
-    if (i > k) Wi[i][j] -= L[i][k] * Wi[k][j];
-    __syncthreads();
+  if (own) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      Ls[lane][j] = (j <= lane) ? row[j] : 0.0;
+      if (lane < nb && j < nb && j <= lane) A[(size_t)(k0 + j) * N + k0 + lane] = row[j];
+    }
   }
-  if (i < nb && j < nb && i >= j) A[(size_t)(k0 + j) * N + k0 + i] = L[i][j];
-  Linv[j * NB + i] = (i < nb && j < nb && i >= j) ? Wi[i][j] : 0.0;
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  // inverse: lane j solves L w = e_j by forward substitution (w[i] = 0 for i < j)
+  if (own) {
+    double w[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      double sres = (i == lane) ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = 0; k < NB; ++k)
+        if (k < i) sres -= Ls[i][k] * w[k];
+      w[i] = (i >= lane) ? sres * idiag[i] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) Linv[lane * NB + i] = (i < nb && lane < nb && i >= lane) ? w[i] : 0.0;
+  }
 }
 
-// panel: A[i, k0:k0+nb] <- A[i, k0:k0+nb] Linv^T  for i >= k0 + nb.  One thread per row.
+// panel: A[i, k0:k0+nb] <- A[i, k0:k0+nb] Linv^T  for i >= k0 + nb.  Workgroup = 64 rows x 4 column octets:
+// the 64 x NB row tile goes through LDS once, every thread forms 8 of the NB outputs of its row.
 __global__ __launch_bounds__(256) void k_trsm_panel(double *A, int N, int k0, int nb, const double *Linv) {
   __shared__ double Ls[NB * NB];
-  for (int t = threadIdx.x; t < NB * NB; t += 256) Ls[t] = Linv[t];
-  __syncthreads();
-  const int i = k0 + nb + blockIdx.x * 256 + threadIdx.x;
-  if (i >= N) return;
-  double row[NB], out[NB];
-#pragma unroll
-  for (int k = 0; k < NB; ++k) row[k] = (k < nb) ? A[(size_t)(k0 + k) * N + i] : 0.0;
-#pragma unroll
-  for (int c = 0; c < NB; ++c) {
-    double s = 0;
-#pragma unroll
-    for (int k = 0; k < NB; ++k)
-      if (k <= c) s += row[k] * Ls[k * NB + c];  // Linv[c,k]
-    out[c] = s;
+  __shared__ double Rs[64][NB + 1];
+  const int tid = threadIdx.x, r = tid & 63, cq = tid >> 6;
+  const int i0 = k0 + nb + blockIdx.x * 64;
+  for (int t = tid; t < NB * NB; t += 256) Ls[t] = Linv[t];
+  for (int t = tid; t < 64 * NB; t += 256) {
+    const int k = t >> 6, ii = t & 63;  // consecutive threads = consecutive rows of one column: coalesced
+    Rs[ii][k] = (k < nb && i0 + ii < N) ? A[(size_t)(k0 + k) * N + i0 + ii] : 0.0;
   }
+  __syncthreads();
+  const int i = i0 + r;
+  if (i >= N) return;
 #pragma unroll
-  for (int c = 0; c < NB; ++c)
-    if (c < nb) A[(size_t)(k0 + c) * N + i] = out[c];
+  for (int u = 0; u < 8; ++u) {
+    const int c = cq * 8 + u;
+    double s = 0;
+    for (int k = 0; k <= c; ++k) s += Rs[r][k] * Ls[k * NB + c];  // Linv[c,k]
+    if (c < nb) A[(size_t)(k0 + c) * N + i] = s;
+  }
 }
 
 // 64x64 output tile, K = NB slab staged in LDS; thread (tx,ty) owns rows tx+16u, cols ty+16v
@@ -105,35 +133,53 @@ __global__ __launch_bounds__(256) void k_syrk(double *A, int N, int k0, int nb, 
     }
 }
 
-// block row ib of W = L^{-1}:  W[ib,jb] = -Linv_ib (sum_{jb<=kb<ib} L[ib,kb] W[kb,jb]),  W[ib,ib] = Linv_ib
-// grid.x = jb in [0, ib]; 1024 threads = one NB x NB block.
-__global__ __launch_bounds__(1024) void k_trtri_row(const double *L, double *W, int N, int ib, const double *LinvAll) {
+// W = L^{-1}, right-looking by block rows.  Block (ib, jb), jb < ib, of the work matrix accumulates
+// S[ib,jb] = sum_{jb<=kb<ib} L[ib,kb] W[kb,jb]; once every block row above ib is final,
+//   W[ib,ib] = Linv_ib,   W[ib,jb] = -Linv_ib S[ib,jb]                                  (k_trtri_fin, ib + 1 workgroups)
+// and the new row is pushed into all rows below:  S[i,jb] += L[i,ib] W[ib,jb], i > ib, jb <= ib   (k_trtri_upd, 64x64 tiles).
+__global__ __launch_bounds__(1024) void k_trtri_fin(double *W, int N, int ib, const double *LinvAll) {
   const int jb = blockIdx.x;
-  __shared__ double Ls[NB][NB + 1], Ws[NB][NB + 1], Ts[NB][NB + 1];
+  __shared__ double Ts[NB][NB + 1];
   const int i = threadIdx.x % NB, j = threadIdx.x / NB;
   const int r0 = ib * NB, c0 = jb * NB;
   const double *Linv = LinvAll + (size_t)ib * NB * NB;
+  const bool in = r0 + i < N && c0 + j < N;
   if (jb == ib) {
-    if (r0 + i < N && c0 + j < N) W[(size_t)(c0 + j) * N + r0 + i] = Linv[j * NB + i];
+    if (in) W[(size_t)(c0 + j) * N + r0 + i] = Linv[j * NB + i];
     return;
   }
-  double acc = 0;
-  for (int kb = jb; kb < ib; ++kb) {
-    const int k0 = kb * NB;
-    __syncthreads();
-    Ls[i][j] = (r0 + i < N) ? L[(size_t)(k0 + j) * N + r0 + i] : 0.0;  // L[ib,kb](i,j)
-    Ws[i][j] = W[(size_t)(c0 + j) * N + k0 + i];                        // W[kb,jb](i,j)
-    __syncthreads();
-#pragma unroll 8
-    for (int k = 0; k < NB; ++k) acc += Ls[i][k] * Ws[k][j];
-  }
-  __syncthreads();
-  Ts[i][j] = acc;
+  Ts[i][j] = in ? W[(size_t)(c0 + j) * N + r0 + i] : 0.0;
   __syncthreads();
   double s = 0;
 #pragma unroll 8
   for (int k = 0; k < NB; ++k) s += Linv[k * NB + i] * Ts[k][j];  // Linv(i,k)
-  if (r0 + i < N) W[(size_t)(c0 + j) * N + r0 + i] = -s;
+  if (in) W[(size_t)(c0 + j) * N + r0 + i] = -s;
+}
+
+__global__ __launch_bounds__(256) void k_trtri_upd(const double *L, double *W, int N, int ib) {
+  __shared__ double As[NB][65], Bs[NB][65];
+  const int k0 = ib * NB, kn = min(NB, N - k0);
+  const int i0 = k0 + NB + 64 * blockIdx.x, j0 = 64 * blockIdx.y;  // rows below block row ib, columns up to it
+  const int jend = min(N, k0 + NB);
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  for (int t = tid; t < NB * 64; t += 256) {
+    const int k = t >> 6, ii = t & 63;
+    As[k][ii] = (k < kn && i0 + ii < N) ? L[(size_t)(k0 + k) * N + i0 + ii] : 0.0;  // L[i, k0 + k]
+  }
+  for (int t = tid; t < NB * 64; t += 256) {
+    const int k = t & 31, jj = t >> 5;
+    Bs[k][jj] = (k < kn && j0 + jj < jend) ? W[(size_t)(j0 + jj) * N + k0 + k] : 0.0;  // W[k0 + k, j]
+  }
+  __syncthreads();
+  double acc[4][4] = {};
+  tile_mac(As, Bs, kn, tx, ty, acc);
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int i = i0 + tx + 16 * u, j = j0 + ty + 16 * v;
+      if (i < N && j < jend) W[(size_t)j * N + i] += acc[u][v];
+    }
 }
 
 // M = W^T W for lower-triangular W (upper part of W must be zero); tiles with bi >= bj, mirrored.
@@ -176,17 +222,21 @@ int dense_spd_inverse(hipStream_t stream, double *A, double *work, double *M, in
   (void)hipMemsetAsync(work, 0, sizeof(double) * (size_t)N * N, stream);
   for (int kb = 0; kb < nblk; ++kb) {
     const int k0 = kb * NB, nb = (N - k0 < NB) ? N - k0 : NB, s0 = k0 + nb;
-    hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(NB * NB), 0, stream, A, N, k0, nb, LinvAll + (size_t)kb * NB * NB,
+    hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(64), 0, stream, A, N, k0, nb, LinvAll + (size_t)kb * NB * NB,
                        fail_d);
     if (s0 < N) {
-      hipLaunchKernelGGL(k_trsm_panel, dim3((N - s0 + 255) / 256), dim3(256), 0, stream, A, N, k0, nb,
+      hipLaunchKernelGGL(k_trsm_panel, dim3((N - s0 + 63) / 64), dim3(256), 0, stream, A, N, k0, nb,
                          LinvAll + (size_t)kb * NB * NB);
       const int nt = (N - s0 + 63) / 64;
       hipLaunchKernelGGL(k_syrk, dim3(nt, nt), dim3(256), 0, stream, A, N, k0, nb, s0);
     }
   }
-  for (int ib = 0; ib < nblk; ++ib)
-    hipLaunchKernelGGL(k_trtri_row, dim3(ib + 1), dim3(NB * NB), 0, stream, A, work, N, ib, LinvAll);
+  for (int ib = 0; ib < nblk; ++ib) {
+    hipLaunchKernelGGL(k_trtri_fin, dim3(ib + 1), dim3(NB * NB), 0, stream, work, N, ib, LinvAll);
+    const int below = N - (ib + 1) * NB;
+    if (below > 0)
+      hipLaunchKernelGGL(k_trtri_upd, dim3((below + 63) / 64, ((ib + 1) * NB + 63) / 64), dim3(256), 0, stream, A, work, N, ib);
+  }
   const int nt = (N + 63) / 64;
   hipLaunchKernelGGL(k_wtw, dim3(nt, nt), dim3(256), 0, stream, work, M, N);
   int fail = 0;

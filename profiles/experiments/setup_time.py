@@ -1,7 +1,8 @@
 import sys, os, time
 sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), '..', '..'))
 from dpgo_ros_amd import capi
-m,n=capi.read_g2o('data/sphere2500.g2o')
+ROOT=os.path.join(os.path.dirname(os.path.abspath(__file__)),'..','..')
+m,n=capi.read_g2o(os.path.join(ROOT,'data/sphere2500.g2o'))
 T=capi.odometry_init(m,n); Y=capi.fixed_stiefel(5)
 for N in (5,2,1):
     mp=capi.partition(m,n,N) if N>1 else m
