@@ -16,10 +16,14 @@ namespace dpgo {
 //   PM_TCG_STEP stages Hd only: r += alpha Hd, eta += alpha d, z += alpha P(Hd M)   (tCG body, part 2)
 //   PM_RGD      v = gf; X <- Retr_X(-step z); [V <- proj(V + gamma (X - Y))]; partial [2] |X - XPrev|^2
 //               (the whole RGD step + Nesterov V update of the two poses this workgroup owns)
-//               ahead (pipelined iterations, see k_eval_stats): bit 0 = the first wave also takes the Nesterov step of
-//               iteration k+1 of its two poses, bit 1 = the second wave takes it for the workgroup's share of the
-//               other agents' poses; advance: 1 = end-of-iteration bookkeeping here, 2 = pipelined (publishes
-//               stats_sel / next_sel only)
+//               advance: 1 = end-of-iteration bookkeeping here (3-launch iteration), 2 = pipelined iteration (see
+//               k_eval_stats): publishes stats_sel / next_sel only, derives gamma and the restart flags of iterations
+//               k and k+1 from the NestState, and a restart iteration is a plain step with V = Y = X.
+//               ahead (pipelined only), bit 0: the first wave also takes the Nesterov step of iteration k+1 of its
+//               two poses; bit 1: the second wave takes it for the workgroup's share of the other agents' poses;
+//               bit 2: those steps also leave what a status query reads (XPrev, |Y' - X|^2 per pose); bit 3: this
+//               step leaves its statistics (X2 snapshot, |X - XPrev|^2).  Mid-run launches carry 3, the last two
+//               of a run 7 and 8.
 // KC = rows of M (scalars of the input vector) handled per chunk: KC * R * 8 bytes of LDS and KC / 64
 // 16-byte registers per lane.  One 2048-row chunk covers a 500-pose agent in a single round trip with one
 // workgroup per CU; larger agents use 1024-row chunks so that 3 workgroups fit a CU and one workgroup's
