@@ -118,7 +118,7 @@ struct dpgo_team {
   int max_n = 0, max_npub = 0;
   dpgo::RtrState *h_state = nullptr;  // pinned
   double *h_scal = nullptr;     // pinned [16]
-  static constexpr int MAX_GRAPH_ITERS = 32;       // iterations captured in one graph (one graph per distinct count)
+  static constexpr int MAX_GRAPH_ITERS = 64;       // iterations captured in one graph (one graph per distinct count)
   std::map<int, hipGraphExec_t> graphs;            // key: see dpgo_team_run
   std::map<int, int> graph_flip;
   bool graph_valid = false;
