@@ -698,3 +698,21 @@ def test_headline_iterations_to_gap(name, kw, init, coarse, expected):
             break
     th.close()
     assert abs(k - expected) <= 2, (name, k, gap)
+
+
+def test_time_kernel_variants_run():
+    """the measurement entry point bench.py uses for its roofline object: bare preconditioner apply (0), evaluation (1),
+    fused step kernel back to back (9) and inside the running pipelined iteration (10)"""
+    kw = dict(method=capi.METHOD_RGD, rgd_stepsize=0.1, acceleration=1, restart_interval=20)
+    th, to, n = make_pair("smallGrid3D", 3, **kw)
+    th.run(5)
+    n0 = th.agents[1].n
+    for which in (0, 1, 9, 10):
+        ms, nbytes = th.time_kernel(1, which, reps=20)
+        assert 0 < ms < 1.0
+        if which == 0:
+            assert nbytes == 8.0 * (4 * n0) ** 2 + 3 * 8.0 * 5 * 4 * n0
+        if which in (9, 10):
+            others = sum(8.0 * 5 * 4 * th.agents[a].n for a in (0, 2))
+            assert nbytes == 8.0 * (4 * n0) ** 2 + 7 * 8.0 * 5 * 4 * n0 + 4 * others
+    th.close()
