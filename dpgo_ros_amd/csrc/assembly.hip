@@ -110,8 +110,9 @@ void build_Q(Agent &a) {
   }
 }
 
-// upload structure + data matrices of one agent and (re)build the dense preconditioner
-int finalize_agent(dpgo_team *t, Agent &a) {
+// upload structure + data matrices of one agent and assemble Q + shift I densely in `scratch` (2 N4^2 doubles: the
+// matrix and the work area of its inversion, which sync_descs runs for all re-assembled agents at once)
+int finalize_agent(dpgo_team *t, Agent &a, double *scratch) {
   rebuild_index(a);
   if (!a.data_dirty) return 0;
   const int r = t->prm.r, n = a.n, N4 = 4 * n;
@@ -202,12 +203,8 @@ int finalize_agent(dpgo_team *t, Agent &a) {
     HIPC(hipMemsetAsync(a.d_st.p, 0, sizeof(RtrState) * 2, s));
     HIPC(hipMemsetAsync(a.d_part.p, 0, sizeof(double) * PART_TOTAL, s));
   }
-  // dense preconditioner  M = (Q + shift I)^-1
-  if (t->d_tmp.alloc(2 * (size_t)N4 * N4)) { set_err("scratch allocation failed"); return DPGO_ERR; }
-  double *A = t->d_tmp.p, *W = t->d_tmp.p + (size_t)N4 * N4;
-  launch_bsr_to_dense(s, a.d_rowptr.p, a.d_col.p, a.d_qval.p, n, t->prm.precond_shift, A);
-  const int fail = dense_spd_inverse(s, A, W, a.d_M.p, N4);
-  if (fail != 0) { set_err("dense Cholesky of Q + shift I failed at pivot " + std::to_string(fail)); return DPGO_ERR; }
+  // dense preconditioner  M = (Q + shift I)^-1: assembled here, inverted by sync_descs
+  launch_bsr_to_dense(s, a.d_rowptr.p, a.d_col.p, a.d_qval.p, n, t->prm.precond_shift, scratch);
 
   // per-neighbour index tables for the packed-slab exchange (a7)
   size_t max_xfer = 1;
@@ -240,9 +237,35 @@ int finalize_agent(dpgo_team *t, Agent &a) {
 }
 
 int sync_descs(dpgo_team *t) {
-  for (auto &a : t->ag) {
-    const int rc = finalize_agent(t, *a);
-    if (rc) return rc;
+  // agents whose data matrices changed: assemble each, then invert all their Q + shift I in one batch (the many
+  // small dependent steps of the blocked inversions share their launches)
+  {
+    size_t total = 0;
+    for (auto &a : t->ag) {
+      rebuild_index(*a);
+      if (a->data_dirty) total += 2 * (size_t)(4 * a->n) * (4 * a->n);
+    }
+    if (total) {
+      if (t->d_tmp.alloc(total)) { set_err("scratch allocation failed"); return DPGO_ERR; }
+      std::vector<double *> As, Ws, Ms;
+      std::vector<int> Ns;
+      size_t off = 0;
+      for (auto &a : t->ag) {
+        if (!a->data_dirty) continue;
+        const size_t NN = (size_t)(4 * a->n) * (4 * a->n);
+        double *A = t->d_tmp.p + off, *W = A + NN;
+        off += 2 * NN;
+        const int rc = finalize_agent(t, *a, A);
+        if (rc) return rc;
+        As.push_back(A); Ws.push_back(W); Ms.push_back(a->d_M.p); Ns.push_back(4 * a->n);
+      }
+      const int fail = dense_spd_inverse_batched(t->stream, (int)Ns.size(), As.data(), Ws.data(), Ms.data(), Ns.data());
+      if (fail != 0) {
+        set_err("dense Cholesky of Q + shift I failed at pivot " + std::to_string(fail & 0xffffff) + " (matrix " +
+                std::to_string(fail >> 24) + " of the batch)");
+        return DPGO_ERR;
+      }
+    }
   }
   if (!t->descs_dirty) return 0;
   std::vector<AgentDev> descs;

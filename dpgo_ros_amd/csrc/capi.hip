@@ -401,10 +401,9 @@ double dpgo_agent_robust_weight(dpgo_team_t *t, int id, double residual) {
   return robust_weight(t->prm, a->mu, residual);
 }
 
-int dpgo_agent_update_measurement_weights(dpgo_team_t *t, int id) {
-  Agent *a = find_agent(t, id);
-  if (!a) return DPGO_ERR;
-  if (sync_descs(t)) return DPGO_ERR;
+// GNC-TLS weights of one agent from the residuals of its current iterate (it owns a shared edge's weight when it is
+// the lower-ID endpoint); marks its data matrices dirty but rebuilds nothing
+static int update_weights_of(dpgo_team_t *t, Agent *a) {
   std::vector<double> res;
   if (a->has_X && compute_residuals(t, *a, res)) return DPGO_ERR;
   int e = (int)a->odom.size();
@@ -423,13 +422,26 @@ int dpgo_agent_update_measurement_weights(dpgo_team_t *t, int id) {
   a->mu *= t->prm.gnc_mu_step;
   a->robust_inner_iter = 0;
   a->data_dirty = true;
+  return DPGO_OK;
+}
+
+// after the rebuild that follows a weight update: the acceleration restarts from X (V = Y = X, gamma = alpha = 0)
+static int reset_acceleration_of(dpgo_team_t *t, Agent *a) {
+  if (!(t->prm.acceleration && a->has_X)) return DPGO_OK;
+  launch_nest_reset(t->ctx(), a->local, a->n);
+  NestState ns{}; ns.iter = a->iter;
+  HIPC(hipMemcpyAsync(a->dev.nest, &ns, sizeof ns, hipMemcpyHostToDevice, t->stream));
+  return DPGO_OK;
+}
+
+int dpgo_agent_update_measurement_weights(dpgo_team_t *t, int id) {
+  Agent *a = find_agent(t, id);
+  if (!a) return DPGO_ERR;
   if (sync_descs(t)) return DPGO_ERR;
-  if (t->prm.acceleration && a->has_X) {
-    launch_nest_reset(t->ctx(), a->local, a->n);
-    NestState ns{}; ns.iter = a->iter;
-    HIPC(hipMemcpyAsync(a->dev.nest, &ns, sizeof ns, hipMemcpyHostToDevice, t->stream));
-    HIPC(hipStreamSynchronize(t->stream));
-  }
+  if (update_weights_of(t, a)) return DPGO_ERR;
+  if (sync_descs(t)) return DPGO_ERR;
+  if (reset_acceleration_of(t, a)) return DPGO_ERR;
+  HIPC(hipStreamSynchronize(t->stream));
   return DPGO_OK;
 }
 
@@ -873,7 +885,9 @@ int dpgo_team_update_weights(dpgo_team_t *t) {
   if (sync_descs(t)) return DPGO_ERR;
   if (dpgo_team_exchange_all(t)) return DPGO_ERR;
   int changed = 0;
-  for (auto &a : t->ag) if (dpgo_agent_update_measurement_weights(t, a->id)) return DPGO_ERR;
+  // all weights first (every agent's residuals come from the current iterate), then ONE rebuild of the data
+  // matrices and preconditioners of the whole team (batched dense inversions)
+  for (auto &a : t->ag) if (update_weights_of(t, a.get())) return DPGO_ERR;
   for (auto &a : t->ag)
     for (auto &m : a->shared) {
       const int other = (m.r1 == a->id) ? m.r2 : m.r1;
@@ -884,6 +898,8 @@ int dpgo_team_update_weights(dpgo_team_t *t) {
       t->ag[t->id2local[other]]->data_dirty = true;
     }
   if (sync_descs(t)) return DPGO_ERR;
+  for (auto &a : t->ag) if (reset_acceleration_of(t, a.get())) return DPGO_ERR;
+  HIPC(hipStreamSynchronize(t->stream));
   return changed;
 }
 

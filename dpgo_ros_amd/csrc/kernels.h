@@ -61,5 +61,9 @@ void launch_bsr_to_dense(hipStream_t s, const int *rowptr, const int *col, const
 // dense_inverse.hip: M = (A)^-1 for a symmetric positive definite N x N column-major matrix.
 // A is destroyed; work must hold N*N doubles.  Returns 0, or the (1-based) failing pivot block.
 int dense_spd_inverse(hipStream_t stream, double *A, double *work, double *M, int N);
+// the same for `count` matrices at once (one per agent): every step's kernels serve the whole batch (blockIdx.z).
+// Returns 0, or failing pivot + (batch index << 24).
+int dense_spd_inverse_batched(hipStream_t stream, int count, double *const *A, double *const *work, double *const *M,
+                              const int *N);
 
 }  // namespace dpgo

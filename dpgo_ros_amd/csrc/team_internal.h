@@ -134,7 +134,7 @@ void rebuild_index(Agent &a);
 int find_np(const Agent &a, int robot, int frame);
 std::vector<int> public_ids(const Agent &a, int nbr);
 std::vector<int> neighbor_ids(const Agent &a, int nbr);
-int finalize_agent(dpgo_team *t, Agent &a);
+int finalize_agent(dpgo_team *t, Agent &a, double *scratch);
 int sync_descs(dpgo_team *t);
 
 // ---- solve.hip
