@@ -139,7 +139,77 @@ def single_gpu(args):
     cp["classes"] = int(nc)
     conv["plain_rtr"] = cp
     conv["asapp_tunnels"] = asapp_leg(capi)
+    conv["gnc_torus3D"] = gnc_leg(capi)
     return ms, roof, conv, cpu, counters
+
+
+def add_outliers(mod, m, n, frac=0.1, seed=0):
+    """SURVEY 8d-4 (grid3D / rim are not in the tree): seeded synthetic outlier loop closures -- 10 % extra edges,
+    endpoints uniform, R uniform on SO(3), t uniform in the bounding box of the odometry-chained trajectory"""
+    rng = np.random.default_rng(seed)
+    T = mod.odometry_init(m, n).reshape(n, 4, 3)
+    lo, hi = T[:, 3, :].min(0), T[:, 3, :].max(0)
+    k = max(1, int(frac * len(m)))
+    out = np.zeros(k, dtype=mod.MEAS_DTYPE)
+    for e in range(k):
+        i, j = rng.integers(0, n, 2)
+        while abs(int(i) - int(j)) < 2:
+            i, j = rng.integers(0, n, 2)
+        Q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+        Q *= np.sign(np.linalg.det(Q))
+        out[e]["p1"], out[e]["p2"] = i, j
+        out[e]["R"] = Q.reshape(-1)
+        out[e]["t"] = lo + rng.random(3) * (hi - lo)
+        out[e]["kappa"], out[e]["tau"], out[e]["weight"] = np.median(m["kappa"]), np.median(m["tau"]), 1.0
+    return np.concatenate([m, out])
+
+
+def gnc_leg(capi):
+    """BASELINE configs[3] (declared substitution: torus3D + synthetic outliers instead of the absent grid3D / rim):
+    8 agents, GNC-TLS with the parameters of launch/dpgo_gnc_demo.launch:32-42 (RTR 3/50/0.5, barc 3, mu 1e-5 x 2,
+    3 weight updates, 50 inner iterations per robot).  Wall time of the whole robust schedule -- iterations AND the
+    UPDATE_WEIGHT rounds with their Q / G / dense-preconditioner rebuild -- next to the CPU restatement."""
+    from oracle import oracle as O
+    N = 8
+    kw = dict(method=0, acceleration=0, rtr_iterations=3, rtr_tcg_iterations=50, gradnorm_tol=0.5, robust_cost_type=5,
+              gnc_barc=3.0, gnc_mu_step=2.0, gnc_init_mu=1e-5, robust_opt_num_weight_updates=3, robust_opt_inner_iters=50 * N)
+    res = {}
+    for name, mod in (("gpu", capi), ("cpu", O)):
+        m, n = mod.read_g2o(os.path.join(ROOT, "data", "torus3D.g2o"))
+        mo = add_outliers(mod, m, n)
+        mp = mod.partition(mo, n, N)
+        T, Y = mod.odometry_init(mo, n), mod.fixed_stiefel(5)
+        if name == "gpu":
+            t = capi.Team.from_measurements(mp, capi.default_params(r=5, num_robots=N, **kw), device=0)
+            t.set_initial(T, Y)
+            t.synchronize()
+            run, sync = t.run, t.synchronize
+        else:
+            t = O.Team(mp, n, O.default_params(r=5, num_robots=N, **kw))
+            t.set_initial(T, Y)
+            run = lambda k: [t.iterate() for _ in range(k)]
+            sync = lambda: None
+        upd = 0.0
+        t0 = time.perf_counter()
+        for u in range(3):
+            run(50 * N)
+            sync()
+            u0 = time.perf_counter()
+            t.update_weights()
+            sync()
+            upd += time.perf_counter() - u0
+        run(50 * N)
+        sync()
+        total = time.perf_counter() - t0
+        ags = t.agents.values() if isinstance(t.agents, dict) else t.agents
+        w = np.concatenate([a.measurements()["weight"] for a in ags])
+        res[name] = {"total_ms": total * 1e3, "weight_update_ms": upd / 3 * 1e3, "cost": t.cost(),
+                     "agent_edge_weights_below_half": int((w < 0.5).sum())}
+        if name == "gpu":
+            t.close()
+    return {"workload": "torus3D (5000 poses) + 10 % seeded outlier loop closures, 8 agents, GNC-TLS, RTR 3/50/0.5, "
+                        "3 weight updates x 400 iterations + 400", "outliers_planted": int(0.1 * 9048), **{k: v for k, v in res.items()},
+            "cost_rel_diff": abs(res["gpu"]["cost"] - res["cpu"]["cost"]) / abs(res["cpu"]["cost"])}
 
 
 def roofline_leg(team, agent_id):
