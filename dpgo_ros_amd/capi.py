@@ -40,7 +40,8 @@ class Params(C.Structure):
                 ("robust_cost_type", C.c_int), ("gnc_barc", C.c_double),
                 ("gnc_mu_step", C.c_double), ("gnc_init_mu", C.c_double),
                 ("robust_opt_num_weight_updates", C.c_int), ("robust_opt_inner_iters", C.c_int),
-                ("robust_opt_min_convergence_ratio", C.c_double), ("weights_as_float32", C.c_int)]
+                ("robust_opt_min_convergence_ratio", C.c_double), ("weights_as_float32", C.c_int),
+                ("robust_opt_num_resets", C.c_int), ("status_every_iterate", C.c_int)]
 
 
 class OptResult(C.Structure):
@@ -76,7 +77,8 @@ dpgo_agent_robust_weight dpgo_agent_update_measurement_weights dpgo_agent_set_me
 dpgo_agent_get_measurements dpgo_agent_should_update_weights dpgo_agent_clear_data_matrices
 dpgo_error_threshold_at_quantile dpgo_team_set_schedule dpgo_team_set_initial dpgo_team_exchange_all
 dpgo_agent_pull_local dpgo_team_time_kernel dpgo_team_run dpgo_team_get_coloring dpgo_team_run_colored dpgo_team_set_groups dpgo_team_run_group dpgo_team_step_begin dpgo_team_step_end dpgo_team_iteration dpgo_team_cost dpgo_team_update_weights dpgo_team_get_counters
-dpgo_write_measurements_csv dpgo_write_g2o dpgo_write_trajectory_csv dpgo_robust_frame_alignment dpgo_robust_local_init dpgo_team_run_simultaneous""".split()
+dpgo_write_measurements_csv dpgo_write_g2o dpgo_write_trajectory_csv dpgo_robust_frame_alignment dpgo_robust_local_init dpgo_team_run_simultaneous
+dpgo_team_should_terminate dpgo_team_run_schedule""".split()
 
 
 class DpgoError(RuntimeError):
@@ -453,6 +455,17 @@ class Team:
         col = np.zeros(len(self.ids), dtype=np.int32)
         nc = _chk(lib().dpgo_team_get_coloring(self.h, _d(col)), "get_coloring")
         return nc, col
+
+    def should_terminate(self):
+        """PGOAgent::shouldTerminate() as the leader evaluates it (src/PGOAgentROS.cpp:208)"""
+        return bool(_chk(lib().dpgo_team_should_terminate(self.h), "should_terminate"))
+
+    def run_schedule(self, max_iters):
+        """the synchronous schedule with the leader's TERMINATE / UPDATE_WEIGHT decisions (src/PGOAgentROS.cpp:206-214);
+        returns (iterations executed, terminated, weight-update rounds)"""
+        term, rounds = C.c_int(0), C.c_int(0)
+        done = _chk(lib().dpgo_team_run_schedule(self.h, int(max_iters), C.byref(term), C.byref(rounds)), "run_schedule")
+        return done, bool(term.value), rounds.value
 
     def run_simultaneous(self, ticks):
         """every agent takes `ticks` RGD steps, all agents per tick in the same launches (ASAPP, clocks in lockstep)"""

@@ -23,10 +23,13 @@ void dpgo_default_params(dpgo_params_t *p, int r, int num_robots) {
   p->robust_opt_num_weight_updates = 4; p->robust_opt_inner_iters = 10 * num_robots;
   p->robust_opt_min_convergence_ratio = 0.8;
   p->weights_as_float32 = 0;
+  p->robust_opt_num_resets = 0;   // launch/PGOAgent.launch:33
+  p->status_every_iterate = 0;
 }
 
 dpgo_team_t *dpgo_team_create(int device, const dpgo_params_t *p, int num_local, const int *agent_ids, void *stream) {
   if (p->d != 3 || p->r < 3 || p->r > 8) { set_err("d must be 3 and r in [3,8]"); return nullptr; }
+  if (p->robust_opt_num_resets < 0) { set_err("robust_opt_num_resets must be >= 0"); return nullptr; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
     set_err("no HIP device: libdpgo_hip has no CPU fallback");
@@ -221,6 +224,7 @@ int dpgo_agent_iterate(dpgo_team_t *t, int id, int do_optimization) {
   if (opt && !neighbor_poses_ready(*a, t->prm.acceleration ? 1 : 0)) { opt = false; a->last_success = false; }
   const int rc = enqueue_iterate(t, a->local, opt ? 1 : 0);
   if (rc) return rc;
+  if (do_optimization) mark_optimized(t, *a, opt ? (a->rel_src == 1 ? 1 : 5) : 2, opt);
   a->iter++;
   if (t->prm.acceleration || opt) a->publish_requested = true;
   return a->last_success ? DPGO_OK : DPGO_NOT_READY;
@@ -231,6 +235,30 @@ int dpgo_agent_get_status(dpgo_team_t *t, int id, dpgo_status_t *s) {
   if (!a) return DPGO_ERR;
   s->agent_id = a->id; s->state = a->state; s->instance_number = a->instance; s->iteration_number = a->iter;
   s->relative_change = 0; s->ready_to_terminate = 0;
+  const bool robust = t->prm.robust_cost_type != DPGO_COST_L2;
+  if (!t->prm.status_every_iterate) {
+    // the status block describes the agent's last iterate(true)
+    if (!a->has_X || a->opt_rel_src < 0) return DPGO_OK;
+    if (!a->opt_cached) {
+      double sum = 0;
+      if (a->opt_rel_src != 2) {
+        const bool tiles = a->opt_rel_src == 5;
+        const int cnt = tiles ? (a->n + 63) / 64 : (4 * a->n + 7) / 8;
+        const int off = tiles ? PART_E : PART_B + 2;
+        std::vector<double> part((size_t)cnt * PART_STRIDE);
+        HIPC(hipMemcpyAsync(part.data(), a->dev.part + off, sizeof(double) * ((size_t)(cnt - 1) * PART_STRIDE + 1),
+                            hipMemcpyDeviceToHost, t->stream));
+        HIPC(hipStreamSynchronize(t->stream));
+        for (int k = 0; k < cnt; ++k) sum += part[(size_t)k * PART_STRIDE];
+      }
+      a->opt_rel_change = std::sqrt(sum / a->n);
+      a->opt_cached = true;
+    }
+    s->relative_change = a->opt_rel_change;
+    s->ready_to_terminate = a->opt_success && (s->relative_change <= t->prm.rel_change_tol) &&
+                            (!robust || a->opt_ratio >= t->prm.robust_opt_min_convergence_ratio);
+    return DPGO_OK;
+  }
   if (!a->has_X || a->iter == 0 || a->rel_src == 2) { s->ready_to_terminate = a->has_X && a->iter > 0 && a->last_success; return DPGO_OK; }
   // |X - XPrev|^2 partials were left by the last kernel that moved X (fixed summation order)
   const int cnt = a->rel_src == 4 ? a->n : (a->rel_src ? (4 * a->n + 7) / 8 : (a->n + 63) / 64);
@@ -243,7 +271,8 @@ int dpgo_agent_get_status(dpgo_team_t *t, int id, dpgo_status_t *s) {
   double sum = 0;
   for (int k = 0; k < cnt; ++k) sum += part[(size_t)k * stride];
   s->relative_change = std::sqrt(sum / a->n);
-  s->ready_to_terminate = a->last_success && (s->relative_change <= t->prm.rel_change_tol);
+  s->ready_to_terminate = a->last_success && (s->relative_change <= t->prm.rel_change_tol) &&
+                          (!robust || converged_ratio(*a) >= t->prm.robust_opt_min_convergence_ratio);
   return DPGO_OK;
 }
 
@@ -646,12 +675,15 @@ int dpgo_team_run(dpgo_team_t *t, int iters) {
       LaunchCtx c = t->ctx();
       const int na = (int)t->ag.size(), mn = t->max_n;
       launch_nest_pre(c, -1, -1, na, mn, p.num_robots, p.restart_interval, 1);
+      // the last L = min(B, schedule period) steps leave their statistics (X2 snapshot, |X - XPrev|^2: every agent's
+      // last block update of the run lies among them, and a status query reads it, a9), the look-aheads in front of
+      // them leave XPrev and |Y' - X|^2; nothing reads these values earlier in the run
+      const int L = std::min(B, (int)t->sched.size());
       for (int rep = 0; rep < B; ++rep) {
-        // statistics (X2 snapshot, |X - XPrev|^2) only from the last step, status data (XPrev, |Y' - X|^2) only from
-        // the last look-ahead: nothing reads them in between
         launch_eval_stats(c, mn, rep == 0, 1, 0, p.num_robots, p.restart_interval);
+        const int ahead = (rep + 1 < B ? 3 : 0) | ((rep + 1 < B && rep + 1 >= B - L) ? 4 : 0) | (rep >= B - L ? 8 : 0);
         launch_precond(c, -1, mn, PM_RGD_, B_X, B_GF, B_Z, 0, 0, p.rgd_stepsize, 1, p.num_robots, 2, p.restart_interval,
-                       rep + 1 < B ? (rep + 2 == B ? 7 : 3) : 8);
+                       ahead);
       }
       launch_eval_stats(c, mn, 0, 0, 1, p.num_robots, p.restart_interval);
     } else if (rc == 0 && B > 0 && p.acceleration) {
@@ -710,6 +742,8 @@ int dpgo_team_run(dpgo_team_t *t, int iters) {
         const int sel = t->sched[(t->iter + q) % t->sched.size()];
         account(sel);
         if (restart && q == 0) account(sel);  // the restart iteration solves twice (from Y, then from XPrev)
+        // status of this block update: the fused step leaves PART_B[2], the un-fused restart iteration k_status tiles
+        mark_optimized(t, *t->ag[sel], (restart && q == 0) ? 5 : 1, true);
         if (q == batch - 1) {
           t->ag[sel]->opt_pending_rgd = true;
           t->ag[sel]->rel_src = (fusedn > 0) ? 1 : 0;  // a lone restart iteration ends with k_status (PART_D tiles)
@@ -720,6 +754,8 @@ int dpgo_team_run(dpgo_team_t *t, int iters) {
       for (auto &a : t->ag) a->rel_src = p.acceleration ? 0 : 2;
       const int rc = enqueue_team_iteration(t, false, restart, sel, 0);
       if (rc) return rc;
+      t->ag[sel]->rel_src = 0;  // k_status tiles of the block update (this path never runs the fused step)
+      mark_optimized(t, *t->ag[sel], 5, true);
     }
     t->iter += batch;
     for (auto &a : t->ag) { a->iter += batch; if (p.robust_cost_type != DPGO_COST_L2) a->robust_inner_iter += batch; }
@@ -767,9 +803,16 @@ int dpgo_team_run_group(dpgo_team_t *t, int g, int count) {
     if (rc) return rc;
   }
   launch_status(c, -3, -1, na, t->max_n);
+  if (!t->groups[g].empty()) {
+    LaunchCtx cg = c;
+    cg.ny = (int)t->groups[g].size();
+    int gmn = 0;
+    for (int k : t->groups[g]) gmn = std::max(gmn, t->ag[k]->n);
+    launch_status(cg, SEL_GROUP0 - g, -1, cg.ny, gmn, 1);
+  }
   launch_advance(c, -1, na, 0, p.num_robots, p.restart_interval, 1, count);
   for (auto &a : t->ag) { a->rel_src = 0; a->iter += count; if (p.robust_cost_type != DPGO_COST_L2) a->robust_inner_iter += count; }
-  for (int k : t->groups[g]) t->ag[k]->publish_requested = true;
+  for (int k : t->groups[g]) { t->ag[k]->publish_requested = true; mark_optimized(t, *t->ag[k], 5, true); }
   t->iter += count;
   t->counters[4] += count;
   return 0;
@@ -833,6 +876,7 @@ int dpgo_team_run_simultaneous(dpgo_team_t *t, int ticks) {
     t->counters[0] += ticks; t->counters[1] += ticks * 8.0 * N4 * N4;
     t->counters[2] += ticks + 1; t->counters[3] += (ticks + 1) * spmm_bytes_of(t, *a);
     a->rel_src = 1; a->iter += ticks; a->opt_pending_rgd = true; a->publish_requested = true;
+    mark_optimized(t, *a, 1, true);
     if (p.robust_cost_type != DPGO_COST_L2) a->robust_inner_iter += ticks;
   }
   t->iter += ticks * na;
@@ -854,8 +898,16 @@ int dpgo_team_run_colored(dpgo_team_t *t, int sweeps) {
       const int rc = enqueue_optimize_group(t, (int)g);
       if (rc) return rc;
       launch_status(c, -3, -1, na, t->max_n);
+      if (gs > 0) {
+        LaunchCtx cg = c;
+        cg.ny = gs;
+        int gmn = 0;
+        for (int k : t->groups[g]) gmn = std::max(gmn, t->ag[k]->n);
+        launch_status(cg, SEL_GROUP0 - (int)g, -1, gs, gmn, 1);
+      }
       launch_advance(c, -1, na, 0, p.num_robots, p.restart_interval, 1, gs);
       for (auto &a : t->ag) { a->rel_src = 0; a->iter += gs; if (p.robust_cost_type != DPGO_COST_L2) a->robust_inner_iter += gs; }
+      for (int k : t->groups[g]) mark_optimized(t, *t->ag[k], 5, true);
       t->iter += gs;
       t->counters[4] += gs;
     }
@@ -901,6 +953,55 @@ int dpgo_team_update_weights(dpgo_team_t *t) {
   for (auto &a : t->ag) if (reset_acceleration_of(t, a.get())) return DPGO_ERR;
   HIPC(hipStreamSynchronize(t->stream));
   return changed;
+}
+
+// PGOAgent::shouldTerminate() from the leader's point of view [UPSTREAM-RECALL for the body; in tree: only the leader
+// evaluates it, right after its own iterate(true), src/PGOAgentROS.cpp:206-214; max_num_iters rule Node.cpp:228-232]
+int dpgo_team_should_terminate(dpgo_team_t *t) {
+  Agent *lead = find_agent(t, 0);
+  if (!lead) { set_err("should_terminate: robot 0 (the leader) does not live in this team"); return DPGO_ERR; }
+  if ((int)t->ag.size() != t->prm.num_robots) { set_err("should_terminate: the team must hold every robot"); return DPGO_ERR; }
+  if (lead->iter > t->prm.max_num_iters) return 1;
+  if (t->prm.robust_cost_type != DPGO_COST_L2 && lead->weight_update_count < t->prm.robust_opt_num_weight_updates) return 0;
+  for (auto &a : t->ag) {
+    dpgo_status_t s;
+    if (dpgo_agent_get_status(t, a->id, &s) != DPGO_OK) return DPGO_ERR;
+    if (s.state != DPGO_INITIALIZED || !s.ready_to_terminate) return 0;
+  }
+  return 1;
+}
+
+int dpgo_team_run_schedule(dpgo_team_t *t, int max_iters, int *terminated, int *weight_rounds) {
+  if (sync_descs(t)) return DPGO_ERR;
+  auto itl = t->id2local.find(0);
+  if (itl == t->id2local.end()) { set_err("run_schedule: robot 0 (the leader) does not live in this team"); return DPGO_ERR; }
+  const int lead = itl->second, len = (int)t->sched.size();
+  bool in_sched = false;
+  for (int s : t->sched) in_sched = in_sched || s == lead;
+  if (!in_sched) { set_err("run_schedule: the leader never optimizes under this schedule"); return DPGO_ERR; }
+  int done = 0, term = 0, rounds = 0;
+  while (done < max_iters) {
+    // iterations up to and including the leader's next block update: only then is anything decided (:206)
+    int chunk = 1;
+    while (t->sched[(t->iter + chunk - 1) % len] != lead) ++chunk;
+    const bool reaches_leader = chunk <= max_iters - done;
+    chunk = std::min(chunk, max_iters - done);
+    const int rc = dpgo_team_run(t, chunk);
+    if (rc) return rc;
+    done += chunk;
+    if (!reaches_leader) break;
+    const int st = dpgo_team_should_terminate(t);
+    if (st < 0) return st;
+    if (st) { term = 1; break; }
+    if (dpgo_agent_should_update_weights(t, 0) == 1) {
+      const int wr = dpgo_team_update_weights(t);
+      if (wr < 0) return wr;
+      ++rounds;
+    }
+  }
+  if (terminated) *terminated = term;
+  if (weight_rounds) *weight_rounds = rounds;
+  return done;
 }
 
 int dpgo_team_get_counters(dpgo_team_t *t, double *out, int n) {

@@ -83,7 +83,9 @@ constexpr int PART_B = MAX_PART * PART_STRIDE;        // preconditioner-type ker
 constexpr int PART_C = 2 * MAX_PART * PART_STRIDE;    // outer-step / initial evaluation
 constexpr int PART_D = 3 * MAX_PART * PART_STRIDE;    // per-pose kernels: |X - XPrev|^2 partials (per 64-pose tile; one double per
                                                       // pose after a look-ahead Nesterov step)
-constexpr int PART_TOTAL = 4 * MAX_PART * PART_STRIDE;
+constexpr int PART_E = 4 * MAX_PART * PART_STRIDE;    // |X - XPrev|^2 tiles of the agent's last iterate(true) (k_status, opt != 0):
+                                                      // nothing an iterate(false) launches writes here
+constexpr int PART_TOTAL = 5 * MAX_PART * PART_STRIDE;
 
 constexpr int LOOKAHEAD_MAX_AGENTS = 8;  // look-ahead Nesterov steps locate a pose's agent with one 9-int fetch
 

@@ -45,7 +45,8 @@ void launch_nest_post(const LaunchCtx &c, int sel, int max_n, int num_robots, in
 void launch_nest_reset(const LaunchCtx &c, int sel, int max_n);
 void launch_advance(const LaunchCtx &c, int only_agent, int num_agents, int accel, int num_robots, int restart_interval,
                     int bump_team, int inc = 1, int team_inc = -1 /* = inc */);
-void launch_status(const LaunchCtx &c, int sel, int only_agent, int num_agents, int max_n);
+// opt != 0: the agent(s) just took a block update; the tiles are also left in PART_E (status of the last iterate(true))
+void launch_status(const LaunchCtx &c, int sel, int only_agent, int num_agents, int max_n, int opt = 0);
 void launch_rtr_begin(const LaunchCtx &c, int sel, double Delta0, double tol, int max_outer);
 void launch_rtr_eval2(const LaunchCtx &c, int sel, int max_n, int sp);
 void launch_rtr_accept(const LaunchCtx &c, int sel, int max_n, int sp, double tol, int max_outer, double max_radius);

@@ -127,7 +127,7 @@ __global__ void k_advance(const AgentDev *agents, TeamDev *team, int only_agent,
 
 // PART_D partial [0] = |X - XPrev|_F^2 over a 64-pose tile (blockIdx.y = agent when sel == -3)
 template <int R>
-__global__ __launch_bounds__(64) void k_status(const AgentDev *agents, const TeamDev *team, int sel, int only_agent) {
+__global__ __launch_bounds__(64) void k_status(const AgentDev *agents, const TeamDev *team, int sel, int only_agent, int opt) {
   const int ai = only_agent >= 0 ? only_agent : (sel == -3 ? (int)blockIdx.y : sel_cur(team, sel));
   const AgentDev &ag = agents[ai];
   const int j0 = blockIdx.x * 64, tid = threadIdx.x;
@@ -143,7 +143,10 @@ __global__ __launch_bounds__(64) void k_status(const AgentDev *agents, const Tea
 #pragma unroll
   for (int k = 0; k < 4 * R; ++k) { const double d = xa[k] - xb[k]; s += d * d; }
   s = wave_sum(s);
-  if (tid == 0) ag.part[PART_D + (size_t)blockIdx.x * PART_STRIDE] = s;
+  if (tid == 0) {
+    ag.part[PART_D + (size_t)blockIdx.x * PART_STRIDE] = s;
+    if (opt) ag.part[PART_E + (size_t)blockIdx.x * PART_STRIDE] = s;  // status of the last block update (a9)
+  }
 }
 
 // buf[to] = buf[from] for one agent or (sel == -3) every agent (blockIdx.y).  As the first kernel of a
@@ -337,9 +340,9 @@ void launch_advance(const LaunchCtx &c, int only_agent, int num_agents, int acce
                      only_agent, accel, num_robots, restart_interval, bump_team, inc, team_inc < 0 ? inc : team_inc);
 }
 
-void launch_status(const LaunchCtx &c, int sel, int only_agent, int num_agents, int max_n) {
-  dim3 grid((max_n + 63) / 64, (sel == -3 && only_agent < 0) ? num_agents : 1);
-  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_status<R>, grid, dim3(64), 0, c.stream, c.agents, c.team, sel, only_agent));
+void launch_status(const LaunchCtx &c, int sel, int only_agent, int num_agents, int max_n, int opt) {
+  dim3 grid((max_n + 63) / 64, (sel == -3 && only_agent < 0) ? num_agents : ((sel <= SEL_GROUP0 && only_agent < 0) ? c.ny : 1));
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_status<R>, grid, dim3(64), 0, c.stream, c.agents, c.team, sel, only_agent, opt));
 }
 
 void launch_rtr_begin(const LaunchCtx &c, int sel, double Delta0, double tol, int max_outer) {

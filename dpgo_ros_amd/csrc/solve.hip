@@ -7,6 +7,23 @@ using namespace dpgo;
 
 namespace dpgo_host {
 
+// share of loop closures whose GNC weight has converged to 0 or 1 (robustOptMinConvergenceRatio,
+// src/PGOAgentROSNode.cpp:214) [UPSTREAM-RECALL]
+double converged_ratio(const Agent &a) {
+  size_t total = a.priv.size() + a.shared.size(), conv = 0;
+  for (const auto &m : a.priv) if (m.weight == 1.0 || m.weight == 0.0) ++conv;
+  for (const auto &m : a.shared) if (m.weight == 1.0 || m.weight == 0.0) ++conv;
+  return total ? (double)conv / (double)total : 1.0;
+}
+
+// the agent just ran iterate(true): remember where the status of this block update can be read
+void mark_optimized(dpgo_team *t, Agent &a, int rel_src, bool success) {
+  a.opt_rel_src = rel_src;
+  a.opt_success = success;
+  a.opt_cached = false;
+  a.opt_ratio = (t->prm.robust_cost_type != DPGO_COST_L2) ? converged_ratio(a) : 1.0;
+}
+
 bool neighbor_poses_ready(const Agent &a, int aux) {
   for (char h : a.np_has[aux]) if (!h) return false;
   return true;
@@ -140,7 +157,7 @@ int enqueue_iterate(dpgo_team *t, int li, int do_opt) {
         if (rc) return rc;
         launch_nest_reset(c, li, a.n);
       }
-      if (fused) a.rel_src = 1; else launch_status(c, li, li, 1, a.n);
+      if (fused) a.rel_src = 1; else launch_status(c, li, li, 1, a.n, 1);
     }
   } else {
     launch_copy(c, li, li, 1, a.n, B_X, B_XPREV, 0);
@@ -148,7 +165,7 @@ int enqueue_iterate(dpgo_team *t, int li, int do_opt) {
       rc = enqueue_optimize(t, li, fl);
       if (rc) return rc;
     }
-    if (fused) a.rel_src = 1; else launch_status(c, li, li, 1, a.n);
+    if (fused) a.rel_src = 1; else launch_status(c, li, li, 1, a.n, do_opt ? 1 : 0);
   }
   launch_advance(c, li, 1, p.acceleration, p.num_robots, p.restart_interval, 0);
   return 0;
@@ -229,7 +246,7 @@ int enqueue_team_iteration(dpgo_team *t, bool capture, bool restart, int sel, in
           launch_nest_reset(c, sel, ns);
         }
       }
-      launch_status(c, sel, -1, 1, ns);
+      launch_status(c, sel, -1, 1, ns, 1);
     }
   }
   if (!fused) launch_advance(c, -1, na, p.acceleration, p.num_robots, p.restart_interval, 1);
@@ -248,6 +265,7 @@ void account_iteration(dpgo_team *t, int sel, bool fused) {
   if (sel >= 0) {
     t->ag[sel]->rel_src = fused ? 1 : 0;
     t->ag[sel]->publish_requested = true;
+    mark_optimized(t, *t->ag[sel], fused ? 1 : 5, true);
   }
   t->iter += 1;
   t->counters[4] += 1;

@@ -86,6 +86,12 @@ struct Agent {
   int tcg_hint = 4, outer_hint = -1;  // launch-pattern sizing from the previous solve of this agent
   int rel_src = 0;  // where the last |X - XPrev|^2 partials live: 0 PART_D (per 64-pose tile), 1 PART_B[2] (fused RGD),
                     // 2 none (X untouched), 4 PART_D one double per pose (look-ahead Nesterov step)
+  // status of the last iterate(true) (a9; refreshed only when the agent optimizes unless status_every_iterate):
+  // where its |X - XPrev|^2 partials live (-1 never optimized, 1 PART_B[2], 2 X untouched, 5 PART_E tiles), whether
+  // the solve ran, the share of converged GNC weights at that moment, and the host copy once it has been read
+  int opt_rel_src = -1;
+  bool opt_success = false, opt_cached = false;
+  double opt_ratio = 1.0, opt_rel_change = 0.0;
   DevBuf<SharedEdgeDev> d_se;
   DevBuf<EdgeDev> d_edges;
   DevBuf<RtrState> d_st;
@@ -138,6 +144,8 @@ int finalize_agent(dpgo_team *t, Agent &a, double *scratch);
 int sync_descs(dpgo_team *t);
 
 // ---- solve.hip
+double converged_ratio(const Agent &a);
+void mark_optimized(dpgo_team *t, Agent &a, int rel_src, bool success);
 struct OptFlags { int aux = 0, pull = 0; bool capture = false, fused = false, last_advances = false; };
 bool neighbor_poses_ready(const Agent &a, int aux);
 EvalOpts eval_opts(const dpgo_team *t, int gmode, int aux, int advance);

@@ -56,6 +56,10 @@ typedef struct {
   int robust_opt_num_weight_updates, robust_opt_inner_iters;
   double robust_opt_min_convergence_ratio;
   int weights_as_float32;
+  int robust_opt_num_resets;  /* src/PGOAgentROSNode.cpp:213: written by the wrapper, never read by it; its semantics live
+                               * in the absent library -> carried, validated (>= 0), no effect */
+  int status_every_iterate;   /* 0 (default): relativeChange / readyToTerminate describe the last iterate(true) of the
+                               * agent [UPSTREAM-RECALL]; 1: refreshed by every iterate (round-1 behaviour) */
 } dpgo_params_t;
 
 /* mLocalOptResult.{success,fInit,fOpt,gradNormInit,gradNormOpt} (src/PGOAgentROS.cpp:169-172) */
@@ -202,6 +206,14 @@ int dpgo_team_iteration(dpgo_team_t *t);
 /* global cost of the concatenated iterate, evaluated on the device */
 int dpgo_team_cost(dpgo_team_t *t, double *f);
 int dpgo_team_update_weights(dpgo_team_t *t);
+/* PGOAgent::shouldTerminate() as the leader (robot 0) evaluates it from the team's statuses
+ * (src/PGOAgentROS.cpp:208): 1 terminate, 0 continue, <0 error.  All robots must live in this team. */
+int dpgo_team_should_terminate(dpgo_team_t *t);
+/* the synchronous schedule with the leader's decisions (src/PGOAgentROS.cpp:129-220): iterate; after every iteration
+ * in which the leader optimized: stop if shouldTerminate() (:208), else an UPDATE_WEIGHT round if
+ * shouldUpdateMeasurementWeights() (:210), else pass the token (:213).  Returns the number of iterations executed
+ * (<= max_iters) or <0; *terminated / *weight_rounds may be NULL. */
+int dpgo_team_run_schedule(dpgo_team_t *t, int max_iters, int *terminated, int *weight_rounds);
 /* refresh this agent's neighbour slabs from co-resident agents (device-to-device) */
 int dpgo_agent_pull_local(dpgo_team_t *t, int id);
 /* average HIP-event duration of one launch of a hot kernel on the team stream.

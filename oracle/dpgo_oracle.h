@@ -61,6 +61,12 @@ typedef struct {
   int robust_opt_num_weight_updates, robust_opt_inner_iters; /* :212-221 */
   double robust_opt_min_convergence_ratio;
   int weights_as_float32;     /* msg/RelativeMeasurementWeights.msg:8 wire rounding */
+  int robust_opt_num_resets;  /* PGOAgentROSNode.cpp:213: set by the wrapper, never read by it; semantics live in the
+                               * absent library and are not recoverable here -> carried, no effect */
+  int status_every_iterate;   /* 0 (default): relativeChange / readyToTerminate are refreshed by iterate(true) only
+                               * [UPSTREAM-RECALL, and the only rule under which the leader's check at
+                               * PGOAgentROS.cpp:206-214 is meaningful without acceleration: iterate(false) leaves
+                               * X = XPrev]; 1: refreshed by every iterate (round-1 behaviour) */
 } orc_params_t;
 
 typedef struct {
@@ -150,6 +156,12 @@ double orc_team_cost(orc_team_t *t);       /* f of the concatenated iterate: sum
 int orc_team_iteration(const orc_team_t *t);
 void orc_team_get_global_X(orc_team_t *t, double *X); /* r x 4 num_poses */
 int orc_team_update_weights(orc_team_t *t); /* UPDATE_WEIGHT round (:1211-1233); returns #changed */
+/* PGOAgent::shouldTerminate() as the leader (robot 0) evaluates it from mTeamStatus (PGOAgentROS.cpp:208) */
+int orc_team_should_terminate(const orc_team_t *t);
+/* the synchronous schedule as the wrapper runs it (PGOAgentROS.cpp:129-220): iterate; after every iteration in which
+ * the leader optimized: TERMINATE if shouldTerminate(), else an UPDATE_WEIGHT round if shouldUpdateMeasurementWeights(),
+ * else pass the token.  Returns the number of iterations executed (<= max_iters); *terminated, *weight_rounds optional. */
+int orc_team_run_schedule(orc_team_t *t, int max_iters, int *terminated, int *weight_rounds);
 
 /* ---------- initialisation + centralized reference solve ---------- */
 void orc_odometry_init(const orc_meas_t *m, int nm, int num_poses, double *T);

@@ -38,7 +38,8 @@ class Params(C.Structure):
                 ("robust_cost_type", C.c_int), ("gnc_barc", C.c_double),
                 ("gnc_mu_step", C.c_double), ("gnc_init_mu", C.c_double),
                 ("robust_opt_num_weight_updates", C.c_int), ("robust_opt_inner_iters", C.c_int),
-                ("robust_opt_min_convergence_ratio", C.c_double), ("weights_as_float32", C.c_int)]
+                ("robust_opt_min_convergence_ratio", C.c_double), ("weights_as_float32", C.c_int),
+                ("robust_opt_num_resets", C.c_int), ("status_every_iterate", C.c_int)]
 
 
 class OptResult(C.Structure):
@@ -348,6 +349,17 @@ class Team:
 
     def exchange_all(self):
         lib().orc_team_exchange_all(self.h)
+
+    def should_terminate(self):
+        """PGOAgent::shouldTerminate() as the leader evaluates it (PGOAgentROS.cpp:208)."""
+        return bool(lib().orc_team_should_terminate(self.h))
+
+    def run_schedule(self, max_iters):
+        """The synchronous schedule with the leader's TERMINATE / UPDATE_WEIGHT decisions (PGOAgentROS.cpp:206-214).
+        Returns (iterations executed, terminated, weight-update rounds)."""
+        term, rounds = C.c_int(0), C.c_int(0)
+        done = lib().orc_team_run_schedule(self.h, int(max_iters), C.byref(term), C.byref(rounds))
+        return done, bool(term.value), rounds.value
 
     def cost(self):
         return lib().orc_team_cost(self.h)

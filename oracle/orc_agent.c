@@ -39,6 +39,8 @@ void orc_default_params(orc_params_t *p, int r, int num_robots) {
   p->robust_opt_inner_iters = 10 * num_robots; /* PGOAgentROSNode.cpp:216-218 */
   p->robust_opt_min_convergence_ratio = 0.8;
   p->weights_as_float32 = 0;
+  p->robust_opt_num_resets = 0;  /* launch/PGOAgent.launch:33 */
+  p->status_every_iterate = 0;
 }
 
 struct orc_agent {
@@ -367,6 +369,13 @@ static void reset_acceleration(orc_agent_t *a) {
   a->gamma = 0; a->alpha = 0;
 }
 
+static double converged_ratio(const orc_agent_t *a) {
+  int total = a->npriv + a->nshared, conv = 0;
+  for (int k = 0; k < a->npriv; ++k) if (a->priv[k].weight == 1.0 || a->priv[k].weight == 0.0) ++conv;
+  for (int k = 0; k < a->nshared; ++k) if (a->shared[k].weight == 1.0 || a->shared[k].weight == 0.0) ++conv;
+  return total ? (double)conv / total : 1.0;
+}
+
 int orc_agent_iterate(orc_agent_t *a, int do_opt) {
   a->iter++;
   if (a->prm.robust_cost_type != ORC_COST_L2) a->robust_inner_iter++;
@@ -396,14 +405,22 @@ int orc_agent_iterate(orc_agent_t *a, int do_opt) {
     success = update_X(a, do_opt, 0);
     if (do_opt) a->publish_requested = 1;
   }
-  double s = 0;
-  for (size_t i = 0; i < N; ++i) { double d = a->X[i] - a->XPrev[i]; s += d * d; }
   a->status.agent_id = a->id;
   a->status.state = a->state;
   a->status.instance_number = a->instance;
   a->status.iteration_number = a->iter;
-  a->status.relative_change = sqrt(s / n);
-  a->status.ready_to_terminate = success && (a->status.relative_change <= a->prm.rel_change_tol);
+  if (do_opt || a->prm.status_every_iterate) {
+    /* [UPSTREAM-RECALL] the status block sits under `if (doOptimization)`: a robot's relativeChange /
+     * readyToTerminate describe its last block update, not the Nesterov bookkeeping of iterate(false) */
+    double s = 0;
+    for (size_t i = 0; i < N; ++i) { double d = a->X[i] - a->XPrev[i]; s += d * d; }
+    a->status.relative_change = sqrt(s / n);
+    int ready = success && (a->status.relative_change <= a->prm.rel_change_tol);
+    /* robustOptMinConvergenceRatio (PGOAgentROSNode.cpp:214) [UPSTREAM-RECALL]: share of loop closures whose GNC
+     * weight has converged to 0 or 1 */
+    if (a->prm.robust_cost_type != ORC_COST_L2 && converged_ratio(a) < a->prm.robust_opt_min_convergence_ratio) ready = 0;
+    a->status.ready_to_terminate = ready;
+  }
   return success;
 }
 
@@ -676,6 +693,34 @@ int orc_team_update_weights(orc_team_t *t) {
   }
   for (int k = 0; k < t->N; ++k) team_publish(t, k, t->prm.acceleration);
   return changed;
+}
+
+/* PGOAgent::shouldTerminate() from the leader's mTeamStatus (messages delivered at once) [UPSTREAM-RECALL for the
+ * body; in-tree: evaluated by the leader only, right after its own iterate(true), PGOAgentROS.cpp:206-214; the
+ * robust max_num_iters rule, PGOAgentROSNode.cpp:228-232] */
+int orc_team_should_terminate(const orc_team_t *t) {
+  const orc_agent_t *lead = t->ag[0];
+  if (lead->iter > t->prm.max_num_iters) return 1;
+  if (t->prm.robust_cost_type != ORC_COST_L2 && lead->weight_update_count < t->prm.robust_opt_num_weight_updates) return 0;
+  for (int k = 0; k < t->N; ++k) {
+    if (t->ag[k]->state != ORC_STATE_INITIALIZED) return 0;
+    if (!t->ag[k]->status.ready_to_terminate) return 0;
+  }
+  return 1;
+}
+
+int orc_team_run_schedule(orc_team_t *t, int max_iters, int *terminated, int *weight_rounds) {
+  int done = 0, term = 0, rounds = 0;
+  while (done < max_iters) {
+    int sel = orc_team_iterate(t);
+    ++done;
+    if (sel != 0) continue; /* only the leader decides (:206) */
+    if (orc_team_should_terminate(t)) { term = 1; break; }
+    if (orc_agent_should_update_weights(t->ag[0])) { orc_team_update_weights(t); ++rounds; }
+  }
+  if (terminated) *terminated = term;
+  if (weight_rounds) *weight_rounds = rounds;
+  return done;
 }
 
 /* ---------------------------------------------------------------- initialisation helpers (8f-1) */

@@ -679,24 +679,35 @@ def test_simultaneous_updates(dataset, N):
 ])
 def test_headline_iterations_to_gap(name, kw, init, coarse, expected):
     """BASELINE metric, second half: iterations until (f - f*) / f* <= 1e-6 on sphere2500 / 5 agents with bench.py's
-    configurations.  `expected` = the oracle's count measured offline with the same protocol (gap checked every
-    `coarse` iterations until < 3e-6, then every iteration; 30 s / 8 s / 2 s of CPU): 12354 for accelerated RGD (step
-    0.2, restart 20), 740 / 227 for RTR + Nesterov from the odometry / chordal guess.  The HIP path must cross at the
-    same iteration give or take round-off drift."""
+    configurations.  The RTR cases run the oracle LIVE with the same protocol (8 s / 2 s of CPU) and the HIP path must
+    cross at the oracle's iteration give or take round-off drift; `expected` (740 / 227) is asserted of the oracle as
+    well.  Accelerated RGD (step 0.2, restart 20) needs 30 s of CPU for its 12354 iterations: the oracle's count
+    measured offline with the same protocol (gap checked every `coarse` iterations until < 3e-6, then every one)."""
     FSTAR = 843.5029071410438
     m, mp, n = load("sphere2500", 5)
     th = capi.Team.from_measurements(mp.view(capi.MEAS_DTYPE), capi.default_params(r=5, num_robots=5, **kw))
     T = O.odometry_init(m, n) if init == "odom" else capi.chordal_init(m.view(capi.MEAS_DTYPE), n)
     th.set_initial(T, O.fixed_stiefel(5))
-    k, gap = 0, float("inf")
-    while k < 20000:
-        ch = coarse if gap > 3e-6 else 1
-        th.run(ch)
-        k += ch
-        gap = (th.cost() - FSTAR) / FSTAR
-        if gap <= 1e-6:
-            break
+
+    def crossing(step, cost):
+        k, gap = 0, float("inf")
+        while k < 20000:
+            ch = coarse if gap > 3e-6 else 1
+            step(ch)
+            k += ch
+            gap = (cost() - FSTAR) / FSTAR
+            if gap <= 1e-6:
+                break
+        return k, gap
+
+    k, gap = crossing(th.run, th.cost)
     th.close()
+    if kw["method"] == capi.METHOD_RTR:
+        to = O.Team(mp, n, O.default_params(r=5, num_robots=5, **kw))
+        to.set_initial(O.odometry_init(m, n) if init == "odom" else O.chordal_init(m, n), O.fixed_stiefel(5))
+        ko, _ = crossing(lambda c: [to.iterate() for _ in range(c)], to.cost)
+        assert abs(ko - expected) <= 2, (name, ko)
+        assert abs(k - ko) <= 2, (name, k, ko, gap)
     assert abs(k - expected) <= 2, (name, k, gap)
 
 

@@ -1,0 +1,161 @@
+"""a9 on the GPU: status flags, PGOAgent::shouldTerminate() and the synchronous schedule with the leader's decisions
+(src/PGOAgentROS.cpp:206-214: TERMINATE / UPDATE_WEIGHT / pass the token), HIP path vs the oracle run live."""
+import os
+
+import numpy as np
+import pytest
+
+from dpgo_ros_amd import capi
+from oracle import oracle as O
+from tests.util import DATA, add_outliers, load, make_pair, merged_graph, params_pair
+
+pytestmark = pytest.mark.gpu
+
+
+def _status_equal(th, to, N):
+    for a in range(N):
+        sh, so = th.agents[a].status(), to.agents[a].status()
+        assert sh.state == so.state
+        assert sh.iteration_number == so.iteration_number
+        assert bool(sh.ready_to_terminate) == bool(so.ready_to_terminate), (a, sh.relative_change, so.relative_change)
+        assert abs(sh.relative_change - so.relative_change) < 1e-8, a
+
+
+@pytest.mark.parametrize("method,accel,tol", [(capi.METHOD_RTR, 0, 0.05), (capi.METHOD_RTR, 1, 0.02),
+                                              (capi.METHOD_RGD, 0, 0.05), (capi.METHOD_RGD, 1, 0.05)])
+def test_status_flags_and_should_terminate_follow_the_oracle(method, accel, tol):
+    """relativeChange / readyToTerminate describe each agent's last iterate(true); the leader's shouldTerminate()
+    flips at the same iteration on both sides (checked every iteration, run in uneven chunks so that the status
+    of an agent is read 0..N-1 iterations after its block update)."""
+    N = 3
+    kw = dict(method=method, acceleration=accel, rgd_stepsize=0.2, restart_interval=7, gradnorm_tol=1e-2,
+              rel_change_tol=tol, max_num_iters=400)
+    th, to, n = make_pair("smallGrid3D", N, **kw)
+    _status_equal(th, to, N)  # before any iterate: zero-initialised status, not ready
+    assert not th.should_terminate() and not to.should_terminate()
+    flipped = None
+    k = 0
+    for chunk in [1, 1, 1, 2, 3, 1, 4, 5, 7] + [3] * 70:
+        th.run(chunk)
+        for _ in range(chunk):
+            to.iterate()
+        k += chunk
+        _status_equal(th, to, N)
+        st_h, st_o = th.should_terminate(), to.should_terminate()
+        assert st_h == st_o, k
+        if st_o and flipped is None:
+            flipped = k
+        if flipped is not None and k > flipped + 6:
+            break
+    assert flipped is not None and 20 < flipped < 220
+    th.close()
+
+
+@pytest.mark.parametrize("method,accel,tol", [(capi.METHOD_RTR, 0, 0.05), (capi.METHOD_RTR, 1, 0.02),
+                                              (capi.METHOD_RGD, 1, 0.05)])
+def test_run_schedule_terminates_where_the_oracle_does(method, accel, tol):
+    N = 3
+    kw = dict(method=method, acceleration=accel, rgd_stepsize=0.2, restart_interval=7, gradnorm_tol=1e-2,
+              rel_change_tol=tol, max_num_iters=400)
+    th, to, n = make_pair("smallGrid3D", N, **kw)
+    rh, ro = th.run_schedule(500), to.run_schedule(500)
+    assert rh == ro and ro[1] and ro[2] == 0
+    assert np.abs(th.global_X() - to.global_X()).max() < 1e-7
+    _status_equal(th, to, N)
+    th.close()
+
+
+def test_run_schedule_stops_at_max_num_iters():
+    N = 3
+    kw = dict(method=capi.METHOD_RTR, gradnorm_tol=1e-2, rel_change_tol=1e-9, max_num_iters=10)
+    th, to, n = make_pair("smallGrid3D", N, **kw)
+    rh, ro = th.run_schedule(100), to.run_schedule(100)
+    assert rh == ro == (13, True, 0)  # the leader's first block update with iteration_number() > 10 is iteration 13
+    th.close()
+
+
+@pytest.mark.parametrize("accel", [0, 1])
+def test_readme_demo_terminates_at_the_oracles_iteration(accel):
+    """the demo of README.md:32,44 end to end on the device (sphere2500 / 5 robots, wrapper weighting kappa 1e4 /
+    tau 1e2, RTR 3-50-0.5, rel-change 0.2, leader-only termination check) against the oracle run live here:
+    196 / 106 iterations (README: around 240 / 150; tests/test_oracle_kats.py::test_readme_iteration_band)."""
+    m, n = O.read_g2o(os.path.join(DATA, "sphere2500.g2o"), O.WEIGHT_WRAPPER)
+    mp = O.partition(m.copy(), n, 5, O.WEIGHT_WRAPPER)
+    kw = dict(r=5, num_robots=5, gradnorm_tol=0.5, rel_change_tol=0.2, acceleration=accel, max_num_iters=1000)
+    ph, po = params_pair(**kw)
+    th = capi.Team.from_measurements(mp.view(capi.MEAS_DTYPE), ph)
+    to = O.Team(mp, n, po)
+    T, Y = O.odometry_init(m, n), O.fixed_stiefel(5)
+    th.set_initial(T, Y)
+    to.set_initial(T, Y)
+    rh, ro = th.run_schedule(1000), to.run_schedule(1000)
+    assert ro[1] and abs(ro[0] - (106 if accel else 196)) <= 2
+    assert rh == ro
+    assert abs(th.cost() - to.cost()) <= 1e-7 * to.cost()
+    th.close()
+
+
+@pytest.mark.parametrize("ratio", [0.0, 0.97])
+def test_gnc_schedule_with_leader_decisions(ratio):
+    """The robust schedule as the wrapper runs it (launch/dpgo_gnc_demo.launch:35-42 scaled down): the leader calls an
+    UPDATE_WEIGHT round every robust_opt_inner_iters iterations, never terminates before the last round, and
+    readyToTerminate also needs robustOptMinConvergenceRatio of the loop closures at weight 0 or 1."""
+    N = 3
+    m, _, n = load("smallGrid3D", 1)
+    mo = add_outliers(m, n, frac=0.1, seed=0)
+    mp = O.partition(mo, n, N)
+    T = O.odometry_init(mo, n)
+    kw = dict(r=5, num_robots=N, method=capi.METHOD_RTR, gradnorm_tol=1e-2, robust_cost_type=capi.COST_GNC_TLS,
+              gnc_barc=3.0, gnc_mu_step=2.0, gnc_init_mu=1e-2, robust_opt_num_weight_updates=3,
+              robust_opt_inner_iters=2 * N, robust_opt_min_convergence_ratio=ratio, rel_change_tol=0.05,
+              max_num_iters=(3 + 1) * 2 * N - 2 if ratio == 0.0 else 200)  # Node.cpp:228-232 for the first case
+    ph, po = params_pair(**kw)
+    th = capi.Team.from_measurements(mp.view(capi.MEAS_DTYPE), ph)
+    to = O.Team(mp, n, po)
+    Y = O.fixed_stiefel(5)
+    th.set_initial(T, Y)
+    to.set_initial(T, Y)
+    rh, ro = th.run_schedule(300), to.run_schedule(300)
+    assert rh == ro, (rh, ro)
+    assert ro[2] == 3                     # three UPDATE_WEIGHT rounds
+    assert np.abs(th.global_X() - to.global_X()).max() < 1e-6
+    for a in range(N):
+        wh, wo = th.agents[a].measurements(), to.agents[a].measurements()
+        assert np.abs(wh["weight"] - wo["weight"]).max() < 1e-7
+    _status_equal(th, to, N)
+    th.close()
+
+
+def test_config3_merged_graph_eight_agents_gnc():
+    """BASELINE configs[3] in merged form (torus3D + cubicle + parking-garage for the absent grid3D / rim):
+    ONE pose graph of 12411 poses split over 8 agents by the reference's contiguous partition rule, so agents hold
+    different components (agents 0-2 torus, 3-6 cubicle, 7 cubicle tail + garage: kappa 2e-9 .. 200, anisotropic tau),
+    10 % seeded outlier loop closures, GNC_TLS barc 3, mu 1e-5 x 2, two UPDATE_WEIGHT rounds."""
+    N = 8
+    mo, n = merged_graph()
+    mp = O.partition(mo, n, N)
+    T = O.odometry_init(mo, n)
+    kw = dict(method=capi.METHOD_RTR, gradnorm_tol=0.5, robust_cost_type=capi.COST_GNC_TLS, gnc_barc=3.0,
+              gnc_mu_step=2.0, gnc_init_mu=1e-5, robust_opt_num_weight_updates=3, robust_opt_inner_iters=8)
+    ph, po = params_pair(r=5, num_robots=N, **kw)
+    th = capi.Team.from_measurements(mp.view(capi.MEAS_DTYPE), ph)
+    to = O.Team(mp, n, po)
+    Y = O.fixed_stiefel(5)
+    th.set_initial(T, Y)
+    to.set_initial(T, Y)
+    assert [th.agents[k].n for k in range(N)] == [n // N] * (N - 1) + [n - (N - 1) * (n // N)]
+    for rnd in range(2):
+        th.run(8)
+        for _ in range(8):
+            to.iterate()
+        # iterates: the garage component has cond ~ 1e9, the preconditioners (dense inverse vs sparse Cholesky) agree
+        # to 1e-7 there; positions are O(100)
+        Xh, Xo = th.global_X(), to.global_X()
+        assert np.abs(Xh - Xo).max() < 1e-5 * max(1.0, np.abs(Xo).max()), rnd
+        assert abs(th.cost() - to.cost()) <= 1e-7 * abs(to.cost())
+        assert th.update_weights() == to.update_weights()
+        wh = np.concatenate([th.agents[a].measurements()["weight"] for a in range(N)])
+        wo = np.concatenate([to.agents[a].measurements()["weight"] for a in range(N)])
+        assert np.abs(wh - wo).max() < 1e-6
+        assert (wo < 1).sum() > 0.05 * len(wo)  # mu = 1e-5: anything with residual^2 > 9e-5 is down-weighted
+    th.close()

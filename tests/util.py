@@ -74,3 +74,30 @@ def load_tunnels(weight_mode=0):
                 seen.add(key)
                 rows.append(e)
     return np.array(rows, dtype=O.MEAS_DTYPE)
+
+
+def merged_graph(names=("torus3D", "cubicle", "parking-garage"), outlier_frac=0.1, seed=0):
+    """BASELINE configs[3] in the merged form SURVEY 8d-4 names: the datasets are concatenated into ONE pose graph
+    (grid3D / rim are absent from the reference mount, so torus3D + cubicle + parking-garage stand in -- a declared
+    substitution), pose indices offset per component, each component tied to the previous one by a single identity-pose
+    edge between its first pose and the previous component's last pose (so that the odometry chain and the contiguous
+    partition rule see one connected graph), plus seeded outlier loop closures per component (10 % extra edges,
+    endpoints uniform, R uniform on SO(3), t uniform in the component's bounding box).  Agents of the contiguous
+    partition then hold disjoint components with kappa from 2e-9 (garage) to 200 and anisotropic tau (cubicle)."""
+    parts, off = [], 0
+    for c, name in enumerate(names):
+        m, n = O.read_g2o(os.path.join(DATA, name + ".g2o"))
+        mo = add_outliers(m, n, frac=outlier_frac, seed=seed + c) if outlier_frac > 0 else m.copy()
+        mo = mo.copy()
+        mo["p1"] += off
+        mo["p2"] += off
+        if c > 0:
+            tie = np.zeros(1, dtype=O.MEAS_DTYPE)
+            tie["p1"], tie["p2"] = off - 1, off
+            tie["R"] = np.eye(3).reshape(-1)
+            tie["kappa"], tie["tau"], tie["weight"] = 1.0, 1.0, 1.0
+            tie["fixed_weight"] = 1
+            parts.append(tie)
+        parts.append(mo)
+        off += n
+    return np.concatenate(parts), off
