@@ -424,7 +424,10 @@ int orc_agent_iterate(orc_agent_t *a, int do_opt) {
   return success;
 }
 
-void orc_agent_get_status(const orc_agent_t *a, orc_status_t *s) { *s = a->status; }
+void orc_agent_get_status(const orc_agent_t *a, orc_status_t *s) {
+  *s = a->status; /* relativeChange / readyToTerminate: as of the last refresh */
+  s->agent_id = a->id; s->state = a->state; s->instance_number = a->instance; s->iteration_number = a->iter;
+}
 void orc_agent_get_opt_result(const orc_agent_t *a, orc_opt_result_t *r) { *r = a->opt; }
 int orc_agent_iteration_number(const orc_agent_t *a) { return a->iter; }
 
