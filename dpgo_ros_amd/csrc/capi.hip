@@ -74,6 +74,22 @@ int dpgo_team_synchronize(dpgo_team_t *t) { HIPC(hipStreamSynchronize(t->stream)
 int dpgo_agent_add_measurements(dpgo_team_t *t, int id, const dpgo_measurement_t *m, int count) {
   Agent *a = find_agent(t, id);
   if (!a) return DPGO_ERR;
+  if (count < 0 || (count > 0 && !m)) { set_err("add_measurements: bad arguments"); return DPGO_ERR; }
+  // indices arrive in network messages in the ROS setting: reject anything that would index outside the pose
+  // arrays (or size the dense preconditioner absurdly) before a single record is stored
+  for (int k = 0; k < count; ++k) {
+    const dpgo_measurement_t &e = m[k];
+    if (e.r1 != id && e.r2 != id) continue;
+    if (e.p1 < 0 || e.p2 < 0 || e.p1 > DPGO_MAX_POSE_INDEX || e.p2 > DPGO_MAX_POSE_INDEX) {
+      set_err("add_measurements: pose index out of range in measurement " + std::to_string(k));
+      return DPGO_ERR;
+    }
+    if (e.r1 < 0 || e.r2 < 0 || e.r1 >= t->prm.num_robots || e.r2 >= t->prm.num_robots) {
+      set_err("add_measurements: robot id outside [0, num_robots) in measurement " + std::to_string(k));
+      return DPGO_ERR;
+    }
+    if (e.r1 == e.r2 && e.p1 == e.p2) { set_err("add_measurements: self loop in measurement " + std::to_string(k)); return DPGO_ERR; }
+  }
   for (int k = 0; k < count; ++k) {
     const dpgo_measurement_t &e = m[k];
     if (e.r1 == id && e.r2 == id) { if (e.p1 + 1 == e.p2) a->odom.push_back(e); else a->priv.push_back(e); }
@@ -490,6 +506,51 @@ int dpgo_agent_get_measurements(dpgo_team_t *t, int id, dpgo_measurement_t *out)
   for (auto *vec : {&a->odom, &a->priv, &a->shared})
     for (auto &m : *vec) { if (out) out[c] = m; ++c; }
   return c;
+}
+
+// residuals of every stored measurement (order of dpgo_agent_get_measurements: odometry, private, shared) from ONE
+// launch of the residual kernel; available[k] = 0 where a neighbour pose has not arrived yet
+int dpgo_agent_compute_residuals(dpgo_team_t *t, int id, double *residuals, int *available) {
+  Agent *a = find_agent(t, id);
+  if (!a) return DPGO_ERR;
+  if (!a->has_X) return DPGO_NOT_READY;
+  if (sync_descs(t)) return DPGO_ERR;
+  std::vector<double> res;
+  if (compute_residuals(t, *a, res)) return DPGO_ERR;
+  int e = 0;
+  for (auto *vec : {&a->odom, &a->priv, &a->shared})
+    for (auto &m : *vec) {
+      int ok = 1;
+      if (m.r1 != a->id) { const int q = find_np(*a, m.r1, m.p1); if (q < 0 || !a->np_has[0][q]) ok = 0; }
+      if (m.r2 != a->id) { const int q = find_np(*a, m.r2, m.p2); if (q < 0 || !a->np_has[0][q]) ok = 0; }
+      if (residuals) residuals[e] = ok ? res[e] : 0.0;
+      if (available) available[e] = ok;
+      ++e;
+    }
+  return e;
+}
+
+// weights / fixed flags of every stored measurement at once (same order); marks the data matrices dirty
+int dpgo_agent_set_measurement_weights(dpgo_team_t *t, int id, const double *weights, const int *fixed, int count) {
+  Agent *a = find_agent(t, id);
+  if (!a) return DPGO_ERR;
+  if (count != (int)(a->odom.size() + a->priv.size() + a->shared.size())) { set_err("set_measurement_weights: count mismatch"); return DPGO_ERR; }
+  int e = 0;
+  for (auto *vec : {&a->odom, &a->priv, &a->shared})
+    for (auto &m : *vec) { m.weight = weights[e]; if (fixed) m.fixed_weight = fixed[e]; ++e; }
+  a->data_dirty = true;
+  return DPGO_OK;
+}
+
+// restartNesterovAcceleration: V = Y = X, gamma = alpha = 0 (what PGOAgent::updateMeasurementWeights does after the
+// weights changed; the facade calls it from its own updateMeasurementWeights)
+int dpgo_agent_reset_acceleration(dpgo_team_t *t, int id) {
+  Agent *a = find_agent(t, id);
+  if (!a) return DPGO_ERR;
+  if (sync_descs(t)) return DPGO_ERR;
+  if (reset_acceleration_of(t, a)) return DPGO_ERR;
+  HIPC(hipStreamSynchronize(t->stream));
+  return DPGO_OK;
 }
 
 // Robust local initialisation (InitializationMethod::GNC_TLS, src/PGOAgentROSNode.cpp:111-112): a single-robot

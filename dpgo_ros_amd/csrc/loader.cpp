@@ -194,10 +194,14 @@ int dpgo_write_trajectory_csv(const char *path, const double *T, int num_poses) 
 }
 
 void dpgo_partition(dpgo_measurement_t *m, int nm, int num_poses, int num_robots, int weight_mode) {
+  if (num_robots <= 0 || nm <= 0 || !m) return;
   const int per = num_poses / num_robots;
   for (int k = 0; k < nm; ++k) {
     const int g1 = m[k].p1, g2 = m[k].p2;
-    const int ra = std::min(g1 / per, num_robots - 1), rb = std::min(g2 / per, num_robots - 1);
+    // more robots than poses (per == 0): the reference logs an error and its index map then gives every pose to the
+    // last robot (src/PGODatasetPublisherNode.cpp:85-103: all ranges but the last are empty); same here, no division
+    const int ra = per > 0 ? std::min(g1 / per, num_robots - 1) : num_robots - 1;
+    const int rb = per > 0 ? std::min(g2 / per, num_robots - 1) : num_robots - 1;
     m[k].r1 = ra; m[k].p1 = g1 - ra * per;
     m[k].r2 = rb; m[k].p2 = g2 - rb * per;
     if (weight_mode == DPGO_WEIGHT_WRAPPER) m[k].fixed_weight = (ra == rb && m[k].p1 + 1 == m[k].p2);

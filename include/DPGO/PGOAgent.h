@@ -301,16 +301,30 @@ class PGOAgent {
   void updateMeasurementWeights() {
     std::lock_guard<std::recursive_mutex> lock_(mMutex);
 
-    for (auto *m : mPoseGraph->activeLoopClosures()) {
-      if (m->fixedWeight) continue;
-      if (m->r1 != m->r2) { const unsigned other = (m->r1 == mID) ? m->r2 : m->r1; if (other < mID) continue; }
-      double res = 0;
-      if (computeMeasurementResidual(*m, &res)) m->weight = mRobustCost.weight(res);
+    if (mState == PGOAgentState::INITIALIZED) {
+      // one residual launch and one copy for all measurements (stored order = odometry, private, shared)
+      syncMeasurements();
+      const auto all = mPoseGraph->allMeasurements();
+      std::vector<double> res(all.size());
+      std::vector<int> ok(all.size());
+      const int cnt = dpgo_agent_compute_residuals(team_, (int)mID, res.data(), ok.data());
+      DPGO_CHECK(cnt == (int)all.size());
+      for (size_t k = mPoseGraph->numOdometry(); k < all.size(); ++k) {
+        RelativeSEMeasurement *m = all[k];
+        if (m->fixedWeight || !ok[k]) continue;
+        if (m->r1 != m->r2) { const unsigned other = (m->r1 == mID) ? m->r2 : m->r1; if (other < mID) continue; }
+        m->weight = mRobustCost.weight(res[k]);
+      }
     }
     mWeightUpdateCount++;
     mRobustCost.update();
     mRobustOptInnerIter = 0;
     mPoseGraph->clearDataMatrices();
+    if (mParams.acceleration && mState == PGOAgentState::INITIALIZED) {
+      // the Nesterov sequences restart from X under the new weights (V = Y = X, gamma = alpha = 0)
+      syncMeasurements();
+      DPGO_CHECK(dpgo_agent_reset_acceleration(team_, (int)mID) == DPGO_OK);
+    }
   }
   bool setMeasurementWeight(const PoseID &src, const PoseID &dst, double weight, bool fixed_weight = false) {
     std::lock_guard<std::recursive_mutex> lock_(mMutex);
@@ -388,6 +402,7 @@ class PGOAgent {
     c.robust_cost_type = p.robustCostParams.costType == RobustCostParameters::Type::L2 ? DPGO_COST_L2 : DPGO_COST_GNC_TLS;
     c.gnc_barc = p.robustCostParams.GNCBarc; c.gnc_mu_step = p.robustCostParams.GNCMuStep; c.gnc_init_mu = p.robustCostParams.GNCInitMu;
     c.robust_opt_num_weight_updates = (int)p.robustOptNumWeightUpdates; c.robust_opt_inner_iters = (int)p.robustOptInnerIters;
+    c.robust_opt_num_resets = (int)p.robustOptNumResets; c.robust_opt_min_convergence_ratio = p.robustOptMinConvergenceRatio;
     return c;
   }
   void destroyTeam() { if (team_) { dpgo_team_destroy(team_); team_ = nullptr; } synced_graph_ = nullptr; pushed_ = {0, 0, 0}; }
@@ -412,9 +427,11 @@ class PGOAgent {
     push(mPoseGraph->sharedLoopClosures(), pushed_.shared);
     mPoseGraph->takeDirtyStructure();
     if (mPoseGraph->takeDirtyData()) {  // weights were edited in place and clearDataMatrices() called (:1351)
-      for (auto *m : mPoseGraph->allMeasurements())
-        dpgo_agent_set_measurement_weight(team_, (int)mID, (int)m->r1, (int)m->p1, (int)m->r2, (int)m->p2, m->weight, m->fixedWeight);
-      dpgo_agent_clear_data_matrices(team_, (int)mID);
+      const auto all = mPoseGraph->allMeasurements();
+      std::vector<double> w(all.size());
+      std::vector<int> fx(all.size());
+      for (size_t k = 0; k < all.size(); ++k) { w[k] = all[k]->weight; fx[k] = all[k]->fixedWeight ? 1 : 0; }
+      DPGO_CHECK(dpgo_agent_set_measurement_weights(team_, (int)mID, w.data(), fx.data(), (int)all.size()) == DPGO_OK);
     }
   }
   Matrix fetchX(int which) {

@@ -34,6 +34,9 @@ enum { DPGO_COST_L2 = 0, DPGO_COST_GNC_TLS = 5 };         /* RobustCostParameter
 enum { DPGO_WAIT_FOR_DATA = 0, DPGO_WAIT_FOR_INITIALIZATION = 1, DPGO_INITIALIZED = 2 }; /* msg/Status.msg:1-3 */
 enum { DPGO_WEIGHT_LIBRARY = 0, DPGO_WEIGHT_WRAPPER = 1 }; /* info-matrix vs kappa=1e4,tau=1e2 */
 enum { DPGO_OK = 0, DPGO_NOT_READY = 1, DPGO_ERR = -1 };
+/* largest pose index dpgo_agent_add_measurements accepts (a dense preconditioner of (4n)^2 doubles is the limit
+ * long before this; see dpgo_agent memory guard in DESIGN.md 3) */
+#define DPGO_MAX_POSE_INDEX 1000000
 
 /* PGOAgentParameters fields written by src/PGOAgentROSNode.cpp:80-231 */
 typedef struct {
@@ -173,6 +176,14 @@ double dpgo_agent_robust_weight(dpgo_team_t *t, int id, double residual);
 int dpgo_agent_update_measurement_weights(dpgo_team_t *t, int id);
 int dpgo_agent_set_measurement_weight(dpgo_team_t *t, int id, int r1, int p1, int r2, int p2, double w, int fixed);
 int dpgo_agent_get_measurements(dpgo_team_t *t, int id, dpgo_measurement_t *out);
+/* the same three calls for every stored measurement at once (order of dpgo_agent_get_measurements: odometry,
+ * private loop closures, shared loop closures, each in insertion order): one residual launch and one copy per
+ * UPDATE_WEIGHT instead of one per loop closure (src/PGOAgentROS.cpp:1049 is called in a loop over all of them).
+ * available[k] = 0 where a neighbour pose is missing.  Returns the count. */
+int dpgo_agent_compute_residuals(dpgo_team_t *t, int id, double *residuals, int *available);
+int dpgo_agent_set_measurement_weights(dpgo_team_t *t, int id, const double *weights, const int *fixed, int count);
+/* restart of the Nesterov sequences (V = Y = X, gamma = alpha = 0) that follows a weight update */
+int dpgo_agent_reset_acceleration(dpgo_team_t *t, int id);
 int dpgo_agent_should_update_weights(dpgo_team_t *t, int id);
 int dpgo_agent_clear_data_matrices(dpgo_team_t *t, int id);
 double dpgo_error_threshold_at_quantile(double quantile, int dim);

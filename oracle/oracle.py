@@ -310,6 +310,9 @@ class Agent:
     def robust_weight(self, residual):
         return lib().orc_robust_weight(self.h, C.c_double(residual))
 
+    def should_update_weights(self):
+        return bool(lib().orc_agent_should_update_weights(self.h))
+
     def update_measurement_weights(self):
         lib().orc_agent_update_measurement_weights(self.h)
 

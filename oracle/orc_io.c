@@ -115,8 +115,9 @@ void orc_partition(orc_meas_t *m, int nm, int num_poses, int num_robots, int wei
   int per = num_poses / num_robots; /* PGODatasetPublisherNode.cpp:85 */
   for (int k = 0; k < nm; ++k) {
     int g1 = m[k].p1, g2 = m[k].p2;
-    int ra = g1 / per; if (ra >= num_robots) ra = num_robots - 1; /* last robot takes remainder :95 */
-    int rb = g2 / per; if (rb >= num_robots) rb = num_robots - 1;
+    /* per == 0 (more robots than poses): every range but the last is empty (:85-103), all poses go to the last robot */
+    int ra = per > 0 ? g1 / per : num_robots - 1; if (ra >= num_robots) ra = num_robots - 1; /* last robot takes remainder :95 */
+    int rb = per > 0 ? g2 / per : num_robots - 1; if (rb >= num_robots) rb = num_robots - 1;
     m[k].r1 = ra; m[k].p1 = g1 - ra * per;
     m[k].r2 = rb; m[k].p2 = g2 - rb * per;
     if (weight_mode == ORC_WEIGHT_WRAPPER)

@@ -54,7 +54,7 @@ int main(int argc, char **argv) {
   const int iters = std::atoi(argv[3]);
   const int mode = argc > 4 ? std::atoi(argv[4]) : 0;  // 0 plain, 1 accelerated, 2 asynchronous (ASAPP), 3 robust cost (GNC-TLS frame alignment),
                                                        // 4 local_initialization_method = GNC_TLS
-  const bool accel = mode == 1;
+  const bool accel = mode == 1 || mode == 5;  // 5: acceleration + GNC-TLS with the leader's UPDATE_WEIGHT / TERMINATE decisions
   size_t num_poses = 0;
   std::vector<RelativeSEMeasurement> dataset = read_g2o_file(argv[1], num_poses);
   PGOAgentParameters params(3, 5, N);
@@ -73,6 +73,18 @@ int main(int argc, char **argv) {
     params.robustCostParams.costType = RobustCostParameters::Type::GNC_TLS;
     params.robustOptInnerIters = 1000000;  // no weight update inside this short run
     params.robustInitMinInliers = 2;
+  }
+  if (mode == 5) {  // launch/dpgo_gnc_demo.launch:35-42 scaled down, with acceleration on
+    params.robustCostParams.costType = RobustCostParameters::Type::GNC_TLS;
+    params.robustCostParams.GNCBarc = 3.0;
+    params.robustCostParams.GNCMuStep = 2.0;
+    params.robustCostParams.GNCInitMu = 1e-2;
+    params.robustOptNumWeightUpdates = 3;
+    params.robustOptInnerIters = 2 * N;
+    params.robustOptMinConvergenceRatio = 0.0;
+    params.robustInitMinInliers = 2;
+    params.relChangeTol = 0.05;
+    params.maxNumIters = 1000;
   }
   if (mode == 4) {  // src/PGOAgentROSNode.cpp:111-112
     params.localInitializationMethod = InitializationMethod::GNC_TLS;
@@ -124,8 +136,27 @@ int main(int argc, char **argv) {
     if (!team[sel]->iterate(true)) { std::fprintf(stderr, "iterate failed\n"); return 6; }
     if (team[sel]->publishRequested()) { publish(team, sel, false); if (accel) publish(team, sel, true); }
     for (auto &a : team) for (auto &b : team) if (a != b) a->setNeighborStatus(b->getStatus());
+    const bool term = team[0]->shouldTerminate();
     std::printf("iter %d robot %u cost %.12e relchange %.6e fdec %.3e terminate %d\n", k + 1, sel, global_cost(team),
-                team[sel]->relChange(), team[sel]->optResult().fInit - team[sel]->optResult().fOpt, (int)team[0]->shouldTerminate());
+                team[sel]->relChange(), team[sel]->optResult().fInit - team[sel]->optResult().fOpt, (int)term);
+    if (mode == 5 && sel == 0) {
+      // the leader's decision after its own block update (src/PGOAgentROS.cpp:206-214)
+      if (term) { std::printf("TERMINATE at %d\n", k + 1); break; }
+      if (team[0]->shouldUpdateMeasurementWeights()) {
+        // UPDATE_WEIGHT (:1211-1233): every robot re-weights what it owns, sends shared-edge weights to the higher-ID
+        // endpoint (:721-754), which applies them and clears its data matrices (:1315-1353); public poses follow
+        for (auto &a : team) a->updateMeasurementWeights();
+        for (auto &a : team)
+          for (const auto &m : a->graph()->sharedLoopClosures()) {
+            const unsigned other = (m.r1 == a->getID()) ? m.r2 : m.r1;
+            if (other <= a->getID()) continue;
+            if (team[other]->setMeasurementWeight(PoseID(m.r1, m.p1), PoseID(m.r2, m.p2), m.weight, m.fixedWeight))
+              team[other]->graph()->clearDataMatrices();
+          }
+        for (unsigned b = 0; b < N; ++b) { publish(team, b, false); publish(team, b, true); }
+        std::printf("UPDATE_WEIGHT at %d cost %.12e\n", k + 1, global_cost(team));
+      }
+    }
   }
   PoseArray T(3, 1);
   if (!team[N - 1]->getTrajectoryInGlobalFrame(T)) return 7;

@@ -130,6 +130,48 @@ def test_mock_wrapper_robust_frame_alignment():
 
 
 @pytest.mark.gpu
+def test_mock_wrapper_accelerated_gnc_schedule():
+    """acceleration + GNC-TLS through the facade, driven the way the wrapper drives it (leader decides UPDATE_WEIGHT /
+    TERMINATE after its own block update, weights travel to the higher-ID endpoint, Nesterov sequences restart after
+    every weight update): costs, the iterations of the weight rounds and the terminate flag follow the oracle."""
+    _compile()
+    N, iters = 3, 60
+    out = subprocess.check_output([BIN, os.path.join(DATA, "smallGrid3D.g2o"), str(N), str(iters), "5"], text=True)
+    init = float(re.search(r"init cost (\S+)", out).group(1))
+    rows = re.findall(r"iter (\d+) robot \d+ cost (\S+) relchange \S+ fdec \S+ terminate (\d)", out)
+    rounds = [(int(a), float(b)) for a, b in re.findall(r"UPDATE_WEIGHT at (\d+) cost (\S+)", out)]
+    m, mp, n = load("smallGrid3D", N)
+    T = _replicated_initial_guess(m, mp, n, N, robust=True)
+    ref = O.Team(mp, n, O.default_params(r=5, num_robots=N, method=O.METHOD_RTR, gradnorm_tol=1e-2, acceleration=1,
+                                         restart_interval=7, rel_change_tol=0.05, rtr_max_radius=500.0,
+                                         robust_cost_type=O.COST_GNC_TLS, gnc_barc=3.0, gnc_mu_step=2.0, gnc_init_mu=1e-2,
+                                         robust_opt_num_weight_updates=3, robust_opt_inner_iters=2 * N,
+                                         robust_opt_min_convergence_ratio=0.0, max_num_iters=1000))
+    ref.set_initial(T, O.fixed_stiefel(5))
+    assert abs(init - ref.cost()) <= 1e-9 * ref.cost()
+    ref_rounds, k = [], 0
+    for it, cost, term in rows:
+        sel = ref.iterate()
+        k += 1
+        assert int(it) == k
+        assert abs(float(cost) - ref.cost()) <= 1e-7 * ref.cost(), k
+        assert bool(int(term)) == ref.should_terminate(), k
+        if sel == 0:
+            if ref.should_terminate():
+                break
+            if ref.agents[0].should_update_weights():
+                ref.update_weights()
+                ref_rounds.append((k, ref.cost()))
+    assert len(ref_rounds) == 3 and [r[0] for r in rounds] == [r[0] for r in ref_rounds]
+    for (_, ch), (_, co) in zip(rounds, ref_rounds):
+        assert abs(ch - co) <= 1e-7 * co
+    term = re.search(r"TERMINATE at (\d+)", out)
+    assert (term is not None) == ref.should_terminate()
+    if term:
+        assert int(term.group(1)) == k
+
+
+@pytest.mark.gpu
 def test_mock_wrapper_gnc_tls_local_initialization():
     """local_initialization_method = GNC_TLS: each robot's local trajectory comes from the GPU single-robot robust
     solve (odometry + private loop closures) instead of the odometry chain, so the team starts lower and descends"""
