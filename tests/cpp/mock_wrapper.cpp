@@ -94,6 +94,7 @@ int main(int argc, char **argv) {
   }
   std::vector<std::unique_ptr<MockAgentROS>> team;
   for (unsigned k = 0; k < N; ++k) team.emplace_back(new MockAgentROS(k, params));
+  for (auto &a : team) for (unsigned k = 0; k < N; ++k) a->setRobotActive(k, true);  // setActiveRobots() (:380-390)
   // src/PGODatasetPublisherNode.cpp:84-135 partition; every robot ends with all edges incident to it
   const unsigned per = (unsigned)num_poses / N;
   for (const auto &mIn : dataset) {
