@@ -236,7 +236,39 @@ int finalize_agent(dpgo_team *t, Agent &a, double *scratch) {
   return 0;
 }
 
+// staged neighbour poses (dpgo_agent_update_neighbor_poses) -> device slabs: one index + payload upload and one scatter
+// kernel per agent and sequence, one synchronisation for the whole team
+int flush_stage(dpgo_team *t) {
+  bool any = false;
+  for (auto &a : t->ag) {
+    const size_t B = (size_t)4 * t->prm.r;
+    const size_t n0 = a->stage_slots[0].size(), n1 = a->stage_slots[1].size();
+    if (n0 + n1 == 0) continue;
+    if (a->d_idx.alloc(n0 + n1) || a->d_xfer.alloc((n0 + n1) * B)) { set_err("device allocation failed"); return DPGO_ERR; }
+    size_t off = 0;
+    for (int aux = 0; aux < 2; ++aux) {
+      const size_t cnt = a->stage_slots[aux].size();
+      if (!cnt) continue;
+      HIPC(hipMemcpyAsync(a->d_idx.p + off, a->stage_slots[aux].data(), sizeof(int) * cnt, hipMemcpyHostToDevice, t->stream));
+      HIPC(hipMemcpyAsync(a->d_xfer.p + off * B, a->stage_data[aux].data(), sizeof(double) * cnt * B, hipMemcpyHostToDevice, t->stream));
+      launch_unpack(t->ctx(), a->dev.nbr[aux], a->d_idx.p + off, (int)cnt, a->d_xfer.p + off * B);
+      off += cnt;
+    }
+    any = true;
+  }
+  if (any) {
+    HIPC(hipStreamSynchronize(t->stream));  // the staging vectors are reused
+    for (auto &a : t->ag) for (int aux = 0; aux < 2; ++aux) { a->stage_slots[aux].clear(); a->stage_data[aux].clear(); }
+  }
+  return 0;
+}
+
 int sync_descs(dpgo_team *t) {
+  const int rc = sync_descs_noflush(t);
+  return rc ? rc : flush_stage(t);
+}
+
+int sync_descs_noflush(dpgo_team *t) {
   // agents whose data matrices changed: assemble each, then invert all their Q + shift I in one batch (the many
   // small dependent steps of the blocked inversions share their launches)
   {

@@ -151,6 +151,7 @@ int dpgo_agent_set_X(dpgo_team_t *t, int id, const double *X) {
   NestState ns{}; ns.iter = a->iter;
   HIPC(hipMemcpyAsync(a->dev.nest, &ns, sizeof ns, hipMemcpyHostToDevice, t->stream));
   HIPC(hipStreamSynchronize(t->stream));
+  ++t->epoch;
   a->has_X = true;
   a->state = DPGO_INITIALIZED;
   return 0;
@@ -173,12 +174,36 @@ int dpgo_agent_get_public_poses(dpgo_team_t *t, int id, int nbr, int aux, double
   if (!a) return DPGO_ERR;
   if (!a->has_X) return DPGO_NOT_READY;
   if (sync_descs(t)) return DPGO_ERR;
-  auto it = a->d_pubframes.find(nbr);
-  if (it == a->d_pubframes.end()) return 0;
-  const int cnt = a->n_pubframes[nbr];
-  launch_pack(t->ctx(), a->dev.buf[aux ? B_Y : B_X], it->second->p, cnt, a->d_xfer.p);
-  HIPC(hipMemcpyAsync(poses, a->d_xfer.p, sizeof(double) * (size_t)cnt * 4 * t->prm.r, hipMemcpyDeviceToHost, t->stream));
-  HIPC(hipStreamSynchronize(t->stream));
+  if (a->d_pubframes.find(nbr) == a->d_pubframes.end()) return 0;
+  if (a->pub_epoch != t->epoch) {
+    // the wrapper asks per neighbour and per sequence (:666-668), right after an iterate: pack everything this agent
+    // publishes (all neighbours, X and Y) into one buffer, ONE copy and ONE synchronisation; later calls are served
+    // from the host copy until the team enqueues device work again
+    const size_t B = (size_t)4 * t->prm.r;
+    size_t total = 0;
+    for (auto &kv : a->n_pubframes) total += 2 * (size_t)kv.second;
+    if (a->d_xfer.alloc(total * B)) { set_err("device allocation failed"); return DPGO_ERR; }
+    size_t off = 0;
+    for (auto &kv : a->d_pubframes)
+      for (int s = 0; s < 2; ++s) {
+        const int cnt = a->n_pubframes[kv.first];
+        launch_pack(t->ctx(), a->dev.buf[s ? B_Y : B_X], kv.second->p, cnt, a->d_xfer.p + off * B);
+        off += cnt;
+      }
+    std::vector<double> host(total * B);
+    HIPC(hipMemcpyAsync(host.data(), a->d_xfer.p, sizeof(double) * total * B, hipMemcpyDeviceToHost, t->stream));
+    HIPC(hipStreamSynchronize(t->stream));
+    off = 0;
+    for (auto &kv : a->d_pubframes)
+      for (int s = 0; s < 2; ++s) {
+        const size_t cnt = (size_t)a->n_pubframes[kv.first];
+        a->pub_cache[s][kv.first].assign(host.begin() + off * B, host.begin() + (off + cnt) * B);
+        off += cnt;
+      }
+    a->pub_epoch = t->epoch;
+  }
+  const std::vector<double> &c = a->pub_cache[aux ? 1 : 0][nbr];
+  std::copy(c.begin(), c.end(), poses);
   return 0;
 }
 
@@ -186,24 +211,22 @@ int dpgo_agent_update_neighbor_poses(dpgo_team_t *t, int id, int nbr, int aux, i
                                      const double *poses) {
   Agent *a = find_agent(t, id);
   if (!a) return DPGO_ERR;
-  if (sync_descs(t)) return DPGO_ERR;
+  if (count < 0 || (count > 0 && (!frames || !poses))) { set_err("update_neighbor_poses: bad arguments"); return DPGO_ERR; }
+  if (sync_descs_noflush(t)) return DPGO_ERR;
   const size_t B = (size_t)4 * t->prm.r;
-  // one staged upload + one scatter kernel instead of a copy per pose
-  std::vector<int> slots;
-  std::vector<double> packed;
+  // staged on the host: the wrapper delivers one message per neighbour and sequence (:1276-1278); everything that
+  // arrived is uploaded with one copy and one scatter kernel when the poses are next used (flush_stage)
+  const int s = aux ? 1 : 0;
   for (int k = 0; k < count; ++k) {
     const int q = find_np(*a, nbr, frames[k]);
     if (q < 0) continue;  // not an endpoint of any shared edge: dropped
-    slots.push_back(q);
-    packed.insert(packed.end(), poses + k * B, poses + (k + 1) * B);
-    a->np_has[aux ? 1 : 0][q] = 1;
+    // a pose delivered twice before it is used keeps its latest value (one scatter target per slot)
+    size_t at = a->stage_slots[s].size();
+    for (size_t u = 0; u < a->stage_slots[s].size(); ++u) if (a->stage_slots[s][u] == q) { at = u; break; }
+    if (at == a->stage_slots[s].size()) { a->stage_slots[s].push_back(q); a->stage_data[s].resize((at + 1) * B); }
+    std::copy(poses + k * B, poses + (k + 1) * B, a->stage_data[s].begin() + at * B);
+    a->np_has[s][q] = 1;
   }
-  if (slots.empty()) return DPGO_OK;
-  if (a->d_idx.alloc(slots.size()) || a->d_xfer.alloc(packed.size())) { set_err("device allocation failed"); return DPGO_ERR; }
-  HIPC(hipMemcpyAsync(a->d_idx.p, slots.data(), sizeof(int) * slots.size(), hipMemcpyHostToDevice, t->stream));
-  HIPC(hipMemcpyAsync(a->d_xfer.p, packed.data(), sizeof(double) * packed.size(), hipMemcpyHostToDevice, t->stream));
-  launch_unpack(t->ctx(), a->dev.nbr[aux ? 1 : 0], a->d_idx.p, (int)slots.size(), a->d_xfer.p);
-  HIPC(hipStreamSynchronize(t->stream));  // the host vectors above go out of scope
   return DPGO_OK;
 }
 
@@ -692,7 +715,9 @@ int dpgo_team_step_end(dpgo_team_t *t, int sel_id) {
   return 0;
 }
 
-int dpgo_team_run(dpgo_team_t *t, int iters) {
+// prepare_only: capture and instantiate every graph a run of `iters` iterations from the current state would replay
+// (both alternating instances of each), execute nothing
+static int team_run_impl(dpgo_team_t *t, int iters, bool prepare_only) {
   if (sync_descs(t)) return DPGO_ERR;
   const dpgo_params_t &p = t->prm;
   for (auto &a : t->ag) if (!a->has_X) { set_err("team_run before set_initial"); return DPGO_NOT_READY; }
@@ -778,16 +803,18 @@ int dpgo_team_run(dpgo_team_t *t, int iters) {
     t->counters[2] += 2; t->counters[3] += 2 * spmm_bytes_of(t, *t->ag[sel]);
   };
   int k = 0;
+  int cur_iter = t->iter;
+  if (prepare_only && !graphable) return 0;
   while (k < iters) {
     const bool uniform = graphable && p.acceleration && pipelined;  // restart iterations are ordinary iterations of the sequence
-    const bool restart = !uniform && p.acceleration && ((t->iter + 2) % p.restart_interval) == 0;
+    const bool restart = !uniform && p.acceleration && ((cur_iter + 2) % p.restart_interval) == 0;
     int batch = 1;
     if (graphable) {
       // one graph per window: [the restart iteration, if the window opens with one] + the fused iterations up to
       // the next restart iteration
       int fusedn = iters - k - (restart ? 1 : 0);
       if (p.acceleration && !uniform) {
-        const int it0 = t->iter + (restart ? 1 : 0);
+        const int it0 = cur_iter + (restart ? 1 : 0);
         const int to_restart = (p.restart_interval - ((it0 + 2) % p.restart_interval)) % p.restart_interval;
         fusedn = std::min(fusedn, to_restart);
       }
@@ -796,6 +823,14 @@ int dpgo_team_run(dpgo_team_t *t, int iters) {
       hipGraphExec_t ge = nullptr;
       const int grc = graph_for(restart, fusedn, &ge);
       if (grc) return grc;
+      if (prepare_only) {
+        const int grc2 = graph_for(restart, fusedn, &ge);  // the other instance; leaves the alternation where it was
+        if (grc2) return grc2;
+        cur_iter += batch;
+        k += batch;
+        continue;
+      }
+      ++t->epoch;
       HIPC(hipGraphLaunch(ge, t->stream));
       // after >= 2 pipelined iterations every agent took its last Nesterov step as a look-ahead (per-pose partials)
       for (auto &a : t->ag) a->rel_src = p.acceleration ? ((pipelined && fusedn >= 2) ? 4 : 0) : 2;
@@ -819,12 +854,16 @@ int dpgo_team_run(dpgo_team_t *t, int iters) {
       mark_optimized(t, *t->ag[sel], 5, true);
     }
     t->iter += batch;
+    cur_iter = t->iter;
     for (auto &a : t->ag) { a->iter += batch; if (p.robust_cost_type != DPGO_COST_L2) a->robust_inner_iter += batch; }
     t->counters[4] += batch;
     k += batch;
   }
   return 0;
 }
+
+int dpgo_team_run(dpgo_team_t *t, int iters) { return team_run_impl(t, iters, false); }
+int dpgo_team_prepare(dpgo_team_t *t, int iters) { return team_run_impl(t, iters, true); }
 
 int dpgo_team_get_coloring(dpgo_team_t *t, int *color_of_agent) {
   if (sync_descs(t)) return DPGO_ERR;
@@ -925,6 +964,7 @@ int dpgo_team_run_simultaneous(dpgo_team_t *t, int ticks) {
       (void)hipGraphDestroy(g);
       t->graphs[key] = ge;
     }
+    ++t->epoch;
     HIPC(hipGraphLaunch(ge, t->stream));
     left -= B;
   }

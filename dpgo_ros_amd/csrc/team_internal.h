@@ -89,6 +89,13 @@ struct Agent {
   // status of the last iterate(true) (a9; refreshed only when the agent optimizes unless status_every_iterate):
   // where its |X - XPrev|^2 partials live (-1 never optimized, 1 PART_B[2], 2 X untouched, 5 PART_E tiles), whether
   // the solve ran, the share of converged GNC weights at that moment, and the host copy once it has been read
+  // host-boundary batching (the per-agent API a ROS wrapper drives): public poses of all neighbours and both sequences
+  // are fetched with ONE copy and served from this cache until the team launches anything again; neighbour poses
+  // handed over by updateNeighborPoses are staged here and uploaded with one copy at the next use
+  unsigned long long pub_epoch = 0;
+  std::map<int, std::vector<double>> pub_cache[2];
+  std::vector<int> stage_slots[2];
+  std::vector<double> stage_data[2];
   int opt_rel_src = -1;
   bool opt_success = false, opt_cached = false;
   double opt_ratio = 1.0, opt_rel_change = 0.0;
@@ -129,7 +136,8 @@ struct dpgo_team {
   std::map<int, int> graph_flip;
   bool graph_valid = false;
   double counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  dpgo::LaunchCtx ctx() { return dpgo::LaunchCtx{prm.r, stream, d_agents.p, d_team.p}; }
+  unsigned long long epoch = 1;  // bumped by everything that enqueues device work (every launch goes through ctx())
+  dpgo::LaunchCtx ctx() { ++epoch; return dpgo::LaunchCtx{prm.r, stream, d_agents.p, d_team.p}; }
 };
 
 namespace dpgo_host {
@@ -141,7 +149,9 @@ int find_np(const Agent &a, int robot, int frame);
 std::vector<int> public_ids(const Agent &a, int nbr);
 std::vector<int> neighbor_ids(const Agent &a, int nbr);
 int finalize_agent(dpgo_team *t, Agent &a, double *scratch);
-int sync_descs(dpgo_team *t);
+int sync_descs(dpgo_team *t);          // structure / data matrices / descriptors up to date, staged neighbour poses uploaded
+int sync_descs_noflush(dpgo_team *t);  // the same without the upload (used while poses are being staged)
+int flush_stage(dpgo_team *t);
 
 // ---- solve.hip
 double converged_ratio(const Agent &a);

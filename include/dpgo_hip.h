@@ -195,6 +195,9 @@ int dpgo_team_set_initial(dpgo_team_t *t, const double *T, const double *YLift, 
 int dpgo_team_exchange_all(dpgo_team_t *t);
 /* run `iters` global RBCD iterations without host synchronisation (RGD: one hipGraph replay each) */
 int dpgo_team_run(dpgo_team_t *t, int iters);
+/* capture and instantiate, without executing anything, every hipGraph that dpgo_team_run(t, iters) would replay from
+ * the current iteration counter (a first run otherwise builds them on the fly: ~0.3 ms per distinct batch size) */
+int dpgo_team_prepare(dpgo_team_t *t, int iters);
 /* the same iteration split around the neighbour exchange, for teams that hold only part of the agents
  * (one process per GPU): begin = iterate(false) part of every local agent; [exchange]; end = local solve
  * of `sel_id` if it lives here + bookkeeping.  sel_id is a global robot id. */
