@@ -191,7 +191,7 @@ int finalize_agent(dpgo_team *t, Agent &a, double *scratch) {
       a.d_pub_pose.upload(pub_pose, s) || a.d_pub_ptr.upload(pub_ptr, s) || a.d_se.upload(se, s) ||
       a.d_edges.upload(edges, s) || a.d_vec.alloc(len * NBUF) || a.d_nbr.alloc(2 * a.np.size() * 4 * r) ||
       a.d_part.alloc(PART_TOTAL) || a.d_scal.alloc(16) || a.d_resid.alloc(edges.size()) || a.d_st.alloc(2) ||
-      a.d_nest.alloc(1) || a.d_M.alloc((size_t)N4 * N4)) {
+      a.d_M.alloc((size_t)N4 * N4)) {
     set_err("device allocation/upload failed");
     return DPGO_ERR;
   }
@@ -199,7 +199,7 @@ int finalize_agent(dpgo_team *t, Agent &a, double *scratch) {
     HIPC(hipMemsetAsync(a.d_vec.p, 0, sizeof(double) * len * NBUF, s));
     HIPC(hipMemsetAsync(a.d_nbr.p, 0, sizeof(double) * a.d_nbr.n, s));
     HIPC(hipMemsetAsync(a.d_scal.p, 0, sizeof(double) * 16, s));
-    HIPC(hipMemsetAsync(a.d_nest.p, 0, sizeof(NestState), s));
+    HIPC(hipMemsetAsync(t->d_nest_all.p + a.local, 0, sizeof(NestState), s));
     HIPC(hipMemsetAsync(a.d_st.p, 0, sizeof(RtrState) * 2, s));
     HIPC(hipMemsetAsync(a.d_part.p, 0, sizeof(double) * PART_TOTAL, s));
   }
@@ -229,7 +229,7 @@ int finalize_agent(dpgo_team *t, Agent &a, double *scratch) {
   d.pub_pose = a.d_pub_pose.p; d.pub_ptr = a.d_pub_ptr.p; d.se = a.d_se.p; d.edges = a.d_edges.p;
   d.nbr[0] = a.d_nbr.p; d.nbr[1] = a.d_nbr.p + a.np.size() * 4 * r;
   for (int b = 0; b < NBUF; ++b) d.buf[b] = a.d_vec.p + len * b;
-  d.part = a.d_part.p; d.st = a.d_st.p; d.nest = a.d_nest.p; d.scal = a.d_scal.p; d.resid = a.d_resid.p;
+  d.part = a.d_part.p; d.st = a.d_st.p; d.nest = t->d_nest_all.p + a.local; d.scal = a.d_scal.p; d.resid = a.d_resid.p;
   a.data_dirty = false;
   t->descs_dirty = true;
   t->graph_valid = false;

@@ -45,6 +45,19 @@ dpgo_team_t *dpgo_team_create(int device, const dpgo_params_t *p, int num_local,
       hipHostMalloc((void **)&t->h_scal, sizeof(double) * 16) != hipSuccess) {
     delete t; set_err("pinned allocation failed"); return nullptr;
   }
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess) t->num_cus = cus;
+    const char *e = std::getenv("DPGO_FUSED_ITER");
+    if (e) t->use_fused = (e[0] == '1') ? 1 : 0;
+    if (t->d_nest_all.alloc(std::max(1, num_local)) ||
+        hipMemset(t->d_nest_all.p, 0, sizeof(NestState) * std::max(1, num_local)) != hipSuccess ||
+        t->d_bar.alloc(ITER_BAR_WORDS) || hipMemset(t->d_bar.p, 0, sizeof(unsigned long long) * ITER_BAR_WORDS) != hipSuccess ||
+        hipHostMalloc((void **)&t->h_bar_err, sizeof(int)) != hipSuccess) {
+      delete t; set_err("hand-off state allocation failed"); return nullptr;
+    }
+    *t->h_bar_err = 0;
+  }
   for (int k = 0; k < num_local; ++k) {
     auto a = std::make_unique<Agent>();
     a->id = agent_ids[k]; a->local = k; a->mu = p->gnc_init_mu;
@@ -63,13 +76,25 @@ void dpgo_team_destroy(dpgo_team_t *t) {
   if (t->h_state) (void)hipHostFree(t->h_state);
   if (t->h_states) (void)hipHostFree(t->h_states);
   if (t->h_scal) (void)hipHostFree(t->h_scal);
+  if (t->h_bar_err) (void)hipHostFree(t->h_bar_err);
   if (t->own_stream) (void)hipStreamDestroy(t->stream);
   delete t;
 }
 
 int dpgo_team_num_local(const dpgo_team_t *t) { return (int)t->ag.size(); }
 void *dpgo_team_stream(dpgo_team_t *t) { return (void *)t->stream; }
-int dpgo_team_synchronize(dpgo_team_t *t) { HIPC(hipStreamSynchronize(t->stream)); return 0; }
+int dpgo_team_synchronize(dpgo_team_t *t) {
+  HIPC(hipStreamSynchronize(t->stream));
+  if (t->h_bar_err && *t->h_bar_err) {
+    *t->h_bar_err = 0;
+    t->use_fused = 0;  // the grid was not resident at once on this device: two launches per iteration from now on
+    for (auto &kv : t->graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);
+    t->graphs.clear(); t->graph_flip.clear();
+    set_err("fused iteration kernel: grid-wide hand-off timed out (iterates of this run are invalid)");
+    return DPGO_ERR;
+  }
+  return 0;
+}
 
 int dpgo_agent_add_measurements(dpgo_team_t *t, int id, const dpgo_measurement_t *m, int count) {
   Agent *a = find_agent(t, id);
@@ -765,9 +790,16 @@ static int team_run_impl(dpgo_team_t *t, int iters, bool prepare_only) {
       // last block update of the run lies among them, and a status query reads it, a9), the look-aheads in front of
       // them leave XPrev and |Y' - X|^2; nothing reads these values earlier in the run
       const int L = std::min(B, (int)t->sched.size());
+      std::vector<int> ns;
+      for (auto &a : t->ag) ns.push_back(a->n);
+      const bool fused_iter = t->use_fused && iter_fused_eligible(p.r, mn, ns.data(), na, t->num_cus);
       for (int rep = 0; rep < B; ++rep) {
-        launch_eval_stats(c, mn, rep == 0, 1, 0, p.num_robots, p.restart_interval);
         const int ahead = (rep + 1 < B ? 3 : 0) | ((rep + 1 < B && rep + 1 >= B - L) ? 4 : 0) | (rep >= B - L ? 8 : 0);
+        if (fused_iter) {  // evaluation + hand-off + step in ONE launch (iter_fused.hip)
+          launch_iter_rgd(c, mn, t->d_nest_all.p, t->d_bar.p, t->h_bar_err, rep == 0, p.rgd_stepsize, p.num_robots, p.restart_interval, ahead);
+          continue;
+        }
+        launch_eval_stats(c, mn, rep == 0, 1, 0, p.num_robots, p.restart_interval);
         launch_precond(c, -1, mn, PM_RGD_, B_X, B_GF, B_Z, 0, 0, p.rgd_stepsize, 1, p.num_robots, 2, p.restart_interval,
                        ahead);
       }
@@ -1103,6 +1135,14 @@ int dpgo_team_run_schedule(dpgo_team_t *t, int max_iters, int *terminated, int *
   if (terminated) *terminated = term;
   if (weight_rounds) *weight_rounds = rounds;
   return done;
+}
+
+// diagnostic: raw hand-off words of the fused iteration kernel (counters, generation words, epoch, and -- in
+// DPGO_ITER_TRACE builds -- the per-phase timestamps of two workgroups)
+int dpgo_team_read_handoff_state(dpgo_team_t *t, unsigned long long *out, int n) {
+  HIPC(hipStreamSynchronize(t->stream));
+  HIPC(hipMemcpy(out, t->d_bar.p, sizeof(unsigned long long) * std::min(n, ITER_BAR_WORDS), hipMemcpyDeviceToHost));
+  return std::min(n, ITER_BAR_WORDS);
 }
 
 int dpgo_team_get_counters(dpgo_team_t *t, double *out, int n) {

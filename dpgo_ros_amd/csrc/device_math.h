@@ -101,24 +101,41 @@ __device__ __forceinline__ void polar_eig_inplace(double *A) {
 // neighbouring Stiefel points), so the fast path is the Newton-Schulz iteration
 //   A <- A (3 I - A^T A) / 2        (quadratic: |I - A^T A| -> 3/4 |I - A^T A|^2),
 // pure FMAs with no divide / square root / rotation chain (a per-lane fp64 Jacobi costs ~3 us of
-// dependent latency on CDNA4); anything further from the manifold than |I - A^T A|_F^2 = 0.1 goes through
-// the eigen-decomposition.
-template <int R>
+// dependent latency on CDNA4).  Anything further from the manifold than |I - A^T A|_F^2 = 0.1 is first scaled by
+// 1 / sqrt(|A^T A|_inf) (>= the largest singular value), which puts every singular value into (0, 1]: from there the same iteration raises them monotonically to 1
+// (sigma <- sigma (3 - sigma^2) / 2), a few linear steps and then the quadratic tail.  EIG = true (the stand-alone
+// projection entry point, arbitrary input) takes the symmetric eigen-decomposition for that case instead; the solver
+// kernels instantiate the compact form: three inlined copies of the eigen path were 20 KB of the step kernel's 44 KB,
+// and the instruction cache holds 64 KB for two CUs.
+template <int R, bool EIG = false>
 __device__ __forceinline__ void polar_inplace(double *A) {
   double S[9];
   gram3<R>(A, S);
-  const double e0 = 1.0 - S[0], e1 = 1.0 - S[4], e2 = 1.0 - S[8];
-  const double dev = e0 * e0 + e1 * e1 + e2 * e2 + 2.0 * (S[1] * S[1] + S[2] * S[2] + S[5] * S[5]);
+  double e0 = 1.0 - S[0], e1 = 1.0 - S[4], e2 = 1.0 - S[8];
+  double dev = e0 * e0 + e1 * e1 + e2 * e2 + 2.0 * (S[1] * S[1] + S[2] * S[2] + S[5] * S[5]);
+  int max_steps = 8;
   if (!(dev < 0.1)) {
-    polar_eig_inplace<R>(A);
-    return;
+    if (EIG) {
+      polar_eig_inplace<R>(A);
+      return;
+    }
+    const double r0 = fabs(S[0]) + fabs(S[1]) + fabs(S[2]), r1 = fabs(S[3]) + fabs(S[4]) + fabs(S[5]),
+                 r2 = fabs(S[6]) + fabs(S[7]) + fabs(S[8]);
+    const double sc2 = 1.0 / fmax(r0, fmax(r1, r2)), sc = sqrt(sc2);
+#pragma unroll
+    for (int i = 0; i < 3 * R; ++i) A[i] *= sc;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) S[i] *= sc2;
+    e0 = 1.0 - S[0]; e1 = 1.0 - S[4]; e2 = 1.0 - S[8];
+    dev = e0 * e0 + e1 * e1 + e2 * e2 + 2.0 * (S[1] * S[1] + S[2] * S[2] + S[5] * S[5]);
+    max_steps = 120;
   }
   // quadratic convergence: stop once |I - A^T A|_F^2 is at round-off (1e-31 ~ (3e-16)^2); at most 8 steps
   // (|E|_F: 0.32 -> 7.5e-2 -> 4e-3 -> 1.3e-5 -> 1.3e-10 -> 1e-20).  Points that are already on the manifold
   // (V = proj(V), late iterations) take 0 or 1 step instead of a fixed seven.
   double d = dev;
 #pragma unroll 1
-  for (int it = 0; it < 8 && d > 1e-31; ++it) {
+  for (int it = 0; it < max_steps && d > 1e-31; ++it) {
     double T[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) T[i] = -0.5 * S[i];

@@ -156,12 +156,16 @@ __device__ __forceinline__ void advance_agent(const AgentDev &ag, int accel, int
 // f, Euclidean gradient, Riemannian gradient (a3).  partials: [0] f, [1] |rgrad|^2
 // gmode: 0 G from the buffer, 1 assemble G from the slab, 2 assemble G pulling from co-resident
 // agents (both also store G).
-template <int R>
+// IN_WAVE: the tile runs on ONE wave of a larger workgroup (fused iteration kernel): `sel` is the agent index itself,
+// the LDS exchange between the lanes of the tile is ordered by a wave-level fence instead of __syncthreads(), and the
+// Riemannian gradient is stored write-through (agent-scope relaxed atomics = global_store sc1) because other
+// workgroups of the SAME launch read it behind the grid barrier.
+template <int R, bool IN_WAVE = false>
 __device__ __forceinline__ void eval_body(const AgentDev *agents, const TeamDev *team, int sel, int xb, int egb, int gfb,
                                           int poff, int gmode, int aux, int bx, double *Ysh, double *Wsh) {
-  const AgentDev &ag = agents[sel_cur(team, sel)];
+  const AgentDev &ag = agents[IN_WAVE ? sel : sel_cur(team, sel)];
   constexpr int PPB = 64 / R;
-  const int lane = threadIdx.x, lp = lane / R, a = lane - lp * R;
+  const int lane = IN_WAVE ? (int)(threadIdx.x & 63) : (int)threadIdx.x, lp = lane / R, a = lane - lp * R;
   const int j = bx * PPB + lp;
   if (bx * PPB >= ag.n) return;
   const bool act = lp < PPB && j < ag.n;
@@ -198,14 +202,26 @@ __device__ __forceinline__ void eval_body(const AgentDev *agents, const TeamDev 
       if (c == 3) eg3 = eg;
     }
   }
-  __syncthreads();
+  if (IN_WAVE) {
+    // LDS operations of one wave execute in order; the fence keeps the compiler from moving the reads up
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  } else {
+    __syncthreads();
+  }
   if (act) {
     double o[3];
     tangent_row<R>(Ysh + lp * 4 * R, Wsh + lp * 4 * R, a, o);
     double *GF = ag.buf[gfb] + (size_t)j * 4 * R;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) { GF[c * R + a] = o[c]; gpart += o[c] * o[c]; }
-    GF[3 * R + a] = eg3;
+    for (int c = 0; c < 3; ++c) {
+      if (IN_WAVE) __hip_atomic_store(GF + c * R + a, o[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else GF[c * R + a] = o[c];
+      gpart += o[c] * o[c];
+    }
+    if (IN_WAVE) __hip_atomic_store(GF + 3 * R + a, eg3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else GF[3 * R + a] = eg3;
     gpart += eg3 * eg3;
   }
   fpart = wave_sum(fpart);

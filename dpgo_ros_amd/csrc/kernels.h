@@ -59,6 +59,15 @@ void launch_copy(const LaunchCtx &c, int sel, int only_agent, int num_agents, in
 void launch_bsr_to_dense(hipStream_t s, const int *rowptr, const int *col, const double *qval, int n, double shift,
                          double *A);
 
+// iter_fused.hip: one launch per pipelined accelerated-RGD iteration (evaluation, grid-wide hand-off, step).
+// bar: 18 x 128 bytes of zero-initialised device memory owned by the team; err: pinned host word raised on a spin
+// time-out.  Eligibility: every agent fits one chunk, the grid is resident at once, every evaluation tile has a
+// non-padding workgroup.
+constexpr int ITER_BAR_WORDS = 18 * 16 + 48;  // + optional phase timestamps (DPGO_ITER_TRACE builds)
+bool iter_fused_eligible(int r, int max_n, const int *agent_n, int num_agents, int num_cus);
+void launch_iter_rgd(const LaunchCtx &c, int max_n, NestState *nest_all, unsigned long long *bar, int *err, int first,
+                     double step, int num_robots, int restart_interval, int ahead);
+
 // dense_inverse.hip: M = (A)^-1 for a symmetric positive definite N x N column-major matrix.
 // A is destroyed; work must hold N*N doubles.  Returns 0, or the (1-based) failing pivot block.
 int dense_spd_inverse(hipStream_t stream, double *A, double *work, double *M, int N);

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(64) void k_raw_op(const double *X, const double *V,
   if (tid < cnt) {
     double x[4 * R], v[4 * R];
     tile_get<R>(TA, tid, x);
-    if (OP == 0) { polar_inplace<R>(x); tile_put<R>(TA, tid, x); }
+    if (OP == 0) { polar_inplace<R, true>(x); tile_put<R>(TA, tid, x); }
     if (OP == 1) { tile_get<R>(TB, tid, v); tangent_inplace<R>(x, v); tile_put<R>(TA, tid, v); }
     if (OP == 2) {
       tile_get<R>(TB, tid, v);

@@ -102,7 +102,6 @@ struct Agent {
   DevBuf<SharedEdgeDev> d_se;
   DevBuf<EdgeDev> d_edges;
   DevBuf<RtrState> d_st;
-  DevBuf<NestState> d_nest;
   AgentDev dev{};
   int nedges = 0;
 };
@@ -136,6 +135,14 @@ struct dpgo_team {
   std::map<int, int> graph_flip;
   bool graph_valid = false;
   double counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  // fused iteration kernel (iter_fused.hip): hand-off counters, time-out flag (pinned), resident capacity, switch
+  dpgo_host::DevBuf<dpgo::NestState> d_nest_all;  // NestState of local agent k at [k]: one array, so that a kernel finds any agent's
+                                                   // state from the agent index alone (no descriptor round trip)
+  dpgo_host::DevBuf<unsigned long long> d_bar;
+  int *h_bar_err = nullptr;
+  int num_cus = 0;
+  int use_fused = 0;  // DPGO_FUSED_ITER=1 selects the one-launch iteration (measured 27 us against 25 for two launches on
+                      // sphere2500 / 5 agents, profiles/r02_fused_iteration.md, hence off by default)
   unsigned long long epoch = 1;  // bumped by everything that enqueues device work (every launch goes through ctx())
   dpgo::LaunchCtx ctx() { ++epoch; return dpgo::LaunchCtx{prm.r, stream, d_agents.p, d_team.p}; }
 };
