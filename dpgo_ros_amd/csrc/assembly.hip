@@ -144,6 +144,10 @@ int finalize_agent(dpgo_team *t, Agent &a, double *scratch) {
   }
   pub_ptr.push_back((int)se.size());
   a.npub = (int)pub_pose.size();
+  std::vector<int> pose_eptr(n + 1, 0);
+  for (const auto &d : se) pose_eptr[d.lpose + 1] += 1;
+  for (int j = 0; j < n; ++j) pose_eptr[j + 1] += pose_eptr[j];
+  a.se_host = se;  // the neighbour-pose pointers are filled in by sync_descs once every agent's buffers exist
   // edge records for residual / cost evaluation
   std::vector<EdgeDev> edges;
   auto push_edge = [&](const dpgo_measurement_t &m) {
@@ -182,7 +186,8 @@ int finalize_agent(dpgo_team *t, Agent &a, double *scratch) {
   std::vector<int> pub_index(n, -1);
   for (size_t q = 0; q < pub_pose.size(); ++q) pub_index[pub_pose[q]] = (int)q;
   if (a.d_ell_col.upload(ell_col, s) || a.d_ell_val.upload(ell_val, s) || a.d_trowptr.upload(trowptr, s) ||
-      a.d_tcol.upload(tcol, s) || a.d_tval.upload(tval, s) || a.d_pub_index.upload(pub_index, s)) {
+      a.d_tcol.upload(tcol, s) || a.d_tval.upload(tval, s) || a.d_pub_index.upload(pub_index, s) ||
+      a.d_pose_eptr.upload(pose_eptr, s)) {
     set_err("device allocation/upload failed");
     return DPGO_ERR;
   }
@@ -226,6 +231,7 @@ int finalize_agent(dpgo_team *t, Agent &a, double *scratch) {
   d.rowptr = a.d_rowptr.p; d.col = a.d_col.p; d.qval = a.d_qval.p; d.M = a.d_M.p;
   d.ell_w = EW; d.ell_col = a.d_ell_col.p; d.ell_val = a.d_ell_val.p;
   d.trowptr = a.d_trowptr.p; d.tcol = a.d_tcol.p; d.tval = a.d_tval.p; d.pub_index = a.d_pub_index.p;
+  d.pose_eptr = a.d_pose_eptr.p;
   d.pub_pose = a.d_pub_pose.p; d.pub_ptr = a.d_pub_ptr.p; d.se = a.d_se.p; d.edges = a.d_edges.p;
   d.nbr[0] = a.d_nbr.p; d.nbr[1] = a.d_nbr.p + a.np.size() * 4 * r;
   for (int b = 0; b < NBUF; ++b) d.buf[b] = a.d_vec.p + len * b;
@@ -300,6 +306,21 @@ int sync_descs_noflush(dpgo_team *t) {
     }
   }
   if (!t->descs_dirty) return 0;
+  // direct pointers from every shared edge to the neighbour's pose (buffers of re-assembled agents may have moved)
+  for (auto &a : t->ag) {
+    if (a->se_host.empty() || !a->d_se.p) continue;
+    const size_t B = (size_t)4 * t->prm.r;
+    for (auto &d : a->se_host) {
+      d.src[0] = d.src[1] = nullptr;
+      if (d.src_agent_local < 0) continue;
+      const Agent &sa = *t->ag[d.src_agent_local];
+      if (!sa.dev.buf[B_X] || d.src_frame < 0 || d.src_frame >= sa.n) continue;
+      d.src[0] = sa.dev.buf[B_X] + (size_t)d.src_frame * B;
+      d.src[1] = sa.dev.buf[B_Y] + (size_t)d.src_frame * B;
+    }
+    if (a->d_se.upload(a->se_host, t->stream)) { set_err("shared-edge upload failed"); return DPGO_ERR; }
+    a->dev.se = a->d_se.p;
+  }
   std::vector<AgentDev> descs;
   t->max_n = 0; t->max_npub = 0;
   for (auto &a : t->ag) {

@@ -18,6 +18,8 @@ struct SharedEdgeDev {
   int slot;   // index into the neighbour-pose slab
   int src_agent_local;  // local index of the neighbour agent in this team, or -1 if remote
   int src_frame;
+  const double *src[2];  // the neighbour's pose in its agent's X ([0]) / Y ([1]) array when co-resident, else null:
+                         // one load instead of the agents[src].buf[...] descriptor round trip
   double coef[16];
 };
 
@@ -61,6 +63,8 @@ struct AgentDev {
   const int *tcol;
   const double *tval;
   const int *pub_index;       // [n] index into pub_pose/pub_ptr or -1
+  const int *pose_eptr;       // [n+1] CSR of `se` by local pose: the shared edges of pose j are [pose_eptr[j], pose_eptr[j+1])
+                              // (the evaluation finds them with one round trip instead of pub_index -> pub_ptr)
   const double *M;            // dense (Q + shift I)^-1, N4 x N4 column-major (symmetric)
   const int *pub_pose;        // [npub] local poses that own >= 1 shared edge
   const int *pub_ptr;         // [npub+1] CSR into se

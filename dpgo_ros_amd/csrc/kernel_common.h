@@ -113,15 +113,14 @@ __device__ __forceinline__ void spmm_row(const AgentDev &ag, int j, Src src, dou
 
 // G_j row a from the shared edges of public pose index q (a2)
 template <int R>
-__device__ __forceinline__ void g_row(const AgentDev *agents, const AgentDev &ag, int q, int a, int aux, int pull,
-                                      double g[4]) {
+__device__ __forceinline__ void g_row_range(const AgentDev &ag, int e0, int e1, int a, int aux, int pull, double g[4]) {
   g[0] = g[1] = g[2] = g[3] = 0.0;
-  for (int e = ag.pub_ptr[q]; e < ag.pub_ptr[q + 1]; ++e) {
+  for (int e = e0; e < e1; ++e) {
     const SharedEdgeDev &se = ag.se[e];
     double *slab = ag.nbr[aux] + (size_t)se.slot * 4 * R;
     double x[4];
-    if (pull && se.src_agent_local >= 0) {
-      const double *src = agents[se.src_agent_local].buf[aux ? B_Y : B_X] + (size_t)se.src_frame * 4 * R;
+    const double *src = se.src[aux];
+    if (pull && src) {
 #pragma unroll
       for (int cp = 0; cp < 4; ++cp) { x[cp] = src[cp * R + a]; slab[cp * R + a] = x[cp]; }
     } else {
@@ -133,6 +132,12 @@ __device__ __forceinline__ void g_row(const AgentDev *agents, const AgentDev &ag
 #pragma unroll
       for (int cp = 0; cp < 4; ++cp) g[c] -= x[cp] * se.coef[cp + 4 * c];
   }
+}
+
+template <int R>
+__device__ __forceinline__ void g_row(const AgentDev *agents, const AgentDev &ag, int q, int a, int aux, int pull,
+                                      double g[4]) {
+  g_row_range<R>(ag, ag.pub_ptr[q], ag.pub_ptr[q + 1], a, aux, pull, g);
 }
 
 // end of an iteration: advance gamma/alpha/iter of one agent
@@ -172,20 +177,22 @@ __device__ __forceinline__ void eval_body(const AgentDev *agents, const TeamDev 
   const double *X = ag.buf[xb];
   double fpart = 0, gpart = 0, eg3 = 0;
   if (act) {
+    // shared edges of this pose, requested in front of the SpMM so that the two chains of dependent round trips
+    // (index -> X gather, edge range -> edge -> neighbour pose) run side by side
+    const int e0 = ag.pose_eptr[j], e1 = ag.pose_eptr[j + 1];
     double acc[1][4] = {{0, 0, 0, 0}};
     spmm_row<R, 1>(ag, j, [&](int i, double(*x)[4]) {
 #pragma unroll
       for (int cp = 0; cp < 4; ++cp) x[0][cp] = X[((size_t)4 * i + cp) * R + a];
     }, acc);
     double g[4] = {0, 0, 0, 0};
-    const int q = ag.pub_index[j];
     double *Gj = ag.buf[B_G] + (size_t)j * 4 * R;
-    if (q >= 0) {
+    if (e1 > e0) {
       if (gmode == 0) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) g[c] = Gj[c * R + a];
       } else {
-        g_row<R>(agents, ag, q, a, aux, gmode == 2, g);
+        g_row_range<R>(ag, e0, e1, a, aux, gmode == 2, g);
 #pragma unroll
         for (int c = 0; c < 4; ++c) Gj[c * R + a] = g[c];
       }

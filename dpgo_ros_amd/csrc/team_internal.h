@@ -100,6 +100,8 @@ struct Agent {
   bool opt_success = false, opt_cached = false;
   double opt_ratio = 1.0, opt_rel_change = 0.0;
   DevBuf<SharedEdgeDev> d_se;
+  std::vector<SharedEdgeDev> se_host;
+  DevBuf<int> d_pose_eptr;
   DevBuf<EdgeDev> d_edges;
   DevBuf<RtrState> d_st;
   AgentDev dev{};
