@@ -1137,6 +1137,15 @@ int dpgo_team_run_schedule(dpgo_team_t *t, int max_iters, int *terminated, int *
   return done;
 }
 
+// diagnostic: `n` doubles of an agent's partial-sum scratch starting at `offset` (phase timestamps of trace builds)
+int dpgo_agent_read_partials(dpgo_team_t *t, int id, int offset, double *out, int n) {
+  Agent *a = find_agent(t, id);
+  if (!a || offset < 0 || n < 0 || offset + n > PART_TOTAL) return DPGO_ERR;
+  HIPC(hipStreamSynchronize(t->stream));
+  HIPC(hipMemcpy(out, a->dev.part + offset, sizeof(double) * n, hipMemcpyDeviceToHost));
+  return n;
+}
+
 // diagnostic: raw hand-off words of the fused iteration kernel (counters, generation words, epoch, and -- in
 // DPGO_ITER_TRACE builds -- the per-phase timestamps of two workgroups)
 int dpgo_team_read_handoff_state(dpgo_team_t *t, unsigned long long *out, int n) {

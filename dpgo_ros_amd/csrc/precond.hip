@@ -5,6 +5,14 @@
 
 namespace dpgo {
 
+// optional per-phase timestamps of hardware block 100, wave 0 / wave 1 (build with -DDPGO_PC_TRACE): written to the
+// partial-sum scratch of the agent, region PART_E, words [4000 ..]
+#ifdef DPGO_PC_TRACE
+#define PC_STAMP(k) do { if (MODE == PM_RGD_ && (threadIdx.x & 63) == 0 && blockIdx.x == 100) ag.part[PART_E + 4000 * PART_STRIDE + ((threadIdx.x >> 6) * 16) + (k)] = (double)wall_clock64(); } while (0)
+#else
+#define PC_STAMP(k) do { } while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // Dense preconditioner apply  z = P_X( v (Q + shift I)^-1 )  (a3 PreConditioner).
 // Workgroup = 256 threads = 8 scalar columns (2 poses) x 32 k-lanes.  M (the only large operand,
@@ -39,6 +47,7 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
   // being split between two.  The grid is padded to a multiple of 8; padding blocks fall out at the nblk test.
   const int bx = ((int)blockIdx.x % 8) * ((int)gridDim.x / 8) + (int)blockIdx.x / 8;
   const AgentDev &ag = agents[sel_cur(team, sel)];
+  PC_STAMP(0);
   if (MODE == PM_RGD_ && advance == 2 && bx == 0 && threadIdx.x == 0) {
     // pipelined iterations: nothing that a workgroup of THIS launch reads is written here (cur_sel, iter and the
     // NestStates move in the next k_eval_stats); the next launch finds its statistics agent and its own agent
@@ -194,6 +203,7 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
   // stride: conflict-free for R = 3, 5).  Measured (profiles/experiments/pc_bench.hip): ingest per CU, not HBM, is
   // the limit -- every workgroup has to pull the full 8*R*N4-byte vector through L2 next to its slab.
   constexpr int NSTG = (KC * R / 2 + 255) / 256;  // 16-byte pairs per lane per chunk
+  PC_STAMP(1);
   for (int k0 = 0; k0 < N4; k0 += KC) {
     const int kn = min(KC, N4 - k0);
     if (k0 > 0) __syncthreads();
@@ -211,12 +221,14 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
       }
     }
     __syncthreads();
+    PC_STAMP(2);
     double2 mreg[MREG];
 #pragma unroll
     for (int m = 0; m < MREG; ++m) {
       const int k = 2 * kl + 64 * m;
       mreg[m] = (cact && k < kn) ? ld2_nt(Mc + k0 + k) : make_double2(0.0, 0.0);
     }
+    PC_STAMP(3);
 #pragma unroll
     for (int m = 0; m < MREG; ++m) {
       const int k = 2 * kl + 64 * m;
@@ -230,6 +242,7 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
       for (int a = 0; a < R; ++a) acc[a] += w[a] * mreg[m].x + w[R + a] * mreg[m].y;
     }
   }
+  PC_STAMP(4);
   if (MODE == PM_RGD_ && (ahead & 2)) {
     // look-ahead operands of the second wave, requested once its share of the stream is consumed: they arrive while
     // the partial sums are reduced and the first wave starts its tail, and they do not occupy registers during the
@@ -281,7 +294,9 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
     Ysh[tid] = pre_x;
     if (MODE == PM_RGD_) { Esh[0][tid] = pre_v; Esh[1][tid] = pre_y; Esh[2][tid] = pre_p; }
   }
+  PC_STAMP(5);
   __syncthreads();
+  PC_STAMP(6);
 
   if (MODE == PM_RGD_ && (ahead & 2) && tid >= 64 && tid < 128) {
     // look-ahead of the other agents' poses on the second wave (operands prefetched in the prologue)
@@ -317,6 +332,7 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
         }
       }
     }
+    PC_STAMP(7);
     return;
   }
   if (MODE == PM_RGD_) {
@@ -397,6 +413,7 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
       rel = wave_sum(rel);
       if (tid == 0) ag.part[PART_B + (size_t)bx * PART_STRIDE + 2] = rel;
     }
+    PC_STAMP(7);
     return;
   }
 

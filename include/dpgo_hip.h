@@ -233,6 +233,8 @@ int dpgo_agent_pull_local(dpgo_team_t *t, int id);
 /* average HIP-event duration of one launch of a hot kernel on the team stream.
  * which: 0 dense preconditioner apply, 1 cost+gradient SpMM, 2 Hessian-vector SpMM */
 int dpgo_team_time_kernel(dpgo_team_t *t, int id, int which, int reps, double *avg_ms, double *algorithmic_bytes);
+/* diagnostic: `n` doubles of an agent's device-side partial-sum scratch (csrc/dpgo_dev.h PART_*) from `offset` */
+int dpgo_agent_read_partials(dpgo_team_t *t, int id, int offset, double *out, int n);
 /* diagnostic: the hand-off words of the fused iteration kernel (csrc/iter_fused.hip); returns the count copied */
 int dpgo_team_read_handoff_state(dpgo_team_t *t, unsigned long long *out, int n);
 /* counters for the roofline report: launches and algorithmic bytes of the dominant kernels */
