@@ -22,67 +22,78 @@ struct InvJob {
   int N, nblk;
 };
 
+// broadcast of lane `l`'s double to the whole wave through two v_readlane_b32 (l is a compile-time constant after
+// unrolling): the value arrives in scalar registers, no LDS round trip
+__device__ __forceinline__ double lane_bcast(double x, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(x), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
+  return __hiloint2double(hi, lo);
+}
+
+// 1 / sqrt(d): hardware estimate (v_rsq_f64) refined by two Newton steps -- no division, no sqrt expansion on the
+// 2 x NB long dependency chain of the diagonal block
+__device__ __forceinline__ double rsqrt_nr(double d) {
+  double y = __builtin_amdgcn_rsq(d);
+  y = y * (1.5 - 0.5 * d * y * y);
+  y = y * (1.5 - 0.5 * d * y * y);
+  return y;
+}
+
 // factor the nb x nb diagonal block at (k0,k0) in place and write its inverse (lower, dense NB x NB
-// column-major, zero padded) to Linv.  One wave: lane i < NB keeps row i of the block in registers; the column that
-// every step produces is exchanged through LDS (broadcast reads), so there is no workgroup barrier in the 2 x NB
-// dependent steps (1024 threads with three barriers per step took 26 us, this takes about 5).
-__global__ __launch_bounds__(64) void k_potrf_diag(const InvJob *jobs, int kb, int *fail) {
-  const InvJob jb_ = jobs[blockIdx.z];
-  if (kb >= jb_.nblk) return;
+// column-major, zero padded) to Linv.  ONE wave (lane = threadIdx.x & 63), lane i < NB keeps row i of the block in
+// registers.  Left-looking: column k of L needs row k of the finished part, L[k][0..k), which lane k owns -- it is
+// broadcast through scalar registers (v_readlane), so the whole factorisation is register code without LDS or
+// barriers, and 1 / sqrt comes from v_rsq_f64 + two Newton steps.  The inverse W = L^-1 is formed the same way (lane j
+// owns column j of W).  It is a chain of ~2 x NB^2 / 2 dependent multiply-adds either way: 30 us as a kernel of its own
+// (measured: LDS column exchange 32 us, v_readlane 30 us, rolled LDS loops 48 us), which is why the trailing update
+// of step k runs it for step k + 1 in the workgroup that owns the next diagonal tile, under the rest of the update.
+__device__ __forceinline__ void potrf_diag_body(const InvJob &jb_, int kb, int *fail, int z) {
   double *A = jb_.A;
   const int N = jb_.N, k0 = kb * NB, nb = min(NB, N - k0);
   double *Linv = jb_.Linv + (size_t)kb * NB * NB;
-  __shared__ double Ls[NB][NB + 1];  // the factor, row-major, for the broadcast reads of the inverse
-  __shared__ double col[NB], idiag[NB];
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
   const bool own = lane < NB;
   double row[NB];
 #pragma unroll
   for (int j = 0; j < NB; ++j)
     row[j] = (own && lane < nb && j < nb && j <= lane) ? A[(size_t)(k0 + j) * N + k0 + lane] : ((own && j == lane) ? 1.0 : 0.0);
+  double idiag[NB];  // 1 / L[k][k], wave-uniform
 #pragma unroll
   for (int k = 0; k < NB; ++k) {
-    // pivot: lane k holds L[k][k] after the updates of the previous steps
-    double d = __shfl(row[k], k, 64);
-    if (!(d > 0.0)) { if (lane == 0) fail[blockIdx.z] = k0 + k + 1; d = 1.0; }
-    const double inv = 1.0 / sqrt(d);  // one division per step; the column and the inverse below only multiply
-    double lik = 0.0;
-    if (own && lane >= k) { lik = (lane == k) ? d * inv : row[k] * inv; row[k] = lik; }
-    if (own) col[lane] = (lane >= k) ? lik : 0.0;
-    if (lane == k) idiag[k] = inv;
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    if (own && lane > k) {
+    // row[k] <- A[i][k] - sum_{m<k} L[i][m] L[k][m]   (lanes i >= k; the others hold zeros / unused values)
+    double s = row[k];
 #pragma unroll
-      for (int j = k + 1; j < NB; ++j)
-        if (j <= lane) row[j] -= lik * col[j];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    for (int m = 0; m < k; ++m) s -= row[m] * lane_bcast(row[m], k);
+    double d = lane_bcast(s, k);
+    if (!(d > 0.0)) { if (lane == 0) fail[z] = k0 + k + 1; d = 1.0; }
+    const double inv = rsqrt_nr(d);
+    idiag[k] = inv;
+    row[k] = (lane == k) ? d * inv : ((lane > k) ? s * inv : 0.0);
+  }
+  if (own && lane < nb) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+      if (j < nb && j <= lane) A[(size_t)(k0 + j) * N + k0 + lane] = row[j];
+  }
+  // inverse: lane j solves L w = e_j by forward substitution (w[i] = 0 for i < j); L[i][k] = lane i's row[k]
+  double w[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    double sres = (i == lane) ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < i; ++k) sres -= lane_bcast(row[k], i) * w[k];
+    w[i] = (i >= lane) ? sres * idiag[i] : 0.0;
   }
   if (own) {
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      Ls[lane][j] = (j <= lane) ? row[j] : 0.0;
-      if (lane < nb && j < nb && j <= lane) A[(size_t)(k0 + j) * N + k0 + lane] = row[j];
-    }
-  }
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  // inverse: lane j solves L w = e_j by forward substitution (w[i] = 0 for i < j)
-  if (own) {
-    double w[NB];
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      double sres = (i == lane) ? 1.0 : 0.0;
-#pragma unroll
-      for (int k = 0; k < NB; ++k)
-        if (k < i) sres -= Ls[i][k] * w[k];
-      w[i] = (i >= lane) ? sres * idiag[i] : 0.0;
-    }
 #pragma unroll
     for (int i = 0; i < NB; ++i) Linv[lane * NB + i] = (i < nb && lane < nb && i >= lane) ? w[i] : 0.0;
   }
+}
+
+__global__ __launch_bounds__(64) void k_potrf_diag(const InvJob *jobs, int kb, int *fail) {
+  const InvJob jb_ = jobs[blockIdx.z];
+  if (kb >= jb_.nblk) return;
+  potrf_diag_body(jb_, kb, fail, (int)blockIdx.z);
 }
 
 // panel: A[i, k0:k0+nb] <- A[i, k0:k0+nb] Linv^T  for i >= k0 + nb.  Workgroup = 64 rows x 4 column octets:
@@ -115,22 +126,47 @@ __global__ __launch_bounds__(256) void k_trsm_panel(const InvJob *jobs, int kb) 
   }
 }
 
-// 64x64 output tile, K = NB slab staged in LDS; thread (tx,ty) owns rows tx+16u, cols ty+16v
-__device__ __forceinline__ void tile_mac(const double (*As)[65], const double (*Bs)[65], int kn, int tx, int ty,
-                                         double acc[4][4]) {
-  for (int k = 0; k < kn; ++k) {
-    double a[4], b[4];
+// 64x64 output tile C[i][j] += sum_k As[k][i] Bs[k][j], K = NB slab staged in LDS (zero padded to NB), on the matrix
+// cores: v_mfma_f64_16x16x4_f64, the one fp64 MFMA shape of gfx950.  256 threads = 4 waves; wave w owns the 32 x 32
+// quadrant rows 32 (w & 1), columns 32 (w >> 1) as 2 x 2 blocks of 16 x 16.  Operand / result layout of the
+// instruction (cdna_hip_programming.md, "f64 MFMA does NOT use these maps"): A[row = lane & 15][k = lane >> 4],
+// B[k = lane >> 4][col = lane & 15], D[row = (lane >> 4) + 4 reg][col = lane & 15].  The instruction's ROW index is
+// mapped to the matrix COLUMN j and its column index to the matrix row i, so that the 16 lanes that share a result
+// register hold 16 consecutive rows i of one column: 128 contiguous bytes of the column-major matrices per store.
+typedef double v4f64_t __attribute__((ext_vector_type(4)));
+
+struct TileAcc {
+  v4f64_t c[2][2];  // [u: i-block][v: j-block]
+};
+
+__device__ __forceinline__ void tile_zero(TileAcc &t) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { a[u] = As[k][tx + 16 * u]; b[u] = Bs[k][ty + 16 * u]; }
+  for (int u = 0; u < 2; ++u)
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int v = 0; v < 2; ++v) t.c[u][v] = v4f64_t{0.0, 0.0, 0.0, 0.0};
+}
+
+__device__ __forceinline__ void tile_mac(const double (*As)[65], const double (*Bs)[65], int tid, TileAcc &t) {
+  const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const int ib = 32 * (wave & 1), jb = 32 * (wave >> 1);
 #pragma unroll
-      for (int v = 0; v < 4; ++v) acc[u][v] += a[u] * b[v];
+  for (int k = 0; k < NB; k += 4) {
+    double a[2], b[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { a[u] = Bs[k + lk][jb + 16 * u + li]; b[u] = As[k + lk][ib + 16 * u + li]; }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int v = 0; v < 2; ++v) t.c[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[v], b[u], t.c[u][v], 0, 0, 0);
   }
 }
 
+// element `reg` of block (u, v) held by this lane: tile row i, tile column j
+__device__ __forceinline__ int tile_row(int tid, int u) { return 32 * ((tid >> 6) & 1) + 16 * u + (tid & 15); }
+__device__ __forceinline__ int tile_col(int tid, int v, int reg) { return 32 * (tid >> 7) + 16 * v + ((tid & 63) >> 4) + 4 * reg; }
+
 // trailing update: A[i,j] -= sum_k P[i,k] P[j,k], i >= j >= s0 (= k0 + nb), P = columns k0..k0+nb
-__global__ __launch_bounds__(256) void k_syrk(const InvJob *jobs, int kb) {
+__global__ __launch_bounds__(256) void k_syrk(const InvJob *jobs, int kb, int *fail) {
   const InvJob jb_ = jobs[blockIdx.z];
   if (kb >= jb_.nblk) return;
   double *A = jb_.A;
@@ -139,22 +175,32 @@ __global__ __launch_bounds__(256) void k_syrk(const InvJob *jobs, int kb) {
   if (bj > bi || s0 + 64 * bi >= N) return;
   __shared__ double As[NB][65], Bs[NB][65];
   const int i0 = s0 + 64 * bi, j0 = s0 + 64 * bj;
-  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int tid = threadIdx.x;
   for (int t = tid; t < NB * 64; t += 256) {
     const int k = t >> 6, ii = t & 63;
     As[k][ii] = (k < nb && i0 + ii < N) ? A[(size_t)(k0 + k) * N + i0 + ii] : 0.0;
     Bs[k][ii] = (k < nb && j0 + ii < N) ? A[(size_t)(k0 + k) * N + j0 + ii] : 0.0;
   }
   __syncthreads();
-  double acc[4][4] = {};
-  tile_mac(As, Bs, nb, tx, ty, acc);
+  TileAcc acc;
+  tile_zero(acc);
+  tile_mac(As, Bs, tid, acc);
 #pragma unroll
-  for (int u = 0; u < 4; ++u)
+  for (int u = 0; u < 2; ++u)
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const int i = i0 + tx + 16 * u, j = j0 + ty + 16 * v;
-      if (i < N && j < N && i >= j) A[(size_t)j * N + i] -= acc[u][v];
-    }
+    for (int v = 0; v < 2; ++v)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = i0 + tile_row(tid, u), j = j0 + tile_col(tid, v, q);
+        if (i < N && j < N && i >= j) A[(size_t)j * N + i] -= acc.c[u][v][q];
+      }
+  if (bi == 0 && bj == 0 && kb + 1 < jb_.nblk) {
+    // this workgroup has just finished the tile that holds the next diagonal block (s0, s0): factor it here, under the
+    // rest of the trailing update, instead of in a launch of its own on the critical path
+    __threadfence();
+    __syncthreads();
+    if (tid < 64) potrf_diag_body(jb_, kb + 1, fail, (int)blockIdx.z);
+  }
 }
 
 // W = L^{-1}, right-looking by block rows.  Block (ib, jb), jb < ib, of the work matrix accumulates
@@ -196,7 +242,7 @@ __global__ __launch_bounds__(256) void k_trtri_upd(const InvJob *jobs, int ib) {
   if (k0 + NB + 64 * (int)blockIdx.x >= N || 64 * (int)blockIdx.y >= k0 + NB) return;
   const int i0 = k0 + NB + 64 * blockIdx.x, j0 = 64 * blockIdx.y;  // rows below block row ib, columns up to it
   const int jend = min(N, k0 + NB);
-  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int tid = threadIdx.x;
   for (int t = tid; t < NB * 64; t += 256) {
     const int k = t >> 6, ii = t & 63;
     As[k][ii] = (k < kn && i0 + ii < N) ? L[(size_t)(k0 + k) * N + i0 + ii] : 0.0;  // L[i, k0 + k]
@@ -206,15 +252,18 @@ __global__ __launch_bounds__(256) void k_trtri_upd(const InvJob *jobs, int ib) {
     Bs[k][jj] = (k < kn && j0 + jj < jend) ? W[(size_t)(j0 + jj) * N + k0 + k] : 0.0;  // W[k0 + k, j]
   }
   __syncthreads();
-  double acc[4][4] = {};
-  tile_mac(As, Bs, kn, tx, ty, acc);
+  TileAcc acc;
+  tile_zero(acc);
+  tile_mac(As, Bs, tid, acc);
 #pragma unroll
-  for (int u = 0; u < 4; ++u)
+  for (int u = 0; u < 2; ++u)
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const int i = i0 + tx + 16 * u, j = j0 + ty + 16 * v;
-      if (i < N && j < jend) W[(size_t)j * N + i] += acc[u][v];
-    }
+    for (int v = 0; v < 2; ++v)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = i0 + tile_row(tid, u), j = j0 + tile_col(tid, v, q);
+        if (i < N && j < jend) W[(size_t)j * N + i] += acc.c[u][v][q];
+      }
 }
 
 // M = W^T W for lower-triangular W (upper part of W must be zero); tiles with bi >= bj, mirrored.
@@ -227,8 +276,9 @@ __global__ __launch_bounds__(256) void k_wtw(const InvJob *jobs) {
   if (bj > bi || 64 * bi >= N) return;
   __shared__ double As[NB][65], Bs[NB][65];
   const int i0 = 64 * bi, j0 = 64 * bj;
-  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-  double acc[4][4] = {};
+  const int tid = threadIdx.x;
+  TileAcc acc;
+  tile_zero(acc);
   for (int kk = (i0 / NB) * NB; kk < N; kk += NB) {
     __syncthreads();
     for (int t = tid; t < NB * 64; t += 256) {
@@ -237,18 +287,20 @@ __global__ __launch_bounds__(256) void k_wtw(const InvJob *jobs) {
       Bs[k][ii] = (kk + k < N && j0 + ii < N) ? W[(size_t)(j0 + ii) * N + kk + k] : 0.0;
     }
     __syncthreads();
-    tile_mac(As, Bs, NB, tx, ty, acc);
+    tile_mac(As, Bs, tid, acc);
   }
 #pragma unroll
-  for (int u = 0; u < 4; ++u)
+  for (int u = 0; u < 2; ++u)
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const int i = i0 + tx + 16 * u, j = j0 + ty + 16 * v;
-      if (i < N && j < N) {
-        M[(size_t)j * N + i] = acc[u][v];
-        M[(size_t)i * N + j] = acc[u][v];
+    for (int v = 0; v < 2; ++v)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = i0 + tile_row(tid, u), j = j0 + tile_col(tid, v, q);
+        if (i < N && j < N) {
+          M[(size_t)j * N + i] = acc.c[u][v][q];
+          M[(size_t)i * N + j] = acc.c[u][v][q];
+        }
       }
-    }
 }
 
 int dense_spd_inverse_batched(hipStream_t stream, int count, double *const *A, double *const *work, double *const *M,
@@ -280,11 +332,12 @@ int dense_spd_inverse_batched(hipStream_t stream, int count, double *const *A, d
   const unsigned nz = (unsigned)count;
   for (int kb = 0; kb < max_blk; ++kb) {
     const int s0 = (kb + 1) * NB;
-    hipLaunchKernelGGL(k_potrf_diag, dim3(1, 1, nz), dim3(64), 0, stream, jobs_d, kb, fail_d);
+    // the diagonal block of step kb + 1 is factored by the trailing update of step kb (k_syrk, tile (0,0))
+    if (kb == 0) hipLaunchKernelGGL(k_potrf_diag, dim3(1, 1, nz), dim3(64), 0, stream, jobs_d, kb, fail_d);
     if (s0 < max_n) {
       hipLaunchKernelGGL(k_trsm_panel, dim3((max_n - s0 + 63) / 64, 1, nz), dim3(256), 0, stream, jobs_d, kb);
       const int nt = (max_n - s0 + 63) / 64;
-      hipLaunchKernelGGL(k_syrk, dim3(nt, nt, nz), dim3(256), 0, stream, jobs_d, kb);
+      hipLaunchKernelGGL(k_syrk, dim3(nt, nt, nz), dim3(256), 0, stream, jobs_d, kb, fail_d);
     }
   }
   for (int ib = 0; ib < max_blk; ++ib) {
