@@ -6,12 +6,50 @@
 #pragma once
 #include <cmath>
 #include <cstddef>
+#include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <functional>
+#include <iostream>
 #include <map>
 #include <optional>
+#include <set>
 #include <string>
 #include <vector>
+
+// The wrapper's translation units rely on the library's headers for glog's CHECK macros (src/utils.cpp:284 uses CHECK
+// and includes nothing else that declares it), for <fstream> (include/dpgo_ros/PGOAgentROS.h:153 std::ofstream) and for
+// unqualified `vector` (src/PGOAgentROS.cpp:288).  tests/test_wrapper_sources.py type-checks those sources against
+// these headers.
+#if __has_include(<glog/logging.h>)
+#include <glog/logging.h>
+#else
+namespace DPGO { namespace detail {
+struct CheckSink {
+  bool fatal;
+  explicit CheckSink(bool f) : fatal(f) {}
+  ~CheckSink() { if (fatal) { std::cerr << std::endl; std::abort(); } }
+  template <class T> CheckSink &operator<<(const T &v) { if (fatal) std::cerr << v; return *this; }
+  CheckSink &operator<<(std::ostream &(*f)(std::ostream &)) { if (fatal) std::cerr << f; return *this; }
+};
+} }
+#define CHECK(cond) if (cond) {} else ::DPGO::detail::CheckSink(true) << "CHECK failed: " #cond " "
+#define CHECK_EQ(a, b) CHECK((a) == (b))
+#define CHECK_NE(a, b) CHECK((a) != (b))
+#define CHECK_LT(a, b) CHECK((a) < (b))
+#define CHECK_LE(a, b) CHECK((a) <= (b))
+#define CHECK_GT(a, b) CHECK((a) > (b))
+#define CHECK_GE(a, b) CHECK((a) >= (b))
+#define LOG(severity) ::DPGO::detail::CheckSink(false)
+#define LOG_IF(severity, cond) ::DPGO::detail::CheckSink(false)
+#endif
+
+namespace DPGO {
+using std::map;
+using std::set;
+using std::string;
+using std::vector;
+}
 
 #if __has_include(<Eigen/Dense>) && !defined(DPGO_FACADE_NO_EIGEN)
 #include <Eigen/Dense>
@@ -19,6 +57,8 @@
 namespace DPGO {
 typedef Eigen::MatrixXd Matrix;
 typedef Eigen::VectorXd Vector;
+typedef Eigen::Block<Matrix> MatrixBlockRef;
+inline MatrixBlockRef mat_block_ref(Matrix &M, size_t i, size_t j, size_t p, size_t q) { return M.block(i, j, p, q); }
 }  // namespace DPGO
 #else
 #define DPGO_FACADE_HAS_EIGEN 0
@@ -28,6 +68,13 @@ class Matrix {
   Matrix() : r_(0), c_(0) {}
   Matrix(size_t r, size_t c) : r_(r), c_(c), d_(r * c, 0.0) {}
   static Matrix Zero(size_t r, size_t c) { return Matrix(r, c); }
+  static Matrix Zero(size_t n) { return Matrix(n, 1); }  // Vector::Zero(n) (src/PGOAgentROS.cpp:1465)
+  // Eigen's comma initialiser, row by row (src/utils.cpp:69-71,80:  R << a, b, c, ...;)
+  struct CommaInit {
+    Matrix *m; size_t k;
+    CommaInit &operator,(double v) { m->d_[(k % m->c_) * m->r_ + k / m->c_] = v; ++k; return *this; }
+  };
+  CommaInit operator<<(double v) { CommaInit ci{this, 0}; ci, v; return ci; }
   static Matrix Identity(size_t r, size_t c) { Matrix m(r, c); for (size_t i = 0; i < r && i < c; ++i) m(i, i) = 1.0; return m; }
   size_t rows() const { return r_; }
   size_t cols() const { return c_; }
@@ -60,6 +107,27 @@ class Matrix {
   std::vector<double> d_;
 };
 typedef Matrix Vector;
+// assignable view of a block, what Eigen's M.block(i, j, p, q) is on the ROS box: the wrapper writes
+// `X.rotation() = YLift.value()` (src/PGOAgentROS.cpp:1464) and `poses.rotation(i) = R` (:299-300)
+class MatrixBlock {
+ public:
+  MatrixBlock(Matrix &m, size_t i, size_t j, size_t p, size_t q) : m_(m), i_(i), j_(j), p_(p), q_(q) {}
+  MatrixBlock &operator=(const Matrix &b) { m_.setBlock(i_, j_, b); return *this; }
+  MatrixBlock &operator=(const MatrixBlock &b) { m_.setBlock(i_, j_, (Matrix)b); return *this; }
+  operator Matrix() const { return m_.block(i_, j_, p_, q_); }
+  size_t rows() const { return p_; }
+  size_t cols() const { return q_; }
+  double &operator()(size_t x, size_t y) { return m_(i_ + x, j_ + y); }
+  double operator()(size_t x, size_t y) const { return m_(i_ + x, j_ + y); }
+  Matrix transpose() const { return ((Matrix)*this).transpose(); }
+  double norm() const { return ((Matrix)*this).norm(); }
+  Matrix operator*(const Matrix &o) const { return (Matrix)*this * o; }
+ private:
+  Matrix &m_;
+  size_t i_, j_, p_, q_;
+};
+typedef MatrixBlock MatrixBlockRef;
+inline MatrixBlockRef mat_block_ref(Matrix &M, size_t i, size_t j, size_t p, size_t q) { return MatrixBlock(M, i, j, p, q); }
 }  // namespace DPGO
 #endif
 
@@ -118,6 +186,9 @@ class LiftedPose {
   void setData(const Matrix &X) { X_ = X; }
   Matrix rotation() const { return mat_block(X_, 0, 0, r_, d_); }
   Matrix translation() const { return mat_block(X_, 0, d_, r_, 1); }
+  // assignable views (src/PGOAgentROS.cpp:1464-1465: X.rotation() = ..., X.translation() = ...)
+  MatrixBlockRef rotation() { return mat_block_ref(X_, 0, 0, r_, d_); }
+  MatrixBlockRef translation() { return mat_block_ref(X_, 0, d_, r_, 1); }
   void setRotation(const Matrix &Y) { mat_set_block(X_, 0, 0, Y); }
   void setTranslation(const Matrix &p) { mat_set_block(X_, 0, d_, p); }
  protected:
@@ -127,6 +198,7 @@ class LiftedPose {
 // Pose(d), Pose(Matrix)  (:353,357,1398-1399)
 class Pose : public LiftedPose {
  public:
+  Pose() : LiftedPose() {}  // containers / std::optional of Pose in the wrapper need it
   explicit Pose(unsigned d) : LiftedPose(d, d) {}
   explicit Pose(const Matrix &T) : LiftedPose(T) {}
   Pose inverse() const {
@@ -156,6 +228,9 @@ class PoseArray {
   Matrix pose(unsigned i) const { return mat_block(X_, 0, i * (d_ + 1), d_, d_ + 1); }
   Matrix rotation(unsigned i) const { return mat_block(X_, 0, i * (d_ + 1), d_, d_); }
   Matrix translation(unsigned i) const { return mat_block(X_, 0, i * (d_ + 1) + d_, d_, 1); }
+  // assignable views (src/PGOAgentROS.cpp:299-300: poses.rotation(i) = R; poses.translation(i) = t)
+  MatrixBlockRef rotation(unsigned i) { return mat_block_ref(X_, 0, i * (d_ + 1), d_, d_); }
+  MatrixBlockRef translation(unsigned i) { return mat_block_ref(X_, 0, i * (d_ + 1) + d_, d_, 1); }
   void setPose(unsigned i, const Matrix &T) { mat_set_block(X_, 0, i * (d_ + 1), T); }
  private:
   unsigned d_, n_;
@@ -164,7 +239,9 @@ class PoseArray {
 typedef std::map<PoseID, LiftedPose, ComparePoseID> PoseDict;
 
 // msg/Status.msg:1-3, tests/testUtils.cpp:67-69
-enum class PGOAgentState { WAIT_FOR_DATA = 0, WAIT_FOR_INITIALIZATION = 1, INITIALIZED = 2 };
+// unscoped: the wrapper assigns it to a uint8 message field without a cast (src/utils.cpp:265) and also spells the
+// enumerators PGOAgentState::X
+enum PGOAgentState { WAIT_FOR_DATA = 0, WAIT_FOR_INITIALIZATION = 1, INITIALIZED = 2 };
 // PGOAgentStatus(agentID, state, instanceNumber, iterationNumber, readyToTerminate, relativeChange)
 struct PGOAgentStatus {
   unsigned agentID;
