@@ -41,7 +41,7 @@ class Params(C.Structure):
                 ("gnc_mu_step", C.c_double), ("gnc_init_mu", C.c_double),
                 ("robust_opt_num_weight_updates", C.c_int), ("robust_opt_inner_iters", C.c_int),
                 ("robust_opt_min_convergence_ratio", C.c_double), ("weights_as_float32", C.c_int),
-                ("robust_opt_num_resets", C.c_int), ("status_every_iterate", C.c_int)]
+                ("robust_opt_num_resets", C.c_int), ("precond_mode", C.c_int), ("status_every_iterate", C.c_int)]
 
 
 class OptResult(C.Structure):
@@ -61,6 +61,7 @@ METHOD_RTR, METHOD_RGD = 0, 1
 COST_L2, COST_GNC_TLS = 0, 5
 WEIGHT_LIBRARY, WEIGHT_WRAPPER = 0, 1
 OK, NOT_READY, ERR = 0, 1, -1
+PRECOND_AUTO, PRECOND_DENSE, PRECOND_BLOCK_JACOBI = 0, 1, 2
 
 # every symbol include/dpgo_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = """dpgo_default_params dpgo_last_error dpgo_read_g2o dpgo_read_measurements_csv dpgo_partition
@@ -79,7 +80,7 @@ dpgo_error_threshold_at_quantile dpgo_team_set_schedule dpgo_team_set_initial dp
 dpgo_agent_pull_local dpgo_team_time_kernel dpgo_team_run dpgo_team_get_coloring dpgo_team_run_colored dpgo_team_set_groups dpgo_team_run_group dpgo_team_step_begin dpgo_team_step_end dpgo_team_iteration dpgo_team_cost dpgo_team_update_weights dpgo_team_get_counters
 dpgo_write_measurements_csv dpgo_write_g2o dpgo_write_trajectory_csv dpgo_robust_frame_alignment dpgo_robust_local_init dpgo_team_run_simultaneous
 dpgo_team_should_terminate dpgo_team_run_schedule dpgo_agent_compute_residuals dpgo_agent_set_measurement_weights
-dpgo_agent_reset_acceleration dpgo_team_prepare dpgo_team_read_handoff_state dpgo_agent_read_partials""".split()
+dpgo_agent_reset_acceleration dpgo_team_prepare dpgo_team_read_handoff_state dpgo_agent_read_partials dpgo_agent_preconditioner""".split()
 
 
 class DpgoError(RuntimeError):
@@ -320,6 +321,10 @@ class Agent:
         s = OptResult()
         _chk(lib().dpgo_agent_get_opt_result(self.t, self.id, C.byref(s)), "opt_result")
         return s
+
+    def preconditioner(self):
+        """1 dense inverse, 2 block-Jacobi (the fallback when the dense inverse does not fit or was not asked for)"""
+        return _chk(lib().dpgo_agent_preconditioner(self.t, self.id), "preconditioner")
 
     def publish_requested(self, clear=False):
         return bool(lib().dpgo_agent_publish_requested(self.t, self.id, int(clear)))

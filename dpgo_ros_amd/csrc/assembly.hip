@@ -110,6 +110,30 @@ void build_Q(Agent &a) {
   }
 }
 
+// Which preconditioner an agent runs.  The dense inverse needs N4^2 doubles for M and twice that as scratch while it
+// is factored; where that does not fit the device (or block-Jacobi was asked for) the agent keeps the inverted 4 x 4
+// diagonal blocks of Q + shift I instead -- declared: NOT the reference's preconditioner (include/dpgo_hip.h).
+// `budget`: bytes of device memory still unclaimed by the agents decided before this one in the same set-up pass.
+static int choose_precond(dpgo_team *t, Agent &a, double &budget) {
+  const double N4 = 4.0 * a.n, need = 3.0 * 8.0 * N4 * N4;
+  const double held = 8.0 * (double)a.d_M.n;  // an inverse this agent already holds is reused
+  const bool fits = need - held + 512e6 <= budget;
+  int mode = t->prm.precond_mode;
+  if (mode == DPGO_PRECOND_DENSE && !fits) {
+    char msg[400];
+    std::snprintf(msg, sizeof msg, "agent %d: the dense preconditioner of %d poses needs %.1f GB of device memory (%.1f GB for "
+                  "the inverse, the rest while it is factored), %.1f GB are available; precond_mode = 0 (automatic) or 2 "
+                  "(block-Jacobi) runs this agent without it", a.id, a.n, need / 1e9, need / 3e9, budget / 1e9);
+    set_err(msg);
+    return DPGO_ERR;
+  }
+  if (mode == DPGO_PRECOND_AUTO) mode = fits ? DPGO_PRECOND_DENSE : DPGO_PRECOND_BLOCK_JACOBI;
+  if (mode != DPGO_PRECOND_DENSE && mode != DPGO_PRECOND_BLOCK_JACOBI) { set_err("bad precond_mode"); return DPGO_ERR; }
+  if (mode == DPGO_PRECOND_DENSE) budget -= need - held;
+  a.precond = mode;
+  return 0;
+}
+
 // upload structure + data matrices of one agent and assemble Q + shift I densely in `scratch` (2 N4^2 doubles: the
 // matrix and the work area of its inversion, which sync_descs runs for all re-assembled agents at once)
 int finalize_agent(dpgo_team *t, Agent &a, double *scratch) {
@@ -191,12 +215,13 @@ int finalize_agent(dpgo_team *t, Agent &a, double *scratch) {
     set_err("device allocation/upload failed");
     return DPGO_ERR;
   }
+  const bool dense = a.precond == DPGO_PRECOND_DENSE;
   const bool fresh_vec = a.d_vec.n < len * NBUF;
   if (a.d_rowptr.upload(a.rowptr, s) || a.d_col.upload(a.col, s) || a.d_qval.upload(a.qval, s) ||
       a.d_pub_pose.upload(pub_pose, s) || a.d_pub_ptr.upload(pub_ptr, s) || a.d_se.upload(se, s) ||
       a.d_edges.upload(edges, s) || a.d_vec.alloc(len * NBUF) || a.d_nbr.alloc(2 * a.np.size() * 4 * r) ||
       a.d_part.alloc(PART_TOTAL) || a.d_scal.alloc(16) || a.d_resid.alloc(edges.size()) || a.d_st.alloc(2) ||
-      a.d_M.alloc((size_t)N4 * N4)) {
+      (dense && a.d_M.alloc((size_t)N4 * N4))) {
     set_err("device allocation/upload failed");
     return DPGO_ERR;
   }
@@ -208,8 +233,27 @@ int finalize_agent(dpgo_team *t, Agent &a, double *scratch) {
     HIPC(hipMemsetAsync(a.d_st.p, 0, sizeof(RtrState) * 2, s));
     HIPC(hipMemsetAsync(a.d_part.p, 0, sizeof(double) * PART_TOTAL, s));
   }
-  // dense preconditioner  M = (Q + shift I)^-1: assembled here, inverted by sync_descs
-  launch_bsr_to_dense(s, a.d_rowptr.p, a.d_col.p, a.d_qval.p, n, t->prm.precond_shift, scratch);
+  if (dense) {
+    // dense preconditioner  M = (Q + shift I)^-1: assembled here, inverted by sync_descs
+    launch_bsr_to_dense(s, a.d_rowptr.p, a.d_col.p, a.d_qval.p, n, t->prm.precond_shift, scratch);
+  } else {
+    // block-Jacobi: invert the 4 x 4 diagonal blocks of Q + shift I on the host (Gauss-Jordan, SPD: no pivoting)
+    std::vector<double> dinv((size_t)16 * n);
+    for (int j = 0; j < n; ++j) {
+      double m[4][8];
+      for (int p = a.rowptr[j]; p < a.rowptr[j + 1]; ++p)
+        if (a.col[p] == j)
+          for (int i = 0; i < 4; ++i) for (int c = 0; c < 4; ++c) m[i][c] = a.qval[(size_t)16 * p + i + 4 * c] + (i == c ? t->prm.precond_shift : 0.0);
+      for (int i = 0; i < 4; ++i) for (int c = 0; c < 4; ++c) m[i][4 + c] = (i == c) ? 1.0 : 0.0;
+      for (int k = 0; k < 4; ++k) {
+        const double pv = 1.0 / m[k][k];
+        for (int c = 0; c < 8; ++c) m[k][c] *= pv;
+        for (int i = 0; i < 4; ++i) if (i != k) { const double f = m[i][k]; for (int c = 0; c < 8; ++c) m[i][c] -= f * m[k][c]; }
+      }
+      for (int i = 0; i < 4; ++i) for (int c = 0; c < 4; ++c) dinv[(size_t)16 * j + i + 4 * c] = m[i][4 + c];
+    }
+    if (a.d_dinv.upload(dinv, s)) { set_err("device allocation/upload failed"); return DPGO_ERR; }
+  }
 
   // per-neighbour index tables for the packed-slab exchange (a7)
   size_t max_xfer = 1;
@@ -228,7 +272,7 @@ int finalize_agent(dpgo_team *t, Agent &a, double *scratch) {
   AgentDev &d = a.dev;
   d.id = a.id; d.n = n; d.nb = (int)a.col.size(); d.N4 = N4;
   d.npub = a.npub; d.nshared = (int)se.size(); d.nnp = (int)a.np.size(); d.nedges = a.nedges;
-  d.rowptr = a.d_rowptr.p; d.col = a.d_col.p; d.qval = a.d_qval.p; d.M = a.d_M.p;
+  d.rowptr = a.d_rowptr.p; d.col = a.d_col.p; d.qval = a.d_qval.p; d.M = dense ? a.d_M.p : nullptr; d.Dinv = dense ? nullptr : a.d_dinv.p;
   d.ell_w = EW; d.ell_col = a.d_ell_col.p; d.ell_val = a.d_ell_val.p;
   d.trowptr = a.d_trowptr.p; d.tcol = a.d_tcol.p; d.tval = a.d_tval.p; d.pub_index = a.d_pub_index.p;
   d.pose_eptr = a.d_pose_eptr.p;
@@ -279,17 +323,29 @@ int sync_descs_noflush(dpgo_team *t) {
   // small dependent steps of the blocked inversions share their launches)
   {
     size_t total = 0;
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    double budget = (double)free_b + 8.0 * (double)t->d_tmp.n;  // the scratch of an earlier pass is reused
+    bool any_dirty = false;
     for (auto &a : t->ag) {
       rebuild_index(*a);
-      if (a->data_dirty) total += 2 * (size_t)(4 * a->n) * (4 * a->n);
+      if (!a->data_dirty) continue;
+      any_dirty = true;
+      if (choose_precond(t, *a, budget)) return DPGO_ERR;
+      if (a->precond == DPGO_PRECOND_DENSE) total += 2 * (size_t)(4 * a->n) * (4 * a->n);
     }
-    if (total) {
-      if (t->d_tmp.alloc(total)) { set_err("scratch allocation failed"); return DPGO_ERR; }
+    if (any_dirty) {
+      if (total && t->d_tmp.alloc(total)) { set_err("scratch allocation failed"); return DPGO_ERR; }
       std::vector<double *> As, Ws, Ms;
       std::vector<int> Ns;
       size_t off = 0;
       for (auto &a : t->ag) {
         if (!a->data_dirty) continue;
+        if (a->precond != DPGO_PRECOND_DENSE) {  // block-Jacobi: nothing to invert on the device
+          const int rc = finalize_agent(t, *a, nullptr);
+          if (rc) return rc;
+          continue;
+        }
         const size_t NN = (size_t)(4 * a->n) * (4 * a->n);
         double *A = t->d_tmp.p + off, *W = A + NN;
         off += 2 * NN;

@@ -24,6 +24,7 @@ void dpgo_default_params(dpgo_params_t *p, int r, int num_robots) {
   p->robust_opt_min_convergence_ratio = 0.8;
   p->weights_as_float32 = 0;
   p->robust_opt_num_resets = 0;   // launch/PGOAgent.launch:33
+  p->precond_mode = DPGO_PRECOND_AUTO;
   p->status_every_iterate = 0;
 }
 
@@ -353,6 +354,13 @@ int dpgo_agent_iteration_number(dpgo_team_t *t, int id) {
   return a ? a->iter : DPGO_ERR;
 }
 
+int dpgo_agent_preconditioner(dpgo_team_t *t, int id) {
+  Agent *a = find_agent(t, id);
+  if (!a) return DPGO_ERR;
+  if (sync_descs(t)) return DPGO_ERR;
+  return a->precond;
+}
+
 int dpgo_agent_set_iteration_number(dpgo_team_t *t, int id, int iteration) {
   Agent *a = find_agent(t, id);
   if (!a) return DPGO_ERR;
@@ -392,12 +400,12 @@ int dpgo_agent_eval(dpgo_team_t *t, int id, const double *X, double *f, double *
   const size_t bytes = sizeof(double) * (size_t)t->prm.r * 4 * a->n;
   HIPC(hipMemcpyAsync(a->dev.buf[B_T0], X, bytes, hipMemcpyHostToDevice, t->stream));
   launch_eval(t->ctx(), a->local, a->n, B_T0, B_T1, B_T2, PART_A, eval_opts(t, 0, 0, 0));
-  std::vector<double> part((size_t)PART_STRIDE * MAX_PART);
+  const int ppb = 64 / t->prm.r, nb = (a->n + ppb - 1) / ppb;
+  std::vector<double> part((size_t)PART_STRIDE * nb);
   HIPC(hipMemcpyAsync(part.data(), a->dev.part + PART_A, sizeof(double) * part.size(), hipMemcpyDeviceToHost, t->stream));
   if (egrad) HIPC(hipMemcpyAsync(egrad, a->dev.buf[B_T1], bytes, hipMemcpyDeviceToHost, t->stream));
   if (rgrad) HIPC(hipMemcpyAsync(rgrad, a->dev.buf[B_T2], bytes, hipMemcpyDeviceToHost, t->stream));
   HIPC(hipStreamSynchronize(t->stream));
-  const int ppb = 64 / t->prm.r, nb = (a->n + ppb - 1) / ppb;
   double s = 0;
   for (int i = 0; i < nb; ++i) s += part[(size_t)i * PART_STRIDE];
   if (f) *f = s;
@@ -792,7 +800,9 @@ static int team_run_impl(dpgo_team_t *t, int iters, bool prepare_only) {
       const int L = std::min(B, (int)t->sched.size());
       std::vector<int> ns;
       for (auto &a : t->ag) ns.push_back(a->n);
-      const bool fused_iter = t->use_fused && iter_fused_eligible(p.r, mn, ns.data(), na, t->num_cus);
+      bool all_dense = true;
+      for (auto &a : t->ag) all_dense = all_dense && a->precond == DPGO_PRECOND_DENSE;
+      const bool fused_iter = t->use_fused && all_dense && iter_fused_eligible(p.r, mn, ns.data(), na, t->num_cus);
       for (int rep = 0; rep < B; ++rep) {
         const int ahead = (rep + 1 < B ? 3 : 0) | ((rep + 1 < B && rep + 1 >= B - L) ? 4 : 0) | (rep >= B - L ? 8 : 0);
         if (fused_iter) {  // evaluation + hand-off + step in ONE launch (iter_fused.hip)

@@ -65,7 +65,8 @@ struct AgentDev {
   const int *pub_index;       // [n] index into pub_pose/pub_ptr or -1
   const int *pose_eptr;       // [n+1] CSR of `se` by local pose: the shared edges of pose j are [pose_eptr[j], pose_eptr[j+1])
                               // (the evaluation finds them with one round trip instead of pub_index -> pub_ptr)
-  const double *M;            // dense (Q + shift I)^-1, N4 x N4 column-major (symmetric)
+  const double *M;            // dense (Q + shift I)^-1, N4 x N4 column-major (symmetric); null: block-Jacobi agent
+  const double *Dinv;         // block-Jacobi agents: the inverted 4 x 4 diagonal blocks of Q + shift I, [n][16] column-major
   const int *pub_pose;        // [npub] local poses that own >= 1 shared edge
   const int *pub_ptr;         // [npub+1] CSR into se
   const SharedEdgeDev *se;    // [nshared] sorted by lpose
@@ -80,7 +81,8 @@ struct AgentDev {
 };
 
 constexpr int PART_STRIDE = 8;   // doubles per block of partials
-constexpr int MAX_PART = 4096;   // max blocks contributing partials
+constexpr int MAX_PART = 32768;  // max blocks contributing partials: agents of up to 65536 poses (8 columns per block of
+                                 // the preconditioner kernels); 2 MB per region
 // regions of AgentDev::part (each MAX_PART * PART_STRIDE doubles)
 constexpr int PART_A = 0;                             // SpMM-type kernels (eval / Hess-vec)
 constexpr int PART_B = MAX_PART * PART_STRIDE;        // preconditioner-type kernels ([2] |X - XPrev|^2 of the fused RGD step)

@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256) void k_iter_rgd(const AgentDev *agents, TeamDe
 // needs an active workgroup (hardware block h evaluates tile h and must not be a padding block), the agent must fit one
 // chunk, and the whole grid must be resident at once (one workgroup per CU).
 bool iter_fused_eligible(int r, int max_n, const int *agent_n, int num_agents, int num_cus) {
-  if (4 * max_n > 2048) return false;
+  if (4 * max_n > 2048) return false;  // (agents of this size always hold the dense inverse unless block-Jacobi was forced)
   const int grid = ((4 * max_n + 7) / 8 + 7) / 8 * 8, G8 = grid / 8;
   if (grid > num_cus) return false;
   const int ppb = 64 / r;

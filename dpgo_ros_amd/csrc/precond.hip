@@ -204,7 +204,22 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
   // the limit -- every workgroup has to pull the full 8*R*N4-byte vector through L2 next to its slab.
   constexpr int NSTG = (KC * R / 2 + 255) / 256;  // 16-byte pairs per lane per chunk
   PC_STAMP(1);
-  for (int k0 = 0; k0 < N4; k0 += KC) {
+  if (!ag.M) {
+    // block-Jacobi agent (the declared fallback where the dense inverse does not fit, include/dpgo_hip.h): column
+    // c of pose p is  v_p (Q_pp + shift I)^-1[:, c], a 4 x 4 block per pose -- the first k-lane of each column forms it
+    // straight from global memory, the others contribute zeros to the reduction below
+    if (kl == 0 && cact) {
+      const int p = col >> 2, c = col & 3;
+      const double *B = ag.Dinv + (size_t)16 * p + 4 * c;
+#pragma unroll
+      for (int cp = 0; cp < 4; ++cp) {
+        const double b = B[cp];
+#pragma unroll
+        for (int a = 0; a < R; ++a) acc[a] += Vstage[((size_t)4 * p + cp) * R + a] * b;
+      }
+    }
+  }
+  for (int k0 = 0; ag.M && k0 < N4; k0 += KC) {
     const int kn = min(KC, N4 - k0);
     if (k0 > 0) __syncthreads();
     {

@@ -79,6 +79,8 @@ struct Agent {
   int npub = 0;
   // device storage
   DevBuf<int> d_rowptr, d_col, d_pub_pose, d_pub_ptr, d_idx, d_ell_col, d_trowptr, d_tcol, d_pub_index;
+  int precond = DPGO_PRECOND_DENSE;  // what this agent runs (decided when its data matrices are built)
+  DevBuf<double> d_dinv;
   DevBuf<double> d_qval, d_M, d_vec, d_nbr, d_part, d_scal, d_resid, d_ell_val, d_tval;
   std::map<int, std::unique_ptr<DevBuf<int>>> d_pubframes, d_nbrslots;  // per neighbour, cached on the device
   std::map<int, int> n_pubframes, n_nbrslots;

@@ -34,6 +34,11 @@ enum { DPGO_COST_L2 = 0, DPGO_COST_GNC_TLS = 5 };         /* RobustCostParameter
 enum { DPGO_WAIT_FOR_DATA = 0, DPGO_WAIT_FOR_INITIALIZATION = 1, DPGO_INITIALIZED = 2 }; /* msg/Status.msg:1-3 */
 enum { DPGO_WEIGHT_LIBRARY = 0, DPGO_WEIGHT_WRAPPER = 1 }; /* info-matrix vs kappa=1e4,tau=1e2 */
 enum { DPGO_OK = 0, DPGO_NOT_READY = 1, DPGO_ERR = -1 };
+/* preconditioner of the local solves.  The reference's is a sparse Cholesky solve with Q + shift I; DENSE is
+ * the same operator as a dense inverse (12 N^2 doubles of HBM during set-up, N = 4 poses: 2000 poses -> 6 GB, 5750 ->
+ * 51 GB).  BLOCK_JACOBI (the inverses of the 4 x 4 diagonal blocks) is NOT the reference's preconditioner: an O(n)-memory
+ * fallback for agents whose dense inverse does not fit, restated in the oracle (precond_mode 2) for its own parity tests. */
+enum { DPGO_PRECOND_AUTO = 0, DPGO_PRECOND_DENSE = 1, DPGO_PRECOND_BLOCK_JACOBI = 2 };
 /* largest pose index dpgo_agent_add_measurements accepts (a dense preconditioner of (4n)^2 doubles is the limit
  * long before this; see dpgo_agent memory guard in DESIGN.md 3) */
 #define DPGO_MAX_POSE_INDEX 1000000
@@ -61,6 +66,8 @@ typedef struct {
   int weights_as_float32;
   int robust_opt_num_resets;  /* src/PGOAgentROSNode.cpp:213: written by the wrapper, never read by it; its semantics live
                                * in the absent library -> carried, validated (>= 0), no effect */
+  int precond_mode;           /* DPGO_PRECOND_*: 0 automatic (dense inverse where it fits the device, block-Jacobi
+                               * otherwise), 1 dense inverse (error if it does not fit), 2 block-Jacobi */
   int status_every_iterate;   /* 0 (default): relativeChange / readyToTerminate describe the last iterate(true) of the
                                * agent [UPSTREAM-RECALL]; 1: refreshed by every iterate (round-1 behaviour) */
 } dpgo_params_t;
@@ -154,6 +161,9 @@ int dpgo_agent_iterate(dpgo_team_t *t, int id, int do_optimization);    /* :160 
 int dpgo_agent_get_status(dpgo_team_t *t, int id, dpgo_status_t *s);     /* getStatus() :616 */
 int dpgo_agent_get_opt_result(dpgo_team_t *t, int id, dpgo_opt_result_t *r); /* :169-172 */
 int dpgo_agent_iteration_number(dpgo_team_t *t, int id);                 /* iteration_number() :139 */
+/* preconditioner the agent actually runs (DPGO_PRECOND_DENSE or DPGO_PRECOND_BLOCK_JACOBI), after its data matrices
+ * were built; <0 on error */
+int dpgo_agent_preconditioner(dpgo_team_t *t, int id);
 int dpgo_agent_publish_requested(dpgo_team_t *t, int id, int clear);     /* mPublishPublicPosesRequested :109-112 */
 int dpgo_agent_set_iteration_number(dpgo_team_t *t, int id, int iteration); /* mIterationNumber = ... (RECOVER, :1196) */
 

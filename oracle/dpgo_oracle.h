@@ -63,6 +63,10 @@ typedef struct {
   int weights_as_float32;     /* msg/RelativeMeasurementWeights.msg:8 wire rounding */
   int robust_opt_num_resets;  /* PGOAgentROSNode.cpp:213: set by the wrapper, never read by it; semantics live in the
                                * absent library and are not recoverable here -> carried, no effect */
+  int precond_mode;           /* 0 / 1: sparse Cholesky of Q + shift I (the reference's preconditioner);
+                               * 2: block-Jacobi -- the inverses of the 4x4 diagonal blocks of Q + shift I.  NOT the
+                               * reference's preconditioner: the product's declared O(n)-memory fallback for agents whose
+                               * dense inverse does not fit, restated here so that the fallback has a checker too */
   int status_every_iterate;   /* 0 (default): relativeChange / readyToTerminate are refreshed by iterate(true) only
                                * [UPSTREAM-RECALL, and the only rule under which the leader's check at
                                * PGOAgentROS.cpp:206-214 is meaningful without acceleration: iterate(false) leaves

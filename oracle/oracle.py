@@ -39,7 +39,7 @@ class Params(C.Structure):
                 ("gnc_mu_step", C.c_double), ("gnc_init_mu", C.c_double),
                 ("robust_opt_num_weight_updates", C.c_int), ("robust_opt_inner_iters", C.c_int),
                 ("robust_opt_min_convergence_ratio", C.c_double), ("weights_as_float32", C.c_int),
-                ("robust_opt_num_resets", C.c_int), ("status_every_iterate", C.c_int)]
+                ("robust_opt_num_resets", C.c_int), ("precond_mode", C.c_int), ("status_every_iterate", C.c_int)]
 
 
 class OptResult(C.Structure):

@@ -40,6 +40,7 @@ void orc_default_params(orc_params_t *p, int r, int num_robots) {
   p->robust_opt_min_convergence_ratio = 0.8;
   p->weights_as_float32 = 0;
   p->robust_opt_num_resets = 0;  /* launch/PGOAgent.launch:33 */
+  p->precond_mode = 0;
   p->status_every_iterate = 0;
 }
 
@@ -303,10 +304,14 @@ static int ensure_problem(orc_agent_t *a, int aux) {
     a->prob.r = a->prm.r; a->prob.n = a->n;
     build_Q(a);
     a->prob.G = (double *)calloc((size_t)a->prm.r * 4 * a->n, sizeof(double));
-    if (orc_chol_factor(&a->prob.Q, a->prm.precond_shift, &a->prob.chol) != 0) {
-      fprintf(stderr, "[oracle] Cholesky of Q + shift I failed (agent %d)\n", a->id);
+    if (a->prm.precond_mode == 2) {
+      orc_block_jacobi(&a->prob.Q, a->prm.precond_shift, &a->prob.dinv);
+    } else {
+      if (orc_chol_factor(&a->prob.Q, a->prm.precond_shift, &a->prob.chol) != 0) {
+        fprintf(stderr, "[oracle] Cholesky of Q + shift I failed (agent %d)\n", a->id);
+      }
+      a->prob.has_chol = 1;
     }
-    a->prob.has_chol = 1;
     a->prob_valid = 1;
   }
   return build_G(a, aux);

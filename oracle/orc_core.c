@@ -492,9 +492,48 @@ void orc_problem_hessvec(const orc_problem_t *P, const double *X, const double *
   orc_tangent_project(X, out, r, n, out);
 }
 
-/* PreConditioner: solve with Q + shift I, then project to the tangent space */
+/* inverse of an SPD 4x4 block by Gauss-Jordan (no pivoting needed) */
+static void inv4_spd(const double *B, double *out) {
+  double a[4][8];
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { a[i][j] = B[i + 4 * j]; a[i][4 + j] = (i == j) ? 1.0 : 0.0; }
+  for (int k = 0; k < 4; ++k) {
+    double p = 1.0 / a[k][k];
+    for (int j = 0; j < 8; ++j) a[k][j] *= p;
+    for (int i = 0; i < 4; ++i) if (i != k) { double f = a[i][k]; for (int j = 0; j < 8; ++j) a[i][j] -= f * a[k][j]; }
+  }
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) out[i + 4 * j] = a[i][4 + j];
+}
+
+void orc_block_jacobi(const orc_bsr_t *Q, double shift, double **dinv) {
+  double *D = (double *)calloc((size_t)16 * Q->n, sizeof(double));
+  for (int j = 0; j < Q->n; ++j) {
+    double B[16] = {0};
+    for (int p = Q->rowptr[j]; p < Q->rowptr[j + 1]; ++p)
+      if (Q->col[p] == j) memcpy(B, Q->val + (size_t)16 * p, sizeof B);
+    for (int c = 0; c < 4; ++c) B[5 * c] += shift;
+    inv4_spd(B, D + (size_t)16 * j);
+  }
+  *dinv = D;
+}
+
+/* PreConditioner: solve with Q + shift I (or, precond_mode 2, with its 4x4 block diagonal), then project to the tangent space */
 void orc_problem_precond(const orc_problem_t *P, const double *X, const double *V, double *out) {
-  orc_chol_solve(&P->chol, V, P->r, out);
+  if (P->dinv) {
+    int r = P->r;
+    for (int j = 0; j < P->n; ++j) {
+      const double *B = P->dinv + (size_t)16 * j;
+      double tmp[4 * 16];
+      for (int c = 0; c < 4; ++c)
+        for (int a = 0; a < r; ++a) {
+          double s = 0;
+          for (int cp = 0; cp < 4; ++cp) s += V[((size_t)4 * j + cp) * r + a] * B[cp + 4 * c];
+          tmp[c * r + a] = s;
+        }
+      memcpy(out + (size_t)4 * j * r, tmp, sizeof(double) * 4 * r);
+    }
+  } else {
+    orc_chol_solve(&P->chol, V, P->r, out);
+  }
   orc_tangent_project(X, out, P->r, P->n, out);
 }
 
@@ -502,6 +541,7 @@ void orc_problem_free(orc_problem_t *P) {
   orc_bsr_free(&P->Q);
   free(P->G);
   if (P->has_chol) orc_chol_free(&P->chol);
+  free(P->dinv);
   memset(P, 0, sizeof *P);
 }
 

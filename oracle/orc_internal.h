@@ -29,6 +29,7 @@ typedef struct {
   double *G;       /* r x 4n */
   orc_chol_t chol; /* of Q + shift I */
   int has_chol;
+  double *dinv;    /* precond_mode 2: n inverted 4x4 diagonal blocks of Q + shift I (column-major), else NULL */
 } orc_problem_t;
 
 void orc_bsr_free(orc_bsr_t *Q);
@@ -43,6 +44,8 @@ void orc_bsr_mult(const orc_bsr_t *Q, const double *X, int r, double *out); /* o
 int orc_chol_factor(const orc_bsr_t *Q, double shift, orc_chol_t *C);
 void orc_chol_solve(const orc_chol_t *C, const double *B, int r, double *out); /* out = B (Q+sI)^-1 */
 void orc_chol_free(orc_chol_t *C);
+/* inverses of the 4x4 diagonal blocks of Q + shift I (n x 16 doubles, column-major blocks) */
+void orc_block_jacobi(const orc_bsr_t *Q, double shift, double **dinv);
 
 void orc_edge_blocks(const orc_meas_t *m, double TO[16], double TOT[16], double Om[16]);
 

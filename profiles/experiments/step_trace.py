@@ -9,7 +9,7 @@ prm = capi.default_params(r=5, num_robots=5, **bench.RGD)
 team = capi.Team.from_measurements(mp, prm, device=0)
 team.set_initial(T, Y)
 names = ["start", "prologue done", "vector staged", "M requested", "M consumed", "reduced", "sync", "end"]
-PART_E = 4 * 4096 * 8
+PART_E = 4 * 32768 * 8
 for rep in range(4):
     team.run(36)   # the last step kernel of the run belongs to agent (35 % 5) = 0
     buf = np.zeros(64)

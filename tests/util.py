@@ -101,3 +101,36 @@ def merged_graph(names=("torus3D", "cubicle", "parking-garage"), outlier_frac=0.
         parts.append(mo)
         off += n
     return np.concatenate(parts), off
+
+
+def synthetic_chain(n, seed=0, lc_every=40, noise=0.01):
+    """a long single-robot pose graph: random-walk ground truth, odometry i -> i+1 and a loop closure i -> i+lc_every/2
+    every lc_every poses, measurements perturbed by small rotations / translations (seeded); kappa 100, tau 50"""
+    rng = np.random.default_rng(seed)
+
+    def rot(w):
+        th = np.linalg.norm(w, axis=-1, keepdims=True)
+        k = w / np.maximum(th, 1e-12)
+        K = np.zeros(w.shape[:-1] + (3, 3))
+        K[..., 0, 1], K[..., 0, 2], K[..., 1, 0] = -k[..., 2], k[..., 1], k[..., 2]
+        K[..., 1, 2], K[..., 2, 0], K[..., 2, 1] = -k[..., 0], -k[..., 1], k[..., 0]
+        s, c = np.sin(th)[..., None], (1 - np.cos(th))[..., None]
+        return np.eye(3) + s * K + c * (K @ K)
+
+    dR = rot(0.2 * rng.standard_normal((n - 1, 3)))
+    dt = np.c_[np.ones(n - 1), 0.1 * rng.standard_normal((n - 1, 2))]
+    Rg, tg = np.zeros((n, 3, 3)), np.zeros((n, 3))
+    Rg[0] = np.eye(3)
+    for i in range(n - 1):
+        Rg[i + 1] = Rg[i] @ dR[i]
+        tg[i + 1] = tg[i] + Rg[i] @ dt[i]
+    src = np.r_[np.arange(n - 1), np.arange(0, n - lc_every, lc_every)]
+    dst = np.r_[np.arange(1, n), np.arange(0, n - lc_every, lc_every) + lc_every // 2]
+    m = np.zeros(len(src), dtype=O.MEAS_DTYPE)
+    Rm = np.einsum("eji,ejk->eik", Rg[src], Rg[dst]) @ rot(noise * rng.standard_normal((len(src), 3)))
+    tm = np.einsum("eji,ej->ei", Rg[src], tg[dst] - tg[src]) + noise * rng.standard_normal((len(src), 3))
+    m["p1"], m["p2"] = src, dst
+    m["R"] = Rm.reshape(len(src), 9)
+    m["t"] = tm
+    m["kappa"], m["tau"], m["weight"] = 100.0, 50.0, 1.0
+    return m, n
