@@ -511,9 +511,42 @@ def multi_gpu(args):
     cp_cost = drv2.global_cost(torch, "cuda")
     dist.barrier()
     be2.close()
+
+    # ---- extra: BASELINE configs[4] across ranks -- MIT tunnels, 8 robots (robot a on rank a % N), lockstep ASAPP
+    # ticks: every robot takes one preconditioned RGD step (stepsize 0.2) per tick from the neighbour poses of the
+    # tick's start; all boundary slabs cross the ranks in one batch of RCCL point-to-point operations per tick
+    mt, nk, Tt = load_tunnels(capi, 1)
+    mine8 = [a for a in range(8) if owner_of(a, world) == rank]
+    prm3 = capi.default_params(r=r, num_robots=8, method=1, rgd_stepsize=0.2, acceleration=0)
+    be3 = HipBackend(mt, prm3, mine8, local_rank, torch)
+    off8 = np.concatenate([[0], np.cumsum(nk)[:-1]]).astype(np.int32)
+    if be3.team is not None:
+        with be3.stream_context():
+            be3.team.set_initial(Tt, Y, offsets=np.array([off8[a] for a in mine8], dtype=np.int32))
+    drv3 = DistributedRBCD(dist, be3, mt, 8, 0, rank, world)
+    drv3.exchange_all()
+    c0 = drv3.global_cost(torch, "cuda")
+    for _ in range(20):
+        drv3.tick_simultaneous()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t3 = time.perf_counter()
+    for _ in range(200):
+        drv3.tick_simultaneous()
+    dist.barrier()
+    torch.cuda.synchronize()
+    with be3.stream_context():
+        t4 = torch.tensor([time.perf_counter() - t3], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t4, op=dist.ReduceOp.MAX)
+        tick_ms = t4.item() / 200 * 1e3
+    c1 = drv3.global_cost(torch, "cuda")
+    dist.barrier()
+    be3.close()
     dist.destroy_process_group()
     return rank, ms, cost, roof, {"ms_per_block_update": cp_ms, "classes": len(drv2.groups),
-                            "relcost_after_45_sweeps": (cp_cost - F_STAR[WORKLOAD["dataset"]]) / F_STAR[WORKLOAD["dataset"]]}
+                            "relcost_after_45_sweeps": (cp_cost - F_STAR[WORKLOAD["dataset"]]) / F_STAR[WORKLOAD["dataset"]]}, \
+        {"workload": "data/tunnels, 8 robots on %d rank(s), RGD stepsize 0.2 + preconditioner, lockstep ticks" % world,
+         "ms_per_tick": tick_ms, "cost_initial": c0, "cost_after_220_ticks": c1}
 
 
 def main():
@@ -538,11 +571,12 @@ def main():
                                  "spmm_launches": counters[2], "spmm_bytes": counters[3], "iterations": counters[4]}})
         print(json.dumps(out))
     else:
-        rank, ms, cost, roof, cp = multi_gpu(args)
+        rank, ms, cost, roof, cp, asapp = multi_gpu(args)
         if rank == 0:
             fstar = F_STAR[WORKLOAD["dataset"]]
             out.update({"value": ms, "ms_per_step": ms, "roofline": roof, "cpu_baseline": None,
                         "relcost_after_run": (cost - fstar) / fstar, "colour_parallel_plain_rtr": cp,
+                        "asapp_ticks_tunnels": asapp,
                         "exchange": "RCCL isend/irecv of packed public-pose slabs (X and Y), pull-before-use"})
             print(json.dumps(out))
 

@@ -125,6 +125,48 @@ class HipBackend:
         if self.team is not None:
             self.team.step_begin(sel)
 
+    def tick_local(self):
+        """one simultaneous RGD step of every local agent from the neighbour poses as of now (ASAPP lockstep tick)"""
+        if self.team is not None:
+            self.team.run_simultaneous(1)
+
+    # ---- robust path across ranks (src/PGOAgentROS.cpp:721-754 publishMeasurementWeights, :1315-1353 callback)
+    def local_update_weights(self):
+        """every local agent re-weights what it owns; co-resident endpoints are served in the same call"""
+        return self.team.update_weights() if self.team is not None else 0
+
+    def owned_weights(self, agent, nbr):
+        """(weights, fixed flags) of the shared edges agent <-> nbr in the agent's stored order, as a float64 array
+        [w0, f0, w1, f1, ...] (fp32-rounded on request: msg/RelativeMeasurementWeights.msg:8)"""
+        ms = self.team.agents[agent].measurements()
+        sel = ms[(ms["r1"] != ms["r2"]) & ((ms["r1"] == nbr) | (ms["r2"] == nbr))]
+        w = sel["weight"].astype(np.float64)
+        if self.team.params.weights_as_float32:
+            w = w.astype(np.float32).astype(np.float64)
+        out = np.empty(2 * len(sel))
+        out[0::2], out[1::2] = w, sel["fixed_weight"]
+        return out, sel
+
+    def apply_weights(self, agent, nbr, payload):
+        ms = self.team.agents[agent].measurements()
+        sel = ms[(ms["r1"] != ms["r2"]) & ((ms["r1"] == nbr) | (ms["r2"] == nbr))]
+        changed = 0
+        for e, w, f in zip(sel, payload[0::2], payload[1::2]):
+            self.team.agents[agent].set_measurement_weight(int(e["r1"]), int(e["p1"]), int(e["r2"]), int(e["p2"]), float(w), bool(f))
+            changed += 1
+        self.team.agents[agent].clear_data_matrices()
+        return changed
+
+    def to_transport(self, arr):
+        t = self.torch.from_numpy(np.ascontiguousarray(arr))
+        return t if self.host_staging else t.cuda()
+
+    def from_transport(self, t):
+        return t.cpu().numpy()
+
+    def transport_empty(self, n):
+        return self.torch.empty(n, dtype=self.torch.float64, device="cpu" if self.host_staging else "cuda")
+
     def step_end(self, sel):
         if self.team is not None:
             self.team.step_end(sel)
@@ -147,6 +189,13 @@ class DistributedRBCD:
         self.mine = [a for a in range(num_robots) if self.owner[a] == rank]
         self.schedule = list(range(num_robots)) if schedule is None else list(schedule)
         self.k = 0
+        # shared-edge counts per ordered pair, for the weight messages of the robust path
+        self.nshared = {}
+        for e in meas:
+            a, b = int(e["r1"]), int(e["r2"])
+            if a != b:
+                self.nshared[(a, b)] = self.nshared.get((a, b), 0) + 1
+                self.nshared[(b, a)] = self.nshared.get((b, a), 0) + 1
 
     def _ctx(self):
         import contextlib
@@ -202,6 +251,71 @@ class DistributedRBCD:
                     self.be.iterate(sel, True)
         self.k += 1
         return sel
+
+    def tick_simultaneous(self):
+        """BASELINE configs[4] across ranks: the deterministic lockstep instance of the asynchronous (ASAPP) mode
+        (src/PGOAgentROS.cpp:119-127).  Every agent takes ONE preconditioned RGD step from the neighbour poses of the
+        tick's start: all boundary slabs cross the ranks in one batch of point-to-point operations, then every rank
+        steps all its agents in the same launches.  Equals dpgo_team_run_simultaneous on one GPU."""
+        d = self.dist
+        with self._ctx():
+            ops, todo = [], []
+            for a in range(self.N):  # fixed global order: both ends of a pair enumerate it identically
+                for b in self.nbrs[a]:
+                    ra, rb = self.owner[a], self.owner[b]
+                    if ra == rb:
+                        continue
+                    cnt = self.npub[(b, a)]  # poses of b that a needs
+                    if self.rank == rb:
+                        ops.append(d.P2POp(d.isend, self.be.pack(b, a, (0,), cnt), ra))
+                    if self.rank == ra:
+                        t = self.be.recv_buffer(a, b, (0,), cnt)
+                        ops.append(d.P2POp(d.irecv, t, rb))
+                        todo.append((a, b, t))
+            if ops:
+                for w in d.batch_isend_irecv(ops):
+                    w.wait()
+            for a, b, t in todo:
+                self.be.unpack(a, b, (0,), t)
+            self.be.tick_local()
+        self.k += self.N
+
+    def update_weights(self):
+        """UPDATE_WEIGHT round across ranks (src/PGOAgentROS.cpp:1211-1233): every agent re-weights the edges it owns
+        (lower-ID endpoint), the weights of shared edges travel to the higher-ID endpoint's rank
+        (publishMeasurementWeights :721-754 -> measurementWeightsCallback :1315-1353), which applies them and clears its
+        data matrices; public poses are exchanged afterwards (:1224-1226).  Returns the number of weights applied here."""
+        d = self.dist
+        changed = 0
+        with self._ctx():
+            self.exchange_all_nolock()
+            changed += self.be.local_update_weights()
+            ops, todo, keep = [], [], []
+            for a in range(self.N):
+                for b in self.nbrs[a]:
+                    if b < a or self.owner[a] == self.owner[b]:
+                        continue  # a owns the weights of its edges with the higher-ID b; co-resident pairs are done
+                    cnt = self.nshared[(a, b)]
+                    if self.rank == self.owner[a]:
+                        payload, _ = self.be.owned_weights(a, b)
+                        t = self.be.to_transport(payload)
+                        keep.append(t)
+                        ops.append(d.P2POp(d.isend, t, self.owner[b]))
+                    if self.rank == self.owner[b]:
+                        t = self.be.transport_empty(2 * cnt)
+                        ops.append(d.P2POp(d.irecv, t, self.owner[a]))
+                        todo.append((b, a, t))
+            if ops:
+                for w in d.batch_isend_irecv(ops):
+                    w.wait()
+            for b, a, t in todo:
+                changed += self.be.apply_weights(b, a, self.be.from_transport(t))
+            self.exchange_all_nolock()
+        return changed
+
+    def exchange_all_nolock(self):
+        for a in range(self.N):
+            self._exchange_to(a, (0, 1))
 
     def sweep_colored(self):
         """one colour-parallel sweep of plain (non-accelerated) RBCD: for each colour class, every member

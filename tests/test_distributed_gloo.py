@@ -64,6 +64,55 @@ class OracleBackend:
             for a, ag in self.agents.items():
                 ag.iterate(a == m)
 
+    def tick_local(self):
+        # agents step one by one from their stored (frozen) copies of the neighbour poses = simultaneous
+        for a in sorted(self.agents):
+            self.pull_local(a)
+        for a in sorted(self.agents):
+            self.agents[a].iterate(True)
+
+    def local_update_weights(self):
+        changed = 0
+        for a in sorted(self.agents):
+            self.agents[a].update_measurement_weights()
+        for a in sorted(self.agents):
+            for e in self.agents[a].measurements():
+                if e["r1"] == e["r2"]:
+                    continue
+                other = int(e["r2"] if e["r1"] == a else e["r1"])
+                if other > a and other in self.agents:
+                    self.agents[other].set_measurement_weight(int(e["r1"]), int(e["p1"]), int(e["r2"]), int(e["p2"]),
+                                                              float(e["weight"]), bool(e["fixed_weight"]))
+                    self.agents[other].clear_data_matrices()
+                    changed += 1
+        return changed
+
+    def _pair_edges(self, agent, nbr):
+        ms = self.agents[agent].measurements()
+        return ms[(ms["r1"] != ms["r2"]) & ((ms["r1"] == nbr) | (ms["r2"] == nbr))]
+
+    def owned_weights(self, agent, nbr):
+        sel = self._pair_edges(agent, nbr)
+        out = np.empty(2 * len(sel))
+        out[0::2], out[1::2] = sel["weight"], sel["fixed_weight"]
+        return out, sel
+
+    def apply_weights(self, agent, nbr, payload):
+        sel = self._pair_edges(agent, nbr)
+        for e, w, f in zip(sel, payload[0::2], payload[1::2]):
+            assert self.agents[agent].set_measurement_weight(int(e["r1"]), int(e["p1"]), int(e["r2"]), int(e["p2"]), float(w), bool(f))
+        self.agents[agent].clear_data_matrices()
+        return len(sel)
+
+    def to_transport(self, arr):
+        return self.torch.from_numpy(np.ascontiguousarray(arr))
+
+    def from_transport(self, t):
+        return t.numpy()
+
+    def transport_empty(self, n):
+        return self.torch.empty(n, dtype=self.torch.float64)
+
     def partial_cost(self):
         f = 0.0
         for a, ag in self.agents.items():
@@ -159,3 +208,90 @@ def test_topology_matches_agent_bookkeeping():
         for b in nbrs[a]:
             assert npub[(a, b)] == len(t.agents[a].public_pose_ids(b)) == len(t.agents[b].neighbor_pose_ids(a))
     assert nbrs == {0: [1], 1: [0, 2], 2: [1, 3], 3: [2, 4], 4: [3]}  # chain
+
+
+def _worker_modes(rank, world, port, mode, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from dpgo_ros_amd.distributed import DistributedRBCD, owner_of
+    from oracle import oracle as O
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    N, mp, n, T, kw = _mode_problem(mode)
+    params = O.default_params(r=5, num_robots=N, **kw)
+    per = n // N
+    offsets = {a: a * per for a in range(N)}
+    mine = [a for a in range(N) if owner_of(a, world) == rank]
+    be = OracleBackend(mp, params, mine, T, O.fixed_stiefel(5), offsets)
+    drv = DistributedRBCD(dist, be, mp, N, kw.get("acceleration", 0), rank, world)
+    drv.exchange_all()
+    changed = []
+    if mode == "ticks":
+        for _ in range(6):
+            drv.tick_simultaneous()
+    else:
+        for rnd in range(2):
+            for _ in range(2 * N):
+                drv.step()
+            changed.append(drv.update_weights())
+        for _ in range(N):
+            drv.step()
+    cost = drv.global_cost(torch, "cpu")
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), cost=cost, changed=np.array(changed),
+             **{"X%d" % a: be.agents[a].get_X() for a in mine},
+             **{"W%d" % a: be.agents[a].measurements()["weight"] for a in mine})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _mode_problem(mode):
+    from oracle import oracle as O
+    from tests.util import add_outliers
+    N = 3
+    m, _, n = load("smallGrid3D", 1)
+    if mode == "ticks":
+        kw = dict(method=1, rgd_stepsize=0.05, acceleration=0)
+        mo = m
+    else:
+        kw = dict(method=0, gradnorm_tol=1e-2, acceleration=1, restart_interval=5, robust_cost_type=O.COST_GNC_TLS, gnc_barc=3.0,
+                  gnc_mu_step=2.0, gnc_init_mu=1e-2, robust_opt_num_weight_updates=3, robust_opt_inner_iters=2 * N)
+        mo = add_outliers(m, n, frac=0.1, seed=0)
+    return N, O.partition(mo, n, N), n, O.odometry_init(mo, n), kw
+
+
+@pytest.mark.parametrize("mode", ["ticks", "gnc"])
+def test_two_rank_lockstep_ticks_and_weight_rounds(mode):
+    """BASELINE configs[4] (lockstep ASAPP ticks) and configs[3] (UPDATE_WEIGHT rounds with the weights of shared edges
+    crossing ranks, src/PGOAgentROS.cpp:721-754,1315-1353) over 2 `gloo` ranks: bitwise the single-process runs."""
+    import torch.multiprocessing as mp_
+    from oracle import oracle as O
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    with tempfile.TemporaryDirectory() as d:
+        mp_.spawn(_worker_modes, args=(2, port, mode, d), nprocs=2, join=True)
+        outs = [np.load(os.path.join(d, "rank%d.npz" % r)) for r in range(2)]
+    N, mp, n, T, kw = _mode_problem(mode)
+    ref = O.Team(mp, n, O.default_params(r=5, num_robots=N, **kw))
+    ref.set_initial(T, O.fixed_stiefel(5))
+    if mode == "ticks":
+        for _ in range(6):
+            ref.exchange_all()
+            for a in ref.agents:
+                a.iterate(True)
+        ref.exchange_all()
+    else:
+        for rnd in range(2):
+            for _ in range(2 * N):
+                ref.iterate()
+            ref.update_weights()
+        for _ in range(N):
+            ref.iterate()
+    for a in range(N):
+        assert np.array_equal(outs[a % 2]["X%d" % a], ref.agents[a].get_X()), "agent %d differs" % a
+        assert np.array_equal(outs[a % 2]["W%d" % a], ref.agents[a].measurements()["weight"])
+    assert abs(float(outs[0]["cost"]) - ref.cost()) <= 1e-12 * abs(ref.cost())
+    if mode == "gnc":
+        w = np.concatenate([ref.agents[a].measurements()["weight"] for a in range(N)])
+        assert (w < 1).sum() > 0

@@ -1,0 +1,112 @@
+"""The N > 1 driver with the HIP backend on the GPU box (one GPU): (1) bench.py's multi-rank code path under the `nccl`
+(= RCCL) backend at world size 1, launched the way the driver launches it; (2) two processes sharing cuda:0 (gloo
+transport, slabs bounced through the host: RCCL refuses two ranks on one GPU) for the lockstep ASAPP ticks of BASELINE
+configs[4] and the UPDATE_WEIGHT rounds of configs[3] with shared-edge weights crossing ranks."""
+import json
+import os
+import socket
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+from dpgo_ros_amd import capi
+from oracle import oracle as O
+from tests.util import ROOT, add_outliers, load
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bench_multi_rank_path_runs_under_rccl_at_world_size_one():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, DPGO_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                          "--gpus", "1", "--steps", "60", "--warmup", "10"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and 0 < d["value"] < 1.0 and d["exchange"].startswith("RCCL")
+    assert np.isfinite(d["relcost_after_run"]) and d["colour_parallel_plain_rtr"]["classes"] == 2
+    assert d["asapp_ticks_tunnels"]["ms_per_tick"] > 0
+
+
+def _problem(mode):
+    N = 3
+    m, _, n = load("smallGrid3D", 1)
+    if mode == "ticks":
+        kw = dict(method=1, rgd_stepsize=0.05, acceleration=0)
+        mo = m
+    else:
+        kw = dict(method=0, gradnorm_tol=1e-2, acceleration=1, restart_interval=5, robust_cost_type=O.COST_GNC_TLS, gnc_barc=3.0,
+                  gnc_mu_step=2.0, gnc_init_mu=1e-2, robust_opt_num_weight_updates=3, robust_opt_inner_iters=2 * N)
+        mo = add_outliers(m, n, frac=0.1, seed=0)
+    return N, O.partition(mo, n, N), n, O.odometry_init(mo, n), kw
+
+
+def _worker(rank, world, port, mode, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    from dpgo_ros_amd.distributed import DistributedRBCD, HipBackend, owner_of
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    N, mp, n, T, kw = _problem(mode)
+    mine = [a for a in range(N) if owner_of(a, world) == rank]
+    be = HipBackend(mp.view(capi.MEAS_DTYPE), capi.default_params(r=5, num_robots=N, **kw), mine, 0, torch, host_staging=True)
+    per = n // N
+    be.team.set_initial(T, O.fixed_stiefel(5), offsets=np.array([a * per for a in mine], dtype=np.int32))
+    drv = DistributedRBCD(dist, be, mp, N, kw.get("acceleration", 0), rank, world)
+    drv.exchange_all()
+    if mode == "ticks":
+        for _ in range(6):
+            drv.tick_simultaneous()
+    else:
+        for rnd in range(2):
+            for _ in range(2 * N):
+                drv.step()
+            drv.update_weights()
+        for _ in range(N):
+            drv.step()
+    cost = drv.global_cost(torch, "cpu")
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), cost=cost,
+             **{"X%d" % a: be.team.agents[a].get_X() for a in mine},
+             **{"W%d" % a: be.team.agents[a].measurements()["weight"] for a in mine})
+    dist.barrier()
+    be.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["ticks", "gnc"])
+def test_two_processes_one_gpu_ticks_and_weight_rounds(mode):
+    import torch.multiprocessing as mp_
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    with tempfile.TemporaryDirectory() as d:
+        mp_.spawn(_worker, args=(2, port, mode, d), nprocs=2, join=True)
+        outs = [np.load(os.path.join(d, "rank%d.npz" % r)) for r in range(2)]
+    N, mp, n, T, kw = _problem(mode)
+    ref = O.Team(mp, n, O.default_params(r=5, num_robots=N, **kw))
+    ref.set_initial(T, O.fixed_stiefel(5))
+    if mode == "ticks":
+        for _ in range(6):
+            ref.exchange_all()
+            for a in ref.agents:
+                a.iterate(True)
+        ref.exchange_all()
+    else:
+        for rnd in range(2):
+            for _ in range(2 * N):
+                ref.iterate()
+            ref.update_weights()
+        for _ in range(N):
+            ref.iterate()
+    for a in range(N):
+        assert np.abs(outs[a % 2]["X%d" % a] - ref.agents[a].get_X()).max() < 1e-7, a
+        assert np.abs(outs[a % 2]["W%d" % a] - ref.agents[a].measurements()["weight"]).max() < 1e-7
+    assert abs(float(outs[0]["cost"]) - ref.cost()) <= 1e-8 * abs(ref.cost())
