@@ -180,7 +180,14 @@ class HipBackend:
 
 
 class DistributedRBCD:
-    def __init__(self, dist, backend, meas, num_robots, acceleration, rank, world, schedule=None):
+    def __init__(self, dist, backend, meas, num_robots, acceleration, rank, world, schedule=None, max_delayed_iterations=0):
+        """max_delayed_iterations: the staleness gate of src/PGOAgentROS.cpp:136-149 (struct default 3,
+        include/dpgo_ros/PGOAgentROS.h:83; the demos set 0).  Robot `sel` may optimize with a neighbour's public poses
+        from iteration >= required - max_delayed_iterations, `required` being the neighbour's latest update (every
+        iteration under acceleration).  On this lossless transport the gate decides which messages are SENT: a remote
+        neighbour b sends to sel only when the copy sel holds is more than max_delayed_iterations behind b's latest
+        change -- and never when b has not changed since it last sent (which already removes the redundant messages of
+        the plain schedule at 0).  Co-resident neighbours are always read fresh (device-to-device, free)."""
         self.dist, self.be = dist, backend
         self.N, self.rank, self.world = num_robots, rank, world
         self.accel = bool(acceleration)
@@ -189,6 +196,10 @@ class DistributedRBCD:
         self.mine = [a for a in range(num_robots) if self.owner[a] == rank]
         self.schedule = list(range(num_robots)) if schedule is None else list(schedule)
         self.k = 0
+        self.max_delay = int(max_delayed_iterations)
+        self.version = [0] * num_robots   # iteration at which each agent's public poses last changed
+        self.sent = {}                    # (b, sel) -> version of b that sel's rank holds
+        self.messages = 0                 # point-to-point operations issued by this rank (for the tests / bench)
         # shared-edge counts per ordered pair, for the weight messages of the robust path
         self.nshared = {}
         for e in meas:
@@ -206,7 +217,7 @@ class DistributedRBCD:
         with self._ctx():
             self._exchange_to(sel, seqs)
 
-    def _exchange_to(self, sel, seqs, pull=True):
+    def _exchange_to(self, sel, seqs, pull=True, force=False):
         d = self.dist
         ops, todo = [], []
         rs = self.owner[sel]
@@ -214,6 +225,12 @@ class DistributedRBCD:
             rb = self.owner[b]
             if rb == rs:
                 continue
+            held = self.sent.get((b, sel))
+            if not force and held is not None:
+                behind = self.version[b] - held
+                if behind == 0 or behind <= self.max_delay:
+                    continue  # the copy on sel's rank is current, or fresh enough for the staleness gate
+            self.sent[(b, sel)] = self.version[b]
             cnt = self.npub[(b, sel)]
             if self.rank == rb:
                 ops.append(d.P2POp(d.isend, self.be.pack(b, sel, seqs, cnt), rs))
@@ -222,6 +239,7 @@ class DistributedRBCD:
                 ops.append(d.P2POp(d.irecv, t, rb))
                 todo.append((b, t))
         if ops:
+            self.messages += len(ops)
             for w in d.batch_isend_irecv(ops):
                 w.wait()
         for b, t in todo:
@@ -230,13 +248,16 @@ class DistributedRBCD:
             self.be.pull_local(sel)
 
     def exchange_all(self):
-        for a in range(self.N):
-            self.exchange_to(a)
+        with self._ctx():
+            for a in range(self.N):
+                self._exchange_to(a, (0, 1), force=True)
 
     def step(self):
         """one global RBCD iteration (src/PGOAgentROS.cpp:129-220): everyone but the token holder
         calls iterate(false) first, then the token holder receives its neighbours' poses and optimizes."""
         sel = self.schedule[self.k % len(self.schedule)]
+        if self.accel:  # iterate(false) moves X and Y of everyone else BEFORE the token holder pulls them
+            self.version = [self.k + 1 if a != sel else self.version[a] for a in range(self.N)]
         with self._ctx():
             if hasattr(self.be, "step_begin"):
                 self.be.step_begin(sel)
@@ -250,6 +271,7 @@ class DistributedRBCD:
                 if self.owner[sel] == self.rank:
                     self.be.iterate(sel, True)
         self.k += 1
+        self.version[sel] = self.k
         return sel
 
     def tick_simultaneous(self):
@@ -279,6 +301,7 @@ class DistributedRBCD:
                 self.be.unpack(a, b, (0,), t)
             self.be.tick_local()
         self.k += self.N
+        self.version = [self.k] * self.N
 
     def update_weights(self):
         """UPDATE_WEIGHT round across ranks (src/PGOAgentROS.cpp:1211-1233): every agent re-weights the edges it owns
@@ -315,7 +338,7 @@ class DistributedRBCD:
 
     def exchange_all_nolock(self):
         for a in range(self.N):
-            self._exchange_to(a, (0, 1))
+            self._exchange_to(a, (0, 1), force=True)
 
     def sweep_colored(self):
         """one colour-parallel sweep of plain (non-accelerated) RBCD: for each colour class, every member
@@ -330,6 +353,8 @@ class DistributedRBCD:
                     self._exchange_to(a, (0,))
                 self.be.run_group(g, members)
                 self.k += len(members)
+                for a in members:
+                    self.version[a] = self.k
 
     def global_cost(self, torch_module, device):
         """f of the concatenated iterate: owned-edge partial sums, one 1-double all-reduce."""

@@ -295,3 +295,94 @@ def test_two_rank_lockstep_ticks_and_weight_rounds(mode):
     if mode == "gnc":
         w = np.concatenate([ref.agents[a].measurements()["weight"] for a in range(N)])
         assert (w < 1).sum() > 0
+
+
+def _worker_delay(rank, world, port, cfg, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from dpgo_ros_amd.distributed import DistributedRBCD, owner_of
+    from oracle import oracle as O
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    N, kw, iters, delay = cfg
+    m, mp, n = load("smallGrid3D", N)
+    params = O.default_params(r=5, num_robots=N, **kw)
+    per = n // N
+    mine = [a for a in range(N) if owner_of(a, world) == rank]
+    be = OracleBackend(mp, params, mine, O.odometry_init(m, n), O.fixed_stiefel(5), {a: a * per for a in range(N)})
+    drv = DistributedRBCD(dist, be, mp, N, kw.get("acceleration", 0), rank, world, max_delayed_iterations=delay)
+    drv.exchange_all()
+    m0 = drv.messages
+    for _ in range(iters):
+        drv.step()
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), messages=drv.messages - m0,
+             **{"X%d" % a: be.agents[a].get_X() for a in mine})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _staleness_reference(N, kw, iters, delay, world):
+    """single-process emulation of the staleness gate (src/PGOAgentROS.cpp:136-149) with oracle agents: a remote
+    neighbour's copy is refreshed only when it is more than `delay` iterations behind the neighbour's latest change;
+    co-resident neighbours are always read fresh."""
+    from dpgo_ros_amd.distributed import owner_of
+    from oracle import oracle as O
+    m, mp, n = load("smallGrid3D", N)
+    t = O.Team(mp, n, O.default_params(r=5, num_robots=N, **kw))
+    t.set_initial(O.odometry_init(m, n), O.fixed_stiefel(5))   # everyone holds everyone's initial poses
+    accel = bool(kw.get("acceleration", 0))
+    version, sent = [0] * N, {}
+    for a in range(N):
+        for b in t.agents[a].neighbors():
+            sent[(b, a)] = 0
+
+    def deliver(b, a):
+        for aux in ((False, True) if accel else (False,)):
+            ids, P = t.agents[b].get_public_poses(a, aux)
+            t.agents[a].update_neighbor_poses(b, ids, P, aux)
+
+    for k in range(iters):
+        sel = k % N
+        for b in range(N):
+            if b != sel:
+                t.agents[b].iterate(False)
+                if accel:
+                    version[b] = k + 1
+        for b in t.agents[sel].neighbors():
+            if owner_of(b, world) == owner_of(sel, world):
+                deliver(b, sel)
+            else:
+                behind = version[b] - sent[(b, sel)]
+                if behind != 0 and behind > delay:
+                    deliver(b, sel)
+                    sent[(b, sel)] = version[b]
+        t.agents[sel].iterate(True)
+        version[sel] = k + 1
+    return t
+
+
+@pytest.mark.parametrize("cfg", [
+    (3, dict(method=0, gradnorm_tol=1e-2), 12, 0),
+    (3, dict(method=0, gradnorm_tol=1e-2), 12, 3),                                       # the struct default
+    (4, dict(method=1, acceleration=1, rgd_stepsize=0.1, restart_interval=50), 16, 2),
+])
+def test_staleness_gate_with_delayed_iterations(cfg):
+    """maxDelayedIterations (include/dpgo_ros/PGOAgentROS.h:83, src/PGOAgentROS.cpp:136-149): the 2-rank run equals the
+    single-process emulation of the gate bit for bit, and a larger allowance sends fewer messages"""
+    import torch.multiprocessing as mp_
+    N, kw, iters, delay = cfg
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    with tempfile.TemporaryDirectory() as d:
+        mp_.spawn(_worker_delay, args=(2, port, cfg, d), nprocs=2, join=True)
+        outs = [np.load(os.path.join(d, "rank%d.npz" % r)) for r in range(2)]
+    ref = _staleness_reference(N, kw, iters, delay, 2)
+    for a in range(N):
+        assert np.array_equal(outs[a % 2]["X%d" % a], ref.agents[a].get_X()), "agent %d differs" % a
+    msgs = int(outs[0]["messages"]) + int(outs[1]["messages"])
+    if delay == 0:
+        # plain RBCD: a neighbour that has not moved since it last sent sends nothing (2 ops per delivered message)
+        assert 0 < msgs <= 2 * 2 * iters
+    else:
+        assert msgs < 2 * 2 * iters
