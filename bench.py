@@ -334,11 +334,11 @@ def roofline_leg(team, agent_id):
     # with profiles/collect.sh.
     roof = {"kernel": "k_precond<5,PM_RGD> (fused step kernel of the timed loop)", "bound": "hbm",
             "achieved": f_bytes / (f_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-            "traffic": (2 * 16572.8 + 811.9) * 1024, "traffic_source": "profiles/r01_pmc_fetch.md, profiles/r01_pmc_write.md",
+            "traffic": (2 * 16571.9 + 833.1) * 1024, "traffic_source": "profiles/r02_pmc_fetch.md, profiles/r02_pmc_write.md",
             "bytes_per_launch": f_bytes, "us_per_launch": f_ms * 1e3, "us_per_launch_back_to_back": b_ms * 1e3,
             "apply_only": {"kernel": "k_precond<5,PM_PLAIN>", "bytes_per_launch": p_bytes, "us_per_launch": p_ms * 1e3,
                            "achieved": p_bytes / (p_ms * 1e-3) / 1e9, "frac": p_bytes / (p_ms * 1e-3) / 1e9 / 8000.0,
-                           "traffic": (2 * 16075.6 + 85.9) * 1024},
+                           "traffic": (2 * 16078.1 + 85.9) * 1024},
             "spmm_eval": {"kernel": "k_eval<5>", "bytes_per_launch": s_bytes, "us_per_launch": s_ms * 1e3,
                           "achieved": s_bytes / (s_ms * 1e-3) / 1e9}}
     roof["frac"] = roof["achieved"] / roof["peak"]

@@ -287,7 +287,7 @@ int dpgo_agent_iterate(dpgo_team_t *t, int id, int do_optimization) {
   bool opt = do_optimization != 0;
   a->last_success = true;
   if (opt && !neighbor_poses_ready(*a, t->prm.acceleration ? 1 : 0)) { opt = false; a->last_success = false; }
-  const int rc = enqueue_iterate(t, a->local, opt ? 1 : 0);
+  const int rc = enqueue_iterate(t, a->local, opt ? 1 : (do_optimization ? 2 : 0));
   if (rc) return rc;
   if (do_optimization) mark_optimized(t, *a, opt ? (a->rel_src == 1 ? 1 : 5) : 2, opt);
   a->iter++;

@@ -337,8 +337,10 @@ template <int R>
 __device__ __forceinline__ void nest_pre_body(const AgentDev *agents, TeamDev *team, int sel, int only_agent,
                                               int num_robots, int restart_interval, int bx, int by, Tile<R> &TX,
                                               Tile<R> &TV, int fused_restart = 0) {
-  // fused_restart: the pipelined RGD sequence takes a restart iteration as one plain step from X (the accelerated
-  // solve that the un-fused path runs first, and discards, is skipped), so the selected agent only saves XPrev
+  // fused_restart bit 0: the pipelined RGD sequence takes a restart iteration as one plain step from X (the accelerated
+  // solve that the un-fused path runs first, and discards, is skipped), so the selected agent only saves XPrev.
+  // bit 1 (keep X): iterate(true) whose neighbour poses have not all arrived -- the local solve is skipped and X stays
+  // where it is (it does NOT move to Y), while Y and, afterwards, V are updated as in any accelerated iteration
   const int ai = only_agent >= 0 ? only_agent : by;
   const AgentDev &ag = agents[ai];
   const int selected = (sel == -2) ? -1 : sel_sched(team, sel);
@@ -357,7 +359,8 @@ __device__ __forceinline__ void nest_pre_body(const AgentDev *agents, TeamDev *t
   tile_in<R>(TV, ag.buf[B_V], j0, cnt, tid);
   __syncthreads();
   tile_out<R>(TX, ag.buf[B_XPREV], j0, cnt, tid);
-  if (fused_restart && optimizing && restart) return;
+  const bool keep_x = (fused_restart & 2) != 0;
+  if ((fused_restart & 1) && optimizing && restart) return;
   double x[4 * R], v[4 * R], y[4 * R];
   double rel = 0;
   if (tid < cnt) {
@@ -380,7 +383,7 @@ __device__ __forceinline__ void nest_pre_body(const AgentDev *agents, TeamDev *t
   __syncthreads();
   if (optimizing) {
     tile_out<R>(TX, ag.buf[B_Y], j0, cnt, tid);
-    tile_out<R>(TX, ag.buf[B_X], j0, cnt, tid);  // the local solve starts from Y, in place on X
+    if (!keep_x) tile_out<R>(TX, ag.buf[B_X], j0, cnt, tid);  // the local solve starts from Y, in place on X
   } else if (restart) {
     tile_out<R>(TX, ag.buf[B_Y], j0, cnt, tid);
     tile_out<R>(TX, ag.buf[B_V], j0, cnt, tid);

@@ -144,6 +144,20 @@ int enqueue_iterate(dpgo_team *t, int li, int do_opt) {
   fl.fused = fused;
   int rc = 0;
   a.rel_src = 0;
+  if (do_opt == 2) {
+    // iterate(true) while a neighbour's poses are still missing (the delayed-message case): no local solve, X stays
+    // put; under acceleration Y, V and the periodic restart are updated as in any iteration
+    if (p.acceleration) {
+      launch_nest_pre(c, li, li, 1, a.n, p.num_robots, p.restart_interval, 2);
+      launch_nest_post(c, li, a.n, p.num_robots, p.restart_interval);
+      if (restart) launch_nest_reset(c, li, a.n);
+    } else {
+      launch_copy(c, li, li, 1, a.n, B_X, B_XPREV, 0);
+    }
+    a.rel_src = 2;
+    launch_advance(c, li, 1, p.acceleration, p.num_robots, p.restart_interval, 0);
+    return 0;
+  }
   if (p.acceleration) {
     launch_nest_pre(c, do_opt ? li : -2, li, 1, a.n, p.num_robots, p.restart_interval);
     if (do_opt) {

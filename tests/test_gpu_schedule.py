@@ -159,3 +159,40 @@ def test_config3_merged_graph_eight_agents_gnc():
         assert np.abs(wh - wo).max() < 1e-6
         assert (wo < 1).sum() > 0.05 * len(wo)  # mu = 1e-5: anything with residual^2 > 9e-5 is down-weighted
     th.close()
+
+
+@pytest.mark.parametrize("accel,restart", [(1, 50), (1, 2), (0, 50)])
+def test_iterate_true_with_a_missing_neighbour_pose_keeps_x(accel, restart):
+    """the delayed-message case (src/PGOAgentROS.cpp:136-149 lets a robot run iterate(true) only when its neighbours'
+    poses are there; the library itself skips the solve when one is missing): X stays where it is -- it does NOT move
+    to Y -- while Y, V and the periodic restart are updated as in any accelerated iteration; iterate returns false and
+    the status says not ready"""
+    N = 3
+    m, mp, n = load("smallGrid3D", N)
+    kw = dict(r=5, num_robots=N, method=capi.METHOD_RTR, acceleration=accel, restart_interval=restart, gradnorm_tol=1e-2)
+    ph, po = params_pair(**kw)
+    th = capi.Team.from_measurements(mp.view(capi.MEAS_DTYPE), ph)
+    to = O.Team(mp, n, po)
+    X0 = O.lift(O.odometry_init(m, n), n, O.fixed_stiefel(5), 5)
+    off = 0
+    for k in range(N):
+        nk = to.agents[k].n
+        for team in (th, to):
+            team.agents[k].set_X(X0[20 * off:20 * (off + nk)])
+        off += nk
+    # agent 1 hears from agent 0 only; agent 2's poses never arrive
+    for team in (th, to):
+        for aux in ((False, True) if accel else (False,)):
+            ids, P = team.agents[0].get_public_poses(1, aux)
+            team.agents[1].update_neighbor_poses(0, ids, P, aux)
+    for it in range(3):
+        rh, ro = th.agents[1].iterate(True), to.agents[1].iterate(True)
+        assert not rh and not ro
+        ah, ao = th.agents[1], to.agents[1]
+        assert np.abs(ah.get_X() - ao.get_X()).max() < 1e-12
+        assert np.abs(ah.get_Y() - ao.get_Y()).max() < 1e-12
+        assert np.abs(ah.get_V() - ao.get_V()).max() < 1e-12
+        sh, so = ah.status(), ao.status()
+        assert not sh.ready_to_terminate and not so.ready_to_terminate
+        assert abs(sh.relative_change - so.relative_change) < 1e-12 and sh.iteration_number == so.iteration_number
+    th.close()
