@@ -84,6 +84,7 @@ __global__ __launch_bounds__(256) void k_iter_rgd(const AgentDev *agents, TeamDe
   constexpr bool SLAB_LDS = false && (size_t)R * KC * 8 + (size_t)MREG * 1024 + 4096 <= 160 * 1024;
   __shared__ __attribute__((aligned(16))) double vs[R * KC];
   __shared__ __attribute__((aligned(16))) double zs[8 * R];
+  __shared__ double red[32 * (8 * R + 1)];
   __shared__ double Ysh[2 * 4 * R];
   __shared__ double Esh[3][2 * 4 * R];
   __shared__ double EvY[PPB * 4 * R], EvW[PPB * 4 * R];
@@ -347,18 +348,19 @@ __global__ __launch_bounds__(256) void k_iter_rgd(const AgentDev *agents, TeamDe
     for (int a = 0; a < R; ++a) acc[a] += w[a] * mreg[m].x + w[R + a] * mreg[m].y;
   }
 
+  // k-lane partial sums through LDS, one lane per (column, a) adds them in k-lane order (as k_precond does)
 #pragma unroll
-  for (int a = 0; a < R; ++a) {
-#pragma unroll
-    for (int off = 16; off > 0; off >>= 1) acc[a] += __shfl_xor(acc[a], off, 64);
-  }
-  if (kl == 0) {
-#pragma unroll
-    for (int a = 0; a < R; ++a) zs[cg * R + a] = acc[a];
-  }
+  for (int a = 0; a < R; ++a) red[kl * (8 * R + 1) + cg * R + a] = acc[a];
   if (tid < npose * 4 * R) {
     Ysh[tid] = pre_x;
     Esh[0][tid] = pre_v; Esh[1][tid] = pre_y; Esh[2][tid] = pre_p;
+  }
+  __syncthreads();
+  if (tid < 8 * R) {
+    double s = 0;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) s += red[q * (8 * R + 1) + tid];
+    zs[tid] = s;
   }
   ITER_STAMP(9);
   __syncthreads();
@@ -427,7 +429,7 @@ __global__ __launch_bounds__(256) void k_iter_rgd(const AgentDev *agents, TeamDe
 #pragma unroll
     for (int i = 0; i < 4 * R; ++i) ag.buf[B_V][o + i] = v[i];
   }
-  if (tid < 64) {
+  if (tid < 64 && want_stats) {
     rel = wave_sum(rel);
     if (tid == 0) ag.part[PART_B + (size_t)bx * PART_STRIDE + 2] = rel;
   }

@@ -11,6 +11,8 @@ struct LaunchCtx {
   const AgentDev *agents;  // device array
   TeamDev *team;           // device
   int ny = 1;              // grid.y of the per-agent kernels: members of the colour class being updated
+  const NestState *nest_all = nullptr;  // the team's NestStates, [local agent]: lets a kernel read an agent's Nesterov
+                                        // state from the agent index alone, next to (not behind) its descriptor
 };
 
 // preconditioner kernel modes (see precond.hip)

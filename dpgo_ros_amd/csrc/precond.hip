@@ -7,6 +7,9 @@ namespace dpgo {
 
 // optional per-phase timestamps of hardware block 100, wave 0 / wave 1 (build with -DDPGO_PC_TRACE): written to the
 // partial-sum scratch of the agent, region PART_E, words [4000 ..]
+#ifndef DPGO_PC_MPRE
+#define DPGO_PC_MPRE 4
+#endif
 #ifdef DPGO_PC_TRACE
 #define PC_STAMP(k) do { if (MODE == PM_RGD_ && (threadIdx.x & 63) == 0 && blockIdx.x == 100) ag.part[PART_E + 4000 * PART_STRIDE + ((threadIdx.x >> 6) * 16) + (k)] = (double)wall_clock64(); } while (0)
 #else
@@ -40,13 +43,15 @@ namespace dpgo {
 template <int R, int MODE, int KC>
 __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev *team, int sel, int xb, int vb,
                                                  int zb, int sp, int max_inner, double step, int accel,
-                                                 int num_robots, int advance, int restart_interval, int ahead) {
+                                                 int num_robots, int advance, int restart_interval, int ahead,
+                                                 const NestState *nest_all) {
   // XCD-aware block order: hardware workgroup h runs on XCD h % 8 (each with its own L2).  Logical block
   // (h % 8) * (grid / 8) + h / 8 gives every XCD one contiguous range of poses, so that the cache lines shared by
   // neighbouring poses (a pose is 4R doubles, not a multiple of a line) are written inside one L2 instead of
   // being split between two.  The grid is padded to a multiple of 8; padding blocks fall out at the nblk test.
   const int bx = ((int)blockIdx.x % 8) * ((int)gridDim.x / 8) + (int)blockIdx.x / 8;
-  const AgentDev &ag = agents[sel_cur(team, sel)];
+  const int agent_index = sel_cur(team, sel);
+  const AgentDev &ag = agents[agent_index];
   PC_STAMP(0);
   if (MODE == PM_RGD_ && advance == 2 && bx == 0 && threadIdx.x == 0) {
     // pipelined iterations: nothing that a workgroup of THIS launch reads is written here (cur_sel, iter and the
@@ -65,6 +70,7 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
   constexpr int MREG = KC / 64;
   __shared__ double vs[R * KC];
   __shared__ double zs[8 * R];
+  __shared__ double red[32 * (8 * R + 1)];
   __shared__ double Ysh[2 * 4 * R];
   __shared__ double Esh[3][2 * 4 * R];  // PM_RGD: V, Yaux, XPrev of the two poses
   const int tid = threadIdx.x, lane = tid & 63;
@@ -162,7 +168,7 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
     if (advance == 2) {
       // the NestState describes iteration k-1 (it is advanced by the next k_eval_stats): gamma of this iteration,
       // and gamma / alpha / selected agent of iteration k+1 for the look-ahead Nesterov step of the epilogue
-      const NestState ns = *ag.nest;
+      const NestState ns = nest_all ? nest_all[agent_index] : *ag.nest;  // (one round trip less than through the descriptor)
       const double Nr = (double)num_robots;
       // restart iterations are part of the uniform sequence: iteration k restarts when (iter + 2) % interval == 0
       // (the test of k_nest_pre / advance_agent); its step is a plain RGD step from X with V = Y = X afterwards
@@ -219,9 +225,19 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
       }
     }
   }
+  // MPRE of the MREG slab loads of a chunk are requested BEFORE the vector is staged: a handful of requests per lane
+  // (they do not hold the wave at the issue queue as the full 32 would) that take the ~2 us first-byte latency of the
+  // stream -- row activation, translation -- under the 1.6 us of the staging instead of behind it
+  constexpr int MPRE = DPGO_PC_MPRE;
   for (int k0 = 0; ag.M && k0 < N4; k0 += KC) {
     const int kn = min(KC, N4 - k0);
     if (k0 > 0) __syncthreads();
+    double2 mreg[MREG];
+#pragma unroll
+    for (int m = 0; m < MPRE; ++m) {
+      const int k = 2 * kl + 64 * m;
+      mreg[m] = (cact && k < kn) ? ld2_nt(Mc + k0 + k) : make_double2(0.0, 0.0);
+    }
     {
       double2 v[NSTG];
 #pragma unroll
@@ -237,9 +253,8 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
     }
     __syncthreads();
     PC_STAMP(2);
-    double2 mreg[MREG];
 #pragma unroll
-    for (int m = 0; m < MREG; ++m) {
+    for (int m = MPRE; m < MREG; ++m) {
       const int k = 2 * kl + 64 * m;
       mreg[m] = (cact && k < kn) ? ld2_nt(Mc + k0 + k) : make_double2(0.0, 0.0);
     }
@@ -258,7 +273,35 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
     }
   }
   PC_STAMP(4);
-  if (MODE == PM_RGD_ && (ahead & 2)) {
+  // the 32 k-lane partial sums of every column go through LDS ([k-lane][column * R + a], rows padded to an odd number
+  // of doubles: conflict-free both ways) and ONE lane per (column, a) adds them in k-lane order: 0.5 us where five
+  // 5-stage ds_bpermute butterflies took 2.2 (profiles/experiments/step_trace.py)
+#pragma unroll
+  for (int a = 0; a < R; ++a) red[kl * (8 * R + 1) + cg * R + a] = acc[a];
+  if (tid < npose * 4 * R) {
+    Ysh[tid] = pre_x;
+    if (MODE == PM_RGD_) { Esh[0][tid] = pre_v; Esh[1][tid] = pre_y; Esh[2][tid] = pre_p; }
+  }
+  __syncthreads();
+  // from here on the waves go separate ways and need no workgroup barrier: the first wave adds the partial sums and
+  // finishes the step of the two poses (LDS operations of one wave execute in order), the second wave takes the
+  // look-ahead step of the other agents' poses (its operand addresses come from a chain of scalar loads that used to sit
+  // on every wave's path: 1.5 us), the other two are done
+  if (tid >= 128) return;
+  if (tid < 8 * R) {
+    double s = 0;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) s += red[q * (8 * R + 1) + tid];
+    zs[tid] = s;
+  }
+  PC_STAMP(5);
+  if (tid < 64) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  PC_STAMP(6);
+  if (MODE == PM_RGD_ && (ahead & 2) && tid >= 64 && tid < 128) {
     // look-ahead operands of the second wave, requested once its share of the stream is consumed: they arrive while
     // the partial sums are reduced and the first wave starts its tail, and they do not occupy registers during the
     // stream (the tail is register-bound).
@@ -296,22 +339,6 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
       for (int i = 0; i < 4 * R; ++i) { la_x[i] = xa[o + i]; la_v[i] = va[o + i]; }
     }
   }
-#pragma unroll
-  for (int a = 0; a < R; ++a) {
-#pragma unroll
-    for (int off = 16; off > 0; off >>= 1) acc[a] += __shfl_xor(acc[a], off, 64);
-  }
-  if (kl == 0) {
-#pragma unroll
-    for (int a = 0; a < R; ++a) zs[cg * R + a] = acc[a];
-  }
-  if (tid < npose * 4 * R) {
-    Ysh[tid] = pre_x;
-    if (MODE == PM_RGD_) { Esh[0][tid] = pre_v; Esh[1][tid] = pre_y; Esh[2][tid] = pre_p; }
-  }
-  PC_STAMP(5);
-  __syncthreads();
-  PC_STAMP(6);
 
   if (MODE == PM_RGD_ && (ahead & 2) && tid >= 64 && tid < 128) {
     // look-ahead of the other agents' poses on the second wave (operands prefetched in the prologue)
@@ -362,7 +389,9 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
       tangent_inplace<R>(x, z);
 #pragma unroll
       for (int i = 0; i < 4 * R; ++i) x[i] -= step * z[i];
+      PC_STAMP(8);
       qf_inplace<R>(x);
+      PC_STAMP(9);
       if (want_stats) {
 #pragma unroll
         for (int i = 0; i < 4 * R; ++i) {
@@ -386,6 +415,7 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
           polar_inplace<R>(v);
         }
       }
+      PC_STAMP(10);
       if (accel && (ahead & 1)) {
         // Nesterov step of iteration k+1 for this pose (what k_nest_pre would do next): XPrev = X, then
         //   k+1 regular:  Y = proj((1 - alpha') X + alpha' V), X = Y (V = proj(V) is the identity: V was just projected)
@@ -406,6 +436,7 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
 #pragma unroll
           for (int i = 0; i < 4 * R; ++i) y[i] = (1.0 - ahead_alpha) * x[i] + ahead_alpha * v[i];
           polar_inplace<R>(y);
+          PC_STAMP(11);
 #pragma unroll
           for (int i = 0; i < 4 * R; ++i) { ag.buf[B_Y][o + i] = y[i]; ag.buf[B_X][o + i] = y[i]; }
           if (la_status && !ahead_opt) {
@@ -424,7 +455,7 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
         for (int i = 0; i < 4 * R; ++i) ag.buf[B_V][o + i] = v[i];
       }
     }
-    if (tid < 64) {
+    if (tid < 64 && want_stats) {  // (mid-run launches leave no statistics: nothing reads them)
       rel = wave_sum(rel);
       if (tid == 0) ag.part[PART_B + (size_t)bx * PART_STRIDE + 2] = rel;
     }
@@ -476,11 +507,11 @@ void launch_precond(const LaunchCtx &c, int sel, int max_n, int mode, int xb, in
   if (4 * max_n > 1024 && 4 * max_n <= 2048) {                                                                       \
     DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL((k_precond<R, M, 2048>), dim3(grid, c.ny), dim3(256), 0, c.stream, c.agents,   \
                                             c.team, sel, xb, vb, zb, sp, max_inner, step, accel, num_robots, advance,   \
-                                            restart_interval, ahead));                                                \
+                                            restart_interval, ahead, c.nest_all));                                                \
   } else {                                                                                                           \
     DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL((k_precond<R, M, 1024>), dim3(grid, c.ny), dim3(256), 0, c.stream, c.agents,   \
                                             c.team, sel, xb, vb, zb, sp, max_inner, step, accel, num_robots, advance,   \
-                                            restart_interval, ahead));                                                \
+                                            restart_interval, ahead, c.nest_all));                                                \
   }
   if (mode == PM_PLAIN_) { PC_CALL(PM_PLAIN_); }
   else if (mode == PM_TCG_INIT_) { PC_CALL(PM_TCG_INIT_); }

@@ -148,7 +148,12 @@ struct dpgo_team {
   int use_fused = 0;  // DPGO_FUSED_ITER=1 selects the one-launch iteration (measured 27 us against 25 for two launches on
                       // sphere2500 / 5 agents, profiles/r02_fused_iteration.md, hence off by default)
   unsigned long long epoch = 1;  // bumped by everything that enqueues device work (every launch goes through ctx())
-  dpgo::LaunchCtx ctx() { ++epoch; return dpgo::LaunchCtx{prm.r, stream, d_agents.p, d_team.p}; }
+  dpgo::LaunchCtx ctx() {
+    ++epoch;
+    dpgo::LaunchCtx c{prm.r, stream, d_agents.p, d_team.p};
+    c.nest_all = d_nest_all.p;
+    return c;
+  }
 };
 
 namespace dpgo_host {

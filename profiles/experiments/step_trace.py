@@ -8,12 +8,12 @@ m, mp, n, T, Y = bench.load_problem(capi)
 prm = capi.default_params(r=5, num_robots=5, **bench.RGD)
 team = capi.Team.from_measurements(mp, prm, device=0)
 team.set_initial(T, Y)
-names = ["start", "prologue done", "vector staged", "M requested", "M consumed", "reduced", "sync", "end"]
+names = ["start", "prologue done", "vector staged", "M requested", "M consumed", "reduced", "sync", "end", "tangent+step", "qf", "V polar", "Y polar"]
 PART_E = 4 * 32768 * 8
 for rep in range(4):
     team.run(36)   # the last step kernel of the run belongs to agent (35 % 5) = 0
     buf = np.zeros(64)
     capi.lib().dpgo_agent_read_partials(team.h, 0, PART_E + 4000 * 8, capi._d(buf), 64)
     for w in (0, 1, 2):
-        t = buf[16 * w:16 * w + 8]
-        print("wave %d " % w + " ".join("%s=%.2f" % (names[k], (t[k] - buf[0]) / 100.0) for k in range(8) if t[k]))
+        t = buf[16 * w:16 * w + 12]
+        print("wave %d " % w + " ".join("%s=%.2f" % (names[k], (t[k] - buf[0]) / 100.0) for k in (0,1,2,3,4,5,6,8,9,10,11,7) if t[k]))
