@@ -267,6 +267,13 @@ int finalize_agent(dpgo_team *t, Agent &a, double *scratch) {
     a.n_pubframes[nb] = (int)fr.size(); a.n_nbrslots[nb] = (int)slots.size();
     max_xfer = std::max(max_xfer, std::max(fr.size(), slots.size()));
   }
+  {
+    std::vector<int> all;
+    for (auto &kv : a.d_pubframes) { const std::vector<int> fr = public_ids(a, kv.first); all.insert(all.end(), fr.begin(), fr.end()); }
+    a.n_pub_all = (int)all.size();
+    if (a.d_pub_all.upload(all, s)) { set_err("index upload failed"); return DPGO_ERR; }
+    max_xfer = std::max(max_xfer, 2 * all.size());
+  }
   if (a.d_xfer.alloc(max_xfer * 4 * r)) { set_err("device allocation failed"); return DPGO_ERR; }
 
   AgentDev &d = a.dev;
@@ -289,26 +296,36 @@ int finalize_agent(dpgo_team *t, Agent &a, double *scratch) {
 // staged neighbour poses (dpgo_agent_update_neighbor_poses) -> device slabs: one index + payload upload and one scatter
 // kernel per agent and sequence, one synchronisation for the whole team
 int flush_stage(dpgo_team *t) {
-  bool any = false;
   for (auto &a : t->ag) {
     const size_t B = (size_t)4 * t->prm.r;
     const size_t n0 = a->stage_slots[0].size(), n1 = a->stage_slots[1].size();
     if (n0 + n1 == 0) continue;
-    if (a->d_idx.alloc(n0 + n1) || a->d_xfer.alloc((n0 + n1) * B)) { set_err("device allocation failed"); return DPGO_ERR; }
+    if (a->d_idx.alloc(n0 + n1) || a->d_xfer.alloc((n0 + n1) * B) || a->h_up_idx.alloc(n0 + n1) || a->h_up.alloc((n0 + n1) * B)) {
+      set_err("allocation failed");
+      return DPGO_ERR;
+    }
+    if (!a->up_done) HIPC(hipEventCreateWithFlags(&a->up_done, hipEventDisableTiming));
+    else HIPC(hipEventSynchronize(a->up_done));  // the previous upload has read the pinned image (normally long ago)
     size_t off = 0;
     for (int aux = 0; aux < 2; ++aux) {
       const size_t cnt = a->stage_slots[aux].size();
       if (!cnt) continue;
-      HIPC(hipMemcpyAsync(a->d_idx.p + off, a->stage_slots[aux].data(), sizeof(int) * cnt, hipMemcpyHostToDevice, t->stream));
-      HIPC(hipMemcpyAsync(a->d_xfer.p + off * B, a->stage_data[aux].data(), sizeof(double) * cnt * B, hipMemcpyHostToDevice, t->stream));
-      launch_unpack(t->ctx(), a->dev.nbr[aux], a->d_idx.p + off, (int)cnt, a->d_xfer.p + off * B);
+      std::memcpy(a->h_up_idx.p + off, a->stage_slots[aux].data(), sizeof(int) * cnt);
+      std::memcpy(a->h_up.p + off * B, a->stage_data[aux].data(), sizeof(double) * cnt * B);
       off += cnt;
     }
-    any = true;
-  }
-  if (any) {
-    HIPC(hipStreamSynchronize(t->stream));  // the staging vectors are reused
-    for (auto &a : t->ag) for (int aux = 0; aux < 2; ++aux) { a->stage_slots[aux].clear(); a->stage_data[aux].clear(); }
+    HIPC(hipMemcpyAsync(a->d_idx.p, a->h_up_idx.p, sizeof(int) * (n0 + n1), hipMemcpyHostToDevice, t->stream));
+    HIPC(hipMemcpyAsync(a->d_xfer.p, a->h_up.p, sizeof(double) * (n0 + n1) * B, hipMemcpyHostToDevice, t->stream));
+    off = 0;
+    for (int aux = 0; aux < 2; ++aux) {
+      const size_t cnt = a->stage_slots[aux].size();
+      if (!cnt) continue;
+      launch_unpack(t->ctx(), a->dev.nbr[aux], a->d_idx.p + off, (int)cnt, a->d_xfer.p + off * B);
+      off += cnt;
+      a->stage_slots[aux].clear();
+      a->stage_data[aux].clear();
+    }
+    HIPC(hipEventRecord(a->up_done, t->stream));
   }
   return 0;
 }

@@ -206,26 +206,20 @@ int dpgo_agent_get_public_poses(dpgo_team_t *t, int id, int nbr, int aux, double
     // publishes (all neighbours, X and Y) into one buffer, ONE copy and ONE synchronisation; later calls are served
     // from the host copy until the team enqueues device work again
     const size_t B = (size_t)4 * t->prm.r;
-    size_t total = 0;
-    for (auto &kv : a->n_pubframes) total += 2 * (size_t)kv.second;
+    const size_t total = 2 * (size_t)a->n_pub_all;
     if (a->d_xfer.alloc(total * B)) { set_err("device allocation failed"); return DPGO_ERR; }
-    size_t off = 0;
-    for (auto &kv : a->d_pubframes)
-      for (int s = 0; s < 2; ++s) {
-        const int cnt = a->n_pubframes[kv.first];
-        launch_pack(t->ctx(), a->dev.buf[s ? B_Y : B_X], kv.second->p, cnt, a->d_xfer.p + off * B);
-        off += cnt;
-      }
+    launch_pack2(t->ctx(), a->dev.buf[B_X], a->dev.buf[B_Y], a->d_pub_all.p, a->n_pub_all, a->d_xfer.p);
     std::vector<double> host(total * B);
     HIPC(hipMemcpyAsync(host.data(), a->d_xfer.p, sizeof(double) * total * B, hipMemcpyDeviceToHost, t->stream));
     HIPC(hipStreamSynchronize(t->stream));
-    off = 0;
-    for (auto &kv : a->d_pubframes)
-      for (int s = 0; s < 2; ++s) {
-        const size_t cnt = (size_t)a->n_pubframes[kv.first];
-        a->pub_cache[s][kv.first].assign(host.begin() + off * B, host.begin() + (off + cnt) * B);
-        off += cnt;
-      }
+    size_t off = 0;
+    for (auto &kv : a->d_pubframes) {
+      const size_t cnt = (size_t)a->n_pubframes[kv.first];
+      for (int s = 0; s < 2; ++s)
+        a->pub_cache[s][kv.first].assign(host.begin() + ((size_t)s * a->n_pub_all + off) * B,
+                                         host.begin() + ((size_t)s * a->n_pub_all + off + cnt) * B);
+      off += cnt;
+    }
     a->pub_epoch = t->epoch;
   }
   const std::vector<double> &c = a->pub_cache[aux ? 1 : 0][nbr];
@@ -278,6 +272,64 @@ int dpgo_agent_unpack_neighbor_poses_device(dpgo_team_t *t, int id, int nbr, int
   return a->n_nbrslots[nbr];
 }
 
+// Everything the wrapper asks for right after an iterate -- the public poses of all neighbours and both sequences
+// (:666-668), the status of the block update (:616) and the result of a local RGD solve (:169-172) -- fetched with ONE
+// batch of copies and ONE synchronisation at the end of dpgo_agent_iterate; the getters then answer from the host copies.
+static int report_after_iterate(dpgo_team_t *t, Agent *a, bool did_opt) {
+  const size_t B = (size_t)4 * t->prm.r;
+  const size_t npub = 2 * (size_t)a->n_pub_all * B;
+  const bool want_status = did_opt && !t->prm.status_every_iterate && (a->opt_rel_src == 1 || a->opt_rel_src == 5);
+  const bool tiles = a->opt_rel_src == 5;
+  const int scnt = want_status ? (tiles ? (a->n + 63) / 64 : (4 * a->n + 7) / 8) : 0;
+  const size_t nstat = want_status ? (size_t)(scnt - 1) * PART_STRIDE + 1 : 0;
+  const int ppb = 64 / t->prm.r, nb = (a->n + ppb - 1) / ppb;
+  const bool want_opt = did_opt && a->opt_pending_rgd;
+  const size_t nopt = want_opt ? (size_t)PART_STRIDE * nb : 0;
+  if (a->h_down.alloc(npub + nstat + 2 * nopt + 1)) { set_err("pinned allocation failed"); return DPGO_ERR; }
+  double *pub = a->h_down.p, *stat = pub + npub, *pc = stat + nstat, *pa = pc + nopt;
+  if (npub) {
+    if (a->d_xfer.alloc(npub)) { set_err("device allocation failed"); return DPGO_ERR; }
+    // (the staged upload also went through d_xfer, earlier on the same stream)
+    launch_pack2(t->ctx(), a->dev.buf[B_X], a->dev.buf[B_Y], a->d_pub_all.p, a->n_pub_all, a->d_xfer.p);
+    HIPC(hipMemcpyAsync(pub, a->d_xfer.p, sizeof(double) * npub, hipMemcpyDeviceToHost, t->stream));
+  }
+  if (want_status)
+    HIPC(hipMemcpyAsync(stat, a->dev.part + (tiles ? PART_E : PART_B + 2), sizeof(double) * nstat, hipMemcpyDeviceToHost, t->stream));
+  if (want_opt) {
+    HIPC(hipMemcpyAsync(pc, a->dev.part + PART_C, sizeof(double) * nopt, hipMemcpyDeviceToHost, t->stream));
+    HIPC(hipMemcpyAsync(pa, a->dev.part + PART_A, sizeof(double) * nopt, hipMemcpyDeviceToHost, t->stream));
+  }
+  HIPC(hipStreamSynchronize(t->stream));
+  if (npub) {
+    size_t off = 0;
+    for (auto &kv : a->d_pubframes) {
+      const size_t cnt = (size_t)a->n_pubframes[kv.first];
+      for (int s = 0; s < 2; ++s) {
+        const double *src = pub + ((size_t)s * a->n_pub_all + off) * B;
+        a->pub_cache[s][kv.first].assign(src, src + cnt * B);
+      }
+      off += cnt;
+    }
+    a->pub_epoch = t->epoch;
+  }
+  if (want_status) {
+    double sum = 0;
+    for (int k = 0; k < scnt; ++k) sum += stat[(size_t)k * PART_STRIDE];
+    a->opt_rel_change = std::sqrt(sum / a->n);
+    a->opt_cached = true;
+  }
+  if (want_opt) {
+    auto sum = [&](const double *p, int o) { double s = 0; for (int i = 0; i < nb; ++i) s += p[(size_t)i * PART_STRIDE + o]; return s; };
+    a->opt.success = 1;
+    a->opt.f_init = sum(pc, 0); a->opt.gradnorm_init = std::sqrt(sum(pc, 1));
+    a->opt.f_opt = sum(pa, 0); a->opt.gradnorm_opt = std::sqrt(sum(pa, 1));
+    a->opt.rtr_outer_iters = 0; a->opt.tcg_iters_total = 0; a->opt.hessvec_count = 0;
+    a->opt.precond_count = t->prm.rgd_use_preconditioner ? 1 : 0; a->opt.accepted = 1;
+    a->opt_pending_rgd = false;
+  }
+  return DPGO_OK;
+}
+
 int dpgo_agent_iterate(dpgo_team_t *t, int id, int do_optimization) {
   Agent *a = find_agent(t, id);
   if (!a) return DPGO_ERR;
@@ -292,6 +344,10 @@ int dpgo_agent_iterate(dpgo_team_t *t, int id, int do_optimization) {
   if (do_optimization) mark_optimized(t, *a, opt ? (a->rel_src == 1 ? 1 : 5) : 2, opt);
   a->iter++;
   if (t->prm.acceleration || opt) a->publish_requested = true;
+  if (a->publish_requested || opt) {
+    const int rr = report_after_iterate(t, a, opt);
+    if (rr) return rr;
+  }
   return a->last_success ? DPGO_OK : DPGO_NOT_READY;
 }
 

@@ -53,6 +53,7 @@ void launch_rtr_begin(const LaunchCtx &c, int sel, double Delta0, double tol, in
 void launch_rtr_eval2(const LaunchCtx &c, int sel, int max_n, int sp);
 void launch_rtr_accept(const LaunchCtx &c, int sel, int max_n, int sp, double tol, int max_outer, double max_radius);
 void launch_pack(const LaunchCtx &c, const double *X, const int *frames, int count, double *out);
+void launch_pack2(const LaunchCtx &c, const double *X, const double *Y, const int *frames, int count, double *out);
 void launch_unpack(const LaunchCtx &c, double *slab, const int *slots, int count, const double *in);
 void launch_residuals(const LaunchCtx &c, int ai, int nedges);
 void launch_cost(const LaunchCtx &c, int ai);

@@ -234,6 +234,16 @@ __global__ void k_pack(const double *X, const int *frames, int count, double *ou
   out[t] = X[(size_t)frames[q] * 4 * R + k];
 }
 
+// both sequences of every listed pose in one launch: out = [X of frames[0..count) | Y of the same frames]
+template <int R>
+__global__ void k_pack2(const double *X, const double *Y, const int *frames, int count, double *out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= count * 4 * R) return;
+  const int q = t / (4 * R), k = t - q * 4 * R;
+  const double *src = blockIdx.y ? Y : X;
+  out[(size_t)blockIdx.y * count * 4 * R + t] = src[(size_t)frames[q] * 4 * R + k];
+}
+
 template <int R>
 __global__ void k_unpack(double *slab, const int *slots, int count, const double *in) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -362,6 +372,13 @@ void launch_pack(const LaunchCtx &c, const double *X, const int *frames, int cou
   if (count <= 0) return;
   const int len = count * 4 * c.r;
   DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_pack<R>, dim3((len + 255) / 256), dim3(256), 0, c.stream, X, frames, count,
+                                          out));
+}
+
+void launch_pack2(const LaunchCtx &c, const double *X, const double *Y, const int *frames, int count, double *out) {
+  if (count <= 0) return;
+  const int len = count * 4 * c.r;
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_pack2<R>, dim3((len + 255) / 256, 2), dim3(256), 0, c.stream, X, Y, frames, count,
                                           out));
 }
 

@@ -56,6 +56,24 @@ struct DevBuf {
   }
 };
 
+// grow-only pinned host buffer: copies to / from it are truly asynchronous (a pageable source or destination makes
+// hipMemcpyAsync stage the transfer and block the host for every call)
+template <class T>
+struct PinnedBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+  int alloc(size_t count) {
+    if (count <= n && p) return 0;
+    if (p) (void)hipHostFree(p);
+    p = nullptr; n = 0;
+    const size_t want = std::max<size_t>(count + count / 2, 64);
+    if (hipHostMalloc((void **)&p, sizeof(T) * want) != hipSuccess) return -1;
+    n = want;
+    return 0;
+  }
+};
+
 struct Agent {
   int id = 0, local = 0;
   std::vector<dpgo_measurement_t> odom, priv, shared;
@@ -84,6 +102,8 @@ struct Agent {
   DevBuf<double> d_qval, d_M, d_vec, d_nbr, d_part, d_scal, d_resid, d_ell_val, d_tval;
   std::map<int, std::unique_ptr<DevBuf<int>>> d_pubframes, d_nbrslots;  // per neighbour, cached on the device
   std::map<int, int> n_pubframes, n_nbrslots;
+  DevBuf<int> d_pub_all;  // the public frames of every neighbour, concatenated in neighbour order (one pack launch)
+  int n_pub_all = 0;
   DevBuf<double> d_xfer;
   int tcg_hint = 4, outer_hint = -1;  // launch-pattern sizing from the previous solve of this agent
   int rel_src = 0;  // where the last |X - XPrev|^2 partials live: 0 PART_D (per 64-pose tile), 1 PART_B[2] (fused RGD),
@@ -98,6 +118,10 @@ struct Agent {
   std::map<int, std::vector<double>> pub_cache[2];
   std::vector<int> stage_slots[2];
   std::vector<double> stage_data[2];
+  PinnedBuf<int> h_up_idx;       // pinned images of the staged upload and of the report that closes an iterate
+  PinnedBuf<double> h_up, h_down;
+  hipEvent_t up_done = nullptr;  // recorded behind the last upload: the pinned image is reused only after it
+  ~Agent() { if (up_done) (void)hipEventDestroy(up_done); }
   int opt_rel_src = -1;
   bool opt_success = false, opt_cached = false;
   double opt_ratio = 1.0, opt_rel_change = 0.0;
