@@ -42,6 +42,7 @@ struct RtrState {
   int outer_it, outer_done, tcg_active, tcg_j, tcg_status;
   int need_init, pad0;  // need_init: the next tCG has not been set up yet (after begin / accept)
   int hv_count, pc_count, tcg_total, accepted, outer_count;
+  int tcg_o[4];  // (Hess-vec, step) launch pairs the tCG of outer iteration o consumed: sizes the blind patterns of the next solve
 };
 
 struct NestState {

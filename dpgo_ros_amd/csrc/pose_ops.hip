@@ -209,6 +209,7 @@ __global__ void k_rtr_accept(const AgentDev *agents, const TeamDev *team, int se
     }
     if (accept) { T.f1 = f2; T.ngf = sqrt(g2); T.accepted = S.accepted + 1; }
     T.hv_count = S.hv_count + 1;
+    if (S.outer_it < 4) T.tcg_o[S.outer_it] = S.tcg_j + 1;
     T.outer_it = S.outer_it + 1;
     T.outer_done = (T.outer_it >= max_outer) || (T.ngf < tol);
     T.tcg_active = 0;

@@ -93,8 +93,15 @@ int enqueue_optimize(dpgo_team *t, int sel, const OptFlags &fl) {
   // One outer iteration = [tCG init, (Hess-vec, step) x J, retract, evaluate, accept].  Every kernel is
   // gated by the device-side phase, so whole patterns are enqueued blindly: the expected number of outer
   // iterations first, then one read-back; more patterns only if the state says the solve is not done.
-  const int J = std::max(1, std::min(a.tcg_hint, p.rtr_tcg_iterations));
+  // J launch pairs per pattern: what the tCG of the same outer iteration took in this agent's previous solve (38 % of the
+  // Hess-vec launches and 21 % of the step launches were phase-gated no-ops with one J for all outer iterations,
+  // profiles/experiments/idle_hist.py); a tCG that needs more continues in the next pattern's pairs
+  const int Jdef = std::max(1, std::min(a.tcg_hint, p.rtr_tcg_iterations));
+  int pat = 0;
   auto pattern = [&]() {
+    const int Jo = (pat < 4 && a.tcg_hint_o[pat] > 0) ? a.tcg_hint_o[pat] : Jdef;
+    const int J = std::max(1, std::min(Jo, p.rtr_tcg_iterations + 1));
+    ++pat;
     launch_precond(c, sel, mn, PM_TCG_INIT_, B_X, 0, 0, sp, p.rtr_tcg_iterations, 0.0, 0, p.num_robots); sp ^= 1;
     for (int q = 0; q < J; ++q) {
       launch_tcg_hv(c, sel, mn, sp, p.rtr_tcg_iterations); sp ^= 1;
@@ -121,6 +128,7 @@ int enqueue_optimize(dpgo_team *t, int sel, const OptFlags &fl) {
   }
   a.outer_hint = hs->outer_count;
   if (hs->outer_count > 0) a.tcg_hint = std::max(2, std::min(8, (hs->tcg_total + hs->outer_count - 1) / hs->outer_count + 1));
+  for (int o = 0; o < 4; ++o) a.tcg_hint_o[o] = (o < hs->outer_count) ? hs->tcg_o[o] : 0;
   a.opt.success = 1;
   a.opt.f_init = hs->f_init; a.opt.gradnorm_init = hs->gn_init;
   a.opt.f_opt = hs->f1; a.opt.gradnorm_opt = hs->ngf;

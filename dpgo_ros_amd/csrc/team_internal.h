@@ -106,6 +106,7 @@ struct Agent {
   int n_pub_all = 0;
   DevBuf<double> d_xfer;
   int tcg_hint = 4, outer_hint = -1;  // launch-pattern sizing from the previous solve of this agent
+  int tcg_hint_o[4] = {0, 0, 0, 0};   // per outer iteration: launch pairs its tCG took last time (0 = unknown)
   int rel_src = 0;  // where the last |X - XPrev|^2 partials live: 0 PART_D (per 64-pose tile), 1 PART_B[2] (fused RGD),
                     // 2 none (X untouched), 4 PART_D one double per pose (look-ahead Nesterov step)
   // status of the last iterate(true) (a9; refreshed only when the agent optimizes unless status_every_iterate):

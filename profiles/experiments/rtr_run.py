@@ -1,5 +1,6 @@
 import sys, os, time
 sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), '..', '..'))
+os.chdir(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 from dpgo_ros_amd import capi
 m,n=capi.read_g2o('data/sphere2500.g2o')
 mp=capi.partition(m,n,5); T=capi.odometry_init(m,n); Y=capi.fixed_stiefel(5)
