@@ -543,12 +543,33 @@ def multi_gpu(args):
         tick_ms = t4.item() / 200 * 1e3
     c1 = drv3.global_cost(torch, "cuda")
     dist.barrier()
+    # the asynchronous mode proper: every rank imports its neighbours' pose arrays (HIP IPC, peer loads over xGMI) and
+    # steps at its own pace with no message and no rendezvous -- timed per rank, the slowest rank reported
+    free = {"peer_access": False}
+    if drv3.enable_peer_access():
+        drv3.free_run(20)
+        be3.sync()
+        dist.barrier()
+        t5 = time.perf_counter()
+        drv3.free_run(400)
+        be3.sync()
+        mine_ms = (time.perf_counter() - t5) / 400 * 1e3
+        dist.barrier()
+        with be3.stream_context():
+            t6 = torch.tensor([mine_ms], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t6, op=dist.ReduceOp.MAX)
+        drv3.exchange_all()
+        free = {"peer_access": True, "ms_per_tick_free_running": t6.item(),
+                "cost_after_640_ticks": drv3.global_cost(torch, "cuda")}
+    else:
+        free["error"] = drv3.peer_error
+    dist.barrier()
     be3.close()
     dist.destroy_process_group()
     return rank, ms, cost, roof, {"ms_per_block_update": cp_ms, "classes": len(drv2.groups),
                             "relcost_after_45_sweeps": (cp_cost - F_STAR[WORKLOAD["dataset"]]) / F_STAR[WORKLOAD["dataset"]]}, \
         {"workload": "data/tunnels, 8 robots on %d rank(s), RGD stepsize 0.2 + preconditioner, lockstep ticks" % world,
-         "ms_per_tick": tick_ms, "cost_initial": c0, "cost_after_220_ticks": c1}
+         "ms_per_tick": tick_ms, "cost_initial": c0, "cost_after_220_ticks": c1, **free}
 
 
 def main():

@@ -80,7 +80,7 @@ dpgo_error_threshold_at_quantile dpgo_team_set_schedule dpgo_team_set_initial dp
 dpgo_agent_pull_local dpgo_team_time_kernel dpgo_team_run dpgo_team_get_coloring dpgo_team_run_colored dpgo_team_set_groups dpgo_team_run_group dpgo_team_step_begin dpgo_team_step_end dpgo_team_iteration dpgo_team_cost dpgo_team_update_weights dpgo_team_get_counters
 dpgo_write_measurements_csv dpgo_write_g2o dpgo_write_trajectory_csv dpgo_robust_frame_alignment dpgo_robust_local_init dpgo_team_run_simultaneous
 dpgo_team_should_terminate dpgo_team_run_schedule dpgo_agent_compute_residuals dpgo_agent_set_measurement_weights
-dpgo_agent_reset_acceleration dpgo_team_prepare dpgo_team_read_handoff_state dpgo_agent_read_partials dpgo_agent_preconditioner""".split()
+dpgo_agent_reset_acceleration dpgo_team_prepare dpgo_team_read_handoff_state dpgo_agent_read_partials dpgo_agent_preconditioner dpgo_agent_export_state dpgo_team_import_peer""".split()
 
 
 class DpgoError(RuntimeError):
@@ -465,6 +465,18 @@ class Team:
         col = np.zeros(len(self.ids), dtype=np.int32)
         nc = _chk(lib().dpgo_team_get_coloring(self.h, _d(col)), "get_coloring")
         return nc, col
+
+    def export_state(self, agent_id):
+        """(64-byte IPC handle, offset of X, offset of Y, poses) of a local agent's arrays, for dpgo_team_import_peer"""
+        h = (C.c_ubyte * 64)()
+        ox, oy, n = C.c_longlong(), C.c_longlong(), C.c_int()
+        _chk(lib().dpgo_agent_export_state(self.h, agent_id, h, C.byref(ox), C.byref(oy), C.byref(n)), "export_state")
+        return bytes(h), ox.value, oy.value, n.value
+
+    def import_peer(self, robot_id, handle, off_x, off_y, n):
+        """read the public poses of a robot that lives in another process in place (HIP IPC / peer access)"""
+        h = (C.c_ubyte * 64).from_buffer_copy(handle)
+        _chk(lib().dpgo_team_import_peer(self.h, robot_id, h, C.c_longlong(off_x), C.c_longlong(off_y), n), "import_peer")
 
     def should_terminate(self):
         """PGOAgent::shouldTerminate() as the leader evaluates it (src/PGOAgentROS.cpp:208)"""

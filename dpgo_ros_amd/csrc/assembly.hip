@@ -157,6 +157,7 @@ int finalize_agent(dpgo_team *t, Agent &a, double *scratch) {
     auto it = t->id2local.find(nr);
     d.src_agent_local = (it == t->id2local.end()) ? -1 : it->second;
     d.src_frame = nf;
+    d.src_robot = nr;
     for (int cp = 0; cp < 4; ++cp)
       for (int c = 0; c < 4; ++c) d.coef[cp + 4 * c] = out ? TO[c + 4 * cp] : TO[cp + 4 * c];
     se.push_back(d);
@@ -385,7 +386,15 @@ int sync_descs_noflush(dpgo_team *t) {
     const size_t B = (size_t)4 * t->prm.r;
     for (auto &d : a->se_host) {
       d.src[0] = d.src[1] = nullptr;
-      if (d.src_agent_local < 0) continue;
+      if (d.src_agent_local < 0) {
+        // a neighbour in another process whose X / Y arrays were imported: read it in place, like a co-resident one
+        auto pit = t->peers.find(d.src_robot);
+        if (pit != t->peers.end() && d.src_frame >= 0 && d.src_frame < pit->second.n) {
+          d.src[0] = pit->second.base + pit->second.off_x + (size_t)d.src_frame * B;
+          d.src[1] = pit->second.base + pit->second.off_y + (size_t)d.src_frame * B;
+        }
+        continue;
+      }
       const Agent &sa = *t->ag[d.src_agent_local];
       if (!sa.dev.buf[B_X] || d.src_frame < 0 || d.src_frame >= sa.n) continue;
       d.src[0] = sa.dev.buf[B_X] + (size_t)d.src_frame * B;

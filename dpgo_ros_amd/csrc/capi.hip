@@ -73,6 +73,7 @@ void dpgo_team_destroy(dpgo_team_t *t) {
   (void)hipSetDevice(t->device);
   (void)hipStreamSynchronize(t->stream);
   for (auto &kv : t->graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);
+  for (auto &kv : t->peers) if (kv.second.base) (void)hipIpcCloseMemHandle(kv.second.base);
   t->ag.clear();
   if (t->h_state) (void)hipHostFree(t->h_state);
   if (t->h_states) (void)hipHostFree(t->h_states);
@@ -1201,6 +1202,44 @@ int dpgo_team_run_schedule(dpgo_team_t *t, int max_iters, int *terminated, int *
   if (terminated) *terminated = term;
   if (weight_rounds) *weight_rounds = rounds;
   return done;
+}
+
+// ---- peer access (one process per GPU, asynchronous mode): a robot's X / Y arrays are exported as a HIP IPC handle
+// and imported by the processes that hold its neighbours, which then read its public poses in place -- one-sided, with
+// no message and no rendezvous, over xGMI when the processes sit on different GPUs.  This is what carries the
+// asynchronous (ASAPP) configuration, whose robots step from whatever neighbour poses are there
+// (src/PGOAgentROS.cpp:119-127); RCCL point-to-point is two-sided and cannot.
+int dpgo_agent_export_state(dpgo_team_t *t, int id, unsigned char *handle64, long long *offset_x, long long *offset_y, int *n) {
+  Agent *a = find_agent(t, id);
+  if (!a) return DPGO_ERR;
+  if (sync_descs(t)) return DPGO_ERR;
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
+  hipIpcMemHandle_t h;
+  HIPC(hipIpcGetMemHandle(&h, a->d_vec.p));
+  std::memcpy(handle64, &h, 64);
+  *offset_x = a->dev.buf[B_X] - a->d_vec.p;
+  *offset_y = a->dev.buf[B_Y] - a->d_vec.p;
+  *n = a->n;
+  return DPGO_OK;
+}
+
+int dpgo_team_import_peer(dpgo_team_t *t, int robot_id, const unsigned char *handle64, long long offset_x, long long offset_y, int n) {
+  if (t->id2local.count(robot_id)) { set_err("import_peer: the robot lives in this team"); return DPGO_ERR; }
+  hipIpcMemHandle_t h;
+  std::memcpy(&h, handle64, 64);
+  void *p = nullptr;
+  HIPC(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+  dpgo_team::Peer pr;
+  pr.base = (double *)p; pr.off_x = (size_t)offset_x; pr.off_y = (size_t)offset_y; pr.n = n;
+  t->peers[robot_id] = pr;
+  // its poses are readable from now on: the agents that neighbour it need no message before they may optimize
+  for (auto &a : t->ag) {
+    rebuild_index(*a);
+    for (size_t q = 0; q < a->np.size(); ++q)
+      if (a->np[q].first == robot_id) { a->np_has[0][q] = 1; a->np_has[1][q] = 1; }
+  }
+  t->descs_dirty = true;
+  return DPGO_OK;
 }
 
 // diagnostic: `n` doubles of an agent's partial-sum scratch starting at `offset` (phase timestamps of trace builds)

@@ -18,8 +18,10 @@ struct SharedEdgeDev {
   int slot;   // index into the neighbour-pose slab
   int src_agent_local;  // local index of the neighbour agent in this team, or -1 if remote
   int src_frame;
-  const double *src[2];  // the neighbour's pose in its agent's X ([0]) / Y ([1]) array when co-resident, else null:
-                         // one load instead of the agents[src].buf[...] descriptor round trip
+  int src_robot, pad_;  // global id of the neighbour (locates an imported peer, see dpgo_team_import_peer)
+  const double *src[2];  // the neighbour's pose in its agent's X ([0]) / Y ([1]) array when co-resident -- or when the
+                         // neighbour lives in another process whose arrays were imported (IPC, peer access over xGMI) --
+                         // else null: one load instead of the agents[src].buf[...] descriptor round trip
   double coef[16];
 };
 

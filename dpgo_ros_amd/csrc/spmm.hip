@@ -32,10 +32,9 @@ __global__ void k_pull(const AgentDev *agents, int dst) {
   if (t >= ag.nshared * 4 * R) return;
   const int e = t / (4 * R), k = t - e * 4 * R;
   const SharedEdgeDev &se = ag.se[e];
-  if (se.src_agent_local < 0) return;
-  const AgentDev &sa = agents[se.src_agent_local];
-  ag.nbr[0][(size_t)se.slot * 4 * R + k] = sa.buf[B_X][(size_t)se.src_frame * 4 * R + k];
-  ag.nbr[1][(size_t)se.slot * 4 * R + k] = sa.buf[B_Y][(size_t)se.src_frame * 4 * R + k];
+  if (!se.src[0]) return;  // neither co-resident nor imported: its poses arrive as messages
+  ag.nbr[0][(size_t)se.slot * 4 * R + k] = se.src[0][k];
+  ag.nbr[1][(size_t)se.slot * 4 * R + k] = se.src[1][k];
 }
 
 template <int R>

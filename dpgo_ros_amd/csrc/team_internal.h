@@ -164,6 +164,10 @@ struct dpgo_team {
   std::map<int, int> graph_flip;
   bool graph_valid = false;
   double counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  // X / Y arrays of robots that live in other processes, imported through HIP IPC (dpgo_team_import_peer): their
+  // public poses are read in place over peer access instead of travelling as messages
+  struct Peer { double *base = nullptr; size_t off_x = 0, off_y = 0; int n = 0; };
+  std::map<int, Peer> peers;
   // fused iteration kernel (iter_fused.hip): hand-off counters, time-out flag (pinned), resident capacity, switch
   dpgo_host::DevBuf<dpgo::NestState> d_nest_all;  // NestState of local agent k at [k]: one array, so that a kernel finds any agent's
                                                    // state from the agent index alone (no descriptor round trip)

@@ -130,6 +130,25 @@ class HipBackend:
         if self.team is not None:
             self.team.run_simultaneous(1)
 
+    # ---- peer access: neighbours in other processes read in place (HIP IPC; xGMI loads between GPUs)
+    def export_states(self):
+        """{agent: (ipc handle, offset of X, offset of Y, poses)} of the local agents"""
+        if self.team is None:
+            return {}
+        return {a: self.team.export_state(a) for a in self.team.agents}
+
+    def import_peer(self, robot, state):
+        self.team.import_peer(robot, *state)
+
+    def sync(self):
+        self.stream.synchronize()
+
+    def free_run(self, ticks):
+        """`ticks` steps of every local agent back to back, each from whatever the neighbours' arrays hold when its
+        kernels read them -- no message, no rendezvous with the other ranks (the asynchronous mode proper)"""
+        if self.team is not None:
+            self.team.run_simultaneous(ticks)
+
     # ---- robust path across ranks (src/PGOAgentROS.cpp:721-754 publishMeasurementWeights, :1315-1353 callback)
     def local_update_weights(self):
         """every local agent re-weights what it owns; co-resident endpoints are served in the same call"""
@@ -200,6 +219,7 @@ class DistributedRBCD:
         self.version = [0] * num_robots   # iteration at which each agent's public poses last changed
         self.sent = {}                    # (b, sel) -> version of b that sel's rank holds
         self.messages = 0                 # point-to-point operations issued by this rank (for the tests / bench)
+        self._imported, self.peer_access, self.peer_error = set(), False, None
         # shared-edge counts per ordered pair, for the weight messages of the robust path
         self.nshared = {}
         for e in meas:
@@ -301,6 +321,67 @@ class DistributedRBCD:
                 self.be.unpack(a, b, (0,), t)
             self.be.tick_local()
         self.k += self.N
+        self.version = [self.k] * self.N
+
+    def enable_peer_access(self):
+        """Every rank exports the X / Y arrays of its agents and imports those of its agents' remote neighbours
+        (dpgo_agent_export_state / dpgo_team_import_peer): from here on remote public poses are read in place, like
+        co-resident ones.  Collective (all_gather of the 64-byte handles, then of the outcome); call after the team is
+        built.  Returns whether EVERY rank succeeded (peer_error holds the first failure) so that all ranks take the same
+        branch afterwards."""
+        d = self.dist
+        err = None
+        try:
+            mine = self.be.export_states()
+        except RuntimeError as e:  # agree on the outcome before anyone enters another collective
+            mine, err = {}, str(e)
+        everyone = [None] * self.world
+        d.all_gather_object(everyone, mine)
+        states = {}
+        for part in everyone:
+            states.update(part)
+        if err is None and getattr(self.be, "team", None) is not None:
+            try:
+                for a in self.mine:
+                    for b in self.nbrs[a]:
+                        if self.owner[b] != self.rank and b not in self._imported:
+                            self.be.import_peer(b, states[b])
+                            self._imported.add(b)
+            except (RuntimeError, KeyError) as e:
+                err = str(e)
+        errs = [None] * self.world
+        d.all_gather_object(errs, err)
+        self.peer_access = all(e is None for e in errs)
+        self.peer_error = next((e for e in errs if e is not None), None)
+        return self.peer_access
+
+    def step_peer(self):
+        """step() with the neighbours read in place instead of sent: the point-to-point messages become rendezvous
+        (stream drained + barrier) -- one before the token holder reads, and under acceleration one before everyone
+        moves its Y.  Same iterates as step(); needs enable_peer_access."""
+        assert self.peer_access, "step_peer needs enable_peer_access()"
+        sel = self.schedule[self.k % len(self.schedule)]
+        with self._ctx():
+            if self.accel:
+                self.be.sync()
+                self.dist.barrier()
+            self.be.step_begin(sel)
+            self.be.sync()
+            self.dist.barrier()
+            self.be.step_end(sel)
+        self.k += 1
+        return sel
+
+    def free_run(self, ticks):
+        """The asynchronous (ASAPP) mode across ranks, src/PGOAgentROS.cpp:119-127: every rank steps its agents `ticks`
+        times at its own pace, reading the other ranks' public poses in place (needs enable_peer_access).  No
+        collective, no barrier: which iterate of a neighbour a step sees depends on timing, as in the reference's
+        free-running optimization threads; the result is therefore not reproducible bit for bit -- the tests check
+        what the asynchronous mode promises (the cost goes down to the synchronous answer's neighbourhood)."""
+        assert self.peer_access, "free_run needs enable_peer_access()"
+        with self._ctx():
+            self.be.free_run(ticks)
+        self.k += self.N * ticks
         self.version = [self.k] * self.N
 
     def update_weights(self):

@@ -243,6 +243,12 @@ int dpgo_agent_pull_local(dpgo_team_t *t, int id);
 /* average HIP-event duration of one launch of a hot kernel on the team stream.
  * which: 0 dense preconditioner apply, 1 cost+gradient SpMM, 2 Hessian-vector SpMM */
 int dpgo_team_time_kernel(dpgo_team_t *t, int id, int which, int reps, double *avg_ms, double *algorithmic_bytes);
+/* peer access for one-process-per-GPU runs of the asynchronous mode (src/PGOAgentROS.cpp:119-127): a robot's X / Y arrays
+ * exported as a 64-byte HIP IPC handle (+ the offsets of X and Y in doubles and its pose count), imported by the
+ * processes that hold its neighbours; from then on its public poses are read in place (xGMI peer loads), one-sided:
+ * no PublicPoses message, no rendezvous.  The exporting process must outlive the importers' use. */
+int dpgo_agent_export_state(dpgo_team_t *t, int id, unsigned char *handle64, long long *offset_x, long long *offset_y, int *n);
+int dpgo_team_import_peer(dpgo_team_t *t, int robot_id, const unsigned char *handle64, long long offset_x, long long offset_y, int n);
 /* diagnostic: `n` doubles of an agent's device-side partial-sum scratch (csrc/dpgo_dev.h PART_*) from `offset` */
 int dpgo_agent_read_partials(dpgo_team_t *t, int id, int offset, double *out, int n);
 /* diagnostic: the hand-off words of the fused iteration kernel (csrc/iter_fused.hip); returns the count copied */
