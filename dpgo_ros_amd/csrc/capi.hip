@@ -51,6 +51,8 @@ dpgo_team_t *dpgo_team_create(int device, const dpgo_params_t *p, int num_local,
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess) t->num_cus = cus;
     const char *e = std::getenv("DPGO_FUSED_ITER");
     if (e) t->use_fused = (e[0] == '1') ? 1 : 0;
+    const char *e2 = std::getenv("DPGO_FUSED_RTR");
+    if (e2) t->use_fused_rtr = (e2[0] == '0') ? 0 : 1;
     if (t->d_nest_all.alloc(std::max(1, num_local)) ||
         hipMemset(t->d_nest_all.p, 0, sizeof(NestState) * std::max(1, num_local)) != hipSuccess ||
         t->d_bar.alloc(ITER_BAR_WORDS) || hipMemset(t->d_bar.p, 0, sizeof(unsigned long long) * ITER_BAR_WORDS) != hipSuccess ||
@@ -87,6 +89,7 @@ int dpgo_team_num_local(const dpgo_team_t *t) { return (int)t->ag.size(); }
 void *dpgo_team_stream(dpgo_team_t *t) { return (void *)t->stream; }
 int dpgo_team_synchronize(dpgo_team_t *t) {
   HIPC(hipStreamSynchronize(t->stream));
+  for (auto &a : t->ag) if (a->opt_pending_rtr && refresh_rtr_result(t, *a)) return DPGO_ERR;
   if (t->h_bar_err && *t->h_bar_err) {
     *t->h_bar_err = 0;
     t->use_fused = 0;  // the grid was not resident at once on this device: two launches per iteration from now on
@@ -401,7 +404,7 @@ int dpgo_agent_get_status(dpgo_team_t *t, int id, dpgo_status_t *s) {
 int dpgo_agent_get_opt_result(dpgo_team_t *t, int id, dpgo_opt_result_t *r) {
   Agent *a = find_agent(t, id);
   if (!a) return DPGO_ERR;
-  if (refresh_rgd_result(t, *a)) return DPGO_ERR;
+  if (refresh_rtr_result(t, *a) || refresh_rgd_result(t, *a)) return DPGO_ERR;
   *r = a->opt;
   return DPGO_OK;
 }
@@ -1242,6 +1245,15 @@ int dpgo_team_import_peer(dpgo_team_t *t, int robot_id, const unsigned char *han
   return DPGO_OK;
 }
 
+// diagnostic: the hand-off words of an agent's one-launch RTR solve (phase timestamps in -DDPGO_RTR_TRACE builds)
+int dpgo_agent_read_rtr_handoff(dpgo_team_t *t, int id, unsigned long long *out, int n) {
+  Agent *a = find_agent(t, id);
+  if (!a || !a->d_rtr_bar.p) return DPGO_ERR;
+  HIPC(hipStreamSynchronize(t->stream));
+  HIPC(hipMemcpy(out, a->d_rtr_bar.p, sizeof(unsigned long long) * std::min(n, RTR_BAR_WORDS), hipMemcpyDeviceToHost));
+  return DPGO_OK;
+}
+
 // diagnostic: `n` doubles of an agent's partial-sum scratch starting at `offset` (phase timestamps of trace builds)
 int dpgo_agent_read_partials(dpgo_team_t *t, int id, int offset, double *out, int n) {
   Agent *a = find_agent(t, id);
@@ -1260,6 +1272,7 @@ int dpgo_team_read_handoff_state(dpgo_team_t *t, unsigned long long *out, int n)
 }
 
 int dpgo_team_get_counters(dpgo_team_t *t, double *out, int n) {
+  for (auto &a : t->ag) if (refresh_rtr_result(t, *a)) return DPGO_ERR;
   for (int k = 0; k < n && k < 8; ++k) out[k] = t->counters[k];
   return 0;
 }

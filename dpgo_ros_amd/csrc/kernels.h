@@ -71,6 +71,17 @@ bool iter_fused_eligible(int r, int max_n, const int *agent_n, int num_agents, i
 void launch_iter_rgd(const LaunchCtx &c, int max_n, NestState *nest_all, unsigned long long *bar, int *err, int first,
                      double step, int num_robots, int restart_interval, int ahead);
 
+// rtr_fused.hip: one launch per local RTR solve, the agent's preconditioner resident in LDS over the whole solve.
+// bar: RTR_BAR_WORDS zero-initialised 64-bit words owned by the AGENT (the arrival counts depend on its grid);
+// ws: RTR_WS_DOUBLES doubles of partial-sum scratch; err: pinned host word raised on a spin time-out.
+constexpr int RTR_BAR_WORDS = 18 * 16 + 160;
+constexpr int RTR_WS_DOUBLES = 7 * 256;
+bool rtr_fused_eligible(int r, int n, int num_cus);
+// cum: 4 zero-initialised 64-bit words per agent: running totals {solves, Hessian-vector products, preconditioner
+// applies, outer iterations} the kernel adds to
+int launch_rtr_solve(const LaunchCtx &c, int ai, int n, unsigned long long *bar, double *ws, unsigned long long *cum, int *err, double Delta0,
+                     double tol, int max_outer, int max_inner, double max_radius);
+
 // dense_inverse.hip: M = (A)^-1 for a symmetric positive definite N x N column-major matrix.
 // A is destroyed; work must hold N*N doubles.  Returns 0, or the (1-based) failing pivot block.
 int dense_spd_inverse(hipStream_t stream, double *A, double *work, double *M, int N);

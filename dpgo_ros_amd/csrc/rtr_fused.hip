@@ -1,0 +1,809 @@
+// rtr_fused.hip -- ONE launch per local RTR solve (QuadraticOptimizer::optimize with the
+// trust-region Newton method, Steihaug truncated CG preconditioned by the dense inverse).  A persistent kernel, one
+// workgroup per CU, that keeps the preconditioner ON CHIP:
+//   * workgroup b owns poses 2b, 2b+1 of the agent, i.e. 8 columns of M = (Q + shift I)^-1.  Its 8 x N4 slab of M
+//     (128 KB for a 500-pose agent; 32 MB over the grid) is read from HBM ONCE per solve into LDS and serves every
+//     preconditioner apply of every tCG iteration of every outer iteration from there.  The launch-per-step sequence
+//     streams the 32 MB once per tCG iteration (solve.hip: [init, (Hess-vec, step) x J, retract, evaluate, accept]
+//     patterns, each kernel 9-15 us, a quarter of them phase-gated no-ops);
+//   * all scalars of the solve (dots, alpha, beta, rho, radius, the phase) live in registers: every wave re-derives
+//     them from the same per-workgroup partial sums in the same order, so the control flow is uniform over the grid
+//     and the host reads ONE state record at the end;
+//   * workgroups exchange the vectors a phase needs from the others (delta, z, H delta, eta, the candidate point and
+//     its gradient) through write-through stores (agent-scope relaxed atomics = global_store sc1), a sharded-counter
+//     grid hand-off (cdna_hip_programming.md Guideline 16, R1 form; see iter_fused.hip) and L1-bypassing loads.
+// The arithmetic is that of the launch-per-step kernels (k_precond<TCG_INIT / TCG_STEP>, k_tcg_hv, k_retract,
+// k_rtr_eval2, k_rtr_accept); only the order in which the 2000 products of a preconditioner row are added differs.
+// Eligibility (rtr_fused_eligible): dense preconditioner, ceil(n / 2) <= CUs, slab + scratch <= 160 KB of LDS.
+// Larger agents, block-Jacobi agents and the colour-parallel group update keep the launch-per-step path.
+#include "kernel_common.h"
+
+namespace dpgo {
+
+constexpr int RB_LINE = 16;             // 64-bit words per 128-byte line
+constexpr int RB_TOP = 8 * RB_LINE;     // shard counters at g * RB_LINE
+constexpr int RB_GEN = 9 * RB_LINE;     // generation words at RB_GEN + g * RB_LINE
+constexpr int RB_EPOCH = 17 * RB_LINE;  // epoch of the last completed hand-off (carried across launches)
+constexpr int RB_ABORT = 17 * RB_LINE + 1;  // raised by a workgroup whose hand-off timed out: everybody leaves
+constexpr int RB_SPIN_LIMIT = 1 << 18;      // ~0.5 s of polling
+constexpr int RTR_WS_PITCH = 256;  // doubles per partial-sum array of the scratch (one entry per workgroup):
+                                   // [0] <delta, H delta>  [1] <z, r>  [2] <r, r>  [3..6] f, |grad|^2, <g, eta>, <eta, H eta>
+
+// optional per-phase timestamps of workgroup 0, wave 0 (build with -DDPGO_RTR_TRACE): bar[RB_TRACE + k]
+constexpr int RB_TRACE = 17 * RB_LINE + 2;
+#ifdef DPGO_RTR_TRACE
+#define RTR_STAMP(k) do { if (tid == 0 && bx == 0 && (k) < 60) bar[RB_TRACE + (k)] = wall_clock64(); } while (0)
+#define RTR_FINE(k) do { if (tid == 0 && bx == 0 && fine_on) bar[RB_TRACE + 64 + (k)] = wall_clock64(); } while (0)
+#else
+#define RTR_STAMP(k) do { } while (0)
+#define RTR_FINE(k) do { } while (0)
+#endif
+
+__device__ __forceinline__ double ld_c(const double *p) {
+  return __hip_atomic_load(const_cast<double *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#ifndef DPGO_RTR_PLAIN_ST
+#define DPGO_RTR_PLAIN_ST 0
+#endif
+#ifndef DPGO_RTR_PLAIN_LD
+#define DPGO_RTR_PLAIN_LD 0
+#endif
+__device__ __forceinline__ void st_c(double *p, double v) {
+#if DPGO_RTR_PLAIN_ST
+  *p = v;
+#else
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+
+// How a workgroup reads what the others published with st_c: buffer loads with sc1 (they bypass this CU's L1 and are
+// served by the L2 / the fabric), 8 or 16 bytes.  Ordinary loads to the compiler, so a batch of them is issued back
+// to back.  The descriptor must be wave-uniform (built from scalar pointers; a lane-dependent choice of buffer turns
+// every load into a waterfall loop).
+typedef unsigned int v4u_t __attribute__((ext_vector_type(4)));
+typedef unsigned int v2u_t __attribute__((ext_vector_type(2)));
+struct CVec {
+  __amdgpu_buffer_rsrc_t rs;
+  __device__ __forceinline__ CVec(const double *p, int count)
+      : rs(__builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(p), 0, count * 8, 0x00020000)) {}
+  __device__ __forceinline__ double ld(int i) const {
+    const v2u_t r = __builtin_amdgcn_raw_buffer_load_b64(rs, i * 8, 0, DPGO_RTR_PLAIN_LD ? 0 : 16);
+    double d;
+    __builtin_memcpy(&d, &r, 8);
+    return d;
+  }
+  __device__ __forceinline__ double2 ld2(int i) const {
+    const v4u_t r = __builtin_amdgcn_raw_buffer_load_b128(rs, i * 8, 0, DPGO_RTR_PLAIN_LD ? 0 : 16);
+    double2 d;
+    __builtin_memcpy(&d, &r, 16);
+    return d;
+  }
+};
+
+#define WSYNC()                                                  \
+  do {                                                           \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       \
+    __builtin_amdgcn_wave_barrier();                             \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       \
+  } while (0)
+
+struct GridBar {
+  unsigned long long *bar;
+  unsigned long long epoch;
+  int g, size_g, ngroups;
+  int *err;
+  int *ok;  // LDS word: 0 once this workgroup's hand-off timed out
+};
+
+// every workgroup of the launch arrives, every workgroup leaves after the last arrival.  Callers publish with st_c
+// (write-through) and read the others' data with CVec loads afterwards.  Returns false when the hand-off timed out:
+// the grid is not resident at once (another process holds CUs with a persistent kernel of its own).  That can only
+// happen at the FIRST hand-off of a launch -- once it completes, every workgroup is resident for good -- and before
+// it nothing but scratch has been written, so the caller leaves, the workgroups that start later find the abort word
+// and leave too, and the host repeats the solve with the launch-per-step kernels.
+__device__ __forceinline__ bool grid_sync(GridBar &gb, unsigned long long *tr = nullptr) {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // every wave: its write-through stores have left the CU
+  if (tr && threadIdx.x == 0) tr[0] = wall_clock64();
+  __syncthreads();
+  if (tr && threadIdx.x == 0) tr[1] = wall_clock64();
+  gb.epoch += 1ull;
+  if (threadIdx.x == 0) {
+#if DPGO_RTR_PLAIN_ST
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    const unsigned long long old =
+        __hip_atomic_fetch_add(&gb.bar[gb.g * RB_LINE], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old + 1ull == (unsigned long long)gb.size_g * gb.epoch) {
+      const unsigned long long old2 =
+          __hip_atomic_fetch_add(&gb.bar[RB_TOP], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (old2 + 1ull == (unsigned long long)gb.ngroups * gb.epoch) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          __hip_atomic_store(&gb.bar[RB_GEN + q * RB_LINE], gb.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if (tr) tr[2] = wall_clock64();
+    int spins = 0;
+    while (__hip_atomic_load(&gb.bar[RB_GEN + gb.g * RB_LINE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gb.epoch) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > RB_SPIN_LIMIT) {
+        *gb.err = 2;
+        *gb.ok = 0;
+        __hip_atomic_store(&gb.bar[RB_ABORT], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+    if (tr) tr[3] = wall_clock64();
+#if DPGO_RTR_PLAIN_LD
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+  }
+  __syncthreads();
+  return *gb.ok != 0;
+}
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_quad(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
+// wave-wide sum on the DPP path (quad swaps, half-row and row mirrors, then the four row totals read back as
+// wave-uniform values and added in row order): ~0.1 us where the ds_bpermute butterfly of wave_sum costs 0.6 with one
+// wave per SIMD.  Every lane receives the same, wave-uniform result.
+__device__ __forceinline__ double wave_sum_u(double x) {
+  x += dpp_quad<0xB1>(x);   // quad_perm [1,0,3,2]
+  x += dpp_quad<0x4E>(x);   // quad_perm [2,3,0,1]
+  x += dpp_quad<0x141>(x);  // row_half_mirror
+  x += dpp_quad<0x140>(x);  // row_mirror: every lane of a 16-lane row holds the row total
+  const int lo = __double2loint(x), hi = __double2hiint(x);
+  double r[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    r[q] = __hiloint2double(__builtin_amdgcn_readlane(hi, 16 * q), __builtin_amdgcn_readlane(lo, 16 * q));
+  return (r[0] + r[1]) + (r[2] + r[3]);
+}
+
+// sum of `count` contiguous partials published by the workgroups of THIS launch, same order in every wave
+template <int NA>
+__device__ __forceinline__ void csum_issue(const CVec &ws, int first, int count, int lane, double (*v)[4]) {
+  // straight-line (a predicated load is waited for on its own): entries beyond `count` re-read the last one, times 0
+#pragma unroll
+  for (int q = 0; q < NA; ++q)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[q][u] = ws.ld((first + q) * RTR_WS_PITCH + min(lane + 64 * u, count - 1));
+}
+template <int NA>
+__device__ __forceinline__ void csum_finish(double (*v)[4], int count, int lane, double *out) {
+#pragma unroll
+  for (int q = 0; q < NA; ++q) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[q][u] *= (lane + 64 * u < count) ? 1.0 : 0.0;
+    out[q] = wave_sum_u((v[q][0] + v[q][1]) + (v[q][2] + v[q][3]));
+  }
+}
+
+// zs[c * R + a] = sum_k V[k][a] * Ms[c][k]  for the 8 columns of the slab: lane t takes rows 2t, 2t+1 (+512 m) of V
+// for ALL 8 columns, so every row of V is fetched once per workgroup (16-byte L1-bypassing loads straight from L2,
+// no LDS staging) and the slab is read from LDS exactly once.  The 256 per-lane sums go through a quad reduction
+// (DPP) and 64 LDS rows added in row order by one lane per output.  The result is valid in wave 0 on return.
+constexpr int SLAB_MAXM = 4;
+// straight-line code: rows beyond N4 read row N4 - 2 again and are multiplied by zero (one wave per SIMD: nothing
+// hides a wait, so every load of a step is in flight before the first FMA)
+template <int R>
+__device__ __forceinline__ void slab_issue(int N4, const CVec &V, int tid, double2 (*v)[R]) {
+#pragma unroll
+  for (int m = 0; m < SLAB_MAXM; ++m) {
+    const int k = 2 * tid + 512 * m, kk = min(k, N4 - 2);
+#pragma unroll
+    for (int q = 0; q < R; ++q) v[m][q] = V.ld2(kk * R + 2 * q);
+  }
+}
+template <int R>
+__device__ __forceinline__ void slab_finish(const double *Ms, int N4, double2 (*v)[R], double *red, double *zs, int tid) {
+  constexpr int MAXM = SLAB_MAXM;
+  double acc[8][R];
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int a = 0; a < R; ++a) acc[c][a] = 0.0;
+#pragma unroll
+  for (int m = 0; m < MAXM; ++m) {
+    const int k = 2 * tid + 512 * m, kk = min(k, N4 - 2);
+    const double live = (k < N4) ? 1.0 : 0.0;
+    double2 mm[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) mm[c] = *reinterpret_cast<const double2 *>(&Ms[(size_t)c * N4 + kk]);
+    double w[2 * R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) { w[2 * q] = v[m][q].x * live; w[2 * q + 1] = v[m][q].y * live; }
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+      for (int a = 0; a < R; ++a) acc[c][a] += w[a] * mm[c].x + w[R + a] * mm[c].y;
+  }
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int a = 0; a < R; ++a) {
+      double x = acc[c][a];
+      x += dpp_quad<0xB1>(x);  // lanes ^ 1
+      x += dpp_quad<0x4E>(x);  // lanes ^ 2
+      acc[c][a] = x;
+    }
+  if ((lane & 3) == 0) {
+    double *row = red + (size_t)(wave * 16 + (lane >> 2)) * (8 * R + 1);
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+      for (int a = 0; a < R; ++a) row[c * R + a] = acc[c][a];
+  }
+  __syncthreads();
+  if (tid < 8 * R) {
+    double t[64];
+#pragma unroll
+    for (int q = 0; q < 64; ++q) t[q] = red[q * (8 * R + 1) + tid];
+    double s = 0;
+#pragma unroll
+    for (int q = 0; q < 64; ++q) s += t[q];
+    zs[tid] = s;
+  }
+  if (tid < 64) WSYNC();
+}
+
+// spmm_row (kernel_common.h) for a pose whose first <= 8 ELL slots (index + 4 x 4 block) sit in LDS: every gather of
+// the row is requested before the first use -- one round trip for the whole row instead of index -> gather per group
+// of four slots.  Rows longer than the cached slots continue in the CSR tail from global memory.
+constexpr int RTR_SLOTS = 8;
+
+// RtrState without the array member: every field is a scalar the compiler keeps in registers (the tcg_o[] array of
+// RtrState, indexed by the outer iteration, forced the whole record into scratch memory: 210 scratch accesses on the
+// scalar path of every phase)
+struct SolveState {
+  double f1, ngf, Delta;
+  double z_r, d_Pd, e_Pd, e_Pe, norm_r0, alpha;
+  double f_init, gn_init;
+  int outer_it, outer_done, tcg_active, tcg_j, tcg_status, need_init;
+  int hv_count, pc_count, tcg_total, accepted, outer_count;
+  int o0, o1, o2, o3;
+};
+__device__ __forceinline__ RtrState to_record(const SolveState &S) {
+  RtrState T = {};
+  T.f1 = S.f1; T.ngf = S.ngf; T.Delta = S.Delta;
+  T.z_r = S.z_r; T.d_Pd = S.d_Pd; T.e_Pd = S.e_Pd; T.e_Pe = S.e_Pe; T.norm_r0 = S.norm_r0; T.alpha = S.alpha;
+  T.f_init = S.f_init; T.gn_init = S.gn_init;
+  T.outer_it = S.outer_it; T.outer_done = S.outer_done; T.tcg_active = S.tcg_active; T.tcg_j = S.tcg_j;
+  T.tcg_status = S.tcg_status; T.need_init = S.need_init;
+  T.hv_count = S.hv_count; T.pc_count = S.pc_count; T.tcg_total = S.tcg_total; T.accepted = S.accepted;
+  T.outer_count = S.outer_count;
+  T.tcg_o[0] = S.o0; T.tcg_o[1] = S.o1; T.tcg_o[2] = S.o2; T.tcg_o[3] = S.o3;
+  return T;
+}
+template <int NRAW, class Ld>
+__device__ __forceinline__ void gather_issue(const int *idxL, Ld ld, double (*raw)[NRAW][4]) {
+  // straight-line: slots the matrix does not have are cached as (own pose, zero block)
+  int idx[RTR_SLOTS];
+#pragma unroll
+  for (int u = 0; u < RTR_SLOTS; ++u) idx[u] = idxL[u];
+#pragma unroll
+  for (int u = 0; u < RTR_SLOTS; ++u) ld(idx[u], raw[u]);
+}
+// ld: pose index -> NRAW x 4 raw operands (row a of the pose); comb: raw operands -> the NV input vectors
+template <int R, int NV, int NRAW, class Ld, class Comb>
+__device__ __forceinline__ void spmm_row_finish(const AgentDev &ag, int j, const double *BL, double (*raw)[NRAW][4], Ld ld,
+                                                Comb comb, double (*acc)[4]) {
+  double x[RTR_SLOTS][NV][4];
+#pragma unroll
+  for (int u = 0; u < RTR_SLOTS; ++u) comb(raw[u], x[u]);
+  auto src = [&](int i, double(*xo)[4]) {
+    double rr[NRAW][4];
+    ld(i, rr);
+    comb(rr, xo);
+  };
+#pragma unroll
+  for (int u = 0; u < RTR_SLOTS; ++u) {
+    const double *B = BL + 16 * u;
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        acc[v][c] += x[u][v][0] * B[4 * c] + x[u][v][1] * B[4 * c + 1] + x[u][v][2] * B[4 * c + 2] + x[u][v][3] * B[4 * c + 3];
+  }
+  for (int s0 = RTR_SLOTS; s0 < ag.ell_w; s0 += 4) ell_group<R, NV>(ag, j, s0, src, acc);
+  const int p0 = ag.trowptr[j], p1 = ag.trowptr[j + 1];
+  for (int p = p0; p < p1; ++p) {
+    const int i = ag.tcol[p];
+    const double *bp = ag.tval + (size_t)16 * p;
+    double xt[NV][4];
+    src(i, xt);
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const double2 b01 = ld2(bp + 4 * c), b23 = ld2(bp + 4 * c + 2);
+        acc[v][c] += xt[v][0] * b01.x + xt[v][1] * b01.y + xt[v][2] * b23.x + xt[v][3] * b23.y;
+      }
+  }
+}
+
+// hess_tail (kernel_common.h) for lanes of ONE wave
+template <int R>
+__device__ __forceinline__ void hess_tail_w(const double *Ysh, const double *Esh, double *Wsh, int a, const double wrow[4],
+                                            const double vrow[4], double hrow[4], bool act) {
+  if (act) {
+    double S[9];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        double s = 0;
+#pragma unroll
+        for (int b = 0; b < R; ++b) s += Ysh[p * R + b] * Esh[q * R + b];
+        S[3 * p + q] = s;
+      }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      double s = wrow[q];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) s -= vrow[p] * 0.5 * (S[3 * p + q] + S[3 * q + p]);
+      Wsh[q * R + a] = s;
+    }
+  }
+  WSYNC();
+  if (act) {
+    double o[3];
+    tangent_row<R>(Ysh, Wsh, a, o);
+    hrow[0] = o[0]; hrow[1] = o[1]; hrow[2] = o[2]; hrow[3] = wrow[3];
+  }
+  WSYNC();
+}
+
+
+template <int R>
+__global__ __launch_bounds__(256) void k_rtr_solve(const AgentDev *agents, int ai, unsigned long long *bar, double *ws,
+                                                   unsigned long long *cum, int *err, double Delta0, double tol, int max_outer, int max_inner,
+                                                   double max_radius) {
+  extern __shared__ double Ms[];  // [8][N4]: this workgroup's columns of M
+  __shared__ double red[64 * (8 * R + 1)];
+  // own two poses, [pose][component c][row a]: X, Euclidean / Riemannian gradient at X; tCG residual, z, delta, eta;
+  // scratch; candidate point and its gradients
+  __shared__ double zs[8 * R], Xs[8 * R], Es[8 * R], Gs[8 * R], Rs[8 * R], Zo[8 * R], Ds[8 * R], Et[8 * R], Ws[8 * R],
+      X2s[8 * R], E2s[8 * R], G2s[8 * R];
+  __shared__ double BL[2 * RTR_SLOTS * 16];  // the first ELL slots of the own two poses: 4 x 4 blocks and indices
+  __shared__ int idxL[2 * RTR_SLOTS];
+  const AgentDev &ag = agents[ai];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bx = (int)blockIdx.x, N4 = ag.N4, n = ag.n;
+  const int nblk = (n + 1) / 2;  // == gridDim.x
+  const int npose = min(2, n - 2 * bx);
+  const int lp = tid / R, a = tid - lp * R;
+  const bool rl = tid < npose * R;  // row lanes: one per (own pose, row of the lifted pose), all in wave 0
+  const int j = 2 * bx + lp;
+  double *wsA = ws, *wsB0 = ws + RTR_WS_PITCH, *wsB1 = ws + 2 * RTR_WS_PITCH, *wsC = ws + 3 * RTR_WS_PITCH;
+
+  // ---- trust-region set-up from the partial sums of the evaluation launched in front (k_rtr_begin)
+  SolveState S = {};
+  {
+    const int nb = spmm_blocks<R>(n);
+    const double f = sum_partials(ag.part + PART_A, nb, PART_STRIDE, lane);
+    const double g = sum_partials(ag.part + PART_A + 1, nb, PART_STRIDE, lane);
+    S.f1 = f; S.ngf = sqrt(g); S.Delta = Delta0;
+    S.f_init = f; S.gn_init = S.ngf;
+    S.outer_done = (S.ngf < tol) || (max_outer <= 0);
+    S.need_init = 1;
+  }
+  if (S.outer_done) {
+    if (bx == 0 && tid == 0) { const RtrState T = to_record(S); ag.st[0] = T; ag.st[1] = T; cum[0] += 1ull; }
+    return;
+  }
+  __shared__ int bar_ok;
+  if (tid == 0) bar_ok = __hip_atomic_load(&bar[RB_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0ull;
+  __syncthreads();
+  if (!bar_ok) return;  // a workgroup of this launch gave up before this one started
+  GridBar gb;
+  gb.bar = bar; gb.err = err; gb.ok = &bar_ok;
+  gb.epoch = bar[RB_EPOCH];
+  gb.g = bx & 7;
+  gb.size_g = (nblk - gb.g + 7) / 8;
+  gb.ngroups = min(8, nblk);
+#ifdef DPGO_RTR_TRACE
+  if (tid == 0 && bx == 0) for (int k = 0; k < 60; ++k) bar[RB_TRACE + k] = 0ull;
+#endif
+  RTR_STAMP(0);
+
+  // ---- the slab: 8 contiguous columns of M, HBM -> LDS, once
+  {
+    const int tot2 = 2 * npose * N4;  // double2 elements of the valid columns
+    const double *Msrc = ag.M + (size_t)8 * bx * N4;
+    for (int i0 = 0; i0 < 4 * N4; i0 += 256 * 8) {
+      double2 t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + tid + 256 * u;
+        t[u] = (i < tot2) ? ld2_nt(Msrc + 2 * (size_t)i) : make_double2(0.0, 0.0);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + tid + 256 * u;
+        if (i < 4 * N4) *reinterpret_cast<double2 *>(&Ms[2 * (size_t)i]) = t[u];
+      }
+    }
+  }
+  if (rl) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const size_t o = ((size_t)4 * j + c) * R + a;
+      const int idx = lp * 4 * R + c * R + a;
+      Xs[idx] = ag.buf[B_X][o];
+      Es[idx] = ag.buf[B_EGRAD][o];
+      Gs[idx] = ag.buf[B_GF][o];
+    }
+  }
+  const int Wc = min(ag.ell_w, RTR_SLOTS);
+  static_assert(2 * RTR_SLOTS * 16 == 256, "one thread per cached block element");
+  {
+    const int q = tid, pl = q / (RTR_SLOTS * 16), u = (q / 16) % RTR_SLOTS, e = q % 16;
+    const int jj = min(2 * bx + pl, n - 1);
+    const bool have = pl < npose && u < Wc;
+    BL[q] = have ? ag.ell_val[((size_t)u * n + jj) * 16 + e] : 0.0;
+    if (e == 0) idxL[pl * RTR_SLOTS + u] = have ? ag.ell_col[(size_t)u * n + jj] : jj;
+  }
+  __syncthreads();
+  RTR_STAMP(1);
+  int stamp = 2;
+  (void)stamp;
+  bool fine_on = false;
+  (void)fine_on;
+
+  double *Zg = ag.buf[B_Z], *HDg = ag.buf[B_HD], *ETAg = ag.buf[B_ETA], *X2g = ag.buf[B_X2], *GFg = ag.buf[B_GF];
+  const int NV8 = N4 * R;
+  const CVec cGF(GFg, NV8), cHD(HDg, NV8), cX2(X2g, NV8), cETA(ETAg, NV8), cWS(ws, RTR_WS_PITCH * 7);
+  const double kappa = 0.1;  // tCG stop: |r| <= |r0| min(|r0|^theta, kappa) with theta = 1
+
+  while (true) {
+    // ================= tCG set-up (k_precond<PM_TCG_INIT>): z0 = P(gf M), r0 = gf, eta = 0, delta0 = -z0
+    {
+      double2 vv[SLAB_MAXM][R];
+      slab_issue<R>(N4, cGF, tid, vv);
+      slab_finish<R>(Ms, N4, vv, red, zs, tid);
+    }
+    {
+      double zr = 0, rr = 0;
+      if (rl) {
+        double z[4];
+        tangent_row<R>(Xs + lp * 4 * R, zs + lp * 4 * R, a, z);
+        z[3] = zs[lp * 4 * R + 3 * R + a];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const size_t o = ((size_t)4 * j + c) * R + a;
+          const int idx = lp * 4 * R + c * R + a;
+          const double v = Gs[idx];
+          Rs[idx] = v; Et[idx] = 0.0; Ds[idx] = -z[c]; Zo[idx] = z[c];
+          st_c(ag.buf[B_D0] + o, -z[c]);
+          st_c(Zg + o, z[c]);
+          zr += z[c] * v;
+          rr += v * v;
+        }
+      }
+      if (wave == 0) {
+        zr = wave_sum_u(zr); rr = wave_sum_u(rr);
+        if (lane == 0) { st_c(wsB0 + bx, zr); st_c(wsB1 + bx, rr); }
+      }
+    }
+    S.tcg_active = 1; S.tcg_j = 0; S.tcg_status = 0; S.need_init = 0;
+    S.e_Pd = 0; S.e_Pe = 0; S.alpha = 0;
+    S.pc_count += 1; S.outer_count += 1;
+    if (!grid_sync(gb)) return;
+    RTR_STAMP(stamp++);
+
+    // ================= tCG iterations
+    while (true) {
+      // ---- part 1 (k_tcg_hv): delta <- -z + beta delta, H delta on the own poses, partial <delta, H delta>
+#ifdef DPGO_RTR_TRACE
+      fine_on = (S.outer_it == 0 && S.tcg_j == 1);
+#endif
+      RTR_FINE(0);
+      // the partial sums and (speculatively: the stop test needs the sums) the neighbour rows of z and delta are
+      // requested together -- one round trip to what the other workgroups just published instead of two
+      const bool fresh = __builtin_amdgcn_readfirstlane(S.tcg_j) == 0;
+      const int jp = __builtin_amdgcn_readfirstlane(S.tcg_j) & 1;
+      const double *Dold = ag.buf[jp ? B_D0 : B_D1];  // delta of iteration j-1
+      double *Dnew = ag.buf[jp ? B_D1 : B_D0];        // delta of iteration j (the set-up wrote D0 for j = 0)
+      // fresh: delta_0 as the set-up published it; else -z + beta delta_{j-1} (the owner's own expression)
+      const CVec cA(fresh ? Dnew : Zg, NV8), cB(fresh ? Dnew : Dold, NV8);
+      auto ldA = [&](int i, double(*rw)[4]) {
+#pragma unroll
+        for (int cp = 0; cp < 4; ++cp) {
+          const int o = (4 * i + cp) * R + a;
+          rw[0][cp] = cA.ld(o);
+          rw[1][cp] = cB.ld(o);
+        }
+      };
+      double sv[2][4], sb[2];
+      csum_issue<2>(cWS, 1, nblk, lane, sv);
+      double rawA[RTR_SLOTS][2][4];
+      if (wave == 0) gather_issue<2>(idxL + min(lp, 1) * RTR_SLOTS, ldA, rawA);
+      csum_finish<2>(sv, nblk, lane, sb);
+      const double zr_new = sb[0], rr_new = sb[1];
+      RTR_FINE(1);
+      double beta = 0;
+      if (fresh) {
+        S.z_r = zr_new; S.d_Pd = zr_new; S.norm_r0 = sqrt(rr_new);
+      } else {
+        const double nr = sqrt(rr_new), thr = S.norm_r0;
+        bool stop = false;
+        if (nr <= S.norm_r0 * (thr < kappa ? thr : kappa)) { S.tcg_status = (kappa < thr) ? 3 : 4; stop = true; }
+        else if (S.tcg_j >= max_inner) { S.tcg_status = 0; stop = true; }
+        if (stop) { S.tcg_active = 0; break; }
+        beta = zr_new / S.z_r;
+        S.e_Pd = beta * (S.e_Pd + S.alpha * S.d_Pd);
+        S.d_Pd = zr_new + beta * beta * S.d_Pd;
+        S.z_r = zr_new;
+      }
+      S.hv_count += 1; S.tcg_total += 1;
+      if (wave == 0) {
+        double w[1][4] = {{0, 0, 0, 0}}, vrow[4] = {0, 0, 0, 0}, hrow[4] = {0, 0, 0, 0};
+        if (rl) {
+          spmm_row_finish<R, 1, 2>(ag, j, BL + lp * RTR_SLOTS * 16, rawA, ldA,
+            [&](double(*rw)[4], double(*x)[4]) {
+#pragma unroll
+              for (int cp = 0; cp < 4; ++cp) x[0][cp] = fresh ? rw[1][cp] : (-rw[0][cp] + beta * rw[1][cp]);
+            }, w);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const size_t o = ((size_t)4 * j + c) * R + a;
+            const int idx = lp * 4 * R + c * R + a;
+            vrow[c] = fresh ? Ds[idx] : (-Zo[idx] + beta * Ds[idx]);
+            if (!fresh) { Ds[idx] = vrow[c]; st_c(Dnew + o, vrow[c]); }
+          }
+        }
+        RTR_FINE(2);
+        hess_tail_w<R>(Xs + lp * 4 * R, Es + lp * 4 * R, Ws + lp * 4 * R, a, w[0], vrow, hrow, rl);
+        RTR_FINE(3);
+        double d = 0;
+        if (rl) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const size_t o = ((size_t)4 * j + c) * R + a;
+            st_c(HDg + o, hrow[c]);
+            Ws[lp * 4 * R + c * R + a] = hrow[c];  // own rows of H delta for the residual update below
+            d += vrow[c] * hrow[c];
+          }
+        }
+        d = wave_sum_u(d);
+        if (lane == 0) st_c(wsA + bx, d);
+      }
+      RTR_FINE(4);
+#ifdef DPGO_RTR_TRACE
+      if (!grid_sync(gb, (bx == 0 && fine_on) ? bar + RB_TRACE + 64 + 5 : nullptr)) return;
+#else
+      if (!grid_sync(gb)) return;
+#endif
+      RTR_FINE(9);
+      RTR_STAMP(stamp++);
+
+      // ---- part 2 (k_precond<PM_TCG_STEP>): alpha, boundary test, eta += alpha delta, r += alpha H delta,
+      //      z += alpha P(H delta M)
+      double sv1[1][4], d_Hd;
+      csum_issue<1>(cWS, 0, nblk, lane, sv1);
+      double2 vv[SLAB_MAXM][R];
+      slab_issue<R>(N4, cHD, tid, vv);  // (speculative: the boundary test below needs the sum)
+      csum_finish<1>(sv1, nblk, lane, &d_Hd);
+      RTR_FINE(10);
+      const double alpha = S.z_r / d_Hd;
+      const double e_Pe_new = S.e_Pe + 2.0 * alpha * S.e_Pd + alpha * alpha * S.d_Pd;
+      if (d_Hd <= 0 || e_Pe_new >= S.Delta * S.Delta) {
+        const double tau = (-S.e_Pd + sqrt(S.e_Pd * S.e_Pd + S.d_Pd * (S.Delta * S.Delta - S.e_Pe))) / S.d_Pd;
+        S.tcg_active = 0;
+        S.tcg_status = (d_Hd <= 0) ? 1 : 2;
+        if (rl) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) { const int idx = lp * 4 * R + c * R + a; Et[idx] += tau * Ds[idx]; }
+        }
+        break;
+      }
+      S.e_Pe = e_Pe_new; S.alpha = alpha; S.tcg_j += 1; S.pc_count += 1;
+      slab_finish<R>(Ms, N4, vv, red, zs, tid);
+      RTR_FINE(11);
+      {
+        double zr = 0, rr = 0;
+        if (rl) {
+          double z[4];
+          tangent_row<R>(Xs + lp * 4 * R, zs + lp * 4 * R, a, z);
+          z[3] = zs[lp * 4 * R + 3 * R + a];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const size_t o = ((size_t)4 * j + c) * R + a;
+            const int idx = lp * 4 * R + c * R + a;
+            Et[idx] += alpha * Ds[idx];
+            const double v = Rs[idx] + alpha * Ws[idx];
+            Rs[idx] = v;
+            const double zn = Zo[idx] + alpha * z[c];
+            Zo[idx] = zn;
+            st_c(Zg + o, zn);
+            zr += zn * v;
+            rr += v * v;
+          }
+        }
+        if (wave == 0) {
+          zr = wave_sum_u(zr); rr = wave_sum_u(rr);
+          if (lane == 0) { st_c(wsB0 + bx, zr); st_c(wsB1 + bx, rr); }
+        }
+      }
+      RTR_FINE(12);
+#ifdef DPGO_RTR_TRACE
+      if (!grid_sync(gb, (bx == 0 && fine_on) ? bar + RB_TRACE + 64 + 13 : nullptr)) return;
+#else
+      if (!grid_sync(gb)) return;
+#endif
+      RTR_FINE(17);
+      RTR_STAMP(stamp++);
+    }
+
+    // ================= candidate point (k_retract): X2 = Retr_X(eta) on the own poses, eta published
+    if (wave == 0) {
+      WSYNC();
+      if (tid < npose) {
+        double x[4 * R];
+#pragma unroll
+        for (int i = 0; i < 4 * R; ++i) x[i] = Xs[tid * 4 * R + i] + Et[tid * 4 * R + i];
+        qf_inplace<R>(x);
+#pragma unroll
+        for (int i = 0; i < 4 * R; ++i) X2s[tid * 4 * R + i] = x[i];
+      }
+      WSYNC();
+      if (rl) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const size_t o = ((size_t)4 * j + c) * R + a;
+          const int idx = lp * 4 * R + c * R + a;
+          st_c(X2g + o, X2s[idx]);
+          st_c(ETAg + o, Et[idx]);
+        }
+      }
+    }
+    if (!grid_sync(gb)) return;
+    RTR_STAMP(stamp++);
+
+    // ================= cost and gradient at X2, model decrease (k_rtr_eval2)
+    if (wave == 0) {
+      double fpart = 0, gpart = 0, ge = 0, eh = 0;
+      double acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, vrow[4] = {0, 0, 0, 0}, hrow[4] = {0, 0, 0, 0}, eg[4] = {0, 0, 0, 0};
+      if (rl) {
+        auto ldE = [&](int i, double(*rw)[4]) {
+#pragma unroll
+          for (int cp = 0; cp < 4; ++cp) {
+            const int o = (4 * i + cp) * R + a;
+            rw[0][cp] = cX2.ld(o);
+            rw[1][cp] = cETA.ld(o);
+          }
+        };
+        double rawE[RTR_SLOTS][2][4];
+        gather_issue<2>(idxL + lp * RTR_SLOTS, ldE, rawE);
+        spmm_row_finish<R, 2, 2>(ag, j, BL + lp * RTR_SLOTS * 16, rawE, ldE,
+          [&](double(*rw)[4], double(*x)[4]) {
+#pragma unroll
+            for (int cp = 0; cp < 4; ++cp) { x[0][cp] = rw[0][cp]; x[1][cp] = rw[1][cp]; }
+          }, acc);
+        const bool pub = ag.pub_index[j] >= 0;
+        const double *G = ag.buf[B_G] + (size_t)j * 4 * R;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int idx = lp * 4 * R + c * R + a;
+          const double xr = X2s[idx], g = pub ? G[c * R + a] : 0.0;
+          fpart += (0.5 * acc[0][c] + g) * xr;
+          eg[c] = acc[0][c] + g;
+          E2s[idx] = eg[c];
+          Ws[idx] = eg[c];
+        }
+      }
+      WSYNC();
+      if (rl) {
+        double o3[3];
+        tangent_row<R>(X2s + lp * 4 * R, Ws + lp * 4 * R, a, o3);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { G2s[lp * 4 * R + c * R + a] = o3[c]; gpart += o3[c] * o3[c]; }
+        G2s[lp * 4 * R + 3 * R + a] = eg[3];
+        gpart += eg[3] * eg[3];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) vrow[c] = Et[lp * 4 * R + c * R + a];
+      }
+      WSYNC();
+      hess_tail_w<R>(Xs + lp * 4 * R, Es + lp * 4 * R, Ws + lp * 4 * R, a, acc[1], vrow, hrow, rl);
+      if (rl) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          ge += Gs[lp * 4 * R + c * R + a] * vrow[c];
+          eh += vrow[c] * hrow[c];
+        }
+      }
+      fpart = wave_sum_u(fpart); gpart = wave_sum_u(gpart); ge = wave_sum_u(ge); eh = wave_sum_u(eh);
+      if (lane == 0) {
+        st_c(wsC + bx, fpart); st_c(wsC + RTR_WS_PITCH + bx, gpart);
+        st_c(wsC + 2 * RTR_WS_PITCH + bx, ge); st_c(wsC + 3 * RTR_WS_PITCH + bx, eh);
+      }
+    }
+    if (!grid_sync(gb)) return;
+    RTR_STAMP(stamp++);
+
+    // ================= acceptance test and radius update (k_rtr_accept; ROPTLIB SolversTR constants)
+    {
+      double sv4[4][4], sc[4];
+      csum_issue<4>(cWS, 3, nblk, lane, sv4);
+      csum_finish<4>(sv4, nblk, lane, sc);
+      const double f2 = sc[0], g2 = sc[1], ge = sc[2], eh = sc[3];
+      const double rho = (S.f1 - f2) / (-ge - 0.5 * eh);
+      const bool accept = rho > 0.1;
+      if (rho > 0.75) {
+        if (S.tcg_status == 1 || S.tcg_status == 2) S.Delta = fmin(2.0 * S.Delta, max_radius);
+      } else if (rho < 0.25) {
+        S.Delta = 0.25 * S.Delta;
+      }
+      if (accept) { S.f1 = f2; S.ngf = sqrt(g2); S.accepted += 1; }
+      S.hv_count += 1;
+      {
+        const int took = S.tcg_j + 1;
+        if (S.outer_it == 0) S.o0 = took; else if (S.outer_it == 1) S.o1 = took;
+        else if (S.outer_it == 2) S.o2 = took; else if (S.outer_it == 3) S.o3 = took;
+      }
+      S.outer_it += 1;
+      S.outer_done = (S.outer_it >= max_outer) || (S.ngf < tol);
+      S.tcg_active = 0;
+      S.need_init = 1;
+      if (accept && rl) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const size_t o = ((size_t)4 * j + c) * R + a;
+          const int idx = lp * 4 * R + c * R + a;
+          Xs[idx] = X2s[idx]; Es[idx] = E2s[idx]; Gs[idx] = G2s[idx];
+          ag.buf[B_X][o] = X2s[idx];
+          ag.buf[B_EGRAD][o] = E2s[idx];
+          st_c(GFg + o, G2s[idx]);
+        }
+      }
+    }
+    if (S.outer_done) break;
+    if (!grid_sync(gb)) return;  // the next set-up pulls the whole new gradient through every workgroup
+    RTR_STAMP(stamp++);
+  }
+  if (bx == 0 && tid == 0) {
+    const RtrState T = to_record(S);
+    ag.st[0] = T; ag.st[1] = T;
+    bar[RB_EPOCH] = gb.epoch;
+    // running totals of this agent's solves: the host reads them (and the record) whenever it next synchronises
+    cum[0] += 1ull; cum[1] += (unsigned long long)S.hv_count; cum[2] += (unsigned long long)S.pc_count;
+    cum[3] += (unsigned long long)S.outer_count;
+  }
+}
+
+static size_t rtr_static_lds(int r) {
+  return sizeof(double) * ((size_t)64 * (8 * r + 1) + 12 * 8 * r + 2 * RTR_SLOTS * 16) + sizeof(int) * 2 * RTR_SLOTS + 256;
+}
+
+bool rtr_fused_eligible(int r, int n, int num_cus) {
+  if (n < 1 || (n + 1) / 2 > num_cus || (n + 1) / 2 > RTR_WS_PITCH || 4 * n > 2048) return false;
+  return (size_t)64 * 4 * n + rtr_static_lds(r) <= (size_t)160 * 1024;
+}
+
+int launch_rtr_solve(const LaunchCtx &c, int ai, int n, unsigned long long *bar, double *ws, unsigned long long *cum, int *err, double Delta0,
+                     double tol, int max_outer, int max_inner, double max_radius) {
+  const size_t dyn = (size_t)64 * 4 * n;  // 8 columns x N4 doubles
+  hipError_t e = hipSuccess;
+  DPGO_DISPATCH_R(c.r, {
+    static bool configured = false;
+    if (!configured) {
+      e = hipFuncSetAttribute((const void *)k_rtr_solve<R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)rtr_static_lds(R));
+      configured = (e == hipSuccess);
+    }
+    if (e == hipSuccess)
+      hipLaunchKernelGGL(k_rtr_solve<R>, dim3((n + 1) / 2), dim3(256), dyn, c.stream, c.agents, ai, bar, ws, cum, err, Delta0, tol,
+                         max_outer, max_inner, max_radius);
+  });
+  return e == hipSuccess ? 0 : -1;
+}
+
+}  // namespace dpgo

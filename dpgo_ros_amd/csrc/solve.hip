@@ -82,7 +82,6 @@ int enqueue_optimize(dpgo_team *t, int sel, const OptFlags &fl) {
   // ---- RTR: trust-region Newton with truncated CG; scalars stay on the device
   Agent &a = *t->ag[sel];
   launch_eval(c, sel, mn, B_X, B_EGRAD, B_GF, PART_A, eval_opts(t, gmode, fl.aux, 0));
-  launch_rtr_begin(c, sel, p.rtr_initial_radius, p.gradnorm_tol, p.rtr_iterations);
   int sp = 0;
   RtrState *hs = t->h_state;
   auto read_state = [&]() -> int {
@@ -90,6 +89,55 @@ int enqueue_optimize(dpgo_team *t, int sel, const OptFlags &fl) {
     HIPC(hipStreamSynchronize(t->stream));
     return 0;
   };
+  auto account = [&]() {
+    a.opt.success = 1;
+    a.opt.f_init = hs->f_init; a.opt.gradnorm_init = hs->gn_init;
+    a.opt.f_opt = hs->f1; a.opt.gradnorm_opt = hs->ngf;
+    a.opt.rtr_outer_iters = hs->outer_count; a.opt.tcg_iters_total = hs->tcg_total;
+    a.opt.hessvec_count = hs->hv_count; a.opt.precond_count = hs->pc_count; a.opt.accepted = hs->accepted;
+    a.opt_pending_rgd = false;
+    t->counters[2] += hs->hv_count + 1 + hs->outer_count;
+    t->counters[3] += (hs->hv_count + 1 + hs->outer_count) * spmm_bytes_of(t, a);
+  };
+  if (t->use_fused_rtr && a.dev.M && rtr_fused_eligible(p.r, a.n, t->num_cus)) {
+    // one launch for the whole solve, the preconditioner resident in LDS (rtr_fused.hip): M leaves HBM once per solve.
+    // The host does not wait for it: the solve's record and the agent's running totals come back asynchronously and
+    // are read by refresh_rtr_result() whenever somebody asks (opt result, counters) -- except for the very first
+    // solve on this device, which is checked at once so that a grid that is not resident at once (another process
+    // running a persistent kernel on this GPU) is met with the launch-per-step sequence instead of an error.
+    if (a.rtr_bar_n != a.n) {
+      if (a.d_rtr_bar.alloc(RTR_BAR_WORDS) || a.d_rtr_ws.alloc(RTR_WS_DOUBLES) || a.h_rtr.alloc(1) || a.h_rtr_cum.alloc(4)) {
+        set_err("RTR scratch allocation failed"); return DPGO_ERR;
+      }
+      if (!a.d_rtr_cum.p) {
+        if (a.d_rtr_cum.alloc(4)) { set_err("RTR scratch allocation failed"); return DPGO_ERR; }
+        HIPC(hipMemsetAsync(a.d_rtr_cum.p, 0, sizeof(unsigned long long) * 4, t->stream));
+      }
+      HIPC(hipMemsetAsync(a.d_rtr_bar.p, 0, sizeof(unsigned long long) * RTR_BAR_WORDS, t->stream));
+      a.rtr_bar_n = a.n;
+    }
+    if (launch_rtr_solve(c, sel, a.n, a.d_rtr_bar.p, a.d_rtr_ws.p, a.d_rtr_cum.p, t->h_bar_err, p.rtr_initial_radius,
+                         p.gradnorm_tol, p.rtr_iterations, p.rtr_tcg_iterations, p.rtr_max_radius)) {
+      set_err("RTR solve launch failed"); return DPGO_ERR;
+    }
+    HIPC(hipMemcpyAsync(a.h_rtr.p, a.dev.st, sizeof(RtrState), hipMemcpyDeviceToHost, t->stream));
+    HIPC(hipMemcpyAsync(a.h_rtr_cum.p, a.d_rtr_cum.p, sizeof(unsigned long long) * 4, hipMemcpyDeviceToHost, t->stream));
+    a.opt_pending_rtr = true;
+    a.opt_pending_rgd = false;
+    if (t->rtr_validated) return 0;
+    HIPC(hipStreamSynchronize(t->stream));
+    if (!*t->h_bar_err) {
+      t->rtr_validated = true;
+      return refresh_rtr_result(t, a);
+    }
+    // timed out at the first hand-off: nothing but scratch was written.  Launch-per-step from now on, this solve included
+    *t->h_bar_err = 0;
+    t->use_fused_rtr = 0;
+    a.rtr_bar_n = -1;
+    a.opt_pending_rtr = false;
+  }
+  if (refresh_rtr_result(t, a)) return DPGO_ERR;  // (totals of earlier one-launch solves, before a.opt is overwritten)
+  launch_rtr_begin(c, sel, p.rtr_initial_radius, p.gradnorm_tol, p.rtr_iterations);
   // One outer iteration = [tCG init, (Hess-vec, step) x J, retract, evaluate, accept].  Every kernel is
   // gated by the device-side phase, so whole patterns are enqueued blindly: the expected number of outer
   // iterations first, then one read-back; more patterns only if the state says the solve is not done.
@@ -129,15 +177,8 @@ int enqueue_optimize(dpgo_team *t, int sel, const OptFlags &fl) {
   a.outer_hint = hs->outer_count;
   if (hs->outer_count > 0) a.tcg_hint = std::max(2, std::min(8, (hs->tcg_total + hs->outer_count - 1) / hs->outer_count + 1));
   for (int o = 0; o < 4; ++o) a.tcg_hint_o[o] = (o < hs->outer_count) ? hs->tcg_o[o] : 0;
-  a.opt.success = 1;
-  a.opt.f_init = hs->f_init; a.opt.gradnorm_init = hs->gn_init;
-  a.opt.f_opt = hs->f1; a.opt.gradnorm_opt = hs->ngf;
-  a.opt.rtr_outer_iters = hs->outer_count; a.opt.tcg_iters_total = hs->tcg_total;
-  a.opt.hessvec_count = hs->hv_count; a.opt.precond_count = hs->pc_count; a.opt.accepted = hs->accepted;
-  a.opt_pending_rgd = false;
+  account();
   t->counters[0] += hs->pc_count; t->counters[1] += hs->pc_count * 8.0 * N4 * (double)N4;
-  t->counters[2] += hs->hv_count + 1 + hs->outer_count;
-  t->counters[3] += (hs->hv_count + 1 + hs->outer_count) * spmm_bytes_of(t, a);
   return 0;
 }
 
@@ -190,6 +231,35 @@ int enqueue_iterate(dpgo_team *t, int li, int do_opt) {
     if (fused) a.rel_src = 1; else launch_status(c, li, li, 1, a.n, do_opt ? 1 : 0);
   }
   launch_advance(c, li, 1, p.acceleration, p.num_robots, p.restart_interval, 0);
+  return 0;
+}
+
+// the record of the agent's last one-launch RTR solve and the running totals of all of them (copied back
+// asynchronously behind every solve) -> a.opt and the team counters
+int refresh_rtr_result(dpgo_team *t, Agent &a) {
+  if (!a.opt_pending_rtr) return 0;
+  HIPC(hipStreamSynchronize(t->stream));
+  a.opt_pending_rtr = false;
+  if (*t->h_bar_err) {
+    *t->h_bar_err = 0;
+    t->use_fused_rtr = 0;
+    a.rtr_bar_n = -1;
+    set_err("one-launch RTR solve: grid-wide hand-off timed out (the iterates since the last synchronisation are invalid)");
+    return DPGO_ERR;
+  }
+  const RtrState *hs = a.h_rtr.p;
+  a.opt.success = 1;
+  a.opt.f_init = hs->f_init; a.opt.gradnorm_init = hs->gn_init;
+  a.opt.f_opt = hs->f1; a.opt.gradnorm_opt = hs->ngf;
+  a.opt.rtr_outer_iters = hs->outer_count; a.opt.tcg_iters_total = hs->tcg_total;
+  a.opt.hessvec_count = hs->hv_count; a.opt.precond_count = hs->pc_count; a.opt.accepted = hs->accepted;
+  unsigned long long d[4];
+  for (int k = 0; k < 4; ++k) { d[k] = a.h_rtr_cum.p[k] - a.rtr_seen[k]; a.rtr_seen[k] = a.h_rtr_cum.p[k]; }
+  const double N4 = 4.0 * a.n;
+  t->counters[0] += (double)d[2];
+  t->counters[1] += (double)d[0] * 8.0 * N4 * N4;  // M is streamed once per solve
+  t->counters[2] += (double)(d[1] + d[0] + d[3]);
+  t->counters[3] += (double)(d[1] + d[0] + d[3]) * spmm_bytes_of(t, a);
   return 0;
 }
 
@@ -320,6 +390,7 @@ int enqueue_optimize_group(dpgo_team *t, int g) {
     }
     return 0;
   }
+  for (int k : mem) if (refresh_rtr_result(t, *t->ag[k])) return DPGO_ERR;
   launch_eval(c, sel, mn, B_X, B_EGRAD, B_GF, PART_A, eval_opts(t, 2, 0, 0));
   launch_rtr_begin(c, sel, p.rtr_initial_radius, p.gradnorm_tol, p.rtr_iterations);
   int sp = 0, J = 2;

@@ -107,6 +107,15 @@ struct Agent {
   DevBuf<double> d_xfer;
   int tcg_hint = 4, outer_hint = -1;  // launch-pattern sizing from the previous solve of this agent
   int tcg_hint_o[4] = {0, 0, 0, 0};   // per outer iteration: launch pairs its tCG took last time (0 = unknown)
+  // one-launch RTR solve (rtr_fused.hip): hand-off counters and partial-sum scratch of this agent's grid
+  DevBuf<unsigned long long> d_rtr_bar;
+  DevBuf<double> d_rtr_ws;
+  int rtr_bar_n = -1;  // pose count the counters were zeroed for
+  DevBuf<unsigned long long> d_rtr_cum;      // running totals {solves, Hess-vecs, preconditioner applies, outer iterations}
+  PinnedBuf<unsigned long long> h_rtr_cum;   // host copy of the totals + of the last solve's record (asynchronous read-back)
+  PinnedBuf<dpgo::RtrState> h_rtr;
+  unsigned long long rtr_seen[4] = {0, 0, 0, 0};
+  bool opt_pending_rtr = false;  // a.opt / the team counters lag behind the device: refresh_rtr_result() catches up
   int rel_src = 0;  // where the last |X - XPrev|^2 partials live: 0 PART_D (per 64-pose tile), 1 PART_B[2] (fused RGD),
                     // 2 none (X untouched), 4 PART_D one double per pose (look-ahead Nesterov step)
   // status of the last iterate(true) (a9; refreshed only when the agent optimizes unless status_every_iterate):
@@ -174,6 +183,8 @@ struct dpgo_team {
   dpgo_host::DevBuf<unsigned long long> d_bar;
   int *h_bar_err = nullptr;
   int num_cus = 0;
+  bool rtr_validated = false;  // a one-launch solve has completed on this device (its grid is resident at once)
+  int use_fused_rtr = 1;  // DPGO_FUSED_RTR=0 keeps the launch-per-step RTR sequence (solve.hip) for every agent
   int use_fused = 0;  // DPGO_FUSED_ITER=1 selects the one-launch iteration (measured 27 us against 25 for two launches on
                       // sphere2500 / 5 agents, profiles/r02_fused_iteration.md, hence off by default)
   unsigned long long epoch = 1;  // bumped by everything that enqueues device work (every launch goes through ctx())
@@ -212,6 +223,7 @@ void account_iteration(dpgo_team *t, int sel, bool fused);
 int enqueue_optimize_group(dpgo_team *t, int g);
 int fetch_scal(dpgo_team *t, Agent &a);
 int refresh_rgd_result(dpgo_team *t, Agent &a);
+int refresh_rtr_result(dpgo_team *t, Agent &a);
 double robust_weight(const dpgo_params_t &p, double mu, double residual);
 int compute_residuals(dpgo_team *t, Agent &a, std::vector<double> &res);
 

@@ -249,6 +249,8 @@ int dpgo_team_time_kernel(dpgo_team_t *t, int id, int which, int reps, double *a
  * no PublicPoses message, no rendezvous.  The exporting process must outlive the importers' use. */
 int dpgo_agent_export_state(dpgo_team_t *t, int id, unsigned char *handle64, long long *offset_x, long long *offset_y, int *n);
 int dpgo_team_import_peer(dpgo_team_t *t, int robot_id, const unsigned char *handle64, long long offset_x, long long offset_y, int n);
+/* diagnostic: hand-off words of an agent's one-launch RTR solve (rtr_fused.hip; phase stamps in trace builds) */
+int dpgo_agent_read_rtr_handoff(dpgo_team_t *t, int id, unsigned long long *out, int n);
 /* diagnostic: `n` doubles of an agent's device-side partial-sum scratch (csrc/dpgo_dev.h PART_*) from `offset` */
 int dpgo_agent_read_partials(dpgo_team_t *t, int id, int offset, double *out, int n);
 /* diagnostic: the hand-off words of the fused iteration kernel (csrc/iter_fused.hip); returns the count copied */

@@ -8,3 +8,6 @@ t=capi.Team.from_measurements(mp, capi.default_params(r=5,num_robots=5,method=0,
 t.set_initial(T,Y)
 t.run(int(sys.argv[1]) if len(sys.argv)>1 else 100); t.synchronize()
 t0=time.perf_counter(); t.run(100); t.synchronize(); print("ms/iter", (time.perf_counter()-t0)*10)
+for rep in range(3):
+    t0=time.perf_counter(); t.run(200); t1=time.perf_counter(); t.synchronize(); t2=time.perf_counter()
+    print("rep", rep, "ms/iter", (t2-t0)*5, " host enqueue ms/iter", (t1-t0)*5)

@@ -547,7 +547,13 @@ def test_colour_parallel_sweeps_equal_the_permuted_sequential_schedule(dataset, 
     ts, _, _ = make_pair(dataset, N, **kw)
     ts.set_schedule(order)
     ts.run(sweeps * N)
-    assert np.array_equal(ts.global_X(), th.global_X())  # same kernels, same order of arithmetic per agent
+    # RGD: same kernels, same order of arithmetic per agent.  RTR: the sequential schedule takes the one-launch solve
+    # (rtr_fused.hip), the colour classes the launch-per-step kernels -- the same arithmetic up to the order in which
+    # a preconditioner row is summed
+    if kw.get("method", 0) == 1:
+        assert np.array_equal(ts.global_X(), th.global_X())
+    else:
+        assert np.abs(ts.global_X() - th.global_X()).max() < 1e-9
     ts.close()
     th.close()
 
