@@ -295,7 +295,7 @@ __device__ __forceinline__ void gather_issue(const int *idxL, Ld ld, double (*ra
 // ld: pose index -> NRAW x 4 raw operands (row a of the pose); comb: raw operands -> the NV input vectors
 template <int R, int NV, int NRAW, class Ld, class Comb>
 __device__ __forceinline__ void spmm_row_finish(const AgentDev &ag, int j, const double *BL, double (*raw)[NRAW][4], Ld ld,
-                                                Comb comb, double (*acc)[4]) {
+                                                Comb comb, double (*acc)[4], int ell_w, int p0, int p1) {
   double x[RTR_SLOTS][NV][4];
 #pragma unroll
   for (int u = 0; u < RTR_SLOTS; ++u) comb(raw[u], x[u]);
@@ -313,8 +313,8 @@ __device__ __forceinline__ void spmm_row_finish(const AgentDev &ag, int j, const
       for (int c = 0; c < 4; ++c)
         acc[v][c] += x[u][v][0] * B[4 * c] + x[u][v][1] * B[4 * c + 1] + x[u][v][2] * B[4 * c + 2] + x[u][v][3] * B[4 * c + 3];
   }
-  for (int s0 = RTR_SLOTS; s0 < ag.ell_w; s0 += 4) ell_group<R, NV>(ag, j, s0, src, acc);
-  const int p0 = ag.trowptr[j], p1 = ag.trowptr[j + 1];
+  // (matrix width and the CSR-tail range of the row come from the caller: read once per launch, not once per product)
+  for (int s0 = RTR_SLOTS; s0 < ell_w; s0 += 4) ell_group<R, NV>(ag, j, s0, src, acc);
   for (int p = p0; p < p1; ++p) {
     const int i = ag.tcol[p];
     const double *bp = ag.tval + (size_t)16 * p;
@@ -331,25 +331,37 @@ __device__ __forceinline__ void spmm_row_finish(const AgentDev &ag, int j, const
 }
 
 // hess_tail (kernel_common.h) for lanes of ONE wave
+// Hc[3 p + q] = 0.5 (S_pq + S_qp), S = Y^T E of the pose: fixed over a tCG solve, formed once per outer iteration by
+// curvature_block (vrow[p] * 0.5 * (S_pq + S_qp) and vrow[p] * Hc are the same number: the halving is exact)
 template <int R>
-__device__ __forceinline__ void hess_tail_w(const double *Ysh, const double *Esh, double *Wsh, int a, const double wrow[4],
+__device__ __forceinline__ void curvature_block(const double *Ysh, const double *Esh, double *Hc) {
+  double S[9];
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      double s = 0;
+#pragma unroll
+      for (int b = 0; b < R; ++b) s += Ysh[p * R + b] * Esh[q * R + b];
+      S[3 * p + q] = s;
+    }
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) Hc[3 * p + q] = 0.5 * (S[3 * p + q] + S[3 * q + p]);
+}
+template <int R>
+__device__ __forceinline__ void hess_tail_w(const double *Ysh, const double *Hc, double *Wsh, int a, const double wrow[4],
                                             const double vrow[4], double hrow[4], bool act) {
   if (act) {
-    double S[9];
+    double h[9];
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        double s = 0;
-#pragma unroll
-        for (int b = 0; b < R; ++b) s += Ysh[p * R + b] * Esh[q * R + b];
-        S[3 * p + q] = s;
-      }
+    for (int i = 0; i < 9; ++i) h[i] = Hc[i];
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
       double s = wrow[q];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) s -= vrow[p] * 0.5 * (S[3 * p + q] + S[3 * q + p]);
+      for (int p = 0; p < 3; ++p) s -= vrow[p] * h[3 * p + q];
       Wsh[q * R + a] = s;
     }
   }
@@ -375,6 +387,7 @@ __global__ __launch_bounds__(256) void k_rtr_solve(const AgentDev *agents, int a
       X2s[8 * R], E2s[8 * R], G2s[8 * R];
   __shared__ double BL[2 * RTR_SLOTS * 16];  // the first ELL slots of the own two poses: 4 x 4 blocks and indices
   __shared__ int idxL[2 * RTR_SLOTS];
+  __shared__ double Hcs[2 * 9];  // curvature blocks of the own two poses at the current X
   const AgentDev &ag = agents[ai];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bx = (int)blockIdx.x, N4 = ag.N4, n = ag.n;
@@ -443,7 +456,8 @@ __global__ __launch_bounds__(256) void k_rtr_solve(const AgentDev *agents, int a
       Gs[idx] = ag.buf[B_GF][o];
     }
   }
-  const int Wc = min(ag.ell_w, RTR_SLOTS);
+  const int ellw = ag.ell_w, Wc = min(ellw, RTR_SLOTS);
+  const int tp0 = rl ? ag.trowptr[j] : 0, tp1 = rl ? ag.trowptr[j + 1] : 0;
   static_assert(2 * RTR_SLOTS * 16 == 256, "one thread per cached block element");
   {
     const int q = tid, pl = q / (RTR_SLOTS * 16), u = (q / 16) % RTR_SLOTS, e = q % 16;
@@ -465,6 +479,8 @@ __global__ __launch_bounds__(256) void k_rtr_solve(const AgentDev *agents, int a
   const double kappa = 0.1;  // tCG stop: |r| <= |r0| min(|r0|^theta, kappa) with theta = 1
 
   while (true) {
+    if (tid < npose) curvature_block<R>(Xs + tid * 4 * R, Es + tid * 4 * R, Hcs + tid * 9);
+    // (visible to the row lanes through the barriers inside the set-up's slab product)
     // ================= tCG set-up (k_precond<PM_TCG_INIT>): z0 = P(gf M), r0 = gf, eta = 0, delta0 = -z0
     {
       double2 vv[SLAB_MAXM][R];
@@ -552,7 +568,7 @@ __global__ __launch_bounds__(256) void k_rtr_solve(const AgentDev *agents, int a
             [&](double(*rw)[4], double(*x)[4]) {
 #pragma unroll
               for (int cp = 0; cp < 4; ++cp) x[0][cp] = fresh ? rw[1][cp] : (-rw[0][cp] + beta * rw[1][cp]);
-            }, w);
+            }, w, ellw, tp0, tp1);
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
             const size_t o = ((size_t)4 * j + c) * R + a;
@@ -562,7 +578,7 @@ __global__ __launch_bounds__(256) void k_rtr_solve(const AgentDev *agents, int a
           }
         }
         RTR_FINE(2);
-        hess_tail_w<R>(Xs + lp * 4 * R, Es + lp * 4 * R, Ws + lp * 4 * R, a, w[0], vrow, hrow, rl);
+        hess_tail_w<R>(Xs + lp * 4 * R, Hcs + min(lp, 1) * 9, Ws + lp * 4 * R, a, w[0], vrow, hrow, rl);
         RTR_FINE(3);
         double d = 0;
         if (rl) {
@@ -688,7 +704,7 @@ __global__ __launch_bounds__(256) void k_rtr_solve(const AgentDev *agents, int a
           [&](double(*rw)[4], double(*x)[4]) {
 #pragma unroll
             for (int cp = 0; cp < 4; ++cp) { x[0][cp] = rw[0][cp]; x[1][cp] = rw[1][cp]; }
-          }, acc);
+          }, acc, ellw, tp0, tp1);
         const bool pub = ag.pub_index[j] >= 0;
         const double *G = ag.buf[B_G] + (size_t)j * 4 * R;
 #pragma unroll
@@ -713,7 +729,7 @@ __global__ __launch_bounds__(256) void k_rtr_solve(const AgentDev *agents, int a
         for (int c = 0; c < 4; ++c) vrow[c] = Et[lp * 4 * R + c * R + a];
       }
       WSYNC();
-      hess_tail_w<R>(Xs + lp * 4 * R, Es + lp * 4 * R, Ws + lp * 4 * R, a, acc[1], vrow, hrow, rl);
+      hess_tail_w<R>(Xs + lp * 4 * R, Hcs + min(lp, 1) * 9, Ws + lp * 4 * R, a, acc[1], vrow, hrow, rl);
       if (rl) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
