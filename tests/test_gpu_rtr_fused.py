@@ -1,0 +1,87 @@
+"""The one-launch RTR solve (dpgo_ros_amd/csrc/rtr_fused.hip: persistent kernel, the agent's dense preconditioner resident in
+LDS) against (1) the launch-per-step kernel sequence it replaces, selected with DPGO_FUSED_RTR=0, and (2) the oracle -- over
+the lifted ranks the templates are instantiated for, agents with an odd pose count (a workgroup that owns ONE pose), rows
+longer than the cached ELL slots, trust-region rejections and boundary steps (small initial radius)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from dpgo_ros_amd import capi
+from oracle import oracle as O
+from tests.util import load, params_pair
+
+pytestmark = pytest.mark.gpu
+
+
+def _team(mp, prm, fused):
+    old = os.environ.get("DPGO_FUSED_RTR")
+    os.environ["DPGO_FUSED_RTR"] = "1" if fused else "0"
+    try:
+        return capi.Team.from_measurements(mp.view(capi.MEAS_DTYPE), prm)
+    finally:
+        if old is None:
+            del os.environ["DPGO_FUSED_RTR"]
+        else:
+            os.environ["DPGO_FUSED_RTR"] = old
+
+
+def _handoffs(team, agent):
+    """epoch of the agent's grid hand-off counters: > 0 iff one-launch solves ran (and passed that many hand-offs)"""
+    out = (C.c_ulonglong * 320)()
+    rc = capi.lib().dpgo_agent_read_rtr_handoff(team.h, agent, out, 320)
+    return int(out[17 * 16]) if rc == 0 else 0
+
+
+@pytest.mark.parametrize("r", [3, 4, 5, 6, 8])
+def test_one_launch_solve_equals_the_launch_per_step_sequence_and_the_oracle(r):
+    N, iters = 3, 12
+    kw = dict(method=capi.METHOD_RTR, acceleration=1, restart_interval=5, gradnorm_tol=1e-3, rtr_iterations=3, rtr_tcg_iterations=30)
+    m, mp, n = load("smallGrid3D", N)
+    ph, po = params_pair(r=r, num_robots=N, **kw)
+    T, Y = O.odometry_init(m, n), O.fixed_stiefel(r)
+    tf, ts = _team(mp, ph, True), _team(mp, ph, False)
+    to = O.Team(mp, n, po)
+    for t in (tf, ts, to):
+        t.set_initial(T, Y)
+    tf.run(iters)
+    ts.run(iters)
+    for _ in range(iters):
+        to.iterate()
+    assert _handoffs(tf, 0) > 0 and _handoffs(ts, 0) == 0
+    assert np.abs(tf.global_X() - ts.global_X()).max() < 1e-9
+    assert np.abs(tf.global_X() - to.global_X()).max() < 1e-7
+    assert abs(tf.cost() - to.cost()) <= 1e-9 * abs(to.cost())
+    for a in range(N):
+        rf, rs = tf.agents[a].opt_result(), ts.agents[a].opt_result()
+        assert (rf.rtr_outer_iters, rf.tcg_iters_total, rf.accepted) == (rs.rtr_outer_iters, rs.tcg_iters_total, rs.accepted)
+        assert abs(rf.f_opt - rs.f_opt) <= 1e-10 * abs(rs.f_opt)
+    tf.close()
+    ts.close()
+
+
+@pytest.mark.parametrize("dataset,N,radius", [("parking-garage", 5, 100.0), ("sphere2500", 5, 0.5), ("sphere2500", 7, 100.0)])
+def test_one_launch_solve_odd_agents_long_rows_and_rejections(dataset, N, radius):
+    """parking-garage / 5: 333- and 332-pose agents (odd: the last workgroup owns one pose); sphere2500 / 7: 358- and
+    357-pose agents; radius 0.5: the first solves hit the trust-region boundary and take rejected steps"""
+    iters = 2 * N
+    kw = dict(method=capi.METHOD_RTR, acceleration=0, gradnorm_tol=1e-2, rtr_iterations=3, rtr_tcg_iterations=8, rtr_initial_radius=radius)
+    m, mp, n = load(dataset, N)
+    ph, po = params_pair(r=5, num_robots=N, **kw)
+    T, Y = O.odometry_init(m, n), O.fixed_stiefel(5)
+    tf = _team(mp, ph, True)
+    to = O.Team(mp, n, po)
+    tf.set_initial(T, Y)
+    to.set_initial(T, Y)
+    tf.run(iters)
+    for _ in range(iters):
+        to.iterate()
+    assert _handoffs(tf, 0) > 0
+    scale = max(1.0, np.abs(to.global_X()).max())
+    assert np.abs(tf.global_X() - to.global_X()).max() < 1e-7 * scale
+    assert abs(tf.cost() - to.cost()) <= 1e-9 * abs(to.cost())
+    for a in range(N):
+        rf, ro = tf.agents[a].opt_result(), to.agents[a].opt_result()
+        assert (rf.rtr_outer_iters, rf.tcg_iters_total, rf.accepted) == (ro.rtr_outer_iters, ro.tcg_iters_total, ro.accepted)
+    tf.close()
