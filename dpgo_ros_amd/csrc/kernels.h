@@ -78,8 +78,10 @@ constexpr int RTR_BAR_WORDS = 18 * 16 + 160;
 constexpr int RTR_WS_DOUBLES = 7 * 256;
 bool rtr_fused_eligible(int r, int n, int num_cus);
 // cum: 4 zero-initialised 64-bit words per agent: running totals {solves, Hessian-vector products, preconditioner
-// applies, outer iterations} the kernel adds to
-int launch_rtr_solve(const LaunchCtx &c, int ai, int n, unsigned long long *bar, double *ws, unsigned long long *cum, int *err, double Delta0,
+// applies, outer iterations} the kernel adds to; host_rec / host_cum: pinned host copies of the solve's record and of
+// the totals, written by the kernel itself
+int launch_rtr_solve(const LaunchCtx &c, int ai, int n, unsigned long long *bar, double *ws, unsigned long long *cum, RtrState *host_rec,
+                     unsigned long long *host_cum, int *err, double Delta0,
                      double tol, int max_outer, int max_inner, double max_radius);
 
 // dense_inverse.hip: M = (A)^-1 for a symmetric positive definite N x N column-major matrix.

@@ -48,6 +48,9 @@ __device__ __forceinline__ double ld_c(const double *p) {
 #ifndef DPGO_RTR_PLAIN_LD
 #define DPGO_RTR_PLAIN_LD 0
 #endif
+#ifndef DPGO_RTR_LDAUX
+#define DPGO_RTR_LDAUX 16  // buffer-load cache policy of the cross-workgroup reads: 16 = sc1
+#endif
 __device__ __forceinline__ void st_c(double *p, double v) {
 #if DPGO_RTR_PLAIN_ST
   *p = v;
@@ -67,13 +70,13 @@ struct CVec {
   __device__ __forceinline__ CVec(const double *p, int count)
       : rs(__builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(p), 0, count * 8, 0x00020000)) {}
   __device__ __forceinline__ double ld(int i) const {
-    const v2u_t r = __builtin_amdgcn_raw_buffer_load_b64(rs, i * 8, 0, DPGO_RTR_PLAIN_LD ? 0 : 16);
+    const v2u_t r = __builtin_amdgcn_raw_buffer_load_b64(rs, i * 8, 0, DPGO_RTR_PLAIN_LD ? 0 : DPGO_RTR_LDAUX);
     double d;
     __builtin_memcpy(&d, &r, 8);
     return d;
   }
   __device__ __forceinline__ double2 ld2(int i) const {
-    const v4u_t r = __builtin_amdgcn_raw_buffer_load_b128(rs, i * 8, 0, DPGO_RTR_PLAIN_LD ? 0 : 16);
+    const v4u_t r = __builtin_amdgcn_raw_buffer_load_b128(rs, i * 8, 0, DPGO_RTR_PLAIN_LD ? 0 : DPGO_RTR_LDAUX);
     double2 d;
     __builtin_memcpy(&d, &r, 16);
     return d;
@@ -377,7 +380,8 @@ __device__ __forceinline__ void hess_tail_w(const double *Ysh, const double *Hc,
 
 template <int R>
 __global__ __launch_bounds__(256) void k_rtr_solve(const AgentDev *agents, int ai, unsigned long long *bar, double *ws,
-                                                   unsigned long long *cum, int *err, double Delta0, double tol, int max_outer, int max_inner,
+                                                   unsigned long long *cum, RtrState *host_rec,
+                                                   unsigned long long *host_cum, int *err, double Delta0, double tol, int max_outer, int max_inner,
                                                    double max_radius) {
   extern __shared__ double Ms[];  // [8][N4]: this workgroup's columns of M
   __shared__ double red[64 * (8 * R + 1)];
@@ -410,7 +414,13 @@ __global__ __launch_bounds__(256) void k_rtr_solve(const AgentDev *agents, int a
     S.need_init = 1;
   }
   if (S.outer_done) {
-    if (bx == 0 && tid == 0) { const RtrState T = to_record(S); ag.st[0] = T; ag.st[1] = T; cum[0] += 1ull; }
+    if (bx == 0 && tid == 0) {
+      const RtrState T = to_record(S);
+      ag.st[0] = T; ag.st[1] = T;
+      cum[0] += 1ull;
+      *host_rec = T;
+      for (int k = 0; k < 4; ++k) host_cum[k] = cum[k];
+    }
     return;
   }
   __shared__ int bar_ok;
@@ -793,6 +803,9 @@ __global__ __launch_bounds__(256) void k_rtr_solve(const AgentDev *agents, int a
     // running totals of this agent's solves: the host reads them (and the record) whenever it next synchronises
     cum[0] += 1ull; cum[1] += (unsigned long long)S.hv_count; cum[2] += (unsigned long long)S.pc_count;
     cum[3] += (unsigned long long)S.outer_count;
+    // ... straight into pinned host memory (no copy kernels behind the solve): valid once the stream has drained
+    *host_rec = T;
+    for (int k = 0; k < 4; ++k) host_cum[k] = cum[k];
   }
 }
 
@@ -805,8 +818,8 @@ bool rtr_fused_eligible(int r, int n, int num_cus) {
   return (size_t)64 * 4 * n + rtr_static_lds(r) <= (size_t)160 * 1024;
 }
 
-int launch_rtr_solve(const LaunchCtx &c, int ai, int n, unsigned long long *bar, double *ws, unsigned long long *cum, int *err, double Delta0,
-                     double tol, int max_outer, int max_inner, double max_radius) {
+int launch_rtr_solve(const LaunchCtx &c, int ai, int n, unsigned long long *bar, double *ws, unsigned long long *cum, RtrState *host_rec, unsigned long long *host_cum,
+                     int *err, double Delta0, double tol, int max_outer, int max_inner, double max_radius) {
   const size_t dyn = (size_t)64 * 4 * n;  // 8 columns x N4 doubles
   hipError_t e = hipSuccess;
   DPGO_DISPATCH_R(c.r, {
@@ -816,7 +829,7 @@ int launch_rtr_solve(const LaunchCtx &c, int ai, int n, unsigned long long *bar,
       configured = (e == hipSuccess);
     }
     if (e == hipSuccess)
-      hipLaunchKernelGGL(k_rtr_solve<R>, dim3((n + 1) / 2), dim3(256), dyn, c.stream, c.agents, ai, bar, ws, cum, err, Delta0, tol,
+      hipLaunchKernelGGL(k_rtr_solve<R>, dim3((n + 1) / 2), dim3(256), dyn, c.stream, c.agents, ai, bar, ws, cum, host_rec, host_cum, err, Delta0, tol,
                          max_outer, max_inner, max_radius);
   });
   return e == hipSuccess ? 0 : -1;

@@ -101,8 +101,8 @@ int enqueue_optimize(dpgo_team *t, int sel, const OptFlags &fl) {
   };
   if (t->use_fused_rtr && a.dev.M && rtr_fused_eligible(p.r, a.n, t->num_cus)) {
     // one launch for the whole solve, the preconditioner resident in LDS (rtr_fused.hip): M leaves HBM once per solve.
-    // The host does not wait for it: the solve's record and the agent's running totals come back asynchronously and
-    // are read by refresh_rtr_result() whenever somebody asks (opt result, counters) -- except for the very first
+    // The host does not wait for it: the kernel leaves the solve's record and the agent's running totals in pinned
+    // host memory, read by refresh_rtr_result() whenever somebody asks (opt result, counters) -- except for the very first
     // solve on this device, which is checked at once so that a grid that is not resident at once (another process
     // running a persistent kernel on this GPU) is met with the launch-per-step sequence instead of an error.
     if (a.rtr_bar_n != a.n) {
@@ -116,12 +116,10 @@ int enqueue_optimize(dpgo_team *t, int sel, const OptFlags &fl) {
       HIPC(hipMemsetAsync(a.d_rtr_bar.p, 0, sizeof(unsigned long long) * RTR_BAR_WORDS, t->stream));
       a.rtr_bar_n = a.n;
     }
-    if (launch_rtr_solve(c, sel, a.n, a.d_rtr_bar.p, a.d_rtr_ws.p, a.d_rtr_cum.p, t->h_bar_err, p.rtr_initial_radius,
+    if (launch_rtr_solve(c, sel, a.n, a.d_rtr_bar.p, a.d_rtr_ws.p, a.d_rtr_cum.p, a.h_rtr.p, a.h_rtr_cum.p, t->h_bar_err, p.rtr_initial_radius,
                          p.gradnorm_tol, p.rtr_iterations, p.rtr_tcg_iterations, p.rtr_max_radius)) {
       set_err("RTR solve launch failed"); return DPGO_ERR;
     }
-    HIPC(hipMemcpyAsync(a.h_rtr.p, a.dev.st, sizeof(RtrState), hipMemcpyDeviceToHost, t->stream));
-    HIPC(hipMemcpyAsync(a.h_rtr_cum.p, a.d_rtr_cum.p, sizeof(unsigned long long) * 4, hipMemcpyDeviceToHost, t->stream));
     a.opt_pending_rtr = true;
     a.opt_pending_rgd = false;
     if (t->rtr_validated) return 0;
