@@ -329,18 +329,23 @@ def roofline_leg(team, agent_id):
     spmm_eval: k_eval back to back."""
     p_ms, p_bytes = team.time_kernel(agent_id, 0, reps=500)
     s_ms, s_bytes = team.time_kernel(agent_id, 1, reps=500)
-    f_ms, f_bytes = team.time_kernel(agent_id, 10, reps=500)   # inside the running iteration (event pair per launch)
+    f_ms, f_bytes = team.time_kernel(agent_id, 10, reps=500)   # the running pipelined iteration, per iteration
+    e_ms, _ = team.time_kernel(agent_id, 11, reps=500)         # the evaluation launches of that sequence alone
     b_ms, _ = team.time_kernel(agent_id, 9, reps=500)          # the same kernel back to back (warm operands)
+    it_ms, f_ms = f_ms, f_ms - e_ms
     # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and --pmc
     # WRITE_SIZE in separate runs; FETCH_SIZE doubled per the gfx950 correction).  Not collectable live; re-measure
     # with profiles/collect.sh.
     roof = {"kernel": "k_precond<5,PM_RGD> (fused step kernel of the timed loop)", "bound": "hbm",
             "achieved": f_bytes / (f_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-            "traffic": (2 * 16571.9 + 833.1) * 1024, "traffic_source": "profiles/r02_pmc_fetch.md, profiles/r02_pmc_write.md",
+            "traffic": (2 * 16564.6 + 826.7) * 1024, "traffic_source": "profiles/r02_pmc_fetch.md, profiles/r02_pmc_write.md",
             "bytes_per_launch": f_bytes, "us_per_launch": f_ms * 1e3, "us_per_launch_back_to_back": b_ms * 1e3,
+            "timing_note": "HIP events around 500 eager pipelined iterations (%.2f us each) minus the same around 500 "
+                           "k_eval_stats launches alone (%.2f us each): the dispatch-to-dispatch time of the step kernel"
+                           % (it_ms * 1e3, e_ms * 1e3),
             "apply_only": {"kernel": "k_precond<5,PM_PLAIN>", "bytes_per_launch": p_bytes, "us_per_launch": p_ms * 1e3,
                            "achieved": p_bytes / (p_ms * 1e-3) / 1e9, "frac": p_bytes / (p_ms * 1e-3) / 1e9 / 8000.0,
-                           "traffic": (2 * 16078.1 + 85.9) * 1024},
+                           "traffic": (2 * 16071.1 + 85.9) * 1024},
             "spmm_eval": {"kernel": "k_eval<5>", "bytes_per_launch": s_bytes, "us_per_launch": s_ms * 1e3,
                           "achieved": s_bytes / (s_ms * 1e-3) / 1e9}}
     roof["frac"] = roof["achieved"] / roof["peak"]
