@@ -10,8 +10,16 @@ namespace dpgo {
 #ifndef DPGO_PC_MPRE
 #define DPGO_PC_MPRE 4
 #endif
+// -DDPGO_PC_DIRECT=1 builds the stream without LDS staging of the input vector (each lane takes two vector rows for all
+// 8 columns, as rtr_fused.hip's slab product does).  Measured: the stream of a 500-pose agent ends 2 us earlier inside
+// the kernel, the launch takes the same 16 us (the per-pose tail, not the stream, decides when the last workgroup
+// leaves), and agents of 625 / 1250 poses lose 25 / 19 % (one workgroup per CU instead of three).  Off.
+#ifndef DPGO_PC_DIRECT
+#define DPGO_PC_DIRECT 0
+#endif
 #ifdef DPGO_PC_TRACE
-#define PC_STAMP(k) do { if (MODE == PM_RGD_ && (threadIdx.x & 63) == 0 && blockIdx.x == 100) ag.part[PART_E + 4000 * PART_STRIDE + ((threadIdx.x >> 6) * 16) + (k)] = (double)wall_clock64(); } while (0)
+#define PC_STAMP(k) do { if (MODE == PM_RGD_ && (threadIdx.x & 63) == 0 && blockIdx.x == 100) ag.part[PART_E + 4000 * PART_STRIDE + ((threadIdx.x >> 6) * 16) + (k)] = (double)wall_clock64(); \
+    if (MODE == PM_RGD_ && threadIdx.x < 128 && (threadIdx.x & 63) == 0 && ((k) == 0 || (k) == 7)) ag.part[PART_E + (4100 + 2 * (int)blockIdx.x + (int)(threadIdx.x >> 6)) * PART_STRIDE + ((k) ? 1 : 0)] = (double)wall_clock64(); } while (0)
 #else
 #define PC_STAMP(k) do { } while (0)
 #endif
@@ -40,6 +48,14 @@ namespace dpgo {
 // workgroup per CU; larger agents use 1024-row chunks so that 3 workgroups fit a CU and one workgroup's
 // arithmetic overlaps the others' streams.
 
+template <int CTRL>
+__device__ __forceinline__ double dpp_quad_pc(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
 template <int R, int MODE, int KC>
 __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev *team, int sel, int xb, int vb,
                                                  int zb, int sp, int max_inner, double step, int accel,
@@ -67,10 +83,15 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
     team->iter += 1;
     team->stats_sel = team->cur_sel;
   }
+#if DPGO_PC_DIRECT
+  __shared__ double zs[8 * R];
+  __shared__ double red[256 * (8 * R + 1)];
+#else
   constexpr int MREG = KC / 64;
   __shared__ double vs[R * KC];
   __shared__ double zs[8 * R];
   __shared__ double red[32 * (8 * R + 1)];
+#endif
   __shared__ double Ysh[2 * 4 * R];
   __shared__ double Esh[3][2 * 4 * R];  // PM_RGD: V, Yaux, XPrev of the two poses
   const int tid = threadIdx.x, lane = tid & 63;
@@ -194,6 +215,97 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
   bool la_act = false, la_opt = false;
   int la_agent = 0, la_pose = 0;
   double la_x[4 * R], la_v[4 * R];
+#if DPGO_PC_DIRECT
+  // Direct form: lane t owns rows 2t, 2t+1 (+512 m) of the input vector for ALL 8 columns of the workgroup.  Every row
+  // of the vector is fetched once per workgroup straight from L2 (16-byte loads, no LDS staging, no barrier between the
+  // prologue and the stream), the slab requests follow immediately, and the 256 per-lane sums of each of the 8R outputs
+  // are combined by a quad reduction (DPP) plus 64 LDS rows.  Straight-line: rows / columns past the matrix re-read the
+  // last valid ones and enter with weight zero.
+  constexpr int MAXM = KC / 512;
+  double acc8[8][R];
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int a = 0; a < R; ++a) acc8[c][a] = 0;
+  PC_STAMP(1);
+  if (!ag.M) {
+    // block-Jacobi agent (the declared fallback where the dense inverse does not fit, include/dpgo_hip.h): column
+    // c of pose p is  v_p (Q_pp + shift I)^-1[:, c], a 4 x 4 block per pose -- one lane per output, no reduction
+    if (tid < 8 * R) {
+      const int cc = tid / R, a = tid - cc * R, col = col0 + cc;
+      double s = 0;
+      if (col < N4) {
+        const int p = col >> 2, c = col & 3;
+        const double *B = ag.Dinv + (size_t)16 * p + 4 * c;
+#pragma unroll
+        for (int cp = 0; cp < 4; ++cp) s += Vstage[((size_t)4 * p + cp) * R + a] * B[cp];
+      }
+      zs[tid] = s;
+    }
+  } else {
+    const double *Mc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) Mc[c] = ag.M + (size_t)min(col0 + c, N4 - 1) * N4;
+    for (int k0 = 0; k0 < N4; k0 += KC) {
+      double2 v[MAXM][R], mm[MAXM][8];
+#pragma unroll
+      for (int m = 0; m < MAXM; ++m) {
+        const int k = k0 + 2 * tid + 512 * m, kk = min(k, N4 - 2);
+#pragma unroll
+        for (int q = 0; q < R; ++q) v[m][q] = ld2(Vstage + (size_t)kk * R + 2 * q);
+      }
+      PC_STAMP(2);
+#pragma unroll
+      for (int m = 0; m < MAXM; ++m) {
+        const int k = k0 + 2 * tid + 512 * m, kk = min(k, N4 - 2);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) mm[m][c] = ld2_nt(Mc[c] + kk);
+      }
+      PC_STAMP(3);
+#pragma unroll
+      for (int m = 0; m < MAXM; ++m) {
+        const int k = k0 + 2 * tid + 512 * m;
+        const double live = (k < N4) ? 1.0 : 0.0;
+        double w[2 * R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) { w[2 * q] = v[m][q].x * live; w[2 * q + 1] = v[m][q].y * live; }
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+#pragma unroll
+          for (int a = 0; a < R; ++a) acc8[c][a] += w[a] * mm[m][c].x + w[R + a] * mm[m][c].y;
+      }
+    }
+    PC_STAMP(4);
+    // every lane leaves its 8R sums in its own LDS row (odd pitch: conflict-free both ways); four lanes per output
+    // then add 64 rows each and meet in a quad (DPP) -- 0.6 us where a DPP reduction of all 8R values per lane took 1.6
+    {
+      double *row = red + (size_t)tid * (8 * R + 1);
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int a = 0; a < R; ++a) row[c * R + a] = acc8[c][a];
+    }
+  }
+  if (tid < npose * 4 * R) {
+    Ysh[tid] = pre_x;
+    if (MODE == PM_RGD_) { Esh[0][tid] = pre_v; Esh[1][tid] = pre_y; Esh[2][tid] = pre_p; }
+  }
+  __syncthreads();
+  if (ag.M && tid < 4 * 8 * R) {
+    const int o = tid >> 2, part = tid & 3;
+    double t[64];
+#pragma unroll
+    for (int q = 0; q < 64; ++q) t[q] = red[(size_t)(part * 64 + q) * (8 * R + 1) + o];
+    double s = 0;
+#pragma unroll
+    for (int q = 0; q < 64; ++q) s += t[q];
+    s += dpp_quad_pc<0xB1>(s);  // lanes ^ 1
+    s += dpp_quad_pc<0x4E>(s);  // lanes ^ 2
+    if (part == 0) zs[o] = s;
+  }
+  __syncthreads();
+  if (tid >= 128) return;
+#else
   const int cg = tid >> 5, kl = tid & 31;
   const int col = col0 + cg;
   const bool cact = col < N4;
@@ -294,6 +406,7 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
     for (int q = 0; q < 32; ++q) s += red[q * (8 * R + 1) + tid];
     zs[tid] = s;
   }
+#endif
   PC_STAMP(5);
   if (tid < 64) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
