@@ -358,6 +358,112 @@ int dense_spd_inverse_batched(hipStream_t stream, int count, double *const *A, d
   return 0;
 }
 
+// ---- solve without the inverse: A X^T = B^T for RR right-hand sides from the Cholesky factor alone (a third of the
+// arithmetic of the inverse; the chordal initialisation applies its 7500^2 system to 3 right-hand sides exactly once).
+// B / Y: RR-vectors per row, [row][RR]; the solution overwrites B, Y is scratch.  Right-looking block substitutions, one
+// launch per block step:
+//   forward   y_kb = Linv_kb b_kb -> Y;       b_i  -= L[i, kb] y_kb   for the rows i below (in B)
+//   backward  x_kb = Linv_kb^T y_kb -> B;     y_j  -= L[kb, j]^T x_kb for the rows j above (in Y)
+template <int RR>
+__global__ __launch_bounds__(256) void k_solve_fwd(const InvJob *jobs, int kb, double *B, double *Y) {
+  const InvJob jb_ = jobs[0];
+  const int N = jb_.N, k0 = kb * NB, nb = min(NB, N - k0);
+  const double *Linv = jb_.Linv + (size_t)kb * NB * NB;  // [col j][row i] = W[i][j], W = inverse of the diagonal block
+  __shared__ double ys[NB][RR];
+  const int tid = threadIdx.x;
+  if (tid < NB * RR) {
+    const int i = tid / RR, a = tid - i * RR;
+    double s = 0;
+    if (i < nb)
+      for (int j = 0; j <= i; ++j) s += Linv[j * NB + i] * B[(size_t)(k0 + j) * RR + a];
+    ys[i][a] = s;
+  }
+  __syncthreads();
+  const int i = k0 + nb + (int)blockIdx.x * 256 + tid;
+  if (i < N) {
+    double acc[RR];
+#pragma unroll
+    for (int a = 0; a < RR; ++a) acc[a] = 0;
+    for (int k = 0; k < nb; ++k) {
+      const double l = jb_.A[(size_t)(k0 + k) * N + i];
+#pragma unroll
+      for (int a = 0; a < RR; ++a) acc[a] += l * ys[k][a];
+    }
+#pragma unroll
+    for (int a = 0; a < RR; ++a) B[(size_t)i * RR + a] -= acc[a];
+  }
+  // y goes to its own array: the rows of block kb in B are still being read by the other workgroups of this launch
+  if (blockIdx.x == gridDim.x - 1 && tid < nb * RR) Y[(size_t)k0 * RR + tid] = ys[tid / RR][tid % RR];
+}
+
+template <int RR>
+__global__ __launch_bounds__(256) void k_solve_bwd(const InvJob *jobs, int kb, double *Y, double *Xk) {
+  const InvJob jb_ = jobs[0];
+  const int N = jb_.N, k0 = kb * NB, nb = min(NB, N - k0);
+  const double *Linv = jb_.Linv + (size_t)kb * NB * NB;
+  __shared__ double xs[NB][RR];
+  const int tid = threadIdx.x;
+  if (tid < NB * RR) {
+    const int j = tid / RR, a = tid - j * RR;
+    double s = 0;
+    if (j < nb)
+      for (int i = j; i < nb; ++i) s += Linv[j * NB + i] * Y[(size_t)(k0 + i) * RR + a];  // (Linv^T y)_j
+    xs[j][a] = s;
+  }
+  __syncthreads();
+  const int c = (int)blockIdx.x * 256 + tid;  // a column (= row of the unknown) above the block
+  if (c < k0) {
+    double acc[RR];
+#pragma unroll
+    for (int a = 0; a < RR; ++a) acc[a] = 0;
+    const double *col = jb_.A + (size_t)c * N + k0;  // L[k0 + r][c], r = 0 .. nb-1: contiguous
+    for (int r = 0; r < nb; ++r) {
+      const double l = col[r];
+#pragma unroll
+      for (int a = 0; a < RR; ++a) acc[a] += l * xs[r][a];
+    }
+#pragma unroll
+    for (int a = 0; a < RR; ++a) Y[(size_t)c * RR + a] -= acc[a];
+  }
+  if (blockIdx.x == gridDim.x - 1 && tid < nb * RR) Xk[(size_t)k0 * RR + tid] = xs[tid / RR][tid % RR];
+}
+
+template <int RR>
+int dense_spd_solve(hipStream_t stream, double *A, int N, double *B, double *Y) {
+  InvJob job;
+  job.A = A; job.W = nullptr; job.M = nullptr; job.N = N; job.nblk = (N + NB - 1) / NB;
+  double *Linv = nullptr;
+  int *fail_d = nullptr;
+  InvJob *job_d = nullptr;
+  if (hipMalloc(&Linv, sizeof(double) * (size_t)job.nblk * NB * NB) != hipSuccess) return -1;
+  if (hipMalloc(&fail_d, sizeof(int)) != hipSuccess) { (void)hipFree(Linv); return -1; }
+  if (hipMalloc(&job_d, sizeof(InvJob)) != hipSuccess) { (void)hipFree(Linv); (void)hipFree(fail_d); return -1; }
+  job.Linv = Linv;
+  (void)hipMemcpyAsync(job_d, &job, sizeof(InvJob), hipMemcpyHostToDevice, stream);
+  (void)hipMemsetAsync(fail_d, 0, sizeof(int), stream);
+  for (int kb = 0; kb < job.nblk; ++kb) {
+    const int s0 = (kb + 1) * NB;
+    if (kb == 0) hipLaunchKernelGGL(k_potrf_diag, dim3(1, 1, 1), dim3(64), 0, stream, job_d, kb, fail_d);
+    if (s0 < N) {
+      hipLaunchKernelGGL(k_trsm_panel, dim3((N - s0 + 63) / 64, 1, 1), dim3(256), 0, stream, job_d, kb);
+      const int nt = (N - s0 + 63) / 64;
+      hipLaunchKernelGGL(k_syrk, dim3(nt, nt, 1), dim3(256), 0, stream, job_d, kb, fail_d);
+    }
+  }
+  for (int kb = 0; kb < job.nblk; ++kb) {
+    const int below = N - std::min(N, (kb + 1) * NB);
+    hipLaunchKernelGGL(k_solve_fwd<RR>, dim3(std::max(1, (below + 255) / 256)), dim3(256), 0, stream, job_d, kb, B, Y);
+  }
+  for (int kb = job.nblk - 1; kb >= 0; --kb)
+    hipLaunchKernelGGL(k_solve_bwd<RR>, dim3(std::max(1, (kb * NB + 255) / 256)), dim3(256), 0, stream, job_d, kb, Y, B);
+  int fail = 0;
+  (void)hipMemcpyAsync(&fail, fail_d, sizeof(int), hipMemcpyDeviceToHost, stream);
+  (void)hipStreamSynchronize(stream);
+  (void)hipFree(Linv); (void)hipFree(fail_d); (void)hipFree(job_d);
+  return fail;
+}
+template int dense_spd_solve<3>(hipStream_t, double *, int, double *, double *);
+
 int dense_spd_inverse(hipStream_t stream, double *A, double *work, double *M, int N) {
   return dense_spd_inverse_batched(stream, 1, &A, &work, &M, &N) & 0xffffff;
 }

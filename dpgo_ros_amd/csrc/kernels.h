@@ -92,4 +92,9 @@ int dense_spd_inverse(hipStream_t stream, double *A, double *work, double *M, in
 int dense_spd_inverse_batched(hipStream_t stream, int count, double *const *A, double *const *work, double *const *M,
                               const int *N);
 
+// A X^T = B^T for RR right-hand sides from the Cholesky factor only (A destroyed; the solution overwrites B [N][RR];
+// Y [N][RR] is scratch).  Returns 0, or the (1-based) failing pivot.
+template <int RR>
+int dense_spd_solve(hipStream_t stream, double *A, int N, double *B, double *Y);
+
 }  // namespace dpgo
