@@ -41,48 +41,71 @@ __device__ __forceinline__ double rsqrt_nr(double d) {
 
 // factor the nb x nb diagonal block at (k0,k0) in place and write its inverse (lower, dense NB x NB
 // column-major, zero padded) to Linv.  ONE wave (lane = threadIdx.x & 63), lane i < NB keeps row i of the block in
-// registers.  Left-looking: column k of L needs row k of the finished part, L[k][0..k), which lane k owns -- it is
-// broadcast through scalar registers (v_readlane), so the whole factorisation is register code without LDS or
-// barriers, and 1 / sqrt comes from v_rsq_f64 + two Newton steps.  The inverse W = L^-1 is formed the same way (lane j
-// owns column j of W).  It is a chain of ~2 x NB^2 / 2 dependent multiply-adds either way: 30 us as a kernel of its own
-// (measured: LDS column exchange 32 us, v_readlane 30 us, rolled LDS loops 48 us), which is why the trailing update
-// of step k runs it for step k + 1 in the workgroup that owns the next diagonal tile, under the rest of the update.
-__device__ __forceinline__ void potrf_diag_body(const InvJob &jb_, int kb, int *fail, int z) {
+// registers; `cols` = NB x NB doubles of LDS.
+// RIGHT-looking, columns exchanged through LDS: once column k is final (one v_readlane broadcast of the pivot, rsqrt from
+// v_rsq_f64 + two Newton steps, one scale) the lanes leave it in LDS and every trailing column j > k takes
+//   row[j] -= L[i][k] L[j][k]        (L[j][k]: a broadcast ds_read, the same address in every lane)
+// -- NB - 1 - k multiply-adds that do not depend on each other.  The inverse W = L^-1 (lane j owns column j) runs the
+// same way from the columns left in LDS: once w[k] is final, w[i] -= L[i][k] w[k] for all i > k.
+// History: the left-looking form (each column's sum accumulated serially, operands through v_readlane: ~8000
+// instructions) took 30 us, 11 of them in 32 predicated loads that were each waited for on their own.
+__device__ __forceinline__ void potrf_diag_body(const InvJob &jb_, int kb, int *fail, int z, double *cols) {
   double *A = jb_.A;
   const int N = jb_.N, k0 = kb * NB, nb = min(NB, N - k0);
   double *Linv = jb_.Linv + (size_t)kb * NB * NB;
   const int lane = threadIdx.x & 63;
   const bool own = lane < NB;
+  const int ls = min(lane, NB - 1);  // LDS slot of this lane (lanes >= NB shadow the last one and never store)
+  // straight-line loads (a predicated load is waited for on its own): every lane reads NB values from clamped, valid
+  // addresses, the padding is selected afterwards
   double row[NB];
+  {
+    const int ll = min(lane, nb - 1);
+    double raw[NB];
 #pragma unroll
-  for (int j = 0; j < NB; ++j)
-    row[j] = (own && lane < nb && j < nb && j <= lane) ? A[(size_t)(k0 + j) * N + k0 + lane] : ((own && j == lane) ? 1.0 : 0.0);
+    for (int j = 0; j < NB; ++j) raw[j] = A[(size_t)(k0 + min(j, nb - 1)) * N + k0 + ll];
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+      row[j] = (own && lane < nb && j < nb && j <= lane) ? raw[j] : ((own && j == lane) ? 1.0 : 0.0);
+  }
   double idiag[NB];  // 1 / L[k][k], wave-uniform
 #pragma unroll
   for (int k = 0; k < NB; ++k) {
-    // row[k] <- A[i][k] - sum_{m<k} L[i][m] L[k][m]   (lanes i >= k; the others hold zeros / unused values)
-    double s = row[k];
-#pragma unroll
-    for (int m = 0; m < k; ++m) s -= row[m] * lane_bcast(row[m], k);
-    double d = lane_bcast(s, k);
+    double d = lane_bcast(row[k], k);
     if (!(d > 0.0)) { if (lane == 0) fail[z] = k0 + k + 1; d = 1.0; }
     const double inv = rsqrt_nr(d);
     idiag[k] = inv;
-    row[k] = (lane == k) ? d * inv : ((lane > k) ? s * inv : 0.0);
+    const double lik = (lane == k) ? d * inv : ((lane > k) ? row[k] * inv : 0.0);  // L[i][k]
+    row[k] = lik;
+    if (own) cols[k * NB + ls] = lik;
+    // (DS operations of one wave execute in order; the fences keep the compiler from moving the reads above the write)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double lj[NB];
+#pragma unroll
+    for (int j = k + 1; j < NB; ++j) lj[j] = cols[k * NB + j];
+#pragma unroll
+    for (int j = k + 1; j < NB; ++j) row[j] -= lik * lj[j];  // (lanes i < j hold unused values there)
   }
   if (own && lane < nb) {
 #pragma unroll
     for (int j = 0; j < NB; ++j)
       if (j < nb && j <= lane) A[(size_t)(k0 + j) * N + k0 + lane] = row[j];
   }
-  // inverse: lane j solves L w = e_j by forward substitution (w[i] = 0 for i < j); L[i][k] = lane i's row[k]
+  // (the substitution in a loop of its own: merged into the loop above it costs registers and runs 30 % slower)
   double w[NB];
 #pragma unroll
-  for (int i = 0; i < NB; ++i) {
-    double sres = (i == lane) ? 1.0 : 0.0;
+  for (int i = 0; i < NB; ++i) w[i] = (i == lane) ? 1.0 : 0.0;
 #pragma unroll
-    for (int k = 0; k < i; ++k) sres -= lane_bcast(row[k], i) * w[k];
-    w[i] = (i >= lane) ? sres * idiag[i] : 0.0;
+  for (int k = 0; k < NB; ++k) {
+    const double wk = (k >= lane) ? w[k] * idiag[k] : 0.0;
+    w[k] = wk;
+    double li[NB];
+#pragma unroll
+    for (int i = k + 1; i < NB; ++i) li[i] = cols[k * NB + i];
+#pragma unroll
+    for (int i = k + 1; i < NB; ++i) w[i] -= li[i] * wk;
   }
   if (own) {
 #pragma unroll
@@ -93,7 +116,32 @@ __device__ __forceinline__ void potrf_diag_body(const InvJob &jb_, int kb, int *
 __global__ __launch_bounds__(64) void k_potrf_diag(const InvJob *jobs, int kb, int *fail) {
   const InvJob jb_ = jobs[blockIdx.z];
   if (kb >= jb_.nblk) return;
-  potrf_diag_body(jb_, kb, fail, (int)blockIdx.z);
+  __shared__ double cols[NB * NB];
+  potrf_diag_body(jb_, kb, fail, (int)blockIdx.z, cols);
+}
+
+// Staging of one NB x 64 operand tile (8 elements per thread): straight-line.  `at(t)` returns a CLAMPED, always valid
+// address for element t, `ok(t)` whether the element exists, `put(t, v)` stores it (zero where it does not).  A load
+// under a predicate is waited for on its own -- eight dependent round trips per tile, which was most of these
+// kernels' time; this way all loads of a stage are in flight together.
+template <class At, class Ok, class Put>
+__device__ __forceinline__ void stage_tile(int tid, At at, Ok ok, Put put) {
+  double v[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) v[q] = *at(tid + 256 * q);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) put(tid + 256 * q, ok(tid + 256 * q) ? v[q] : 0.0);
+}
+template <class At1, class At2, class Ok1, class Ok2, class Put1, class Put2>
+__device__ __forceinline__ void stage_tiles2(int tid, At1 at1, Ok1 ok1, Put1 put1, At2 at2, Ok2 ok2, Put2 put2) {
+  double v[8], w[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { v[q] = *at1(tid + 256 * q); w[q] = *at2(tid + 256 * q); }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    put1(tid + 256 * q, ok1(tid + 256 * q) ? v[q] : 0.0);
+    put2(tid + 256 * q, ok2(tid + 256 * q) ? w[q] : 0.0);
+  }
 }
 
 // panel: A[i, k0:k0+nb] <- A[i, k0:k0+nb] Linv^T  for i >= k0 + nb.  Workgroup = 64 rows x 4 column octets:
@@ -110,10 +158,11 @@ __global__ __launch_bounds__(256) void k_trsm_panel(const InvJob *jobs, int kb) 
   const int tid = threadIdx.x, r = tid & 63, cq = tid >> 6;
   const int i0 = k0 + nb + blockIdx.x * 64;
   for (int t = tid; t < NB * NB; t += 256) Ls[t] = Linv[t];
-  for (int t = tid; t < 64 * NB; t += 256) {
-    const int k = t >> 6, ii = t & 63;  // consecutive threads = consecutive rows of one column: coalesced
-    Rs[ii][k] = (k < nb && i0 + ii < N) ? A[(size_t)(k0 + k) * N + i0 + ii] : 0.0;
-  }
+  static_assert(NB * 64 == 8 * 256, "stage_tile: 8 elements per thread");
+  stage_tile(tid,  // consecutive threads = consecutive rows of one column: coalesced
+             [&](int t) { return A + (size_t)(k0 + min(t >> 6, nb - 1)) * N + min(i0 + (t & 63), N - 1); },
+             [&](int t) { return (t >> 6) < nb && i0 + (t & 63) < N; },
+             [&](int t, double v) { Rs[t & 63][t >> 6] = v; });
   __syncthreads();
   const int i = i0 + r;
   if (i >= N) return;
@@ -176,30 +225,45 @@ __global__ __launch_bounds__(256) void k_syrk(const InvJob *jobs, int kb, int *f
   __shared__ double As[NB][65], Bs[NB][65];
   const int i0 = s0 + 64 * bi, j0 = s0 + 64 * bj;
   const int tid = threadIdx.x;
-  for (int t = tid; t < NB * 64; t += 256) {
-    const int k = t >> 6, ii = t & 63;
-    As[k][ii] = (k < nb && i0 + ii < N) ? A[(size_t)(k0 + k) * N + i0 + ii] : 0.0;
-    Bs[k][ii] = (k < nb && j0 + ii < N) ? A[(size_t)(k0 + k) * N + j0 + ii] : 0.0;
-  }
+  stage_tiles2(tid,
+               [&](int t) { return A + (size_t)(k0 + min(t >> 6, nb - 1)) * N + min(i0 + (t & 63), N - 1); },
+               [&](int t) { return (t >> 6) < nb && i0 + (t & 63) < N; },
+               [&](int t, double v) { As[t >> 6][t & 63] = v; },
+               [&](int t) { return A + (size_t)(k0 + min(t >> 6, nb - 1)) * N + min(j0 + (t & 63), N - 1); },
+               [&](int t) { return (t >> 6) < nb && j0 + (t & 63) < N; },
+               [&](int t, double v) { Bs[t >> 6][t & 63] = v; });
   __syncthreads();
   TileAcc acc;
   tile_zero(acc);
   tile_mac(As, Bs, tid, acc);
+  {
+    // read-modify-write of the tile, straight-line as well: all 16 reads in flight, then the stores
+    double old[2][2][4];
 #pragma unroll
-  for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
-    for (int v = 0; v < 2; ++v)
+      for (int v = 0; v < 2; ++v)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int i = i0 + tile_row(tid, u), j = j0 + tile_col(tid, v, q);
-        if (i < N && j < N && i >= j) A[(size_t)j * N + i] -= acc.c[u][v][q];
-      }
+        for (int q = 0; q < 4; ++q) {
+          const int i = min(i0 + tile_row(tid, u), N - 1), j = min(j0 + tile_col(tid, v, q), N - 1);
+          old[u][v][q] = A[(size_t)j * N + i];
+        }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int v = 0; v < 2; ++v)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int i = i0 + tile_row(tid, u), j = j0 + tile_col(tid, v, q);
+          if (i < N && j < N && i >= j) A[(size_t)j * N + i] = old[u][v][q] - acc.c[u][v][q];
+        }
+  }
   if (bi == 0 && bj == 0 && kb + 1 < jb_.nblk) {
     // this workgroup has just finished the tile that holds the next diagonal block (s0, s0): factor it here, under the
     // rest of the trailing update, instead of in a launch of its own on the critical path
     __threadfence();
     __syncthreads();
-    if (tid < 64) potrf_diag_body(jb_, kb + 1, fail, (int)blockIdx.z);
+    if (tid < 64) potrf_diag_body(jb_, kb + 1, fail, (int)blockIdx.z, &As[0][0]);  // (the operand tiles are done with)
   }
 }
 
@@ -243,27 +307,38 @@ __global__ __launch_bounds__(256) void k_trtri_upd(const InvJob *jobs, int ib) {
   const int i0 = k0 + NB + 64 * blockIdx.x, j0 = 64 * blockIdx.y;  // rows below block row ib, columns up to it
   const int jend = min(N, k0 + NB);
   const int tid = threadIdx.x;
-  for (int t = tid; t < NB * 64; t += 256) {
-    const int k = t >> 6, ii = t & 63;
-    As[k][ii] = (k < kn && i0 + ii < N) ? L[(size_t)(k0 + k) * N + i0 + ii] : 0.0;  // L[i, k0 + k]
-  }
-  for (int t = tid; t < NB * 64; t += 256) {
-    const int k = t & 31, jj = t >> 5;
-    Bs[k][jj] = (k < kn && j0 + jj < jend) ? W[(size_t)(j0 + jj) * N + k0 + k] : 0.0;  // W[k0 + k, j]
-  }
+  stage_tiles2(tid,
+               [&](int t) { return L + (size_t)(k0 + min(t >> 6, kn - 1)) * N + min(i0 + (t & 63), N - 1); },  // L[i, k0 + k]
+               [&](int t) { return (t >> 6) < kn && i0 + (t & 63) < N; },
+               [&](int t, double v) { As[t >> 6][t & 63] = v; },
+               [&](int t) { return W + (size_t)min(j0 + (t >> 5), jend - 1) * N + k0 + min(t & 31, kn - 1); },  // W[k0 + k, j]
+               [&](int t) { return (t & 31) < kn && j0 + (t >> 5) < jend; },
+               [&](int t, double v) { Bs[t & 31][t >> 5] = v; });
   __syncthreads();
   TileAcc acc;
   tile_zero(acc);
   tile_mac(As, Bs, tid, acc);
+  {
+    double old[2][2][4];
 #pragma unroll
-  for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
-    for (int v = 0; v < 2; ++v)
+      for (int v = 0; v < 2; ++v)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int i = i0 + tile_row(tid, u), j = j0 + tile_col(tid, v, q);
-        if (i < N && j < jend) W[(size_t)j * N + i] += acc.c[u][v][q];
-      }
+        for (int q = 0; q < 4; ++q) {
+          const int i = min(i0 + tile_row(tid, u), N - 1), j = min(j0 + tile_col(tid, v, q), jend - 1);
+          old[u][v][q] = W[(size_t)j * N + i];
+        }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int v = 0; v < 2; ++v)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int i = i0 + tile_row(tid, u), j = j0 + tile_col(tid, v, q);
+          if (i < N && j < jend) W[(size_t)j * N + i] = old[u][v][q] + acc.c[u][v][q];
+        }
+  }
 }
 
 // M = W^T W for lower-triangular W (upper part of W must be zero); tiles with bi >= bj, mirrored.
@@ -281,11 +356,13 @@ __global__ __launch_bounds__(256) void k_wtw(const InvJob *jobs) {
   tile_zero(acc);
   for (int kk = (i0 / NB) * NB; kk < N; kk += NB) {
     __syncthreads();
-    for (int t = tid; t < NB * 64; t += 256) {
-      const int k = t & 31, ii = t >> 5;
-      As[k][ii] = (kk + k < N && i0 + ii < N) ? W[(size_t)(i0 + ii) * N + kk + k] : 0.0;
-      Bs[k][ii] = (kk + k < N && j0 + ii < N) ? W[(size_t)(j0 + ii) * N + kk + k] : 0.0;
-    }
+    stage_tiles2(tid,
+                 [&](int t) { return W + (size_t)min(i0 + (t >> 5), N - 1) * N + min(kk + (t & 31), N - 1); },
+                 [&](int t) { return kk + (t & 31) < N && i0 + (t >> 5) < N; },
+                 [&](int t, double v) { As[t & 31][t >> 5] = v; },
+                 [&](int t) { return W + (size_t)min(j0 + (t >> 5), N - 1) * N + min(kk + (t & 31), N - 1); },
+                 [&](int t) { return kk + (t & 31) < N && j0 + (t >> 5) < N; },
+                 [&](int t, double v) { Bs[t & 31][t >> 5] = v; });
     __syncthreads();
     tile_mac(As, Bs, tid, acc);
   }
