@@ -446,28 +446,35 @@ __global__ __launch_bounds__(256) void k_solve_fwd(const InvJob *jobs, int kb, d
   const InvJob jb_ = jobs[0];
   const int N = jb_.N, k0 = kb * NB, nb = min(NB, N - k0);
   const double *Linv = jb_.Linv + (size_t)kb * NB * NB;  // [col j][row i] = W[i][j], W = inverse of the diagonal block
-  __shared__ double ys[NB][RR];
+  __shared__ double ys[NB][RR], Ws[NB * NB], bs[NB][RR];
   const int tid = threadIdx.x;
+  // the block's inverse factor and right-hand sides through LDS, straight-line (loads inside a data-dependent loop
+  // are waited for one by one: 14 us per step)
+#pragma unroll
+  for (int q = 0; q < NB * NB / 256; ++q) Ws[tid + 256 * q] = Linv[tid + 256 * q];
+  if (tid < NB * RR) bs[tid / RR][tid % RR] = B[(size_t)(k0 + min(tid / RR, nb - 1)) * RR + tid % RR];
+  __syncthreads();
   if (tid < NB * RR) {
     const int i = tid / RR, a = tid - i * RR;
     double s = 0;
-    if (i < nb)
-      for (int j = 0; j <= i; ++j) s += Linv[j * NB + i] * B[(size_t)(k0 + j) * RR + a];
-    ys[i][a] = s;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) s += (j <= i && j < nb) ? Ws[j * NB + i] * bs[j][a] : 0.0;
+    ys[i][a] = (i < nb) ? s : 0.0;
   }
   __syncthreads();
   const int i = k0 + nb + (int)blockIdx.x * 256 + tid;
   if (i < N) {
-    double acc[RR];
+    double l[NB], acc[RR], old[RR];
 #pragma unroll
-    for (int a = 0; a < RR; ++a) acc[a] = 0;
-    for (int k = 0; k < nb; ++k) {
-      const double l = jb_.A[(size_t)(k0 + k) * N + i];
+    for (int k = 0; k < NB; ++k) l[k] = jb_.A[(size_t)(k0 + min(k, nb - 1)) * N + i];
 #pragma unroll
-      for (int a = 0; a < RR; ++a) acc[a] += l * ys[k][a];
-    }
+    for (int a = 0; a < RR; ++a) { acc[a] = 0; old[a] = B[(size_t)i * RR + a]; }
 #pragma unroll
-    for (int a = 0; a < RR; ++a) B[(size_t)i * RR + a] -= acc[a];
+    for (int k = 0; k < NB; ++k)
+#pragma unroll
+      for (int a = 0; a < RR; ++a) acc[a] += l[k] * ys[k][a];  // (rows k >= nb of ys are zero)
+#pragma unroll
+    for (int a = 0; a < RR; ++a) B[(size_t)i * RR + a] = old[a] - acc[a];
   }
   // y goes to its own array: the rows of block kb in B are still being read by the other workgroups of this launch
   if (blockIdx.x == gridDim.x - 1 && tid < nb * RR) Y[(size_t)k0 * RR + tid] = ys[tid / RR][tid % RR];
@@ -478,29 +485,34 @@ __global__ __launch_bounds__(256) void k_solve_bwd(const InvJob *jobs, int kb, d
   const InvJob jb_ = jobs[0];
   const int N = jb_.N, k0 = kb * NB, nb = min(NB, N - k0);
   const double *Linv = jb_.Linv + (size_t)kb * NB * NB;
-  __shared__ double xs[NB][RR];
+  __shared__ double xs[NB][RR], Ws[NB * NB], ysb[NB][RR];
   const int tid = threadIdx.x;
+#pragma unroll
+  for (int q = 0; q < NB * NB / 256; ++q) Ws[tid + 256 * q] = Linv[tid + 256 * q];
+  if (tid < NB * RR) ysb[tid / RR][tid % RR] = Y[(size_t)(k0 + min(tid / RR, nb - 1)) * RR + tid % RR];
+  __syncthreads();
   if (tid < NB * RR) {
     const int j = tid / RR, a = tid - j * RR;
     double s = 0;
-    if (j < nb)
-      for (int i = j; i < nb; ++i) s += Linv[j * NB + i] * Y[(size_t)(k0 + i) * RR + a];  // (Linv^T y)_j
-    xs[j][a] = s;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) s += (i >= j && i < nb) ? Ws[j * NB + i] * ysb[i][a] : 0.0;  // (Linv^T y)_j
+    xs[j][a] = (j < nb) ? s : 0.0;
   }
   __syncthreads();
   const int c = (int)blockIdx.x * 256 + tid;  // a column (= row of the unknown) above the block
   if (c < k0) {
-    double acc[RR];
-#pragma unroll
-    for (int a = 0; a < RR; ++a) acc[a] = 0;
+    double l[NB], acc[RR], old[RR];
     const double *col = jb_.A + (size_t)c * N + k0;  // L[k0 + r][c], r = 0 .. nb-1: contiguous
-    for (int r = 0; r < nb; ++r) {
-      const double l = col[r];
 #pragma unroll
-      for (int a = 0; a < RR; ++a) acc[a] += l * xs[r][a];
-    }
+    for (int r = 0; r < NB; ++r) l[r] = col[min(r, nb - 1)];
 #pragma unroll
-    for (int a = 0; a < RR; ++a) Y[(size_t)c * RR + a] -= acc[a];
+    for (int a = 0; a < RR; ++a) { acc[a] = 0; old[a] = Y[(size_t)c * RR + a]; }
+#pragma unroll
+    for (int r = 0; r < NB; ++r)
+#pragma unroll
+      for (int a = 0; a < RR; ++a) acc[a] += l[r] * xs[r][a];  // (rows r >= nb of xs are zero)
+#pragma unroll
+    for (int a = 0; a < RR; ++a) Y[(size_t)c * RR + a] = old[a] - acc[a];
   }
   if (blockIdx.x == gridDim.x - 1 && tid < nb * RR) Xk[(size_t)k0 * RR + tid] = xs[tid / RR][tid % RR];
 }
