@@ -189,6 +189,9 @@ int enqueue_iterate(dpgo_team *t, int li, int do_opt) {
   const bool fused = do_opt && p.method == DPGO_METHOD_RGD && p.rgd_use_preconditioner && !restart;
   OptFlags fl;
   fl.fused = fused;
+  // a team that imported peers (dpgo_team_import_peer) has no messages to fill the neighbour slabs from: its per-agent
+  // iterate reads every neighbour that is readable in place (imported or co-resident) in place, like the team schedule
+  fl.pull = t->peers.empty() ? 0 : 1;
   int rc = 0;
   a.rel_src = 0;
   if (do_opt == 2) {

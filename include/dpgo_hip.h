@@ -246,7 +246,9 @@ int dpgo_team_time_kernel(dpgo_team_t *t, int id, int which, int reps, double *a
 /* peer access for one-process-per-GPU runs of the asynchronous mode (src/PGOAgentROS.cpp:119-127): a robot's X / Y arrays
  * exported as a 64-byte HIP IPC handle (+ the offsets of X and Y in doubles and its pose count), imported by the
  * processes that hold its neighbours; from then on its public poses are read in place (xGMI peer loads), one-sided:
- * no PublicPoses message, no rendezvous.  The exporting process must outlive the importers' use. */
+ * no PublicPoses message, no rendezvous.  The exporting process must outlive the importers' use.  Once a team has imported
+ * a peer, dpgo_agent_iterate reads every neighbour that is readable in place (imported or co-resident) from its owner's
+ * arrays instead of from what dpgo_agent_update_neighbor_poses last supplied. */
 int dpgo_agent_export_state(dpgo_team_t *t, int id, unsigned char *handle64, long long *offset_x, long long *offset_y, int *n);
 int dpgo_team_import_peer(dpgo_team_t *t, int robot_id, const unsigned char *handle64, long long offset_x, long long offset_y, int n);
 /* diagnostic: hand-off words of an agent's one-launch RTR solve (rtr_fused.hip; phase stamps in trace builds) */
