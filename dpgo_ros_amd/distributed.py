@@ -332,7 +332,9 @@ class DistributedRBCD:
         d = self.dist
         err = None
         try:
-            mine = self.be.export_states()
+            mine = self.be.export_states() if hasattr(self.be, "export_states") else {}
+            if not hasattr(self.be, "export_states"):
+                err = "backend has no peer access"
         except RuntimeError as e:  # agree on the outcome before anyone enters another collective
             mine, err = {}, str(e)
         everyone = [None] * self.world

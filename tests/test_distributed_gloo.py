@@ -312,6 +312,9 @@ def _worker_delay(rank, world, port, cfg, outdir):
     be = OracleBackend(mp, params, mine, O.odometry_init(m, n), O.fixed_stiefel(5), {a: a * per for a in range(N)})
     drv = DistributedRBCD(dist, be, mp, N, kw.get("acceleration", 0), rank, world, max_delayed_iterations=delay)
     drv.exchange_all()
+    # peer access is a device feature: on a backend without it every rank must learn so together and carry on
+    # (bench.py relies on this agreement to skip its free-running leg instead of hanging in a collective)
+    assert drv.enable_peer_access() is False and "peer access" in drv.peer_error
     m0 = drv.messages
     for _ in range(iters):
         drv.step()
