@@ -51,6 +51,8 @@ dpgo_team_t *dpgo_team_create(int device, const dpgo_params_t *p, int num_local,
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess) t->num_cus = cus;
     const char *e = std::getenv("DPGO_FUSED_ITER");
     if (e) t->use_fused = (e[0] == '1') ? 1 : 0;
+    const char *e3 = std::getenv("DPGO_BAKE_SEL");
+    if (e3) t->bake_sel = (e3[0] == '0') ? 0 : 1;
     const char *e2 = std::getenv("DPGO_FUSED_RTR");
     if (e2) t->use_fused_rtr = (e2[0] == '0') ? 0 : 1;
     if (t->d_nest_all.alloc(std::max(1, num_local)) ||
@@ -760,6 +762,7 @@ int dpgo_team_set_schedule(dpgo_team_t *t, const int *order, int len) {
     t->sched.push_back(it->second);
   }
   t->descs_dirty = true;
+  t->graph_valid = false;  // (captured runs bake the schedule into their launches)
   return 0;
 }
 
@@ -838,9 +841,16 @@ static int team_run_impl(dpgo_team_t *t, int iters, bool prepare_only) {
   // iterations that follow.  Pipelined teams have no windows: restart iterations are part of the uniform sequence
   // (lead is never set).  Two instances per key alternate, so that a launch never has to wait for the previous
   // replay of the same executable graph.
-  auto graph_for = [&](bool lead, int B, hipGraphExec_t *out) -> int {
-    const int base = ((lead ? 1 : 0) + 2 * B) * 2;
+  // Pipelined teams with a short schedule period bake the agent of every iteration into its launches (one graph per
+  // phase of the schedule): the kernels then address the agent's descriptor from a kernel argument instead of through
+  // team->cur_sel / next_sel, one dependent round trip less in each prologue.
+  const int P = (int)t->sched.size();
+  const bool bake = t->bake_sel && P >= 1 && P <= 8;
+  auto graph_for = [&](bool lead, int B, int iter0, hipGraphExec_t *out) -> int {
+    const int phase = bake ? iter0 % P : -1;
+    const int base = (((lead ? 1 : 0) + 2 * B) * 16 + phase + 1) * 2;
     const int key = base + (t->graph_flip[base / 2] ^= 1);
+    auto sel_at = [&](int rep) { return bake ? t->sched[(size_t)((iter0 + rep) % P)] : -1; };
     auto it = t->graphs.find(key);
     if (it != t->graphs.end()) { *out = it->second; return 0; }
     hipGraph_t g = nullptr;
@@ -869,11 +879,11 @@ static int team_run_impl(dpgo_team_t *t, int iters, bool prepare_only) {
           launch_iter_rgd(c, mn, t->d_nest_all.p, t->d_bar.p, t->h_bar_err, rep == 0, p.rgd_stepsize, p.num_robots, p.restart_interval, ahead);
           continue;
         }
-        launch_eval_stats(c, mn, rep == 0, 1, 0, p.num_robots, p.restart_interval);
-        launch_precond(c, -1, mn, PM_RGD_, B_X, B_GF, B_Z, 0, 0, p.rgd_stepsize, 1, p.num_robots, 2, p.restart_interval,
+        launch_eval_stats(c, mn, rep == 0, 1, 0, p.num_robots, p.restart_interval, sel_at(rep), -1);
+        launch_precond(c, sel_at(rep), mn, PM_RGD_, B_X, B_GF, B_Z, 0, 0, p.rgd_stepsize, 1, p.num_robots, 2, p.restart_interval,
                        ahead);
       }
-      launch_eval_stats(c, mn, 0, 0, 1, p.num_robots, p.restart_interval);
+      launch_eval_stats(c, mn, 0, 0, 1, p.num_robots, p.restart_interval, -1, sel_at(B - 1));
     } else if (rc == 0 && B > 0 && p.acceleration) {
       // 3 launches per iteration: [statistics of iteration k-1 + Nesterov step of iteration k] in one
       // heterogeneous kernel, cost/gradient (+ G from the neighbours' Y), preconditioner + RGD step +
@@ -923,10 +933,10 @@ static int team_run_impl(dpgo_team_t *t, int iters, bool prepare_only) {
       fusedn = std::max(0, std::min(fusedn, dpgo_team::MAX_GRAPH_ITERS));
       batch = fusedn + (restart ? 1 : 0);
       hipGraphExec_t ge = nullptr;
-      const int grc = graph_for(restart, fusedn, &ge);
+      const int grc = graph_for(restart, fusedn, cur_iter, &ge);
       if (grc) return grc;
       if (prepare_only) {
-        const int grc2 = graph_for(restart, fusedn, &ge);  // the other instance; leaves the alternation where it was
+        const int grc2 = graph_for(restart, fusedn, cur_iter, &ge);  // the other instance; leaves the alternation where it was
         if (grc2) return grc2;
         cur_iter += batch;
         k += batch;

@@ -33,8 +33,10 @@ void launch_hess(const LaunchCtx &c, int sel, int max_n, int xb, int egb, int vb
 void launch_precond(const LaunchCtx &c, int sel, int max_n, int mode, int xb, int vb, int zb, int sp, int max_inner,
                     double step, int accel, int num_robots, int advance = 0, int restart_interval = 1, int ahead = 0);
 // pipelined accelerated RGD iterations: evaluation of iteration k || statistics of k-1 || bookkeeping of k-1
+// eval_sel / stats_sel >= 0: the local agent of the evaluation / statistics half, known to the host (graphs that bake
+// the schedule in); -1: read from the device-side schedule state
 void launch_eval_stats(const LaunchCtx &c, int max_n, int first, int has_eval, int has_stats, int num_robots,
-                       int restart_interval);
+                       int restart_interval, int eval_sel = -1, int stats_sel = -1);
 void launch_tcg_hv(const LaunchCtx &c, int sel, int max_n, int sp, int max_inner);
 void launch_retract(const LaunchCtx &c, int sel, int max_n, int xb, int eb, double scale, int ob, int guard_state);
 void launch_project_raw(const LaunchCtx &c, const double *X, double *out, int n);

@@ -192,7 +192,8 @@ __global__ __launch_bounds__(64) void k_stats_nest(const AgentDev *agents, TeamD
 // only the step kernel reads.
 template <int R>
 __global__ __launch_bounds__(64) void k_eval_stats(const AgentDev *agents, TeamDev *team, int nb_eval, int first,
-                                                   int has_eval, int has_stats, int num_robots, int restart_interval) {
+                                                   int has_eval, int has_stats, int num_robots, int restart_interval,
+                                                   int eval_sel, int stats_sel) {
   constexpr int PPB = 64 / R;
   __shared__ double Ysh[PPB * 4 * R], Wsh[PPB * 4 * R];
   const int b = (int)blockIdx.x;
@@ -205,9 +206,10 @@ __global__ __launch_bounds__(64) void k_eval_stats(const AgentDev *agents, TeamD
     return;
   }
   if (has_eval && b < nb_eval) {
-    eval_body<R>(agents, team, first ? -1 : -6, B_X, B_EGRAD, B_GF, PART_C, 2, 1, b, Ysh, Wsh);
+    eval_body<R>(agents, team, eval_sel >= 0 ? eval_sel : (first ? -1 : -6), B_X, B_EGRAD, B_GF, PART_C, 2, 1, b, Ysh, Wsh);
   } else if (has_stats) {
-    eval_body<R>(agents, team, -5, B_X2, B_EGRAD2, B_GF2, PART_A, 0, 0, b - (has_eval ? nb_eval : 0), Ysh, Wsh);
+    eval_body<R>(agents, team, stats_sel >= 0 ? stats_sel : -5, B_X2, B_EGRAD2, B_GF2, PART_A, 0, 0,
+                 b - (has_eval ? nb_eval : 0), Ysh, Wsh);
   }
 }
 
@@ -312,11 +314,11 @@ void launch_hess(const LaunchCtx &c, int sel, int max_n, int xb, int egb, int vb
 }
 
 void launch_eval_stats(const LaunchCtx &c, int max_n, int first, int has_eval, int has_stats, int num_robots,
-                       int restart_interval) {
+                       int restart_interval, int eval_sel, int stats_sel) {
   const int nb = spmm_grid(c.r, max_n);
   const int grid = nb * ((has_eval ? 1 : 0) + (has_stats ? 1 : 0)) + 1;
   DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_eval_stats<R>, dim3(grid), dim3(64), 0, c.stream, c.agents, c.team, nb, first,
-                                          has_eval, has_stats, num_robots, restart_interval));
+                                          has_eval, has_stats, num_robots, restart_interval, eval_sel, stats_sel));
 }
 
 void launch_tcg_hv(const LaunchCtx &c, int sel, int max_n, int sp, int max_inner) {

@@ -183,6 +183,7 @@ struct dpgo_team {
   dpgo_host::DevBuf<unsigned long long> d_bar;
   int *h_bar_err = nullptr;
   int num_cus = 0;
+  int bake_sel = 1;  // DPGO_BAKE_SEL=0: the graphs of the pipelined iteration select their agent on the device only
   bool rtr_validated = false;  // a one-launch solve has completed on this device (its grid is resident at once)
   int use_fused_rtr = 1;  // DPGO_FUSED_RTR=0 keeps the launch-per-step RTR sequence (solve.hip) for every agent
   int use_fused = 0;  // DPGO_FUSED_ITER=1 selects the one-launch iteration (measured 27 us against 25 for two launches on
