@@ -39,9 +39,11 @@ constexpr int RB_TRACE = 17 * RB_LINE + 2;
 #define RTR_FINE(k) do { } while (0)
 #endif
 
-__device__ __forceinline__ double ld_c(const double *p) {
-  return __hip_atomic_load(const_cast<double *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
+// Publish / read flavours, kept as build switches because they were measured against each other (us per tCG iteration,
+// DESIGN.md section 4): write-through stores + sc1 loads (default) 17.0 | write-through stores + plain loads behind an
+// agent acquire per hand-off (DPGO_RTR_PLAIN_LD=1) 18.0 | plain stores + agent release per hand-off
+// (DPGO_RTR_PLAIN_ST=1) 22.5-25.  DPGO_RTR_LDAUX is the cache policy of the reads (16 = sc1; 2 = nt and 18 = sc1 nt
+// are slower; 1 = sc0 is faster and NOT valid: it hits this CU's L1).
 #ifndef DPGO_RTR_PLAIN_ST
 #define DPGO_RTR_PLAIN_ST 0
 #endif

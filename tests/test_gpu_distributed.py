@@ -40,7 +40,7 @@ def test_bench_multi_rank_path_runs_under_rccl_at_world_size_one():
 def _problem(mode):
     N = 3
     m, _, n = load("smallGrid3D", 1)
-    if mode in ("ticks", "peer_free"):
+    if mode in ("ticks", "peer_free", "peer_agent_api"):
         kw = dict(method=1, rgd_stepsize=0.05, acceleration=0)
         mo = m
     elif mode == "peer_sync":
@@ -78,6 +78,21 @@ def _worker(rank, world, port, mode, outdir):
         be.sync()
         dist.barrier()
         extra["messages"] = drv.messages
+    elif mode == "peer_agent_api":
+        drv.enable_peer_access()
+        # per-agent iterate on a team with imported peers: no update_neighbor_poses anywhere, every neighbour is read
+        # in place; the ranks rendezvous around each iterate(true)
+        for k in range(3 * N):
+            sel = k % N
+            be.sync()
+            dist.barrier()
+            if sel in mine:
+                be.team.agents[sel].iterate(True)
+            be.sync()
+            dist.barrier()
+            for a in mine:
+                if a != sel:
+                    be.team.agents[a].iterate(False)
     elif mode == "peer_free":
         c0 = drv.global_cost(torch, "cpu")
         drv.enable_peer_access()
@@ -174,3 +189,16 @@ def test_peer_access_free_running_asynchronous_mode_descends():
     c0, c = float(outs[0]["cost0"]), float(outs[0]["cost"])
     assert np.isfinite(c) and c < 0.05 * c0
     assert c <= 1.05 * ref.cost() and c >= 0.5 * ref.cost()
+
+
+def test_peer_access_per_agent_iterate_reads_neighbours_in_place():
+    """dpgo_agent_iterate on teams that imported their remote neighbours: the sequential schedule with NO pose message
+    and no update_neighbor_poses call after the first exchange -- the oracle's sequential RBCD iterates"""
+    outs = _spawn("peer_agent_api")
+    N, mp, n, T, kw = _problem("peer_agent_api")
+    ref = O.Team(mp, n, O.default_params(r=5, num_robots=N, **kw))
+    ref.set_initial(T, O.fixed_stiefel(5))
+    for _ in range(3 * N):
+        ref.iterate()
+    for a in range(N):
+        assert np.abs(outs[a % 2]["X%d" % a] - ref.agents[a].get_X()).max() < 1e-7, a
