@@ -14,6 +14,9 @@ namespace dpgo {
 // 8 columns, as rtr_fused.hip's slab product does).  Measured: the stream of a 500-pose agent ends 2 us earlier inside
 // the kernel, the launch takes the same 16 us (the per-pose tail, not the stream, decides when the last workgroup
 // leaves), and agents of 625 / 1250 poses lose 25 / 19 % (one workgroup per CU instead of three).  Off.
+#ifndef DPGO_PC_KCMID
+#define DPGO_PC_KCMID 1280
+#endif
 #ifndef DPGO_PC_DIRECT
 #define DPGO_PC_DIRECT 0
 #endif
@@ -616,21 +619,23 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
 void launch_precond(const LaunchCtx &c, int sel, int max_n, int mode, int xb, int vb, int zb, int sp, int max_inner,
                     double step, int accel, int num_robots, int advance, int restart_interval, int ahead) {
   const int grid = (((4 * max_n + 7) / 8) + 7) / 8 * 8;  // multiple of 8: see the XCD-aware block order in k_precond
+#define PC_LAUNCH(M, KCV)                                                                                          \
+    DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL((k_precond<R, M, KCV>), dim3(grid, c.ny), dim3(256), 0, c.stream, c.agents,   \
+                                            c.team, sel, xb, vb, zb, sp, max_inner, step, accel, num_robots, advance,   \
+                                            restart_interval, ahead, c.nest_all))
+  // chunk size by agent size: one 2048-row chunk for agents of 257..512 poses (one round trip, one workgroup per CU);
+  // DPGO_PC_KCMID-row chunks for 513..(DPGO_PC_KCMID / 2) poses (two round trips instead of three, still three
+  // workgroups per CU); 1024-row chunks otherwise
 #define PC_CALL(M)                                                                                                  \
-  if (4 * max_n > 1024 && 4 * max_n <= 2048) {                                                                       \
-    DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL((k_precond<R, M, 2048>), dim3(grid, c.ny), dim3(256), 0, c.stream, c.agents,   \
-                                            c.team, sel, xb, vb, zb, sp, max_inner, step, accel, num_robots, advance,   \
-                                            restart_interval, ahead, c.nest_all));                                                \
-  } else {                                                                                                           \
-    DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL((k_precond<R, M, 1024>), dim3(grid, c.ny), dim3(256), 0, c.stream, c.agents,   \
-                                            c.team, sel, xb, vb, zb, sp, max_inner, step, accel, num_robots, advance,   \
-                                            restart_interval, ahead, c.nest_all));                                                \
-  }
+  if (4 * max_n > 1024 && 4 * max_n <= 2048) { PC_LAUNCH(M, 2048); }                                                  \
+  else if (DPGO_PC_KCMID > 0 && 4 * max_n > 2048 && 4 * max_n <= 2 * DPGO_PC_KCMID) { PC_LAUNCH(M, (DPGO_PC_KCMID > 0 ? DPGO_PC_KCMID : 1024)); } \
+  else { PC_LAUNCH(M, 1024); }
   if (mode == PM_PLAIN_) { PC_CALL(PM_PLAIN_); }
   else if (mode == PM_TCG_INIT_) { PC_CALL(PM_TCG_INIT_); }
   else if (mode == PM_TCG_STEP_) { PC_CALL(PM_TCG_STEP_); }
   else { PC_CALL(PM_RGD_); }
 #undef PC_CALL
+#undef PC_LAUNCH
 }
 
 }  // namespace dpgo
