@@ -1330,6 +1330,55 @@ int dpgo_team_time_kernel(dpgo_team_t *t, int id, int which, int reps, double *a
     *algorithmic_bytes = 8.0 * N4 * N4 + 7.0 * vec + 4.0 * others;
   }
   else *algorithmic_bytes = 8.0 * (16.0 * a->col.size() + 3.0 * r * 4 * n) + 4.0 * (a->col.size() + n + 1);
+  if (which == 12 || which == 13) {
+    // planning aid for DESIGN 5b: what a fork / join per iteration costs inside a hipGraph.  64 x { [plain preconditioner
+    // apply of this agent  ||  cost / gradient evaluation of the NEXT local agent]  ->  one tiny kernel } captured on
+    // two streams (which == 12), against the same three kernels in one chain (which == 13).  Stand-ins with the
+    // durations of the step kernel's stream, E1 and E2; results are not used.
+    const int other = (a->local + 1) % (int)t->ag.size();
+    const int on = t->ag[other]->n;
+    hipStream_t s2;
+    hipEvent_t ef, ej;
+    HIPC(hipStreamCreate(&s2));
+    HIPC(hipEventCreateWithFlags(&ef, hipEventDisableTiming));
+    HIPC(hipEventCreateWithFlags(&ej, hipEventDisableTiming));
+    hipGraph_t g = nullptr;
+    HIPC(hipStreamBeginCapture(t->stream, hipStreamCaptureModeThreadLocal));
+    LaunchCtx c2 = c;
+    c2.stream = s2;
+    for (int k = 0; k < 64; ++k) {
+      if (which == 12) {
+        HIPC(hipEventRecord(ef, t->stream));
+        HIPC(hipStreamWaitEvent(s2, ef, 0));
+        launch_eval(c2, other, on, B_X, B_T1, B_T2, PART_C, eval_opts(t, 0, 0, 0));
+        HIPC(hipEventRecord(ej, s2));
+      } else {
+        launch_eval(c, other, on, B_X, B_T1, B_T2, PART_C, eval_opts(t, 0, 0, 0));
+      }
+      launch_precond(c, a->local, n, PM_PLAIN_, B_X, B_GF, B_T2, 0, 0, 0.0, 0, t->prm.num_robots);
+      if (which == 12) HIPC(hipStreamWaitEvent(t->stream, ej, 0));
+      launch_noop(c, 1, 64);
+    }
+    HIPC(hipStreamEndCapture(t->stream, &g));
+    hipGraphExec_t ge = nullptr;
+    HIPC(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(g);
+    hipEvent_t e0, e1;
+    HIPC(hipEventCreate(&e0)); HIPC(hipEventCreate(&e1));
+    HIPC(hipGraphLaunch(ge, t->stream));
+    HIPC(hipEventRecord(e0, t->stream));
+    for (int k = 0; k < reps; ++k) HIPC(hipGraphLaunch(ge, t->stream));
+    HIPC(hipEventRecord(e1, t->stream));
+    HIPC(hipEventSynchronize(e1));
+    float ms = 0;
+    HIPC(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(ef); (void)hipEventDestroy(ej);
+    (void)hipGraphExecDestroy(ge);
+    (void)hipStreamDestroy(s2);
+    *avg_ms = (double)ms / (64.0 * reps);
+    *algorithmic_bytes = 0;
+    return 0;
+  }
   if (which == 10 || which == 11) {
     // the fused step kernel inside the running iteration.  which == 10: the pipelined accelerated-RGD sequence launched
     // eagerly, (k_eval_stats, k_precond<PM_RGD>) x reps, between ONE pair of events -> average time per iteration;
