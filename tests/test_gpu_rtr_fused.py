@@ -85,3 +85,31 @@ def test_one_launch_solve_odd_agents_long_rows_and_rejections(dataset, N, radius
         rf, ro = tf.agents[a].opt_result(), to.agents[a].opt_result()
         assert (rf.rtr_outer_iters, rf.tcg_iters_total, rf.accepted) == (ro.rtr_outer_iters, ro.tcg_iters_total, ro.accepted)
     tf.close()
+
+
+def test_graphs_with_the_schedule_baked_in_equal_the_device_selected_ones():
+    """DPGO_BAKE_SEL: the pipelined iteration's graphs address every launch's agent from a kernel argument (one graph per
+    schedule phase) or through the device-side schedule state -- the same launches, bitwise the same iterates, also for
+    run lengths that leave the schedule phase and the graph window misaligned"""
+    m, mp, n = load("sphere2500", 5)
+    ph, _ = params_pair(r=5, num_robots=5, method=capi.METHOD_RGD, rgd_stepsize=0.2, acceleration=1, restart_interval=20)
+    T, Y = O.odometry_init(m, n), O.fixed_stiefel(5)
+    X = []
+    for bake in ("1", "0"):
+        old = os.environ.get("DPGO_BAKE_SEL")
+        os.environ["DPGO_BAKE_SEL"] = bake
+        try:
+            t = capi.Team.from_measurements(mp.view(capi.MEAS_DTYPE), ph)
+        finally:
+            if old is None:
+                del os.environ["DPGO_BAKE_SEL"]
+            else:
+                os.environ["DPGO_BAKE_SEL"] = old
+        t.set_initial(T, Y)
+        for k in (7, 64, 131, 3, 200):
+            t.run(k)
+        X.append(t.global_X().copy())
+        st = [t.agents[a].status() for a in range(5)]
+        X.append(np.array([s.relative_change for s in st]))
+        t.close()
+    assert np.array_equal(X[0], X[2]) and np.array_equal(X[1], X[3])
