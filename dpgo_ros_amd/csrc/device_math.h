@@ -257,11 +257,29 @@ __device__ __forceinline__ void tangent_row(const double *Yp, const double *Wp, 
   }
 }
 
-// wave-wide sum, every lane receives the result (fixed xor tree -> bitwise reproducible)
-__device__ __forceinline__ double wave_sum(double v) {
+// wave-wide sum, every lane receives the result (fixed order -> bitwise reproducible).  DPP path: quad swaps, half-row
+// and row mirrors, then the four row totals read back with v_readlane and added in row order -- ~0.1 us where a
+// ds_bpermute xor butterfly costs 0.6 with one wave per SIMD (the sparse kernels run one 64-thread workgroup per CU and
+// end their dependent chains with two to four of these sums).  The result is wave-uniform.  Call with all 64 lanes
+// active (every call site is reached by whole waves).
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum(double x) {
+  x += dpp_move<0xB1>(x);   // quad_perm [1,0,3,2]
+  x += dpp_move<0x4E>(x);   // quad_perm [2,3,0,1]
+  x += dpp_move<0x141>(x);  // row_half_mirror
+  x += dpp_move<0x140>(x);  // row_mirror: every lane of a 16-lane row holds the row total
+  const int lo = __double2loint(x), hi = __double2hiint(x);
+  double r[4];
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  for (int q = 0; q < 4; ++q)
+    r[q] = __hiloint2double(__builtin_amdgcn_readlane(hi, 16 * q), __builtin_amdgcn_readlane(lo, 16 * q));
+  return (r[0] + r[1]) + (r[2] + r[3]);
 }
 
 // sum of a short global array of partials, identical order in every wave that calls it.  The loads of a
