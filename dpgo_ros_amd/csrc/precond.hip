@@ -51,14 +51,6 @@ namespace dpgo {
 // workgroup per CU; larger agents use 1024-row chunks so that 3 workgroups fit a CU and one workgroup's
 // arithmetic overlaps the others' streams.
 
-template <int CTRL>
-__device__ __forceinline__ double dpp_quad_pc(double v) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
-  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
-  return __hiloint2double(hi, lo);
-}
-
 template <int R, int MODE, int KC>
 __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev *team, int sel, int xb, int vb,
                                                  int zb, int sp, int max_inner, double step, int accel,
@@ -302,8 +294,8 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev
     double s = 0;
 #pragma unroll
     for (int q = 0; q < 64; ++q) s += t[q];
-    s += dpp_quad_pc<0xB1>(s);  // lanes ^ 1
-    s += dpp_quad_pc<0x4E>(s);  // lanes ^ 2
+    s += dpp_move<0xB1>(s);  // lanes ^ 1
+    s += dpp_move<0x4E>(s);  // lanes ^ 2
     if (part == 0) zs[o] = s;
   }
   __syncthreads();

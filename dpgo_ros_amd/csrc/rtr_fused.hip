@@ -148,30 +148,6 @@ __device__ __forceinline__ bool grid_sync(GridBar &gb, unsigned long long *tr = 
   return *gb.ok != 0;
 }
 
-template <int CTRL>
-__device__ __forceinline__ double dpp_quad(double v) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
-  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
-  return __hiloint2double(hi, lo);
-}
-
-// wave-wide sum on the DPP path (quad swaps, half-row and row mirrors, then the four row totals read back as
-// wave-uniform values and added in row order): ~0.1 us where the ds_bpermute butterfly of wave_sum costs 0.6 with one
-// wave per SIMD.  Every lane receives the same, wave-uniform result.
-__device__ __forceinline__ double wave_sum_u(double x) {
-  x += dpp_quad<0xB1>(x);   // quad_perm [1,0,3,2]
-  x += dpp_quad<0x4E>(x);   // quad_perm [2,3,0,1]
-  x += dpp_quad<0x141>(x);  // row_half_mirror
-  x += dpp_quad<0x140>(x);  // row_mirror: every lane of a 16-lane row holds the row total
-  const int lo = __double2loint(x), hi = __double2hiint(x);
-  double r[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-    r[q] = __hiloint2double(__builtin_amdgcn_readlane(hi, 16 * q), __builtin_amdgcn_readlane(lo, 16 * q));
-  return (r[0] + r[1]) + (r[2] + r[3]);
-}
-
 // sum of `count` contiguous partials published by the workgroups of THIS launch, same order in every wave
 template <int NA>
 __device__ __forceinline__ void csum_issue(const CVec &ws, int first, int count, int lane, double (*v)[4]) {
@@ -187,7 +163,7 @@ __device__ __forceinline__ void csum_finish(double (*v)[4], int count, int lane,
   for (int q = 0; q < NA; ++q) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) v[q][u] *= (lane + 64 * u < count) ? 1.0 : 0.0;
-    out[q] = wave_sum_u((v[q][0] + v[q][1]) + (v[q][2] + v[q][3]));
+    out[q] = wave_sum((v[q][0] + v[q][1]) + (v[q][2] + v[q][3]));
   }
 }
 
@@ -236,8 +212,8 @@ __device__ __forceinline__ void slab_finish(const double *Ms, int N4, double2 (*
 #pragma unroll
     for (int a = 0; a < R; ++a) {
       double x = acc[c][a];
-      x += dpp_quad<0xB1>(x);  // lanes ^ 1
-      x += dpp_quad<0x4E>(x);  // lanes ^ 2
+      x += dpp_move<0xB1>(x);  // lanes ^ 1
+      x += dpp_move<0x4E>(x);  // lanes ^ 2
       acc[c][a] = x;
     }
   if ((lane & 3) == 0) {
@@ -518,7 +494,7 @@ __global__ __launch_bounds__(256) void k_rtr_solve(const AgentDev *agents, int a
         }
       }
       if (wave == 0) {
-        zr = wave_sum_u(zr); rr = wave_sum_u(rr);
+        zr = wave_sum(zr); rr = wave_sum(rr);
         if (lane == 0) { st_c(wsB0 + bx, zr); st_c(wsB1 + bx, rr); }
       }
     }
@@ -602,7 +578,7 @@ __global__ __launch_bounds__(256) void k_rtr_solve(const AgentDev *agents, int a
             d += vrow[c] * hrow[c];
           }
         }
-        d = wave_sum_u(d);
+        d = wave_sum(d);
         if (lane == 0) st_c(wsA + bx, d);
       }
       RTR_FINE(4);
@@ -658,7 +634,7 @@ __global__ __launch_bounds__(256) void k_rtr_solve(const AgentDev *agents, int a
           }
         }
         if (wave == 0) {
-          zr = wave_sum_u(zr); rr = wave_sum_u(rr);
+          zr = wave_sum(zr); rr = wave_sum(rr);
           if (lane == 0) { st_c(wsB0 + bx, zr); st_c(wsB1 + bx, rr); }
         }
       }
@@ -749,7 +725,7 @@ __global__ __launch_bounds__(256) void k_rtr_solve(const AgentDev *agents, int a
           eh += vrow[c] * hrow[c];
         }
       }
-      fpart = wave_sum_u(fpart); gpart = wave_sum_u(gpart); ge = wave_sum_u(ge); eh = wave_sum_u(eh);
+      fpart = wave_sum(fpart); gpart = wave_sum(gpart); ge = wave_sum(ge); eh = wave_sum(eh);
       if (lane == 0) {
         st_c(wsC + bx, fpart); st_c(wsC + RTR_WS_PITCH + bx, gpart);
         st_c(wsC + 2 * RTR_WS_PITCH + bx, ge); st_c(wsC + 3 * RTR_WS_PITCH + bx, eh);
