@@ -55,7 +55,7 @@ struct IterBcast {  // run state read by the polling wave before the hand-off, h
 };
 
 template <int R, int KC>
-__global__ __launch_bounds__(256) void k_iter_rgd(const AgentDev *agents, TeamDev *team, NestState *nest_all,
+__global__ __launch_bounds__(256) void k_iter_rgd(const AgentDev *__restrict__ agents, TeamDev *team, NestState *nest_all,
                                                   unsigned long long *bar, int *err, int first, int nb_eval,
                                                   double step, int num_robots, int restart_interval, int ahead) {
   const int hw = (int)blockIdx.x, G8 = (int)gridDim.x / 8;

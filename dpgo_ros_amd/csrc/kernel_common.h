@@ -135,7 +135,7 @@ __device__ __forceinline__ void g_row_range(const AgentDev &ag, int e0, int e1, 
 }
 
 template <int R>
-__device__ __forceinline__ void g_row(const AgentDev *agents, const AgentDev &ag, int q, int a, int aux, int pull,
+__device__ __forceinline__ void g_row(const AgentDev *__restrict__ agents, const AgentDev &ag, int q, int a, int aux, int pull,
                                       double g[4]) {
   g_row_range<R>(ag, ag.pub_ptr[q], ag.pub_ptr[q + 1], a, aux, pull, g);
 }
@@ -166,7 +166,7 @@ __device__ __forceinline__ void advance_agent(const AgentDev &ag, int accel, int
 // Riemannian gradient is stored write-through (agent-scope relaxed atomics = global_store sc1) because other
 // workgroups of the SAME launch read it behind the grid barrier.
 template <int R, bool IN_WAVE = false>
-__device__ __forceinline__ void eval_body(const AgentDev *agents, const TeamDev *team, int sel, int xb, int egb, int gfb,
+__device__ __forceinline__ void eval_body(const AgentDev *__restrict__ agents, const TeamDev *team, int sel, int xb, int egb, int gfb,
                                           int poff, int gmode, int aux, int bx, double *Ysh, double *Wsh) {
   const AgentDev &ag = agents[IN_WAVE ? sel : sel_cur(team, sel)];
   constexpr int PPB = 64 / R;
@@ -334,7 +334,7 @@ __device__ __forceinline__ void tile_put(Tile<R> &t, int row, const double *v) {
 // V = Y = X; partial [0] of PART_D = |X_new - XPrev|^2.  First kernel of an accelerated iteration:
 // publishes team->cur_sel.
 template <int R>
-__device__ __forceinline__ void nest_pre_body(const AgentDev *agents, TeamDev *team, int sel, int only_agent,
+__device__ __forceinline__ void nest_pre_body(const AgentDev *__restrict__ agents, TeamDev *team, int sel, int only_agent,
                                               int num_robots, int restart_interval, int bx, int by, Tile<R> &TX,
                                               Tile<R> &TV, int fused_restart = 0) {
   // fused_restart bit 0: the pipelined RGD sequence takes a restart iteration as one plain step from X (the accelerated

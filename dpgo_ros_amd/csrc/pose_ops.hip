@@ -7,7 +7,7 @@ namespace dpgo {
 
 // out = Retr_x(scale * eta).  guard_state >= 0: skip when the trust-region state says done.
 template <int R>
-__global__ __launch_bounds__(64) void k_retract(const AgentDev *agents, const TeamDev *team, int sel, int xb, int eb,
+__global__ __launch_bounds__(64) void k_retract(const AgentDev *__restrict__ agents, const TeamDev *team, int sel, int xb, int eb,
                                                 double scale, int ob, int guard_state) {
   const AgentDev &ag = agents[sel_cur(team, sel)];
   if (guard_state >= 0) {
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(64) void k_raw_op(const double *X, const double *V,
 }
 
 template <int R>
-__global__ __launch_bounds__(64) void k_nest_pre(const AgentDev *agents, TeamDev *team, int sel, int only_agent,
+__global__ __launch_bounds__(64) void k_nest_pre(const AgentDev *__restrict__ agents, TeamDev *team, int sel, int only_agent,
                                                  int num_robots, int restart_interval, int fused_restart) {
   __shared__ Tile<R> TX, TV;
   nest_pre_body<R>(agents, team, sel, only_agent, num_robots, restart_interval, (int)blockIdx.x, (int)blockIdx.y, TX, TV,
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(64) void k_nest_pre(const AgentDev *agents, TeamDev
 // after the selected agent's local solve (unfused path):  V = proj(V + gamma' (X - Y)); on restart
 // X = XPrev (the host then re-optimizes from XPrev and calls k_nest_reset).
 template <int R>
-__global__ __launch_bounds__(64) void k_nest_post(const AgentDev *agents, const TeamDev *team, int sel, int num_robots,
+__global__ __launch_bounds__(64) void k_nest_post(const AgentDev *__restrict__ agents, const TeamDev *team, int sel, int num_robots,
                                                   int restart_interval) {
   const AgentDev &ag = agents[sel_cur(team, sel)];
   const int j0 = blockIdx.x * 64, tid = threadIdx.x;
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(64) void k_nest_post(const AgentDev *agents, const 
 }
 
 // V = X; Y = X  (restart tail / weight update)
-__global__ void k_nest_reset(const AgentDev *agents, const TeamDev *team, int sel, int r) {
+__global__ void k_nest_reset(const AgentDev *__restrict__ agents, const TeamDev *team, int sel, int r) {
   const AgentDev &ag = agents[sel_cur(team, sel)];
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= ag.N4 * r) return;
@@ -117,7 +117,7 @@ __global__ void k_nest_reset(const AgentDev *agents, const TeamDev *team, int se
 }
 
 // end of an iteration (unfused paths): advance gamma/alpha/iter of every agent, and the team counter
-__global__ void k_advance(const AgentDev *agents, TeamDev *team, int only_agent, int accel, int num_robots,
+__global__ void k_advance(const AgentDev *__restrict__ agents, TeamDev *team, int only_agent, int accel, int num_robots,
                           int restart_interval, int bump_team, int inc, int team_inc) {
   const int ai = only_agent >= 0 ? only_agent : (int)blockIdx.x;
   if (threadIdx.x != 0) return;
@@ -127,7 +127,7 @@ __global__ void k_advance(const AgentDev *agents, TeamDev *team, int only_agent,
 
 // PART_D partial [0] = |X - XPrev|_F^2 over a 64-pose tile (blockIdx.y = agent when sel == -3)
 template <int R>
-__global__ __launch_bounds__(64) void k_status(const AgentDev *agents, const TeamDev *team, int sel, int only_agent, int opt) {
+__global__ __launch_bounds__(64) void k_status(const AgentDev *__restrict__ agents, const TeamDev *team, int sel, int only_agent, int opt) {
   const int ai = only_agent >= 0 ? only_agent : (sel == -3 ? (int)blockIdx.y : sel_cur(team, sel));
   const AgentDev &ag = agents[ai];
   const int j0 = blockIdx.x * 64, tid = threadIdx.x;
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(64) void k_status(const AgentDev *agents, const Tea
 
 // buf[to] = buf[from] for one agent or (sel == -3) every agent (blockIdx.y).  As the first kernel of a
 // non-accelerated iteration (publish != 0) it also publishes team->cur_sel.
-__global__ void k_copy(const AgentDev *agents, TeamDev *team, int sel, int only_agent, int r, int from, int to,
+__global__ void k_copy(const AgentDev *__restrict__ agents, TeamDev *team, int sel, int only_agent, int r, int from, int to,
                        int publish) {
   const int ai = only_agent >= 0 ? only_agent : (sel == -3 ? (int)blockIdx.y : sel_cur(team, sel));
   if (publish && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
@@ -164,7 +164,7 @@ __global__ void k_copy(const AgentDev *agents, TeamDev *team, int sel, int only_
 
 // trust-region set-up from the initial evaluation partials
 template <int R>
-__global__ void k_rtr_begin(const AgentDev *agents, const TeamDev *team, int sel, double Delta0, double tol,
+__global__ void k_rtr_begin(const AgentDev *__restrict__ agents, const TeamDev *team, int sel, double Delta0, double tol,
                             int max_outer) {
   const AgentDev &ag = agents[sel_cur(team, sel)];
   const int lane = threadIdx.x;
@@ -184,7 +184,7 @@ __global__ void k_rtr_begin(const AgentDev *agents, const TeamDev *team, int sel
 // outer step, acceptance test + radius update (ROPTLIB SolversTR constants: accept rho > 0.1,
 // grow x2 when rho > 0.75 at the boundary, shrink x0.25 when rho < 0.25)
 template <int R>
-__global__ void k_rtr_accept(const AgentDev *agents, const TeamDev *team, int sel, int sp, double tol, int max_outer,
+__global__ void k_rtr_accept(const AgentDev *__restrict__ agents, const TeamDev *team, int sel, int sp, double tol, int max_outer,
                              double max_radius) {
   const AgentDev &ag = agents[sel_cur(team, sel)];
   const RtrState S = ag.st[sp];
@@ -255,7 +255,7 @@ __global__ void k_unpack(double *slab, const int *slots, int count, const double
 
 // per-edge residual sqrt(kappa |Y_j - Y_i R|^2 + tau |p_j - p_i - Y_i t|^2) (a8) and cost partials
 template <int R>
-__global__ void k_residuals(const AgentDev *agents, int ai) {
+__global__ void k_residuals(const AgentDev *__restrict__ agents, int ai) {
   const AgentDev &ag = agents[ai];
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= ag.nedges) return;
@@ -281,7 +281,7 @@ __global__ void k_residuals(const AgentDev *agents, int ai) {
 }
 
 // scal[5] = sum over owned edges of w/2 * residual^2   (single workgroup, fixed order)
-__global__ __launch_bounds__(256) void k_cost(const AgentDev *agents, int ai) {
+__global__ __launch_bounds__(256) void k_cost(const AgentDev *__restrict__ agents, int ai) {
   const AgentDev &ag = agents[ai];
   __shared__ double red[4];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void k_cost(const AgentDev *agents, int ai) {
   if (tid == 0) ag.scal[5] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-__global__ void k_noop(const AgentDev *agents, int ai) { (void)agents; (void)ai; }
+__global__ void k_noop(const AgentDev *__restrict__ agents, int ai) { (void)agents; (void)ai; }
 
 // dense A = Q + shift I from the block-CSR (column-major N4 x N4; A must be zeroed first)
 __global__ void k_bsr_to_dense(const int *rowptr, const int *col, const double *qval, int n, double shift, double *A) {

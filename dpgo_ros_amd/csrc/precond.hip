@@ -52,7 +52,7 @@ namespace dpgo {
 // arithmetic overlaps the others' streams.
 
 template <int R, int MODE, int KC>
-__global__ __launch_bounds__(256) void k_precond(const AgentDev *agents, TeamDev *team, int sel, int xb, int vb,
+__global__ __launch_bounds__(256) void k_precond(const AgentDev *__restrict__ agents, TeamDev *team, int sel, int xb, int vb,
                                                  int zb, int sp, int max_inner, double step, int accel,
                                                  int num_robots, int advance, int restart_interval, int ahead,
                                                  const NestState *nest_all) {

@@ -285,9 +285,20 @@ __device__ __forceinline__ void spmm_row_finish(const AgentDev &ag, int j, const
     ld(i, rr);
     comb(rr, xo);
   };
+  // the 4 x 4 blocks come from LDS one slot ahead of their multiply-adds (one wave per SIMD: a ds_read that is waited
+  // for where it is used costs its full latency, and there were 64 of them in a row)
+  double2 Bn[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) Bn[q] = *reinterpret_cast<const double2 *>(BL + 2 * q);
 #pragma unroll
   for (int u = 0; u < RTR_SLOTS; ++u) {
-    const double *B = BL + 16 * u;
+    double B[16];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { B[2 * q] = Bn[q].x; B[2 * q + 1] = Bn[q].y; }
+    if (u + 1 < RTR_SLOTS) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) Bn[q] = *reinterpret_cast<const double2 *>(BL + 16 * (u + 1) + 2 * q);
+    }
 #pragma unroll
     for (int v = 0; v < NV; ++v)
 #pragma unroll
@@ -357,7 +368,7 @@ __device__ __forceinline__ void hess_tail_w(const double *Ysh, const double *Hc,
 
 
 template <int R>
-__global__ __launch_bounds__(256) void k_rtr_solve(const AgentDev *agents, int ai, unsigned long long *bar, double *ws,
+__global__ __launch_bounds__(256) void k_rtr_solve(const AgentDev *__restrict__ agents, int ai, unsigned long long *bar, double *ws,
                                                    unsigned long long *cum, RtrState *host_rec,
                                                    unsigned long long *host_cum, int *err, double Delta0, double tol, int max_outer, int max_inner,
                                                    double max_radius) {

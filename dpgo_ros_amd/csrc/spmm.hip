@@ -10,7 +10,7 @@ namespace dpgo {
 // straight from the neighbour agent's X / Y array on this GPU (device-to-device exchange that
 // replaces the PublicPoses topic) and refresh the slab; else read the slab filled by unpack.
 template <int R>
-__global__ __launch_bounds__(64) void k_buildG(const AgentDev *agents, const TeamDev *team, int sel, int aux,
+__global__ __launch_bounds__(64) void k_buildG(const AgentDev *__restrict__ agents, const TeamDev *team, int sel, int aux,
                                                int pull) {
   const AgentDev &ag = agents[sel_cur(team, sel)];
   constexpr int PPB = 64 / R;
@@ -26,7 +26,7 @@ __global__ __launch_bounds__(64) void k_buildG(const AgentDev *agents, const Tea
 
 // refresh every slab entry of one agent from co-resident neighbours (both sequences)
 template <int R>
-__global__ void k_pull(const AgentDev *agents, int dst) {
+__global__ void k_pull(const AgentDev *__restrict__ agents, int dst) {
   const AgentDev &ag = agents[dst];
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= ag.nshared * 4 * R) return;
@@ -38,7 +38,7 @@ __global__ void k_pull(const AgentDev *agents, int dst) {
 }
 
 template <int R>
-__global__ __launch_bounds__(64) void k_eval(const AgentDev *agents, const TeamDev *team, int sel, int xb, int egb,
+__global__ __launch_bounds__(64) void k_eval(const AgentDev *__restrict__ agents, const TeamDev *team, int sel, int xb, int egb,
                                              int gfb, int poff, int gmode, int aux) {
   constexpr int PPB = 64 / R;
   __shared__ double Ysh[PPB * 4 * R], Wsh[PPB * 4 * R];
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(64) void k_eval(const AgentDev *agents, const TeamD
 // generic Riemannian Hessian-vector product at point xb with Euclidean gradient egb:  ob = Hess[vb]
 // partials: [0] <v, Hv>
 template <int R>
-__global__ __launch_bounds__(64) void k_hess(const AgentDev *agents, const TeamDev *team, int sel, int xb, int egb,
+__global__ __launch_bounds__(64) void k_hess(const AgentDev *__restrict__ agents, const TeamDev *team, int sel, int xb, int egb,
                                              int vb, int ob, int poff) {
   const AgentDev &ag = agents[sel_cur(team, sel)];
   constexpr int PPB = 64 / R;
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(64) void k_hess(const AgentDev *agents, const TeamD
 // ------------------------------------------------------------------------------------------------
 // tCG body, part 1:  delta <- -z + beta delta (on the fly), Hd = Hess[delta], partial <delta, Hd>.
 template <int R>
-__global__ __launch_bounds__(64) void k_tcg_hv(const AgentDev *agents, const TeamDev *team, int sel, int sp,
+__global__ __launch_bounds__(64) void k_tcg_hv(const AgentDev *__restrict__ agents, const TeamDev *team, int sel, int sp,
                                                int max_inner) {
   const AgentDev &ag = agents[sel_cur(team, sel)];
   constexpr int PPB = 64 / R;
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(64) void k_tcg_hv(const AgentDev *agents, const Tea
 // The two halves touch disjoint data: the statistics read B_X2 / G of agent a, the Nesterov step writes
 // X, Y, V, XPrev; one launch boundary per iteration disappears.
 template <int R>
-__global__ __launch_bounds__(64) void k_stats_nest(const AgentDev *agents, TeamDev *team, int nest_tiles, int num_agents,
+__global__ __launch_bounds__(64) void k_stats_nest(const AgentDev *__restrict__ agents, TeamDev *team, int nest_tiles, int num_agents,
                                                    int num_robots, int restart_interval) {
   __shared__ Tile<R> TX, TV;
   const int nb_nest = nest_tiles * num_agents;
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(64) void k_stats_nest(const AgentDev *agents, TeamD
 // stats_sel (written by the previous step kernel) while workgroup 0 moves iter, cur_sel and the NestStates, which
 // only the step kernel reads.
 template <int R>
-__global__ __launch_bounds__(64) void k_eval_stats(const AgentDev *agents, TeamDev *team, int nb_eval, int first,
+__global__ __launch_bounds__(64) void k_eval_stats(const AgentDev *__restrict__ agents, TeamDev *team, int nb_eval, int first,
                                                    int has_eval, int has_stats, int num_robots, int restart_interval,
                                                    int eval_sel, int stats_sel) {
   constexpr int PPB = 64 / R;
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(64) void k_eval_stats(const AgentDev *agents, TeamD
 //   egrad2 = x2 Q + G, rgrad2, Heta = Hess_x1[eta];  partials [0] f2 [1] |rgrad2|^2 [2] <gf,eta> [3] <eta,Heta>
 // (both SpMM rows share every Q block load)
 template <int R>
-__global__ __launch_bounds__(64) void k_rtr_eval2(const AgentDev *agents, const TeamDev *team, int sel, int sp) {
+__global__ __launch_bounds__(64) void k_rtr_eval2(const AgentDev *__restrict__ agents, const TeamDev *team, int sel, int sp) {
   const AgentDev &ag = agents[sel_cur(team, sel)];
   constexpr int PPB = 64 / R;
   __shared__ double Ysh[PPB * 4 * R], Esh[PPB * 4 * R], Wsh[PPB * 4 * R];
