@@ -338,7 +338,7 @@ def roofline_leg(team, agent_id):
     # with profiles/collect.sh.
     roof = {"kernel": "k_precond<5,PM_RGD> (fused step kernel of the timed loop)", "bound": "hbm",
             "achieved": f_bytes / (f_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-            "traffic": (2 * 16551.5 + 827.3) * 1024, "traffic_source": "profiles/r02_pmc_fetch.md, profiles/r02_pmc_write.md",
+            "traffic": (2 * 16558.4 + 826.7) * 1024, "traffic_source": "profiles/r02_pmc_fetch.md, profiles/r02_pmc_write.md",
             "bytes_per_launch": f_bytes, "us_per_launch": f_ms * 1e3, "us_per_launch_back_to_back": b_ms * 1e3,
             "timing_note": "HIP events around 500 eager pipelined iterations (%.2f us each) minus the same around 500 "
                            "k_eval_stats launches alone (%.2f us each): the dispatch-to-dispatch time of the step kernel"
