@@ -477,13 +477,19 @@ __global__ __launch_bounds__(256) void k_rtr_solve(const AgentDev *__restrict__ 
   const CVec cGF(GFg, NV8), cHD(HDg, NV8), cX2(X2g, NV8), cETA(ETAg, NV8), cWS(ws, RTR_WS_PITCH * 7);
   const double kappa = 0.1;  // tCG stop: |r| <= |r0| min(|r0|^theta, kappa) with theta = 1
 
+  int gf_fresh = 0;  // the gradient at X was published as the candidate's gradient (GF2) by the evaluation just accepted
   while (true) {
+    if (wave == 0) WSYNC();  // (the acceptance step's LDS updates of X / egrad, written by the row lanes)
     if (tid < npose) curvature_block<R>(Xs + tid * 4 * R, Es + tid * 4 * R, Hcs + tid * 9);
     // (visible to the row lanes through the barriers inside the set-up's slab product)
     // ================= tCG set-up (k_precond<PM_TCG_INIT>): z0 = P(gf M), r0 = gf, eta = 0, delta0 = -z0
     {
+      // after an accepted step the whole new gradient is already visible as GF2 (published before the hand-off in
+      // front of the acceptance test), so no hand-off stands between the acceptance and this product; GF itself
+      // (own rows written through at the acceptance) serves the set-ups that follow a rejection, hand-offs later
+      const CVec cSrc(__builtin_amdgcn_readfirstlane(gf_fresh) ? ag.buf[B_GF2] : GFg, NV8);
       double2 vv[SLAB_MAXM][R];
-      slab_issue<R>(N4, cGF, tid, vv);
+      slab_issue<R>(N4, cSrc, tid, vv);
       slab_finish<R>(Ms, N4, vv, red, zs, tid);
     }
     {
@@ -724,6 +730,12 @@ __global__ __launch_bounds__(256) void k_rtr_solve(const AgentDev *__restrict__ 
         for (int c = 0; c < 3; ++c) { G2s[lp * 4 * R + c * R + a] = o3[c]; gpart += o3[c] * o3[c]; }
         G2s[lp * 4 * R + 3 * R + a] = eg[3];
         gpart += eg[3] * eg[3];
+        {
+          double *GF2g = ag.buf[B_GF2] + (size_t)j * 4 * R;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) st_c(GF2g + c * R + a, o3[c]);
+          st_c(GF2g + 3 * R + a, eg[3]);
+        }
 #pragma unroll
         for (int c = 0; c < 4; ++c) vrow[c] = Et[lp * 4 * R + c * R + a];
       }
@@ -759,6 +771,7 @@ __global__ __launch_bounds__(256) void k_rtr_solve(const AgentDev *__restrict__ 
         S.Delta = 0.25 * S.Delta;
       }
       if (accept) { S.f1 = f2; S.ngf = sqrt(g2); S.accepted += 1; }
+      gf_fresh = accept ? 1 : 0;
       S.hv_count += 1;
       {
         const int took = S.tcg_j + 1;
@@ -782,7 +795,6 @@ __global__ __launch_bounds__(256) void k_rtr_solve(const AgentDev *__restrict__ 
       }
     }
     if (S.outer_done) break;
-    if (!grid_sync(gb)) return;  // the next set-up pulls the whole new gradient through every workgroup
     RTR_STAMP(stamp++);
   }
   if (bx == 0 && tid == 0) {
