@@ -807,7 +807,7 @@ int dpgo_team_step_end(dpgo_team_t *t, int sel_id) {
   const int rc = enqueue_team_iteration(t, false, restart, sel, 2);
   if (rc) return rc;
   const bool fused = p.method == DPGO_METHOD_RGD && p.rgd_use_preconditioner && !restart && sel >= 0;
-  account_iteration(t, sel, fused);
+  account_iteration(t, sel, fused || t->last_iteration_folded);
   return 0;
 }
 
@@ -962,8 +962,10 @@ static int team_run_impl(dpgo_team_t *t, int iters, bool prepare_only) {
       for (auto &a : t->ag) a->rel_src = p.acceleration ? 0 : 2;
       const int rc = enqueue_team_iteration(t, false, restart, sel, 0);
       if (rc) return rc;
-      t->ag[sel]->rel_src = 0;  // k_status tiles of the block update (this path never runs the fused step)
-      mark_optimized(t, *t->ag[sel], 5, true);
+      // status of the block update: k_status tiles, or -- where the one-launch RTR solve took the iteration's tail --
+      // one partial per pose pair in PART_B[2], the fused RGD step's layout
+      t->ag[sel]->rel_src = t->last_iteration_folded ? 1 : 0;
+      mark_optimized(t, *t->ag[sel], t->last_iteration_folded ? 1 : 5, true);
     }
     t->iter += batch;
     cur_iter = t->iter;

@@ -84,7 +84,8 @@ bool rtr_fused_eligible(int r, int n, int num_cus);
 // the totals, written by the kernel itself
 int launch_rtr_solve(const LaunchCtx &c, int ai, int n, unsigned long long *bar, double *ws, unsigned long long *cum, RtrState *host_rec,
                      unsigned long long *host_cum, int *err, double Delta0,
-                     double tol, int max_outer, int max_inner, double max_radius);
+                     double tol, int max_outer, int max_inner, double max_radius, int tail = 0, int num_robots = 1,
+                     int restart_interval = 1);
 
 // dense_inverse.hip: M = (A)^-1 for a symmetric positive definite N x N column-major matrix.
 // A is destroyed; work must hold N*N doubles.  Returns 0, or the (1-based) failing pivot block.

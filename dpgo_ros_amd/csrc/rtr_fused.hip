@@ -26,6 +26,45 @@ constexpr int RB_GEN = 9 * RB_LINE;     // generation words at RB_GEN + g * RB_L
 constexpr int RB_EPOCH = 17 * RB_LINE;  // epoch of the last completed hand-off (carried across launches)
 constexpr int RB_ABORT = 17 * RB_LINE + 1;  // raised by a workgroup whose hand-off timed out: everybody leaves
 constexpr int RB_SPIN_LIMIT = 1 << 18;      // ~0.5 s of polling
+// End of the iteration for the agent that just solved, folded into the solve's launch (tail != 0; the team schedule's
+// non-restart iterations): what k_nest_post, k_status and k_advance do in launches of their own --
+//   bit 0: V <- proj(V + gamma (X - Y)) on the own poses (gamma as k_nest_pre published it in scal[6]);
+//   always: |X - XPrev|^2 of the own poses -> PART_B[2] of this workgroup (the layout of the fused RGD step: rel_src 1);
+//   workgroup 0: the Nesterov scalars of every agent and the team's iteration counter advance.
+// No hand-off: every workgroup touches its own two poses only, and nothing here reads what the advance writes.
+template <int R>
+__device__ __forceinline__ void solve_tail(const AgentDev *__restrict__ agents, const AgentDev &ag, TeamDev *team, int tail,
+                                           int num_robots, int restart_interval, int bx, int npose, int tid) {
+  if (tid < 64) {
+    double rel = 0;
+    if (tid < npose) {
+      const size_t o = (size_t)(2 * bx + tid) * 4 * R;
+      double x[4 * R], xp[4 * R];
+#pragma unroll
+      for (int i = 0; i < 4 * R; ++i) { x[i] = ag.buf[B_X][o + i]; xp[i] = ag.buf[B_XPREV][o + i]; }
+      if (tail & 1) {
+        const double gamma = ag.scal[6];
+        double v[4 * R], y[4 * R];
+#pragma unroll
+        for (int i = 0; i < 4 * R; ++i) { v[i] = ag.buf[B_V][o + i]; y[i] = ag.buf[B_Y][o + i]; }
+#pragma unroll
+        for (int i = 0; i < 4 * R; ++i) v[i] += gamma * (x[i] - y[i]);
+        polar_inplace<R>(v);
+#pragma unroll
+        for (int i = 0; i < 4 * R; ++i) ag.buf[B_V][o + i] = v[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 4 * R; ++i) { const double d = x[i] - xp[i]; rel += d * d; }
+    }
+    rel = wave_sum(rel);
+    if (tid == 0) ag.part[PART_B + (size_t)bx * PART_STRIDE + 2] = rel;
+  }
+  if (bx == 0 && tid == 0) {
+    for (int k = 0; k < team->num_agents; ++k) advance_agent(agents[k], tail & 1, num_robots, restart_interval);
+    team->iter += 1;
+  }
+}
+
 constexpr int RTR_WS_PITCH = 256;  // doubles per partial-sum array of the scratch (one entry per workgroup):
                                    // [0] <delta, H delta>  [1] <z, r>  [2] <r, r>  [3..6] f, |grad|^2, <g, eta>, <eta, H eta>
 
@@ -371,7 +410,8 @@ template <int R>
 __global__ __launch_bounds__(256) void k_rtr_solve(const AgentDev *__restrict__ agents, int ai, unsigned long long *bar, double *ws,
                                                    unsigned long long *cum, RtrState *host_rec,
                                                    unsigned long long *host_cum, int *err, double Delta0, double tol, int max_outer, int max_inner,
-                                                   double max_radius) {
+                                                   double max_radius, TeamDev *team, int tail, int num_robots,
+                                                   int restart_interval) {
   extern __shared__ double Ms[];  // [8][N4]: this workgroup's columns of M
   __shared__ double red[64 * (8 * R + 1)];
   // own two poses, [pose][component c][row a]: X, Euclidean / Riemannian gradient at X; tCG residual, z, delta, eta;
@@ -410,6 +450,7 @@ __global__ __launch_bounds__(256) void k_rtr_solve(const AgentDev *__restrict__ 
       *host_rec = T;
       for (int k = 0; k < 4; ++k) host_cum[k] = cum[k];
     }
+    if (tail) solve_tail<R>(agents, ag, team, tail, num_robots, restart_interval, bx, npose, tid);
     return;
   }
   __shared__ int bar_ok;
@@ -808,6 +849,11 @@ __global__ __launch_bounds__(256) void k_rtr_solve(const AgentDev *__restrict__ 
     *host_rec = T;
     for (int k = 0; k < 4; ++k) host_cum[k] = cum[k];
   }
+  if (tail) {
+    // (the accepted point's own rows went to B_X with plain stores from this workgroup's row lanes)
+    __syncthreads();
+    solve_tail<R>(agents, ag, team, tail, num_robots, restart_interval, bx, npose, tid);
+  }
 }
 
 static size_t rtr_static_lds(int r) {
@@ -820,7 +866,8 @@ bool rtr_fused_eligible(int r, int n, int num_cus) {
 }
 
 int launch_rtr_solve(const LaunchCtx &c, int ai, int n, unsigned long long *bar, double *ws, unsigned long long *cum, RtrState *host_rec, unsigned long long *host_cum,
-                     int *err, double Delta0, double tol, int max_outer, int max_inner, double max_radius) {
+                     int *err, double Delta0, double tol, int max_outer, int max_inner, double max_radius, int tail,
+                     int num_robots, int restart_interval) {
   const size_t dyn = (size_t)64 * 4 * n;  // 8 columns x N4 doubles
   hipError_t e = hipSuccess;
   DPGO_DISPATCH_R(c.r, {
@@ -831,7 +878,7 @@ int launch_rtr_solve(const LaunchCtx &c, int ai, int n, unsigned long long *bar,
     }
     if (e == hipSuccess)
       hipLaunchKernelGGL(k_rtr_solve<R>, dim3((n + 1) / 2), dim3(256), dyn, c.stream, c.agents, ai, bar, ws, cum, host_rec, host_cum, err, Delta0, tol,
-                         max_outer, max_inner, max_radius);
+                         max_outer, max_inner, max_radius, c.team, tail, num_robots, restart_interval);
   });
   return e == hipSuccess ? 0 : -1;
 }

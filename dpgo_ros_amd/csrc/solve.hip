@@ -79,6 +79,7 @@ int enqueue_optimize(dpgo_team *t, int sel, const OptFlags &fl) {
     return 0;
   }
   if (fl.capture) { set_err("RTR cannot be captured"); return DPGO_ERR; }
+  t->last_rtr_folded = false;
   // ---- RTR: trust-region Newton with truncated CG; scalars stay on the device
   Agent &a = *t->ag[sel];
   launch_eval(c, sel, mn, B_X, B_EGRAD, B_GF, PART_A, eval_opts(t, gmode, fl.aux, 0));
@@ -117,9 +118,11 @@ int enqueue_optimize(dpgo_team *t, int sel, const OptFlags &fl) {
       a.rtr_bar_n = a.n;
     }
     if (launch_rtr_solve(c, sel, a.n, a.d_rtr_bar.p, a.d_rtr_ws.p, a.d_rtr_cum.p, a.h_rtr.p, a.h_rtr_cum.p, t->h_bar_err, p.rtr_initial_radius,
-                         p.gradnorm_tol, p.rtr_iterations, p.rtr_tcg_iterations, p.rtr_max_radius)) {
+                         p.gradnorm_tol, p.rtr_iterations, p.rtr_tcg_iterations, p.rtr_max_radius, fl.rtr_tail, p.num_robots,
+                         p.restart_interval)) {
       set_err("RTR solve launch failed"); return DPGO_ERR;
     }
+    t->last_rtr_folded = fl.rtr_tail != 0;
     a.opt_pending_rtr = true;
     a.opt_pending_rgd = false;
     if (t->rtr_validated) return 0;
@@ -129,6 +132,7 @@ int enqueue_optimize(dpgo_team *t, int sel, const OptFlags &fl) {
       return refresh_rtr_result(t, a);
     }
     // timed out at the first hand-off: nothing but scratch was written.  Launch-per-step from now on, this solve included
+    t->last_rtr_folded = false;
     *t->h_bar_err = 0;
     t->use_fused_rtr = 0;
     a.rtr_bar_n = -1;
@@ -324,11 +328,16 @@ int enqueue_team_iteration(dpgo_team *t, bool capture, bool restart, int sel, in
     else launch_copy(c, -3, -1, na, mn, B_X, B_XPREV, capture ? 1 : 0);
   }
   if (phase == 1) return 0;
+  bool folded = false;
   if (sel != -2) {
     fl.aux = p.acceleration ? 1 : 0;
+    // RTR, non-restart iteration: the one-launch solve also takes the Nesterov V update, the status partials and the
+    // end-of-iteration bookkeeping (three launches less); enqueue_optimize reports whether that solve ran
+    if (p.method == DPGO_METHOD_RTR && sel >= 0 && !capture && !restart) fl.rtr_tail = p.acceleration ? 3 : 2;
     rc = enqueue_optimize(t, sel, fl);
     if (rc) return rc;
-    if (!fused) {
+    folded = p.method == DPGO_METHOD_RTR && t->last_rtr_folded;
+    if (!fused && !folded) {
       const int ns = (sel >= 0) ? t->ag[sel]->n : mn;
       if (p.acceleration) {
         launch_nest_post(c, sel, ns, p.num_robots, p.restart_interval);
@@ -342,7 +351,8 @@ int enqueue_team_iteration(dpgo_team *t, bool capture, bool restart, int sel, in
       launch_status(c, sel, -1, 1, ns, 1);
     }
   }
-  if (!fused) launch_advance(c, -1, na, p.acceleration, p.num_robots, p.restart_interval, 1);
+  if (!fused && !folded) launch_advance(c, -1, na, p.acceleration, p.num_robots, p.restart_interval, 1);
+  t->last_iteration_folded = folded;
   return 0;
 }
 

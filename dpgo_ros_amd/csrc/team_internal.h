@@ -184,6 +184,8 @@ struct dpgo_team {
   int *h_bar_err = nullptr;
   int num_cus = 0;
   int bake_sel = 1;  // DPGO_BAKE_SEL=0: the graphs of the pipelined iteration select their agent on the device only
+  bool last_iteration_folded = false;  // ... and enqueue_team_iteration skipped k_nest_post / k_status / k_advance for it
+  bool last_rtr_folded = false;  // the last enqueue_optimize ran the one-launch solve WITH the iteration's tail
   bool rtr_validated = false;  // a one-launch solve has completed on this device (its grid is resident at once)
   int use_fused_rtr = 1;  // DPGO_FUSED_RTR=0 keeps the launch-per-step RTR sequence (solve.hip) for every agent
   int use_fused = 0;  // DPGO_FUSED_ITER=1 selects the one-launch iteration (measured 27 us against 25 for two launches on
@@ -213,7 +215,11 @@ int flush_stage(dpgo_team *t);
 // ---- solve.hip
 double converged_ratio(const Agent &a);
 void mark_optimized(dpgo_team *t, Agent &a, int rel_src, bool success);
-struct OptFlags { int aux = 0, pull = 0; bool capture = false, fused = false, last_advances = false; };
+struct OptFlags {
+  int aux = 0, pull = 0;
+  bool capture = false, fused = false, last_advances = false;
+  int rtr_tail = 0;  // one-launch RTR solve: fold the rest of the iteration into it (bit 0: Nesterov V update; status + advance)
+};
 bool neighbor_poses_ready(const Agent &a, int aux);
 EvalOpts eval_opts(const dpgo_team *t, int gmode, int aux, int advance);
 double spmm_bytes_of(const dpgo_team *t, const Agent &a);
