@@ -472,18 +472,16 @@ __global__ __launch_bounds__(256) void k_rtr_solve(const AgentDev *__restrict__ 
   {
     const int tot2 = 2 * npose * N4;  // double2 elements of the valid columns
     const double *Msrc = ag.M + (size_t)8 * bx * N4;
-    for (int i0 = 0; i0 < 4 * N4; i0 += 256 * 8) {
-      double2 t[8];
+    // straight-line: 32 x 16 bytes per lane (N4 <= 2048), every request in flight before the first LDS store; indices
+    // past the valid columns re-read the last element and store zeros (predicated loads were waited for one by one:
+    // 8.5 us for the 32 MB)
+    double2 t[32];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int i = i0 + tid + 256 * u;
-        t[u] = (i < tot2) ? ld2_nt(Msrc + 2 * (size_t)i) : make_double2(0.0, 0.0);
-      }
+    for (int u = 0; u < 32; ++u) t[u] = ld2_nt(Msrc + 2 * (size_t)min(tid + 256 * u, tot2 - 1));
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int i = i0 + tid + 256 * u;
-        if (i < 4 * N4) *reinterpret_cast<double2 *>(&Ms[2 * (size_t)i]) = t[u];
-      }
+    for (int u = 0; u < 32; ++u) {
+      const int i = tid + 256 * u;
+      if (i < 4 * N4) *reinterpret_cast<double2 *>(&Ms[2 * (size_t)i]) = (i < tot2) ? t[u] : make_double2(0.0, 0.0);
     }
   }
   if (rl) {
