@@ -61,7 +61,7 @@ METHOD_RTR, METHOD_RGD = 0, 1
 COST_L2, COST_GNC_TLS = 0, 5
 WEIGHT_LIBRARY, WEIGHT_WRAPPER = 0, 1
 OK, NOT_READY, ERR = 0, 1, -1
-PRECOND_AUTO, PRECOND_DENSE, PRECOND_BLOCK_JACOBI = 0, 1, 2
+PRECOND_AUTO, PRECOND_DENSE, PRECOND_BLOCK_JACOBI, PRECOND_TWO_LEVEL = 0, 1, 2, 3
 
 # every symbol include/dpgo_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = """dpgo_default_params dpgo_last_error dpgo_read_g2o dpgo_read_measurements_csv dpgo_partition
@@ -80,7 +80,7 @@ dpgo_error_threshold_at_quantile dpgo_team_set_schedule dpgo_team_set_initial dp
 dpgo_agent_pull_local dpgo_team_time_kernel dpgo_team_run dpgo_team_get_coloring dpgo_team_run_colored dpgo_team_set_groups dpgo_team_run_group dpgo_team_step_begin dpgo_team_step_end dpgo_team_iteration dpgo_team_cost dpgo_team_update_weights dpgo_team_get_counters
 dpgo_write_measurements_csv dpgo_write_g2o dpgo_write_trajectory_csv dpgo_robust_frame_alignment dpgo_robust_local_init dpgo_team_run_simultaneous
 dpgo_team_should_terminate dpgo_team_run_schedule dpgo_agent_compute_residuals dpgo_agent_set_measurement_weights
-dpgo_agent_reset_acceleration dpgo_team_prepare dpgo_team_read_handoff_state dpgo_agent_read_partials dpgo_agent_preconditioner dpgo_agent_export_state dpgo_team_import_peer dpgo_agent_read_rtr_handoff""".split()
+dpgo_agent_reset_acceleration dpgo_team_prepare dpgo_agent_read_partials dpgo_agent_preconditioner dpgo_agent_preconditioner_info dpgo_two_level_plan dpgo_agent_export_state dpgo_team_import_peer dpgo_agent_read_rtr_handoff""".split()
 
 
 class DpgoError(RuntimeError):
@@ -106,6 +106,19 @@ def lib():
 
 def _d(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def two_level_plan(rowptr, col, max_sub=0):
+    """the dissection of the two-level preconditioner for a block-CSR pattern (host arithmetic only):
+    (sub_of[n] with -1 = separator, info dict)"""
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+    col = np.ascontiguousarray(col, dtype=np.int32)
+    n = len(rowptr) - 1
+    sub_of = np.zeros(n, dtype=np.int32)
+    info = np.zeros(6)
+    _chk(lib().dpgo_two_level_plan(n, _d(rowptr), _d(col), int(max_sub), _d(sub_of), _d(info)), "two_level_plan")
+    return sub_of, dict(subdomains=int(info[0]), separator_poses=int(info[1]), workgroups=int(info[2]),
+                        producer_workgroups=int(info[3]), bytes_per_apply=info[4], worthwhile=bool(info[5]))
 
 
 def _chk(rc, what):
@@ -323,8 +336,14 @@ class Agent:
         return s
 
     def preconditioner(self):
-        """1 dense inverse, 2 block-Jacobi (the fallback when the dense inverse does not fit or was not asked for)"""
+        """1 dense inverse, 3 two-level (both exact), 2 block-Jacobi (on request, or where neither exact form fits)"""
         return _chk(lib().dpgo_agent_preconditioner(self.t, self.id), "preconditioner")
+
+    def preconditioner_info(self):
+        out = np.zeros(8)
+        _chk(lib().dpgo_agent_preconditioner_info(self.t, self.id, _d(out)), "preconditioner_info")
+        return dict(mode=int(out[0]), subdomains=int(out[1]), separator_poses=int(out[2]), workgroups=int(out[3]),
+                    producer_workgroups=int(out[4]), bytes_per_apply=out[5], dense_bytes=out[6], largest_subdomain=int(out[7]))
 
     def publish_requested(self, clear=False):
         return bool(lib().dpgo_agent_publish_requested(self.t, self.id, int(clear)))

@@ -110,26 +110,61 @@ void build_Q(Agent &a) {
   }
 }
 
-// Which preconditioner an agent runs.  The dense inverse needs N4^2 doubles for M and twice that as scratch while it
-// is factored; where that does not fit the device (or block-Jacobi was asked for) the agent keeps the inverted 4 x 4
-// diagonal blocks of Q + shift I instead -- declared: NOT the reference's preconditioner (include/dpgo_hip.h).
+// Which form of the preconditioner an agent runs.  Both exact forms are the reference's operator (Q + shift I)^-1:
+//   * the two-level form (twolevel.h) where it streams less than half the bytes of the dense inverse (agents of a few
+//     hundred poses and more) -- or for every agent when precond_mode asks for it;
+//   * the dense inverse otherwise (N4^2 doubles for M and twice that as scratch while it is factored).
+// Block-Jacobi (the inverted 4 x 4 diagonal blocks of Q + shift I; declared NOT the reference's preconditioner,
+// include/dpgo_hip.h) runs only on request, or where neither exact form fits the device.
 // `budget`: bytes of device memory still unclaimed by the agents decided before this one in the same set-up pass.
 static int choose_precond(dpgo_team *t, Agent &a, double &budget) {
   const double N4 = 4.0 * a.n, need = 3.0 * 8.0 * N4 * N4;
   const double held = 8.0 * (double)a.d_M.n;  // an inverse this agent already holds is reused
   const bool fits = need - held + 512e6 <= budget;
   int mode = t->prm.precond_mode;
+  if (mode != DPGO_PRECOND_AUTO && mode != DPGO_PRECOND_DENSE && mode != DPGO_PRECOND_BLOCK_JACOBI && mode != DPGO_PRECOND_TWO_LEVEL) {
+    set_err("bad precond_mode");
+    return DPGO_ERR;
+  }
+  double tl_need = 0;
+  bool tl_ok = false;
+  if (mode == DPGO_PRECOND_AUTO || mode == DPGO_PRECOND_TWO_LEVEL) {
+    // the dissection depends on the sparsity pattern only: a weight update keeps it
+    if (a.tl_plan.n != a.n || a.tl_rowptr != a.rowptr || a.tl_col != a.col) {
+      a.tl_plan = tl_make_plan(a.n, a.rowptr, a.col);
+      a.tl_rowptr = a.rowptr; a.tl_col = a.col;
+    }
+    const TLPlan &pl = a.tl_plan;
+    double blocks = 16.0 * pl.ns * pl.ns, coup = 0;
+    for (size_t i = 0; i < pl.sub.size(); ++i) {
+      blocks += 16.0 * (double)pl.sub[i].size() * (double)pl.sub[i].size();
+      coup += 16.0 * (double)pl.sub[i].size() * (double)pl.adj_sep[i].size();
+    }
+    tl_need = pl.bytes + 8.0 * (3.0 * blocks + coup) + 4.0 * (double)pl.nwg * (double)pl.n / std::max<size_t>(1, pl.sub.size()) * 2.0;
+    tl_ok = !pl.sub.empty() && tl_need - 8.0 * (double)a.d_tl_slabs.n + 512e6 <= budget;
+  }
   if (mode == DPGO_PRECOND_DENSE && !fits) {
     char msg[400];
     std::snprintf(msg, sizeof msg, "agent %d: the dense preconditioner of %d poses needs %.1f GB of device memory (%.1f GB for "
-                  "the inverse, the rest while it is factored), %.1f GB are available; precond_mode = 0 (automatic) or 2 "
-                  "(block-Jacobi) runs this agent without it", a.id, a.n, need / 1e9, need / 3e9, budget / 1e9);
+                  "the inverse, the rest while it is factored), %.1f GB are available; precond_mode = 0 (automatic) or 3 "
+                  "(two-level) runs the same operator in a fraction of that", a.id, a.n, need / 1e9, need / 3e9, budget / 1e9);
     set_err(msg);
     return DPGO_ERR;
   }
-  if (mode == DPGO_PRECOND_AUTO) mode = fits ? DPGO_PRECOND_DENSE : DPGO_PRECOND_BLOCK_JACOBI;
-  if (mode != DPGO_PRECOND_DENSE && mode != DPGO_PRECOND_BLOCK_JACOBI) { set_err("bad precond_mode"); return DPGO_ERR; }
+  if (mode == DPGO_PRECOND_TWO_LEVEL && !tl_ok) {
+    char msg[300];
+    std::snprintf(msg, sizeof msg, "agent %d: the two-level preconditioner of %d poses needs %.1f GB of device memory, %.1f GB are "
+                  "available", a.id, a.n, tl_need / 1e9, budget / 1e9);
+    set_err(msg);
+    return DPGO_ERR;
+  }
+  if (mode == DPGO_PRECOND_AUTO) {
+    if (tl_ok && tl_worthwhile(a.tl_plan)) mode = DPGO_PRECOND_TWO_LEVEL;
+    else if (fits) mode = DPGO_PRECOND_DENSE;
+    else mode = tl_ok ? DPGO_PRECOND_TWO_LEVEL : DPGO_PRECOND_BLOCK_JACOBI;
+  }
   if (mode == DPGO_PRECOND_DENSE) budget -= need - held;
+  if (mode == DPGO_PRECOND_TWO_LEVEL) budget -= tl_need - 8.0 * (double)a.d_tl_slabs.n;
   a.precond = mode;
   return 0;
 }
@@ -142,7 +177,7 @@ int finalize_agent(dpgo_team *t, Agent &a, double *scratch) {
   const int r = t->prm.r, n = a.n, N4 = 4 * n;
   const size_t len = (size_t)r * 4 * n;
   hipStream_t s = t->stream;
-  build_Q(a);
+  // (Q itself was assembled by sync_descs, which needs its pattern to choose the preconditioner)
   // shared edges sorted by local pose
   struct SE { int lpose; SharedEdgeDev d; };
   std::vector<SharedEdgeDev> se;
@@ -237,7 +272,7 @@ int finalize_agent(dpgo_team *t, Agent &a, double *scratch) {
   if (dense) {
     // dense preconditioner  M = (Q + shift I)^-1: assembled here, inverted by sync_descs
     launch_bsr_to_dense(s, a.d_rowptr.p, a.d_col.p, a.d_qval.p, n, t->prm.precond_shift, scratch);
-  } else {
+  } else if (a.precond == DPGO_PRECOND_BLOCK_JACOBI) {
     // block-Jacobi: invert the 4 x 4 diagonal blocks of Q + shift I on the host (Gauss-Jordan, SPD: no pivoting)
     std::vector<double> dinv((size_t)16 * n);
     for (int j = 0; j < n; ++j) {
@@ -280,7 +315,9 @@ int finalize_agent(dpgo_team *t, Agent &a, double *scratch) {
   AgentDev &d = a.dev;
   d.id = a.id; d.n = n; d.nb = (int)a.col.size(); d.N4 = N4;
   d.npub = a.npub; d.nshared = (int)se.size(); d.nnp = (int)a.np.size(); d.nedges = a.nedges;
-  d.rowptr = a.d_rowptr.p; d.col = a.d_col.p; d.qval = a.d_qval.p; d.M = dense ? a.d_M.p : nullptr; d.Dinv = dense ? nullptr : a.d_dinv.p;
+  d.rowptr = a.d_rowptr.p; d.col = a.d_col.p; d.qval = a.d_qval.p; d.M = dense ? a.d_M.p : nullptr;
+  d.Dinv = a.precond == DPGO_PRECOND_BLOCK_JACOBI ? a.d_dinv.p : nullptr;
+  if (a.precond != DPGO_PRECOND_TWO_LEVEL) d.tl = TLDev{};  // (two-level agents: filled in by tl_build)
   d.ell_w = EW; d.ell_col = a.d_ell_col.p; d.ell_val = a.d_ell_val.p;
   d.trowptr = a.d_trowptr.p; d.tcol = a.d_tcol.p; d.tval = a.d_tval.p; d.pub_index = a.d_pub_index.p;
   d.pose_eptr = a.d_pose_eptr.p;
@@ -349,6 +386,7 @@ int sync_descs_noflush(dpgo_team *t) {
       rebuild_index(*a);
       if (!a->data_dirty) continue;
       any_dirty = true;
+      build_Q(*a);
       if (choose_precond(t, *a, budget)) return DPGO_ERR;
       if (a->precond == DPGO_PRECOND_DENSE) total += 2 * (size_t)(4 * a->n) * (4 * a->n);
     }
@@ -356,12 +394,14 @@ int sync_descs_noflush(dpgo_team *t) {
       if (total && t->d_tmp.alloc(total)) { set_err("scratch allocation failed"); return DPGO_ERR; }
       std::vector<double *> As, Ws, Ms;
       std::vector<int> Ns;
+      std::vector<Agent *> tl_agents;
       size_t off = 0;
       for (auto &a : t->ag) {
         if (!a->data_dirty) continue;
-        if (a->precond != DPGO_PRECOND_DENSE) {  // block-Jacobi: nothing to invert on the device
+        if (a->precond != DPGO_PRECOND_DENSE) {  // block-Jacobi: nothing to invert on the device; two-level: tl_build
           const int rc = finalize_agent(t, *a, nullptr);
           if (rc) return rc;
+          if (a->precond == DPGO_PRECOND_TWO_LEVEL) tl_agents.push_back(a.get());
           continue;
         }
         const size_t NN = (size_t)(4 * a->n) * (4 * a->n);
@@ -377,6 +417,10 @@ int sync_descs_noflush(dpgo_team *t) {
                 std::to_string(fail >> 24) + " of the batch)");
         return DPGO_ERR;
       }
+      // (the dense batch is done with the scratch: the two-level set-up reuses it)
+      if (tl_build(t, tl_agents)) return DPGO_ERR;
+      t->dense_max_n = 0;
+      for (auto &a : t->ag) if (a->precond == DPGO_PRECOND_DENSE) t->dense_max_n = std::max(t->dense_max_n, a->n);
     }
   }
   if (!t->descs_dirty) return 0;

@@ -49,15 +49,12 @@ dpgo_team_t *dpgo_team_create(int device, const dpgo_params_t *p, int num_local,
   {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess) t->num_cus = cus;
-    const char *e = std::getenv("DPGO_FUSED_ITER");
-    if (e) t->use_fused = (e[0] == '1') ? 1 : 0;
     const char *e3 = std::getenv("DPGO_BAKE_SEL");
     if (e3) t->bake_sel = (e3[0] == '0') ? 0 : 1;
     const char *e2 = std::getenv("DPGO_FUSED_RTR");
     if (e2) t->use_fused_rtr = (e2[0] == '0') ? 0 : 1;
     if (t->d_nest_all.alloc(std::max(1, num_local)) ||
         hipMemset(t->d_nest_all.p, 0, sizeof(NestState) * std::max(1, num_local)) != hipSuccess ||
-        t->d_bar.alloc(ITER_BAR_WORDS) || hipMemset(t->d_bar.p, 0, sizeof(unsigned long long) * ITER_BAR_WORDS) != hipSuccess ||
         hipHostMalloc((void **)&t->h_bar_err, sizeof(int)) != hipSuccess) {
       delete t; set_err("hand-off state allocation failed"); return nullptr;
     }
@@ -94,10 +91,9 @@ int dpgo_team_synchronize(dpgo_team_t *t) {
   for (auto &a : t->ag) if (a->opt_pending_rtr && refresh_rtr_result(t, *a)) return DPGO_ERR;
   if (t->h_bar_err && *t->h_bar_err) {
     *t->h_bar_err = 0;
-    t->use_fused = 0;  // the grid was not resident at once on this device: two launches per iteration from now on
     for (auto &kv : t->graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);
     t->graphs.clear(); t->graph_flip.clear();
-    set_err("fused iteration kernel: grid-wide hand-off timed out (iterates of this run are invalid)");
+    set_err("an in-kernel exchange (two-level preconditioner / one-launch RTR solve) timed out: the iterates of this run are invalid");
     return DPGO_ERR;
   }
   return 0;
@@ -286,7 +282,7 @@ static int report_after_iterate(dpgo_team_t *t, Agent *a, bool did_opt) {
   const size_t npub = 2 * (size_t)a->n_pub_all * B;
   const bool want_status = did_opt && !t->prm.status_every_iterate && (a->opt_rel_src == 1 || a->opt_rel_src == 5);
   const bool tiles = a->opt_rel_src == 5;
-  const int scnt = want_status ? (tiles ? (a->n + 63) / 64 : (4 * a->n + 7) / 8) : 0;
+  const int scnt = want_status ? (tiles ? (a->n + 63) / 64 : precond_nblk(*a)) : 0;
   const size_t nstat = want_status ? (size_t)(scnt - 1) * PART_STRIDE + 1 : 0;
   const int ppb = 64 / t->prm.r, nb = (a->n + ppb - 1) / ppb;
   const bool want_opt = did_opt && a->opt_pending_rgd;
@@ -370,7 +366,7 @@ int dpgo_agent_get_status(dpgo_team_t *t, int id, dpgo_status_t *s) {
       double sum = 0;
       if (a->opt_rel_src != 2) {
         const bool tiles = a->opt_rel_src == 5;
-        const int cnt = tiles ? (a->n + 63) / 64 : (4 * a->n + 7) / 8;
+        const int cnt = tiles ? (a->n + 63) / 64 : precond_nblk(*a);
         const int off = tiles ? PART_E : PART_B + 2;
         std::vector<double> part((size_t)cnt * PART_STRIDE);
         HIPC(hipMemcpyAsync(part.data(), a->dev.part + off, sizeof(double) * ((size_t)(cnt - 1) * PART_STRIDE + 1),
@@ -388,7 +384,7 @@ int dpgo_agent_get_status(dpgo_team_t *t, int id, dpgo_status_t *s) {
   }
   if (!a->has_X || a->iter == 0 || a->rel_src == 2) { s->ready_to_terminate = a->has_X && a->iter > 0 && a->last_success; return DPGO_OK; }
   // |X - XPrev|^2 partials were left by the last kernel that moved X (fixed summation order)
-  const int cnt = a->rel_src == 4 ? a->n : (a->rel_src ? (4 * a->n + 7) / 8 : (a->n + 63) / 64);
+  const int cnt = a->rel_src == 4 ? a->n : (a->rel_src ? precond_nblk(*a) : (a->n + 63) / 64);
   const int stride = a->rel_src == 4 ? 1 : PART_STRIDE;
   const int off = a->rel_src == 1 ? PART_B + 2 : PART_D;
   std::vector<double> part((size_t)cnt * stride);
@@ -421,6 +417,37 @@ int dpgo_agent_preconditioner(dpgo_team_t *t, int id) {
   if (!a) return DPGO_ERR;
   if (sync_descs(t)) return DPGO_ERR;
   return a->precond;
+}
+
+int dpgo_agent_preconditioner_info(dpgo_team_t *t, int id, double *out) {
+  Agent *a = find_agent(t, id);
+  if (!a) return DPGO_ERR;
+  if (sync_descs(t)) return DPGO_ERR;
+  const double N4 = 4.0 * a->n;
+  const bool tl = a->precond == DPGO_PRECOND_TWO_LEVEL;
+  out[0] = a->precond;
+  out[1] = tl ? (double)a->tl_plan.sub.size() : 0;
+  out[2] = tl ? a->tl_plan.ns : 0;
+  out[3] = tl ? a->tl_plan.nwg : (4 * a->n + 7) / 8;
+  out[4] = tl ? a->tl_plan.nA : 0;
+  out[5] = tl ? a->tl_plan.bytes : (a->precond == DPGO_PRECOND_DENSE ? 8.0 * N4 * N4 : 128.0 * a->n);
+  out[6] = 8.0 * N4 * N4;
+  size_t mx = 0;
+  if (tl) for (const auto &s : a->tl_plan.sub) mx = std::max(mx, s.size());
+  out[7] = (double)mx;
+  return DPGO_OK;
+}
+
+int dpgo_two_level_plan(int n, const int *rowptr, const int *col, int max_sub, int *sub_of, double *info) {
+  if (n < 1 || !rowptr || !col) return DPGO_ERR;
+  const std::vector<int> rp(rowptr, rowptr + n + 1), cl(col, col + rowptr[n]);
+  const dpgo_host::TLPlan pl = dpgo_host::tl_make_plan(n, rp, cl, max_sub);
+  if (sub_of) for (int i = 0; i < n; ++i) sub_of[i] = pl.sub_of[i];
+  if (info) {
+    info[0] = (double)pl.sub.size(); info[1] = pl.ns; info[2] = pl.nwg; info[3] = pl.nA; info[4] = pl.bytes;
+    info[5] = dpgo_host::tl_worthwhile(pl) ? 1.0 : 0.0;
+  }
+  return DPGO_OK;
 }
 
 int dpgo_agent_set_iteration_number(dpgo_team_t *t, int id, int iteration) {
@@ -831,7 +858,7 @@ static int team_run_impl(dpgo_team_t *t, int iters, bool prepare_only) {
     int total = 0;
     for (auto &a : t->ag) total += a->n;
     for (auto &a : t->ag) {
-      const int nblk = (4 * a->n + 7) / 8;
+      const int nblk = precond_nblk(*a);
       if ((total - a->n + nblk - 1) / nblk > 64 || a->n > MAX_PART * PART_STRIDE) pipelined = false;
     }
   }
@@ -868,17 +895,8 @@ static int team_run_impl(dpgo_team_t *t, int iters, bool prepare_only) {
       // last block update of the run lies among them, and a status query reads it, a9), the look-aheads in front of
       // them leave XPrev and |Y' - X|^2; nothing reads these values earlier in the run
       const int L = std::min(B, (int)t->sched.size());
-      std::vector<int> ns;
-      for (auto &a : t->ag) ns.push_back(a->n);
-      bool all_dense = true;
-      for (auto &a : t->ag) all_dense = all_dense && a->precond == DPGO_PRECOND_DENSE;
-      const bool fused_iter = t->use_fused && all_dense && iter_fused_eligible(p.r, mn, ns.data(), na, t->num_cus);
       for (int rep = 0; rep < B; ++rep) {
         const int ahead = (rep + 1 < B ? 3 : 0) | ((rep + 1 < B && rep + 1 >= B - L) ? 4 : 0) | (rep >= B - L ? 8 : 0);
-        if (fused_iter) {  // evaluation + hand-off + step in ONE launch (iter_fused.hip)
-          launch_iter_rgd(c, mn, t->d_nest_all.p, t->d_bar.p, t->h_bar_err, rep == 0, p.rgd_stepsize, p.num_robots, p.restart_interval, ahead);
-          continue;
-        }
         launch_eval_stats(c, mn, rep == 0, 1, 0, p.num_robots, p.restart_interval, sel_at(rep), -1);
         launch_precond(c, sel_at(rep), mn, PM_RGD_, B_X, B_GF, B_Z, 0, 0, p.rgd_stepsize, 1, p.num_robots, 2, p.restart_interval,
                        ahead);
@@ -1273,14 +1291,6 @@ int dpgo_agent_read_partials(dpgo_team_t *t, int id, int offset, double *out, in
   HIPC(hipStreamSynchronize(t->stream));
   HIPC(hipMemcpy(out, a->dev.part + offset, sizeof(double) * n, hipMemcpyDeviceToHost));
   return n;
-}
-
-// diagnostic: raw hand-off words of the fused iteration kernel (counters, generation words, epoch, and -- in
-// DPGO_ITER_TRACE builds -- the per-phase timestamps of two workgroups)
-int dpgo_team_read_handoff_state(dpgo_team_t *t, unsigned long long *out, int n) {
-  HIPC(hipStreamSynchronize(t->stream));
-  HIPC(hipMemcpy(out, t->d_bar.p, sizeof(unsigned long long) * std::min(n, ITER_BAR_WORDS), hipMemcpyDeviceToHost));
-  return std::min(n, ITER_BAR_WORDS);
 }
 
 int dpgo_team_get_counters(dpgo_team_t *t, double *out, int n) {

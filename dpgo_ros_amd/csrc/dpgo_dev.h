@@ -53,6 +53,28 @@ struct NestState {
   int pad;
 };
 
+// two-level (nested-dissection / Schur-complement) form of the preconditioner, see twolevel.h.  Workgroup b of an apply
+// owns the poses own[0], own[1] (8 columns of the operator); its slab holds, as [row pair][column][2] doubles in the
+// order the lanes consume them, first the rows that meet the input vector itself (`pre_cnt` poses, listed in
+// rowpose[b * rp_stride ..]: the poses of its subdomain(s), D_i -- or, for a workgroup that owns separator poses, the
+// poses of the adjacent subdomains, -E_i), then the 4 ns separator rows that meet u (W_i, or Sc^-1).
+struct TLWg {
+  int own[2];          // poses (-1: padding slot)
+  int pre_cnt, pad0;
+  long long slab_off;  // doubles from TLDev::slabs
+  long long pad1;
+};
+struct TLDev {
+  int ns, nwg, nA, rp_stride;  // separator poses, workgroups, workgroups that own separator poses (the first nA), row-list stride
+  const TLWg *wg;
+  const int *rowpose;
+  const double *slabs;
+  double *u;                   // [4 ns][R]: v_S - sum_i v_i E_i, published by the first nA workgroups of an apply
+  unsigned long long *flag;    // [0] producers that have published (this apply), [16] workgroups past the exchange (the
+                               // last one clears both), [32] completed exchanges of the persistent solve kernel
+  int *err;                    // pinned host word raised when an exchange timed out
+};
+
 struct AgentDev {
   int id, n, nb, N4;
   int npub, nshared, nnp, nedges;
@@ -70,6 +92,7 @@ struct AgentDev {
                               // (the evaluation finds them with one round trip instead of pub_index -> pub_ptr)
   const double *M;            // dense (Q + shift I)^-1, N4 x N4 column-major (symmetric); null: block-Jacobi agent
   const double *Dinv;         // block-Jacobi agents: the inverted 4 x 4 diagonal blocks of Q + shift I, [n][16] column-major
+  TLDev tl;                   // two-level agents (tl.nwg > 0; M and Dinv null)
   const int *pub_pose;        // [npub] local poses that own >= 1 shared edge
   const int *pub_ptr;         // [npub+1] CSR into se
   const SharedEdgeDev *se;    // [nshared] sorted by lpose

@@ -11,6 +11,7 @@ struct LaunchCtx {
   const AgentDev *agents;  // device array
   TeamDev *team;           // device
   int ny = 1;              // grid.y of the per-agent kernels: members of the colour class being updated
+  int dense_max_n = 1 << 30;  // largest agent of the team that streams a dense inverse (0: none): sizes k_precond's LDS chunk
   const NestState *nest_all = nullptr;  // the team's NestStates, [local agent]: lets a kernel read an agent's Nesterov
                                         // state from the agent index alone, next to (not behind) its descriptor
 };
@@ -63,15 +64,6 @@ void launch_noop(const LaunchCtx &c, int grid, int block);
 void launch_copy(const LaunchCtx &c, int sel, int only_agent, int num_agents, int max_n, int from, int to, int publish);
 void launch_bsr_to_dense(hipStream_t s, const int *rowptr, const int *col, const double *qval, int n, double shift,
                          double *A);
-
-// iter_fused.hip: one launch per pipelined accelerated-RGD iteration (evaluation, grid-wide hand-off, step).
-// bar: 18 x 128 bytes of zero-initialised device memory owned by the team; err: pinned host word raised on a spin
-// time-out.  Eligibility: every agent fits one chunk, the grid is resident at once, every evaluation tile has a
-// non-padding workgroup.
-constexpr int ITER_BAR_WORDS = 18 * 16 + 48;  // + optional phase timestamps (DPGO_ITER_TRACE builds)
-bool iter_fused_eligible(int r, int max_n, const int *agent_n, int num_agents, int num_cus);
-void launch_iter_rgd(const LaunchCtx &c, int max_n, NestState *nest_all, unsigned long long *bar, int *err, int first,
-                     double step, int num_robots, int restart_interval, int ahead);
 
 // rtr_fused.hip: one launch per local RTR solve, the agent's preconditioner resident in LDS over the whole solve.
 // bar: RTR_BAR_WORDS zero-initialised 64-bit words owned by the AGENT (the arrival counts depend on its grid);

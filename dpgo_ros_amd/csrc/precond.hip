@@ -2,6 +2,8 @@
 // solver steps fused into it: tCG set-up and step (a4), the RGD step with the Nesterov V update and the look-ahead
 // Nesterov step of the pipelined iteration (a4, a6).  The one kernel of the path that streams HBM.
 #include "kernel_common.h"
+#include "twolevel_dev.h"
+#include <algorithm>
 
 namespace dpgo {
 
@@ -10,15 +12,8 @@ namespace dpgo {
 #ifndef DPGO_PC_MPRE
 #define DPGO_PC_MPRE 4
 #endif
-// -DDPGO_PC_DIRECT=1 builds the stream without LDS staging of the input vector (each lane takes two vector rows for all
-// 8 columns, as rtr_fused.hip's slab product does).  Measured: the stream of a 500-pose agent ends 2 us earlier inside
-// the kernel, the launch takes the same 16 us (the per-pose tail, not the stream, decides when the last workgroup
-// leaves), and agents of 625 / 1250 poses lose 25 / 19 % (one workgroup per CU instead of three).  Off.
 #ifndef DPGO_PC_KCMID
 #define DPGO_PC_KCMID 1280
-#endif
-#ifndef DPGO_PC_DIRECT
-#define DPGO_PC_DIRECT 0
 #endif
 #ifdef DPGO_PC_TRACE
 #define PC_STAMP(k) do { if (MODE == PM_RGD_ && (threadIdx.x & 63) == 0 && blockIdx.x == 100) ag.part[PART_E + 4000 * PART_STRIDE + ((threadIdx.x >> 6) * 16) + (k)] = (double)wall_clock64(); \
@@ -60,9 +55,12 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *__restrict__ ag
   // (h % 8) * (grid / 8) + h / 8 gives every XCD one contiguous range of poses, so that the cache lines shared by
   // neighbouring poses (a pose is 4R doubles, not a multiple of a line) are written inside one L2 instead of
   // being split between two.  The grid is padded to a multiple of 8; padding blocks fall out at the nblk test.
-  const int bx = ((int)blockIdx.x % 8) * ((int)gridDim.x / 8) + (int)blockIdx.x / 8;
+  // Two-level agents (ag.tl, twolevel.h) keep the hardware order: their first workgroups are the producers of the
+  // exchange and must be dispatched first.
   const int agent_index = sel_cur(team, sel);
   const AgentDev &ag = agents[agent_index];
+  const bool is_tl = ag.tl.nwg > 0;
+  const int bx = is_tl ? (int)blockIdx.x : ((int)blockIdx.x % 8) * ((int)gridDim.x / 8) + (int)blockIdx.x / 8;
   PC_STAMP(0);
   if (MODE == PM_RGD_ && advance == 2 && bx == 0 && threadIdx.x == 0) {
     // pipelined iterations: nothing that a workgroup of THIS launch reads is written here (cur_sel, iter and the
@@ -78,21 +76,23 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *__restrict__ ag
     team->iter += 1;
     team->stats_sel = team->cur_sel;
   }
-#if DPGO_PC_DIRECT
-  __shared__ double zs[8 * R];
-  __shared__ double red[256 * (8 * R + 1)];
-#else
+  // LDS: the staged input vector of the dense stream (R * KC doubles) and the 64 partial-sum rows of the two-level
+  // product (twolevel_dev.h) share one area -- a workgroup runs one or the other
   constexpr int MREG = KC / 64;
-  __shared__ double vs[R * KC];
+  constexpr int SMEM = (R * KC > 64 * (8 * R + 1)) ? R * KC : 64 * (8 * R + 1);
+  __shared__ double vs[SMEM];
   __shared__ double zs[8 * R];
   __shared__ double red[32 * (8 * R + 1)];
-#endif
   __shared__ double Ysh[2 * 4 * R];
   __shared__ double Esh[3][2 * 4 * R];  // PM_RGD: V, Yaux, XPrev of the two poses
   const int tid = threadIdx.x, lane = tid & 63;
   const int N4 = ag.N4;
-  const int nblk = precond_blocks(N4);
+  const int nblk = precond_nblk(ag);
   if (bx >= nblk) return;
+  // the two poses this workgroup owns: consecutive ones, or the pair the two-level layout assigns
+  TLWg tlw = {};
+  int pj0 = 2 * bx, pj1 = (2 * bx + 1 < ag.n) ? 2 * bx + 1 : -1;
+  if (is_tl) { tlw = ag.tl.wg[bx]; pj0 = tlw.own[0]; pj1 = tlw.own[1]; }
 
   // ---- scalar prologue (identical in every workgroup)
   double alpha = 0, tau = 0;
@@ -148,18 +148,16 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *__restrict__ ag
   // so only ONE vector (Hd) has to be pulled through every workgroup's LDS; r and z are updated in place by
   // their owners.  (The oracle recomputes z from r+ directly; the two differ by round-off only.)
   const double *Vstage = (MODE == PM_TCG_STEP_) ? Hd : Vin;
-  const int col0 = 8 * bx;
-  const int npose = min(2, ag.n - 2 * bx);
+  const int npose = (pj1 >= 0) ? 2 : 1;
+  // element `tid` (< npose * 4R) of the own poses in an r x 4n array
+  const size_t own_off = (size_t)((tid >= 4 * R) ? max(pj1, 0) : pj0) * 4 * R + (size_t)(tid % (4 * R));
 
   if (MODE == PM_TCG_STEP_) {
     // eta += (alpha | tau) * delta on the two poses owned by this workgroup
     const double *D = ag.buf[jpar ? B_D1 : B_D0];
     double *E = ag.buf[B_ETA];
     const double stepc = boundary ? tau : alpha;
-    if (tid < npose * 4 * R) {
-      const size_t o = (size_t)col0 * R + tid;
-      E[o] += stepc * D[o];
-    }
+    if (tid < npose * 4 * R) E[own_off] += stepc * D[own_off];
     if (boundary) return;
   }
 
@@ -171,11 +169,11 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *__restrict__ ag
   double pre_x = 0, pre_v = 0, pre_y = 0, pre_p = 0;
   double nest_gamma = 0;
   if (tid < npose * 4 * R) {
-    pre_x = ag.buf[xb][(size_t)col0 * R + tid];
+    pre_x = ag.buf[xb][own_off];
     if (MODE == PM_RGD_) {
-      pre_v = ag.buf[B_V][(size_t)col0 * R + tid];
-      pre_y = ag.buf[B_Y][(size_t)col0 * R + tid];
-      if (want_stats) pre_p = ag.buf[B_XPREV][(size_t)col0 * R + tid];
+      pre_v = ag.buf[B_V][own_off];
+      pre_y = ag.buf[B_Y][own_off];
+      if (want_stats) pre_p = ag.buf[B_XPREV][own_off];
     }
   }
   double ahead_alpha = 0;
@@ -210,97 +208,18 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *__restrict__ ag
   bool la_act = false, la_opt = false;
   int la_agent = 0, la_pose = 0;
   double la_x[4 * R], la_v[4 * R];
-#if DPGO_PC_DIRECT
-  // Direct form: lane t owns rows 2t, 2t+1 (+512 m) of the input vector for ALL 8 columns of the workgroup.  Every row
-  // of the vector is fetched once per workgroup straight from L2 (16-byte loads, no LDS staging, no barrier between the
-  // prologue and the stream), the slab requests follow immediately, and the 256 per-lane sums of each of the 8R outputs
-  // are combined by a quad reduction (DPP) plus 64 LDS rows.  Straight-line: rows / columns past the matrix re-read the
-  // last valid ones and enter with weight zero.
-  constexpr int MAXM = KC / 512;
-  double acc8[8][R];
-#pragma unroll
-  for (int c = 0; c < 8; ++c)
-#pragma unroll
-    for (int a = 0; a < R; ++a) acc8[c][a] = 0;
-  PC_STAMP(1);
-  if (!ag.M) {
-    // block-Jacobi agent (the declared fallback where the dense inverse does not fit, include/dpgo_hip.h): column
-    // c of pose p is  v_p (Q_pp + shift I)^-1[:, c], a 4 x 4 block per pose -- one lane per output, no reduction
-    if (tid < 8 * R) {
-      const int cc = tid / R, a = tid - cc * R, col = col0 + cc;
-      double s = 0;
-      if (col < N4) {
-        const int p = col >> 2, c = col & 3;
-        const double *B = ag.Dinv + (size_t)16 * p + 4 * c;
-#pragma unroll
-        for (int cp = 0; cp < 4; ++cp) s += Vstage[((size_t)4 * p + cp) * R + a] * B[cp];
-      }
-      zs[tid] = s;
+  if (is_tl) {
+    // two-level operator: the product of twolevel_dev.h (one exchange inside the launch), then the common epilogues
+    tl_apply<R>(ag.tl, tlw, bx, Vstage, vs, zs, tid);
+    if (tid < npose * 4 * R) {
+      Ysh[tid] = pre_x;
+      if (MODE == PM_RGD_) { Esh[0][tid] = pre_v; Esh[1][tid] = pre_y; Esh[2][tid] = pre_p; }
     }
+    // (zs and these rows are used by wave 0 / the first lanes of wave 1 only; wave 0 wrote Ysh / Esh itself, and wave 1
+    // reads none of them)
+    if (tid >= 128) return;
   } else {
-    const double *Mc[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) Mc[c] = ag.M + (size_t)min(col0 + c, N4 - 1) * N4;
-    for (int k0 = 0; k0 < N4; k0 += KC) {
-      double2 v[MAXM][R], mm[MAXM][8];
-#pragma unroll
-      for (int m = 0; m < MAXM; ++m) {
-        const int k = k0 + 2 * tid + 512 * m, kk = min(k, N4 - 2);
-#pragma unroll
-        for (int q = 0; q < R; ++q) v[m][q] = ld2(Vstage + (size_t)kk * R + 2 * q);
-      }
-      PC_STAMP(2);
-#pragma unroll
-      for (int m = 0; m < MAXM; ++m) {
-        const int k = k0 + 2 * tid + 512 * m, kk = min(k, N4 - 2);
-#pragma unroll
-        for (int c = 0; c < 8; ++c) mm[m][c] = ld2_nt(Mc[c] + kk);
-      }
-      PC_STAMP(3);
-#pragma unroll
-      for (int m = 0; m < MAXM; ++m) {
-        const int k = k0 + 2 * tid + 512 * m;
-        const double live = (k < N4) ? 1.0 : 0.0;
-        double w[2 * R];
-#pragma unroll
-        for (int q = 0; q < R; ++q) { w[2 * q] = v[m][q].x * live; w[2 * q + 1] = v[m][q].y * live; }
-#pragma unroll
-        for (int c = 0; c < 8; ++c)
-#pragma unroll
-          for (int a = 0; a < R; ++a) acc8[c][a] += w[a] * mm[m][c].x + w[R + a] * mm[m][c].y;
-      }
-    }
-    PC_STAMP(4);
-    // every lane leaves its 8R sums in its own LDS row (odd pitch: conflict-free both ways); four lanes per output
-    // then add 64 rows each and meet in a quad (DPP) -- 0.6 us where a DPP reduction of all 8R values per lane took 1.6
-    {
-      double *row = red + (size_t)tid * (8 * R + 1);
-#pragma unroll
-      for (int c = 0; c < 8; ++c)
-#pragma unroll
-        for (int a = 0; a < R; ++a) row[c * R + a] = acc8[c][a];
-    }
-  }
-  if (tid < npose * 4 * R) {
-    Ysh[tid] = pre_x;
-    if (MODE == PM_RGD_) { Esh[0][tid] = pre_v; Esh[1][tid] = pre_y; Esh[2][tid] = pre_p; }
-  }
-  __syncthreads();
-  if (ag.M && tid < 4 * 8 * R) {
-    const int o = tid >> 2, part = tid & 3;
-    double t[64];
-#pragma unroll
-    for (int q = 0; q < 64; ++q) t[q] = red[(size_t)(part * 64 + q) * (8 * R + 1) + o];
-    double s = 0;
-#pragma unroll
-    for (int q = 0; q < 64; ++q) s += t[q];
-    s += dpp_move<0xB1>(s);  // lanes ^ 1
-    s += dpp_move<0x4E>(s);  // lanes ^ 2
-    if (part == 0) zs[o] = s;
-  }
-  __syncthreads();
-  if (tid >= 128) return;
-#else
+  const int col0 = 8 * bx;
   const int cg = tid >> 5, kl = tid & 31;
   const int col = col0 + cg;
   const bool cact = col < N4;
@@ -336,6 +255,7 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *__restrict__ ag
   // (they do not hold the wave at the issue queue as the full 32 would) that take the ~2 us first-byte latency of the
   // stream -- row activation, translation -- under the 1.6 us of the staging instead of behind it
   constexpr int MPRE = DPGO_PC_MPRE;
+  if constexpr (KC > 0)
   for (int k0 = 0; ag.M && k0 < N4; k0 += KC) {
     const int kn = min(KC, N4 - k0);
     if (k0 > 0) __syncthreads();
@@ -401,7 +321,7 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *__restrict__ ag
     for (int q = 0; q < 32; ++q) s += red[q * (8 * R + 1) + tid];
     zs[tid] = s;
   }
-#endif
+  }  // (dense / block-Jacobi)
   PC_STAMP(5);
   if (tid < 64) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -490,7 +410,7 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *__restrict__ ag
     double rel = 0;
     if (tid < npose) {
       const int lp = tid;
-      const size_t o = (size_t)(2 * bx + lp) * 4 * R;
+      const size_t o = (size_t)(lp ? pj1 : pj0) * 4 * R;
       double x[4 * R], z[4 * R];
 #pragma unroll
       for (int i = 0; i < 4 * R; ++i) { x[i] = Ysh[lp * 4 * R + i]; z[i] = zs[lp * 4 * R + i]; }
@@ -538,7 +458,7 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *__restrict__ ag
             ag.buf[B_X][o + i] = x[i];
             if (!ahead_opt) { ag.buf[B_Y][o + i] = x[i]; v[i] = x[i]; } else if (reset) ag.buf[B_Y][o + i] = x[i];
           }
-          if (la_status && !ahead_opt) ag.part[PART_D + 2 * bx + lp] = 0.0;
+          if (la_status && !ahead_opt) ag.part[PART_D + (lp ? pj1 : pj0)] = 0.0;
         } else {
           double y[4 * R];
 #pragma unroll
@@ -551,7 +471,7 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *__restrict__ ag
             double rel2 = 0;
 #pragma unroll
             for (int i = 0; i < 4 * R; ++i) { const double d = y[i] - x[i]; rel2 += d * d; }
-            ag.part[PART_D + 2 * bx + lp] = rel2;  // look-ahead steps leave |Y' - X|^2 per pose
+            ag.part[PART_D + (lp ? pj1 : pj0)] = rel2;  // look-ahead steps leave |Y' - X|^2 per pose
           }
         }
       } else {
@@ -575,7 +495,7 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *__restrict__ ag
   double zr = 0, rr = 0;
   if (tid < npose * R) {
     const int lp = tid / R, a = tid - lp * R;
-    const size_t o = (size_t)(2 * bx + lp) * 4 * R;
+    const size_t o = (size_t)(lp ? pj1 : pj0) * 4 * R;
     double z[4];
     tangent_row<R>(Ysh + lp * 4 * R, zs + lp * 4 * R, a, z);
     z[3] = zs[lp * 4 * R + 3 * R + a];
@@ -610,17 +530,22 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *__restrict__ ag
 
 void launch_precond(const LaunchCtx &c, int sel, int max_n, int mode, int xb, int vb, int zb, int sp, int max_inner,
                     double step, int accel, int num_robots, int advance, int restart_interval, int ahead) {
-  const int grid = (((4 * max_n + 7) / 8) + 7) / 8 * 8;  // multiple of 8: see the XCD-aware block order in k_precond
+  // multiple of 8 (see the XCD-aware block order in k_precond); two-level agents run up to two workgroups more than
+  // pose pairs (padding of the separator / interior parts of their ownership order)
+  const int grid = (((4 * max_n + 7) / 8 + 2) + 7) / 8 * 8;
+  // largest agent this launch may meet that streams a DENSE inverse (0: none -- two-level / block-Jacobi agents only)
+  const int dn = std::min(max_n, c.dense_max_n);
 #define PC_LAUNCH(M, KCV)                                                                                          \
     DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL((k_precond<R, M, KCV>), dim3(grid, c.ny), dim3(256), 0, c.stream, c.agents,   \
                                             c.team, sel, xb, vb, zb, sp, max_inner, step, accel, num_robots, advance,   \
                                             restart_interval, ahead, c.nest_all))
   // chunk size by agent size: one 2048-row chunk for agents of 257..512 poses (one round trip, one workgroup per CU);
   // DPGO_PC_KCMID-row chunks for 513..(DPGO_PC_KCMID / 2) poses (two round trips instead of three, still three
-  // workgroups per CU); 1024-row chunks otherwise
+  // workgroups per CU); 1024-row chunks otherwise; no dense stream at all (KC = 0) where no dense agent can be met
 #define PC_CALL(M)                                                                                                  \
-  if (4 * max_n > 1024 && 4 * max_n <= 2048) { PC_LAUNCH(M, 2048); }                                                  \
-  else if (DPGO_PC_KCMID > 0 && 4 * max_n > 2048 && 4 * max_n <= 2 * DPGO_PC_KCMID) { PC_LAUNCH(M, (DPGO_PC_KCMID > 0 ? DPGO_PC_KCMID : 1024)); } \
+  if (dn == 0) { PC_LAUNCH(M, 0); }                                                                                    \
+  else if (4 * dn > 1024 && 4 * dn <= 2048) { PC_LAUNCH(M, 2048); }                                                    \
+  else if (DPGO_PC_KCMID > 0 && 4 * dn > 2048 && 4 * dn <= 2 * DPGO_PC_KCMID) { PC_LAUNCH(M, (DPGO_PC_KCMID > 0 ? DPGO_PC_KCMID : 1024)); } \
   else { PC_LAUNCH(M, 1024); }
   if (mode == PM_PLAIN_) { PC_CALL(PM_PLAIN_); }
   else if (mode == PM_TCG_INIT_) { PC_CALL(PM_TCG_INIT_); }

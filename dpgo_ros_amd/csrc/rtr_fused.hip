@@ -78,59 +78,6 @@ constexpr int RB_TRACE = 17 * RB_LINE + 2;
 #define RTR_FINE(k) do { } while (0)
 #endif
 
-// Publish / read flavours, kept as build switches because they were measured against each other (us per tCG iteration,
-// DESIGN.md section 4): write-through stores + sc1 loads (default) 17.0 | write-through stores + plain loads behind an
-// agent acquire per hand-off (DPGO_RTR_PLAIN_LD=1) 18.0 | plain stores + agent release per hand-off
-// (DPGO_RTR_PLAIN_ST=1) 22.5-25.  DPGO_RTR_LDAUX is the cache policy of the reads (16 = sc1; 2 = nt and 18 = sc1 nt
-// are slower; 1 = sc0 is faster and NOT valid: it hits this CU's L1).
-#ifndef DPGO_RTR_PLAIN_ST
-#define DPGO_RTR_PLAIN_ST 0
-#endif
-#ifndef DPGO_RTR_PLAIN_LD
-#define DPGO_RTR_PLAIN_LD 0
-#endif
-#ifndef DPGO_RTR_LDAUX
-#define DPGO_RTR_LDAUX 16  // buffer-load cache policy of the cross-workgroup reads: 16 = sc1
-#endif
-__device__ __forceinline__ void st_c(double *p, double v) {
-#if DPGO_RTR_PLAIN_ST
-  *p = v;
-#else
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
-}
-
-// How a workgroup reads what the others published with st_c: buffer loads with sc1 (they bypass this CU's L1 and are
-// served by the L2 / the fabric), 8 or 16 bytes.  Ordinary loads to the compiler, so a batch of them is issued back
-// to back.  The descriptor must be wave-uniform (built from scalar pointers; a lane-dependent choice of buffer turns
-// every load into a waterfall loop).
-typedef unsigned int v4u_t __attribute__((ext_vector_type(4)));
-typedef unsigned int v2u_t __attribute__((ext_vector_type(2)));
-struct CVec {
-  __amdgpu_buffer_rsrc_t rs;
-  __device__ __forceinline__ CVec(const double *p, int count)
-      : rs(__builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(p), 0, count * 8, 0x00020000)) {}
-  __device__ __forceinline__ double ld(int i) const {
-    const v2u_t r = __builtin_amdgcn_raw_buffer_load_b64(rs, i * 8, 0, DPGO_RTR_PLAIN_LD ? 0 : DPGO_RTR_LDAUX);
-    double d;
-    __builtin_memcpy(&d, &r, 8);
-    return d;
-  }
-  __device__ __forceinline__ double2 ld2(int i) const {
-    const v4u_t r = __builtin_amdgcn_raw_buffer_load_b128(rs, i * 8, 0, DPGO_RTR_PLAIN_LD ? 0 : DPGO_RTR_LDAUX);
-    double2 d;
-    __builtin_memcpy(&d, &r, 16);
-    return d;
-  }
-};
-
-#define WSYNC()                                                  \
-  do {                                                           \
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       \
-    __builtin_amdgcn_wave_barrier();                             \
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       \
-  } while (0)
-
 struct GridBar {
   unsigned long long *bar;
   unsigned long long epoch;

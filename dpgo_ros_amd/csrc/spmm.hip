@@ -100,7 +100,7 @@ __global__ __launch_bounds__(64) void k_tcg_hv(const AgentDev *__restrict__ agen
     return;
   }
   const double kappa = 0.1;  // tCG stop: |r| <= |r0| min(|r0|^theta, kappa) with theta = 1
-  const int npb = precond_blocks(ag.N4);
+  const int npb = precond_nblk(ag);
   double zr_new, rr_new;
   sum_partials2(ag.part + PART_B, npb, PART_STRIDE, lane, zr_new, rr_new);
   RtrState T = S;

@@ -20,6 +20,7 @@
 #include "../../include/dpgo_hip.h"
 #include "dpgo_dev.h"
 #include "kernels.h"
+#include "twolevel.h"
 
 namespace dpgo_host {
 using namespace dpgo;
@@ -99,6 +100,15 @@ struct Agent {
   DevBuf<int> d_rowptr, d_col, d_pub_pose, d_pub_ptr, d_idx, d_ell_col, d_trowptr, d_tcol, d_pub_index;
   int precond = DPGO_PRECOND_DENSE;  // what this agent runs (decided when its data matrices are built)
   DevBuf<double> d_dinv;
+  // two-level form of the preconditioner (twolevel.h): the dissection (kept while the sparsity pattern stands; a weight
+  // update only refills the slabs), its device tables and slabs
+  TLPlan tl_plan;
+  std::vector<int> tl_rowptr, tl_col;  // the pattern the plan was made for
+  DevBuf<int> d_tl_blk, d_tl_lidx, d_tl_subptr, d_tl_subposes, d_tl_adjptr, d_tl_adjlist, d_tl_rowpose;
+  DevBuf<long long> d_tl_doff, d_tl_eoff;
+  DevBuf<dpgo::TLWg> d_tl_wg;
+  DevBuf<double> d_tl_slabs, d_tl_u;
+  DevBuf<unsigned long long> d_tl_flag;
   DevBuf<double> d_qval, d_M, d_vec, d_nbr, d_part, d_scal, d_resid, d_ell_val, d_tval;
   std::map<int, std::unique_ptr<DevBuf<int>>> d_pubframes, d_nbrslots;  // per neighbour, cached on the device
   std::map<int, int> n_pubframes, n_nbrslots;
@@ -177,29 +187,34 @@ struct dpgo_team {
   // public poses are read in place over peer access instead of travelling as messages
   struct Peer { double *base = nullptr; size_t off_x = 0, off_y = 0; int n = 0; };
   std::map<int, Peer> peers;
-  // fused iteration kernel (iter_fused.hip): hand-off counters, time-out flag (pinned), resident capacity, switch
+  // time-out flag of the in-kernel exchanges (pinned), CU count
   dpgo_host::DevBuf<dpgo::NestState> d_nest_all;  // NestState of local agent k at [k]: one array, so that a kernel finds any agent's
                                                    // state from the agent index alone (no descriptor round trip)
-  dpgo_host::DevBuf<unsigned long long> d_bar;
   int *h_bar_err = nullptr;
   int num_cus = 0;
+  int dense_max_n = 0;  // largest agent with a dense inverse (sizes the LDS chunk of the preconditioner kernel)
   int bake_sel = 1;  // DPGO_BAKE_SEL=0: the graphs of the pipelined iteration select their agent on the device only
   bool last_iteration_folded = false;  // ... and enqueue_team_iteration skipped k_nest_post / k_status / k_advance for it
   bool last_rtr_folded = false;  // the last enqueue_optimize ran the one-launch solve WITH the iteration's tail
   bool rtr_validated = false;  // a one-launch solve has completed on this device (its grid is resident at once)
   int use_fused_rtr = 1;  // DPGO_FUSED_RTR=0 keeps the launch-per-step RTR sequence (solve.hip) for every agent
-  int use_fused = 0;  // DPGO_FUSED_ITER=1 selects the one-launch iteration (measured 27 us against 25 for two launches on
-                      // sphere2500 / 5 agents, profiles/r02_fused_iteration.md, hence off by default)
   unsigned long long epoch = 1;  // bumped by everything that enqueues device work (every launch goes through ctx())
   dpgo::LaunchCtx ctx() {
     ++epoch;
     dpgo::LaunchCtx c{prm.r, stream, d_agents.p, d_team.p};
     c.nest_all = d_nest_all.p;
+    c.dense_max_n = dense_max_n;
     return c;
   }
 };
 
 namespace dpgo_host {
+
+// ---- twolevel.hip
+bool tl_worthwhile(const TLPlan &pl);
+int tl_build(dpgo_team *t, const std::vector<Agent *> &agents);
+// workgroups of a preconditioner-type launch that leave partials in PART_B (device twin: precond_nblk)
+inline int precond_nblk(const Agent &a) { return a.precond == DPGO_PRECOND_TWO_LEVEL ? a.tl_plan.nwg : (4 * a.n + 7) / 8; }
 
 // ---- assembly.hip
 Agent *find_agent(dpgo_team *t, int id);

@@ -34,11 +34,14 @@ enum { DPGO_COST_L2 = 0, DPGO_COST_GNC_TLS = 5 };         /* RobustCostParameter
 enum { DPGO_WAIT_FOR_DATA = 0, DPGO_WAIT_FOR_INITIALIZATION = 1, DPGO_INITIALIZED = 2 }; /* msg/Status.msg:1-3 */
 enum { DPGO_WEIGHT_LIBRARY = 0, DPGO_WEIGHT_WRAPPER = 1 }; /* info-matrix vs kappa=1e4,tau=1e2 */
 enum { DPGO_OK = 0, DPGO_NOT_READY = 1, DPGO_ERR = -1 };
-/* preconditioner of the local solves.  The reference's is a sparse Cholesky solve with Q + shift I; DENSE is
- * the same operator as a dense inverse (12 N^2 doubles of HBM during set-up, N = 4 poses: 2000 poses -> 6 GB, 5750 ->
- * 51 GB).  BLOCK_JACOBI (the inverses of the 4 x 4 diagonal blocks) is NOT the reference's preconditioner: an O(n)-memory
- * fallback for agents whose dense inverse does not fit, restated in the oracle (precond_mode 2) for its own parity tests. */
-enum { DPGO_PRECOND_AUTO = 0, DPGO_PRECOND_DENSE = 1, DPGO_PRECOND_BLOCK_JACOBI = 2 };
+/* preconditioner of the local solves.  The reference's is a sparse Cholesky solve with Q + shift I.  Two forms
+ * of that SAME operator are built here: DENSE, the explicit inverse (N^2 doubles, N = 4 poses; small agents), and
+ * TWO_LEVEL, the exact nested-dissection / Schur-complement form (dense inverses of p subdomains + the separator block:
+ * 8 MB instead of 32 MB at 500 poses on sphere2500, 0.9 GB instead of 4.2 GB for cubicle as one agent, 4 GB for a
+ * 60 000-pose chain) -- equal to round-off.  BLOCK_JACOBI (the inverses of the 4 x 4 diagonal blocks) is NOT the
+ * reference's preconditioner: it runs only when asked for (precond_mode 2; restated in the oracle for its own parity
+ * tests) or when neither exact form fits the device. */
+enum { DPGO_PRECOND_AUTO = 0, DPGO_PRECOND_DENSE = 1, DPGO_PRECOND_BLOCK_JACOBI = 2, DPGO_PRECOND_TWO_LEVEL = 3 };
 /* largest pose index dpgo_agent_add_measurements accepts (a dense preconditioner of (4n)^2 doubles is the limit
  * long before this; see dpgo_agent memory guard in DESIGN.md 3) */
 #define DPGO_MAX_POSE_INDEX 1000000
@@ -66,8 +69,9 @@ typedef struct {
   int weights_as_float32;
   int robust_opt_num_resets;  /* src/PGOAgentROSNode.cpp:213: written by the wrapper, never read by it; its semantics live
                                * in the absent library -> carried, validated (>= 0), no effect */
-  int precond_mode;           /* DPGO_PRECOND_*: 0 automatic (dense inverse where it fits the device, block-Jacobi
-                               * otherwise), 1 dense inverse (error if it does not fit), 2 block-Jacobi */
+  int precond_mode;           /* DPGO_PRECOND_*: 0 automatic (dense inverse for small agents, the two-level form where it
+                               * streams less than half the dense bytes), 1 dense inverse (error if it does not fit),
+                               * 2 block-Jacobi, 3 two-level for every agent */
   int status_every_iterate;   /* 0 (default): relativeChange / readyToTerminate describe the last iterate(true) of the
                                * agent [UPSTREAM-RECALL]; 1: refreshed by every iterate (round-1 behaviour) */
 } dpgo_params_t;
@@ -161,9 +165,17 @@ int dpgo_agent_iterate(dpgo_team_t *t, int id, int do_optimization);    /* :160 
 int dpgo_agent_get_status(dpgo_team_t *t, int id, dpgo_status_t *s);     /* getStatus() :616 */
 int dpgo_agent_get_opt_result(dpgo_team_t *t, int id, dpgo_opt_result_t *r); /* :169-172 */
 int dpgo_agent_iteration_number(dpgo_team_t *t, int id);                 /* iteration_number() :139 */
-/* preconditioner the agent actually runs (DPGO_PRECOND_DENSE or DPGO_PRECOND_BLOCK_JACOBI), after its data matrices
+/* preconditioner the agent actually runs (DPGO_PRECOND_DENSE, _TWO_LEVEL or _BLOCK_JACOBI), after its data matrices
  * were built; <0 on error */
 int dpgo_agent_preconditioner(dpgo_team_t *t, int id);
+/* diagnostic, out[8]: {mode, subdomains, separator poses, workgroups of an apply, workgroups that own separator poses,
+ * bytes one apply streams, bytes of the dense inverse, largest subdomain (poses)} */
+int dpgo_agent_preconditioner_info(dpgo_team_t *t, int id, double *out);
+/* the dissection behind the two-level form, host arithmetic only (csrc/twolevel_plan.cpp): block-CSR pattern of Q (row j
+ * lists the poses coupled to j, diagonal included) -> sub_of[n] (subdomain of a pose, -1 = separator); max_sub <= 0: the
+ * subdomain size that streams the fewest bytes.  info[6]: {subdomains, separator poses, workgroups, producer workgroups,
+ * bytes per apply, 1 if the automatic mode would pick this form over the dense inverse} */
+int dpgo_two_level_plan(int n, const int *rowptr, const int *col, int max_sub, int *sub_of, double *info);
 int dpgo_agent_publish_requested(dpgo_team_t *t, int id, int clear);     /* mPublishPublicPosesRequested :109-112 */
 int dpgo_agent_set_iteration_number(dpgo_team_t *t, int id, int iteration); /* mIterationNumber = ... (RECOVER, :1196) */
 
@@ -255,8 +267,6 @@ int dpgo_team_import_peer(dpgo_team_t *t, int robot_id, const unsigned char *han
 int dpgo_agent_read_rtr_handoff(dpgo_team_t *t, int id, unsigned long long *out, int n);
 /* diagnostic: `n` doubles of an agent's device-side partial-sum scratch (csrc/dpgo_dev.h PART_*) from `offset` */
 int dpgo_agent_read_partials(dpgo_team_t *t, int id, int offset, double *out, int n);
-/* diagnostic: the hand-off words of the fused iteration kernel (csrc/iter_fused.hip); returns the count copied */
-int dpgo_team_read_handoff_state(dpgo_team_t *t, unsigned long long *out, int n);
 /* counters for the roofline report: launches and algorithmic bytes of the dominant kernels */
 int dpgo_team_get_counters(dpgo_team_t *t, double *out, int n);
 
