@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdpgo_hip.so")
+# (DPGO_HIP_LIB: an instrumented build of the same library, profiles/experiments/build_variant.sh)
+LIB_PATH = os.environ.get("DPGO_HIP_LIB") or os.path.join(_HERE, "libdpgo_hip.so")
 _LIB = None
 
 

@@ -421,6 +421,8 @@ int sync_descs_noflush(dpgo_team *t) {
       if (tl_build(t, tl_agents)) return DPGO_ERR;
       t->dense_max_n = 0;
       for (auto &a : t->ag) if (a->precond == DPGO_PRECOND_DENSE) t->dense_max_n = std::max(t->dense_max_n, a->n);
+      t->precond_of.clear();
+      for (auto &a : t->ag) t->precond_of.push_back(a->precond);
     }
   }
   if (!t->descs_dirty) return 0;

@@ -928,8 +928,7 @@ static int team_run_impl(dpgo_team_t *t, int iters, bool prepare_only) {
     return 0;
   };
   auto account = [&](int sel) {
-    const int n = t->ag[sel]->n, N4 = 4 * n;
-    t->counters[0] += 1; t->counters[1] += 8.0 * N4 * (double)N4;
+    t->counters[0] += 1; t->counters[1] += precond_operator_bytes(*t->ag[sel]);
     t->counters[2] += 2; t->counters[3] += 2 * spmm_bytes_of(t, *t->ag[sel]);
   };
   int k = 0;
@@ -1105,8 +1104,7 @@ int dpgo_team_run_simultaneous(dpgo_team_t *t, int ticks) {
   LaunchCtx c1 = t->ctx();
   launch_advance(c1, -1, na, 0, p.num_robots, p.restart_interval, 1, ticks, ticks * na);
   for (auto &a : t->ag) {
-    const double N4 = 4.0 * a->n;
-    t->counters[0] += ticks; t->counters[1] += ticks * 8.0 * N4 * N4;
+    t->counters[0] += ticks; t->counters[1] += ticks * precond_operator_bytes(*a);
     t->counters[2] += ticks + 1; t->counters[3] += (ticks + 1) * spmm_bytes_of(t, *a);
     a->rel_src = 1; a->iter += ticks; a->opt_pending_rgd = true; a->publish_requested = true;
     mark_optimized(t, *a, 1, true);
@@ -1332,14 +1330,14 @@ int dpgo_team_time_kernel(dpgo_team_t *t, int id, int which, int reps, double *a
                      t->prm.restart_interval, 3);
     else launch_copy(c, -3, -1, (int)t->ag.size(), t->max_n, B_X, B_XPREV, 0);
   };
-  if (which == 0) *algorithmic_bytes = 8.0 * N4 * N4 + 3.0 * vec;          // M once, v + X in, z out
+  if (which == 0) *algorithmic_bytes = precond_operator_bytes(*a) + 3.0 * vec;  // the operator once, v + X in, z out
   else if (which == 9) {
     // a mid-run iteration: M once; gradient, X, V, Y in and Y, X, V out for this agent; X, V in and Y, X out for the
     // look-ahead Nesterov step of every other agent (XPrev, the X2 snapshot and the status partials only move in the
     // last two iterations of a run)
     double others = 0;
     for (auto &b : t->ag) if (b.get() != a) others += 8.0 * r * 4 * b->n;
-    *algorithmic_bytes = 8.0 * N4 * N4 + 7.0 * vec + 4.0 * others;
+    *algorithmic_bytes = precond_operator_bytes(*a) + 7.0 * vec + 4.0 * others;
   }
   else *algorithmic_bytes = 8.0 * (16.0 * a->col.size() + 3.0 * r * 4 * n) + 4.0 * (a->col.size() + n + 1);
   if (which == 12 || which == 13) {
@@ -1402,7 +1400,7 @@ int dpgo_team_time_kernel(dpgo_team_t *t, int id, int which, int reps, double *a
     const int na = (int)t->ag.size(), mn = t->max_n;
     double others = 0;
     for (auto &b : t->ag) if (b.get() != a) others += 8.0 * r * 4 * b->n;
-    *algorithmic_bytes = 8.0 * N4 * N4 + 7.0 * vec + 4.0 * others;  // as for which == 9
+    *algorithmic_bytes = precond_operator_bytes(*a) + 7.0 * vec + 4.0 * others;  // as for which == 9
     hipEvent_t e0, e1;
     HIPC(hipEventCreate(&e0)); HIPC(hipEventCreate(&e1));
     LaunchCtx cc = t->ctx();

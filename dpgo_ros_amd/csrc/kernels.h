@@ -12,6 +12,8 @@ struct LaunchCtx {
   TeamDev *team;           // device
   int ny = 1;              // grid.y of the per-agent kernels: members of the colour class being updated
   int dense_max_n = 1 << 30;  // largest agent of the team that streams a dense inverse (0: none): sizes k_precond's LDS chunk
+  bool any_two_level = false;      // the team has an agent with the two-level preconditioner
+  const int *host_precond = nullptr;  // [local agent] DPGO_PRECOND_* it runs (host memory; selects the kernel variant)
   const NestState *nest_all = nullptr;  // the team's NestStates, [local agent]: lets a kernel read an agent's Nesterov
                                         // state from the agent index alone, next to (not behind) its descriptor
 };

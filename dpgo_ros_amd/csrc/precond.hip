@@ -15,10 +15,15 @@ namespace dpgo {
 #ifndef DPGO_PC_KCMID
 #define DPGO_PC_KCMID 1280
 #endif
+#ifndef DPGO_PC_TRACE_BLOCK
+#define DPGO_PC_TRACE_BLOCK 100
+#endif
 #ifdef DPGO_PC_TRACE
-#define PC_STAMP(k) do { if (MODE == PM_RGD_ && (threadIdx.x & 63) == 0 && blockIdx.x == 100) ag.part[PART_E + 4000 * PART_STRIDE + ((threadIdx.x >> 6) * 16) + (k)] = (double)wall_clock64(); \
+#define PC_TRACE_ON true
+#define PC_STAMP(k) do { if (MODE == PM_RGD_ && (threadIdx.x & 63) == 0 && blockIdx.x == DPGO_PC_TRACE_BLOCK) ag.part[PART_E + 4000 * PART_STRIDE + ((threadIdx.x >> 6) * 16) + (k)] = (double)wall_clock64(); \
     if (MODE == PM_RGD_ && threadIdx.x < 128 && (threadIdx.x & 63) == 0 && ((k) == 0 || (k) == 7)) ag.part[PART_E + (4100 + 2 * (int)blockIdx.x + (int)(threadIdx.x >> 6)) * PART_STRIDE + ((k) ? 1 : 0)] = (double)wall_clock64(); } while (0)
 #else
+#define PC_TRACE_ON false
 #define PC_STAMP(k) do { } while (0)
 #endif
 
@@ -46,7 +51,9 @@ namespace dpgo {
 // workgroup per CU; larger agents use 1024-row chunks so that 3 workgroups fit a CU and one workgroup's
 // arithmetic overlaps the others' streams.
 
-template <int R, int MODE, int KC>
+// TLC: the two-level product is compiled in (it costs the dense variants registers, i.e. occupancy: teams without a
+// two-level agent run kernels without it)
+template <int R, int MODE, int KC, bool TLC>
 __global__ __launch_bounds__(256) void k_precond(const AgentDev *__restrict__ agents, TeamDev *team, int sel, int xb, int vb,
                                                  int zb, int sp, int max_inner, double step, int accel,
                                                  int num_robots, int advance, int restart_interval, int ahead,
@@ -59,7 +66,7 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *__restrict__ ag
   // exchange and must be dispatched first.
   const int agent_index = sel_cur(team, sel);
   const AgentDev &ag = agents[agent_index];
-  const bool is_tl = ag.tl.nwg > 0;
+  const bool is_tl = TLC && ag.tl.nwg > 0;
   const int bx = is_tl ? (int)blockIdx.x : ((int)blockIdx.x % 8) * ((int)gridDim.x / 8) + (int)blockIdx.x / 8;
   PC_STAMP(0);
   if (MODE == PM_RGD_ && advance == 2 && bx == 0 && threadIdx.x == 0) {
@@ -79,7 +86,7 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *__restrict__ ag
   // LDS: the staged input vector of the dense stream (R * KC doubles) and the 64 partial-sum rows of the two-level
   // product (twolevel_dev.h) share one area -- a workgroup runs one or the other
   constexpr int MREG = KC / 64;
-  constexpr int SMEM = (R * KC > 64 * (8 * R + 1)) ? R * KC : 64 * (8 * R + 1);
+  constexpr int SMEM = (!TLC || R * KC > TL_RED_DOUBLES(R)) ? (R * KC > 0 ? R * KC : 1) : TL_RED_DOUBLES(R);
   __shared__ double vs[SMEM];
   __shared__ double zs[8 * R];
   __shared__ double red[32 * (8 * R + 1)];
@@ -92,7 +99,9 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *__restrict__ ag
   // the two poses this workgroup owns: consecutive ones, or the pair the two-level layout assigns
   TLWg tlw = {};
   int pj0 = 2 * bx, pj1 = (2 * bx + 1 < ag.n) ? 2 * bx + 1 : -1;
-  if (is_tl) { tlw = ag.tl.wg[bx]; pj0 = tlw.own[0]; pj1 = tlw.own[1]; }
+  if constexpr (TLC) {
+    if (is_tl) { tlw = ag.tl.wg[bx]; pj0 = tlw.own[0]; pj1 = tlw.own[1]; }
+  }
 
   // ---- scalar prologue (identical in every workgroup)
   double alpha = 0, tau = 0;
@@ -148,6 +157,11 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *__restrict__ ag
   // so only ONE vector (Hd) has to be pulled through every workgroup's LDS; r and z are updated in place by
   // their owners.  (The oracle recomputes z from r+ directly; the two differ by round-off only.)
   const double *Vstage = (MODE == PM_TCG_STEP_) ? Hd : Vin;
+  // two-level agents: the first pass of the product is requested here, in front of everything the epilogue will need
+  TLPre<R> tlpre;
+  if constexpr (TLC) {
+    if (is_tl) tl_issue<R>(ag.tl, tlw, bx, Vstage, tid, tlpre);
+  }
   const int npose = (pj1 >= 0) ? 2 : 1;
   // element `tid` (< npose * 4R) of the own poses in an r x 4n array
   const size_t own_off = (size_t)((tid >= 4 * R) ? max(pj1, 0) : pj0) * 4 * R + (size_t)(tid % (4 * R));
@@ -210,7 +224,9 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *__restrict__ ag
   double la_x[4 * R], la_v[4 * R];
   if (is_tl) {
     // two-level operator: the product of twolevel_dev.h (one exchange inside the launch), then the common epilogues
-    tl_apply<R>(ag.tl, tlw, bx, Vstage, vs, zs, tid);
+    if constexpr (TLC)
+    tl_apply<R, PC_TRACE_ON>(ag.tl, tlw, bx, Vstage, tlpre, vs, zs, tid,
+                             (MODE == PM_RGD_ && blockIdx.x == DPGO_PC_TRACE_BLOCK) ? ag.part + PART_E + 4000 * PART_STRIDE : nullptr);
     if (tid < npose * 4 * R) {
       Ysh[tid] = pre_x;
       if (MODE == PM_RGD_) { Esh[0][tid] = pre_v; Esh[1][tid] = pre_y; Esh[2][tid] = pre_p; }
@@ -533,25 +549,33 @@ void launch_precond(const LaunchCtx &c, int sel, int max_n, int mode, int xb, in
   // multiple of 8 (see the XCD-aware block order in k_precond); two-level agents run up to two workgroups more than
   // pose pairs (padding of the separator / interior parts of their ownership order)
   const int grid = (((4 * max_n + 7) / 8 + 2) + 7) / 8 * 8;
-  // largest agent this launch may meet that streams a DENSE inverse (0: none -- two-level / block-Jacobi agents only)
-  const int dn = std::min(max_n, c.dense_max_n);
-#define PC_LAUNCH(M, KCV)                                                                                          \
-    DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL((k_precond<R, M, KCV>), dim3(grid, c.ny), dim3(256), 0, c.stream, c.agents,   \
+  // What this launch may meet: a host-selected agent is known; a device-selected one (schedule, colour class) may be
+  // any agent of the team.  dn: largest agent that streams a DENSE inverse (0: none); tl: a two-level agent is possible.
+  int dn = std::min(max_n, c.dense_max_n);
+  bool tl = c.any_two_level;
+  if (sel >= 0 && c.host_precond) {
+    tl = c.host_precond[sel] == 3;
+    if (c.host_precond[sel] != 1) dn = 0;
+  }
+#define PC_LAUNCH(M, KCV, TLV)                                                                                      \
+    DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL((k_precond<R, M, KCV, TLV>), dim3(grid, c.ny), dim3(256), 0, c.stream, c.agents, \
                                             c.team, sel, xb, vb, zb, sp, max_inner, step, accel, num_robots, advance,   \
                                             restart_interval, ahead, c.nest_all))
   // chunk size by agent size: one 2048-row chunk for agents of 257..512 poses (one round trip, one workgroup per CU);
   // DPGO_PC_KCMID-row chunks for 513..(DPGO_PC_KCMID / 2) poses (two round trips instead of three, still three
   // workgroups per CU); 1024-row chunks otherwise; no dense stream at all (KC = 0) where no dense agent can be met
-#define PC_CALL(M)                                                                                                  \
-  if (dn == 0) { PC_LAUNCH(M, 0); }                                                                                    \
-  else if (4 * dn > 1024 && 4 * dn <= 2048) { PC_LAUNCH(M, 2048); }                                                    \
-  else if (DPGO_PC_KCMID > 0 && 4 * dn > 2048 && 4 * dn <= 2 * DPGO_PC_KCMID) { PC_LAUNCH(M, (DPGO_PC_KCMID > 0 ? DPGO_PC_KCMID : 1024)); } \
-  else { PC_LAUNCH(M, 1024); }
+#define PC_CALL2(M, TLV)                                                                                            \
+  if (dn == 0) { PC_LAUNCH(M, 0, TLV); }                                                                               \
+  else if (4 * dn > 1024 && 4 * dn <= 2048) { PC_LAUNCH(M, 2048, TLV); }                                               \
+  else if (DPGO_PC_KCMID > 0 && 4 * dn > 2048 && 4 * dn <= 2 * DPGO_PC_KCMID) { PC_LAUNCH(M, (DPGO_PC_KCMID > 0 ? DPGO_PC_KCMID : 1024), TLV); } \
+  else { PC_LAUNCH(M, 1024, TLV); }
+#define PC_CALL(M) if (tl) { PC_CALL2(M, true) } else { PC_CALL2(M, false) }
   if (mode == PM_PLAIN_) { PC_CALL(PM_PLAIN_); }
   else if (mode == PM_TCG_INIT_) { PC_CALL(PM_TCG_INIT_); }
   else if (mode == PM_TCG_STEP_) { PC_CALL(PM_TCG_STEP_); }
   else { PC_CALL(PM_RGD_); }
 #undef PC_CALL
+#undef PC_CALL2
 #undef PC_LAUNCH
 }
 

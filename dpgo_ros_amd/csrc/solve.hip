@@ -72,7 +72,7 @@ int enqueue_optimize(dpgo_team *t, int sel, const OptFlags &fl) {
     }
     if (sel >= 0 && !fl.capture) {
       Agent &a = *t->ag[sel];
-      if (p.rgd_use_preconditioner) { t->counters[0] += 1; t->counters[1] += 8.0 * N4 * (double)N4; }
+      if (p.rgd_use_preconditioner) { t->counters[0] += 1; t->counters[1] += precond_operator_bytes(a); }
       t->counters[2] += 2; t->counters[3] += 2 * spmm_bytes_of(t, a);
       a.opt_pending_rgd = true;
     }
@@ -180,7 +180,7 @@ int enqueue_optimize(dpgo_team *t, int sel, const OptFlags &fl) {
   if (hs->outer_count > 0) a.tcg_hint = std::max(2, std::min(8, (hs->tcg_total + hs->outer_count - 1) / hs->outer_count + 1));
   for (int o = 0; o < 4; ++o) a.tcg_hint_o[o] = (o < hs->outer_count) ? hs->tcg_o[o] : 0;
   account();
-  t->counters[0] += hs->pc_count; t->counters[1] += hs->pc_count * 8.0 * N4 * (double)N4;
+  t->counters[0] += hs->pc_count; t->counters[1] += hs->pc_count * precond_operator_bytes(a);
   return 0;
 }
 
@@ -260,9 +260,8 @@ int refresh_rtr_result(dpgo_team *t, Agent &a) {
   a.opt.hessvec_count = hs->hv_count; a.opt.precond_count = hs->pc_count; a.opt.accepted = hs->accepted;
   unsigned long long d[4];
   for (int k = 0; k < 4; ++k) { d[k] = a.h_rtr_cum.p[k] - a.rtr_seen[k]; a.rtr_seen[k] = a.h_rtr_cum.p[k]; }
-  const double N4 = 4.0 * a.n;
   t->counters[0] += (double)d[2];
-  t->counters[1] += (double)d[0] * 8.0 * N4 * N4;  // M is streamed once per solve
+  t->counters[1] += (double)d[0] * precond_operator_bytes(a);  // the operator leaves HBM once per solve
   t->counters[2] += (double)(d[1] + d[0] + d[3]);
   t->counters[3] += (double)(d[1] + d[0] + d[3]) * spmm_bytes_of(t, a);
   return 0;
@@ -394,8 +393,7 @@ int enqueue_optimize_group(dpgo_team *t, int g) {
     launch_eval(c, sel, mn, B_X, B_EGRAD, B_GF, PART_A, eval_opts(t, 0, 0, 0));
     for (int k : mem) {
       Agent &a = *t->ag[k];
-      const double N4 = 4.0 * a.n;
-      if (p.rgd_use_preconditioner) { t->counters[0] += 1; t->counters[1] += 8.0 * N4 * N4; }
+      if (p.rgd_use_preconditioner) { t->counters[0] += 1; t->counters[1] += precond_operator_bytes(a); }
       t->counters[2] += 2; t->counters[3] += 2 * spmm_bytes_of(t, a);
       a.opt_pending_rgd = true;
     }
@@ -442,8 +440,7 @@ int enqueue_optimize_group(dpgo_team *t, int g) {
     a.opt.hessvec_count = hs.hv_count; a.opt.precond_count = hs.pc_count; a.opt.accepted = hs.accepted;
     a.opt_pending_rgd = false;
     if (hs.outer_count > 0) a.tcg_hint = std::max(2, std::min(8, (hs.tcg_total + hs.outer_count - 1) / hs.outer_count + 1));
-    const double N4 = 4.0 * a.n;
-    t->counters[0] += hs.pc_count; t->counters[1] += hs.pc_count * 8.0 * N4 * N4;
+    t->counters[0] += hs.pc_count; t->counters[1] += hs.pc_count * precond_operator_bytes(a);
     t->counters[2] += hs.hv_count + 1 + hs.outer_count;
     t->counters[3] += (hs.hv_count + 1 + hs.outer_count) * spmm_bytes_of(t, a);
   }

@@ -193,6 +193,7 @@ struct dpgo_team {
   int *h_bar_err = nullptr;
   int num_cus = 0;
   int dense_max_n = 0;  // largest agent with a dense inverse (sizes the LDS chunk of the preconditioner kernel)
+  std::vector<int> precond_of;  // [local agent] the form each agent runs (selects the preconditioner kernel's variant)
   int bake_sel = 1;  // DPGO_BAKE_SEL=0: the graphs of the pipelined iteration select their agent on the device only
   bool last_iteration_folded = false;  // ... and enqueue_team_iteration skipped k_nest_post / k_status / k_advance for it
   bool last_rtr_folded = false;  // the last enqueue_optimize ran the one-launch solve WITH the iteration's tail
@@ -204,6 +205,8 @@ struct dpgo_team {
     dpgo::LaunchCtx c{prm.r, stream, d_agents.p, d_team.p};
     c.nest_all = d_nest_all.p;
     c.dense_max_n = dense_max_n;
+    c.host_precond = precond_of.empty() ? nullptr : precond_of.data();
+    for (int k : precond_of) if (k == DPGO_PRECOND_TWO_LEVEL) c.any_two_level = true;
     return c;
   }
 };
@@ -214,6 +217,12 @@ namespace dpgo_host {
 bool tl_worthwhile(const TLPlan &pl);
 int tl_build(dpgo_team *t, const std::vector<Agent *> &agents);
 // workgroups of a preconditioner-type launch that leave partials in PART_B (device twin: precond_nblk)
+// bytes of the operator one preconditioner apply streams: the dense inverse, the two-level slabs, or the 4 x 4 blocks
+inline double precond_operator_bytes(const Agent &a) {
+  if (a.precond == DPGO_PRECOND_TWO_LEVEL) return a.tl_plan.bytes;
+  if (a.precond == DPGO_PRECOND_BLOCK_JACOBI) return 128.0 * a.n;
+  return 8.0 * 16.0 * (double)a.n * (double)a.n;
+}
 inline int precond_nblk(const Agent &a) { return a.precond == DPGO_PRECOND_TWO_LEVEL ? a.tl_plan.nwg : (4 * a.n + 7) / 8; }
 
 // ---- assembly.hip

@@ -12,6 +12,7 @@
 // coalesced access.
 #include "team_internal.h"
 #include "twolevel.h"
+#include "twolevel_dev.h"
 
 using namespace dpgo;
 
@@ -234,10 +235,14 @@ static TLHostLayout tl_layout(const TLPlan &pl) {
   return L;
 }
 
-// Does the two-level form pay for this agent?  (bytes one apply streams, against the dense inverse)
+// Does the two-level form pay for this agent?  Measured on MI355X (profiles/experiments/scale.py, sphere2500 split
+// 8 / 5 / 4 / 3 / 2 / 1 ways, us per apply, dense | two-level): 312 poses 8.1 | 12.0, 500: 10.1 | 15.8, 625: 16.5 | 24.1,
+// 833: 24.1 | 29.1, 1250: 41.9 | 47.8, 2500: 134 | 101.  The exchange between phase A and phase B (publish, counter,
+// re-read: ~8 us of dependent round trips across XCDs) costs more than streaming a dense inverse of up to ~200 MB, so
+// the automatic mode takes the two-level form only beyond that -- and wherever the dense inverse does not fit at all.
 bool tl_worthwhile(const TLPlan &pl) {
   const double dense = 8.0 * 16.0 * (double)pl.n * (double)pl.n;
-  return pl.n >= 64 && dense > 6.0e6 && pl.bytes < 0.5 * dense && !pl.sub.empty();
+  return dense > 256.0e6 && pl.bytes < 0.5 * dense && !pl.sub.empty();
 }
 
 // device memory the two-level form of an agent holds for good (slabs + tables), and its set-up scratch
@@ -276,8 +281,8 @@ int tl_build(dpgo_team *t, const std::vector<Agent *> &agents) {
       return DPGO_ERR;
     }
     if (!a.d_tl_flag.p) {
-      if (a.d_tl_flag.alloc(64)) { set_err("two-level preconditioner: device allocation failed"); return DPGO_ERR; }
-      HIPC(hipMemsetAsync(a.d_tl_flag.p, 0, sizeof(unsigned long long) * 64, s));
+      if (a.d_tl_flag.alloc(TL_FLAG_WORDS)) { set_err("two-level preconditioner: device allocation failed"); return DPGO_ERR; }
+      HIPC(hipMemsetAsync(a.d_tl_flag.p, 0, sizeof(unsigned long long) * TL_FLAG_WORDS, s));
     }
     TLSetupAgent &g = setup[k];
     g.rowptr = a.d_rowptr.p; g.col = a.d_col.p; g.qval = a.d_qval.p;

@@ -5,9 +5,10 @@ m,n=capi.read_g2o('data/sphere2500.g2o')
 T=capi.odometry_init(m,n); Y=capi.fixed_stiefel(5)
 print("| agents | poses/agent | M bytes | precond us/launch | GB/s | frac of 8 TB/s | eval us | eval GB/s |")
 print("|---|---|---|---|---|---|---|---|")
-for N in (8,5,4,2,1):
+MODE=int(os.environ.get('PRECOND_MODE','0'))
+for N in (8,5,4,3,2,1):
     mp=capi.partition(m,n,N) if N>1 else m
-    t=capi.Team.from_measurements(mp, capi.default_params(r=5,num_robots=N,method=1,acceleration=0,rgd_stepsize=0.1))
+    t=capi.Team.from_measurements(mp, capi.default_params(r=5,num_robots=N,method=1,acceleration=0,rgd_stepsize=0.1,precond_mode=MODE))
     t.set_initial(T,Y)
     a=0
     ms,b=t.time_kernel(a,0,reps=100)

@@ -9,6 +9,9 @@ prm = capi.default_params(r=5, num_robots=5, **bench.RGD)
 team = capi.Team.from_measurements(mp, prm, device=0)
 team.set_initial(T, Y)
 names = ["start", "prologue done", "vector staged", "M requested", "M consumed", "reduced", "sync", "end", "tangent+step", "qf", "V polar", "Y polar"]
+if team.agents[0].preconditioner() == capi.PRECOND_TWO_LEVEL:  # stamps of twolevel_dev.h
+    names[1:6] = ["pre rows done", "u published (producers)", "exchange passed", "u rows done", "reduced"]
+    print(team.agents[0].preconditioner_info())
 PART_E = 4 * 32768 * 8
 for rep in range(4):
     team.run(36)   # the last step kernel of the run belongs to agent (35 % 5) = 0

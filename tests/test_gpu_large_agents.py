@@ -1,6 +1,7 @@
-"""Large agents (round-1 verdict item 8): the size guard of the dense preconditioner, the automatic fall back to the
-declared block-Jacobi preconditioner (include/dpgo_hip.h DPGO_PRECOND_*; NOT the reference's preconditioner -- the
-oracle restates it as precond_mode 2 so that the fallback has a checker), and a 5750-pose agent on the dense path."""
+"""Large agents: the size guard of the dense preconditioner, the two-level form (csrc/twolevel.h: the same operator as
+the reference's sparse Cholesky solve) that the automatic mode gives an agent whose dense inverse would not fit -- or
+would stream more than 256 MB per apply --, the block-Jacobi preconditioner on request (NOT the reference's; the
+oracle restates it as precond_mode 2 so that it has a checker), and cubicle as ONE 5750-pose agent both ways."""
 import os
 
 import numpy as np
@@ -35,30 +36,38 @@ def test_block_jacobi_matches_the_oracles_block_jacobi(method, accel):
     th.close()
 
 
-def test_dense_preconditioner_size_guard_and_automatic_fallback():
-    """60 000 poses: the dense inverse would need 1.4 TB.  precond_mode = DENSE fails with a message that says so;
-    AUTO runs the agent with block-Jacobi, and its iterates follow the oracle's block-Jacobi run."""
+def test_dense_preconditioner_size_guard_and_the_exact_two_level_form_for_a_60000_pose_agent():
+    """60 000 poses: the dense inverse would need 1.4 TB.  precond_mode = DENSE fails with a message that says so; AUTO
+    runs the agent with the two-level form (4 GB) -- the reference's preconditioner, exactly: tCG and acceptance counts,
+    costs and iterates follow the oracle's sparse-Cholesky run."""
     m, n = synthetic_chain(60000)
     T = O.odometry_init(m, n)
     Y = O.fixed_stiefel(5)
     t = capi.Team.from_measurements(m.view(capi.MEAS_DTYPE), capi.default_params(r=5, num_robots=1, precond_mode=capi.PRECOND_DENSE))
     with pytest.raises(capi.DpgoError) as ei:
         t.set_initial(T, Y)
-    assert "dense preconditioner of 60000 poses needs" in str(ei.value) and "block-Jacobi" in str(ei.value)
+    assert "dense preconditioner of 60000 poses needs" in str(ei.value) and "two-level" in str(ei.value)
     t.close()
     kw = dict(r=5, num_robots=1, method=capi.METHOD_RTR, rtr_iterations=2, rtr_tcg_iterations=20, gradnorm_tol=1e-3)
     ph, po = params_pair(**kw)
-    po.precond_mode = 2
     th = capi.Team.from_measurements(m.view(capi.MEAS_DTYPE), ph)   # AUTO
     to = O.Team(m, n, po)
     th.set_initial(T, Y)
     to.set_initial(T, Y)
-    assert th.agents[0].preconditioner() == capi.PRECOND_BLOCK_JACOBI
+    ah, ao = th.agents[0], to.agents[0]
+    info = ah.preconditioner_info()
+    assert info["mode"] == capi.PRECOND_TWO_LEVEL and info["bytes_per_apply"] < 8e9
+    ah.build_problem(False)
+    ao.build_problem(False)
+    rng = np.random.default_rng(1)
+    X = random_point(rng, 5, n)
+    V = rng.standard_normal(X.size)
+    assert relerr(ah.precondition(X, V), ao.precondition(X, V)) < 1e-9
     f0 = to.cost()
     for k in range(2):
         th.run(1)
         to.iterate()
-        rh, ro = th.agents[0].opt_result(), to.agents[0].opt_result()
+        rh, ro = ah.opt_result(), ao.opt_result()
         assert rh.tcg_iters_total == ro.tcg_iters_total and rh.accepted == ro.accepted
         assert abs(th.cost() - to.cost()) <= 1e-9 * abs(to.cost())
     assert np.abs(th.global_X() - to.global_X()).max() < 1e-7 * max(1.0, np.abs(to.global_X()).max())
@@ -66,9 +75,32 @@ def test_dense_preconditioner_size_guard_and_automatic_fallback():
     th.close()
 
 
-def test_cubicle_single_agent_on_the_dense_path():
-    """cubicle.g2o as ONE agent: 5750 poses, a 23000 x 23000 inverse (4.2 GB, 12.7 GB while it is factored) -- the size
-    the verdict names; anisotropic information matrices; two RTR iterations vs the oracle's sparse Cholesky"""
+def test_block_jacobi_on_request_for_a_large_agent():
+    """precond_mode = 2 on a 20 000-pose chain: follows the oracle's block-Jacobi run"""
+    m, n = synthetic_chain(20000)
+    T = O.odometry_init(m, n)
+    Y = O.fixed_stiefel(5)
+    kw = dict(r=5, num_robots=1, method=capi.METHOD_RTR, rtr_iterations=2, rtr_tcg_iterations=20, gradnorm_tol=1e-3, precond_mode=2)
+    ph, po = params_pair(**kw)
+    th = capi.Team.from_measurements(m.view(capi.MEAS_DTYPE), ph)
+    to = O.Team(m, n, po)
+    th.set_initial(T, Y)
+    to.set_initial(T, Y)
+    assert th.agents[0].preconditioner() == capi.PRECOND_BLOCK_JACOBI
+    for k in range(2):
+        th.run(1)
+        to.iterate()
+        rh, ro = th.agents[0].opt_result(), to.agents[0].opt_result()
+        assert rh.tcg_iters_total == ro.tcg_iters_total and rh.accepted == ro.accepted
+        assert abs(th.cost() - to.cost()) <= 1e-9 * abs(to.cost())
+    assert np.abs(th.global_X() - to.global_X()).max() < 1e-7 * max(1.0, np.abs(to.global_X()).max())
+    th.close()
+
+
+@pytest.mark.parametrize("mode", [capi.PRECOND_AUTO, capi.PRECOND_DENSE])
+def test_cubicle_single_agent(mode):
+    """cubicle.g2o as ONE agent: 5750 poses; anisotropic information matrices; two RTR iterations vs the oracle's sparse
+    Cholesky.  AUTO: the two-level form (0.9 GB); DENSE: a 23000 x 23000 inverse (4.2 GB, 12.7 GB while it is factored)"""
     m, n = O.read_g2o(os.path.join(DATA, "cubicle.g2o"))
     T = O.chordal_init(m, n)
     Y = O.fixed_stiefel(5)
@@ -77,12 +109,13 @@ def test_cubicle_single_agent_on_the_dense_path():
     # then meet again: 1.4e-8 after the second; profiles/experiments/cubicle_dense.py)
     kw = dict(r=5, num_robots=1, method=capi.METHOD_RTR, rtr_iterations=2, rtr_tcg_iterations=8, gradnorm_tol=1e-3)
     ph, po = params_pair(**kw)
+    ph.precond_mode = mode
     th = capi.Team.from_measurements(m.view(capi.MEAS_DTYPE), ph)
     to = O.Team(m, n, po)
     th.set_initial(T, Y)
     to.set_initial(T, Y)
     ah, ao = th.agents[0], to.agents[0]
-    assert ah.preconditioner() == capi.PRECOND_DENSE and ah.n == 5750
+    assert ah.preconditioner() == (capi.PRECOND_DENSE if mode == capi.PRECOND_DENSE else capi.PRECOND_TWO_LEVEL) and ah.n == 5750
     ah.build_problem(False)
     ao.build_problem(False)
     rng = np.random.default_rng(0)

@@ -27,14 +27,26 @@ def test_two_level_apply_matches_sparse_cholesky(dataset, robots):
         assert relerr(zh, zo) < 1e-9, (dataset, ah.id, info, relerr(zh, zo))
 
 
-def test_automatic_mode_picks_two_level_for_sphere2500_agents_and_dense_for_small_ones():
+def test_automatic_mode_by_agent_size():
+    """the dense inverse where its stream is cheaper than the exchange inside a two-level apply (measured: up to ~1250
+    poses), the two-level form beyond"""
     th, _, _ = make_pair("sphere2500", 5)
+    assert all(a.preconditioner() == capi.PRECOND_DENSE for a in th.agents.values())
+    th.close()
+    th, _, _ = make_pair("sphere2500", 1)
+    info = th.agents[0].preconditioner_info()
+    assert info["mode"] == capi.PRECOND_TWO_LEVEL
+    assert info["bytes_per_apply"] < 0.25 * info["dense_bytes"] == 0.25 * 8e8
+    th.close()
+
+
+def test_two_level_bytes_on_the_bench_agents():
+    """sphere2500 / 5: 11 subdomains + 71 separator poses, 8.4 MB per apply against the dense inverse's 32 MB"""
+    th, _, _ = make_pair("sphere2500", 5, precond_mode=capi.PRECOND_TWO_LEVEL)
     for ah in th.agents.values():
         info = ah.preconditioner_info()
-        assert info["mode"] == capi.PRECOND_TWO_LEVEL
-        assert info["bytes_per_apply"] < 9e6 and info["dense_bytes"] == 32e6
-    th, _, _ = make_pair("smallGrid3D", 2)
-    assert all(a.preconditioner() == capi.PRECOND_DENSE for a in th.agents.values())
+        assert info["mode"] == capi.PRECOND_TWO_LEVEL and info["bytes_per_apply"] < 9e6 and info["dense_bytes"] == 32e6
+    th.close()
 
 
 @pytest.mark.parametrize("method", [O.METHOD_RGD, O.METHOD_RTR])
