@@ -15,6 +15,7 @@ import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -248,8 +249,35 @@ def agent_api_leg(capi, mp, n, T, Y):
         res[name] = {"ms_per_iterate_agent_api": (time.perf_counter() - a0) / iters * 1e3, "iterations": iters}
         for t_ in teams:
             t_.close()
-    res["note"] = "5 single-agent teams on one GPU, exchange through host buffers after every call (the ROS-topic path)"
+    res["note"] = ("5 single-agent teams on one GPU, exchange through host buffers after every call (the ROS-topic path); "
+                   "ms_per_iterate_agent_api: this loop driven from Python through ctypes; ms_per_iterate_cxx: the same loop "
+                   "compiled (tests/cpp/agent_api_bench.cpp), with the host time per iterate(false) / iterate(true) call and "
+                   "per report round trip")
+    # the same loop without an interpreter in it
+    try:
+        exe = build_agent_api_bench()
+        data = os.path.join(ROOT, "data", "sphere2500.g2o")
+        for name, cfg, iters in (("rgd_nesterov", RGD, 400), ("rtr_nesterov", RTR, 100)):
+            out = subprocess.check_output([exe, data, str(NA), str(cfg["method"]), str(cfg["acceleration"]), str(iters),
+                                           str(cfg.get("rgd_stepsize", 0.2)), str(cfg.get("restart_interval", 20)), str(cfg.get("gradnorm_tol", 0.5))],
+                                          text=True, timeout=300)
+            j = json.loads(out.strip().splitlines()[-1])
+            res[name]["ms_per_iterate_cxx"] = j["ms_per_iteration"]
+            res[name]["cxx_host_us"] = {k: j[k] for k in ("us_per_iterate_false", "us_per_iterate_true", "us_other_per_iteration", "us_report_wait")}
+    except Exception as e:  # (the figure is additional: a box without g++ still gets the ctypes one)
+        res["cxx_error"] = repr(e)
     return res
+
+
+def build_agent_api_bench():
+    """tests/cpp/agent_api_bench.cpp -> tests/cpp/agent_api_bench (links libdpgo_hip.so through the C-ABI)"""
+    src = os.path.join(ROOT, "tests", "cpp", "agent_api_bench.cpp")
+    exe = os.path.join(ROOT, "tests", "cpp", "agent_api_bench")
+    lib = os.path.join(ROOT, "dpgo_ros_amd")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(os.path.join(lib, "libdpgo_hip.so"))):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-pthread", "-I" + os.path.join(ROOT, "include"), src, "-o", exe,
+                               "-L" + lib, "-ldpgo_hip", "-Wl,-rpath," + lib])
+    return exe
 
 
 def add_outliers(mod, m, n, frac=0.1, seed=0):

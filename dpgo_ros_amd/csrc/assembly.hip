@@ -46,6 +46,9 @@ void rebuild_index(Agent &a) {
   a.np = np;
   a.np_has[0].assign(np.size(), 0);
   a.np_has[1].assign(np.size(), 0);
+  // poses staged for the old numbering of the slots would land in the wrong ones: they are dropped with it (their
+  // np_has flags are gone too, so the next iterate(true) waits for fresh ones)
+  for (int s = 0; s < 2; ++s) { a.stage_slots[s].clear(); a.stage_data[s].clear(); a.stage_pos[s].assign(np.size(), -1); }
   a.neighbors.clear();
   for (auto &p : np) if (a.neighbors.empty() || a.neighbors.back() != p.first) a.neighbors.push_back(p.first);
   a.n = n;
@@ -331,39 +334,42 @@ int finalize_agent(dpgo_team *t, Agent &a, double *scratch) {
   return 0;
 }
 
-// staged neighbour poses (dpgo_agent_update_neighbor_poses) -> device slabs: one index + payload upload and one scatter
-// kernel per agent and sequence, one synchronisation for the whole team
+// staged neighbour poses (dpgo_agent_update_neighbor_poses) -> device slabs: the indices and poses of both sequences go
+// into one pinned image that ONE kernel reads in place (no copy engine, no device-side staging buffer): the scatter
+// kernel launched by flush_stage, or -- where nothing in front of it needs the poses -- the report kernel that closes a
+// dpgo_agent_iterate (stage_to_pinned + launch_report)
+int stage_to_pinned(dpgo_team *t, Agent &a, int *n0_out, int *n1_out) {
+  const size_t B = (size_t)4 * t->prm.r;
+  const size_t n0 = a.stage_slots[0].size(), n1 = a.stage_slots[1].size();
+  *n0_out = (int)n0; *n1_out = (int)n1;
+  if (n0 + n1 == 0) return 0;
+  if (a.up_pending) {
+    // the pinned image may still be owed to an earlier kernel (nothing has proved since that the stream moved past it):
+    // wait before it is overwritten or re-allocated
+    HIPC(hipStreamSynchronize(t->stream));
+    for (auto &b : t->ag) b->up_pending = false;
+  }
+  if (a.h_up_idx.alloc(n0 + n1) || a.h_up.alloc((n0 + n1) * B)) { set_err("allocation failed"); return DPGO_ERR; }
+  size_t off = 0;
+  for (int aux = 0; aux < 2; ++aux) {
+    const size_t cnt = a.stage_slots[aux].size();
+    if (!cnt) continue;
+    std::memcpy(a.h_up_idx.p + off, a.stage_slots[aux].data(), sizeof(int) * cnt);
+    std::memcpy(a.h_up.p + off * B, a.stage_data[aux].data(), sizeof(double) * cnt * B);
+    off += cnt;
+    for (int q : a.stage_slots[aux]) a.stage_pos[aux][q] = -1;
+    a.stage_slots[aux].clear();
+    a.stage_data[aux].clear();
+  }
+  a.up_pending = true;
+  return 0;
+}
+
 int flush_stage(dpgo_team *t) {
   for (auto &a : t->ag) {
-    const size_t B = (size_t)4 * t->prm.r;
-    const size_t n0 = a->stage_slots[0].size(), n1 = a->stage_slots[1].size();
-    if (n0 + n1 == 0) continue;
-    if (a->d_idx.alloc(n0 + n1) || a->d_xfer.alloc((n0 + n1) * B) || a->h_up_idx.alloc(n0 + n1) || a->h_up.alloc((n0 + n1) * B)) {
-      set_err("allocation failed");
-      return DPGO_ERR;
-    }
-    if (!a->up_done) HIPC(hipEventCreateWithFlags(&a->up_done, hipEventDisableTiming));
-    else HIPC(hipEventSynchronize(a->up_done));  // the previous upload has read the pinned image (normally long ago)
-    size_t off = 0;
-    for (int aux = 0; aux < 2; ++aux) {
-      const size_t cnt = a->stage_slots[aux].size();
-      if (!cnt) continue;
-      std::memcpy(a->h_up_idx.p + off, a->stage_slots[aux].data(), sizeof(int) * cnt);
-      std::memcpy(a->h_up.p + off * B, a->stage_data[aux].data(), sizeof(double) * cnt * B);
-      off += cnt;
-    }
-    HIPC(hipMemcpyAsync(a->d_idx.p, a->h_up_idx.p, sizeof(int) * (n0 + n1), hipMemcpyHostToDevice, t->stream));
-    HIPC(hipMemcpyAsync(a->d_xfer.p, a->h_up.p, sizeof(double) * (n0 + n1) * B, hipMemcpyHostToDevice, t->stream));
-    off = 0;
-    for (int aux = 0; aux < 2; ++aux) {
-      const size_t cnt = a->stage_slots[aux].size();
-      if (!cnt) continue;
-      launch_unpack(t->ctx(), a->dev.nbr[aux], a->d_idx.p + off, (int)cnt, a->d_xfer.p + off * B);
-      off += cnt;
-      a->stage_slots[aux].clear();
-      a->stage_data[aux].clear();
-    }
-    HIPC(hipEventRecord(a->up_done, t->stream));
+    int n0 = 0, n1 = 0;
+    if (stage_to_pinned(t, *a, &n0, &n1)) return DPGO_ERR;
+    if (n0 + n1) launch_upload2(t->ctx(), a->dev.nbr[0], a->dev.nbr[1], a->h_up_idx.p, a->h_up.p, n0, n1);
   }
   return 0;
 }

@@ -1,4 +1,7 @@
 // capi.hip -- the extern "C" entry points of libdpgo_hip.so (contract: include/dpgo_hip.h).
+#include <atomic>
+#include <chrono>
+
 #include "team_internal.h"
 
 using namespace dpgo;
@@ -243,9 +246,15 @@ int dpgo_agent_update_neighbor_poses(dpgo_team_t *t, int id, int nbr, int aux, i
     const int q = find_np(*a, nbr, frames[k]);
     if (q < 0) continue;  // not an endpoint of any shared edge: dropped
     // a pose delivered twice before it is used keeps its latest value (one scatter target per slot)
-    size_t at = a->stage_slots[s].size();
-    for (size_t u = 0; u < a->stage_slots[s].size(); ++u) if (a->stage_slots[s][u] == q) { at = u; break; }
-    if (at == a->stage_slots[s].size()) { a->stage_slots[s].push_back(q); a->stage_data[s].resize((at + 1) * B); }
+    if (a->stage_pos[s].size() != a->np.size()) a->stage_pos[s].assign(a->np.size(), -1);
+    size_t at;
+    if (a->stage_pos[s][q] >= 0) at = (size_t)a->stage_pos[s][q];
+    else {
+      at = a->stage_slots[s].size();
+      a->stage_pos[s][q] = (int)at;
+      a->stage_slots[s].push_back(q);
+      a->stage_data[s].resize((at + 1) * B);
+    }
     std::copy(poses + k * B, poses + (k + 1) * B, a->stage_data[s].begin() + at * B);
     a->np_has[s][q] = 1;
   }
@@ -275,33 +284,48 @@ int dpgo_agent_unpack_neighbor_poses_device(dpgo_team_t *t, int id, int nbr, int
 }
 
 // Everything the wrapper asks for right after an iterate -- the public poses of all neighbours and both sequences
-// (:666-668), the status of the block update (:616) and the result of a local RGD solve (:169-172) -- fetched with ONE
-// batch of copies and ONE synchronisation at the end of dpgo_agent_iterate; the getters then answer from the host copies.
-static int report_after_iterate(dpgo_team_t *t, Agent *a, bool did_opt) {
+// (:666-668), the status of the block update (:616) and the result of a local RGD solve (:169-172) -- is written by ONE
+// kernel behind the iterate's launches straight into pinned host memory, followed by a sequence word; the host polls
+// that word (no copy engine, no stream-wide wait) and the getters then answer from the host copies.
+static int report_after_iterate(dpgo_team_t *t, Agent *a, bool did_opt, bool advance, bool upload) {
   const size_t B = (size_t)4 * t->prm.r;
   const size_t npub = 2 * (size_t)a->n_pub_all * B;
   const bool want_status = did_opt && !t->prm.status_every_iterate && (a->opt_rel_src == 1 || a->opt_rel_src == 5);
   const bool tiles = a->opt_rel_src == 5;
   const int scnt = want_status ? (tiles ? (a->n + 63) / 64 : precond_nblk(*a)) : 0;
-  const size_t nstat = want_status ? (size_t)(scnt - 1) * PART_STRIDE + 1 : 0;
   const int ppb = 64 / t->prm.r, nb = (a->n + ppb - 1) / ppb;
   const bool want_opt = did_opt && a->opt_pending_rgd;
-  const size_t nopt = want_opt ? (size_t)PART_STRIDE * nb : 0;
-  if (a->h_down.alloc(npub + nstat + 2 * nopt + 1)) { set_err("pinned allocation failed"); return DPGO_ERR; }
-  double *pub = a->h_down.p, *stat = pub + npub, *pc = stat + nstat, *pa = pc + nopt;
-  if (npub) {
-    if (a->d_xfer.alloc(npub)) { set_err("device allocation failed"); return DPGO_ERR; }
-    // (the staged upload also went through d_xfer, earlier on the same stream)
-    launch_pack2(t->ctx(), a->dev.buf[B_X], a->dev.buf[B_Y], a->d_pub_all.p, a->n_pub_all, a->d_xfer.p);
-    HIPC(hipMemcpyAsync(pub, a->d_xfer.p, sizeof(double) * npub, hipMemcpyDeviceToHost, t->stream));
+  if (a->h_down.alloc(8 + npub, true)) { set_err("pinned allocation failed"); return DPGO_ERR; }
+  if (!a->d_report_seq.p) {
+    if (a->d_report_seq.alloc(1)) { set_err("device allocation failed"); return DPGO_ERR; }
+    HIPC(hipMemsetAsync(a->d_report_seq.p, 0, sizeof(unsigned long long), t->stream));
+    a->report_seq = 0;
+    *reinterpret_cast<volatile unsigned long long *>(a->h_down.p) = 0ull;
   }
-  if (want_status)
-    HIPC(hipMemcpyAsync(stat, a->dev.part + (tiles ? PART_E : PART_B + 2), sizeof(double) * nstat, hipMemcpyDeviceToHost, t->stream));
-  if (want_opt) {
-    HIPC(hipMemcpyAsync(pc, a->dev.part + PART_C, sizeof(double) * nopt, hipMemcpyDeviceToHost, t->stream));
-    HIPC(hipMemcpyAsync(pa, a->dev.part + PART_A, sizeof(double) * nopt, hipMemcpyDeviceToHost, t->stream));
+  int up0 = 0, up1 = 0;
+  if (upload && stage_to_pinned(t, *a, &up0, &up1)) return DPGO_ERR;
+  const unsigned long long expect = ++a->report_seq;
+  const auto tq0 = std::chrono::steady_clock::now();
+  launch_report(t->ctx(), a->local, a->d_pub_all.p, a->n_pub_all, a->h_down.p, tiles ? PART_E : PART_B + 2, scnt, PART_STRIDE,
+                want_opt ? nb : 0, a->d_report_seq.p, advance ? 1 : 0, t->prm.acceleration, t->prm.num_robots,
+                t->prm.restart_interval, a->h_up_idx.p, a->h_up.p, up0, up1);
+  {
+    volatile unsigned long long *flag = reinterpret_cast<volatile unsigned long long *>(a->h_down.p);
+    unsigned long long spins = 0;
+    while (*flag != expect) {
+      __builtin_ia32_pause();
+      if (++spins > (1ull << 26)) {  // (seconds: something is wrong -- let the runtime say what)
+        HIPC(hipStreamSynchronize(t->stream));
+        if (*flag != expect) { set_err("report kernel did not deliver (sequence word not written)"); return DPGO_ERR; }
+      }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
   }
-  HIPC(hipStreamSynchronize(t->stream));
+  // diagnostics (dpgo_team_get_counters [5..6]): host time between the launch of a report and its arrival (us), reports
+  t->counters[5] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tq0).count();
+  t->counters[6] += 1;
+  for (auto &b : t->ag) b->up_pending = false;  // this team's stream has drained past every upload enqueued before
+  const double *out = a->h_down.p, *pub = out + 8;
   if (npub) {
     size_t off = 0;
     for (auto &kv : a->d_pubframes) {
@@ -315,16 +339,13 @@ static int report_after_iterate(dpgo_team_t *t, Agent *a, bool did_opt) {
     a->pub_epoch = t->epoch;
   }
   if (want_status) {
-    double sum = 0;
-    for (int k = 0; k < scnt; ++k) sum += stat[(size_t)k * PART_STRIDE];
-    a->opt_rel_change = std::sqrt(sum / a->n);
+    a->opt_rel_change = std::sqrt(out[1] / a->n);
     a->opt_cached = true;
   }
   if (want_opt) {
-    auto sum = [&](const double *p, int o) { double s = 0; for (int i = 0; i < nb; ++i) s += p[(size_t)i * PART_STRIDE + o]; return s; };
     a->opt.success = 1;
-    a->opt.f_init = sum(pc, 0); a->opt.gradnorm_init = std::sqrt(sum(pc, 1));
-    a->opt.f_opt = sum(pa, 0); a->opt.gradnorm_opt = std::sqrt(sum(pa, 1));
+    a->opt.f_init = out[2]; a->opt.gradnorm_init = std::sqrt(out[3]);
+    a->opt.f_opt = out[4]; a->opt.gradnorm_opt = std::sqrt(out[5]);
     a->opt.rtr_outer_iters = 0; a->opt.tcg_iters_total = 0; a->opt.hessvec_count = 0;
     a->opt.precond_count = t->prm.rgd_use_preconditioner ? 1 : 0; a->opt.accepted = 1;
     a->opt_pending_rgd = false;
@@ -336,18 +357,24 @@ int dpgo_agent_iterate(dpgo_team_t *t, int id, int do_optimization) {
   Agent *a = find_agent(t, id);
   if (!a) return DPGO_ERR;
   if (a->state != DPGO_INITIALIZED || !a->has_X) { a->iter++; return DPGO_NOT_READY; }
-  if (sync_descs(t)) return DPGO_ERR;
+  // iterate(false) reads no neighbour pose: what is staged on the host travels with the report kernel that closes the
+  // call instead of a scatter launch in front of it
+  const bool defer_upload = !do_optimization && t->prm.acceleration && t->peers.empty();
+  if (defer_upload ? sync_descs_noflush(t) : sync_descs(t)) return DPGO_ERR;
   if (t->prm.robust_cost_type != DPGO_COST_L2) a->robust_inner_iter++;
   bool opt = do_optimization != 0;
   a->last_success = true;
   if (opt && !neighbor_poses_ready(*a, t->prm.acceleration ? 1 : 0)) { opt = false; a->last_success = false; }
-  const int rc = enqueue_iterate(t, a->local, opt ? 1 : (do_optimization ? 2 : 0));
+  // a report closes this call whenever there is something to publish or a result to read: its kernel then also takes
+  // the end-of-iterate bookkeeping (one launch less)
+  const bool will_report = t->prm.acceleration || opt || a->publish_requested;
+  const int rc = enqueue_iterate(t, a->local, opt ? 1 : (do_optimization ? 2 : 0), will_report);
   if (rc) return rc;
   if (do_optimization) mark_optimized(t, *a, opt ? (a->rel_src == 1 ? 1 : 5) : 2, opt);
   a->iter++;
   if (t->prm.acceleration || opt) a->publish_requested = true;
-  if (a->publish_requested || opt) {
-    const int rr = report_after_iterate(t, a, opt);
+  if (will_report) {
+    const int rr = report_after_iterate(t, a, opt, true, defer_upload);
     if (rr) return rr;
   }
   return a->last_success ? DPGO_OK : DPGO_NOT_READY;

@@ -60,6 +60,13 @@ void launch_rtr_accept(const LaunchCtx &c, int sel, int max_n, int sp, double to
 void launch_pack(const LaunchCtx &c, const double *X, const int *frames, int count, double *out);
 void launch_pack2(const LaunchCtx &c, const double *X, const double *Y, const int *frames, int count, double *out);
 void launch_unpack(const LaunchCtx &c, double *slab, const int *slots, int count, const double *in);
+// the host boundary of the per-agent API: staged neighbour poses read straight from pinned host memory; public poses,
+// status / result sums and a sequence word written straight into it (see pose_ops.hip)
+void launch_upload2(const LaunchCtx &c, double *slab0, double *slab1, const int *host_slots, const double *host_in, int n0, int n1);
+void launch_report(const LaunchCtx &c, int ai, const int *frames, int count, double *host_out, int stat_off, int stat_cnt,
+                   int stat_stride, int opt_nb, unsigned long long *seq, int advance, int accel, int num_robots,
+                   int restart_interval, const int *up_slots = nullptr, const double *up_in = nullptr, int up_n0 = 0,
+                   int up_n1 = 0);
 void launch_residuals(const LaunchCtx &c, int ai, int nedges);
 void launch_cost(const LaunchCtx &c, int ai);
 void launch_noop(const LaunchCtx &c, int grid, int block);

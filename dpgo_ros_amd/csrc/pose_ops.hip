@@ -253,6 +253,63 @@ __global__ void k_unpack(double *slab, const int *slots, int count, const double
   slab[(size_t)slots[q] * 4 * R + k] = in[t];
 }
 
+// ---- the host boundary of the per-agent API (the path a ROS wrapper drives), without copy engines or stream-wide waits:
+// neighbour poses staged by updateNeighborPoses are scattered into the slabs straight FROM pinned host memory
+// (slots / in: host pointers; counts[2]: poses of the main / auxiliary sequence, in that order)
+template <int R>
+__global__ void k_upload2(double *slab0, double *slab1, const int *slots, const double *in, int n0, int n1) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (n0 + n1) * 4 * R) return;
+  const int q = t / (4 * R), k = t - q * 4 * R;
+  double *slab = q < n0 ? slab0 : slab1;
+  slab[(size_t)slots[q] * 4 * R + k] = in[t];
+}
+
+// ... and everything the wrapper asks for right after an iterate goes straight INTO pinned host memory, followed by a
+// sequence word the host polls (one workgroup: its own stores are ordered by one system-scope fence):
+//   out[0]            sequence number (written last)
+//   out[1]            sum of the `stat_cnt` status partials part[stat_off + k * stat_stride]   (|X - XPrev|^2)
+//   out[2 .. 5]       f_init, |grad|^2_init (PART_C), f_opt, |grad|^2_opt (PART_A) over `opt_nb` blocks
+//   out[8 ..]         [X of the public frames | Y of the same frames], the layout of k_pack2
+template <int R>
+__global__ __launch_bounds__(512) void k_report(const AgentDev *__restrict__ agents, int ai, const int *frames, int count,
+                                                  double *out, int stat_off, int stat_cnt, int stat_stride, int opt_nb,
+                                                  unsigned long long *seq, int advance, int accel, int num_robots,
+                                                  int restart_interval, const int *up_slots, const double *up_in, int up_n0,
+                                                  int up_n1) {
+  const AgentDev &ag = agents[ai];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // neighbour poses staged on the host that no launch of this iterate needed (iterate(false)): scattered here, one
+  // launch less (what k_upload2 does)
+  for (int t = tid; t < (up_n0 + up_n1) * 4 * R; t += 512) {
+    const int q = t / (4 * R), k = t - q * 4 * R;
+    ag.nbr[q < up_n0 ? 0 : 1][(size_t)up_slots[q] * 4 * R + k] = up_in[t];
+  }
+  // end of the iterate for this agent (what k_advance does in a launch of its own): nothing below reads the NestState
+  if (advance && tid == 511) advance_agent(ag, accel, num_robots, restart_interval);
+  const int len = count * 4 * R;
+  for (int t = tid; t < 2 * len; t += 512) {
+    const int sq = t >= len, u = t - sq * len, q = u / (4 * R), k = u - q * 4 * R;
+    out[8 + t] = ag.buf[sq ? B_Y : B_X][(size_t)frames[q] * 4 * R + k];
+  }
+  if (wave == 0 && stat_cnt > 0) {
+    const double s = sum_partials(ag.part + stat_off, stat_cnt, stat_stride, lane);
+    if (lane == 0) out[1] = s;
+  }
+  if (wave >= 1 && wave <= 4 && opt_nb > 0) {
+    const int w = wave - 1;  // 0 f_init, 1 g2_init, 2 f_opt, 3 g2_opt
+    const double s = sum_partials(ag.part + ((w < 2) ? PART_C : PART_A) + (w & 1), opt_nb, PART_STRIDE, lane);
+    if (lane == 0) out[2 + w] = s;
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned long long v = *seq + 1ull;
+    *seq = v;
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(out), v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 // per-edge residual sqrt(kappa |Y_j - Y_i R|^2 + tau |p_j - p_i - Y_i t|^2) (a8) and cost partials
 template <int R>
 __global__ void k_residuals(const AgentDev *__restrict__ agents, int ai) {
@@ -388,6 +445,21 @@ void launch_unpack(const LaunchCtx &c, double *slab, const int *slots, int count
   const int len = count * 4 * c.r;
   DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_unpack<R>, dim3((len + 255) / 256), dim3(256), 0, c.stream, slab, slots,
                                           count, in));
+}
+
+void launch_upload2(const LaunchCtx &c, double *slab0, double *slab1, const int *host_slots, const double *host_in, int n0, int n1) {
+  if (n0 + n1 <= 0) return;
+  const int len = (n0 + n1) * 4 * c.r;
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_upload2<R>, dim3((len + 255) / 256), dim3(256), 0, c.stream, slab0, slab1, host_slots,
+                                          host_in, n0, n1));
+}
+
+void launch_report(const LaunchCtx &c, int ai, const int *frames, int count, double *host_out, int stat_off, int stat_cnt,
+                   int stat_stride, int opt_nb, unsigned long long *seq, int advance, int accel, int num_robots,
+                   int restart_interval, const int *up_slots, const double *up_in, int up_n0, int up_n1) {
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_report<R>, dim3(1), dim3(512), 0, c.stream, c.agents, ai, frames, count, host_out,
+                                          stat_off, stat_cnt, stat_stride, opt_nb, seq, advance, accel, num_robots,
+                                          restart_interval, up_slots, up_in, up_n0, up_n1));
 }
 
 void launch_residuals(const LaunchCtx &c, int ai, int nedges) {

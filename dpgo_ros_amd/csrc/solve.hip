@@ -185,7 +185,9 @@ int enqueue_optimize(dpgo_team *t, int sel, const OptFlags &fl) {
 }
 
 // one PGOAgent::iterate for local agent `li` (host-driven variant used by the per-agent API)
-int enqueue_iterate(dpgo_team *t, int li, int do_opt) {
+// defer_advance: the caller's report kernel (capi.hip) advances the agent's Nesterov scalars / iteration counter, one
+// launch less
+int enqueue_iterate(dpgo_team *t, int li, int do_opt, bool defer_advance) {
   Agent &a = *t->ag[li];
   LaunchCtx c = t->ctx();
   const dpgo_params_t &p = t->prm;
@@ -209,7 +211,7 @@ int enqueue_iterate(dpgo_team *t, int li, int do_opt) {
       launch_copy(c, li, li, 1, a.n, B_X, B_XPREV, 0);
     }
     a.rel_src = 2;
-    launch_advance(c, li, 1, p.acceleration, p.num_robots, p.restart_interval, 0);
+    if (!defer_advance) launch_advance(c, li, 1, p.acceleration, p.num_robots, p.restart_interval, 0);
     return 0;
   }
   if (p.acceleration) {
@@ -235,7 +237,7 @@ int enqueue_iterate(dpgo_team *t, int li, int do_opt) {
     }
     if (fused) a.rel_src = 1; else launch_status(c, li, li, 1, a.n, do_opt ? 1 : 0);
   }
-  launch_advance(c, li, 1, p.acceleration, p.num_robots, p.restart_interval, 0);
+  if (!defer_advance) launch_advance(c, li, 1, p.acceleration, p.num_robots, p.restart_interval, 0);
   return 0;
 }
 

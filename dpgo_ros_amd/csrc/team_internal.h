@@ -64,12 +64,15 @@ struct PinnedBuf {
   T *p = nullptr;
   size_t n = 0;
   ~PinnedBuf() { if (p) (void)hipHostFree(p); }
-  int alloc(size_t count) {
+  // coherent: fine-grained memory -- what a kernel stores there (behind a system-scope fence) becomes visible to a host
+  // that polls it while the kernel's stream is still busy
+  int alloc(size_t count, bool coherent = false) {
     if (count <= n && p) return 0;
     if (p) (void)hipHostFree(p);
     p = nullptr; n = 0;
     const size_t want = std::max<size_t>(count + count / 2, 64);
-    if (hipHostMalloc((void **)&p, sizeof(T) * want) != hipSuccess) return -1;
+    if (hipHostMalloc((void **)&p, sizeof(T) * want, coherent ? hipHostMallocCoherent : hipHostMallocDefault) != hipSuccess) return -1;
+    std::memset(p, 0, sizeof(T) * want);
     n = want;
     return 0;
   }
@@ -137,11 +140,14 @@ struct Agent {
   unsigned long long pub_epoch = 0;
   std::map<int, std::vector<double>> pub_cache[2];
   std::vector<int> stage_slots[2];
+  std::vector<int> stage_pos[2];  // [slot] position of a staged pose in stage_slots / stage_data, -1: not staged
   std::vector<double> stage_data[2];
   PinnedBuf<int> h_up_idx;       // pinned images of the staged upload and of the report that closes an iterate
   PinnedBuf<double> h_up, h_down;
-  hipEvent_t up_done = nullptr;  // recorded behind the last upload: the pinned image is reused only after it
-  ~Agent() { if (up_done) (void)hipEventDestroy(up_done); }
+  bool up_pending = false;       // an upload kernel that reads the pinned image may still be queued (cleared by the next
+                                 // report the host has seen: the report kernel runs behind it on the same stream)
+  DevBuf<unsigned long long> d_report_seq;  // sequence number of the agent's reports (device side)
+  unsigned long long report_seq = 0;        // ... and what the host expects next
   int opt_rel_src = -1;
   bool opt_success = false, opt_cached = false;
   double opt_ratio = 1.0, opt_rel_change = 0.0;
@@ -235,6 +241,7 @@ int finalize_agent(dpgo_team *t, Agent &a, double *scratch);
 int sync_descs(dpgo_team *t);          // structure / data matrices / descriptors up to date, staged neighbour poses uploaded
 int sync_descs_noflush(dpgo_team *t);  // the same without the upload (used while poses are being staged)
 int flush_stage(dpgo_team *t);
+int stage_to_pinned(dpgo_team *t, Agent &a, int *n0, int *n1);
 
 // ---- solve.hip
 double converged_ratio(const Agent &a);
@@ -248,7 +255,7 @@ bool neighbor_poses_ready(const Agent &a, int aux);
 EvalOpts eval_opts(const dpgo_team *t, int gmode, int aux, int advance);
 double spmm_bytes_of(const dpgo_team *t, const Agent &a);
 int enqueue_optimize(dpgo_team *t, int sel, const OptFlags &fl);
-int enqueue_iterate(dpgo_team *t, int li, int do_opt);
+int enqueue_iterate(dpgo_team *t, int li, int do_opt, bool defer_advance = false);
 int enqueue_team_iteration(dpgo_team *t, bool capture, bool restart, int sel, int phase);
 void account_iteration(dpgo_team *t, int sel, bool fused);
 int enqueue_optimize_group(dpgo_team *t, int g);

@@ -267,7 +267,9 @@ int dpgo_team_import_peer(dpgo_team_t *t, int robot_id, const unsigned char *han
 int dpgo_agent_read_rtr_handoff(dpgo_team_t *t, int id, unsigned long long *out, int n);
 /* diagnostic: `n` doubles of an agent's device-side partial-sum scratch (csrc/dpgo_dev.h PART_*) from `offset` */
 int dpgo_agent_read_partials(dpgo_team_t *t, int id, int offset, double *out, int n);
-/* counters for the roofline report: launches and algorithmic bytes of the dominant kernels */
+/* counters for the roofline report: launches and algorithmic bytes of the dominant kernels ([0] preconditioner applies,
+ * [1] their bytes, [2] sparse evaluations, [3] their bytes, [4] iterations); diagnostics of the per-agent API: [5] host
+ * microseconds between the launch of a report kernel and the arrival of its sequence word, [6] reports */
 int dpgo_team_get_counters(dpgo_team_t *t, double *out, int n);
 
 #ifdef __cplusplus

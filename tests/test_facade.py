@@ -199,3 +199,18 @@ def test_mock_wrapper_asynchronous_mode():
     assert its[-1] > 20 and its == sorted(its)
     final = float(re.search(r"final cost (\S+)", out).group(1))
     assert final < 0.5 * init, (init, final, costs[::10])
+
+
+@pytest.mark.gpu
+def test_agent_api_bench_harness_runs_and_repeats_bitwise():
+    """tests/cpp/agent_api_bench.cpp (the drop-in path timed from C++, bench.py convergence.agent_api.*.ms_per_iterate_cxx):
+    builds against the C-ABI, runs the wrapper's call sequence on 2 robots, and two runs leave the same iterate bit for bit
+    (the boundary kernels -- staged poses read from pinned host memory, reports written into it -- carry no race)"""
+    import json
+    import bench
+    exe = bench.build_agent_api_bench()
+    outs = [json.loads(subprocess.check_output([exe, os.path.join(DATA, "smallGrid3D.g2o"), "2", m, a, "40", "0.1", "7", "0.01"],
+                                               text=True).strip().splitlines()[-1])
+            for m, a in (("1", "1"), ("1", "1"), ("0", "1"), ("0", "1"), ("1", "0"))]
+    assert outs[0]["checksum"] == outs[1]["checksum"] and outs[2]["checksum"] == outs[3]["checksum"]
+    assert all(o["ms_per_iteration"] > 0 and np.isfinite(o["checksum"]) for o in outs)
