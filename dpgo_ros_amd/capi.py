@@ -81,7 +81,7 @@ dpgo_error_threshold_at_quantile dpgo_team_set_schedule dpgo_team_set_initial dp
 dpgo_agent_pull_local dpgo_team_time_kernel dpgo_team_run dpgo_team_get_coloring dpgo_team_run_colored dpgo_team_set_groups dpgo_team_run_group dpgo_team_step_begin dpgo_team_step_end dpgo_team_iteration dpgo_team_cost dpgo_team_update_weights dpgo_team_get_counters
 dpgo_write_measurements_csv dpgo_write_g2o dpgo_write_trajectory_csv dpgo_robust_frame_alignment dpgo_robust_local_init dpgo_team_run_simultaneous
 dpgo_team_should_terminate dpgo_team_run_schedule dpgo_agent_compute_residuals dpgo_agent_set_measurement_weights
-dpgo_agent_reset_acceleration dpgo_team_prepare dpgo_agent_read_partials dpgo_agent_preconditioner dpgo_agent_preconditioner_info dpgo_two_level_plan dpgo_agent_export_state dpgo_team_import_peer dpgo_agent_read_rtr_handoff""".split()
+dpgo_agent_reset_acceleration dpgo_team_prepare dpgo_agent_read_partials dpgo_agent_preconditioner dpgo_agent_preconditioner_info dpgo_agent_preconditioner_residual dpgo_two_level_plan dpgo_agent_export_state dpgo_team_import_peer dpgo_agent_read_rtr_handoff""".split()
 
 
 class DpgoError(RuntimeError):
@@ -339,6 +339,12 @@ class Agent:
     def preconditioner(self):
         """1 dense inverse, 3 two-level (both exact), 2 block-Jacobi (on request, or where neither exact form fits)"""
         return _chk(lib().dpgo_agent_preconditioner(self.t, self.id), "preconditioner")
+
+    def preconditioner_residual(self):
+        """|z (Q + shift I) - v| / |v| for the operator the kernels apply (fixed pseudo-random v)"""
+        rel = C.c_double()
+        _chk(lib().dpgo_agent_preconditioner_residual(self.t, self.id, C.byref(rel)), "preconditioner_residual")
+        return rel.value
 
     def preconditioner_info(self):
         out = np.zeros(8)

@@ -52,6 +52,8 @@ dpgo_team_t *dpgo_team_create(int device, const dpgo_params_t *p, int num_local,
   {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess) t->num_cus = cus;
+    int lds = 0;
+    if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && lds > 0) t->max_lds = lds;
     const char *e3 = std::getenv("DPGO_BAKE_SEL");
     if (e3) t->bake_sel = (e3[0] == '0') ? 0 : 1;
     const char *e2 = std::getenv("DPGO_FUSED_RTR");
@@ -76,6 +78,7 @@ void dpgo_team_destroy(dpgo_team_t *t) {
   if (!t) return;
   (void)hipSetDevice(t->device);
   (void)hipStreamSynchronize(t->stream);
+  release_fused_rtr_lock(t);
   for (auto &kv : t->graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);
   for (auto &kv : t->peers) if (kv.second.base) (void)hipIpcCloseMemHandle(kv.second.base);
   t->ag.clear();
@@ -553,6 +556,45 @@ int dpgo_agent_precondition(dpgo_team_t *t, int id, const double *X, const doubl
   HIPC(hipMemcpyAsync(out, a->dev.buf[B_T2], bytes, hipMemcpyDeviceToHost, t->stream));
   HIPC(hipStreamSynchronize(t->stream));
   return 0;
+}
+
+// how well the operator the kernels apply inverts Q + shift I:  |z (Q + shift I) - v| / |v|  for a fixed pseudo-random v,
+// z from the device (the plain apply at X = 0, where the tangent projection is the identity), the product with the sparse
+// matrix on the host.  What the reference's backward-stable Cholesky solve would leave is ~1e-16 x cond.
+int dpgo_agent_preconditioner_residual(dpgo_team_t *t, int id, double *rel) {
+  Agent *a = find_agent(t, id);
+  if (!a) return DPGO_ERR;
+  if (sync_descs(t)) return DPGO_ERR;
+  const int r = t->prm.r, n = a->n;
+  const size_t len = (size_t)r * 4 * n;
+  std::vector<double> v(len), z(len), zero(len, 0.0);
+  unsigned long long s = 0x9E3779B97F4A7C15ull;
+  for (size_t i = 0; i < len; ++i) {
+    s = s * 6364136223846793005ull + 1442695040888963407ull;
+    v[i] = (double)(s >> 11) / 9007199254740992.0 - 0.5;
+  }
+  if (dpgo_agent_precondition(t, id, zero.data(), v.data(), z.data())) return DPGO_ERR;
+  double num = 0, den = 0;
+  std::vector<double> w(4 * (size_t)r);
+  for (int j = 0; j < n; ++j) {
+    std::fill(w.begin(), w.end(), 0.0);
+    for (int p = a->rowptr[j]; p < a->rowptr[j + 1]; ++p) {
+      const int i = a->col[p];
+      const double *val = a->qval.data() + (size_t)16 * p;
+      for (int c = 0; c < 4; ++c)
+        for (int cp = 0; cp < 4; ++cp) {
+          const double q = val[cp + 4 * c] + ((i == j && cp == c) ? t->prm.precond_shift : 0.0);
+          for (int b = 0; b < r; ++b) w[(size_t)c * r + b] += z[((size_t)4 * i + cp) * r + b] * q;
+        }
+    }
+    for (int e = 0; e < 4 * r; ++e) {
+      const double d = w[e] - v[(size_t)j * 4 * r + e];
+      num += d * d;
+      den += v[(size_t)j * 4 * r + e] * v[(size_t)j * 4 * r + e];
+    }
+  }
+  *rel = std::sqrt(num / den);
+  return DPGO_OK;
 }
 
 int dpgo_agent_get_Q(dpgo_team_t *t, int id, int *rowptr, int *col, double *val) {

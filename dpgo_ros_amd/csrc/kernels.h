@@ -80,6 +80,7 @@ void launch_bsr_to_dense(hipStream_t s, const int *rowptr, const int *col, const
 constexpr int RTR_BAR_WORDS = 18 * 16 + 160;
 constexpr int RTR_WS_DOUBLES = 7 * 256;
 bool rtr_fused_eligible(int r, int n, int num_cus);
+size_t rtr_fused_lds_bytes(int r, int n);  // LDS the solve of an n-pose agent needs (checked against the device's limit)
 // cum: 4 zero-initialised 64-bit words per agent: running totals {solves, Hessian-vector products, preconditioner
 // applies, outer iterations} the kernel adds to; host_rec / host_cum: pinned host copies of the solve's record and of
 // the totals, written by the kernel itself

@@ -25,7 +25,7 @@ constexpr int RB_TOP = 8 * RB_LINE;     // shard counters at g * RB_LINE
 constexpr int RB_GEN = 9 * RB_LINE;     // generation words at RB_GEN + g * RB_LINE
 constexpr int RB_EPOCH = 17 * RB_LINE;  // epoch of the last completed hand-off (carried across launches)
 constexpr int RB_ABORT = 17 * RB_LINE + 1;  // raised by a workgroup whose hand-off timed out: everybody leaves
-constexpr int RB_SPIN_LIMIT = 1 << 18;      // ~0.5 s of polling
+constexpr long long RB_TIMEOUT_TICKS = 50000000;  // 0.5 s of the 100 MHz wall clock (a time, not a count of polls)
 // End of the iteration for the agent that just solved, folded into the solve's launch (tail != 0; the team schedule's
 // non-restart iterations): what k_nest_post, k_status and k_advance do in launches of their own --
 //   bit 0: V <- proj(V + gamma (X - Y)) on the own poses (gamma as k_nest_pre published it in scal[6]);
@@ -115,10 +115,10 @@ __device__ __forceinline__ bool grid_sync(GridBar &gb, unsigned long long *tr = 
       }
     }
     if (tr) tr[2] = wall_clock64();
-    int spins = 0;
+    const long long t_start = (long long)wall_clock64();
     while (__hip_atomic_load(&gb.bar[RB_GEN + gb.g * RB_LINE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gb.epoch) {
       __builtin_amdgcn_s_sleep(1);
-      if (++spins > RB_SPIN_LIMIT) {
+      if ((long long)wall_clock64() - t_start > RB_TIMEOUT_TICKS) {
         *gb.err = 2;
         *gb.ok = 0;
         __hip_atomic_store(&gb.bar[RB_ABORT], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -804,6 +804,8 @@ __global__ __launch_bounds__(256) void k_rtr_solve(const AgentDev *__restrict__ 
 static size_t rtr_static_lds(int r) {
   return sizeof(double) * ((size_t)64 * (8 * r + 1) + 12 * 8 * r + 2 * RTR_SLOTS * 16) + sizeof(int) * 2 * RTR_SLOTS + 256;
 }
+
+size_t rtr_fused_lds_bytes(int r, int n) { return (size_t)64 * 4 * n + rtr_static_lds(r); }
 
 bool rtr_fused_eligible(int r, int n, int num_cus) {
   if (n < 1 || (n + 1) / 2 > num_cus || (n + 1) / 2 > RTR_WS_PITCH || 4 * n > 2048) return false;

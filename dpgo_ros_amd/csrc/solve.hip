@@ -1,11 +1,49 @@
 // solve.hip -- launch sequencing: one agent's local solve (RTR with tCG / fused RGD), PGOAgent::iterate,
 // the synchronous team iteration and the colour-parallel group update.  The host enqueues blind launch
 // patterns; every decision (accept/reject, tCG termination, schedule) is taken on the device.
+#include <fcntl.h>
+#include <sys/file.h>
+#include <unistd.h>
+
+#include <mutex>
+
 #include "team_internal.h"
 
 using namespace dpgo;
 
 namespace dpgo_host {
+
+// ---- who may launch the persistent RTR solve on a device (see dpgo_team::rtr_lock_state)
+static std::mutex g_rtr_mu;
+static std::map<int, dpgo_team *> g_rtr_owner;  // device -> the team of THIS process that holds the lock
+
+bool acquire_fused_rtr_lock(dpgo_team *t) {
+  if (t->rtr_lock_state >= 0) return t->rtr_lock_state == 1;
+  std::lock_guard<std::mutex> g(g_rtr_mu);
+  t->rtr_lock_state = 0;
+  if (g_rtr_owner.count(t->device)) return false;  // another team of this process
+  // across processes: an advisory lock keyed by the device's PCI bus id (the same GPU whatever the visible-device order)
+  char bus[64] = "unknown";
+  (void)hipDeviceGetPCIBusId(bus, sizeof bus, t->device);
+  for (char *c = bus; *c; ++c) if (*c == ':' || *c == '.' || *c == '/') *c = '_';
+  const std::string path = std::string("/dev/shm/dpgo_hip_rtr_") + bus + ".lock";
+  const int fd = ::open(path.c_str(), O_CREAT | O_RDWR, 0666);
+  if (fd >= 0) {
+    if (::flock(fd, LOCK_EX | LOCK_NB) != 0) { ::close(fd); return false; }  // another process runs it on this GPU
+    t->rtr_lock_fd = fd;
+  }  // (no /dev/shm: the in-process rule alone)
+  g_rtr_owner[t->device] = t;
+  t->rtr_lock_state = 1;
+  return true;
+}
+
+void release_fused_rtr_lock(dpgo_team *t) {
+  std::lock_guard<std::mutex> g(g_rtr_mu);
+  auto it = g_rtr_owner.find(t->device);
+  if (it != g_rtr_owner.end() && it->second == t) g_rtr_owner.erase(it);
+  if (t->rtr_lock_fd >= 0) { (void)::flock(t->rtr_lock_fd, LOCK_UN); ::close(t->rtr_lock_fd); t->rtr_lock_fd = -1; }
+  t->rtr_lock_state = -1;
+}
 
 // share of loop closures whose GNC weight has converged to 0 or 1 (robustOptMinConvergenceRatio,
 // src/PGOAgentROSNode.cpp:214) [UPSTREAM-RECALL]
@@ -100,7 +138,8 @@ int enqueue_optimize(dpgo_team *t, int sel, const OptFlags &fl) {
     t->counters[2] += hs->hv_count + 1 + hs->outer_count;
     t->counters[3] += (hs->hv_count + 1 + hs->outer_count) * spmm_bytes_of(t, a);
   };
-  if (t->use_fused_rtr && a.dev.M && rtr_fused_eligible(p.r, a.n, t->num_cus)) {
+  if (t->use_fused_rtr && a.dev.M && rtr_fused_eligible(p.r, a.n, t->num_cus) && acquire_fused_rtr_lock(t) &&
+      rtr_fused_lds_bytes(p.r, a.n) <= (size_t)t->max_lds) {
     // one launch for the whole solve, the preconditioner resident in LDS (rtr_fused.hip): M leaves HBM once per solve.
     // The host does not wait for it: the kernel leaves the solve's record and the agent's running totals in pinned
     // host memory, read by refresh_rtr_result() whenever somebody asks (opt result, counters) -- except for the very first
@@ -120,7 +159,9 @@ int enqueue_optimize(dpgo_team *t, int sel, const OptFlags &fl) {
     if (launch_rtr_solve(c, sel, a.n, a.d_rtr_bar.p, a.d_rtr_ws.p, a.d_rtr_cum.p, a.h_rtr.p, a.h_rtr_cum.p, t->h_bar_err, p.rtr_initial_radius,
                          p.gradnorm_tol, p.rtr_iterations, p.rtr_tcg_iterations, p.rtr_max_radius, fl.rtr_tail, p.num_robots,
                          p.restart_interval)) {
-      set_err("RTR solve launch failed"); return DPGO_ERR;
+      // (LDS attribute or launch refused on this device / partition mode: the launch-per-step sequence below serves)
+      t->use_fused_rtr = 0;
+      goto per_step;
     }
     t->last_rtr_folded = fl.rtr_tail != 0;
     a.opt_pending_rtr = true;
@@ -138,6 +179,7 @@ int enqueue_optimize(dpgo_team *t, int sel, const OptFlags &fl) {
     a.rtr_bar_n = -1;
     a.opt_pending_rtr = false;
   }
+per_step:
   if (refresh_rtr_result(t, a)) return DPGO_ERR;  // (totals of earlier one-launch solves, before a.opt is overwritten)
   launch_rtr_begin(c, sel, p.rtr_initial_radius, p.gradnorm_tol, p.rtr_iterations);
   // One outer iteration = [tCG init, (Hess-vec, step) x J, retract, evaluate, accept].  Every kernel is

@@ -198,6 +198,7 @@ struct dpgo_team {
                                                    // state from the agent index alone (no descriptor round trip)
   int *h_bar_err = nullptr;
   int num_cus = 0;
+  int max_lds = 160 * 1024;  // hipDeviceAttributeMaxSharedMemoryPerBlock
   int dense_max_n = 0;  // largest agent with a dense inverse (sizes the LDS chunk of the preconditioner kernel)
   std::vector<int> precond_of;  // [local agent] the form each agent runs (selects the preconditioner kernel's variant)
   int bake_sel = 1;  // DPGO_BAKE_SEL=0: the graphs of the pipelined iteration select their agent on the device only
@@ -205,6 +206,12 @@ struct dpgo_team {
   bool last_rtr_folded = false;  // the last enqueue_optimize ran the one-launch solve WITH the iteration's tail
   bool rtr_validated = false;  // a one-launch solve has completed on this device (its grid is resident at once)
   int use_fused_rtr = 1;  // DPGO_FUSED_RTR=0 keeps the launch-per-step RTR sequence (solve.hip) for every agent
+  // The one-launch solve is a persistent kernel whose workgroups wait for each other: two such grids on one device
+  // (two teams, two processes) can each hold half the CUs and starve.  Only the team that holds the device's lock --
+  // one per device across processes (flock on a file under /dev/shm) and across the teams of this process -- launches
+  // it; everybody else runs the launch-per-step sequence.  -1: not asked yet, 0: somebody else has it, 1: ours.
+  int rtr_lock_state = -1;
+  int rtr_lock_fd = -1;
   unsigned long long epoch = 1;  // bumped by everything that enqueues device work (every launch goes through ctx())
   dpgo::LaunchCtx ctx() {
     ++epoch;
@@ -244,6 +251,8 @@ int flush_stage(dpgo_team *t);
 int stage_to_pinned(dpgo_team *t, Agent &a, int *n0, int *n1);
 
 // ---- solve.hip
+bool acquire_fused_rtr_lock(dpgo_team *t);
+void release_fused_rtr_lock(dpgo_team *t);
 double converged_ratio(const Agent &a);
 void mark_optimized(dpgo_team *t, Agent &a, int rel_src, bool success);
 struct OptFlags {

@@ -184,6 +184,9 @@ int dpgo_agent_build_problem(dpgo_team_t *t, int id, int aux);
 int dpgo_agent_eval(dpgo_team_t *t, int id, const double *X, double *f, double *egrad, double *rgrad);
 int dpgo_agent_hessvec(dpgo_team_t *t, int id, const double *X, const double *eta, double *out);
 int dpgo_agent_precondition(dpgo_team_t *t, int id, const double *X, const double *V, double *out);
+/* |z (Q + shift I) - v| / |v| for a fixed pseudo-random v and z = the device's preconditioner apply: how well the operator
+ * the kernels run (dense inverse or two-level form) inverts Q + shift I (the reference solves with a Cholesky factor) */
+int dpgo_agent_preconditioner_residual(dpgo_team_t *t, int id, double *rel);
 int dpgo_agent_get_Q(dpgo_team_t *t, int id, int *rowptr, int *col, double *val); /* returns #blocks */
 int dpgo_agent_get_G(dpgo_team_t *t, int id, double *G);
 

@@ -733,3 +733,33 @@ def test_time_kernel_variants_run():
             others = sum(8.0 * 5 * 4 * th.agents[a].n for a in (0, 2))
             assert nbytes == 8.0 * (4 * n0) ** 2 + 7 * 8.0 * 5 * 4 * n0 + 4 * others
     th.close()
+
+
+def test_bench_configuration_against_the_live_oracle():
+    """The EXACT workload bench.py times (sphere2500 / 5 agents, preconditioned RGD step 0.2 + Nesterov, restart 20,
+    odometry guess) against the oracle run live, 320 iterations -- sixteen restart iterations among them -- compared
+    every 20: X, the auxiliary sequence Y and the momentum sequence V of every agent, the cost, and at the end every
+    agent's status and the local result of the last block update.  Tolerance: the two runs differ in summation order only (1e-13 per operation);
+    over 320 accelerated iterations that grows to what the asserts state."""
+    import bench
+    th, to, n = make_pair("sphere2500", 5, **bench.RGD)
+    worst = 0.0
+    for chunk in range(16):
+        th.run(20)
+        for _ in range(20):
+            to.iterate()
+        for a in range(5):
+            ah, ao = th.agents[a], to.agents[a]
+            for gh, go in ((ah.get_X, ao.get_X), (ah.get_Y, ao.get_Y), (ah.get_V, ao.get_V)):
+                worst = max(worst, np.abs(gh() - go()).max())
+        assert worst < 1e-10, (chunk, worst)   # measured: 2.7e-13 after 320 iterations
+        assert abs(th.cost() - to.cost()) <= 1e-10 * abs(to.cost()), chunk
+    for a in range(5):
+        sh, so = th.agents[a].status(), to.agents[a].status()
+        assert sh.iteration_number == so.iteration_number == 320
+        assert abs(sh.relative_change - so.relative_change) < 1e-9 and sh.ready_to_terminate == so.ready_to_terminate
+    # (a run keeps the local result of its LAST block update only: iteration 319 belongs to agent 4)
+    rh, ro = th.agents[4].opt_result(), to.agents[4].opt_result()
+    assert abs(rh.f_opt - ro.f_opt) <= 1e-10 * abs(ro.f_opt) and abs(rh.gradnorm_opt - ro.gradnorm_opt) <= 1e-8 * max(1.0, ro.gradnorm_opt)
+    print("bench configuration vs live oracle, 320 iterations: max |X, Y, V difference| = %.2e" % worst)
+    th.close()

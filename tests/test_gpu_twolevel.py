@@ -61,3 +61,13 @@ def test_two_level_iterates_match_the_oracle(method, accel):
     assert np.abs(th.global_X() - to.global_X()).max() < 1e-7
     assert abs(th.cost() - to.cost()) <= 1e-9 * abs(to.cost())
     th.close()
+
+
+@pytest.mark.parametrize("mode", [capi.PRECOND_DENSE, capi.PRECOND_TWO_LEVEL])
+def test_preconditioner_residual_of_both_exact_forms(mode):
+    """|z (Q + 0.1 I) - v| / |v| of the operator the kernels apply, bench agents (cond ~ 1e5): round-off either way"""
+    th, _, _ = make_pair("sphere2500", 5, precond_mode=mode)
+    for ah in th.agents.values():
+        assert ah.preconditioner() == mode
+        assert ah.preconditioner_residual() < 1e-12
+    th.close()
