@@ -81,7 +81,7 @@ dpgo_error_threshold_at_quantile dpgo_team_set_schedule dpgo_team_set_initial dp
 dpgo_agent_pull_local dpgo_team_time_kernel dpgo_team_run dpgo_team_get_coloring dpgo_team_run_colored dpgo_team_set_groups dpgo_team_run_group dpgo_team_step_begin dpgo_team_step_end dpgo_team_iteration dpgo_team_cost dpgo_team_update_weights dpgo_team_get_counters
 dpgo_write_measurements_csv dpgo_write_g2o dpgo_write_trajectory_csv dpgo_robust_frame_alignment dpgo_robust_local_init dpgo_team_run_simultaneous
 dpgo_team_should_terminate dpgo_team_run_schedule dpgo_agent_compute_residuals dpgo_agent_set_measurement_weights
-dpgo_agent_reset_acceleration dpgo_team_prepare dpgo_agent_read_partials dpgo_agent_preconditioner dpgo_agent_preconditioner_info dpgo_agent_preconditioner_residual dpgo_two_level_plan dpgo_agent_export_state dpgo_team_import_peer dpgo_agent_read_rtr_handoff""".split()
+dpgo_agent_reset_acceleration dpgo_team_prepare dpgo_agent_read_partials dpgo_agent_preconditioner dpgo_agent_preconditioner_info dpgo_agent_preconditioner_residual dpgo_two_level_plan dpgo_agent_export_state dpgo_team_import_peer dpgo_team_export_mailbox dpgo_team_import_mailbox dpgo_team_run_peer dpgo_agent_read_rtr_handoff""".split()
 
 
 class DpgoError(RuntimeError):
@@ -503,6 +503,23 @@ class Team:
         """read the public poses of a robot that lives in another process in place (HIP IPC / peer access)"""
         h = (C.c_ubyte * 64).from_buffer_copy(handle)
         _chk(lib().dpgo_team_import_peer(self.h, robot_id, h, C.c_longlong(off_x), C.c_longlong(off_y), n), "import_peer")
+
+    def export_mailbox(self):
+        """64-byte IPC handle of this team's mailbox (the device-side UPDATE token, dpgo_team_run_peer)"""
+        h = (C.c_ubyte * 64)()
+        _chk(lib().dpgo_team_export_mailbox(self.h, h), "export_mailbox")
+        return bytes(h)
+
+    def import_mailbox(self, handle, robot_ids):
+        h = (C.c_ubyte * 64).from_buffer_copy(handle)
+        ids = np.ascontiguousarray(robot_ids, dtype=np.int32)
+        _chk(lib().dpgo_team_import_mailbox(self.h, h, _d(ids), len(ids)), "import_mailbox")
+
+    def run_peer(self, sel_ids):
+        """len(sel_ids) global iterations, robot sel_ids[q] holding the token in the q-th, enqueued without host
+        synchronisation; remote neighbours are read in place and ordered by the device-side mailboxes"""
+        ids = np.ascontiguousarray(sel_ids, dtype=np.int32)
+        _chk(lib().dpgo_team_run_peer(self.h, _d(ids), len(ids)), "run_peer")
 
     def should_terminate(self):
         """PGOAgent::shouldTerminate() as the leader evaluates it (src/PGOAgentROS.cpp:208)"""

@@ -431,6 +431,10 @@ int sync_descs_noflush(dpgo_team *t) {
       for (auto &a : t->ag) t->precond_of.push_back(a->precond);
     }
   }
+  if (!t->peers.empty())  // robots read in place stay "received" across a re-indexing of the neighbour slots
+    for (auto &a : t->ag)
+      for (size_t q = 0; q < a->np.size(); ++q)
+        if (t->peers.count(a->np[q].first)) { a->np_has[0][q] = 1; a->np_has[1][q] = 1; }
   if (!t->descs_dirty) return 0;
   // direct pointers from every shared edge to the neighbour's pose (buffers of re-assembled agents may have moved)
   for (auto &a : t->ag) {

@@ -81,6 +81,7 @@ void dpgo_team_destroy(dpgo_team_t *t) {
   release_fused_rtr_lock(t);
   for (auto &kv : t->graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);
   for (auto &kv : t->peers) if (kv.second.base) (void)hipIpcCloseMemHandle(kv.second.base);
+  for (void *p : t->mail_handles) if (p) (void)hipIpcCloseMemHandle(p);
   t->ag.clear();
   if (t->h_state) (void)hipHostFree(t->h_state);
   if (t->h_states) (void)hipHostFree(t->h_states);
@@ -1328,6 +1329,15 @@ int dpgo_team_import_peer(dpgo_team_t *t, int robot_id, const unsigned char *han
   hipIpcMemHandle_t h;
   std::memcpy(&h, handle64, 64);
   void *p = nullptr;
+  {
+    // a robot imported before (its owner re-exported after its arrays moved): drop the old mapping first
+    auto old = t->peers.find(robot_id);
+    if (old != t->peers.end()) {
+      HIPC(hipStreamSynchronize(t->stream));
+      if (old->second.base) (void)hipIpcCloseMemHandle(old->second.base);
+      t->peers.erase(old);
+    }
+  }
   HIPC(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
   dpgo_team::Peer pr;
   pr.base = (double *)p; pr.off_x = (size_t)offset_x; pr.off_y = (size_t)offset_y; pr.n = n;
@@ -1339,6 +1349,126 @@ int dpgo_team_import_peer(dpgo_team_t *t, int robot_id, const unsigned char *han
       if (a->np[q].first == robot_id) { a->np_has[0][q] = 1; a->np_has[1][q] = 1; }
   }
   t->descs_dirty = true;
+  return DPGO_OK;
+}
+
+// ---- the synchronous schedule across processes with the UPDATE token on the device (src/PGOAgentROS.cpp:136-149,
+// 443-504, 1161-1189 replaced): see k_mail_signal / k_mail_wait in pose_ops.hip
+static int ensure_mailbox(dpgo_team_t *t) {
+  const size_t words = 2 * (size_t)t->prm.num_robots;
+  if (t->d_mail.p) return 0;
+  if (t->d_mail.alloc(words)) { set_err("mailbox allocation failed"); return DPGO_ERR; }
+  HIPC(hipMemsetAsync(t->d_mail.p, 0, sizeof(unsigned long long) * words, t->stream));
+  HIPC(hipStreamSynchronize(t->stream));
+  t->last_fin.assign(t->prm.num_robots, 0ull);
+  return 0;
+}
+
+int dpgo_team_export_mailbox(dpgo_team_t *t, unsigned char *handle64) {
+  if (ensure_mailbox(t)) return DPGO_ERR;
+  hipIpcMemHandle_t h;
+  HIPC(hipIpcGetMemHandle(&h, t->d_mail.p));
+  std::memcpy(handle64, &h, 64);
+  return DPGO_OK;
+}
+
+int dpgo_team_import_mailbox(dpgo_team_t *t, const unsigned char *handle64, const int *robot_ids, int count) {
+  if (ensure_mailbox(t)) return DPGO_ERR;
+  hipIpcMemHandle_t h;
+  std::memcpy(&h, handle64, 64);
+  void *p = nullptr;
+  HIPC(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+  t->mail_handles.push_back(p);
+  for (int k = 0; k < count; ++k) {
+    if (robot_ids[k] < 0 || robot_ids[k] >= t->prm.num_robots || t->id2local.count(robot_ids[k])) {
+      set_err("import_mailbox: bad robot id");
+      return DPGO_ERR;
+    }
+    t->peer_mail[robot_ids[k]] = (unsigned long long *)p;
+  }
+  return DPGO_OK;
+}
+
+// `iters` global iterations in which robot sel_ids[q] holds the token, enqueued without any host synchronisation:
+// every process calls this with the same list; neighbours in other processes are read in place (dpgo_team_import_peer)
+// and ordered by the mailboxes.  Per iteration k (t->iter), with acceleration:
+//   wait   fin[s] >= k         for s = the token holder of k - 1, if it neighbours a local robot from another process
+//                              (it has finished reading the Y this process is about to move)
+//   P1     iterate(false) part of every local robot (dpgo_team_step_begin)
+//   signal ready[a] = k + 1    into the mailbox of the token holder's team, for its local neighbours a
+//   wait   ready[b] >= k + 1   for the remote neighbours b of a local token holder
+//   P2     the block update (dpgo_team_step_end)
+//   signal fin[sel] = k + 1    into the mailboxes of the token holder's remote neighbours
+// Without acceleration only block updates move poses: the token holder waits for fin[b] of every remote neighbour's last
+// block update (what it reads is final, and nobody still reads what it overwrites).
+int dpgo_team_run_peer(dpgo_team_t *t, const int *sel_ids, int iters) {
+  if (sync_descs(t)) return DPGO_ERR;
+  if (ensure_mailbox(t)) return DPGO_ERR;
+  const dpgo_params_t &p = t->prm;
+  const int NR = p.num_robots;
+  for (auto &a : t->ag) if (!a->has_X) { set_err("run_peer before set_initial"); return DPGO_NOT_READY; }
+  // remote neighbours of every local robot must be readable in place and reachable by mail
+  for (auto &a : t->ag)
+    for (int b : a->neighbors)
+      if (!t->id2local.count(b) && (!t->peers.count(b) || !t->peer_mail.count(b))) {
+        set_err("run_peer: neighbour " + std::to_string(b) + " of robot " + std::to_string(a->id) + " was not imported (state + mailbox)");
+        return DPGO_ERR;
+      }
+  auto is_nbr = [](const Agent &a, int b) { return std::binary_search(a.neighbors.begin(), a.neighbors.end(), b); };
+  auto flush_waits = [&](MailWaits &w) { launch_mail_wait(t->stream, t->d_mail.p, w, t->h_bar_err); w.count = 0; };
+  auto add_wait = [&](MailWaits &w, int index, unsigned long long value) {
+    for (int q = 0; q < w.count; ++q) if (w.index[q] == index) { w.value[q] = std::max(w.value[q], value); return; }
+    if (w.count == MAIL_MAX) flush_waits(w);
+    w.index[w.count] = index; w.value[w.count] = value; ++w.count;
+  };
+  auto flush_sigs = [&](MailSignals &s) { launch_mail_signal(t->stream, s); s.count = 0; };
+  auto add_sig = [&](MailSignals &s, unsigned long long *word, unsigned long long value) {
+    for (int q = 0; q < s.count; ++q) if (s.word[q] == word) { s.value[q] = value; return; }
+    if (s.count == MAIL_MAX) flush_sigs(s);
+    s.word[s.count] = word; s.value[s.count] = value; ++s.count;
+  };
+  int prev_sel = -1;
+  {
+    // (the token holder of the iteration in front of this call, if any)
+    unsigned long long best = 0;
+    for (int b = 0; b < NR; ++b) if (t->last_fin[b] > best) { best = t->last_fin[b]; prev_sel = b; }
+    if (best != (unsigned long long)t->iter) prev_sel = -1;
+  }
+  for (int q = 0; q < iters; ++q) {
+    const int sel_id = sel_ids[q];
+    if (sel_id < 0 || sel_id >= NR) { set_err("run_peer: bad robot id in the schedule"); return DPGO_ERR; }
+    const unsigned long long k = (unsigned long long)t->iter;
+    auto it = t->id2local.find(sel_id);
+    const int sel = (it == t->id2local.end()) ? -2 : it->second;
+    const bool restart = p.acceleration && ((t->iter + 2) % p.restart_interval) == 0;
+    MailWaits w{};
+    MailSignals s{};
+    if (p.acceleration && prev_sel >= 0 && !t->id2local.count(prev_sel))
+      for (auto &a : t->ag) if (is_nbr(*a, prev_sel)) { add_wait(w, NR + prev_sel, k); break; }
+    flush_waits(w);
+    int rc = enqueue_team_iteration(t, false, restart, sel, 1);
+    if (rc) return rc;
+    if (p.acceleration && sel == -2)
+      for (auto &a : t->ag) if (is_nbr(*a, sel_id)) add_sig(s, t->peer_mail[sel_id] + a->id, k + 1);
+    flush_sigs(s);
+    if (sel >= 0)
+      for (int b : t->ag[sel]->neighbors)
+        if (!t->id2local.count(b)) {
+          if (p.acceleration) add_wait(w, b, k + 1);
+          if (t->last_fin[b] > 0) add_wait(w, NR + b, t->last_fin[b]);
+        }
+    flush_waits(w);
+    rc = enqueue_team_iteration(t, false, restart, sel, 2);
+    if (rc) return rc;
+    const bool fused = p.method == DPGO_METHOD_RGD && p.rgd_use_preconditioner && !restart && sel >= 0;
+    account_iteration(t, sel, fused || t->last_iteration_folded);
+    if (sel >= 0)
+      for (int b : t->ag[sel]->neighbors)
+        if (!t->id2local.count(b)) add_sig(s, t->peer_mail[b] + NR + sel_id, k + 1);
+    flush_sigs(s);
+    t->last_fin[sel_id] = k + 1;
+    prev_sel = sel_id;
+  }
   return DPGO_OK;
 }
 

@@ -69,6 +69,12 @@ void launch_report(const LaunchCtx &c, int ai, const int *frames, int count, dou
                    int up_n1 = 0);
 void launch_residuals(const LaunchCtx &c, int ai, int nedges);
 void launch_cost(const LaunchCtx &c, int ai);
+// the device-side UPDATE token (pose_ops.hip k_mail_signal / k_mail_wait): up to MAIL_MAX words per launch
+constexpr int MAIL_MAX = 16;
+struct MailSignals { int count; unsigned long long *word[MAIL_MAX]; unsigned long long value[MAIL_MAX]; };
+struct MailWaits { int count; int index[MAIL_MAX]; unsigned long long value[MAIL_MAX]; };
+void launch_mail_signal(hipStream_t s, const MailSignals &sig);
+void launch_mail_wait(hipStream_t s, const unsigned long long *mail, const MailWaits &w, int *err);
 void launch_noop(const LaunchCtx &c, int grid, int block);
 void launch_copy(const LaunchCtx &c, int sel, int only_agent, int num_agents, int max_n, int from, int to, int publish);
 void launch_bsr_to_dense(hipStream_t s, const int *rowptr, const int *col, const double *qval, int n, double shift,

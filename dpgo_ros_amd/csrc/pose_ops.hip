@@ -355,6 +355,28 @@ __global__ __launch_bounds__(256) void k_cost(const AgentDev *__restrict__ agent
 
 __global__ void k_noop(const AgentDev *__restrict__ agents, int ai) { (void)agents; (void)ai; }
 
+// ---- the UPDATE token across processes, on the device (dpgo_team_run_peer, capi.hip): every team owns a mailbox of
+// 64-bit words that the OTHER teams write over peer access (HIP IPC: xGMI stores between GPUs) and that its own wait
+// kernels poll in local memory.  A signal kernel runs behind the launches whose results it announces (their stores are
+// device-visible at the kernel boundary); a wait kernel runs in front of the launches that read a peer's arrays in
+// place, or that overwrite what a peer was reading.  Monotonic values, wall-clock time-out raised in a pinned host word.
+__global__ void k_mail_signal(MailSignals s) {
+  const int i = threadIdx.x;
+  if (i >= s.count) return;
+  __threadfence_system();
+  __hip_atomic_store(s.word[i], s.value[i], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ void k_mail_wait(const unsigned long long *mail, MailWaits w, int *err) {
+  const int i = threadIdx.x;
+  if (i >= w.count) return;
+  const long long t0 = (long long)wall_clock64();
+  while (__hip_atomic_load(mail + w.index[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < w.value[i]) {
+    __builtin_amdgcn_s_sleep(2);
+    if ((long long)wall_clock64() - t0 > 400000000ll) { *err = 4; break; }  // 4 s of the 100 MHz clock
+  }
+}
+
 // dense A = Q + shift I from the block-CSR (column-major N4 x N4; A must be zeroed first)
 __global__ void k_bsr_to_dense(const int *rowptr, const int *col, const double *qval, int n, double shift, double *A) {
   const int j = blockIdx.x;  // block row = output pose = column block of A
@@ -465,6 +487,14 @@ void launch_report(const LaunchCtx &c, int ai, const int *frames, int count, dou
 void launch_residuals(const LaunchCtx &c, int ai, int nedges) {
   if (nedges <= 0) return;
   DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_residuals<R>, dim3((nedges + 63) / 64), dim3(64), 0, c.stream, c.agents, ai));
+}
+
+void launch_mail_signal(hipStream_t s, const MailSignals &sig) {
+  if (sig.count > 0) hipLaunchKernelGGL(k_mail_signal, dim3(1), dim3(64), 0, s, sig);
+}
+
+void launch_mail_wait(hipStream_t s, const unsigned long long *mail, const MailWaits &w, int *err) {
+  if (w.count > 0) hipLaunchKernelGGL(k_mail_wait, dim3(1), dim3(64), 0, s, mail, w, err);
 }
 
 void launch_noop(const LaunchCtx &c, int grid, int block) {

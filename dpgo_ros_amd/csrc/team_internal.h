@@ -193,6 +193,13 @@ struct dpgo_team {
   // public poses are read in place over peer access instead of travelling as messages
   struct Peer { double *base = nullptr; size_t off_x = 0, off_y = 0; int n = 0; };
   std::map<int, Peer> peers;
+  // the device-side UPDATE token (dpgo_team_run_peer): this team's mailbox -- [robot] "moved its public poses for
+  // iteration k" (k + 1), [num_robots + robot] "finished its block update of iteration k" (k + 1) -- written by the
+  // teams that hold those robots; the mailboxes of the other teams, by robot they serve; every robot's last block update
+  dpgo_host::DevBuf<unsigned long long> d_mail;
+  std::map<int, unsigned long long *> peer_mail;      // robot id -> mailbox of the team that holds it
+  std::vector<void *> mail_handles;                   // imported mappings (closed with the team)
+  std::vector<unsigned long long> last_fin;           // [robot] k + 1 of its last block update in a run_peer schedule
   // time-out flag of the in-kernel exchanges (pinned), CU count
   dpgo_host::DevBuf<dpgo::NestState> d_nest_all;  // NestState of local agent k at [k]: one array, so that a kernel finds any agent's
                                                    // state from the agent index alone (no descriptor round trip)

@@ -140,6 +140,17 @@ class HipBackend:
     def import_peer(self, robot, state):
         self.team.import_peer(robot, *state)
 
+    # ---- the UPDATE token on the device (dpgo_team_run_peer): mailboxes written over peer access
+    def export_mailbox(self):
+        return self.team.export_mailbox() if self.team is not None else None
+
+    def import_mailbox(self, handle, robots):
+        self.team.import_mailbox(handle, robots)
+
+    def run_peer(self, sel_ids):
+        if self.team is not None:
+            self.team.run_peer(sel_ids)
+
     def sync(self):
         self.stream.synchronize()
 
@@ -220,6 +231,7 @@ class DistributedRBCD:
         self.sent = {}                    # (b, sel) -> version of b that sel's rank holds
         self.messages = 0                 # point-to-point operations issued by this rank (for the tests / bench)
         self._imported, self.peer_access, self.peer_error = set(), False, None
+        self._mail_imported = set()
         # shared-edge counts per ordered pair, for the weight messages of the robust path
         self.nshared = {}
         for e in meas:
@@ -331,16 +343,19 @@ class DistributedRBCD:
         branch afterwards."""
         d = self.dist
         err = None
+        mail = None
         try:
             mine = self.be.export_states() if hasattr(self.be, "export_states") else {}
             if not hasattr(self.be, "export_states"):
                 err = "backend has no peer access"
+            elif hasattr(self.be, "export_mailbox"):
+                mail = self.be.export_mailbox()
         except RuntimeError as e:  # agree on the outcome before anyone enters another collective
             mine, err = {}, str(e)
         everyone = [None] * self.world
-        d.all_gather_object(everyone, mine)
+        d.all_gather_object(everyone, (mine, mail))
         states = {}
-        for part in everyone:
+        for part, _ in everyone:
             states.update(part)
         if err is None and getattr(self.be, "team", None) is not None:
             try:
@@ -349,6 +364,14 @@ class DistributedRBCD:
                         if self.owner[b] != self.rank and b not in self._imported:
                             self.be.import_peer(b, states[b])
                             self._imported.add(b)
+                # the mailbox of every rank that holds a neighbour of a local robot (the device-side UPDATE token)
+                ranks = sorted({self.owner[b] for a in self.mine for b in self.nbrs[a] if self.owner[b] != self.rank})
+                for rk in ranks:
+                    if rk in self._mail_imported:
+                        continue
+                    if everyone[rk][1] is not None and hasattr(self.be, "import_mailbox"):
+                        self.be.import_mailbox(everyone[rk][1], [b for b in range(self.N) if self.owner[b] == rk])
+                        self._mail_imported.add(rk)
             except (RuntimeError, KeyError) as e:
                 err = str(e)
         errs = [None] * self.world
@@ -373,6 +396,21 @@ class DistributedRBCD:
             self.be.step_end(sel)
         self.k += 1
         return sel
+
+    def run_peer(self, iters):
+        """`iters` iterations of the synchronous schedule with NO host in the loop: neighbours in other processes are
+        read in place and the UPDATE token lives on the device (dpgo_team_run_peer: every rank enqueues the same
+        schedule once; wait / signal kernels around the launches that read a peer or overwrite what a peer was
+        reading order the ranks through mailboxes written over peer access).  Same iterates as step(); returns
+        without synchronising.  Needs enable_peer_access."""
+        assert self.peer_access, "run_peer needs enable_peer_access()"
+        sels = [self.schedule[(self.k + q) % len(self.schedule)] for q in range(iters)]
+        with self._ctx():
+            self.be.run_peer(sels)
+        self.k += iters
+        self.version = [self.k] * self.N  # (conservative: a later step() sends everything once)
+        self.sent = {}
+        return sels
 
     def free_run(self, ticks):
         """The asynchronous (ASAPP) mode across ranks, src/PGOAgentROS.cpp:119-127: every rank steps its agents `ticks`

@@ -266,6 +266,15 @@ int dpgo_team_time_kernel(dpgo_team_t *t, int id, int which, int reps, double *a
  * arrays instead of from what dpgo_agent_update_neighbor_poses last supplied. */
 int dpgo_agent_export_state(dpgo_team_t *t, int id, unsigned char *handle64, long long *offset_x, long long *offset_y, int *n);
 int dpgo_team_import_peer(dpgo_team_t *t, int robot_id, const unsigned char *handle64, long long offset_x, long long offset_y, int n);
+/* The synchronous schedule across processes WITHOUT the host in the loop (the UPDATE token of src/PGOAgentROS.cpp:136-149,
+ * 443-504, 1161-1189 on the device): every team exports a mailbox of 64-bit words (IPC handle) that the teams holding its
+ * robots' neighbours import (robot_ids: the robots that live in the exporting team); dpgo_team_run_peer then enqueues
+ * `iters` global iterations -- robot sel_ids[q] holds the token in the q-th -- with wait / signal kernels around the
+ * launches that read a neighbour in place or overwrite what a neighbour was reading.  Every process passes the same
+ * list; nothing synchronises with the host; the iterates are those of dpgo_team_step_begin / _end with messages. */
+int dpgo_team_export_mailbox(dpgo_team_t *t, unsigned char *handle64);
+int dpgo_team_import_mailbox(dpgo_team_t *t, const unsigned char *handle64, const int *robot_ids, int count);
+int dpgo_team_run_peer(dpgo_team_t *t, const int *sel_ids, int iters);
 /* diagnostic: hand-off words of an agent's one-launch RTR solve (rtr_fused.hip; phase stamps in trace builds) */
 int dpgo_agent_read_rtr_handoff(dpgo_team_t *t, int id, unsigned long long *out, int n);
 /* diagnostic: `n` doubles of an agent's device-side partial-sum scratch (csrc/dpgo_dev.h PART_*) from `offset` */

@@ -43,8 +43,14 @@ def _problem(mode):
     if mode in ("ticks", "peer_free", "peer_agent_api"):
         kw = dict(method=1, rgd_stepsize=0.05, acceleration=0)
         mo = m
-    elif mode == "peer_sync":
+    elif mode in ("peer_sync", "peer_token"):
         kw = dict(method=0, gradnorm_tol=1e-2, acceleration=1, restart_interval=5)
+        mo = m
+    elif mode == "peer_token_rgd":
+        kw = dict(method=1, rgd_stepsize=0.05, acceleration=1, restart_interval=7)
+        mo = m
+    elif mode == "peer_token_plain":
+        kw = dict(method=0, gradnorm_tol=1e-2, acceleration=0)
         mo = m
     else:
         kw = dict(method=0, gradnorm_tol=1e-2, acceleration=1, restart_interval=5, robust_cost_type=O.COST_GNC_TLS, gnc_barc=3.0,
@@ -75,6 +81,14 @@ def _worker(rank, world, port, mode, outdir):
         drv.enable_peer_access()
         for _ in range(4 * N):
             drv.step_peer()
+        be.sync()
+        dist.barrier()
+        extra["messages"] = drv.messages
+    elif mode.startswith("peer_token"):
+        assert drv.enable_peer_access(), drv.peer_error
+        # the whole run is enqueued in three calls; no barrier, no stream synchronisation, no message in between
+        for chunk in (5, 1, 4 * N - 6):
+            drv.run_peer(chunk)
         be.sync()
         dist.barrier()
         extra["messages"] = drv.messages
@@ -202,3 +216,22 @@ def test_peer_access_per_agent_iterate_reads_neighbours_in_place():
         ref.iterate()
     for a in range(N):
         assert np.abs(outs[a % 2]["X%d" % a] - ref.agents[a].get_X()).max() < 1e-7, a
+
+
+@pytest.mark.parametrize("mode", ["peer_token", "peer_token_rgd", "peer_token_plain"])
+def test_device_side_update_token_over_peer_access(mode):
+    """The synchronous schedule across two processes with the host out of the loop (dpgo_team_run_peer): each process
+    enqueues the schedule, wait / signal kernels around the launches that read the other process's poses in place -- or
+    overwrite what it was reading -- order the two streams through mailboxes written over HIP IPC.  RTR + Nesterov with
+    restarts, RGD + Nesterov, plain RTR: the oracle's sequential iterates, no message after the first exchange."""
+    outs = _spawn(mode)
+    N, mp, n, T, kw = _problem(mode)
+    ref = O.Team(mp, n, O.default_params(r=5, num_robots=N, **kw))
+    ref.set_initial(T, O.fixed_stiefel(5))
+    for _ in range(4 * N):
+        ref.iterate()
+    for a in range(N):
+        assert np.abs(outs[a % 2]["X%d" % a] - ref.agents[a].get_X()).max() < 1e-7, a
+    assert abs(float(outs[0]["cost"]) - ref.cost()) <= 1e-8 * abs(ref.cost())
+    first = sum(1 for a in range(N) for b in range(N) if a != b and a % 2 != b % 2)
+    assert int(outs[0]["messages"]) <= first and int(outs[1]["messages"]) <= first
