@@ -78,8 +78,18 @@ def single_gpu(args):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ms = dt / (reps * args.steps) * 1e3
+    # spread: 15 more runs of exactly K steps, each between two synchronisations (mean / p95 of ms per step)
+    singles = []
+    for _ in range(15):
+        a0 = time.perf_counter()
+        team.run(args.steps)
+        team.synchronize()
+        torch.cuda.synchronize()
+        singles.append((time.perf_counter() - a0) / args.steps * 1e3)
     timing = {"timed_steps": reps * args.steps, "timed_region_ms": dt * 1e3,
-              "ms_per_step_single_run_of_K": dt_single / args.steps * 1e3}
+              "ms_per_step_single_run_of_K": dt_single / args.steps * 1e3,
+              "ms_per_step_runs_of_K": {"runs": len(singles), "mean": float(np.mean(singles)), "p95": float(np.percentile(singles, 95)),
+                                        "min": float(np.min(singles))}}
     counters = team.counters()
     c_timed = counters - c0
     iter_bytes = (c_timed[1] + c_timed[3]) / max(c_timed[4], 1)   # algorithmic bytes per RBCD iteration
@@ -88,6 +98,30 @@ def single_gpu(args):
     roof = roofline_leg(team, 1)
     roof["iteration"] = {"algorithmic_bytes": iter_bytes, "achieved": iter_bytes / (ms * 1e-3) / 1e9, "unit": "GB/s",
                          "note": "B_iter = #precond x B_P + #eval x B from the run's own counters, / ms per iteration"}
+    # the SAME operator in its two-level (nested-dissection / Schur-complement) form, csrc/twolevel.h: a quarter of the
+    # bytes, and slower at this agent size (one exchange across XCDs inside the launch) -- which is why the automatic
+    # mode keeps the dense inverse up to 256 MB.  Timed exactly like the figures above.
+    ptl = capi.default_params(r=WORKLOAD["r"], num_robots=WORKLOAD["num_robots"], precond_mode=capi.PRECOND_TWO_LEVEL, **RGD)
+    ttl = capi.Team.from_measurements(mp, ptl, device=0)
+    ttl.set_initial(T, Y)
+    ttl.run(args.warmup)
+    ttl.prepare(reps * args.steps)
+    ttl.synchronize()
+    a0 = time.perf_counter()
+    ttl.run(reps * args.steps)
+    ttl.synchronize()
+    torch.cuda.synchronize()
+    tl_ms = (time.perf_counter() - a0) / (reps * args.steps) * 1e3
+    rtl = roofline_leg(ttl, 1)
+    info = ttl.agents[1].preconditioner_info()
+    roof["two_level_form"] = {"ms_per_step": tl_ms, "bytes_per_apply": info["bytes_per_apply"], "dense_bytes": info["dense_bytes"],
+                              "subdomains": info["subdomains"], "separator_poses": info["separator_poses"],
+                              "step_kernel": {k: rtl[k] for k in ("bytes_per_launch", "us_per_launch", "achieved", "frac")},
+                              "apply_only": {k: rtl["apply_only"][k] for k in ("bytes_per_launch", "us_per_launch", "achieved", "frac")},
+                              "cost_after_run": ttl.cost(),
+                              "note": "precond_mode = 3 on the same workload; bytes_per_launch = the slabs one apply streams "
+                                      "+ the vectors; see profiles/r03_precond_forms_by_size.md for the crossover by agent size"}
+    ttl.close()
 
     # ---- RTR + Nesterov, the reference's synchronous default (PGOAgentROSNode.cpp:82-85), timed the same way
     p3 = capi.default_params(r=WORKLOAD["r"], num_robots=WORKLOAD["num_robots"], **RTR)
@@ -466,9 +500,23 @@ def cpu_baseline(mp, n, T, Y, cfg=None, seconds=12.0):
             to.iterate()
         iters += chunk
     dt = time.perf_counter() - t0
-    return {"value": dt / iters * 1e3, "unit": "ms/RBCD-iteration", "cores": 1, "kind": "port",
+    return {"value": dt / iters * 1e3, "unit": "ms/RBCD-iteration", "cores": 1, "kind": "port", "host": host_cpu(),
             "sample": "%d iterations of the same 5-agent %s+Nesterov workload (~%d s), oracle/liboracle.so"
                       % (iters, "RGD" if cfg["method"] == 1 else "RTR", int(seconds))}
+
+
+def host_cpu():
+    """model name and logical core count of the host the baseline ran on"""
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"model": model, "logical_cores": os.cpu_count()}
 
 
 def multi_gpu(args):
