@@ -134,7 +134,10 @@ static int choose_precond(dpgo_team *t, Agent &a, double &budget) {
   if (mode == DPGO_PRECOND_AUTO || mode == DPGO_PRECOND_TWO_LEVEL) {
     // the dissection depends on the sparsity pattern only: a weight update keeps it
     if (a.tl_plan.n != a.n || a.tl_rowptr != a.rowptr || a.tl_col != a.col) {
-      a.tl_plan = tl_make_plan(a.n, a.rowptr, a.col);
+      // RTR: prefer a dissection whose slabs fit the one-launch solve (two workgroups per CU) over the one that streams
+      // the fewest bytes per stand-alone apply
+      const bool rtr = t->prm.method == DPGO_METHOD_RTR && t->use_fused_rtr;
+      a.tl_plan = tl_make_plan(a.n, a.rowptr, a.col, 0, rtr ? rtr_fused_tl_fit_pairs(t->prm.r) : 0, rtr ? std::min(512, 2 * t->num_cus) : 0);
       a.tl_rowptr = a.rowptr; a.tl_col = a.col;
     }
     const TLPlan &pl = a.tl_plan;
@@ -162,7 +165,15 @@ static int choose_precond(dpgo_team *t, Agent &a, double &budget) {
     return DPGO_ERR;
   }
   if (mode == DPGO_PRECOND_AUTO) {
-    if (tl_ok && tl_worthwhile(a.tl_plan)) mode = DPGO_PRECOND_TWO_LEVEL;
+    // RTR: an agent too large for the dense one-launch solve (its 8-column slabs do not fit LDS beyond 512 poses) keeps
+    // the solve in one launch with the two-level form, whose slabs do (rtr_fused.hip) -- worth more than the cheaper
+    // single apply of the dense inverse
+    const bool rtr_tl = t->prm.method == DPGO_METHOD_RTR && t->use_fused_rtr && tl_ok &&
+                        !(rtr_fused_eligible(t->prm.r, a.n, t->num_cus) && rtr_fused_lds_bytes(t->prm.r, a.n) <= (size_t)t->max_lds) &&
+                        a.tl_plan.prod_post &&
+                        rtr_fused_tl_eligible(t->prm.r, a.tl_plan.nwg - a.tl_plan.nS2, tl_max_pre_poses(a.tl_plan), a.tl_plan.ns, t->num_cus, t->max_lds);
+    if (rtr_tl) mode = DPGO_PRECOND_TWO_LEVEL;
+    else if (tl_ok && tl_worthwhile(a.tl_plan)) mode = DPGO_PRECOND_TWO_LEVEL;
     else if (fits) mode = DPGO_PRECOND_DENSE;
     else mode = tl_ok ? DPGO_PRECOND_TWO_LEVEL : DPGO_PRECOND_BLOCK_JACOBI;
   }
@@ -429,6 +440,8 @@ int sync_descs_noflush(dpgo_team *t) {
       for (auto &a : t->ag) if (a->precond == DPGO_PRECOND_DENSE) t->dense_max_n = std::max(t->dense_max_n, a->n);
       t->precond_of.clear();
       for (auto &a : t->ag) t->precond_of.push_back(a->precond);
+      t->tl_max_wg = 0;
+      for (auto &a : t->ag) if (a->precond == DPGO_PRECOND_TWO_LEVEL) t->tl_max_wg = std::max(t->tl_max_wg, a->tl_plan.nwg);
     }
   }
   if (!t->peers.empty())  // robots read in place stay "received" across a re-indexing of the neighbour slots

@@ -60,12 +60,13 @@ struct NestState {
 // poses of the adjacent subdomains, -E_i), then the 4 ns separator rows that meet u (W_i, or Sc^-1).
 struct TLWg {
   int own[2];          // poses (-1: padding slot)
-  int pre_cnt, pad0;
+  int pre_cnt, sep0;   // sep0: position of own[0] in the separator (rows of u it publishes), workgroups that own separator poses
   long long slab_off;  // doubles from TLDev::slabs
   long long pad1;
 };
 struct TLDev {
-  int ns, nwg, nA, rp_stride;  // separator poses, workgroups, workgroups that own separator poses (the first nA), row-list stride
+  int ns, nwg, nA, rp_stride;  // separator poses, workgroups, producers (the first nA: one separator pose each), row-list stride
+  int nS2, prod_post;          // workgroups [nA, nA + nS2) own the separator poses' columns; producers' slabs also hold them
   const TLWg *wg;
   const int *rowpose;
   const double *slabs;

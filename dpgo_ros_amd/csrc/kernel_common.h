@@ -46,7 +46,7 @@ __device__ __forceinline__ int spmm_blocks(int n) { return (n + (64 / R) - 1) / 
 
 __device__ __forceinline__ int precond_blocks(int N4) { return (N4 + 7) / 8; }
 // workgroups of a preconditioner-type launch that own poses of this agent (and leave partials in PART_B)
-__device__ __forceinline__ int precond_nblk(const AgentDev &ag) { return ag.tl.nwg > 0 ? ag.tl.nwg : (ag.N4 + 7) / 8; }
+__device__ __forceinline__ int precond_nblk(const AgentDev &ag) { return ag.tl.nwg > 0 ? ag.tl.nwg - ag.tl.nA : (ag.N4 + 7) / 8; }
 
 __device__ __forceinline__ double2 ld2(const double *p) { return *reinterpret_cast<const double2 *>(p); }
 

@@ -13,6 +13,7 @@ struct LaunchCtx {
   int ny = 1;              // grid.y of the per-agent kernels: members of the colour class being updated
   int dense_max_n = 1 << 30;  // largest agent of the team that streams a dense inverse (0: none): sizes k_precond's LDS chunk
   bool any_two_level = false;      // the team has an agent with the two-level preconditioner
+  int tl_max_wg = 0;               // ... and the most workgroups one of their applies runs
   const int *host_precond = nullptr;  // [local agent] DPGO_PRECOND_* it runs (host memory; selects the kernel variant)
   const NestState *nest_all = nullptr;  // the team's NestStates, [local agent]: lets a kernel read an agent's Nesterov
                                         // state from the agent index alone, next to (not behind) its descriptor
@@ -84,7 +85,7 @@ void launch_bsr_to_dense(hipStream_t s, const int *rowptr, const int *col, const
 // bar: RTR_BAR_WORDS zero-initialised 64-bit words owned by the AGENT (the arrival counts depend on its grid);
 // ws: RTR_WS_DOUBLES doubles of partial-sum scratch; err: pinned host word raised on a spin time-out.
 constexpr int RTR_BAR_WORDS = 18 * 16 + 160;
-constexpr int RTR_WS_DOUBLES = 7 * 256;
+constexpr int RTR_WS_DOUBLES = 7 * 512;
 bool rtr_fused_eligible(int r, int n, int num_cus);
 size_t rtr_fused_lds_bytes(int r, int n);  // LDS the solve of an n-pose agent needs (checked against the device's limit)
 // cum: 4 zero-initialised 64-bit words per agent: running totals {solves, Hessian-vector products, preconditioner
@@ -93,7 +94,11 @@ size_t rtr_fused_lds_bytes(int r, int n);  // LDS the solve of an n-pose agent n
 int launch_rtr_solve(const LaunchCtx &c, int ai, int n, unsigned long long *bar, double *ws, unsigned long long *cum, RtrState *host_rec,
                      unsigned long long *host_cum, int *err, double Delta0,
                      double tol, int max_outer, int max_inner, double max_radius, int tail = 0, int num_robots = 1,
-                     int restart_interval = 1);
+                     int restart_interval = 1, int tl_nwg = 0, size_t tl_dyn = 0);
+// ... for an agent with the two-level preconditioner (tl_nwg workgroups, tl_dyn bytes of slab per workgroup)
+size_t rtr_fused_tl_lds_bytes(int r, int max_pre_poses, int ns);
+bool rtr_fused_tl_eligible(int r, int nwg, int max_pre_poses, int ns, int num_cus, int max_lds);
+int rtr_fused_tl_fit_pairs(int r);
 
 // dense_inverse.hip: M = (A)^-1 for a symmetric positive definite N x N column-major matrix.
 // A is destroyed; work must hold N*N doubles.  Returns 0, or the (1-based) failing pivot block.

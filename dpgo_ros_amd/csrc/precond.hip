@@ -67,7 +67,11 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *__restrict__ ag
   const int agent_index = sel_cur(team, sel);
   const AgentDev &ag = agents[agent_index];
   const bool is_tl = TLC && ag.tl.nwg > 0;
-  const int bx = is_tl ? (int)blockIdx.x : ((int)blockIdx.x % 8) * ((int)gridDim.x / 8) + (int)blockIdx.x / 8;
+  // (two-level agents: the first nA workgroups of the launch are the producers of the exchange -- they own no columns and
+  // no logical index; workgroup nA + k is logical block k)
+  const int hb = (int)blockIdx.x;
+  const bool producer = is_tl && hb < ag.tl.nA;
+  const int bx = is_tl ? hb - ag.tl.nA : (hb % 8) * ((int)gridDim.x / 8) + hb / 8;
   PC_STAMP(0);
   if (MODE == PM_RGD_ && advance == 2 && bx == 0 && threadIdx.x == 0) {
     // pipelined iterations: nothing that a workgroup of THIS launch reads is written here (cur_sel, iter and the
@@ -95,12 +99,12 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *__restrict__ ag
   const int tid = threadIdx.x, lane = tid & 63;
   const int N4 = ag.N4;
   const int nblk = precond_nblk(ag);
-  if (bx >= nblk) return;
+  if (bx >= nblk) return;  // (producers: bx < 0)
   // the two poses this workgroup owns: consecutive ones, or the pair the two-level layout assigns
   TLWg tlw = {};
   int pj0 = 2 * bx, pj1 = (2 * bx + 1 < ag.n) ? 2 * bx + 1 : -1;
   if constexpr (TLC) {
-    if (is_tl) { tlw = ag.tl.wg[bx]; pj0 = tlw.own[0]; pj1 = tlw.own[1]; }
+    if (is_tl) { tlw = ag.tl.wg[hb]; pj0 = tlw.own[0]; pj1 = tlw.own[1]; }
   }
 
   // ---- scalar prologue (identical in every workgroup)
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *__restrict__ ag
   // two-level agents: the first pass of the product is requested here, in front of everything the epilogue will need
   TLPre<R> tlpre;
   if constexpr (TLC) {
-    if (is_tl) tl_issue<R>(ag.tl, tlw, bx, Vstage, tid, tlpre);
+    if (is_tl) tl_issue<R>(ag.tl, tlw, hb, Vstage, tid, tlpre);
   }
   const int npose = (pj1 >= 0) ? 2 : 1;
   // element `tid` (< npose * 4R) of the own poses in an r x 4n array
@@ -171,7 +175,7 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *__restrict__ ag
     const double *D = ag.buf[jpar ? B_D1 : B_D0];
     double *E = ag.buf[B_ETA];
     const double stepc = boundary ? tau : alpha;
-    if (tid < npose * 4 * R) E[own_off] += stepc * D[own_off];
+    if (tid < npose * 4 * R && !producer) E[own_off] += stepc * D[own_off];
     if (boundary) return;
   }
 
@@ -224,9 +228,11 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *__restrict__ ag
   double la_x[4 * R], la_v[4 * R];
   if (is_tl) {
     // two-level operator: the product of twolevel_dev.h (one exchange inside the launch), then the common epilogues
-    if constexpr (TLC)
-    tl_apply<R, PC_TRACE_ON>(ag.tl, tlw, bx, Vstage, tlpre, vs, zs, tid,
-                             (MODE == PM_RGD_ && blockIdx.x == DPGO_PC_TRACE_BLOCK) ? ag.part + PART_E + 4000 * PART_STRIDE : nullptr);
+    if constexpr (TLC) {
+      if (!tl_apply<R, PC_TRACE_ON>(ag.tl, tlw, hb, Vstage, tlpre, vs, zs, tid,
+                                    (MODE == PM_RGD_ && blockIdx.x == DPGO_PC_TRACE_BLOCK) ? ag.part + PART_E + 4000 * PART_STRIDE : nullptr))
+        return;  // a producer: its entry of u is published, it owns no columns
+    }
     if (tid < npose * 4 * R) {
       Ysh[tid] = pre_x;
       if (MODE == PM_RGD_) { Esh[0][tid] = pre_v; Esh[1][tid] = pre_y; Esh[2][tid] = pre_p; }
@@ -546,9 +552,9 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *__restrict__ ag
 
 void launch_precond(const LaunchCtx &c, int sel, int max_n, int mode, int xb, int vb, int zb, int sp, int max_inner,
                     double step, int accel, int num_robots, int advance, int restart_interval, int ahead) {
-  // multiple of 8 (see the XCD-aware block order in k_precond); two-level agents run up to two workgroups more than
-  // pose pairs (padding of the separator / interior parts of their ownership order)
-  const int grid = (((4 * max_n + 7) / 8 + 2) + 7) / 8 * 8;
+  // multiple of 8 (see the XCD-aware block order in k_precond); two-level agents run a few workgroups more than pose
+  // pairs (every part of their ownership order is padded to an even number of slots)
+  const int grid = (std::max((4 * max_n + 7) / 8, c.tl_max_wg) + 7) / 8 * 8;
   // What this launch may meet: a host-selected agent is known; a device-selected one (schedule, colour class) may be
   // any agent of the team.  dn: largest agent that streams a DENSE inverse (0: none); tl: a two-level agent is possible.
   int dn = std::min(max_n, c.dense_max_n);

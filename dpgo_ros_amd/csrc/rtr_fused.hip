@@ -17,6 +17,7 @@
 // Eligibility (rtr_fused_eligible): dense preconditioner, ceil(n / 2) <= CUs, slab + scratch <= 160 KB of LDS.
 // Larger agents, block-Jacobi agents and the colour-parallel group update keep the launch-per-step path.
 #include "kernel_common.h"
+#include "twolevel_dev.h"
 
 namespace dpgo {
 
@@ -34,11 +35,11 @@ constexpr long long RB_TIMEOUT_TICKS = 50000000;  // 0.5 s of the 100 MHz wall c
 // No hand-off: every workgroup touches its own two poses only, and nothing here reads what the advance writes.
 template <int R>
 __device__ __forceinline__ void solve_tail(const AgentDev *__restrict__ agents, const AgentDev &ag, TeamDev *team, int tail,
-                                           int num_robots, int restart_interval, int bx, int npose, int tid) {
+                                           int num_robots, int restart_interval, int bx, int npose, int tid, int pj0, int pj1) {
   if (tid < 64) {
     double rel = 0;
     if (tid < npose) {
-      const size_t o = (size_t)(2 * bx + tid) * 4 * R;
+      const size_t o = (size_t)(tid ? pj1 : pj0) * 4 * R;
       double x[4 * R], xp[4 * R];
 #pragma unroll
       for (int i = 0; i < 4 * R; ++i) { x[i] = ag.buf[B_X][o + i]; xp[i] = ag.buf[B_XPREV][o + i]; }
@@ -65,7 +66,7 @@ __device__ __forceinline__ void solve_tail(const AgentDev *__restrict__ agents, 
   }
 }
 
-constexpr int RTR_WS_PITCH = 256;  // doubles per partial-sum array of the scratch (one entry per workgroup):
+constexpr int RTR_WS_PITCH = 512;  // doubles per partial-sum array of the scratch (one entry per workgroup):
                                    // [0] <delta, H delta>  [1] <z, r>  [2] <r, r>  [3..6] f, |grad|^2, <g, eta>, <eta, H eta>
 
 // optional per-phase timestamps of workgroup 0, wave 0 (build with -DDPGO_RTR_TRACE): bar[RB_TRACE + k]
@@ -135,21 +136,24 @@ __device__ __forceinline__ bool grid_sync(GridBar &gb, unsigned long long *tr = 
 }
 
 // sum of `count` contiguous partials published by the workgroups of THIS launch, same order in every wave
-template <int NA>
-__device__ __forceinline__ void csum_issue(const CVec &ws, int first, int count, int lane, double (*v)[4]) {
+// (CSUM_U partials per lane: 4 for the dense solve's <= 256 workgroups, 8 for the two-level solve's <= 512)
+template <int NA, int CSUM_U>
+__device__ __forceinline__ void csum_issue(const CVec &ws, int first, int count, int lane, double (*v)[CSUM_U]) {
   // straight-line (a predicated load is waited for on its own): entries beyond `count` re-read the last one, times 0
 #pragma unroll
   for (int q = 0; q < NA; ++q)
 #pragma unroll
-    for (int u = 0; u < 4; ++u) v[q][u] = ws.ld((first + q) * RTR_WS_PITCH + min(lane + 64 * u, count - 1));
+    for (int u = 0; u < CSUM_U; ++u) v[q][u] = ws.ld((first + q) * RTR_WS_PITCH + min(lane + 64 * u, count - 1));
 }
-template <int NA>
-__device__ __forceinline__ void csum_finish(double (*v)[4], int count, int lane, double *out) {
+template <int NA, int CSUM_U>
+__device__ __forceinline__ void csum_finish(double (*v)[CSUM_U], int count, int lane, double *out) {
 #pragma unroll
   for (int q = 0; q < NA; ++q) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) v[q][u] *= (lane + 64 * u < count) ? 1.0 : 0.0;
-    out[q] = wave_sum((v[q][0] + v[q][1]) + (v[q][2] + v[q][3]));
+    for (int u = 0; u < CSUM_U; ++u) v[q][u] *= (lane + 64 * u < count) ? 1.0 : 0.0;
+    double s = (v[q][0] + v[q][1]) + (v[q][2] + v[q][3]);
+    if constexpr (CSUM_U == 8) s += (v[q][4] + v[q][5]) + (v[q][6] + v[q][7]);
+    out[q] = wave_sum(s);
   }
 }
 
@@ -353,14 +357,128 @@ __device__ __forceinline__ void hess_tail_w(const double *Ysh, const double *Hc,
 }
 
 
+// ---- the two-level form of the preconditioner (twolevel.h) inside the persistent solve: the workgroup's slab -- rows
+// that meet the input vector (its subdomain's D_i, or -E_i of the adjacent subdomains for a workgroup that owns
+// separator poses), then the separator rows (W_i or Sc^-1) -- sits in LDS for the whole solve: 37 KB instead of the
+// 128 KB of a dense slab, which is what lets agents of 513 .. 1024 poses keep the one-launch solve (two workgroups per
+// CU).  An apply is twolevel_dev.h's product with the exchange carried by one more grid hand-off: the producers publish
+// u, everybody re-reads it.  Lane t takes row pairs t + 128 m; which rows of the vector they meet is fixed over the solve.
+// The two-level solve runs 128-thread workgroups: two of them share a CU with ONE wave per SIMD each, i.e. with the whole
+// register file the solve's gather phases need (two 256-thread workgroups per CU would halve it and spill).
+constexpr int TLS_NT = 128;
+constexpr int TLS_NPRE = 4, TLS_NPOST = 8;  // passes of 128 row pairs: subdomains of <= 256 poses, <= 512 separator poses
+struct TLLane {
+  int voff[TLS_NPRE];     // offset (doubles) of the pair's two rows in an r x 4n vector
+  double vlive[TLS_NPRE]; // 0 for lanes past the workgroup's rows
+};
+// the 128 per-lane sums of the 8R outputs -> zs (valid in both waves): quad reduction, 32 LDS rows, one lane per output
 template <int R>
-__global__ __launch_bounds__(256) void k_rtr_solve(const AgentDev *__restrict__ agents, int ai, unsigned long long *bar, double *ws,
+__device__ __forceinline__ void tls_reduce(double (*acc)[R], double *red, double *zs, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int a = 0; a < R; ++a) {
+      double x = acc[c][a];
+      x += dpp_move<0xB1>(x);
+      x += dpp_move<0x4E>(x);
+      acc[c][a] = x;
+    }
+  if ((lane & 3) == 0) {
+    double *row = red + (size_t)(wave * 16 + (lane >> 2)) * (8 * R + 1);
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+      for (int a = 0; a < R; ++a) row[c * R + a] = acc[c][a];
+  }
+  __syncthreads();
+  if (tid < 8 * R) {
+    double t[32];
+#pragma unroll
+    for (int q = 0; q < 32; ++q) t[q] = red[q * (8 * R + 1) + tid];
+    double s = 0;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) s += t[q];
+    zs[tid] = s;
+  }
+  __syncthreads();
+}
+template <int R>
+__device__ __forceinline__ bool tl_product_lds(const double *Ms, const TLDev &tl, const TLWg &w, int b, const TLLane &ln,
+                                               const CVec &V, GridBar &gb, double *red, double *zs, int tid) {
+  const int npre = 2 * w.pre_cnt, npost = 2 * tl.ns;
+  const bool producer = b < tl.nA;
+  double acc[8][R];
+  tl_zero<R>(acc);
+  double vown = 0;
+  if (producer && tid < 8 * R) {
+    const int lp = tid / (4 * R), own = w.own[lp];
+    if (own >= 0) vown = V.ld(own * 4 * R + (tid - lp * 4 * R));
+  }
+  // rows that meet the input vector: two passes per batch (every request of a batch in flight before its first product)
+#pragma unroll 1
+  for (int m0 = 0; m0 < TLS_NPRE && m0 * TLS_NT < npre; m0 += 2) {
+    double2 v[2][R];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int a = 0; a < R; ++a) v[u][a] = V.ld2(ln.voff[m0 + u] + 2 * a);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int qq = min(tid + TLS_NT * (m0 + u), max(npre - 1, 0));
+      double2 mm[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) mm[c] = *reinterpret_cast<const double2 *>(&Ms[(size_t)qq * 16 + 2 * c]);
+      tl_fma<R>(acc, v[u], mm, ln.vlive[m0 + u]);
+    }
+  }
+  if (npost == 0) {
+    tls_reduce<R>(acc, red, zs, tid);
+    return true;
+  }
+  if (producer) {
+    tls_reduce<R>(acc, red, zs, tid);
+    if (tid < 8 * R) {
+      const int lp = tid / (4 * R), e = tid - lp * 4 * R;
+      if (w.own[lp] >= 0) st_c(tl.u + ((size_t)(w.sep0 + lp) * 4 * R + e), vown + zs[tid]);
+    }
+    tl_zero<R>(acc);
+  }
+  if (!grid_sync(gb)) return false;
+  const CVec cu(tl.u, 4 * tl.ns * R);
+  const double *post = Ms + (size_t)npre * 16;
+#pragma unroll 1
+  for (int m0 = 0; m0 < TLS_NPOST && m0 * TLS_NT < npost; m0 += 2) {
+    double2 v[2][R];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int qq = min(tid + TLS_NT * (m0 + u), npost - 1);
+#pragma unroll
+      for (int a = 0; a < R; ++a) v[u][a] = cu.ld2(qq * 2 * R + 2 * a);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int q = tid + TLS_NT * (m0 + u), qq = min(q, npost - 1);
+      double2 mm[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) mm[c] = *reinterpret_cast<const double2 *>(&post[(size_t)qq * 16 + 2 * c]);
+      tl_fma<R>(acc, v[u], mm, q < npost ? 1.0 : 0.0);
+    }
+  }
+  tls_reduce<R>(acc, red, zs, tid);
+  return true;
+}
+
+// TL: the agent runs the two-level form of the preconditioner (slab layout and ownership of twolevel.h; up to two
+// workgroups per CU) instead of the dense inverse
+template <int R, bool TL>
+__global__ __launch_bounds__(TL ? TLS_NT : 256) void k_rtr_solve(const AgentDev *__restrict__ agents, int ai, unsigned long long *bar, double *ws,
                                                    unsigned long long *cum, RtrState *host_rec,
                                                    unsigned long long *host_cum, int *err, double Delta0, double tol, int max_outer, int max_inner,
                                                    double max_radius, TeamDev *team, int tail, int num_robots,
                                                    int restart_interval) {
   extern __shared__ double Ms[];  // [8][N4]: this workgroup's columns of M
-  __shared__ double red[64 * (8 * R + 1)];
+  __shared__ double red[(TL ? 32 : 64) * (8 * R + 1)];  // (the two-level solve runs 128 threads: 32 rows of partial sums)
   // own two poses, [pose][component c][row a]: X, Euclidean / Riemannian gradient at X; tCG residual, z, delta, eta;
   // scratch; candidate point and its gradients
   __shared__ double zs[8 * R], Xs[8 * R], Es[8 * R], Gs[8 * R], Rs[8 * R], Zo[8 * R], Ds[8 * R], Et[8 * R], Ws[8 * R],
@@ -371,11 +489,20 @@ __global__ __launch_bounds__(256) void k_rtr_solve(const AgentDev *__restrict__ 
   const AgentDev &ag = agents[ai];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bx = (int)blockIdx.x, N4 = ag.N4, n = ag.n;
-  const int nblk = (n + 1) / 2;  // == gridDim.x
-  const int npose = min(2, n - 2 * bx);
+  const int nblk = TL ? ag.tl.nwg - ag.tl.nS2 : (n + 1) / 2;  // == gridDim.x
+  // the two poses this workgroup owns: consecutive ones, or the pair the two-level layout assigns.  Two-level: the
+  // solve's workgroups are the layout's producers (one separator pose each: here they also take that pose's column of
+  // Sc^-1, which their slabs carry, TLDev::prod_post) and its interior workgroups; `tb` is the workgroup's index in the
+  // layout's tables (the nS2 workgroups that own the separator columns in a stand-alone apply are skipped)
+  TLWg tlw = {};
+  const int tb = (TL && bx >= ag.tl.nA) ? bx + ag.tl.nS2 : bx;
+  int pj0 = 2 * bx, pj1 = (2 * bx + 1 < n) ? 2 * bx + 1 : -1;
+  if constexpr (TL) { tlw = ag.tl.wg[tb]; pj0 = tlw.own[0]; pj1 = tlw.own[1]; }
+  const int npose = (pj1 >= 0) ? 2 : 1;
   const int lp = tid / R, a = tid - lp * R;
   const bool rl = tid < npose * R;  // row lanes: one per (own pose, row of the lifted pose), all in wave 0
-  const int j = 2 * bx + lp;
+  const int j = (lp == 1 && pj1 >= 0) ? pj1 : pj0;
+  constexpr int CSUM_U = TL ? 8 : 4;
   double *wsA = ws, *wsB0 = ws + RTR_WS_PITCH, *wsB1 = ws + 2 * RTR_WS_PITCH, *wsC = ws + 3 * RTR_WS_PITCH;
 
   // ---- trust-region set-up from the partial sums of the evaluation launched in front (k_rtr_begin)
@@ -397,7 +524,7 @@ __global__ __launch_bounds__(256) void k_rtr_solve(const AgentDev *__restrict__ 
       *host_rec = T;
       for (int k = 0; k < 4; ++k) host_cum[k] = cum[k];
     }
-    if (tail) solve_tail<R>(agents, ag, team, tail, num_robots, restart_interval, bx, npose, tid);
+    if (tail) solve_tail<R>(agents, ag, team, tail, num_robots, restart_interval, bx, npose, tid, pj0, pj1);
     return;
   }
   __shared__ int bar_ok;
@@ -415,8 +542,31 @@ __global__ __launch_bounds__(256) void k_rtr_solve(const AgentDev *__restrict__ 
 #endif
   RTR_STAMP(0);
 
-  // ---- the slab: 8 contiguous columns of M, HBM -> LDS, once
-  {
+  // ---- the slab, HBM -> LDS, once: the workgroup's slab of the two-level form ...
+  TLLane tln = {};
+  if constexpr (TL) {
+    const int cnt2 = (2 * tlw.pre_cnt + 2 * ag.tl.ns) * 8;  // double2 elements
+    const double *src = ag.tl.slabs + tlw.slab_off;
+    for (int base = 0; base < cnt2; base += 8 * TLS_NT) {
+      double2 t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = ld2_nt(src + 2 * (size_t)min(base + tid + TLS_NT * u, cnt2 - 1));
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = base + tid + TLS_NT * u;
+        if (i < cnt2) *reinterpret_cast<double2 *>(&Ms[2 * (size_t)i]) = t[u];
+      }
+    }
+    const int npre = 2 * tlw.pre_cnt;
+    const int *rp = ag.tl.rowpose + (size_t)tb * ag.tl.rp_stride;
+#pragma unroll
+    for (int m = 0; m < TLS_NPRE; ++m) {
+      const int q = tid + TLS_NT * m, qq = max(min(q, npre - 1), 0);
+      tln.voff[m] = (4 * rp[qq >> 1] + 2 * (qq & 1)) * R;
+      tln.vlive[m] = q < npre ? 1.0 : 0.0;
+    }
+  } else {
+    // ... or 8 contiguous columns of the dense M
     const int tot2 = 2 * npose * N4;  // double2 elements of the valid columns
     const double *Msrc = ag.M + (size_t)8 * bx * N4;
     // straight-line: 32 x 16 bytes per lane (N4 <= 2048), every request in flight before the first LDS store; indices
@@ -444,9 +594,10 @@ __global__ __launch_bounds__(256) void k_rtr_solve(const AgentDev *__restrict__ 
   const int ellw = ag.ell_w, Wc = min(ellw, RTR_SLOTS);
   const int tp0 = rl ? ag.trowptr[j] : 0, tp1 = rl ? ag.trowptr[j + 1] : 0;
   static_assert(2 * RTR_SLOTS * 16 == 256, "one thread per cached block element");
-  {
-    const int q = tid, pl = q / (RTR_SLOTS * 16), u = (q / 16) % RTR_SLOTS, e = q % 16;
-    const int jj = min(2 * bx + pl, n - 1);
+#pragma unroll
+  for (int q = tid; q < 2 * RTR_SLOTS * 16; q += (TL ? TLS_NT : 256)) {
+    const int pl = q / (RTR_SLOTS * 16), u = (q / 16) % RTR_SLOTS, e = q % 16;
+    const int jj = (pl == 1 && pj1 >= 0) ? pj1 : pj0;
     const bool have = pl < npose && u < Wc;
     BL[q] = have ? ag.ell_val[((size_t)u * n + jj) * 16 + e] : 0.0;
     if (e == 0) idxL[pl * RTR_SLOTS + u] = have ? ag.ell_col[(size_t)u * n + jj] : jj;
@@ -474,9 +625,13 @@ __global__ __launch_bounds__(256) void k_rtr_solve(const AgentDev *__restrict__ 
       // front of the acceptance test), so no hand-off stands between the acceptance and this product; GF itself
       // (own rows written through at the acceptance) serves the set-ups that follow a rejection, hand-offs later
       const CVec cSrc(__builtin_amdgcn_readfirstlane(gf_fresh) ? ag.buf[B_GF2] : GFg, NV8);
-      double2 vv[SLAB_MAXM][R];
-      slab_issue<R>(N4, cSrc, tid, vv);
-      slab_finish<R>(Ms, N4, vv, red, zs, tid);
+      if constexpr (TL) {
+        if (!tl_product_lds<R>(Ms, ag.tl, tlw, tb, tln, cSrc, gb, red, zs, tid)) return;
+      } else {
+        double2 vv[SLAB_MAXM][R];
+        slab_issue<R>(N4, cSrc, tid, vv);
+        slab_finish<R>(Ms, N4, vv, red, zs, tid);
+      }
     }
     {
       double zr = 0, rr = 0;
@@ -530,11 +685,11 @@ __global__ __launch_bounds__(256) void k_rtr_solve(const AgentDev *__restrict__ 
           rw[1][cp] = cB.ld(o);
         }
       };
-      double sv[2][4], sb[2];
-      csum_issue<2>(cWS, 1, nblk, lane, sv);
+      double sv[2][CSUM_U], sb[2];
+      csum_issue<2, CSUM_U>(cWS, 1, nblk, lane, sv);
       double rawA[RTR_SLOTS][2][4];
       if (wave == 0) gather_issue<2>(idxL + min(lp, 1) * RTR_SLOTS, ldA, rawA);
-      csum_finish<2>(sv, nblk, lane, sb);
+      csum_finish<2, CSUM_U>(sv, nblk, lane, sb);
       const double zr_new = sb[0], rr_new = sb[1];
       RTR_FINE(1);
       double beta = 0;
@@ -595,11 +750,11 @@ __global__ __launch_bounds__(256) void k_rtr_solve(const AgentDev *__restrict__ 
 
       // ---- part 2 (k_precond<PM_TCG_STEP>): alpha, boundary test, eta += alpha delta, r += alpha H delta,
       //      z += alpha P(H delta M)
-      double sv1[1][4], d_Hd;
-      csum_issue<1>(cWS, 0, nblk, lane, sv1);
-      double2 vv[SLAB_MAXM][R];
-      slab_issue<R>(N4, cHD, tid, vv);  // (speculative: the boundary test below needs the sum)
-      csum_finish<1>(sv1, nblk, lane, &d_Hd);
+      double sv1[1][CSUM_U], d_Hd;
+      csum_issue<1, CSUM_U>(cWS, 0, nblk, lane, sv1);
+      double2 vv[TL ? 1 : SLAB_MAXM][R];
+      if constexpr (!TL) slab_issue<R>(N4, cHD, tid, vv);  // (speculative: the boundary test below needs the sum)
+      csum_finish<1, CSUM_U>(sv1, nblk, lane, &d_Hd);
       RTR_FINE(10);
       const double alpha = S.z_r / d_Hd;
       const double e_Pe_new = S.e_Pe + 2.0 * alpha * S.e_Pd + alpha * alpha * S.d_Pd;
@@ -614,7 +769,11 @@ __global__ __launch_bounds__(256) void k_rtr_solve(const AgentDev *__restrict__ 
         break;
       }
       S.e_Pe = e_Pe_new; S.alpha = alpha; S.tcg_j += 1; S.pc_count += 1;
-      slab_finish<R>(Ms, N4, vv, red, zs, tid);
+      if constexpr (TL) {
+        if (!tl_product_lds<R>(Ms, ag.tl, tlw, tb, tln, cHD, gb, red, zs, tid)) return;
+      } else {
+        slab_finish<R>(Ms, N4, vv, red, zs, tid);
+      }
       RTR_FINE(11);
       {
         double zr = 0, rr = 0;
@@ -745,9 +904,9 @@ __global__ __launch_bounds__(256) void k_rtr_solve(const AgentDev *__restrict__ 
 
     // ================= acceptance test and radius update (k_rtr_accept; ROPTLIB SolversTR constants)
     {
-      double sv4[4][4], sc[4];
-      csum_issue<4>(cWS, 3, nblk, lane, sv4);
-      csum_finish<4>(sv4, nblk, lane, sc);
+      double sv4[4][CSUM_U], sc[4];
+      csum_issue<4, CSUM_U>(cWS, 3, nblk, lane, sv4);
+      csum_finish<4, CSUM_U>(sv4, nblk, lane, sc);
       const double f2 = sc[0], g2 = sc[1], ge = sc[2], eh = sc[3];
       const double rho = (S.f1 - f2) / (-ge - 0.5 * eh);
       const bool accept = rho > 0.1;
@@ -797,35 +956,59 @@ __global__ __launch_bounds__(256) void k_rtr_solve(const AgentDev *__restrict__ 
   if (tail) {
     // (the accepted point's own rows went to B_X with plain stores from this workgroup's row lanes)
     __syncthreads();
-    solve_tail<R>(agents, ag, team, tail, num_robots, restart_interval, bx, npose, tid);
+    solve_tail<R>(agents, ag, team, tail, num_robots, restart_interval, bx, npose, tid, pj0, pj1);
   }
 }
 
-static size_t rtr_static_lds(int r) {
-  return sizeof(double) * ((size_t)64 * (8 * r + 1) + 12 * 8 * r + 2 * RTR_SLOTS * 16) + sizeof(int) * 2 * RTR_SLOTS + 256;
+static size_t rtr_static_lds(int r, bool tl = false) {
+  return sizeof(double) * ((size_t)(tl ? 32 : 64) * (8 * r + 1) + 12 * 8 * r + 2 * RTR_SLOTS * 16) + sizeof(int) * 2 * RTR_SLOTS + 256;
 }
 
 size_t rtr_fused_lds_bytes(int r, int n) { return (size_t)64 * 4 * n + rtr_static_lds(r); }
 
 bool rtr_fused_eligible(int r, int n, int num_cus) {
-  if (n < 1 || (n + 1) / 2 > num_cus || (n + 1) / 2 > RTR_WS_PITCH || 4 * n > 2048) return false;
+  if (n < 1 || (n + 1) / 2 > num_cus || (n + 1) / 2 > 256 || 4 * n > 2048) return false;
   return (size_t)64 * 4 * n + rtr_static_lds(r) <= (size_t)160 * 1024;
+}
+
+// the same for an agent with the two-level preconditioner: nwg workgroups (separator / subdomain parts of the ownership
+// order, each padded to even), max_rows = the most rows (poses) any workgroup's slab meets before the exchange.  Two
+// workgroups share a CU where their LDS allows it, so agents of up to ~1000 poses stay in one launch.
+size_t rtr_fused_tl_lds_bytes(int r, int max_pre_poses, int ns) { return (size_t)128 * (2 * max_pre_poses + 2 * ns) + rtr_static_lds(r, true); }
+
+// row pairs (rows before the exchange + separator rows) a workgroup's slab may hold for two workgroups to share a CU
+int rtr_fused_tl_fit_pairs(int r) { return (int)(((size_t)80 * 1024 - rtr_static_lds(r, true)) / 128); }
+
+bool rtr_fused_tl_eligible(int r, int nwg, int max_pre_poses, int ns, int num_cus, int max_lds) {
+  if (nwg < 1 || nwg > RTR_WS_PITCH) return false;
+  if (2 * max_pre_poses > TLS_NT * TLS_NPRE || 2 * ns > TLS_NT * TLS_NPOST) return false;
+  const size_t lds = rtr_fused_tl_lds_bytes(r, max_pre_poses, ns);
+  if (lds > (size_t)max_lds) return false;
+  const int per_cu = (2 * lds <= (size_t)160 * 1024) ? 2 : 1;  // (128-thread workgroups: two per CU still run one wave per SIMD)
+  return nwg <= num_cus * per_cu;
 }
 
 int launch_rtr_solve(const LaunchCtx &c, int ai, int n, unsigned long long *bar, double *ws, unsigned long long *cum, RtrState *host_rec, unsigned long long *host_cum,
                      int *err, double Delta0, double tol, int max_outer, int max_inner, double max_radius, int tail,
-                     int num_robots, int restart_interval) {
-  const size_t dyn = (size_t)64 * 4 * n;  // 8 columns x N4 doubles
+                     int num_robots, int restart_interval, int tl_nwg, size_t tl_dyn) {
+  const size_t dyn = tl_nwg > 0 ? tl_dyn : (size_t)64 * 4 * n;  // the two-level slab, or 8 columns x N4 doubles
   hipError_t e = hipSuccess;
   DPGO_DISPATCH_R(c.r, {
     static bool configured = false;
     if (!configured) {
-      e = hipFuncSetAttribute((const void *)k_rtr_solve<R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)rtr_static_lds(R));
+      e = hipFuncSetAttribute((const void *)k_rtr_solve<R, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)rtr_static_lds(R));
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void *)k_rtr_solve<R, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)rtr_static_lds(R, true));
       configured = (e == hipSuccess);
     }
-    if (e == hipSuccess)
-      hipLaunchKernelGGL(k_rtr_solve<R>, dim3((n + 1) / 2), dim3(256), dyn, c.stream, c.agents, ai, bar, ws, cum, host_rec, host_cum, err, Delta0, tol,
-                         max_outer, max_inner, max_radius, c.team, tail, num_robots, restart_interval);
+    if (e == hipSuccess) {
+      if (tl_nwg > 0)
+        hipLaunchKernelGGL((k_rtr_solve<R, true>), dim3(tl_nwg), dim3(TLS_NT), dyn, c.stream, c.agents, ai, bar, ws, cum, host_rec, host_cum, err,
+                           Delta0, tol, max_outer, max_inner, max_radius, c.team, tail, num_robots, restart_interval);
+      else
+        hipLaunchKernelGGL((k_rtr_solve<R, false>), dim3((n + 1) / 2), dim3(256), dyn, c.stream, c.agents, ai, bar, ws, cum, host_rec, host_cum, err,
+                           Delta0, tol, max_outer, max_inner, max_radius, c.team, tail, num_robots, restart_interval);
+    }
   });
   return e == hipSuccess ? 0 : -1;
 }

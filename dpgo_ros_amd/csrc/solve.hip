@@ -138,14 +138,17 @@ int enqueue_optimize(dpgo_team *t, int sel, const OptFlags &fl) {
     t->counters[2] += hs->hv_count + 1 + hs->outer_count;
     t->counters[3] += (hs->hv_count + 1 + hs->outer_count) * spmm_bytes_of(t, a);
   };
-  if (t->use_fused_rtr && a.dev.M && rtr_fused_eligible(p.r, a.n, t->num_cus) && acquire_fused_rtr_lock(t) &&
-      rtr_fused_lds_bytes(p.r, a.n) <= (size_t)t->max_lds) {
+  const bool tl_fused = a.precond == DPGO_PRECOND_TWO_LEVEL && a.tl_plan.prod_post &&
+                        rtr_fused_tl_eligible(p.r, a.tl_plan.nwg - a.tl_plan.nS2, tl_max_pre_poses(a.tl_plan), a.tl_plan.ns, t->num_cus, t->max_lds);
+  const bool dense_fused = a.dev.M && rtr_fused_eligible(p.r, a.n, t->num_cus) && rtr_fused_lds_bytes(p.r, a.n) <= (size_t)t->max_lds;
+  if (t->use_fused_rtr && (dense_fused || tl_fused) && acquire_fused_rtr_lock(t)) {
     // one launch for the whole solve, the preconditioner resident in LDS (rtr_fused.hip): M leaves HBM once per solve.
     // The host does not wait for it: the kernel leaves the solve's record and the agent's running totals in pinned
     // host memory, read by refresh_rtr_result() whenever somebody asks (opt result, counters) -- except for the very first
     // solve on this device, which is checked at once so that a grid that is not resident at once (another process
     // running a persistent kernel on this GPU) is met with the launch-per-step sequence instead of an error.
-    if (a.rtr_bar_n != a.n) {
+    const int grid_key = tl_fused ? 100000000 + a.tl_plan.nwg - a.tl_plan.nS2 : a.n;  // the hand-off counters depend on the grid
+    if (a.rtr_bar_n != grid_key) {
       if (a.d_rtr_bar.alloc(RTR_BAR_WORDS) || a.d_rtr_ws.alloc(RTR_WS_DOUBLES) || a.h_rtr.alloc(1) || a.h_rtr_cum.alloc(4)) {
         set_err("RTR scratch allocation failed"); return DPGO_ERR;
       }
@@ -154,11 +157,12 @@ int enqueue_optimize(dpgo_team *t, int sel, const OptFlags &fl) {
         HIPC(hipMemsetAsync(a.d_rtr_cum.p, 0, sizeof(unsigned long long) * 4, t->stream));
       }
       HIPC(hipMemsetAsync(a.d_rtr_bar.p, 0, sizeof(unsigned long long) * RTR_BAR_WORDS, t->stream));
-      a.rtr_bar_n = a.n;
+      a.rtr_bar_n = grid_key;
     }
     if (launch_rtr_solve(c, sel, a.n, a.d_rtr_bar.p, a.d_rtr_ws.p, a.d_rtr_cum.p, a.h_rtr.p, a.h_rtr_cum.p, t->h_bar_err, p.rtr_initial_radius,
                          p.gradnorm_tol, p.rtr_iterations, p.rtr_tcg_iterations, p.rtr_max_radius, fl.rtr_tail, p.num_robots,
-                         p.restart_interval)) {
+                         p.restart_interval, tl_fused ? a.tl_plan.nwg - a.tl_plan.nS2 : 0,
+                         tl_fused ? (size_t)128 * (2 * tl_max_pre_poses(a.tl_plan) + 2 * a.tl_plan.ns) : 0)) {
       // (LDS attribute or launch refused on this device / partition mode: the launch-per-step sequence below serves)
       t->use_fused_rtr = 0;
       goto per_step;
@@ -290,10 +294,12 @@ int refresh_rtr_result(dpgo_team *t, Agent &a) {
   HIPC(hipStreamSynchronize(t->stream));
   a.opt_pending_rtr = false;
   if (*t->h_bar_err) {
+    const int code = *t->h_bar_err;  // 2 grid hand-off of the solve, 3 exchange of a two-level apply, 4 mailbox wait
     *t->h_bar_err = 0;
     t->use_fused_rtr = 0;
     a.rtr_bar_n = -1;
-    set_err("one-launch RTR solve: grid-wide hand-off timed out (the iterates since the last synchronisation are invalid)");
+    set_err("an in-kernel exchange timed out (code " + std::to_string(code) + ": 2 hand-off of the one-launch RTR solve, 3 two-level "
+            "preconditioner, 4 mailbox of the device-side token); the iterates since the last synchronisation are invalid");
     return DPGO_ERR;
   }
   const RtrState *hs = a.h_rtr.p;

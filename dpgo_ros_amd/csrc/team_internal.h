@@ -208,6 +208,7 @@ struct dpgo_team {
   int max_lds = 160 * 1024;  // hipDeviceAttributeMaxSharedMemoryPerBlock
   int dense_max_n = 0;  // largest agent with a dense inverse (sizes the LDS chunk of the preconditioner kernel)
   std::vector<int> precond_of;  // [local agent] the form each agent runs (selects the preconditioner kernel's variant)
+  int tl_max_wg = 0;            // most workgroups a two-level apply of this team runs
   int bake_sel = 1;  // DPGO_BAKE_SEL=0: the graphs of the pipelined iteration select their agent on the device only
   bool last_iteration_folded = false;  // ... and enqueue_team_iteration skipped k_nest_post / k_status / k_advance for it
   bool last_rtr_folded = false;  // the last enqueue_optimize ran the one-launch solve WITH the iteration's tail
@@ -226,6 +227,7 @@ struct dpgo_team {
     c.nest_all = d_nest_all.p;
     c.dense_max_n = dense_max_n;
     c.host_precond = precond_of.empty() ? nullptr : precond_of.data();
+    c.tl_max_wg = tl_max_wg;
     for (int k : precond_of) if (k == DPGO_PRECOND_TWO_LEVEL) c.any_two_level = true;
     return c;
   }
@@ -243,7 +245,7 @@ inline double precond_operator_bytes(const Agent &a) {
   if (a.precond == DPGO_PRECOND_BLOCK_JACOBI) return 128.0 * a.n;
   return 8.0 * 16.0 * (double)a.n * (double)a.n;
 }
-inline int precond_nblk(const Agent &a) { return a.precond == DPGO_PRECOND_TWO_LEVEL ? a.tl_plan.nwg : (4 * a.n + 7) / 8; }
+inline int precond_nblk(const Agent &a) { return a.precond == DPGO_PRECOND_TWO_LEVEL ? a.tl_plan.nwg - a.tl_plan.nA : (4 * a.n + 7) / 8; }
 
 // ---- assembly.hip
 Agent *find_agent(dpgo_team *t, int id);

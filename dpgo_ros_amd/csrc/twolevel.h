@@ -26,18 +26,21 @@ struct TLPlan {
   std::vector<std::vector<int>> adj_sep;   // per subdomain: separator positions (ascending) coupled to it
   std::vector<std::vector<int>> adj_sub;   // per separator pose: subdomains coupled to it (ascending)
   // workgroup layout of the apply: `order` lists the poses in ownership order (separator first, then subdomain by
-  // subdomain), padded with -1 so that the separator part holds an even number of slots; workgroup b owns slots
-  // 2b, 2b+1.  The first nA = ceil(ns / 2) workgroups own separator poses (they are dispatched first: every other
+  // subdomain), each part padded with -1 to an even number of slots; workgroup b owns slots 2b, 2b+1.  The first nA = ns workgroups own ONE separator pose each (they are dispatched first: every other
   // workgroup waits for what they publish, none of them waits for anybody).
   std::vector<int> order;
-  int nwg = 0, nA = 0;
+  int nwg = 0, nA = 0, nS2 = 0;             // workgroups; producers; workgroups that own the separator poses' columns
+  bool prod_post = false;                  // producers' slabs also hold their pose's column of Sc^-1 (one-launch RTR solve)
   double bytes = 0;                        // bytes one apply streams (slabs)
 };
 
 // rowptr / col: block-CSR pattern of Q (row j lists the poses coupled to j, the diagonal included).
 // max_sub <= 0: try a ladder of subdomain sizes and keep the plan that streams the fewest bytes.
-TLPlan tl_make_plan(int n, const std::vector<int> &rowptr, const std::vector<int> &col, int max_sub = 0);
+TLPlan tl_make_plan(int n, const std::vector<int> &rowptr, const std::vector<int> &col, int max_sub = 0, int fit_pairs = 0,
+                    int fit_wg = 0);
 // poses whose rows of the input vector enter workgroup b's product before the exchange (see twolevel_plan.cpp)
 std::vector<int> tl_pre_rows(const TLPlan &pl, int b);
+// the most poses any workgroup's slab meets before the exchange (sizes the LDS slab of the one-launch RTR solve)
+int tl_max_pre_poses(const TLPlan &pl);
 
 }  // namespace dpgo_host

@@ -131,9 +131,10 @@ __global__ __launch_bounds__(256) void k_tl_pack(const TLSetupAgent *ags, const 
   const int *rp = g.tl.rowpose + (size_t)b * g.tl.rp_stride;
   double *slab = g.slabs_rw + w.slab_off;
   const int npre = 2 * w.pre_cnt, NS4 = 4 * g.ns;
-  const bool sepwg = b < g.tl.nA;
+  const bool sepwg = b < g.tl.nA;                     // producer: rows of -E_i
+  const bool has_post = !sepwg || g.tl.prod_post;     // ... whose slab carries separator rows only for the one-launch solve
   const double *Sci = g.D + g.Doff[g.P];
-  // ---- rows that meet the input vector: D_i (interior workgroup) or -E_i (separator workgroup)
+  // ---- rows that meet the input vector: D_i (interior workgroup) or -E_i (producer)
   for (int x = threadIdx.x; x < npre * 16; x += 256) {
     const int t = x >> 4, c8 = (x >> 1) & 7, h = x & 1, lp = c8 >> 2, c = c8 & 3;
     const int own = w.own[lp], rpose = rp[t >> 1], rloc = 4 * g.lidx[rpose] + 2 * (t & 1) + h;
@@ -153,12 +154,12 @@ __global__ __launch_bounds__(256) void k_tl_pack(const TLSetupAgent *ags, const 
   }
   // ---- separator rows: Sc^-1 (separator workgroup) or W_i = -Sc^-1[:, adj_i] E_i^T (interior workgroup)
   double *post = slab + (size_t)npre * 16;
-  for (int y = threadIdx.x; y < NS4 * 8; y += 256) {
+  for (int y = threadIdx.x; has_post && y < NS4 * 8; y += 256) {
     const int srow = y % NS4, c8 = y / NS4, lp = c8 >> 2, c = c8 & 3;
     const int own = w.own[lp];
     double v = 0;
     if (own >= 0) {
-      if (sepwg) {
+      if (g.blk_of[own] == g.P) {  // a separator pose: its column of Sc^-1
         v = Sci[(size_t)(4 * g.lidx[own] + c) * NS4 + srow];
       } else {
         const int i = g.blk_of[own];
@@ -226,9 +227,10 @@ static TLHostLayout tl_layout(const TLPlan &pl) {
   for (int b = 0; b < pl.nwg; ++b) {
     TLWg &w = L.wg[b];
     w.own[0] = pl.order[2 * b]; w.own[1] = pl.order[2 * b + 1];
-    w.pre_cnt = (int)rows[b].size(); w.pad0 = 0; w.pad1 = 0;
+    w.pre_cnt = (int)rows[b].size(); w.pad1 = 0;
+    w.sep0 = (b < pl.nA && w.own[0] >= 0) ? pl.sep_index[w.own[0]] : 0;
     w.slab_off = (long long)L.slab_total;
-    L.slab_total += (size_t)16 * (2 * rows[b].size() + 2 * pl.ns);
+    L.slab_total += (size_t)16 * (2 * rows[b].size() + ((b >= pl.nA || pl.prod_post) ? 2 * pl.ns : 0));
     const int fill = w.own[0] >= 0 ? w.own[0] : 0;
     for (int q = 0; q < L.rp_stride; ++q) L.rowpose[(size_t)b * L.rp_stride + q] = q < (int)rows[b].size() ? rows[b][q] : fill;
   }
@@ -293,7 +295,7 @@ int tl_build(dpgo_team *t, const std::vector<Agent *> &agents) {
     off += 3 * L.d_total + L.e_total;
     g.P = P; g.ns = pl.ns; g.n = pl.n; g.pad = 0; g.shift = t->prm.precond_shift;
     TLDev &tl = a.dev.tl;
-    tl.ns = pl.ns; tl.nwg = pl.nwg; tl.nA = pl.nA; tl.rp_stride = L.rp_stride;
+    tl.ns = pl.ns; tl.nwg = pl.nwg; tl.nA = pl.nA; tl.rp_stride = L.rp_stride; tl.nS2 = pl.nS2; tl.prod_post = pl.prod_post ? 1 : 0;
     tl.wg = a.d_tl_wg.p; tl.rowpose = a.d_tl_rowpose.p; tl.slabs = a.d_tl_slabs.p; tl.u = a.d_tl_u.p;
     tl.flag = a.d_tl_flag.p; tl.err = t->h_bar_err;
     g.tl = tl; g.slabs_rw = a.d_tl_slabs.p;

@@ -3,12 +3,12 @@
 // for the 8 columns (2 poses) a workgroup owns.  Lane t takes row pair t (+256 m) of its workgroup's slab for ALL 8
 // columns -- 128 contiguous bytes per lane, stored in exactly that order by the set-up -- and the 2R matching entries of
 // the input vector (gathered through the workgroup's row-pose list) or of u.  The first nA workgroups of the launch own
-// the separator poses: they form u for their poses from the adjacent subdomains' rows, publish it (write-through stores,
-// one counter increment per workgroup) and only then turn to their own columns of Sc^-1.  Everybody else multiplies its
-// subdomain's rows by D_i while it waits for that counter, then adds the u rows.  Producers are the FIRST workgroups of
-// the grid and never wait for anybody, so the exchange cannot deadlock however many workgroups are resident at once
-// (a grid larger than the device simply finds the counter complete); the last workgroup past the exchange clears the
-// counters for the next launch.
+// one separator pose each: they form its entry of u from the adjacent subdomains' rows, publish it (write-through stores,
+// one counter increment per workgroup) and leave.  Everybody else multiplies its subdomain's rows by D_i while it waits
+// for that counter, then adds the u rows (the separator poses' own columns of Sc^-1 belong to the workgroups right
+// behind the producers).  Producers are the FIRST workgroups of the grid and wait for NOBODY, so the exchange cannot
+// deadlock however many workgroups are resident at once (a grid larger than the device simply finds the counter
+// complete); the last workgroup past the exchange clears the counters for the next launch.
 #pragma once
 #include "kernel_common.h"
 
@@ -97,10 +97,11 @@ __device__ __forceinline__ void tl_issue(const TLDev &tl, const TLWg &w, int b, 
 }
 
 // One apply for workgroup b of the launch (256 threads).  V: the input vector (r x 4n, written by an EARLIER launch).
-// On return zs[(4 lp + c) * R + a] holds column c of own pose lp (all waves may read it).
+// Returns false for a producer (it has published its entry of u and is done: no columns of its own); otherwise
+// zs[(4 lp + c) * R + a] holds column c of own pose lp on return (all waves may read it).
 // trace (TRACE builds of the step kernel): per-wave wall-clock stamps [wave][16], slots 1..5 written here
 template <int R, bool TRACE = false>
-__device__ __forceinline__ void tl_apply(const TLDev &tl, const TLWg &w, int b, const double *__restrict__ V, const TLPre<R> &pre,
+__device__ __forceinline__ bool tl_apply(const TLDev &tl, const TLWg &w, int b, const double *__restrict__ V, const TLPre<R> &pre,
                                          double *red, double *zs, int tid, double *trace = nullptr) {
 #define TL_STAMP(k) do { if (TRACE && trace && (tid & 63) == 0) trace[(tid >> 6) * 16 + (k)] = (double)wall_clock64(); } while (0)
   const int *rp = tl.rowpose + (size_t)b * tl.rp_stride;
@@ -109,14 +110,11 @@ __device__ __forceinline__ void tl_apply(const TLDev &tl, const TLWg &w, int b, 
   const bool producer = b < tl.nA;
   // a producer adds its own separator rows of the input vector to what the subdomains contribute: requested now
   double vown = 0;
-  if (producer && tid < 8 * R) {
-    const int lp = tid / (4 * R), own = w.own[lp];
-    if (own >= 0) vown = V[(size_t)own * 4 * R + (tid - lp * 4 * R)];
-  }
+  if (producer && tid < 4 * R && w.own[0] >= 0) vown = V[(size_t)w.own[0] * 4 * R + tid];
   const double *post = slab + (size_t)npre * 16;
   // the first pass of the separator rows is requested before the wait as well
   double2 mmP[8];
-  {
+  if (!producer) {
     const int qq = max(min(tid, npost - 1), 0);
 #pragma unroll
     for (int c = 0; c < 8; ++c) mmP[c] = ld2_nt(post + (size_t)qq * 16 + 2 * c);
@@ -139,56 +137,54 @@ __device__ __forceinline__ void tl_apply(const TLDev &tl, const TLWg &w, int b, 
   TL_STAMP(1);
   if (npost == 0) {  // no separator: the operator is block diagonal
     tl_reduce<R>(acc, red, zs, tid);
-    return;
+    return true;
   }
+  unsigned long long departed = 0;
   if (producer) {
-    // phase A: u of the own separator poses = v + (what the adjacent subdomains contribute), published for everybody:
-    // write-through stores, then one increment of every XCD's copy of the counter
+    // phase A: u of the own separator pose = v + (what the adjacent subdomains contribute), published for everybody:
+    // write-through stores, then one increment of every XCD's copy of the counter.  Producers wait for nobody.
     tl_reduce<R>(acc, red, zs, tid);
-    if (tid < 8 * R) {
-      const int lp = tid / (4 * R), e = tid - lp * 4 * R;
-      if (w.own[lp] >= 0) st_c(tl.u + ((size_t)(2 * b + lp) * 4 * R + e), vown + zs[tid]);
-    }
+    if (tid < 4 * R && w.own[0] >= 0) st_c(tl.u + ((size_t)w.sep0 * 4 * R + tid), vown + zs[tid]);
     if (tid < 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-through stores have left the CU
     __syncthreads();
     if (tid < 8) __hip_atomic_fetch_add(&tl.flag[TL_FLAG_PUB + 16 * tid], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    tl_zero<R>(acc);
     TL_STAMP(2);
-  }
-  // ---- the exchange: every producer has published (the workgroups of an XCD poll that XCD's copy of the counter)
-  if (tid == 0) {
-    const unsigned long long *f = &tl.flag[TL_FLAG_PUB + 16 * ((int)blockIdx.x & 7)];
-    int spins = 0;
-    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned long long)tl.nA) {
-      if (++spins > TL_SPIN_LIMIT) { *tl.err = 3; break; }
+    if (tid == 255) departed = __hip_atomic_fetch_add(&tl.flag[TL_FLAG_DONE], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    // ---- the exchange: every producer has published (the workgroups of an XCD poll that XCD's copy of the counter)
+    if (tid == 0) {
+      const unsigned long long *f = &tl.flag[TL_FLAG_PUB + 16 * ((int)blockIdx.x & 7)];
+      int spins = 0;
+      while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned long long)tl.nA) {
+        if (++spins > TL_SPIN_LIMIT) { *tl.err = 3; break; }
+      }
     }
-  }
-  __syncthreads();
-  TL_STAMP(3);
-  unsigned long long departed = 0;
-  if (tid == 255) departed = __hip_atomic_fetch_add(&tl.flag[TL_FLAG_DONE], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  // ---- separator rows: u.  Written once per launch, by write-through stores, before the counter moved, and never
-  // read by anybody in this launch before that: ordinary loads (the L2 of this XCD fetches each line once for all its
-  // workgroups; caches start a launch invalidated)
-  {
-    const int qq = min(tid, npost - 1);
-    double2 v[R];
+    __syncthreads();
+    TL_STAMP(3);
+    if (tid == 255) departed = __hip_atomic_fetch_add(&tl.flag[TL_FLAG_DONE], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // ---- separator rows: u.  Written once per launch, by write-through stores, before the counter moved, and never
+    // read by anybody in this launch before that: ordinary loads (the L2 of this XCD fetches each line once for all its
+    // workgroups; caches start a launch invalidated)
+    {
+      const int qq = min(tid, npost - 1);
+      double2 v[R];
 #pragma unroll
-    for (int a = 0; a < R; ++a) v[a] = ld2(tl.u + (size_t)qq * 2 * R + 2 * a);
-    tl_fma<R>(acc, v, mmP, tid < npost ? 1.0 : 0.0);
-  }
-  for (int q0 = 256; q0 < npost; q0 += 256) {
-    const int q = q0 + tid, qq = min(q, npost - 1);
-    double2 v[R], mm[8];
+      for (int a = 0; a < R; ++a) v[a] = ld2(tl.u + (size_t)qq * 2 * R + 2 * a);
+      tl_fma<R>(acc, v, mmP, tid < npost ? 1.0 : 0.0);
+    }
+    for (int q0 = 256; q0 < npost; q0 += 256) {
+      const int q = q0 + tid, qq = min(q, npost - 1);
+      double2 v[R], mm[8];
 #pragma unroll
-    for (int a = 0; a < R; ++a) v[a] = ld2(tl.u + (size_t)qq * 2 * R + 2 * a);
+      for (int a = 0; a < R; ++a) v[a] = ld2(tl.u + (size_t)qq * 2 * R + 2 * a);
 #pragma unroll
-    for (int c = 0; c < 8; ++c) mm[c] = ld2_nt(post + (size_t)qq * 16 + 2 * c);
-    tl_fma<R>(acc, v, mm, q < npost ? 1.0 : 0.0);
+      for (int c = 0; c < 8; ++c) mm[c] = ld2_nt(post + (size_t)qq * 16 + 2 * c);
+      tl_fma<R>(acc, v, mm, q < npost ? 1.0 : 0.0);
+    }
+    TL_STAMP(4);
+    tl_reduce<R>(acc, red, zs, tid);
+    TL_STAMP(5);
   }
-  TL_STAMP(4);
-  tl_reduce<R>(acc, red, zs, tid);
-  TL_STAMP(5);
   // the last workgroup past the exchange clears the counters for the next launch on this agent
   if (tid == 255 && departed + 1ull == (unsigned long long)tl.nwg) {
 #pragma unroll
@@ -196,6 +192,7 @@ __device__ __forceinline__ void tl_apply(const TLDev &tl, const TLWg &w, int b, 
     __hip_atomic_store(&tl.flag[TL_FLAG_DONE], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 #undef TL_STAMP
+  return !producer;
 }
 
 }  // namespace dpgo

@@ -164,16 +164,30 @@ TLPlan finish_plan(const Graph &g, Dissection d) {
     a.erase(std::unique(a.begin(), a.end()), a.end());
     for (int s : a) pl.adj_sub[s].push_back((int)i);
   }
-  // ownership order: separator (padded to an even count), then the subdomains
+  // Workgroups of an apply, in launch order (workgroup b owns slots 2b, 2b+1 of `order`):
+  //   [0, nA)          PRODUCERS, one per separator pose: they form that pose's entry of u from the subdomains adjacent
+  //                    to it, publish it and leave -- they never wait for anybody, so whatever part of the grid is
+  //                    resident the exchange completes (a producer that waited for the other producers could starve
+  //                    them of the slots they need: 636 producers on cubicle as one agent, ~512 resident);
+  //   [nA, nA + nS2)   the separator poses again, two per workgroup: their columns of Sc^-1 against u (no rows before
+  //                    the exchange);
+  //   the rest         the subdomains, each padded to an even number of slots (no workgroup straddles two of them).
+  for (int v : pl.sep) { pl.order.push_back(v); pl.order.push_back(-1); }
+  pl.nA = (int)pl.order.size() / 2;
   for (int v : pl.sep) pl.order.push_back(v);
   if (pl.order.size() & 1) pl.order.push_back(-1);
-  pl.nA = (int)pl.order.size() / 2;
-  for (auto &s : pl.sub) for (int v : s) pl.order.push_back(v);
-  if (pl.order.size() & 1) pl.order.push_back(-1);
+  pl.nS2 = (int)pl.order.size() / 2 - pl.nA;
+  for (auto &s : pl.sub) {
+    for (int v : s) pl.order.push_back(v);
+    if (pl.order.size() & 1) pl.order.push_back(-1);
+  }
   pl.nwg = (int)pl.order.size() / 2;
-  // bytes of one apply: per workgroup (rows before the exchange + separator rows) x 8 columns x 8 bytes
+  // the one-launch RTR solve (rtr_fused.hip) runs producers that also own their pose's column of Sc^-1: their slabs
+  // carry it where such a solve is possible at all (<= 512 workgroups, <= 512 separator poses)
+  pl.prod_post = pl.ns > 0 && pl.ns <= 512 && pl.nwg - pl.nS2 <= 512;
+  // bytes of one apply: per workgroup (rows before the exchange [+ separator rows]) x 8 columns x 8 bytes
   double rows = 0;
-  for (int b = 0; b < pl.nwg; ++b) rows += 4.0 * (tl_pre_rows(pl, b).size() + pl.ns);
+  for (int b = 0; b < pl.nwg; ++b) rows += 4.0 * (tl_pre_rows(pl, b).size() + (b < pl.nA ? 0 : pl.ns));
   pl.bytes = rows * 8 * 8;
   return pl;
 }
@@ -185,6 +199,7 @@ TLPlan finish_plan(const Graph &g, Dissection d) {
 // of its own poses
 std::vector<int> tl_pre_rows(const TLPlan &pl, int b) {
   std::vector<int> subs;
+  if (b >= pl.nA && b < pl.nA + pl.nS2) return {};  // separator poses, consumer side: u rows only
   for (int q = 0; q < 2; ++q) {
     const int v = pl.order[2 * b + q];
     if (v < 0) continue;
@@ -198,8 +213,22 @@ std::vector<int> tl_pre_rows(const TLPlan &pl, int b) {
   return rows;
 }
 
-TLPlan tl_make_plan(int n, const std::vector<int> &rowptr, const std::vector<int> &col, int max_sub) {
+int tl_max_pre_poses(const TLPlan &pl) {
+  // (no workgroup straddles two subdomains: an interior workgroup meets its subdomain, a separator workgroup the
+  // subdomains adjacent to its two poses)
+  size_t mx = 0;
+  for (const auto &s : pl.sub) mx = std::max(mx, s.size());
+  for (int b = 0; b < pl.nA; ++b) mx = std::max(mx, tl_pre_rows(pl, b).size());
+  return (int)mx;
+}
+
+TLPlan tl_make_plan(int n, const std::vector<int> &rowptr, const std::vector<int> &col, int max_sub, int fit_pairs, int fit_wg) {
   const Graph g{n, rowptr, col};
+  // fit_pairs / fit_wg > 0: among the ladder's plans prefer those whose largest slab (row pairs) and solve grid fit the
+  // one-launch RTR solve (two workgroups per CU), fewest bytes among them; none fits: fewest bytes overall
+  auto fits = [&](const TLPlan &pl) {
+    return fit_pairs > 0 && pl.prod_post && 2 * (tl_max_pre_poses(pl) + pl.ns) <= fit_pairs && pl.nwg - pl.nS2 <= fit_wg;
+  };
   if (max_sub > 0) {
     Dissection d = dissect(g, max_sub);
     thin(g, d, max_sub);
@@ -216,7 +245,8 @@ TLPlan tl_make_plan(int n, const std::vector<int> &rowptr, const std::vector<int
     Dissection d = dissect(g, ms);
     thin(g, d, ms);
     TLPlan pl = finish_plan(g, std::move(d));
-    if (!have || pl.bytes < best.bytes) { best = std::move(pl); have = true; }
+    const bool f_new = fits(pl), f_old = have && fits(best);
+    if (!have || (f_new && !f_old) || (f_new == f_old && pl.bytes < best.bytes)) { best = std::move(pl); have = true; }
     if (ms <= 4) break;
   }
   return best;

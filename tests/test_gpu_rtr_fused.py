@@ -113,3 +113,45 @@ def test_graphs_with_the_schedule_baked_in_equal_the_device_selected_ones():
         X.append(np.array([s.relative_change for s in st]))
         t.close()
     assert np.array_equal(X[0], X[2]) and np.array_equal(X[1], X[3])
+
+
+@pytest.mark.parametrize("dataset,N,r,accel,mode", [
+    ("torus3D", 8, 5, 1, capi.PRECOND_AUTO),        # 625-pose agents: too large for the dense slabs, automatic mode -> two-level
+    ("sphere2500", 5, 5, 0, capi.PRECOND_TWO_LEVEL),
+    ("sphere2500", 4, 3, 1, capi.PRECOND_AUTO),     # 625-pose agents, rank 3
+    ("smallGrid3D", 2, 8, 1, capi.PRECOND_TWO_LEVEL),
+])
+def test_one_launch_solve_with_the_two_level_preconditioner(dataset, N, r, accel, mode):
+    """agents whose 8-column slabs of the dense inverse do not fit LDS (more than 512 poses) keep the solve in ONE launch
+    with the two-level form of the preconditioner resident in LDS instead (rtr_fused.hip, k_rtr_solve<R, true>: 128-thread
+    workgroups, two per CU, one more grid hand-off per apply): the oracle's tCG / acceptance counts and iterates, and the
+    launch-per-step sequence's"""
+    iters = 2 * N
+    kw = dict(method=capi.METHOD_RTR, acceleration=accel, restart_interval=5, gradnorm_tol=1e-2, rtr_iterations=3,
+              rtr_tcg_iterations=12, precond_mode=mode)
+    m, mp, n = load(dataset, N)
+    ph, po = params_pair(r=r, num_robots=N, **kw)
+    po.precond_mode = 0
+    T, Y = O.odometry_init(m, n), O.fixed_stiefel(r)
+    tf, ts = _team(mp, ph, True), _team(mp, ph, False)
+    to = O.Team(mp, n, po)
+    for t in (tf, ts, to):
+        t.set_initial(T, Y)
+    assert all(a.preconditioner() == capi.PRECOND_TWO_LEVEL for a in tf.agents.values())
+    # one team at a time on the device: the one-launch solve is a persistent kernel whose workgroups wait for each other
+    # (two per CU here), and a second stream's launches in between can keep part of its grid from becoming resident
+    tf.run(iters)
+    tf.synchronize()
+    ts.run(iters)
+    for _ in range(iters):
+        to.iterate()
+    assert _handoffs(tf, 0) > 0 and _handoffs(ts, 0) == 0
+    scale = max(1.0, np.abs(to.global_X()).max())
+    assert np.abs(tf.global_X() - ts.global_X()).max() < 1e-8 * scale
+    assert np.abs(tf.global_X() - to.global_X()).max() < 1e-7 * scale
+    assert abs(tf.cost() - to.cost()) <= 1e-9 * abs(to.cost())
+    for a in range(N):
+        rf, ro = tf.agents[a].opt_result(), to.agents[a].opt_result()
+        assert (rf.rtr_outer_iters, rf.tcg_iters_total, rf.accepted) == (ro.rtr_outer_iters, ro.tcg_iters_total, ro.accepted)
+    tf.close()
+    ts.close()
