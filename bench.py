@@ -112,12 +112,12 @@ def single_gpu(args):
     ttl.synchronize()
     torch.cuda.synchronize()
     tl_ms = (time.perf_counter() - a0) / (reps * args.steps) * 1e3
-    rtl = roofline_leg(ttl, 1)
+    rtl = roofline_leg(ttl, 1, "two_level")
     info = ttl.agents[1].preconditioner_info()
     roof["two_level_form"] = {"ms_per_step": tl_ms, "bytes_per_apply": info["bytes_per_apply"], "dense_bytes": info["dense_bytes"],
                               "subdomains": info["subdomains"], "separator_poses": info["separator_poses"],
-                              "step_kernel": {k: rtl[k] for k in ("bytes_per_launch", "us_per_launch", "achieved", "frac")},
-                              "apply_only": {k: rtl["apply_only"][k] for k in ("bytes_per_launch", "us_per_launch", "achieved", "frac")},
+                              "step_kernel": {k: rtl[k] for k in ("bytes_per_launch", "us_per_launch", "achieved", "frac", "traffic")},
+                              "apply_only": {k: rtl["apply_only"][k] for k in ("bytes_per_launch", "us_per_launch", "achieved", "frac", "traffic")},
                               "cost_after_run": ttl.cost(),
                               "note": "precond_mode = 3 on the same workload; bytes_per_launch = the slabs one apply streams "
                                       "+ the vectors; see profiles/r03_precond_forms_by_size.md for the crossover by agent size"}
@@ -383,7 +383,14 @@ def gnc_leg(capi):
             "cost_rel_diff": abs(res["gpu"]["cost"] - res["cpu"]["cost"]) / abs(res["cpu"]["cost"])}
 
 
-def roofline_leg(team, agent_id):
+# HBM traffic per launch (KB) from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in
+# separate runs of this command, profiles/collect.sh; FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md)
+PMC = {"source": "profiles/r03_pmc_fetch.md, profiles/r03_pmc_write.md",
+       "dense": {"step": (16561.6, 835.7), "apply": (16081.1, 85.9)},      # k_precond<5,3,2048,false>, k_precond<5,0,2048,false>
+       "two_level": {"step": (5501.4, 903.6), "apply": (4945.2, 125.3)}}   # k_precond<5,3,0,true>,     k_precond<5,0,0,true>
+
+
+def roofline_leg(team, agent_id, form="dense"):
     """HIP events on the team stream.  Top level: the dominant kernel of the timed loop, k_precond<5,PM_RGD>
     (preconditioner stream + RGD step + Nesterov V + look-ahead Nesterov step of all agents), timed inside the running
     pipelined iteration with an event pair around every launch (the sequence consumes the team's state, so this runs
@@ -400,14 +407,14 @@ def roofline_leg(team, agent_id):
     # with profiles/collect.sh.
     roof = {"kernel": "k_precond<5,PM_RGD> (fused step kernel of the timed loop)", "bound": "hbm",
             "achieved": f_bytes / (f_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-            "traffic": (2 * 16558.4 + 826.7) * 1024, "traffic_source": "profiles/r02_pmc_fetch.md, profiles/r02_pmc_write.md",
+            "traffic": (2 * PMC[form]["step"][0] + PMC[form]["step"][1]) * 1024, "traffic_source": PMC["source"],
             "bytes_per_launch": f_bytes, "us_per_launch": f_ms * 1e3, "us_per_launch_back_to_back": b_ms * 1e3,
             "timing_note": "HIP events around 500 eager pipelined iterations (%.2f us each) minus the same around 500 "
                            "k_eval_stats launches alone (%.2f us each): the dispatch-to-dispatch time of the step kernel"
                            % (it_ms * 1e3, e_ms * 1e3),
             "apply_only": {"kernel": "k_precond<5,PM_PLAIN>", "bytes_per_launch": p_bytes, "us_per_launch": p_ms * 1e3,
                            "achieved": p_bytes / (p_ms * 1e-3) / 1e9, "frac": p_bytes / (p_ms * 1e-3) / 1e9 / 8000.0,
-                           "traffic": (2 * 16071.1 + 85.9) * 1024},
+                           "traffic": (2 * PMC[form]["apply"][0] + PMC[form]["apply"][1]) * 1024},
             "spmm_eval": {"kernel": "k_eval<5>", "bytes_per_launch": s_bytes, "us_per_launch": s_ms * 1e3,
                           "achieved": s_bytes / (s_ms * 1e-3) / 1e9}}
     roof["frac"] = roof["achieved"] / roof["peak"]

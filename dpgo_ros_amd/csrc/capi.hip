@@ -1,4 +1,6 @@
 // capi.hip -- the extern "C" entry points of libdpgo_hip.so (contract: include/dpgo_hip.h).
+#include <unistd.h>
+
 #include <atomic>
 #include <chrono>
 
@@ -79,6 +81,7 @@ void dpgo_team_destroy(dpgo_team_t *t) {
   (void)hipSetDevice(t->device);
   (void)hipStreamSynchronize(t->stream);
   release_fused_rtr_lock(t);
+  if (t->rtr_lock_fd >= 0) { ::close(t->rtr_lock_fd); t->rtr_lock_fd = -1; }
   for (auto &kv : t->graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);
   for (auto &kv : t->peers) if (kv.second.base) (void)hipIpcCloseMemHandle(kv.second.base);
   for (void *p : t->mail_handles) if (p) (void)hipIpcCloseMemHandle(p);
@@ -95,6 +98,7 @@ int dpgo_team_num_local(const dpgo_team_t *t) { return (int)t->ag.size(); }
 void *dpgo_team_stream(dpgo_team_t *t) { return (void *)t->stream; }
 int dpgo_team_synchronize(dpgo_team_t *t) {
   HIPC(hipStreamSynchronize(t->stream));
+  release_fused_rtr_lock(t);
   for (auto &a : t->ag) if (a->opt_pending_rtr && refresh_rtr_result(t, *a)) return DPGO_ERR;
   if (t->h_bar_err && *t->h_bar_err) {
     *t->h_bar_err = 0;
@@ -329,6 +333,7 @@ static int report_after_iterate(dpgo_team_t *t, Agent *a, bool did_opt, bool adv
   t->counters[5] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tq0).count();
   t->counters[6] += 1;
   for (auto &b : t->ag) b->up_pending = false;  // this team's stream has drained past every upload enqueued before
+  release_fused_rtr_lock(t);                    // ... and past any one-launch solve
   const double *out = a->h_down.p, *pub = out + 8;
   if (npub) {
     size_t off = 0;

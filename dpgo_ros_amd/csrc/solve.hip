@@ -18,31 +18,31 @@ static std::mutex g_rtr_mu;
 static std::map<int, dpgo_team *> g_rtr_owner;  // device -> the team of THIS process that holds the lock
 
 bool acquire_fused_rtr_lock(dpgo_team *t) {
-  if (t->rtr_lock_state >= 0) return t->rtr_lock_state == 1;
+  if (t->rtr_lock_state == 1) return true;  // (held since an earlier solve that nobody has waited for yet)
   std::lock_guard<std::mutex> g(g_rtr_mu);
-  t->rtr_lock_state = 0;
-  if (g_rtr_owner.count(t->device)) return false;  // another team of this process
+  if (g_rtr_owner.count(t->device)) return false;  // another team of this process has a solve in flight
   // across processes: an advisory lock keyed by the device's PCI bus id (the same GPU whatever the visible-device order)
-  char bus[64] = "unknown";
-  (void)hipDeviceGetPCIBusId(bus, sizeof bus, t->device);
-  for (char *c = bus; *c; ++c) if (*c == ':' || *c == '.' || *c == '/') *c = '_';
-  const std::string path = std::string("/dev/shm/dpgo_hip_rtr_") + bus + ".lock";
-  const int fd = ::open(path.c_str(), O_CREAT | O_RDWR, 0666);
-  if (fd >= 0) {
-    if (::flock(fd, LOCK_EX | LOCK_NB) != 0) { ::close(fd); return false; }  // another process runs it on this GPU
-    t->rtr_lock_fd = fd;
-  }  // (no /dev/shm: the in-process rule alone)
+  if (t->rtr_lock_fd < 0) {
+    char bus[64] = "unknown";
+    (void)hipDeviceGetPCIBusId(bus, sizeof bus, t->device);
+    for (char *c = bus; *c; ++c) if (*c == ':' || *c == '.' || *c == '/') *c = '_';
+    const std::string path = std::string("/dev/shm/dpgo_hip_rtr_") + bus + ".lock";
+    t->rtr_lock_fd = ::open(path.c_str(), O_CREAT | O_RDWR, 0666);  // (no /dev/shm: the in-process rule alone)
+  }
+  if (t->rtr_lock_fd >= 0 && ::flock(t->rtr_lock_fd, LOCK_EX | LOCK_NB) != 0) return false;  // another process runs one on this GPU
   g_rtr_owner[t->device] = t;
   t->rtr_lock_state = 1;
   return true;
 }
 
+// called wherever the team's stream is known to have drained (nothing of this team is in flight any more)
 void release_fused_rtr_lock(dpgo_team *t) {
+  if (t->rtr_lock_state != 1) return;
   std::lock_guard<std::mutex> g(g_rtr_mu);
   auto it = g_rtr_owner.find(t->device);
   if (it != g_rtr_owner.end() && it->second == t) g_rtr_owner.erase(it);
-  if (t->rtr_lock_fd >= 0) { (void)::flock(t->rtr_lock_fd, LOCK_UN); ::close(t->rtr_lock_fd); t->rtr_lock_fd = -1; }
-  t->rtr_lock_state = -1;
+  if (t->rtr_lock_fd >= 0) (void)::flock(t->rtr_lock_fd, LOCK_UN);
+  t->rtr_lock_state = 0;
 }
 
 // share of loop closures whose GNC weight has converged to 0 or 1 (robustOptMinConvergenceRatio,
@@ -172,6 +172,7 @@ int enqueue_optimize(dpgo_team *t, int sel, const OptFlags &fl) {
     a.opt_pending_rgd = false;
     if (t->rtr_validated) return 0;
     HIPC(hipStreamSynchronize(t->stream));
+    release_fused_rtr_lock(t);
     if (!*t->h_bar_err) {
       t->rtr_validated = true;
       return refresh_rtr_result(t, a);
@@ -292,6 +293,7 @@ int enqueue_iterate(dpgo_team *t, int li, int do_opt, bool defer_advance) {
 int refresh_rtr_result(dpgo_team *t, Agent &a) {
   if (!a.opt_pending_rtr) return 0;
   HIPC(hipStreamSynchronize(t->stream));
+  release_fused_rtr_lock(t);
   a.opt_pending_rtr = false;
   if (*t->h_bar_err) {
     const int code = *t->h_bar_err;  // 2 grid hand-off of the solve, 3 exchange of a two-level apply, 4 mailbox wait

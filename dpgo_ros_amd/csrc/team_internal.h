@@ -215,10 +215,11 @@ struct dpgo_team {
   bool rtr_validated = false;  // a one-launch solve has completed on this device (its grid is resident at once)
   int use_fused_rtr = 1;  // DPGO_FUSED_RTR=0 keeps the launch-per-step RTR sequence (solve.hip) for every agent
   // The one-launch solve is a persistent kernel whose workgroups wait for each other: two such grids on one device
-  // (two teams, two processes) can each hold half the CUs and starve.  Only the team that holds the device's lock --
-  // one per device across processes (flock on a file under /dev/shm) and across the teams of this process -- launches
-  // it; everybody else runs the launch-per-step sequence.  -1: not asked yet, 0: somebody else has it, 1: ours.
-  int rtr_lock_state = -1;
+  // (two teams, two processes) can each hold half the CUs and starve.  A team launches it only while it holds the
+  // device's lock -- one holder per device across processes (flock on a file under /dev/shm) and across the teams of
+  // this process --, taken at the launch and given back wherever the team's stream is known to have drained; a solve
+  // that does not get the lock runs the launch-per-step sequence.  1: held.
+  int rtr_lock_state = 0;
   int rtr_lock_fd = -1;
   unsigned long long epoch = 1;  // bumped by everything that enqueues device work (every launch goes through ctx())
   dpgo::LaunchCtx ctx() {
