@@ -267,6 +267,13 @@ int finalize_agent(dpgo_team *t, Agent &a, double *scratch) {
   }
   const bool dense = a.precond == DPGO_PRECOND_DENSE;
   const bool fresh_vec = a.d_vec.n < len * NBUF;
+  if (fresh_vec && a.exported && a.d_vec.p) {
+    // other processes read this agent's poses in place through an IPC mapping of these arrays (dpgo_agent_export_state):
+    // re-allocating them would leave the importers with a dangling mapping
+    set_err("agent " + std::to_string(a.id) + ": its pose count grew after its arrays were exported over IPC; create the team "
+            "with all measurements before dpgo_agent_export_state");
+    return DPGO_ERR;
+  }
   if (a.d_rowptr.upload(a.rowptr, s) || a.d_col.upload(a.col, s) || a.d_qval.upload(a.qval, s) ||
       a.d_pub_pose.upload(pub_pose, s) || a.d_pub_ptr.upload(pub_ptr, s) || a.d_se.upload(se, s) ||
       a.d_edges.upload(edges, s) || a.d_vec.alloc(len * NBUF) || a.d_nbr.alloc(2 * a.np.size() * 4 * r) ||

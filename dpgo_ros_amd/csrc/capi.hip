@@ -1323,6 +1323,7 @@ int dpgo_agent_export_state(dpgo_team_t *t, int id, unsigned char *handle64, lon
   hipIpcMemHandle_t h;
   HIPC(hipIpcGetMemHandle(&h, a->d_vec.p));
   std::memcpy(handle64, &h, 64);
+  a->exported = true;
   *offset_x = a->dev.buf[B_X] - a->d_vec.p;
   *offset_y = a->dev.buf[B_Y] - a->d_vec.p;
   *n = a->n;

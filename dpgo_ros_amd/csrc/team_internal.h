@@ -91,6 +91,7 @@ struct Agent {
   int iter = 0, instance = 0;
   bool publish_requested = false;
   bool has_X = false;
+  bool exported = false;  // its X / Y arrays were handed to other processes (IPC): they must not move any more
   double mu = 0;
   int weight_update_count = 0, robust_inner_iter = 0;
   dpgo_opt_result_t opt{};
