@@ -329,6 +329,14 @@ int finalize_agent(dpgo_team *t, Agent &a, double *scratch) {
     for (auto &kv : a.d_pubframes) { const std::vector<int> fr = public_ids(a, kv.first); all.insert(all.end(), fr.begin(), fr.end()); }
     a.n_pub_all = (int)all.size();
     if (a.d_pub_all.upload(all, s)) { set_err("index upload failed"); return DPGO_ERR; }
+    // where each public pose goes in that packed list (k_iterate_false writes the report pose by pose)
+    std::vector<int> pp_ptr(pub_pose.size() + 1, 0), pp;
+    for (size_t q = 0; q < pub_pose.size(); ++q) {
+      for (size_t p = 0; p < all.size(); ++p) if (all[p] == pub_pose[q]) pp.push_back((int)p);
+      pp_ptr[q + 1] = (int)pp.size();
+    }
+    if (pp.empty()) pp.push_back(0);
+    if (a.d_pubpos_ptr.upload(pp_ptr, s) || a.d_pubpos.upload(pp, s)) { set_err("index upload failed"); return DPGO_ERR; }
     max_xfer = std::max(max_xfer, 2 * all.size());
   }
   if (a.d_xfer.alloc(max_xfer * 4 * r)) { set_err("device allocation failed"); return DPGO_ERR; }

@@ -212,7 +212,7 @@ int dpgo_agent_get_public_poses(dpgo_team_t *t, int id, int nbr, int aux, double
   Agent *a = find_agent(t, id);
   if (!a) return DPGO_ERR;
   if (!a->has_X) return DPGO_NOT_READY;
-  if (sync_descs(t)) return DPGO_ERR;
+  if (sync_descs_noflush(t)) return DPGO_ERR;  // (reads this agent's own poses: staged neighbour poses stay staged)
   if (a->d_pubframes.find(nbr) == a->d_pubframes.end()) return 0;
   if (a->pub_epoch != t->epoch) {
     // the wrapper asks per neighbour and per sequence (:666-668), right after an iterate: pack everything this agent
@@ -295,7 +295,8 @@ int dpgo_agent_unpack_neighbor_poses_device(dpgo_team_t *t, int id, int nbr, int
 // (:666-668), the status of the block update (:616) and the result of a local RGD solve (:169-172) -- is written by ONE
 // kernel behind the iterate's launches straight into pinned host memory, followed by a sequence word; the host polls
 // that word (no copy engine, no stream-wide wait) and the getters then answer from the host copies.
-static int report_after_iterate(dpgo_team_t *t, Agent *a, bool did_opt, bool advance, bool upload) {
+static int report_after_iterate(dpgo_team_t *t, Agent *a, bool did_opt, bool advance, bool upload, bool one_seq = false,
+                                bool whole_iterate_false = false) {
   const size_t B = (size_t)4 * t->prm.r;
   const size_t npub = 2 * (size_t)a->n_pub_all * B;
   const bool want_status = did_opt && !t->prm.status_every_iterate && (a->opt_rel_src == 1 || a->opt_rel_src == 5);
@@ -305,8 +306,8 @@ static int report_after_iterate(dpgo_team_t *t, Agent *a, bool did_opt, bool adv
   const bool want_opt = did_opt && a->opt_pending_rgd;
   if (a->h_down.alloc(8 + npub, true)) { set_err("pinned allocation failed"); return DPGO_ERR; }
   if (!a->d_report_seq.p) {
-    if (a->d_report_seq.alloc(1)) { set_err("device allocation failed"); return DPGO_ERR; }
-    HIPC(hipMemsetAsync(a->d_report_seq.p, 0, sizeof(unsigned long long), t->stream));
+    if (a->d_report_seq.alloc(2)) { set_err("device allocation failed"); return DPGO_ERR; }
+    HIPC(hipMemsetAsync(a->d_report_seq.p, 0, 2 * sizeof(unsigned long long), t->stream));
     a->report_seq = 0;
     *reinterpret_cast<volatile unsigned long long *>(a->h_down.p) = 0ull;
   }
@@ -314,9 +315,13 @@ static int report_after_iterate(dpgo_team_t *t, Agent *a, bool did_opt, bool adv
   if (upload && stage_to_pinned(t, *a, &up0, &up1)) return DPGO_ERR;
   const unsigned long long expect = ++a->report_seq;
   const auto tq0 = std::chrono::steady_clock::now();
+  if (whole_iterate_false) {
+    launch_iterate_false(t->ctx(), a->local, a->n, t->prm.num_robots, t->prm.restart_interval, a->d_pubpos_ptr.p, a->d_pubpos.p,
+                         a->h_down.p, a->d_report_seq.p, a->d_report_seq.p + 1, a->h_up_idx.p, a->h_up.p, up0, up1);
+  } else
   launch_report(t->ctx(), a->local, a->d_pub_all.p, a->n_pub_all, a->h_down.p, tiles ? PART_E : PART_B + 2, scnt, PART_STRIDE,
                 want_opt ? nb : 0, a->d_report_seq.p, advance ? 1 : 0, t->prm.acceleration, t->prm.num_robots,
-                t->prm.restart_interval, a->h_up_idx.p, a->h_up.p, up0, up1);
+                t->prm.restart_interval, a->h_up_idx.p, a->h_up.p, up0, up1, one_seq ? 1 : 0);
   {
     volatile unsigned long long *flag = reinterpret_cast<volatile unsigned long long *>(a->h_down.p);
     unsigned long long spins = 0;
@@ -334,13 +339,14 @@ static int report_after_iterate(dpgo_team_t *t, Agent *a, bool did_opt, bool adv
   t->counters[6] += 1;
   for (auto &b : t->ag) b->up_pending = false;  // this team's stream has drained past every upload enqueued before
   release_fused_rtr_lock(t);                    // ... and past any one-launch solve
+  if (a->opt_pending_rtr && refresh_rtr_result(t, *a, true)) return DPGO_ERR;  // (its record is in pinned memory already)
   const double *out = a->h_down.p, *pub = out + 8;
   if (npub) {
     size_t off = 0;
     for (auto &kv : a->d_pubframes) {
       const size_t cnt = (size_t)a->n_pubframes[kv.first];
       for (int s = 0; s < 2; ++s) {
-        const double *src = pub + ((size_t)s * a->n_pub_all + off) * B;
+        const double *src = pub + ((size_t)(one_seq ? 0 : s) * a->n_pub_all + off) * B;
         a->pub_cache[s][kv.first].assign(src, src + cnt * B);
       }
       off += cnt;
@@ -366,8 +372,7 @@ int dpgo_agent_iterate(dpgo_team_t *t, int id, int do_optimization) {
   Agent *a = find_agent(t, id);
   if (!a) return DPGO_ERR;
   if (a->state != DPGO_INITIALIZED || !a->has_X) { a->iter++; return DPGO_NOT_READY; }
-  // iterate(false) reads no neighbour pose: what is staged on the host travels with the report kernel that closes the
-  // call instead of a scatter launch in front of it
+  // iterate(false) reads no neighbour pose: what is staged on the host is not uploaded in front of it
   const bool defer_upload = !do_optimization && t->prm.acceleration && t->peers.empty();
   if (defer_upload ? sync_descs_noflush(t) : sync_descs(t)) return DPGO_ERR;
   if (t->prm.robust_cost_type != DPGO_COST_L2) a->robust_inner_iter++;
@@ -377,13 +382,19 @@ int dpgo_agent_iterate(dpgo_team_t *t, int id, int do_optimization) {
   // a report closes this call whenever there is something to publish or a result to read: its kernel then also takes
   // the end-of-iterate bookkeeping (one launch less)
   const bool will_report = t->prm.acceleration || opt || a->publish_requested;
-  const int rc = enqueue_iterate(t, a->local, opt ? 1 : (do_optimization ? 2 : 0), will_report);
+  // an accelerated iterate(false) is ONE launch (k_iterate_false): Nesterov step, staged poses, bookkeeping and report
+  const bool one_launch = defer_upload && !t->prm.status_every_iterate;
+  if (one_launch) a->rel_src = 0;
+  const int rc = one_launch ? 0 : enqueue_iterate(t, a->local, opt ? 1 : (do_optimization ? 2 : 0), will_report);
   if (rc) return rc;
   if (do_optimization) mark_optimized(t, *a, opt ? (a->rel_src == 1 ? 1 : 5) : 2, opt);
   a->iter++;
   if (t->prm.acceleration || opt) a->publish_requested = true;
   if (will_report) {
-    const int rr = report_after_iterate(t, a, opt, true, defer_upload);
+    // (an accelerated iterate(false) leaves X = Y at every pose: one sequence crosses the bus)
+    // (what updateNeighborPoses staged stays on the host across iterate(false) calls -- nothing reads the slabs until
+    // this agent's next iterate(true), whose first launch scatters the latest value of every slot)
+    const int rr = report_after_iterate(t, a, opt, true, defer_upload && !one_launch, !do_optimization && t->prm.acceleration, one_launch);
     if (rr) return rr;
   }
   return a->last_success ? DPGO_OK : DPGO_NOT_READY;

@@ -67,7 +67,11 @@ void launch_upload2(const LaunchCtx &c, double *slab0, double *slab1, const int 
 void launch_report(const LaunchCtx &c, int ai, const int *frames, int count, double *host_out, int stat_off, int stat_cnt,
                    int stat_stride, int opt_nb, unsigned long long *seq, int advance, int accel, int num_robots,
                    int restart_interval, const int *up_slots = nullptr, const double *up_in = nullptr, int up_n0 = 0,
-                   int up_n1 = 0);
+                   int up_n1 = 0, int one_seq = 0);
+// the whole accelerated iterate(false) of one agent -- Nesterov step, staged neighbour poses in, bookkeeping, report -- in ONE launch
+void launch_iterate_false(const LaunchCtx &c, int ai, int n, int num_robots, int restart_interval, const int *pubpos_ptr,
+                          const int *pubpos, double *host_out, unsigned long long *seq, unsigned long long *ticket,
+                          const int *up_slots, const double *up_in, int up_n0, int up_n1);
 void launch_residuals(const LaunchCtx &c, int ai, int nedges);
 void launch_cost(const LaunchCtx &c, int ai);
 // the device-side UPDATE token (pose_ops.hip k_mail_signal / k_mail_wait): up to MAIL_MAX words per launch

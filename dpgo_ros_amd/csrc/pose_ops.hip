@@ -253,6 +253,33 @@ __global__ void k_unpack(double *slab, const int *slots, int count, const double
   slab[(size_t)slots[q] * 4 * R + k] = in[t];
 }
 
+// staged neighbour poses, pinned host memory -> slabs: elements first, first + stride, ... of the (n0 + n1) * 4R doubles.
+// Reads from host memory cross PCIe (~2 us each): eight per lane are in flight before the first is stored (a plain loop
+// would wait for every one in turn).
+template <int R>
+__device__ __forceinline__ void upload_slice(const AgentDev &ag, const int *slots, const double *in, int n0, int n1, int first,
+                                             int stride) {
+  const int total = (n0 + n1) * 4 * R;
+  for (int base = first; base < total; base += 8 * stride) {
+    double v[8];
+    int sl[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int t = min(base + u * stride, total - 1);
+      v[u] = in[t];
+      sl[u] = slots[t / (4 * R)];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int t = base + u * stride;
+      if (t < total) {
+        const int q = t / (4 * R), k = t - q * 4 * R;
+        ag.nbr[q < n0 ? 0 : 1][(size_t)sl[u] * 4 * R + k] = v[u];
+      }
+    }
+  }
+}
+
 // ---- the host boundary of the per-agent API (the path a ROS wrapper drives), without copy engines or stream-wide waits:
 // neighbour poses staged by updateNeighborPoses are scattered into the slabs straight FROM pinned host memory
 // (slots / in: host pointers; counts[2]: poses of the main / auxiliary sequence, in that order)
@@ -276,19 +303,18 @@ __global__ __launch_bounds__(512) void k_report(const AgentDev *__restrict__ age
                                                   double *out, int stat_off, int stat_cnt, int stat_stride, int opt_nb,
                                                   unsigned long long *seq, int advance, int accel, int num_robots,
                                                   int restart_interval, const int *up_slots, const double *up_in, int up_n0,
-                                                  int up_n1) {
+                                                  int up_n1, int one_seq) {
   const AgentDev &ag = agents[ai];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // neighbour poses staged on the host that no launch of this iterate needed (iterate(false)): scattered here, one
   // launch less (what k_upload2 does)
-  for (int t = tid; t < (up_n0 + up_n1) * 4 * R; t += 512) {
-    const int q = t / (4 * R), k = t - q * 4 * R;
-    ag.nbr[q < up_n0 ? 0 : 1][(size_t)up_slots[q] * 4 * R + k] = up_in[t];
-  }
+  upload_slice<R>(ag, up_slots, up_in, up_n0, up_n1, tid, 512);
   // end of the iterate for this agent (what k_advance does in a launch of its own): nothing below reads the NestState
   if (advance && tid == 511) advance_agent(ag, accel, num_robots, restart_interval);
   const int len = count * 4 * R;
-  for (int t = tid; t < 2 * len; t += 512) {
+  // (one_seq: X == Y at the public poses -- an accelerated iterate(false) leaves X = Y --, so half the payload crosses
+  // the bus and the host duplicates it)
+  for (int t = tid; t < (one_seq ? 1 : 2) * len; t += 512) {
     const int sq = t >= len, u = t - sq * len, q = u / (4 * R), k = u - q * 4 * R;
     out[8 + t] = ag.buf[sq ? B_Y : B_X][(size_t)frames[q] * 4 * R + k];
   }
@@ -304,6 +330,51 @@ __global__ __launch_bounds__(512) void k_report(const AgentDev *__restrict__ age
   __threadfence_system();
   __syncthreads();
   if (tid == 0) {
+    const unsigned long long v = *seq + 1ull;
+    *seq = v;
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(out), v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// The whole accelerated iterate(false) of one agent in ONE launch (the wrapper makes one such call per robot and
+// iteration, and every launch in front of the report costs ~3-5 us of the host's wait): the Nesterov step of k_nest_pre
+// on 64-pose tiles; every tile also scatters its share of the staged neighbour poses (read from pinned host memory) and
+// writes the new X (= Y) of its PUBLIC poses straight into the pinned report (pubpos: where each public pose goes, one
+// place per neighbour that shares it), makes that visible system-wide and takes a ticket; the workgroup that draws the
+// last ticket advances the agent's Nesterov scalars and writes the sequence word the host polls.
+template <int R>
+__global__ __launch_bounds__(64) void k_iterate_false(const AgentDev *__restrict__ agents, TeamDev *team, int ai, int num_robots,
+                                                      int restart_interval, const int *pubpos_ptr, const int *pubpos, double *out,
+                                                      unsigned long long *seq, unsigned long long *ticket, const int *up_slots,
+                                                      const double *up_in, int up_n0, int up_n1) {
+  __shared__ Tile<R> TX, TV;
+  const AgentDev &ag = agents[ai];
+  const int tid = threadIdx.x, j0 = (int)blockIdx.x * 64;
+  // this tile's share of the staged neighbour poses (nothing in this launch reads them)
+  upload_slice<R>(ag, up_slots, up_in, up_n0, up_n1, (int)blockIdx.x * 64 + tid, 64 * (int)gridDim.x);
+  int q = -1, p0 = 0, p1 = 0;
+  if (j0 < ag.n && tid < min(64, ag.n - j0)) {
+    q = ag.pub_index[j0 + tid];
+    if (q >= 0) { p0 = pubpos_ptr[q]; p1 = pubpos_ptr[q + 1]; }
+  }
+  nest_pre_body<R>(agents, team, -2, ai, num_robots, restart_interval, (int)blockIdx.x, 0, TX, TV, 0);
+  if (q >= 0) {
+    double v[4 * R];
+    tile_get<R>(TX, tid, v);  // the tile still holds what went to X (and Y)
+    for (int p = p0; p < p1; ++p) {
+      double *dst = out + 8 + (size_t)pubpos[p] * 4 * R;
+#pragma unroll
+      for (int i = 0; i < 4 * R; ++i) dst[i] = v[i];
+    }
+  }
+  __threadfence_system();
+  unsigned int tk = 0;
+  if (tid == 0) tk = (unsigned int)__hip_atomic_fetch_add(ticket, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+  tk = (unsigned int)__builtin_amdgcn_readfirstlane((int)tk);
+  if (tk + 1u != gridDim.x) return;
+  if (tid == 0) {
+    __hip_atomic_store(ticket, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    advance_agent(ag, 1, num_robots, restart_interval);
     const unsigned long long v = *seq + 1ull;
     *seq = v;
     __hip_atomic_store(reinterpret_cast<unsigned long long *>(out), v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -478,10 +549,18 @@ void launch_upload2(const LaunchCtx &c, double *slab0, double *slab1, const int 
 
 void launch_report(const LaunchCtx &c, int ai, const int *frames, int count, double *host_out, int stat_off, int stat_cnt,
                    int stat_stride, int opt_nb, unsigned long long *seq, int advance, int accel, int num_robots,
-                   int restart_interval, const int *up_slots, const double *up_in, int up_n0, int up_n1) {
+                   int restart_interval, const int *up_slots, const double *up_in, int up_n0, int up_n1, int one_seq) {
   DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_report<R>, dim3(1), dim3(512), 0, c.stream, c.agents, ai, frames, count, host_out,
                                           stat_off, stat_cnt, stat_stride, opt_nb, seq, advance, accel, num_robots,
-                                          restart_interval, up_slots, up_in, up_n0, up_n1));
+                                          restart_interval, up_slots, up_in, up_n0, up_n1, one_seq));
+}
+
+void launch_iterate_false(const LaunchCtx &c, int ai, int n, int num_robots, int restart_interval, const int *pubpos_ptr,
+                          const int *pubpos, double *host_out, unsigned long long *seq, unsigned long long *ticket,
+                          const int *up_slots, const double *up_in, int up_n0, int up_n1) {
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_iterate_false<R>, dim3((n + 63) / 64), dim3(64), 0, c.stream, c.agents, c.team, ai,
+                                          num_robots, restart_interval, pubpos_ptr, pubpos, host_out, seq, ticket, up_slots, up_in,
+                                          up_n0, up_n1));
 }
 
 void launch_residuals(const LaunchCtx &c, int ai, int nedges) {

@@ -290,9 +290,9 @@ int enqueue_iterate(dpgo_team *t, int li, int do_opt, bool defer_advance) {
 
 // the record of the agent's last one-launch RTR solve and the running totals of all of them (copied back
 // asynchronously behind every solve) -> a.opt and the team counters
-int refresh_rtr_result(dpgo_team *t, Agent &a) {
+int refresh_rtr_result(dpgo_team *t, Agent &a, bool drained) {
   if (!a.opt_pending_rtr) return 0;
-  HIPC(hipStreamSynchronize(t->stream));
+  if (!drained) HIPC(hipStreamSynchronize(t->stream));  // (drained: the caller has seen a report launched behind the solve)
   release_fused_rtr_lock(t);
   a.opt_pending_rtr = false;
   if (*t->h_bar_err) {

@@ -147,7 +147,8 @@ struct Agent {
   PinnedBuf<double> h_up, h_down;
   bool up_pending = false;       // an upload kernel that reads the pinned image may still be queued (cleared by the next
                                  // report the host has seen: the report kernel runs behind it on the same stream)
-  DevBuf<unsigned long long> d_report_seq;  // sequence number of the agent's reports (device side)
+  DevBuf<unsigned long long> d_report_seq;  // [0] sequence number of the agent's reports (device side), [1] tile ticket of k_iterate_false
+  DevBuf<int> d_pubpos_ptr, d_pubpos;       // per public pose: its places in the packed report (one per neighbour sharing it)
   unsigned long long report_seq = 0;        // ... and what the host expects next
   int opt_rel_src = -1;
   bool opt_success = false, opt_cached = false;
@@ -281,7 +282,7 @@ void account_iteration(dpgo_team *t, int sel, bool fused);
 int enqueue_optimize_group(dpgo_team *t, int g);
 int fetch_scal(dpgo_team *t, Agent &a);
 int refresh_rgd_result(dpgo_team *t, Agent &a);
-int refresh_rtr_result(dpgo_team *t, Agent &a);
+int refresh_rtr_result(dpgo_team *t, Agent &a, bool drained = false);
 double robust_weight(const dpgo_params_t &p, double mu, double residual);
 int compute_residuals(dpgo_team *t, Agent &a, std::vector<double> &res);
 
