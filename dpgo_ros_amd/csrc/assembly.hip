@@ -495,6 +495,7 @@ int sync_descs_noflush(dpgo_team *t) {
     t->max_npub = std::max(t->max_npub, a->npub);
   }
   if (t->d_agents.upload(descs, t->stream)) { set_err("descriptor upload failed"); return DPGO_ERR; }
+  t->h_descs = descs;
   if (t->sched.empty()) for (size_t k = 0; k < t->ag.size(); ++k) t->sched.push_back((int)k);
   if (t->d_sched.upload(t->sched, t->stream) || t->d_team.alloc(1)) { set_err("schedule upload failed"); return DPGO_ERR; }
   // greedy colouring of the (local) agent graph in index order: same colour = no shared edge

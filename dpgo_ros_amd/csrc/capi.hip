@@ -58,6 +58,8 @@ dpgo_team_t *dpgo_team_create(int device, const dpgo_params_t *p, int num_local,
     if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && lds > 0) t->max_lds = lds;
     const char *e3 = std::getenv("DPGO_BAKE_SEL");
     if (e3) t->bake_sel = (e3[0] == '0') ? 0 : 1;
+    const char *e4 = std::getenv("DPGO_BAKE_DESC");
+    if (e4) t->bake_desc = (e4[0] == '0') ? 0 : 1;
     const char *e2 = std::getenv("DPGO_FUSED_RTR");
     if (e2) t->use_fused_rtr = (e2[0] == '0') ? 0 : 1;
     if (t->d_nest_all.alloc(std::max(1, num_local)) ||
@@ -975,6 +977,7 @@ static int team_run_impl(dpgo_team_t *t, int iters, bool prepare_only) {
       // the first iteration is a launch of its own, the last iteration does not look ahead, and its statistics /
       // bookkeeping close the run.
       LaunchCtx c = t->ctx();
+      c.bake_desc = bake && t->bake_desc;  // the agent's descriptor by value in the launches that name their agent
       const int na = (int)t->ag.size(), mn = t->max_n;
       launch_nest_pre(c, -1, -1, na, mn, p.num_robots, p.restart_interval, 1);
       // the last L = min(B, schedule period) steps leave their statistics (X2 snapshot, |X - XPrev|^2: every agent's

@@ -41,6 +41,16 @@ __device__ __forceinline__ int sel_cur(const TeamDev *team, int sel) {
   return team->group_members[team->group_ptr[SEL_GROUP0 - sel] + blockIdx.y];  // colour-parallel update
 }
 
+// Graphs that bake the agent of every iteration into its launches (dpgo_team_run, schedule period <= 8) also pass that
+// agent's DESCRIPTOR by value: its fields then come from the kernel-argument segment with the launch instead of from
+// agents[i] behind the argument pointer -- one dependent (scalar) round trip less at the head of both kernels of an
+// iteration.  BAKED is a template flag: the two sources live in different address spaces.
+template <bool BAKED>
+__device__ __forceinline__ const AgentDev &pick_agent(const AgentDev &by_value, const AgentDev *__restrict__ agents, int index) {
+  if constexpr (BAKED) return by_value;
+  else return agents[index];
+}
+
 template <int R>
 __device__ __forceinline__ int spmm_blocks(int n) { return (n + (64 / R) - 1) / (64 / R); }
 
@@ -167,10 +177,11 @@ __device__ __forceinline__ void advance_agent(const AgentDev &ag, int accel, int
 // the LDS exchange between the lanes of the tile is ordered by a wave-level fence instead of __syncthreads(), and the
 // Riemannian gradient is stored write-through (agent-scope relaxed atomics = global_store sc1) because other
 // workgroups of the SAME launch read it behind the grid barrier.
-template <int R, bool IN_WAVE = false>
+template <int R, bool IN_WAVE = false, bool BAKED = false>
 __device__ __forceinline__ void eval_body(const AgentDev *__restrict__ agents, const TeamDev *team, int sel, int xb, int egb, int gfb,
-                                          int poff, int gmode, int aux, int bx, double *Ysh, double *Wsh) {
-  const AgentDev &ag = agents[IN_WAVE ? sel : sel_cur(team, sel)];
+                                          int poff, int gmode, int aux, int bx, double *Ysh, double *Wsh,
+                                          const AgentDev &agv) {
+  const AgentDev &ag = pick_agent<BAKED>(agv, agents, BAKED ? 0 : (IN_WAVE ? sel : sel_cur(team, sel)));
   constexpr int PPB = 64 / R;
   const int lane = IN_WAVE ? (int)(threadIdx.x & 63) : (int)threadIdx.x, lp = lane / R, a = lane - lp * R;
   const int j = bx * PPB + lp;

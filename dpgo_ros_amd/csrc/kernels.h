@@ -15,6 +15,8 @@ struct LaunchCtx {
   bool any_two_level = false;      // the team has an agent with the two-level preconditioner
   int tl_max_wg = 0;               // ... and the most workgroups one of their applies runs
   const int *host_precond = nullptr;  // [local agent] DPGO_PRECOND_* it runs (host memory; selects the kernel variant)
+  const AgentDev *host_agents = nullptr;  // [local agent] host copies of the descriptors (what d_agents holds)
+  bool bake_desc = false;          // pass the agent's descriptor BY VALUE where the launch names its agent (baked graphs)
   const NestState *nest_all = nullptr;  // the team's NestStates, [local agent]: lets a kernel read an agent's Nesterov
                                         // state from the agent index alone, next to (not behind) its descriptor
 };

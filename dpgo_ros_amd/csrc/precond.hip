@@ -53,19 +53,20 @@ namespace dpgo {
 
 // TLC: the two-level product is compiled in (it costs the dense variants registers, i.e. occupancy: teams without a
 // two-level agent run kernels without it)
-template <int R, int MODE, int KC, bool TLC>
+// BAKED: the agent's descriptor arrives by value with the launch (pick_agent, kernel_common.h)
+template <int R, int MODE, int KC, bool TLC, bool BAKED>
 __global__ __launch_bounds__(256) void k_precond(const AgentDev *__restrict__ agents, TeamDev *team, int sel, int xb, int vb,
                                                  int zb, int sp, int max_inner, double step, int accel,
                                                  int num_robots, int advance, int restart_interval, int ahead,
-                                                 const NestState *nest_all) {
+                                                 const NestState *nest_all, const AgentDev agv) {
   // XCD-aware block order: hardware workgroup h runs on XCD h % 8 (each with its own L2).  Logical block
   // (h % 8) * (grid / 8) + h / 8 gives every XCD one contiguous range of poses, so that the cache lines shared by
   // neighbouring poses (a pose is 4R doubles, not a multiple of a line) are written inside one L2 instead of
   // being split between two.  The grid is padded to a multiple of 8; padding blocks fall out at the nblk test.
   // Two-level agents (ag.tl, twolevel.h) keep the hardware order: their first workgroups are the producers of the
   // exchange and must be dispatched first.
-  const int agent_index = sel_cur(team, sel);
-  const AgentDev &ag = agents[agent_index];
+  const int agent_index = BAKED ? sel : sel_cur(team, sel);
+  const AgentDev &ag = pick_agent<BAKED>(agv, agents, agent_index);
   const bool is_tl = TLC && ag.tl.nwg > 0;
   // (two-level agents: the first nA workgroups of the launch are the producers of the exchange -- they own no columns and
   // no logical index; workgroup nA + k is logical block k)
@@ -563,10 +564,20 @@ void launch_precond(const LaunchCtx &c, int sel, int max_n, int mode, int xb, in
     tl = c.host_precond[sel] == 3;
     if (c.host_precond[sel] != 1) dn = 0;
   }
+  // graphs with the schedule baked in pass the step kernel's agent descriptor by value (PM_RGD only)
+  const bool baked = mode == PM_RGD_ && sel >= 0 && c.host_agents && c.bake_desc && c.ny == 1;
+  AgentDev none{};
+  const AgentDev &agv = baked ? c.host_agents[sel] : none;
 #define PC_LAUNCH(M, KCV, TLV)                                                                                      \
-    DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL((k_precond<R, M, KCV, TLV>), dim3(grid, c.ny), dim3(256), 0, c.stream, c.agents, \
-                                            c.team, sel, xb, vb, zb, sp, max_inner, step, accel, num_robots, advance,   \
-                                            restart_interval, ahead, c.nest_all))
+    if (baked && M == PM_RGD_) {                                                                                    \
+      DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL((k_precond<R, PM_RGD_, KCV, TLV, true>), dim3(grid, c.ny), dim3(256), 0, c.stream, \
+                                              c.agents, c.team, sel, xb, vb, zb, sp, max_inner, step, accel, num_robots,   \
+                                              advance, restart_interval, ahead, c.nest_all, agv));                         \
+    } else {                                                                                                        \
+      DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL((k_precond<R, M, KCV, TLV, false>), dim3(grid, c.ny), dim3(256), 0, c.stream, \
+                                              c.agents, c.team, sel, xb, vb, zb, sp, max_inner, step, accel, num_robots,   \
+                                              advance, restart_interval, ahead, c.nest_all, agv));                         \
+    }
   // chunk size by agent size: one 2048-row chunk for agents of 257..512 poses (one round trip, one workgroup per CU);
   // DPGO_PC_KCMID-row chunks for 513..(DPGO_PC_KCMID / 2) poses (two round trips instead of three, still three
   // workgroups per CU); 1024-row chunks otherwise; no dense stream at all (KC = 0) where no dense agent can be met

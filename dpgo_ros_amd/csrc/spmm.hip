@@ -42,7 +42,7 @@ __global__ __launch_bounds__(64) void k_eval(const AgentDev *__restrict__ agents
                                              int gfb, int poff, int gmode, int aux) {
   constexpr int PPB = 64 / R;
   __shared__ double Ysh[PPB * 4 * R], Wsh[PPB * 4 * R];
-  eval_body<R>(agents, team, sel, xb, egb, gfb, poff, gmode, aux, (int)blockIdx.x, Ysh, Wsh);
+  eval_body<R>(agents, team, sel, xb, egb, gfb, poff, gmode, aux, (int)blockIdx.x, Ysh, Wsh, agents[0]);
 }
 
 // generic Riemannian Hessian-vector product at point xb with Euclidean gradient egb:  ob = Hess[vb]
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(64) void k_stats_nest(const AgentDev *__restrict__ 
   if (b < nb_nest) {
     nest_pre_body<R>(agents, team, -1, -1, num_robots, restart_interval, b % nest_tiles, b / nest_tiles, TX, TV);
   } else {
-    eval_body<R>(agents, team, -5, B_X2, B_EGRAD2, B_GF2, PART_A, 0, 0, b - nb_nest, TX.d, TV.d);
+    eval_body<R>(agents, team, -5, B_X2, B_EGRAD2, B_GF2, PART_A, 0, 0, b - nb_nest, TX.d, TV.d, agents[0]);
   }
 }
 
@@ -190,10 +190,10 @@ __global__ __launch_bounds__(64) void k_stats_nest(const AgentDev *__restrict__ 
 // No workgroup reads what another workgroup of the same launch writes: this kernel's workgroups read next_sel /
 // stats_sel (written by the previous step kernel) while workgroup 0 moves iter, cur_sel and the NestStates, which
 // only the step kernel reads.
-template <int R>
+template <int R, bool BAKED>
 __global__ __launch_bounds__(64) void k_eval_stats(const AgentDev *__restrict__ agents, TeamDev *team, int nb_eval, int first,
                                                    int has_eval, int has_stats, int num_robots, int restart_interval,
-                                                   int eval_sel, int stats_sel) {
+                                                   int eval_sel, int stats_sel, const AgentDev agv) {
   constexpr int PPB = 64 / R;
   __shared__ double Ysh[PPB * 4 * R], Wsh[PPB * 4 * R];
   const int b = (int)blockIdx.x;
@@ -206,10 +206,10 @@ __global__ __launch_bounds__(64) void k_eval_stats(const AgentDev *__restrict__ 
     return;
   }
   if (has_eval && b < nb_eval) {
-    eval_body<R>(agents, team, eval_sel >= 0 ? eval_sel : (first ? -1 : -6), B_X, B_EGRAD, B_GF, PART_C, 2, 1, b, Ysh, Wsh);
+    eval_body<R, false, BAKED>(agents, team, eval_sel >= 0 ? eval_sel : (first ? -1 : -6), B_X, B_EGRAD, B_GF, PART_C, 2, 1, b, Ysh, Wsh, agv);
   } else if (has_stats) {
     eval_body<R>(agents, team, stats_sel >= 0 ? stats_sel : -5, B_X2, B_EGRAD2, B_GF2, PART_A, 0, 0,
-                 b - (has_eval ? nb_eval : 0), Ysh, Wsh);
+                 b - (has_eval ? nb_eval : 0), Ysh, Wsh, agents[0]);
   }
 }
 
@@ -317,8 +317,15 @@ void launch_eval_stats(const LaunchCtx &c, int max_n, int first, int has_eval, i
                        int restart_interval, int eval_sel, int stats_sel) {
   const int nb = spmm_grid(c.r, max_n);
   const int grid = nb * ((has_eval ? 1 : 0) + (has_stats ? 1 : 0)) + 1;
-  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_eval_stats<R>, dim3(grid), dim3(64), 0, c.stream, c.agents, c.team, nb, first,
-                                          has_eval, has_stats, num_robots, restart_interval, eval_sel, stats_sel));
+  if (has_eval && eval_sel >= 0 && c.host_agents && c.bake_desc) {
+    const AgentDev &d = c.host_agents[eval_sel];
+    DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL((k_eval_stats<R, true>), dim3(grid), dim3(64), 0, c.stream, c.agents, c.team, nb, first,
+                                            has_eval, has_stats, num_robots, restart_interval, eval_sel, stats_sel, d));
+    return;
+  }
+  AgentDev none{};
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL((k_eval_stats<R, false>), dim3(grid), dim3(64), 0, c.stream, c.agents, c.team, nb, first,
+                                          has_eval, has_stats, num_robots, restart_interval, eval_sel, stats_sel, none));
 }
 
 void launch_tcg_hv(const LaunchCtx &c, int sel, int max_n, int sp, int max_inner) {

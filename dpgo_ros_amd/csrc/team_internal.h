@@ -210,8 +210,10 @@ struct dpgo_team {
   int max_lds = 160 * 1024;  // hipDeviceAttributeMaxSharedMemoryPerBlock
   int dense_max_n = 0;  // largest agent with a dense inverse (sizes the LDS chunk of the preconditioner kernel)
   std::vector<int> precond_of;  // [local agent] the form each agent runs (selects the preconditioner kernel's variant)
+  std::vector<dpgo::AgentDev> h_descs;  // host copies of the uploaded descriptors (baked graphs pass them by value)
   int tl_max_wg = 0;            // most workgroups a two-level apply of this team runs
   int bake_sel = 1;  // DPGO_BAKE_SEL=0: the graphs of the pipelined iteration select their agent on the device only
+  int bake_desc = 1; // DPGO_BAKE_DESC=0: ... and find its descriptor in the device array instead of in their arguments
   bool last_iteration_folded = false;  // ... and enqueue_team_iteration skipped k_nest_post / k_status / k_advance for it
   bool last_rtr_folded = false;  // the last enqueue_optimize ran the one-launch solve WITH the iteration's tail
   bool rtr_validated = false;  // a one-launch solve has completed on this device (its grid is resident at once)
@@ -231,6 +233,7 @@ struct dpgo_team {
     c.dense_max_n = dense_max_n;
     c.host_precond = precond_of.empty() ? nullptr : precond_of.data();
     c.tl_max_wg = tl_max_wg;
+    c.host_agents = h_descs.empty() ? nullptr : h_descs.data();
     for (int k : precond_of) if (k == DPGO_PRECOND_TWO_LEVEL) c.any_two_level = true;
     return c;
   }
