@@ -54,6 +54,7 @@ void rebuild_index(Agent &a) {
   a.n = n;
   a.index_dirty = false;
   a.data_dirty = true;
+  a.struct_uploaded = false;
 }
 
 int find_np(const Agent &a, int robot, int frame) {
@@ -139,6 +140,7 @@ static int choose_precond(dpgo_team *t, Agent &a, double &budget) {
       const bool rtr = t->prm.method == DPGO_METHOD_RTR && t->use_fused_rtr;
       a.tl_plan = tl_make_plan(a.n, a.rowptr, a.col, 0, rtr ? rtr_fused_tl_fit_pairs(t->prm.r) : 0, rtr ? std::min(512, 2 * t->num_cus) : 0);
       a.tl_rowptr = a.rowptr; a.tl_col = a.col;
+      a.tl_plan_serial += 1;
     }
     const TLPlan &pl = a.tl_plan;
     double blocks = 16.0 * pl.ns * pl.ns, coup = 0;
@@ -259,9 +261,11 @@ int finalize_agent(dpgo_team *t, Agent &a, double *scratch) {
   }
   std::vector<int> pub_index(n, -1);
   for (size_t q = 0; q < pub_pose.size(); ++q) pub_index[pub_pose[q]] = (int)q;
-  if (a.d_ell_col.upload(ell_col, s) || a.d_ell_val.upload(ell_val, s) || a.d_trowptr.upload(trowptr, s) ||
-      a.d_tcol.upload(tcol, s) || a.d_tval.upload(tval, s) || a.d_pub_index.upload(pub_index, s) ||
-      a.d_pose_eptr.upload(pose_eptr, s)) {
+  // index arrays depend on the measurement STRUCTURE only: a weight update (same edges, new weights) re-sends values
+  const bool idx = !a.struct_uploaded;
+  if ((idx && (a.d_ell_col.upload(ell_col, s) || a.d_trowptr.upload(trowptr, s) || a.d_tcol.upload(tcol, s) ||
+               a.d_pub_index.upload(pub_index, s) || a.d_pose_eptr.upload(pose_eptr, s))) ||
+      a.d_ell_val.upload(ell_val, s) || a.d_tval.upload(tval, s)) {
     set_err("device allocation/upload failed");
     return DPGO_ERR;
   }
@@ -274,8 +278,9 @@ int finalize_agent(dpgo_team *t, Agent &a, double *scratch) {
             "with all measurements before dpgo_agent_export_state");
     return DPGO_ERR;
   }
-  if (a.d_rowptr.upload(a.rowptr, s) || a.d_col.upload(a.col, s) || a.d_qval.upload(a.qval, s) ||
-      a.d_pub_pose.upload(pub_pose, s) || a.d_pub_ptr.upload(pub_ptr, s) || a.d_se.upload(se, s) ||
+  if ((idx && (a.d_rowptr.upload(a.rowptr, s) || a.d_col.upload(a.col, s) || a.d_pub_pose.upload(pub_pose, s) ||
+               a.d_pub_ptr.upload(pub_ptr, s))) ||
+      a.d_qval.upload(a.qval, s) || a.d_se.upload(se, s) ||
       a.d_edges.upload(edges, s) || a.d_vec.alloc(len * NBUF) || a.d_nbr.alloc(2 * a.np.size() * 4 * r) ||
       a.d_part.alloc(PART_TOTAL) || a.d_scal.alloc(16) || a.d_resid.alloc(edges.size()) || a.d_st.alloc(2) ||
       (dense && a.d_M.alloc((size_t)N4 * N4))) {
@@ -314,6 +319,7 @@ int finalize_agent(dpgo_team *t, Agent &a, double *scratch) {
 
   // per-neighbour index tables for the packed-slab exchange (a7)
   size_t max_xfer = 1;
+  if (idx) {
   for (int nb : a.neighbors) {
     const std::vector<int> fr = public_ids(a, nb);
     std::vector<int> slots;
@@ -340,6 +346,8 @@ int finalize_agent(dpgo_team *t, Agent &a, double *scratch) {
     max_xfer = std::max(max_xfer, 2 * all.size());
   }
   if (a.d_xfer.alloc(max_xfer * 4 * r)) { set_err("device allocation failed"); return DPGO_ERR; }
+  }
+  a.struct_uploaded = true;
 
   AgentDev &d = a.dev;
   d.id = a.id; d.n = n; d.nb = (int)a.col.size(); d.N4 = N4;

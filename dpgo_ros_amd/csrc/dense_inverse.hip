@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256) void k_wtw(const InvJob *jobs) {
 }
 
 int dense_spd_inverse_batched(hipStream_t stream, int count, double *const *A, double *const *work, double *const *M,
-                              const int *N) {
+                              const int *N, bool work_is_zero) {
   if (count <= 0) return 0;
   std::vector<InvJob> jobs(count);
   size_t linv_total = 0;
@@ -405,7 +405,8 @@ int dense_spd_inverse_batched(hipStream_t stream, int count, double *const *A, d
   }
   (void)hipMemcpyAsync(jobs_d, jobs.data(), sizeof(InvJob) * count, hipMemcpyHostToDevice, stream);
   (void)hipMemsetAsync(fail_d, 0, sizeof(int) * count, stream);
-  for (int b = 0; b < count; ++b) (void)hipMemsetAsync(work[b], 0, sizeof(double) * (size_t)N[b] * N[b], stream);
+  if (!work_is_zero)  // (one memset per matrix: a batch of a hundred subdomain blocks passes an area it has zeroed in one)
+    for (int b = 0; b < count; ++b) (void)hipMemsetAsync(work[b], 0, sizeof(double) * (size_t)N[b] * N[b], stream);
   const unsigned nz = (unsigned)count;
   for (int kb = 0; kb < max_blk; ++kb) {
     const int s0 = (kb + 1) * NB;

@@ -112,7 +112,7 @@ int dense_spd_inverse(hipStream_t stream, double *A, double *work, double *M, in
 // the same for `count` matrices at once (one per agent): every step's kernels serve the whole batch (blockIdx.z).
 // Returns 0, or failing pivot + (batch index << 24).
 int dense_spd_inverse_batched(hipStream_t stream, int count, double *const *A, double *const *work, double *const *M,
-                              const int *N);
+                              const int *N, bool work_is_zero = false);
 
 // A X^T = B^T for RR right-hand sides from the Cholesky factor only (A destroyed; the solution overwrites B [N][RR];
 // Y [N][RR] is scratch).  Returns 0, or the (1-based) failing pivot.

@@ -82,6 +82,7 @@ struct Agent {
   int id = 0, local = 0;
   std::vector<dpgo_measurement_t> odom, priv, shared;
   bool index_dirty = true, data_dirty = true;
+  bool struct_uploaded = false;  // the index arrays of the current measurement structure are on the device
   int n = 0;
   // neighbour pose dictionary (sorted (robot, frame)) and per-neighbour public ids
   std::vector<std::pair<int, int>> np;
@@ -108,6 +109,7 @@ struct Agent {
   // update only refills the slabs), its device tables and slabs
   TLPlan tl_plan;
   std::vector<int> tl_rowptr, tl_col;  // the pattern the plan was made for
+  int tl_plan_serial = 0, tl_tables_serial = -1;  // plan generation / generation the device tables were uploaded for
   DevBuf<int> d_tl_blk, d_tl_lidx, d_tl_subptr, d_tl_subposes, d_tl_adjptr, d_tl_adjlist, d_tl_rowpose;
   DevBuf<long long> d_tl_doff, d_tl_eoff;
   DevBuf<dpgo::TLWg> d_tl_wg;

@@ -274,14 +274,18 @@ int tl_build(dpgo_team *t, const std::vector<Agent *> &agents) {
     const TLPlan &pl = a.tl_plan;
     TLHostLayout &L = lay[k];
     const int P = (int)pl.sub.size();
-    if (a.d_tl_blk.upload(L.blk_of, s) || a.d_tl_lidx.upload(L.lidx, s) || a.d_tl_subptr.upload(L.subptr, s) ||
-        a.d_tl_subposes.upload(L.subposes, s) || a.d_tl_adjptr.upload(L.adjptr, s) || a.d_tl_adjlist.upload(L.adjlist, s) ||
-        a.d_tl_doff.upload(L.Doff, s) || a.d_tl_eoff.upload(L.Eoff, s) || a.d_tl_wg.upload(L.wg, s) ||
-        a.d_tl_rowpose.upload(L.rowpose, s) || a.d_tl_slabs.alloc(L.slab_total) ||
-        a.d_tl_u.alloc((size_t)std::max(1, 4 * pl.ns) * t->prm.r)) {
+    // the tables depend on the dissection alone: a weight update (same sparsity pattern, same plan) refills the slabs only
+    const bool tables_current = a.tl_tables_serial == a.tl_plan_serial && a.d_tl_wg.p;
+    if ((!tables_current &&
+         (a.d_tl_blk.upload(L.blk_of, s) || a.d_tl_lidx.upload(L.lidx, s) || a.d_tl_subptr.upload(L.subptr, s) ||
+          a.d_tl_subposes.upload(L.subposes, s) || a.d_tl_adjptr.upload(L.adjptr, s) || a.d_tl_adjlist.upload(L.adjlist, s) ||
+          a.d_tl_doff.upload(L.Doff, s) || a.d_tl_eoff.upload(L.Eoff, s) || a.d_tl_wg.upload(L.wg, s) ||
+          a.d_tl_rowpose.upload(L.rowpose, s))) ||
+        a.d_tl_slabs.alloc(L.slab_total) || a.d_tl_u.alloc((size_t)std::max(1, 4 * pl.ns) * t->prm.r)) {
       set_err("two-level preconditioner: device allocation / upload failed");
       return DPGO_ERR;
     }
+    a.tl_tables_serial = a.tl_plan_serial;
     if (!a.d_tl_flag.p) {
       if (a.d_tl_flag.alloc(TL_FLAG_WORDS)) { set_err("two-level preconditioner: device allocation failed"); return DPGO_ERR; }
       HIPC(hipMemsetAsync(a.d_tl_flag.p, 0, sizeof(unsigned long long) * TL_FLAG_WORDS, s));
@@ -333,7 +337,7 @@ int tl_build(dpgo_team *t, const std::vector<Agent *> &agents) {
     hipLaunchKernelGGL(k_tl_gather, dim3(max_cnt, 1, (unsigned)sep_jobs.size()), dim3(64), 0, s, d_setup.p, d_sep_jobs.p);
   for (size_t j0 = 0; j0 < invN.size(); j0 += 32768) {
     const int cnt = (int)std::min<size_t>(32768, invN.size() - j0);
-    const int fail = dense_spd_inverse_batched(s, cnt, invA.data() + j0, invW.data() + j0, invM.data() + j0, invN.data() + j0);
+    const int fail = dense_spd_inverse_batched(s, cnt, invA.data() + j0, invW.data() + j0, invM.data() + j0, invN.data() + j0, true);
     if (fail) return fail_msg("a subdomain block of Q + shift I", fail);
   }
   if (!sep_jobs.empty()) {
@@ -345,7 +349,7 @@ int tl_build(dpgo_team *t, const std::vector<Agent *> &agents) {
       }
     hipLaunchKernelGGL(k_tl_schur, dim3(max_ns, 1, (unsigned)sep_jobs.size()), dim3(256), 0, s, d_setup.p, d_sep_jobs.p);
     // 5.
-    const int fail = dense_spd_inverse_batched(s, (int)invN2.size(), invA2.data(), invW2.data(), invM2.data(), invN2.data());
+    const int fail = dense_spd_inverse_batched(s, (int)invN2.size(), invA2.data(), invW2.data(), invM2.data(), invN2.data(), true);
     if (fail) return fail_msg("the Schur complement", fail);
   }
   // 6.
