@@ -1623,11 +1623,17 @@ int dpgo_team_time_kernel(dpgo_team_t *t, int id, int which, int reps, double *a
     hipEvent_t e0, e1;
     HIPC(hipEventCreate(&e0)); HIPC(hipEventCreate(&e1));
     LaunchCtx cc = t->ctx();
+    // the launches of the timed loop's graphs: the agent of every iteration named in its launches and its descriptor
+    // passed by value where the team bakes them (schedule period <= 8), device-selected otherwise
+    const int P = (int)t->sched.size();
+    const bool bake = t->bake_sel && P >= 1 && P <= 8;
+    cc.bake_desc = bake && t->bake_desc;
+    auto sel_at = [&](int rep) { return bake ? t->sched[(size_t)((t->iter + rep) % P)] : -1; };
     launch_nest_pre(cc, -1, -1, na, mn, p.num_robots, p.restart_interval);
     for (int k = -8; k < reps; ++k) {
       if (k == 0) HIPC(hipEventRecord(e0, t->stream));
-      launch_eval_stats(cc, mn, k == -8, 1, k > -8, p.num_robots, p.restart_interval);
-      if (which == 10) launch_precond(cc, -1, mn, PM_RGD_, B_X, B_GF, B_Z, 0, 0, p.rgd_stepsize, 1, p.num_robots, 2, p.restart_interval, 3);
+      launch_eval_stats(cc, mn, k == -8, 1, k > -8, p.num_robots, p.restart_interval, sel_at(k + 8), k > -8 ? sel_at(k + 7) : -1);
+      if (which == 10) launch_precond(cc, sel_at(k + 8), mn, PM_RGD_, B_X, B_GF, B_Z, 0, 0, p.rgd_stepsize, 1, p.num_robots, 2, p.restart_interval, 3);
     }
     HIPC(hipEventRecord(e1, t->stream));
     HIPC(hipEventSynchronize(e1));
