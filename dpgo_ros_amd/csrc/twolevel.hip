@@ -238,8 +238,8 @@ static TLHostLayout tl_layout(const TLPlan &pl) {
 }
 
 // Does the two-level form pay for this agent?  Measured on MI355X (profiles/experiments/scale.py, sphere2500 split
-// 8 / 5 / 4 / 3 / 2 / 1 ways, us per apply, dense | two-level): 312 poses 8.1 | 12.0, 500: 10.1 | 15.8, 625: 16.5 | 24.1,
-// 833: 24.1 | 29.1, 1250: 41.9 | 47.8, 2500: 134 | 101.  The exchange between phase A and phase B (publish, counter,
+// 8 / 5 / 4 / 3 / 2 / 1 ways, us per apply, dense | two-level): 312 poses 8.1 | 11.2, 500: 10.2 | 15.6, 625: 16.6 | 20.4,
+// 833: 24.0 | 28.7, 1250: 41.9 | 47.1, 2500: 134 | 101.  The exchange between phase A and phase B (publish, counter,
 // re-read: ~8 us of dependent round trips across XCDs) costs more than streaming a dense inverse of up to ~200 MB, so
 // the automatic mode takes the two-level form only beyond that -- and wherever the dense inverse does not fit at all.
 bool tl_worthwhile(const TLPlan &pl) {
