@@ -259,13 +259,39 @@ int finalize_agent(dpgo_team *t, Agent &a, double *scratch) {
     for (int p = p0 + EW; p < p1; ++p) { tcol.push_back(a.col[p]); tval.insert(tval.end(), a.qval.begin() + (size_t)16 * p, a.qval.begin() + (size_t)16 * (p + 1)); }
     trowptr[j + 1] = (int)tcol.size();
   }
+  // rows without a tail also get the blocks in structure-of-arrays order, [slot][16-byte chunk][pose]: the one-launch
+  // iteration (step_fused.hip) runs one lane per pose, and this way every load of its 64 lanes is one contiguous KB
+  std::vector<double> soa_val;
+  std::vector<int> soa_col;
+  const int SW = std::max(EW, 5);
+  if (maxlen <= 8 && maxlen > 0) {
+    // [tile of 64 poses][slot][chunk][lane]: a wave's loads differ by compile-time offsets only
+    const int tiles = std::max((n + 63) / 64, 8);  // (the one-launch iteration runs 8 waves whatever the agent's size)
+    soa_val.assign((size_t)tiles * SW * 8 * 64 * 2, 0.0);
+    soa_col.resize((size_t)tiles * SW * 64);
+    for (int jt = 0; jt < tiles * 64; ++jt) {
+      const int tile = jt / 64, lane = jt % 64, j = std::min(jt, n - 1);
+      const int p0 = a.rowptr[j], p1 = (jt < n) ? a.rowptr[j + 1] : p0;  // (lanes beyond the agent: zero blocks)
+      for (int u = 0; u < SW; ++u) {
+        soa_col[((size_t)tile * SW + u) * 64 + lane] = (p0 + u < p1) ? a.col[p0 + u] : j;
+        if (p0 + u >= p1) continue;
+        for (int q = 0; q < 8; ++q) {
+          const size_t o = ((((size_t)tile * SW + u) * 8 + q) * 64 + lane) * 2;
+          soa_val[o] = a.qval[(size_t)16 * (p0 + u) + 2 * q];
+          soa_val[o + 1] = a.qval[(size_t)16 * (p0 + u) + 2 * q + 1];
+        }
+      }
+    }
+  }
+  a.has_soa = !soa_val.empty();
   std::vector<int> pub_index(n, -1);
   for (size_t q = 0; q < pub_pose.size(); ++q) pub_index[pub_pose[q]] = (int)q;
   // index arrays depend on the measurement STRUCTURE only: a weight update (same edges, new weights) re-sends values
   const bool idx = !a.struct_uploaded;
   if ((idx && (a.d_ell_col.upload(ell_col, s) || a.d_trowptr.upload(trowptr, s) || a.d_tcol.upload(tcol, s) ||
+               (a.has_soa && a.d_soa_col.upload(soa_col, s)) ||
                a.d_pub_index.upload(pub_index, s) || a.d_pose_eptr.upload(pose_eptr, s))) ||
-      a.d_ell_val.upload(ell_val, s) || a.d_tval.upload(tval, s)) {
+      a.d_ell_val.upload(ell_val, s) || a.d_tval.upload(tval, s) || (a.has_soa && a.d_soa_val.upload(soa_val, s))) {
     set_err("device allocation/upload failed");
     return DPGO_ERR;
   }
@@ -356,6 +382,9 @@ int finalize_agent(dpgo_team *t, Agent &a, double *scratch) {
   d.Dinv = a.precond == DPGO_PRECOND_BLOCK_JACOBI ? a.d_dinv.p : nullptr;
   if (a.precond != DPGO_PRECOND_TWO_LEVEL) d.tl = TLDev{};  // (two-level agents: filled in by tl_build)
   d.ell_w = EW; d.ell_col = a.d_ell_col.p; d.ell_val = a.d_ell_val.p;
+  d.soa_val = a.has_soa ? a.d_soa_val.p : nullptr;
+  d.soa_col = a.has_soa ? a.d_soa_col.p : nullptr;
+  d.soa_w = a.has_soa ? std::max(EW, 5) : 0;
   d.trowptr = a.d_trowptr.p; d.tcol = a.d_tcol.p; d.tval = a.d_tval.p; d.pub_index = a.d_pub_index.p;
   d.pose_eptr = a.d_pose_eptr.p;
   d.pub_pose = a.d_pub_pose.p; d.pub_ptr = a.d_pub_ptr.p; d.se = a.d_se.p; d.edges = a.d_edges.p;

@@ -62,8 +62,11 @@ dpgo_team_t *dpgo_team_create(int device, const dpgo_params_t *p, int num_local,
     if (e4) t->bake_desc = (e4[0] == '0') ? 0 : 1;
     const char *e2 = std::getenv("DPGO_FUSED_RTR");
     if (e2) t->use_fused_rtr = (e2[0] == '0') ? 0 : 1;
-    if (t->d_nest_all.alloc(std::max(1, num_local)) ||
-        hipMemset(t->d_nest_all.p, 0, sizeof(NestState) * std::max(1, num_local)) != hipSuccess ||
+    const char *e5 = std::getenv("DPGO_FUSED_EVAL");
+    if (e5) t->use_fused_eval = (e5[0] == '0') ? 0 : 1;
+    if (t->d_nest_all.alloc(3 * std::max(1, num_local)) || t->d_fe_sync.alloc(16) ||
+        hipMemset(t->d_nest_all.p, 0, sizeof(NestState) * 3 * std::max(1, num_local)) != hipSuccess ||
+        hipMemset(t->d_fe_sync.p, 0, sizeof(unsigned long long) * 16) != hipSuccess ||
         hipHostMalloc((void **)&t->h_bar_err, sizeof(int)) != hipSuccess) {
       delete t; set_err("hand-off state allocation failed"); return nullptr;
     }
@@ -106,7 +109,7 @@ int dpgo_team_synchronize(dpgo_team_t *t) {
     *t->h_bar_err = 0;
     for (auto &kv : t->graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);
     t->graphs.clear(); t->graph_flip.clear();
-    set_err("an in-kernel exchange (two-level preconditioner / one-launch RTR solve) timed out: the iterates of this run are invalid");
+    set_err("an in-kernel exchange (two-level preconditioner / one-launch RTR solve / one-launch iteration) timed out: the iterates of this run are invalid");
     return DPGO_ERR;
   }
   return 0;
@@ -928,6 +931,25 @@ int dpgo_team_step_end(dpgo_team_t *t, int sel_id) {
 
 // prepare_only: capture and instantiate every graph a run of `iters` iterations from the current state would replay
 // (both alternating instances of each), execute nothing
+// the one-launch iteration (step_fused.hip) may serve this team: dense agents of 257 .. 512 poses whose rows fit the ELL
+// part, few enough public poses / shared edges for its LDS tables, the schedule and the descriptors baked into the
+// launches (period <= 8), every workgroup of a launch resident at once
+static bool fused_eval_eligible(dpgo_team_t *t) {
+  const dpgo_params_t &p = t->prm;
+  const int P = (int)t->sched.size();
+  if (!(t->use_fused_eval && t->bake_sel && t->bake_desc && P >= 1 && P <= 8 && step_fe_supported(p.r) && p.acceleration &&
+        p.method == DPGO_METHOD_RGD && p.rgd_use_preconditioner && (int)t->ag.size() <= LOOKAHEAD_MAX_AGENTS &&
+        t->h_descs.size() == t->ag.size() && t->precond_of.size() == t->ag.size()))
+    return false;
+  for (size_t k = 0; k < t->ag.size(); ++k) {
+    const int n = t->ag[k]->n, grid = ((4 * n + 7) / 8 + 7) / 8 * 8;
+    if (t->precond_of[k] != DPGO_PRECOND_DENSE || n <= 256 || n > 512 || grid > t->num_cus || !t->ag[k]->has_soa ||
+        t->h_descs[k].npub * p.r > 512 || t->h_descs[k].nshared > step_fe_max_edges())
+      return false;
+  }
+  return true;
+}
+
 static int team_run_impl(dpgo_team_t *t, int iters, bool prepare_only) {
   if (sync_descs(t)) return DPGO_ERR;
   const dpgo_params_t &p = t->prm;
@@ -961,9 +983,14 @@ static int team_run_impl(dpgo_team_t *t, int iters, bool prepare_only) {
   // team->cur_sel / next_sel, one dependent round trip less in each prologue.
   const int P = (int)t->sched.size();
   const bool bake = t->bake_sel && P >= 1 && P <= 8;
-  auto graph_for = [&](bool lead, int B, int iter0, hipGraphExec_t *out) -> int {
+  // One-launch iterations (step_fused.hip) for the mid-run part of a pipelined graph: dense agents of 257 .. 512 poses,
+  // the schedule and the descriptors baked in, every workgroup of a launch resident at once -- and, because their
+  // workgroups wait for each other before they store, only while this team holds the device's lock (as the one-launch
+  // RTR solve: two such grids on one device could starve each other)
+  const bool fe_ok = pipelined && graphable && fused_eval_eligible(t);
+  auto graph_for = [&](bool lead, int B, int iter0, bool fe, hipGraphExec_t *out) -> int {
     const int phase = bake ? iter0 % P : -1;
-    const int base = (((lead ? 1 : 0) + 2 * B) * 16 + phase + 1) * 2;
+    const int base = ((((lead ? 1 : 0) + 2 * B) * 16 + phase + 1) * 2 + (fe ? 1 : 0)) * 2;
     const int key = base + (t->graph_flip[base / 2] ^= 1);
     auto sel_at = [&](int rep) { return bake ? t->sched[(size_t)((iter0 + rep) % P)] : -1; };
     auto it = t->graphs.find(key);
@@ -984,9 +1011,21 @@ static int team_run_impl(dpgo_team_t *t, int iters, bool prepare_only) {
       // last block update of the run lies among them, and a status query reads it, a9), the look-aheads in front of
       // them leave XPrev and |Y' - X|^2; nothing reads these values earlier in the run
       const int L = std::min(B, (int)t->sched.size());
+      // iterations [0, nfe): one launch each (they are the ones that leave nothing behind: ahead == 3)
+      const int nfe = fe ? std::max(0, B - L - 1) : 0;
+      NestState *nest_own = t->d_nest_all.p, *nest_fe[2] = {t->d_nest_all.p + na, t->d_nest_all.p + 2 * na};
+      unsigned long long target = 0;
+      if (nfe > 0) HIPC(hipMemsetAsync(t->d_fe_sync.p, 0, sizeof(unsigned long long), t->stream));
       for (int rep = 0; rep < B; ++rep) {
         const int ahead = (rep + 1 < B ? 3 : 0) | ((rep + 1 < B && rep + 1 >= B - L) ? 4 : 0) | (rep >= B - L ? 8 : 0);
-        launch_eval_stats(c, mn, rep == 0, 1, 0, p.num_robots, p.restart_interval, sel_at(rep), -1);
+        if (rep < nfe) {
+          target += (unsigned long long)((4 * t->ag[sel_at(rep)]->n + 7) / 8);
+          launch_step_fe(c, sel_at(rep), sel_at(rep + 1), p.rgd_stepsize, p.num_robots, p.restart_interval,
+                         rep == 0 ? nest_own : nest_fe[rep & 1], nest_fe[(rep + 1) & 1], t->d_fe_sync.p, target, t->h_bar_err);
+          continue;
+        }
+        launch_eval_stats(c, mn, rep == 0, 1, 0, p.num_robots, p.restart_interval, sel_at(rep), -1,
+                          (rep == nfe && nfe > 0) ? nest_fe[nfe & 1] : nullptr);
         launch_precond(c, sel_at(rep), mn, PM_RGD_, B_X, B_GF, B_Z, 0, 0, p.rgd_stepsize, 1, p.num_robots, 2, p.restart_interval,
                        ahead);
       }
@@ -1036,13 +1075,17 @@ static int team_run_impl(dpgo_team_t *t, int iters, bool prepare_only) {
         const int to_restart = (p.restart_interval - ((it0 + 2) % p.restart_interval)) % p.restart_interval;
         fusedn = std::min(fusedn, to_restart);
       }
-      fusedn = std::max(0, std::min(fusedn, dpgo_team::MAX_GRAPH_ITERS));
+      // (the uniform pipelined sequence pays two extra launches per graph -- the first Nesterov step, the closing
+      // statistics -- and six two-launch iterations at its end: longer graphs)
+      fusedn = std::max(0, std::min(fusedn, uniform ? dpgo_team::MAX_PIPELINED_GRAPH_ITERS : dpgo_team::MAX_GRAPH_ITERS));
       batch = fusedn + (restart ? 1 : 0);
       hipGraphExec_t ge = nullptr;
-      const int grc = graph_for(restart, fusedn, cur_iter, &ge);
+      // (prepared graphs are the ones a run will ask for: with the one-launch iterations if this team may take the lock)
+      const bool fe = fe_ok && fusedn > (int)t->sched.size() + 1 && (prepare_only || acquire_fused_rtr_lock(t));
+      const int grc = graph_for(restart, fusedn, cur_iter, fe, &ge);
       if (grc) return grc;
       if (prepare_only) {
-        const int grc2 = graph_for(restart, fusedn, cur_iter, &ge);  // the other instance; leaves the alternation where it was
+        const int grc2 = graph_for(restart, fusedn, cur_iter, fe, &ge);  // the other instance; leaves the alternation where it was
         if (grc2) return grc2;
         cur_iter += batch;
         k += batch;
@@ -1050,6 +1093,7 @@ static int team_run_impl(dpgo_team_t *t, int iters, bool prepare_only) {
       }
       ++t->epoch;
       HIPC(hipGraphLaunch(ge, t->stream));
+      if (fe) t->counters[7] += std::max(0, fusedn - std::min(fusedn, (int)t->sched.size()) - 1);  // one-launch iterations
       // after >= 2 pipelined iterations every agent took its last Nesterov step as a look-ahead (per-pose partials)
       for (auto &a : t->ag) a->rel_src = p.acceleration ? ((pipelined && fusedn >= 2) ? 4 : 0) : 2;
       for (int q = 0; q < batch; ++q) {
@@ -1606,6 +1650,50 @@ int dpgo_team_time_kernel(dpgo_team_t *t, int id, int which, int reps, double *a
     (void)hipStreamDestroy(s2);
     *avg_ms = (double)ms / (64.0 * reps);
     *algorithmic_bytes = 0;
+    return 0;
+  }
+  if (which == 14) {
+    // the one-launch iteration (step_fused.hip) launched eagerly x reps between ONE pair of events: its dispatch-to-
+    // dispatch time.  The iterations are real ones (restarts included); the closing launch copies the Nesterov state back.
+    // Like which == 10 it consumes the state: its last iteration has looked ahead, which a run's last iteration does not.
+    const dpgo_params_t &p = t->prm;
+    const int na = (int)t->ag.size(), mn = t->max_n, P = (int)t->sched.size();
+    bool pipelined = true;
+    {
+      int total = 0;
+      for (auto &b : t->ag) total += b->n;
+      for (auto &b : t->ag) if ((total - b->n + precond_nblk(*b) - 1) / precond_nblk(*b) > 64) pipelined = false;
+    }
+    if (!pipelined || !fused_eval_eligible(t) || !acquire_fused_rtr_lock(t)) { set_err("one-launch iteration not available for this team"); return DPGO_ERR; }
+    double others = 0;
+    for (auto &b : t->ag) if (b.get() != a) others += 8.0 * r * 4 * b->n;
+    *algorithmic_bytes = precond_operator_bytes(*a) + 7.0 * vec + 4.0 * others + spmm_bytes_of(t, *a);
+    hipEvent_t e0, e1;
+    HIPC(hipEventCreate(&e0)); HIPC(hipEventCreate(&e1));
+    LaunchCtx cc = t->ctx();
+    cc.bake_desc = true;
+    auto sel_at = [&](int rep) { return t->sched[(size_t)((t->iter + rep) % P)]; };
+    NestState *nest_own = t->d_nest_all.p, *nest_fe[2] = {t->d_nest_all.p + na, t->d_nest_all.p + 2 * na};
+    unsigned long long target = 0;
+    launch_nest_pre(cc, -1, -1, na, mn, p.num_robots, p.restart_interval, 1);
+    HIPC(hipMemsetAsync(t->d_fe_sync.p, 0, sizeof(unsigned long long), t->stream));
+    const int total_reps = reps + 8;
+    for (int k = 0; k < total_reps; ++k) {
+      if (k == 8) HIPC(hipEventRecord(e0, t->stream));
+      target += (unsigned long long)((4 * t->ag[sel_at(k)]->n + 7) / 8);
+      launch_step_fe(cc, sel_at(k), sel_at(k + 1), p.rgd_stepsize, p.num_robots, p.restart_interval,
+                     k == 0 ? nest_own : nest_fe[k & 1], nest_fe[(k + 1) & 1], t->d_fe_sync.p, target, t->h_bar_err);
+    }
+    HIPC(hipEventRecord(e1, t->stream));
+    launch_eval_stats(cc, mn, 0, 0, 1, p.num_robots, p.restart_interval, -1, sel_at(total_reps - 1), nest_fe[total_reps & 1]);
+    HIPC(hipEventSynchronize(e1));
+    HIPC(hipStreamSynchronize(t->stream));
+    release_fused_rtr_lock(t);
+    t->iter += total_reps;
+    float ms = 0;
+    HIPC(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *avg_ms = (double)ms / reps;
     return 0;
   }
   if (which == 10 || which == 11) {

@@ -82,9 +82,11 @@ struct AgentDev {
   const int *rowptr;          // full block-CSR (dense assembly, read-back)
   const int *col;
   const double *qval;
-  int ell_w, pad0;            // ELL part of the same matrix: slot-major [ell_w][n], padded with (j, 0)
+  int ell_w, soa_w;           // ELL part of the same matrix: slot-major [ell_w][n], padded with (j, 0)
   const int *ell_col;
   const double *ell_val;
+  const double *soa_val;      // the ELL blocks once more as [tile of 64 poses][soa_w][16-byte chunk][lane], soa_w = max(ell_w, 5)
+  const int *soa_col;         // slots (null when a row has a tail); their columns [tile][soa_w][lane]: padded slots hold (j, 0)
   const int *trowptr;         // CSR tail: blocks beyond ell_w of long rows
   const int *tcol;
   const double *tval;

@@ -58,6 +58,15 @@ __device__ __forceinline__ int precond_blocks(int N4) { return (N4 + 7) / 8; }
 // workgroups of a preconditioner-type launch that own poses of this agent (and leave partials in PART_B)
 __device__ __forceinline__ int precond_nblk(const AgentDev &ag) { return ag.tl.nwg > 0 ? ag.tl.nwg - ag.tl.nA : (ag.N4 + 7) / 8; }
 
+// workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope release / acquire over ALL address
+// spaces, and gfx9 counts loads and stores in one counter (vmcnt): every global load still in flight is waited for in
+// front of the barrier -- a kernel that keeps a stream of HBM requests outstanding across its barriers must not use it.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 __device__ __forceinline__ double2 ld2(const double *p) { return *reinterpret_cast<const double2 *>(p); }
 
 typedef double v2d_t __attribute__((ext_vector_type(2)));

@@ -41,8 +41,18 @@ void launch_precond(const LaunchCtx &c, int sel, int max_n, int mode, int xb, in
 // pipelined accelerated RGD iterations: evaluation of iteration k || statistics of k-1 || bookkeeping of k-1
 // eval_sel / stats_sel >= 0: the local agent of the evaluation / statistics half, known to the host (graphs that bake
 // the schedule in); -1: read from the device-side schedule state
+// nest_copy: this launch leaves a run of one-launch iterations (step_fused.hip): its bookkeeping workgroup copies the
+// NestStates those launches advanced next to the team's own (iter / cur_sel have moved with them already)
 void launch_eval_stats(const LaunchCtx &c, int max_n, int first, int has_eval, int has_stats, int num_robots,
-                       int restart_interval, int eval_sel = -1, int stats_sel = -1);
+                       int restart_interval, int eval_sel = -1, int stats_sel = -1, const NestState *nest_copy = nullptr);
+// one launch per pipelined accelerated-RGD iteration (step_fused.hip): evaluation + preconditioned step + look-ahead.
+// sel / next_sel: the agents of this iteration and the next (baked); nest_src / nest_dst: the NestStates [local agent]
+// this launch reads / leaves advanced; sync[0] counts the workgroups whose evaluation is done, `target` = its value once
+// every workgroup of THIS launch has arrived (cumulative over the fused launches since sync was cleared)
+bool step_fe_supported(int r);
+int step_fe_max_edges();
+void launch_step_fe(const LaunchCtx &c, int sel, int next_sel, double step, int num_robots, int restart_interval,
+                    const NestState *nest_src, NestState *nest_dst, unsigned long long *sync, unsigned long long target, int *err);
 void launch_tcg_hv(const LaunchCtx &c, int sel, int max_n, int sp, int max_inner);
 void launch_retract(const LaunchCtx &c, int sel, int max_n, int xb, int eb, double scale, int ob, int guard_state);
 void launch_project_raw(const LaunchCtx &c, const double *X, double *out, int n);

@@ -54,11 +54,14 @@ namespace dpgo {
 // TLC: the two-level product is compiled in (it costs the dense variants registers, i.e. occupancy: teams without a
 // two-level agent run kernels without it)
 // BAKED: the agent's descriptor arrives by value with the launch (pick_agent, kernel_common.h)
-template <int R, int MODE, int KC, bool TLC, bool BAKED>
+// LEAN: a mid-run step of the pipelined sequence (accelerated, advance = 2, ahead = 3: nothing a status query reads is
+// left behind) -- the flags become compile-time constants and the tail loses its statistics paths
+template <int R, int MODE, int KC, bool TLC, bool BAKED, bool LEAN = false>
 __global__ __launch_bounds__(256) void k_precond(const AgentDev *__restrict__ agents, TeamDev *team, int sel, int xb, int vb,
                                                  int zb, int sp, int max_inner, double step, int accel,
                                                  int num_robots, int advance, int restart_interval, int ahead,
                                                  const NestState *nest_all, const AgentDev agv) {
+  if constexpr (LEAN) { accel = 1; advance = 2; ahead = 3; }
   // XCD-aware block order: hardware workgroup h runs on XCD h % 8 (each with its own L2).  Logical block
   // (h % 8) * (grid / 8) + h / 8 gives every XCD one contiguous range of poses, so that the cache lines shared by
   // neighbouring poses (a pose is 4R doubles, not a multiple of a line) are written inside one L2 instead of
@@ -569,7 +572,11 @@ void launch_precond(const LaunchCtx &c, int sel, int max_n, int mode, int xb, in
   AgentDev none{};
   const AgentDev &agv = baked ? c.host_agents[sel] : none;
 #define PC_LAUNCH(M, KCV, TLV)                                                                                      \
-    if (baked && M == PM_RGD_) {                                                                                    \
+    if (baked && M == PM_RGD_ && accel == 1 && advance == 2 && ahead == 3) {                                        \
+      DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL((k_precond<R, PM_RGD_, KCV, TLV, true, true>), dim3(grid, c.ny), dim3(256), 0, c.stream, \
+                                              c.agents, c.team, sel, xb, vb, zb, sp, max_inner, step, accel, num_robots,   \
+                                              advance, restart_interval, ahead, c.nest_all, agv));                         \
+    } else if (baked && M == PM_RGD_) {                                                                             \
       DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL((k_precond<R, PM_RGD_, KCV, TLV, true>), dim3(grid, c.ny), dim3(256), 0, c.stream, \
                                               c.agents, c.team, sel, xb, vb, zb, sp, max_inner, step, accel, num_robots,   \
                                               advance, restart_interval, ahead, c.nest_all, agv));                         \

@@ -193,15 +193,21 @@ __global__ __launch_bounds__(64) void k_stats_nest(const AgentDev *__restrict__ 
 template <int R, bool BAKED>
 __global__ __launch_bounds__(64) void k_eval_stats(const AgentDev *__restrict__ agents, TeamDev *team, int nb_eval, int first,
                                                    int has_eval, int has_stats, int num_robots, int restart_interval,
-                                                   int eval_sel, int stats_sel, const AgentDev agv) {
+                                                   int eval_sel, int stats_sel, const NestState *nest_copy, const AgentDev agv) {
   constexpr int PPB = 64 / R;
   __shared__ double Ysh[PPB * 4 * R], Wsh[PPB * 4 * R];
   const int b = (int)blockIdx.x;
   if (b == (int)gridDim.x - 1) {  // the extra workgroup: bookkeeping only, so that no evaluation waits for it
     if (!first && threadIdx.x == 0) {
-      for (int k = 0; k < team->num_agents; ++k) advance_agent(agents[k], 1, num_robots, restart_interval);
-      team->iter += 1;
-      if (has_eval) team->cur_sel = team->next_sel;
+      if (nest_copy) {
+        // the iterations in front of this one were one-launch iterations (step_fused.hip): they moved iter / cur_sel
+        // themselves and left the advanced NestStates next to the team's own
+        for (int k = 0; k < team->num_agents; ++k) *agents[k].nest = nest_copy[k];
+      } else {
+        for (int k = 0; k < team->num_agents; ++k) advance_agent(agents[k], 1, num_robots, restart_interval);
+        team->iter += 1;
+        if (has_eval) team->cur_sel = team->next_sel;
+      }
     }
     return;
   }
@@ -314,18 +320,18 @@ void launch_hess(const LaunchCtx &c, int sel, int max_n, int xb, int egb, int vb
 }
 
 void launch_eval_stats(const LaunchCtx &c, int max_n, int first, int has_eval, int has_stats, int num_robots,
-                       int restart_interval, int eval_sel, int stats_sel) {
+                       int restart_interval, int eval_sel, int stats_sel, const NestState *nest_copy) {
   const int nb = spmm_grid(c.r, max_n);
   const int grid = nb * ((has_eval ? 1 : 0) + (has_stats ? 1 : 0)) + 1;
   if (has_eval && eval_sel >= 0 && c.host_agents && c.bake_desc) {
     const AgentDev &d = c.host_agents[eval_sel];
     DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL((k_eval_stats<R, true>), dim3(grid), dim3(64), 0, c.stream, c.agents, c.team, nb, first,
-                                            has_eval, has_stats, num_robots, restart_interval, eval_sel, stats_sel, d));
+                                            has_eval, has_stats, num_robots, restart_interval, eval_sel, stats_sel, nest_copy, d));
     return;
   }
   AgentDev none{};
   DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL((k_eval_stats<R, false>), dim3(grid), dim3(64), 0, c.stream, c.agents, c.team, nb, first,
-                                          has_eval, has_stats, num_robots, restart_interval, eval_sel, stats_sel, none));
+                                          has_eval, has_stats, num_robots, restart_interval, eval_sel, stats_sel, nest_copy, none));
 }
 
 void launch_tcg_hv(const LaunchCtx &c, int sel, int max_n, int sp, int max_inner) {

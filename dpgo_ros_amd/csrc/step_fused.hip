@@ -1,0 +1,518 @@
+// step_fused.hip -- ONE launch per pipelined accelerated-RGD iteration: the step
+// kernel of precond.hip with the evaluation of spmm.hip's k_eval_stats folded in, without any hand-off between
+// workgroups.  Every workgroup (512 threads, one per CU) forms the WHOLE Riemannian gradient of the selected agent
+// itself, straight into its LDS -- the vector its slab of the dense inverse is about to meet:
+//
+//   1. X of the agent (80 KB at 500 poses) is staged in LDS; the operands of the shared edges (neighbour poses,
+//      coefficients) follow it into LDS, one double per lane and trip.
+//   2. one lane per pose: W_j = sum_i X_i Q_ij over the row -- the 4 x 4 blocks from a [tile of 64 poses][slot][16-byte
+//      chunk][lane] copy of the ELL part (every load of a wave is one contiguous KB; padded slots hold zero blocks),
+//      through a ring of four slots in registers; X_i gathered from LDS.  One lane per (public pose, row) forms the
+//      linear term G from LDS.  Tangent projection in registers; barrier; the result replaces X in LDS.
+//   3. waves 0-3 request their 128 KB slab of M = (Q + shift I)^-1 in four parts, each as soon as a slot of the ring is
+//      free for good, then: slab x vector, partial sums, and exactly the tail of k_precond<PM_RGD>: wave 0 finishes the
+//      step of the two poses the workgroup owns (step, QF retraction, Nesterov V, look-ahead Y), wave 1 takes the
+//      look-ahead step of its share of the other agents' poses.
+//
+// The sparse operator is 0.3 MB and L2 resident: 250 workgroups reading it again replace a launch whose 6.6 us were a
+// chain of dependent round trips plus a kernel boundary.  The arithmetic of the gradient is eval_body's (same
+// expressions, same order): the iterates are BITWISE those of the two-launch sequence (tests/test_gpu_fused_step.py).
+//
+// What was learned building it (profiles/r03_fused_step.md has the phase traces):
+//   * a CU serves its vector-memory requests in order.  A slab requested first holds every later load of the same CU
+//     back until it has landed (X staged at 6.5 us instead of 2): the evaluation cannot hide under the stream, its loads
+//     must be IN FRONT of the slab's in the queue.  Loads under a divergent predicate are waited for at the end of
+//     their block, a pointer that was loaded from memory makes a flat load (waited for with vmcnt(0)), and a value the
+//     compiler may resolve early (src ? src : slab) is resolved -- and waited for -- early: every one of these turns
+//     "requested now, used later" into a wait for the whole queue (asm volatile pins below).
+//   * __syncthreads() waits for every global load in flight (one counter for loads and stores on gfx9): the barriers
+//     here order LDS only (lds_barrier).
+//   * one lane per pose reading 128-byte blocks touches 64 cache lines per load instruction: the blocks are stored
+//     once more in the order the lanes read them (4x on the evaluation).
+//   * the scheduler hoists every gather above the first multiply and spills: the accumulators are pinned per block.
+//
+// What no longer holds "for free" behind a kernel boundary, and how it is kept:
+//   * the evaluation reads X of the whole agent and the neighbours' auxiliary poses, the tails / look-ahead steps of the
+//     SAME launch overwrite them: every workgroup counts itself in once its gradient is formed (one counter, cumulative
+//     target baked into the launch), and nobody stores a pose before the counter is complete.  All workgroups of the
+//     launch are resident at once (one per CU, checked by the host; the team holds the device's lock while such graphs
+//     run, as for the one-launch RTR solve); the stores come 5 us after the last arrival.
+//   * the Nesterov scalars advance between iterations: they are double-buffered -- workgroup 0 writes the next state
+//     next to the one every workgroup of this launch reads; the launch that leaves the fused run copies it back
+//     (k_eval_stats, nest_copy).
+// Mid-run iterations only (ahead == 3: nothing a status query reads is left behind); the last iterations of a run take
+// the two-launch sequence, which leaves the statistics.  Dense agents of 257 .. 512 poses, r <= 5, rows of <= 8 blocks,
+// npub * r <= 512, <= 144 shared edges; DPGO_FUSED_EVAL=0 keeps the two-launch sequence everywhere.
+#include "kernel_common.h"
+#include <algorithm>
+
+namespace dpgo {
+
+// -DDPGO_FE_TRACE: per-wave wall-clock stamps kept in LDS (no registers: the kernel sits at the VGPR limit) and written to
+// the agent's partial-sum scratch (PART_E, words [4000 ..]: workgroup DPGO_FE_TRACE_BLOCK, [wave][16]; [4100 + 2 * block]:
+// start / end of every workgroup's first wave) when a wave leaves -- profiles/experiments/fe_trace.py
+#ifdef DPGO_FE_TRACE
+#ifndef DPGO_FE_TRACE_BLOCK
+#define DPGO_FE_TRACE_BLOCK 100
+#endif
+#define FE_TRACE_DECL __shared__ unsigned long long fe_stamps[8 * 16];
+#ifndef DPGO_FE_STAMP_MASK
+#define DPGO_FE_STAMP_MASK 0xFFFF
+#endif
+#define FE_STAMP(k) do { if (((DPGO_FE_STAMP_MASK >> (k)) & 1) && (threadIdx.x & 63) == 0) fe_stamps[(threadIdx.x >> 6) * 16 + (k)] = wall_clock64(); } while (0)
+#define FE_FLUSH() do { if ((threadIdx.x & 63) == 0) { const int w_ = threadIdx.x >> 6; \
+    if (blockIdx.x == DPGO_FE_TRACE_BLOCK) for (int k_ = 0; k_ < 16; ++k_) ag.part[PART_E + 4000 * PART_STRIDE + w_ * 16 + k_] = (double)fe_stamps[w_ * 16 + k_]; \
+    if (w_ == 0) { ag.part[PART_E + (4100 + 2 * (int)blockIdx.x) * PART_STRIDE] = (double)fe_stamps[0]; ag.part[PART_E + (4100 + 2 * (int)blockIdx.x) * PART_STRIDE + 1] = (double)fe_stamps[15]; } } } while (0)
+#else
+#define FE_TRACE_DECL
+#define FE_STAMP(k) do { } while (0)
+#define FE_FLUSH() do { } while (0)
+#endif
+
+constexpr int FE_KC = 2048;
+constexpr int FE_SPIN_LIMIT = 1 << 22;
+#ifndef DPGO_FE_PARTS
+#define DPGO_FE_PARTS 4
+#endif
+constexpr int FE_PARTS = DPGO_FE_PARTS;  // the slab is requested in this many parts, behind the last blocks of the row
+constexpr int FE_MAX_EDGES = 144;  // shared edges of an agent whose operands fit the LDS left over (41 KB at r = 5)
+#ifndef DPGO_FE_GROUP
+#define DPGO_FE_GROUP 2
+#endif
+
+// one block of the row: W += X_i Q_ij, X_i gathered from the staged copy of X
+template <int R>
+__device__ __forceinline__ void fe_block(const double *Xs, int i, const double2 *B, double *W) {
+  const double *xp = Xs + (size_t)4 * R * i;
+  double x[4 * R];
+#pragma unroll
+  for (int t = 0; t < 2 * R; ++t) { const double2 v = *reinterpret_cast<const double2 *>(xp + 2 * t); x[2 * t] = v.x; x[2 * t + 1] = v.y; }
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int a = 0; a < R; ++a)
+      W[c * R + a] += x[a] * B[2 * c].x + x[R + a] * B[2 * c].y + x[2 * R + a] * B[2 * c + 1].x + x[3 * R + a] * B[2 * c + 1].y;
+}
+
+// the accumulators of a row as operands of an empty volatile asm: everything that feeds them is computed in front of it,
+// nothing behind it moves up -- the compiler otherwise gathers every X_i of the row before the first multiply and spills
+template <int N>
+__device__ __forceinline__ void fe_pin(double *w) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm volatile("" : "+v"(w[i]));
+  asm volatile("" ::: "memory");
+}
+
+template <int R, int WD>
+__global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ agents, TeamDev *team, int sel, int next_sel, double step,
+                                                 int num_robots, int restart_interval, const NestState *nest_src, NestState *nest_dst,
+                                                 unsigned long long *sync, unsigned long long target, int *err, const AgentDev agv) {
+  const AgentDev &ag = agv;
+  // XCD-aware block order, as in k_precond
+  const int hb = (int)blockIdx.x;
+  const int bx = (hb % 8) * ((int)gridDim.x / 8) + hb / 8;
+  const int tid = threadIdx.x;
+  const int N4 = ag.N4, n = ag.n;
+  const int nblk = (N4 + 7) / 8;
+  if (bx >= nblk) return;
+  constexpr int KC = FE_KC, MREG = KC / 64;
+  __shared__ double vs[R * KC];          // X of the agent, then its Riemannian gradient: [k][a], the arrays' own layout
+  __shared__ double zs[8 * R];
+  __shared__ double red[32 * (8 * R + 1)];
+  __shared__ double Ysh[2 * 4 * R];
+  __shared__ double Esh[2][2 * 4 * R];   // V, Yaux of the two poses
+  __shared__ double Gs[512 * 4];         // the linear term of the public poses, [public pose][c][a]
+  __shared__ double Es[FE_MAX_EDGES * (4 * R + 16)];  // operands of the shared edges: neighbour pose, coefficients
+  FE_TRACE_DECL
+  FE_STAMP(0);
+  const int pj0 = 2 * bx, pj1 = (2 * bx + 1 < n) ? 2 * bx + 1 : -1;
+  const int npose = (pj1 >= 0) ? 2 : 1;
+
+  // ================================================================ the evaluation: one lane per pose, all 8 waves
+  // W_j = sum_i X_i Q_ij + G_j (see the head of the file)
+  const int j = tid;
+  const bool act = j < n;
+  const int jj = act ? j : 0;
+  const int qi = ag.pub_index[jj];  // >= 0: the pose owns shared edges
+  // The linear term G (the neighbours' poses through the shared edges): the operands of every shared edge -- the
+  // neighbour's auxiliary pose, 4R doubles, and the edge's 16 coefficients -- are copied into LDS by all lanes, one double
+  // per lane and trip (consecutive lanes read consecutive doubles of an edge); then one lane per (public pose, row a)
+  // forms its four entries from LDS, edge after edge in g_row_range's order (the host checks npub * R <= 512 and
+  // nshared <= FE_MAX_EDGES).  The neighbour's pose comes straight from its agent's Y array where it is co-resident (or
+  // imported), from the neighbour slab otherwise (g_row_range, aux = 1, pull).
+  constexpr int EPE = 4 * R + 16;                              // doubles per edge in LDS
+  constexpr int NEI = (FE_MAX_EDGES * EPE + 511) / 512;        // trips that cover FE_MAX_EDGES edges
+  const int nsh = ag.nshared, etotal = nsh * EPE;
+  const double *esrc[NEI];
+  int eslot[NEI];
+#pragma unroll
+  for (int i = 0; i < NEI; ++i) {
+    esrc[i] = nullptr; eslot[i] = 0;
+    if (i * 512 < etotal) {  // (uniform; lanes beyond the last double re-read the last edge and drop it)
+      const SharedEdgeDev &se = ag.se[min((tid + 512 * i) / EPE, nsh - 1)];
+      esrc[i] = se.src[1]; eslot[i] = se.slot;
+    }
+  }
+  const int gq = tid / R, ga = tid - gq * R;
+  const bool gact = gq < ag.npub;
+  int ge0 = 0, ge1 = 0;
+  if (ag.npub > 0) {  // (uniform; lanes beyond the last item read the last one and drop it)
+    const int gqc = min(gq, ag.npub - 1);
+    ge0 = ag.pub_ptr[gqc]; ge1 = ag.pub_ptr[gqc + 1];
+  }
+  if (!gact) ge1 = ge0;
+  // operands of the tail (consumed 10 us from here)
+  const size_t own_off = (size_t)((tid >= 4 * R) ? max(pj1, 0) : pj0) * 4 * R + (size_t)(tid % (4 * R));
+  double pre_x = 0, pre_v = 0, pre_y = 0;
+  if (tid < npose * 4 * R) {
+    pre_x = ag.buf[B_X][own_off];
+    pre_v = ag.buf[B_V][own_off];
+    pre_y = ag.buf[B_Y][own_off];
+  }
+  NestState ns = {};
+  if (tid < 128) ns = nest_src[sel];
+  constexpr int NSTG = (KC * R / 2 + 511) / 512;
+  double2 xv[NSTG];
+  {
+    const double *X = ag.buf[B_X];
+#pragma unroll
+    for (int u = 0; u < NSTG; ++u) {
+      const int tt = 2 * (tid + 512 * u);  // N4 * R is even
+      const double2 t = ld2(X + min(tt, N4 * R - 2));
+      xv[u] = (tt < N4 * R) ? t : make_double2(0.0, 0.0);
+    }
+  }
+  // (every wave waits for ITS OWN share of X before it requests the ring: a CU serves its requests in order)
+#pragma unroll
+  for (int u = 0; u < NSTG; ++u) {
+    const int tt = 2 * (tid + 512 * u);
+    if (tt < KC * R) *reinterpret_cast<double2 *>(&vs[tt]) = xv[u];
+  }
+  // second trip of the edge operands (their descriptors were requested first and are back), in front of the ring
+  double ev[NEI];
+#pragma unroll
+  for (int i = 0; i < NEI; ++i) {
+    ev[i] = 0.0;
+    if (i * 512 < etotal) {
+      const int t = tid + 512 * i, e = min(t / EPE, nsh - 1), k = t - (t / EPE) * EPE;
+      // (the descriptor is LOOKED AT here and not earlier: left alone, the compiler resolves each pointer right behind
+      // its loads -- one exposed round trip per descriptor)
+      asm volatile("" : "+v"(esrc[i]), "+v"(eslot[i]));
+      const double *xp = esrc[i] ? esrc[i] : ag.nbr[1] + (size_t)eslot[i] * 4 * R;
+      const double *src = (k < 4 * R) ? xp + k : ag.se[e].coef + (k - 4 * R);
+      // (a pointer that was loaded from memory is a generic pointer to the compiler; a flat load may return out of
+      // order, so its data would be waited for with vmcnt(0): behind the whole ring.  These are global addresses.)
+      ev[i] = *(const __attribute__((address_space(1))) double *)src;
+    }
+  }
+  lds_barrier();  // #1: X is in LDS.  (LDS-only barrier: the edge operands stay in flight)
+  FE_STAMP(1);
+  // the blocks of the row travel through a ring of FE_RING slots: the first FE_RING are requested here -- BEHIND the
+  // barrier: a wave is held at the issue of its loads for as long as the CU's address unit is busy with everybody's
+  // (36 KB-sized requests per wave, 8 waves), and nothing in front of the barrier may wait for that --, slot u + FE_RING
+  // as soon as slot u has been used
+  constexpr int RING = 4;
+  constexpr int Wd = WD;  // = ag.soa_w, 5 .. 8 (the launch picks the instance)
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63;
+  const double *qt = ag.soa_val + (size_t)wv * Wd * 1024 + 2 * ln;  // this wave's tile of blocks, this lane's 16 bytes
+  const int *ct = ag.soa_col + (size_t)wv * Wd * 64 + ln;
+  int idx[RING];
+  double2 B[RING][8];
+#pragma unroll
+  for (int k = 0; k < RING; ++k) {
+    idx[k] = ct[k * 64];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) B[k][q] = ld2(qt + (k * 8 + q) * 128);
+  }
+  // the slab of M (waves 0-3): requested in four parts, each as soon as a slot of the ring is free for good -- behind
+  // every load of the evaluation in the CU's queue (a slab requested earlier holds them back until it has landed:
+  // measured, X staged at 6.5 us instead of 2), and as early as the registers allow: it streams under the rest of the row
+  const int cg = (tid >> 5) & 7, kl = tid & 31;
+  const int col = 8 * bx + cg;
+  const bool cact = col < N4 && tid < 256;
+  const double *Mc = ag.M + (size_t)(cact ? col : 0) * N4;
+  double2 mreg[MREG];
+  double w[4 * R];
+#pragma unroll
+  for (int i = 0; i < 4 * R; ++i) w[i] = 0.0;
+#pragma unroll
+  for (int u = 0; u < WD; ++u) {
+    const int k = u % RING;
+    __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise hoists every gather and refill above the first block and spills)
+    fe_block<R>(vs, idx[k], B[k], w);
+    fe_pin<4 * R>(w);
+    if (u + RING < WD) {
+      idx[k] = ct[(u + RING) * 64];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) B[k][q] = ld2(qt + ((u + RING) * 8 + q) * 128);
+    } else if (tid < 256 && u >= WD - FE_PARTS) {  // (wave-uniform)
+      constexpr int PART = MREG / FE_PARTS;
+      const int part = u - (WD - FE_PARTS);  // 0 .. FE_PARTS - 1
+#pragma unroll
+      for (int m = part * PART; m < (part + 1) * PART; ++m) {
+        const int kk = 2 * kl + 64 * m;
+        const double2 t = ld2_nt(Mc + min(kk, N4 - 2));
+        mreg[m] = (cact && kk < N4) ? t : make_double2(0.0, 0.0);
+      }
+    }
+    if (u == 0) {
+      // the edge operands were requested in front of the ring: they are back with its first slot
+#pragma unroll
+      for (int i = 0; i < NEI; ++i)
+        if (i * 512 < etotal) { const int t = tid + 512 * i; if (t < etotal) Es[t] = ev[i]; }
+    }
+    if (u == 1) {
+      lds_barrier();  // #1a: the edge operands are in LDS
+      if (gact) {
+        // G of (pose gq, row ga): g[c] -= x[cp] coef[cp + 4c], edge after edge (g_row_range's order)
+        double g[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int e = ge0; e < ge1; ++e) {
+          const double *E = Es + (size_t)e * EPE;
+          double x[4];
+#pragma unroll
+          for (int cp = 0; cp < 4; ++cp) x[cp] = E[cp * R + ga];
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int cp = 0; cp < 4; ++cp) g[c] -= x[cp] * E[4 * R + cp + 4 * c];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) Gs[gq * 4 * R + c * R + ga] = g[c];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  lds_barrier();  // #1b: G of every public pose is in LDS
+  if (act && qi >= 0) {
+#pragma unroll
+    for (int i = 0; i < 4 * R; ++i) w[i] = w[i] + Gs[qi * 4 * R + i];
+  }
+  FE_STAMP(2);
+  {
+    double y[4 * R];
+#pragma unroll
+    for (int i = 0; i < 4 * R; ++i) y[i] = vs[(size_t)4 * R * (act ? j : 0) + i];
+    tangent_inplace<R>(y, w);
+  }
+  FE_STAMP(3);
+  lds_barrier();  // #2: nobody reads X in LDS any more; this workgroup's reads of X and of the neighbours' poses are done
+  if (tid == 0) __hip_atomic_fetch_add(&sync[0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (act) {
+#pragma unroll
+    for (int i = 0; i < 4 * R; ++i) vs[(size_t)4 * R * j + i] = w[i];
+  }
+  lds_barrier();  // #3: the gradient is in LDS
+  FE_STAMP(4);
+  if (tid >= 256) {
+    if (bx == 0 && tid == 256) {
+      // what the bookkeeping workgroup of the next k_eval_stats would do (advance_agent, accelerated): into the OTHER
+      // state buffer -- every workgroup of this launch reads nest_src
+      const int na = team->num_agents;
+      const double Nr = (double)num_robots;
+      for (int k = 0; k < na; ++k) {
+        NestState s2 = nest_src[k];
+        const bool restart = ((s2.iter + 2) % restart_interval) == 0;
+        if (restart) { s2.gamma = 0; s2.alpha = 0; }
+        else {
+          s2.gamma = (1.0 + sqrt(1.0 + 4.0 * Nr * Nr * s2.gamma * s2.gamma)) / (2.0 * Nr);
+          s2.alpha = 1.0 / (s2.gamma * Nr);
+        }
+        s2.iter += 1;
+        nest_dst[k] = s2;
+      }
+      team->iter += 1;
+      team->stats_sel = sel;
+      team->next_sel = next_sel;
+      team->cur_sel = next_sel;
+    }
+    lds_barrier();  // #4: (the stream waves' partial sums)
+    FE_FLUSH();
+    return;
+  }
+
+  const double Nr = (double)num_robots;
+  const bool restart_now = ((ns.iter + 2) % restart_interval) == 0;
+  const bool restart_next = ((ns.iter + 3) % restart_interval) == 0;
+  const double nest_gamma = restart_now ? 0.0 : (1.0 + sqrt(1.0 + 4.0 * Nr * Nr * ns.gamma * ns.gamma)) / (2.0 * Nr);
+  const double g2 = (1.0 + sqrt(1.0 + 4.0 * Nr * Nr * nest_gamma * nest_gamma)) / (2.0 * Nr);
+  const double ahead_alpha = 1.0 / (g2 * Nr);
+  const bool ahead_opt = next_sel == sel;
+  double acc[R];
+#pragma unroll
+  for (int a = 0; a < R; ++a) acc[a] = 0;
+#pragma unroll
+  for (int m = 0; m < MREG; ++m) {
+    const int k = 2 * kl + 64 * m;
+    double wv[2 * R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      const double2 t2 = *reinterpret_cast<const double2 *>(&vs[k * R + 2 * q]);
+      wv[2 * q] = t2.x; wv[2 * q + 1] = t2.y;
+    }
+#pragma unroll
+    for (int a = 0; a < R; ++a) acc[a] += wv[a] * mreg[m].x + wv[R + a] * mreg[m].y;
+  }
+  FE_STAMP(5);
+#pragma unroll
+  for (int a = 0; a < R; ++a) red[kl * (8 * R + 1) + cg * R + a] = acc[a];
+  if (tid < npose * 4 * R) { Ysh[tid] = pre_x; Esh[0][tid] = pre_v; Esh[1][tid] = pre_y; }
+  lds_barrier();  // #4
+  if (tid >= 128) { FE_FLUSH(); return; }
+  if (tid < 8 * R) {
+    double s = 0;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) s += red[q * (8 * R + 1) + tid];
+    zs[tid] = s;
+  }
+  FE_STAMP(6);
+  if (tid < 64) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  // nobody stores a pose before every workgroup has formed its gradient (the counter is long complete by then: the
+  // value is requested here and looked at in front of the first store)
+  unsigned long long seen = __hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  auto wait_all = [&]() {
+    int spins = 0;
+    while (seen < target) {
+      if (++spins > FE_SPIN_LIMIT) { *err = 5; break; }
+      seen = __hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+
+  if (tid >= 64) {
+    // ---- look-ahead Nesterov step of iteration k+1 for this workgroup's share of the OTHER agents' poses (second wave;
+    // k_precond<PM_RGD>, ahead bit 1, without the status outputs)
+    const int self = sel;
+    int pre[LOOKAHEAD_MAX_AGENTS + 1];
+    double *px[LOOKAHEAD_MAX_AGENTS], *pv[LOOKAHEAD_MAX_AGENTS], *py[LOOKAHEAD_MAX_AGENTS];
+#pragma unroll
+    for (int k = 0; k <= LOOKAHEAD_MAX_AGENTS; ++k) pre[k] = team->pose_prefix[k];
+    const int na = team->num_agents;
+#pragma unroll
+    for (int k = 0; k < LOOKAHEAD_MAX_AGENTS; ++k) {
+      px[k] = (k < na) ? agents[k].buf[B_X] : nullptr;
+      pv[k] = (k < na) ? agents[k].buf[B_V] : nullptr;
+      py[k] = (k < na) ? agents[k].buf[B_Y] : nullptr;
+    }
+    const int total = pre[LOOKAHEAD_MAX_AGENTS] - n;
+    const int per = (total + nblk - 1) / nblk;  // <= 64, checked by the host
+    const int l1 = tid - 64;
+    const int q = bx * per + l1;
+    if (l1 < per && q < total) {
+      int self_lo = 0;
+#pragma unroll
+      for (int k = 0; k < LOOKAHEAD_MAX_AGENTS; ++k) if (k == self) self_lo = pre[k];
+      const int gq = q < self_lo ? q : q + n;
+      int a = 0, lo = 0;
+      double *xa = px[0], *va = pv[0], *ya = py[0];
+#pragma unroll
+      for (int k = 1; k < LOOKAHEAD_MAX_AGENTS; ++k)
+        if (k < na && gq >= pre[k]) { a = k; lo = pre[k]; xa = px[k]; va = pv[k]; ya = py[k]; }
+      const int la_pose = gq - lo;
+      const bool la_opt = next_sel == a;
+      const size_t o = (size_t)la_pose * 4 * R;
+      double la_x[4 * R], la_v[4 * R];
+#pragma unroll
+      for (int i = 0; i < 4 * R; ++i) { la_x[i] = xa[o + i]; la_v[i] = va[o + i]; }
+      double *oY = ya, *oX = xa, *oV = va;
+      if (restart_next) {
+        wait_all();
+#pragma unroll
+        for (int i = 0; i < 4 * R; ++i) {
+          if (!la_opt) { oY[o + i] = la_x[i]; oV[o + i] = la_x[i]; }
+        }
+      } else {
+        double y[4 * R];
+#pragma unroll
+        for (int i = 0; i < 4 * R; ++i) y[i] = (1.0 - ahead_alpha) * la_x[i] + ahead_alpha * la_v[i];
+        polar_inplace<R>(y);
+        wait_all();
+#pragma unroll
+        for (int i = 0; i < 4 * R; ++i) { oY[o + i] = y[i]; oX[o + i] = y[i]; }
+      }
+    }
+    FE_STAMP(15);
+    FE_FLUSH();
+    return;
+  }
+
+  // ---- one lane per pose finishes the step in registers (k_precond<PM_RGD>, advance = 2, ahead bit 0, no statistics)
+  if (tid < npose) {
+    const int lp = tid;
+    const size_t o = (size_t)(lp ? pj1 : pj0) * 4 * R;
+    double x[4 * R], z[4 * R];
+#pragma unroll
+    for (int i = 0; i < 4 * R; ++i) { x[i] = Ysh[lp * 4 * R + i]; z[i] = zs[lp * 4 * R + i]; }
+    tangent_inplace<R>(x, z);
+#pragma unroll
+    for (int i = 0; i < 4 * R; ++i) x[i] -= step * z[i];
+    qf_inplace<R>(x);
+    FE_STAMP(7);
+    const bool reset = restart_now;  // restart iteration: V = Y = X
+    double v[4 * R];
+    if (reset) {
+#pragma unroll
+      for (int i = 0; i < 4 * R; ++i) v[i] = x[i];
+    } else {
+      const double gamma = nest_gamma;
+#pragma unroll
+      for (int i = 0; i < 4 * R; ++i) v[i] = Esh[0][lp * 4 * R + i] + gamma * (x[i] - Esh[1][lp * 4 * R + i]);
+      polar_inplace<R>(v);
+    }
+    FE_STAMP(8);
+    if (restart_next) {
+      wait_all();
+#pragma unroll
+      for (int i = 0; i < 4 * R; ++i) {
+        ag.buf[B_X][o + i] = x[i];
+        if (!ahead_opt) { ag.buf[B_Y][o + i] = x[i]; v[i] = x[i]; } else if (reset) ag.buf[B_Y][o + i] = x[i];
+      }
+    } else {
+      double y[4 * R];
+#pragma unroll
+      for (int i = 0; i < 4 * R; ++i) y[i] = (1.0 - ahead_alpha) * x[i] + ahead_alpha * v[i];
+      polar_inplace<R>(y);
+      FE_STAMP(9);
+      wait_all();
+#pragma unroll
+      for (int i = 0; i < 4 * R; ++i) { ag.buf[B_Y][o + i] = y[i]; ag.buf[B_X][o + i] = y[i]; }
+    }
+#pragma unroll
+    for (int i = 0; i < 4 * R; ++i) ag.buf[B_V][o + i] = v[i];
+  }
+  FE_STAMP(15);
+  FE_FLUSH();
+}
+
+// r <= 5: R * 2048 + 256 * 4R doubles of LDS next to the partial sums (133 KB at r = 5)
+bool step_fe_supported(int r) { return r >= 3 && r <= 5; }
+int step_fe_max_edges() { return FE_MAX_EDGES; }
+
+void launch_step_fe(const LaunchCtx &c, int sel, int next_sel, double step, int num_robots, int restart_interval,
+                    const NestState *nest_src, NestState *nest_dst, unsigned long long *sync, unsigned long long target, int *err) {
+  const AgentDev &d = c.host_agents[sel];
+  const int grid = ((d.N4 + 7) / 8 + 7) / 8 * 8;
+#define FE_LAUNCH(RR, WW)                                                                                              \
+  hipLaunchKernelGGL((k_step_fe<RR, WW>), dim3(grid), dim3(512), 0, c.stream, c.agents, c.team, sel, next_sel, step, num_robots, \
+                     restart_interval, nest_src, nest_dst, sync, target, err, d)
+#define FE_LAUNCH_W(RR)                                                                                                \
+  switch (d.soa_w) {                                                                                                   \
+    case 5: FE_LAUNCH(RR, 5); break;                                                                                   \
+    case 6: FE_LAUNCH(RR, 6); break;                                                                                   \
+    case 7: FE_LAUNCH(RR, 7); break;                                                                                   \
+    case 8: FE_LAUNCH(RR, 8); break;                                                                                   \
+    default: break;                                                                                                    \
+  }
+  switch (c.r) {
+    case 3: FE_LAUNCH_W(3); break;
+    case 4: FE_LAUNCH_W(4); break;
+    case 5: FE_LAUNCH_W(5); break;
+    default: break;
+  }
+#undef FE_LAUNCH_W
+#undef FE_LAUNCH
+}
+
+}  // namespace dpgo

@@ -102,7 +102,7 @@ struct Agent {
   std::vector<double> qval;
   int npub = 0;
   // device storage
-  DevBuf<int> d_rowptr, d_col, d_pub_pose, d_pub_ptr, d_idx, d_ell_col, d_trowptr, d_tcol, d_pub_index;
+  DevBuf<int> d_rowptr, d_col, d_pub_pose, d_pub_ptr, d_idx, d_ell_col, d_trowptr, d_tcol, d_pub_index, d_soa_col;
   int precond = DPGO_PRECOND_DENSE;  // what this agent runs (decided when its data matrices are built)
   DevBuf<double> d_dinv;
   // two-level form of the preconditioner (twolevel.h): the dissection (kept while the sparsity pattern stands; a weight
@@ -115,7 +115,8 @@ struct Agent {
   DevBuf<dpgo::TLWg> d_tl_wg;
   DevBuf<double> d_tl_slabs, d_tl_u;
   DevBuf<unsigned long long> d_tl_flag;
-  DevBuf<double> d_qval, d_M, d_vec, d_nbr, d_part, d_scal, d_resid, d_ell_val, d_tval;
+  DevBuf<double> d_qval, d_M, d_vec, d_nbr, d_part, d_scal, d_resid, d_ell_val, d_tval, d_soa_val;
+  bool has_soa = false;  // every row fits the ELL part: the blocks are also stored [slot][chunk][pose] (step_fused.hip)
   std::map<int, std::unique_ptr<DevBuf<int>>> d_pubframes, d_nbrslots;  // per neighbour, cached on the device
   std::map<int, int> n_pubframes, n_nbrslots;
   DevBuf<int> d_pub_all;  // the public frames of every neighbour, concatenated in neighbour order (one pack launch)
@@ -189,6 +190,7 @@ struct dpgo_team {
   dpgo::RtrState *h_state = nullptr;  // pinned
   double *h_scal = nullptr;     // pinned [16]
   static constexpr int MAX_GRAPH_ITERS = 64;       // iterations captured in one graph (one graph per distinct count)
+  static constexpr int MAX_PIPELINED_GRAPH_ITERS = 256;  // ... of the uniform pipelined accelerated-RGD sequence
   std::map<int, hipGraphExec_t> graphs;            // key: see dpgo_team_run
   std::map<int, int> graph_flip;
   bool graph_valid = false;
@@ -207,6 +209,10 @@ struct dpgo_team {
   // time-out flag of the in-kernel exchanges (pinned), CU count
   dpgo_host::DevBuf<dpgo::NestState> d_nest_all;  // NestState of local agent k at [k]: one array, so that a kernel finds any agent's
                                                    // state from the agent index alone (no descriptor round trip)
+  // one-launch iterations (step_fused.hip): d_nest_all holds three copies of the NestStates -- the team's own at
+  // [0, num_local), the two alternating buffers of the fused launches behind it -- and one arrival counter
+  dpgo_host::DevBuf<unsigned long long> d_fe_sync;
+  int use_fused_eval = 1;  // DPGO_FUSED_EVAL=0: every pipelined iteration takes the two-launch sequence
   int *h_bar_err = nullptr;
   int num_cus = 0;
   int max_lds = 160 * 1024;  // hipDeviceAttributeMaxSharedMemoryPerBlock

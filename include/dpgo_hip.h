@@ -256,7 +256,9 @@ int dpgo_team_run_schedule(dpgo_team_t *t, int max_iters, int *terminated, int *
 /* refresh this agent's neighbour slabs from co-resident agents (device-to-device) */
 int dpgo_agent_pull_local(dpgo_team_t *t, int id);
 /* average HIP-event duration of one launch of a hot kernel on the team stream.
- * which: 0 dense preconditioner apply, 1 cost+gradient SpMM, 2 Hessian-vector SpMM */
+ * which: 0 dense preconditioner apply, 1 cost+gradient SpMM, 2 Hessian-vector SpMM; 9 / 10 / 11 the step kernel of the
+ * pipelined sequence back to back / that sequence launched eagerly / its evaluation launches alone; 14 the one-launch
+ * iteration (csrc/step_fused.hip) launched eagerly, real iterations (fails where the team cannot take that form) */
 int dpgo_team_time_kernel(dpgo_team_t *t, int id, int which, int reps, double *avg_ms, double *algorithmic_bytes);
 /* peer access for one-process-per-GPU runs of the asynchronous mode (src/PGOAgentROS.cpp:119-127): a robot's X / Y arrays
  * exported as a 64-byte HIP IPC handle (+ the offsets of X and Y in doubles and its pose count), imported by the
@@ -281,7 +283,8 @@ int dpgo_agent_read_rtr_handoff(dpgo_team_t *t, int id, unsigned long long *out,
 int dpgo_agent_read_partials(dpgo_team_t *t, int id, int offset, double *out, int n);
 /* counters for the roofline report: launches and algorithmic bytes of the dominant kernels ([0] preconditioner applies,
  * [1] their bytes, [2] sparse evaluations, [3] their bytes, [4] iterations); diagnostics of the per-agent API: [5] host
- * microseconds between the launch of a report kernel and the arrival of its sequence word, [6] reports */
+ * microseconds between the launch of a report kernel and the arrival of its sequence word, [6] reports; [7] iterations
+ * of dpgo_team_run that took the one-launch form (csrc/step_fused.hip) */
 int dpgo_team_get_counters(dpgo_team_t *t, double *out, int n);
 
 #ifdef __cplusplus

@@ -1,0 +1,119 @@
+"""The one-launch pipelined iteration (csrc/step_fused.hip: evaluation + preconditioner stream + RGD step + Nesterov in
+one kernel): its iterates are BITWISE those of the two-launch sequence (k_eval_stats,
+k_precond<PM_RGD>) -- same arithmetic in the same order --, both follow the oracle, and teams it cannot serve keep the
+two-launch sequence.  DPGO_FUSED_EVAL is read when a team is created."""
+import os
+
+import numpy as np
+import pytest
+
+from dpgo_ros_amd import capi
+from oracle import oracle as O
+from tests.util import load, make_pair
+
+pytestmark = pytest.mark.gpu
+
+RGD = dict(method=1, acceleration=1, rgd_stepsize=0.2, rgd_use_preconditioner=1, restart_interval=20)
+
+
+def _team(dataset, robots, fused, r=5, **kw):
+    old = os.environ.get("DPGO_FUSED_EVAL")
+    os.environ["DPGO_FUSED_EVAL"] = "1" if fused else "0"
+    try:
+        m, mp, n = load(dataset, robots)
+        prm = capi.default_params(r=r, num_robots=robots, **kw)
+        t = capi.Team.from_measurements(mp.view(capi.MEAS_DTYPE), prm)
+        t.set_initial(O.odometry_init(m, n), O.fixed_stiefel(r))
+    finally:
+        if old is None:
+            os.environ.pop("DPGO_FUSED_EVAL", None)
+        else:
+            os.environ["DPGO_FUSED_EVAL"] = old
+    return t
+
+
+@pytest.mark.parametrize("robots,r", [(5, 5), (8, 5), (5, 3), (6, 4)])
+def test_one_launch_iterations_bitwise_equal_the_two_launch_sequence(robots, r):
+    """sphere2500 over 5 / 6 / 8 robots (500 / 416 / 312 poses), runs of several lengths: whole graphs of 256 iterations,
+    short graphs, restarts (every 20 iterations) inside and at the edges of the one-launch part"""
+    ta, tb = _team("sphere2500", robots, False, r=r, **RGD), _team("sphere2500", robots, True, r=r, **RGD)
+    for iters in (23, 300, 64, 7, 129):
+        ta.run(iters)
+        ta.synchronize()
+        tb.run(iters)
+        tb.synchronize()
+        for k in ta.ids:
+            assert np.array_equal(ta.agents[k].get_X(), tb.agents[k].get_X()), (robots, r, iters, k)
+        sa, sb = ta.agents[ta.ids[-1]].status(), tb.agents[tb.ids[-1]].status()
+        assert sa.iteration_number == sb.iteration_number and sa.relative_change == sb.relative_change
+    assert ta.counters()[7] == 0
+    # 23 = 17 + 5 + 1, 300 = 256 + 44, ...: every graph longer than period + 1 leaves period + 1 iterations to the two-launch form
+    P = robots
+    expect = sum(max(0, b - P - 1) for b in (23, 256, 44, 64, 7, 129))
+    assert tb.counters()[7] == expect, (tb.counters()[7], expect)
+    assert np.isclose(ta.cost(), tb.cost(), rtol=0, atol=0)
+    ta.close()
+    tb.close()
+
+
+def test_one_launch_iterations_follow_the_oracle():
+    """120 iterations of the bench configuration against the live oracle (the two-launch sequence is held to the same
+    bound in test_gpu_parity.py)"""
+    th, to, n = make_pair("sphere2500", 5, **RGD)
+    th.run(120)
+    th.synchronize()
+    for _ in range(120):
+        to.iterate()
+    assert th.counters()[7] > 0
+    for k in th.ids:
+        assert np.abs(th.agents[k].get_X() - to.agents[k].get_X()).max() < 1e-10
+    th.close()
+
+
+def test_teams_the_one_launch_form_cannot_serve_keep_the_two_launch_sequence():
+    """agents beyond 512 poses (torus3D / 8: 625), agents of <= 256 poses (sphere2500 / 10), the two-level form, no
+    acceleration: dpgo_team_run runs, counters[7] stays 0"""
+    cases = [("torus3D", 8, dict(RGD)), ("sphere2500", 10, dict(RGD)),
+             ("sphere2500", 5, dict(RGD, precond_mode=capi.PRECOND_TWO_LEVEL)), ("sphere2500", 5, dict(RGD, acceleration=0))]
+    for dataset, robots, kw in cases:
+        t = _team(dataset, robots, True, **kw)
+        c0 = t.cost()
+        t.run(40)
+        t.synchronize()
+        assert t.counters()[7] == 0, (dataset, robots, kw)
+        assert t.cost() < c0
+        t.close()
+
+
+def test_a_second_team_on_the_device_takes_the_two_launch_sequence_while_the_first_holds_the_lock():
+    """the workgroups of a one-launch iteration wait for each other before they store: one team per device at a time
+    (the lock of the one-launch RTR solve); the other team's run is the two-launch sequence, same iterates"""
+    ta, tb = _team("sphere2500", 5, True, **RGD), _team("sphere2500", 5, True, **RGD)
+    ta.run(40)          # not synchronized: ta holds the lock
+    tb.run(40)
+    ta.synchronize()
+    tb.synchronize()
+    assert ta.counters()[7] > 0 and tb.counters()[7] == 0
+    for k in ta.ids:
+        assert np.array_equal(ta.agents[k].get_X(), tb.agents[k].get_X())
+    tb.run(40)          # ta has synchronized: the lock is free
+    tb.synchronize()
+    assert tb.counters()[7] > 0
+    ta.close()
+    tb.close()
+
+
+def test_dispatch_to_dispatch_timing_entry():
+    """dpgo_team_time_kernel(14) (bench.py's roofline leg): reps + 8 one-launch iterations launched eagerly; like the
+    other in-loop timing entries it consumes the state (its last iteration has looked ahead); teams that cannot take
+    the one-launch form get an error"""
+    tb = _team("sphere2500", 5, True, **RGD)
+    c0 = tb.cost()
+    ms, nbytes = tb.time_kernel(0, 14, reps=42)
+    assert 0.005 < ms < 0.1 and nbytes > 32e6
+    assert tb.cost() < c0
+    tb.close()
+    tc = _team("torus3D", 8, True, **RGD)
+    with pytest.raises(capi.DpgoError):
+        tc.time_kernel(0, 14, reps=4)
+    tc.close()
