@@ -228,7 +228,7 @@ class DistributedRBCD:
         self.k = 0
         self.max_delay = int(max_delayed_iterations)
         self.version = [0] * num_robots   # iteration at which each agent's public poses last changed
-        self.sent = {}                    # (b, sel) -> version of b that sel's rank holds
+        self.sent = {}                    # (b, sel, sequence) -> version of b's X (0) / Y (1) that sel's rank holds
         self.messages = 0                 # point-to-point operations issued by this rank (for the tests / bench)
         self._imported, self.peer_access, self.peer_error = set(), False, None
         self._mail_imported = set()
@@ -257,12 +257,15 @@ class DistributedRBCD:
             rb = self.owner[b]
             if rb == rs:
                 continue
-            held = self.sent.get((b, sel))
-            if not force and held is not None:
-                behind = self.version[b] - held
+            # the gate is kept PER SEQUENCE (0 = X, 1 = auxiliary Y): a copy of X that is fresh enough says nothing about
+            # Y -- an X-only exchange (colour sweep, lockstep tick) followed by an accelerated step must still deliver Y
+            held = [self.sent.get((b, sel, q)) for q in seqs]
+            if not force and all(h is not None for h in held):
+                behind = max(self.version[b] - h for h in held)
                 if behind == 0 or behind <= self.max_delay:
-                    continue  # the copy on sel's rank is current, or fresh enough for the staleness gate
-            self.sent[(b, sel)] = self.version[b]
+                    continue  # the copies on sel's rank are current, or fresh enough for the staleness gate
+            for q in seqs:
+                self.sent[(b, sel, q)] = self.version[b]
             cnt = self.npub[(b, sel)]
             if self.rank == rb:
                 ops.append(d.P2POp(d.isend, self.be.pack(b, sel, seqs, cnt), rs))

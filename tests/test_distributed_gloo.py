@@ -389,3 +389,55 @@ def test_staleness_gate_with_delayed_iterations(cfg):
         assert 0 < msgs <= 2 * 2 * iters
     else:
         assert msgs < 2 * 2 * iters
+
+
+def test_staleness_gate_is_kept_per_sequence():
+    """an X-only exchange (colour sweep / lockstep tick / exchange_to(sel, (0,))) must not make the gate skip the
+    auxiliary sequence of a later accelerated step, whatever max_delayed_iterations allows for X (host logic only: a
+    recording stand-in for torch.distributed, rank 0 of 2)"""
+    from dpgo_ros_amd.distributed import DistributedRBCD
+
+    class FakeDist:
+        isend, irecv = "isend", "irecv"
+
+        @staticmethod
+        def P2POp(op, t, peer):
+            return (op, t, peer)
+
+        @staticmethod
+        def batch_isend_irecv(ops):
+            return []
+
+    class Recorder:
+        def __init__(self):
+            self.packed, self.unpacked = [], []
+
+        def iterate(self, agent, do_opt):
+            return True
+
+        def pack(self, agent, nbr, seqs, count):
+            self.packed.append((agent, nbr, tuple(seqs)))
+            return None
+
+        def recv_buffer(self, agent, nbr, seqs, count):
+            return None
+
+        def unpack(self, agent, nbr, seqs, tensor):
+            self.unpacked.append((agent, nbr, tuple(seqs)))
+
+        def pull_local(self, agent):
+            pass
+
+    m, mp, n = load("smallGrid3D", 2)
+    for delay in (0, 2):
+        be = Recorder()
+        drv = DistributedRBCD(FakeDist, be, mp, 2, 1, 0, 2, max_delayed_iterations=delay)
+        drv.exchange_to(0, (0,))                    # robot 1 (rank 1) -> robot 0 (rank 0): X only
+        assert be.unpacked == [(0, 1, (0,))]
+        assert drv.step() == 0                      # accelerated: robot 0 needs X AND Y of robot 1
+        assert be.unpacked[-1] == (0, 1, (0, 1)), (delay, be.unpacked)
+        n_before = len(be.unpacked)
+        drv.exchange_to(0, (0, 1))                  # nothing moved since: both sequences are current
+        assert len(be.unpacked) == n_before
+        assert drv.step() == 1                      # robot 1 optimizes on rank 1: rank 0 packs robot 0's poses for it
+        assert be.packed[-1] == (0, 1, (0, 1))
