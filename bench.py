@@ -386,9 +386,9 @@ def gnc_leg(capi):
 # HBM traffic per launch (KB) from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in
 # separate runs of this command, profiles/collect.sh; FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md)
 PMC = {"source": "profiles/r03_pmc_fetch.md, profiles/r03_pmc_write.md",
-       "dense": {"step": (16572.0, 846.1), "apply": (16081.1, 85.9),       # k_precond<5,3,2048,false,true>, k_precond<5,0,2048,false,false>
-                 "fused_step": (16572.0, 846.1)},                           # k_step_fe<5,5>
-       "two_level": {"step": (5503.4, 894.8), "apply": (4936.4, 125.3)}}   # k_precond<5,3,0,true,false>,    k_precond<5,0,0,true,false>
+       "dense": {"step": (16560.5, 851.7), "apply": (16081.5, 85.9),       # k_precond<5,3,2048,false,true,true>, k_precond<5,0,2048,false,false,false>
+                 "fused_step": (18026.1, 860.6)},                           # k_step_fe<5,5>: + the sparse operator and X once per XCD L2
+       "two_level": {"step": (5476.0, 891.1), "apply": (4951.2, 125.3)}}   # k_precond<5,3,0,true,true,true>, k_precond<5,0,0,true,false,false>
 
 
 def roofline_leg(team, agent_id, form="dense"):
