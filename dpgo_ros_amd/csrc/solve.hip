@@ -451,6 +451,30 @@ int enqueue_optimize_group(dpgo_team *t, int g) {
     }
     return 0;
   }
+  // The members of a class share no edge: their block updates commute, and on ONE device nothing is gained by running
+  // them in the same launches -- the launch-per-step sequence below (grid.y = members) measured 0.37 ms per block update
+  // against 0.30 for the one-launch solve of one agent after the other, which needs the whole device.  Where every
+  // member can take the one-launch solve, the class is a sequence of those (the parallelism of a class is across GPUs:
+  // DistributedRBCD.sweep_colored, one rank per member).
+  if (t->use_fused_rtr) {
+    bool all = true;
+    for (int k : mem) {
+      const Agent &a = *t->ag[k];
+      const bool tl_fused = a.precond == DPGO_PRECOND_TWO_LEVEL && a.tl_plan.prod_post &&
+                            rtr_fused_tl_eligible(p.r, a.tl_plan.nwg - a.tl_plan.nS2, tl_max_pre_poses(a.tl_plan), a.tl_plan.ns, t->num_cus, t->max_lds);
+      const bool dense_fused = a.dev.M && rtr_fused_eligible(p.r, a.n, t->num_cus) && rtr_fused_lds_bytes(p.r, a.n) <= (size_t)t->max_lds;
+      all = all && (tl_fused || dense_fused);
+    }
+    if (all) {
+      OptFlags fl;
+      fl.pull = 1;
+      for (int k : mem) {
+        const int rc = enqueue_optimize(t, k, fl);
+        if (rc) return rc;
+      }
+      return 0;
+    }
+  }
   for (int k : mem) if (refresh_rtr_result(t, *t->ag[k])) return DPGO_ERR;
   launch_eval(c, sel, mn, B_X, B_EGRAD, B_GF, PART_A, eval_opts(t, 2, 0, 0));
   launch_rtr_begin(c, sel, p.rtr_initial_radius, p.gradnorm_tol, p.rtr_iterations);

@@ -526,11 +526,13 @@ def test_full_size_properties_sphere2500():
     t.close()
 
 
-@pytest.mark.parametrize("dataset,N,method", [("sphere2500", 5, capi.METHOD_RTR), ("sphere2500", 8, capi.METHOD_RGD),
-                                               ("smallGrid3D", 3, capi.METHOD_RTR)])
-def test_colour_parallel_sweeps_equal_the_permuted_sequential_schedule(dataset, N, method):
-    """agents of one colour class update in the same launches; the result must equal the
+@pytest.mark.parametrize("dataset,N,method,fused_rtr", [("sphere2500", 5, capi.METHOD_RTR, 1), ("sphere2500", 8, capi.METHOD_RGD, 1),
+                                                         ("smallGrid3D", 3, capi.METHOD_RTR, 1), ("sphere2500", 5, capi.METHOD_RTR, 0)])
+def test_colour_parallel_sweeps_equal_the_permuted_sequential_schedule(dataset, N, method, fused_rtr, monkeypatch):
+    """agents of one colour class update together (RGD, and RTR without the one-launch solve: in the same
+    launches; RTR with it: one one-launch solve after the other -- the members share no edge); the result must equal the
     sequential schedule [class 0 ..., class 1 ...] -- bitwise on the HIP path, to tolerance vs the oracle."""
+    monkeypatch.setenv("DPGO_FUSED_RTR", str(fused_rtr))   # (read when a team is created)
     kw = dict(method=method, acceleration=0, rgd_stepsize=0.2, gradnorm_tol=1e-2)
     th, to, n = make_pair(dataset, N, **kw)
     nc, col = th.coloring()
@@ -547,10 +549,9 @@ def test_colour_parallel_sweeps_equal_the_permuted_sequential_schedule(dataset, 
     ts, _, _ = make_pair(dataset, N, **kw)
     ts.set_schedule(order)
     ts.run(sweeps * N)
-    # RGD: same kernels, same order of arithmetic per agent.  RTR: the sequential schedule takes the one-launch solve
-    # (rtr_fused.hip), the colour classes the launch-per-step kernels -- the same arithmetic up to the order in which
-    # a preconditioner row is summed
-    if kw.get("method", 0) == 1:
+    # RGD, launch-per-step RTR: same kernels, same order of arithmetic per agent.  One-launch RTR solves: the sequential
+    # schedule folds the iteration's tail into the solve kernel, the class does not -- round-off apart
+    if method == capi.METHOD_RGD or not fused_rtr:
         assert np.array_equal(ts.global_X(), th.global_X())
     else:
         assert np.abs(ts.global_X() - th.global_X()).max() < 1e-9
