@@ -14,6 +14,9 @@
 namespace dpgo {
 
 constexpr int NB = 32;
+#ifndef DPGO_SOLVE_SBK
+#define DPGO_SOLVE_SBK 8
+#endif
 
 // one matrix of a batch: the kernels take the batch index from blockIdx.z, so that the many small, dependent steps
 // of several inversions (one per agent) share their launches
@@ -264,6 +267,66 @@ __global__ __launch_bounds__(256) void k_syrk(const InvJob *jobs, int kb, int *f
     __threadfence();
     __syncthreads();
     if (tid < 64) potrf_diag_body(jb_, kb + 1, fail, (int)blockIdx.z, &As[0][0]);  // (the operand tiles are done with)
+  }
+}
+
+// Trailing update by SUPER-BLOCKS (dense_spd_solve: one large system, the chordal relaxation's 7500^2): a rank-32 update
+// of the whole trailing matrix reads and writes it once per block column -- n^3 / (3 NB) x 16 bytes, 14 ms of HBM time
+// at n = 7500 -- so the columns beyond the current super-block (SBK block columns) are left alone until the super-block
+// is factored and then receive all of its block columns in ONE pass (K = SBK x NB, accumulated in registers); inside
+// the super-block every block column still updates the (few) columns up to its end at once.
+//   A[i, j] -= sum_{kb0 <= kb < kb0 + nk} P_kb[i, :] P_kb[j, :]^T   for t0 <= j < jhi, i >= j;  tile (0, 0) factors the
+//   diagonal block `next_kb` (>= 0) when it is done, as k_syrk does
+__global__ __launch_bounds__(256) void k_syrk_sb(const InvJob *jobs, int kb0, int nk, int t0, int jhi, int next_kb, int *fail) {
+  const InvJob jb_ = jobs[blockIdx.z];
+  double *A = jb_.A;
+  const int N = jb_.N;
+  const int bi = blockIdx.x, bj = blockIdx.y;
+  const int i0 = t0 + 64 * bi, j0 = t0 + 64 * bj;
+  if (bj > bi || i0 >= N || j0 >= jhi) return;
+  __shared__ double As[NB][65], Bs[NB][65];
+  const int tid = threadIdx.x;
+  TileAcc acc;
+  tile_zero(acc);
+  for (int q = 0; q < nk; ++q) {
+    const int k0 = (kb0 + q) * NB, nb = min(NB, N - k0);
+    if (q > 0) __syncthreads();
+    stage_tiles2(tid,
+                 [&](int t) { return A + (size_t)(k0 + min(t >> 6, nb - 1)) * N + min(i0 + (t & 63), N - 1); },
+                 [&](int t) { return (t >> 6) < nb && i0 + (t & 63) < N; },
+                 [&](int t, double v) { As[t >> 6][t & 63] = v; },
+                 [&](int t) { return A + (size_t)(k0 + min(t >> 6, nb - 1)) * N + min(j0 + (t & 63), N - 1); },
+                 [&](int t) { return (t >> 6) < nb && j0 + (t & 63) < N; },
+                 [&](int t, double v) { Bs[t >> 6][t & 63] = v; });
+    __syncthreads();
+    tile_mac(As, Bs, tid, acc);
+  }
+  {
+    double old[2][2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int v = 0; v < 2; ++v)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int i = min(i0 + tile_row(tid, u), N - 1), j = min(j0 + tile_col(tid, v, q), N - 1);
+          old[u][v][q] = A[(size_t)j * N + i];
+        }
+    const int jend = min(N, jhi);
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int v = 0; v < 2; ++v)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int i = i0 + tile_row(tid, u), j = j0 + tile_col(tid, v, q);
+          if (i < N && j < jend && i >= j) A[(size_t)j * N + i] = old[u][v][q] - acc.c[u][v][q];
+        }
+  }
+  if (bi == 0 && bj == 0 && next_kb >= 0 && next_kb < jb_.nblk) {
+    __threadfence();
+    __syncthreads();
+    if (tid < 64) potrf_diag_body(jb_, next_kb, fail, (int)blockIdx.z, &As[0][0]);
   }
 }
 
@@ -531,13 +594,19 @@ int dense_spd_solve(hipStream_t stream, double *A, int N, double *B, double *Y) 
   job.Linv = Linv;
   (void)hipMemcpyAsync(job_d, &job, sizeof(InvJob), hipMemcpyHostToDevice, stream);
   (void)hipMemsetAsync(fail_d, 0, sizeof(int), stream);
-  for (int kb = 0; kb < job.nblk; ++kb) {
-    const int s0 = (kb + 1) * NB;
-    if (kb == 0) hipLaunchKernelGGL(k_potrf_diag, dim3(1, 1, 1), dim3(64), 0, stream, job_d, kb, fail_d);
-    if (s0 < N) {
-      hipLaunchKernelGGL(k_trsm_panel, dim3((N - s0 + 63) / 64, 1, 1), dim3(256), 0, stream, job_d, kb);
+  constexpr int SBK = DPGO_SOLVE_SBK;  // block columns per super-block (k_syrk_sb)
+  for (int sb0 = 0; sb0 < job.nblk; sb0 += SBK) {
+    const int sb1 = std::min(sb0 + SBK, job.nblk), c1 = std::min(N, sb1 * NB);
+    for (int kb = sb0; kb < sb1; ++kb) {
+      const int s0 = (kb + 1) * NB;
+      if (kb == 0) hipLaunchKernelGGL(k_potrf_diag, dim3(1, 1, 1), dim3(64), 0, stream, job_d, kb, fail_d);
+      if (s0 >= N) continue;
       const int nt = (N - s0 + 63) / 64;
-      hipLaunchKernelGGL(k_syrk, dim3(nt, nt, 1), dim3(256), 0, stream, job_d, kb, fail_d);
+      hipLaunchKernelGGL(k_trsm_panel, dim3(nt, 1, 1), dim3(256), 0, stream, job_d, kb);
+      if (kb + 1 < sb1)  // inside the super-block: this block column alone, onto the columns up to the super-block's end
+        hipLaunchKernelGGL(k_syrk_sb, dim3(nt, (c1 - s0 + 63) / 64, 1), dim3(256), 0, stream, job_d, kb, 1, s0, c1, kb + 1, fail_d);
+      else               // its last block column: all of them onto everything beyond
+        hipLaunchKernelGGL(k_syrk_sb, dim3(nt, nt, 1), dim3(256), 0, stream, job_d, sb0, sb1 - sb0, s0, N, kb + 1, fail_d);
     }
   }
   for (int kb = 0; kb < job.nblk; ++kb) {
