@@ -2,6 +2,9 @@
 // preconditioner and the device descriptors of a team (PoseGraph of the reference: constructQ/constructG,
 // SURVEY 8a rows 'PoseGraph data matrices').
 #include "team_internal.h"
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 using namespace dpgo;
 
@@ -82,13 +85,39 @@ std::vector<int> neighbor_ids(const Agent &a, int nbr) {
 
 // connection Laplacian in block-CSR (row j lists (i, Q_ij)); duplicates merged in insertion order
 void build_Q(Agent &a) {
+  double TO[16], TOT[16], Om[16];
+  if (a.struct_uploaded && (int)a.rowptr.size() == a.n + 1 && a.qval.size() == 16 * a.col.size()) {
+    // same measurements, new weights (an UPDATE_WEIGHT round): the pattern stands, the blocks are accumulated in place --
+    // in the order of the general path below, so the values are bitwise the same (the per-row maps were 1 ms of a round)
+    std::fill(a.qval.begin(), a.qval.end(), 0.0);
+    auto add = [&](int row, int colm, const double *v, bool transpose, double sign) {
+      int p = a.rowptr[row];
+      while (a.col[p] != colm) ++p;  // (present by construction: the pattern came from these measurements)
+      double *blk = a.qval.data() + (size_t)16 * p;
+      for (int cp = 0; cp < 4; ++cp)
+        for (int c = 0; c < 4; ++c) blk[cp + 4 * c] += sign * (transpose ? v[c + 4 * cp] : v[cp + 4 * c]);
+    };
+    for (int pass = 0; pass < 2; ++pass)
+      for (auto &m : (pass ? a.priv : a.odom)) {
+        edge_blocks(m, TO, TOT, Om);
+        add(m.p1, m.p1, TOT, false, 1.0);
+        add(m.p2, m.p2, Om, false, 1.0);
+        add(m.p2, m.p1, TO, false, -1.0);
+        add(m.p1, m.p2, TO, true, -1.0);
+      }
+    for (auto &m : a.shared) {
+      edge_blocks(m, TO, TOT, Om);
+      if (m.r1 == a.id) add(m.p1, m.p1, TOT, false, 1.0);
+      else add(m.p2, m.p2, Om, false, 1.0);
+    }
+    return;
+  }
   std::vector<std::map<int, std::array<double, 16>>> rows(a.n);
   auto add = [&](int row, int colm, const double *v, bool transpose, double sign) {
     auto &blk = rows[row][colm];
     for (int cp = 0; cp < 4; ++cp)
       for (int c = 0; c < 4; ++c) blk[cp + 4 * c] += sign * (transpose ? v[c + 4 * cp] : v[cp + 4 * c]);
   };
-  double TO[16], TOT[16], Om[16];
   for (int i = 0; i < a.n; ++i) rows[i][i];  // every pose owns a diagonal block
   for (int pass = 0; pass < 2; ++pass)
     for (auto &m : (pass ? a.priv : a.odom)) {
@@ -451,6 +480,9 @@ int sync_descs_noflush(dpgo_team *t) {
     (void)hipMemGetInfo(&free_b, &total_b);
     double budget = (double)free_b + 8.0 * (double)t->d_tmp.n;  // the scratch of an earlier pass is reused
     bool any_dirty = false;
+    static const bool timing = std::getenv("DPGO_TIMING") != nullptr;
+    const auto q0 = std::chrono::steady_clock::now();
+    auto since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
     for (auto &a : t->ag) {
       rebuild_index(*a);
       if (!a->data_dirty) continue;
@@ -459,6 +491,8 @@ int sync_descs_noflush(dpgo_team *t) {
       if (choose_precond(t, *a, budget)) return DPGO_ERR;
       if (a->precond == DPGO_PRECOND_DENSE) total += 2 * (size_t)(4 * a->n) * (4 * a->n);
     }
+    const double t_q = since(q0);
+    const auto q1 = std::chrono::steady_clock::now();
     if (any_dirty) {
       if (total && t->d_tmp.alloc(total)) { set_err("scratch allocation failed"); return DPGO_ERR; }
       std::vector<double *> As, Ws, Ms;
@@ -480,6 +514,8 @@ int sync_descs_noflush(dpgo_team *t) {
         if (rc) return rc;
         As.push_back(A); Ws.push_back(W); Ms.push_back(a->d_M.p); Ns.push_back(4 * a->n);
       }
+      const double t_fin = since(q1);
+      const auto q2 = std::chrono::steady_clock::now();
       const int fail = dense_spd_inverse_batched(t->stream, (int)Ns.size(), As.data(), Ws.data(), Ms.data(), Ns.data());
       if (fail != 0) {
         set_err("dense Cholesky of Q + shift I failed at pivot " + std::to_string(fail & 0xffffff) + " (matrix " +
@@ -487,7 +523,12 @@ int sync_descs_noflush(dpgo_team *t) {
         return DPGO_ERR;
       }
       // (the dense batch is done with the scratch: the two-level set-up reuses it)
+      const double t_inv = since(q2);
+      const auto q3 = std::chrono::steady_clock::now();
       if (tl_build(t, tl_agents)) return DPGO_ERR;
+      if (timing)
+        std::fprintf(stderr, "sync_descs: index + Q %.2f  finalize (tables, uploads) %.2f  dense inversions %.2f  two-level set-up %.2f ms\n",
+                     t_q, t_fin, t_inv, since(q3));
       t->dense_max_n = 0;
       for (auto &a : t->ag) if (a->precond == DPGO_PRECOND_DENSE) t->dense_max_n = std::max(t->dense_max_n, a->n);
       t->precond_of.clear();

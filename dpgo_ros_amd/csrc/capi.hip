@@ -2,7 +2,9 @@
 #include <unistd.h>
 
 #include <atomic>
+#include <array>
 #include <chrono>
+#include <unordered_map>
 
 #include "team_internal.h"
 
@@ -1298,24 +1300,59 @@ int dpgo_team_cost(dpgo_team_t *t, double *f) {
 }
 
 int dpgo_team_update_weights(dpgo_team_t *t) {
+  static const bool timing = std::getenv("DPGO_TIMING") != nullptr;  // stage times of a round on stderr (profiles/experiments)
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+    return std::chrono::duration<double, std::milli>(b - a).count();
+  };
+  const auto q0 = now();
   if (sync_descs(t)) return DPGO_ERR;
   if (dpgo_team_exchange_all(t)) return DPGO_ERR;
+  const auto q1 = now();
   int changed = 0;
   // all weights first (every agent's residuals come from the current iterate), then ONE rebuild of the data
   // matrices and preconditioners of the whole team (batched dense inversions)
   for (auto &a : t->ag) if (update_weights_of(t, a.get())) return DPGO_ERR;
-  for (auto &a : t->ag)
-    for (auto &m : a->shared) {
-      const int other = (m.r1 == a->id) ? m.r2 : m.r1;
-      if (other < a->id || !t->id2local.count(other)) continue;
-      double w = m.weight;
-      if (t->prm.weights_as_float32) w = (double)(float)w;
-      if (dpgo_agent_set_measurement_weight(t, other, m.r1, m.p1, m.r2, m.p2, w, m.fixed_weight) == DPGO_OK) ++changed;
-      t->ag[t->id2local[other]]->data_dirty = true;
+  const auto q2 = now();
+  // the owner of a shared edge (the robot with the smaller id) hands its weight to the other end point's copy: one index
+  // over every agent's shared edges per round (a scan of the receiver's measurements per edge was 0.9 ms of a round).
+  // Parallel edges between the same two poses: the FIRST stored copy receives every one of them, as the scan did (and
+  // the oracle does).
+  {
+    typedef std::array<int, 4> EdgeKey;
+    struct EdgeHash {
+      size_t operator()(const EdgeKey &k) const {
+        unsigned long long h = (unsigned long long)(unsigned)k[0] * 0x9E3779B97F4A7C15ull;
+        h = (h ^ (unsigned)k[1]) * 0xC2B2AE3D27D4EB4Full;
+        h = (h ^ (unsigned)k[2]) * 0x165667B19E3779F9ull;
+        return (size_t)((h ^ (unsigned)k[3]) * 0x9E3779B97F4A7C15ull);
+      }
+    };
+    std::vector<std::unordered_map<EdgeKey, dpgo_measurement_t *, EdgeHash>> index(t->ag.size());
+    for (size_t k = 0; k < t->ag.size(); ++k) {
+      index[k].reserve(2 * t->ag[k]->shared.size());
+      for (auto &m : t->ag[k]->shared) index[k].emplace(EdgeKey{m.r1, m.p1, m.r2, m.p2}, &m);  // (keeps the first)
     }
+    for (auto &a : t->ag)
+      for (auto &m : a->shared) {
+        const int other = (m.r1 == a->id) ? m.r2 : m.r1;
+        auto ol = t->id2local.find(other);
+        if (other < a->id || ol == t->id2local.end()) continue;
+        double w = m.weight;
+        if (t->prm.weights_as_float32) w = (double)(float)w;
+        auto it = index[ol->second].find(EdgeKey{m.r1, m.p1, m.r2, m.p2});
+        if (it != index[ol->second].end()) { it->second->weight = w; it->second->fixed_weight = m.fixed_weight; ++changed; }
+        t->ag[ol->second]->data_dirty = true;
+      }
+  }
+  const auto q3 = now();
   if (sync_descs(t)) return DPGO_ERR;
+  const auto q4 = now();
   for (auto &a : t->ag) if (reset_acceleration_of(t, a.get())) return DPGO_ERR;
   HIPC(hipStreamSynchronize(t->stream));
+  if (timing)
+    std::fprintf(stderr, "update_weights: exchange %.2f  residuals+weights %.2f  shared weights %.2f  rebuild (enqueue) %.2f  "
+                         "reset + drain %.2f ms\n", ms(q0, q1), ms(q1, q2), ms(q2, q3), ms(q3, q4), ms(q4, now()));
   return changed;
 }
 
