@@ -85,6 +85,32 @@ def test_teams_the_one_launch_form_cannot_serve_keep_the_two_launch_sequence():
         t.close()
 
 
+def test_rows_longer_than_the_ell_part_keep_the_two_launch_sequence():
+    """a pose with more than 8 blocks in its row of Q (7 extra loop closures at one pose of robot 0): no lane-ordered copy of
+    the blocks exists for that agent, the team runs the two-launch sequence -- and follows the oracle"""
+    m, mp, n = load("sphere2500", 5)
+    mp = mp.copy()
+    intra = np.flatnonzero((mp["r1"] == 0) & (mp["r2"] == 0) & (mp["p2"] == mp["p1"] + 1))
+    extra = mp[intra[:7]].copy()
+    for k in range(7):
+        extra[k]["p1"], extra[k]["p2"] = 10, 100 + 20 * k
+    mq = np.concatenate([mp, extra])
+    prm_h, prm_o = capi.default_params(r=5, num_robots=5, **RGD), O.default_params(r=5, num_robots=5, **RGD)
+    T, Y = O.odometry_init(m, n), O.fixed_stiefel(5)
+    th = capi.Team.from_measurements(mq.view(capi.MEAS_DTYPE), prm_h)
+    to = O.Team(mq, n, prm_o)
+    th.set_initial(T, Y)
+    to.set_initial(T, Y)
+    th.run(40)
+    th.synchronize()
+    for _ in range(40):
+        to.iterate()
+    assert th.counters()[7] == 0
+    for k in th.ids:
+        assert np.abs(th.agents[k].get_X() - to.agents[k].get_X()).max() < 1e-10
+    th.close()
+
+
 def test_a_second_team_on_the_device_takes_the_two_launch_sequence_while_the_first_holds_the_lock():
     """the workgroups of a one-launch iteration wait for each other before they store: one team per device at a time
     (the lock of the one-launch RTR solve); the other team's run is the two-launch sequence, same iterates"""
