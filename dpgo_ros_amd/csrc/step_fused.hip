@@ -76,9 +76,6 @@ constexpr int FE_SPIN_LIMIT = 1 << 22;
 #endif
 constexpr int FE_PARTS = DPGO_FE_PARTS;  // the slab is requested in this many parts, behind the last blocks of the row
 constexpr int FE_MAX_EDGES = 144;  // shared edges of an agent whose operands fit the LDS left over (41 KB at r = 5)
-#ifndef DPGO_FE_GROUP
-#define DPGO_FE_GROUP 2
-#endif
 
 // one block of the row: W += X_i Q_ij, X_i gathered from the staged copy of X
 template <int R>
@@ -209,7 +206,7 @@ __global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ ag
   FE_STAMP(1);
   // the blocks of the row travel through a ring of FE_RING slots: the first FE_RING are requested here -- BEHIND the
   // barrier: a wave is held at the issue of its loads for as long as the CU's address unit is busy with everybody's
-  // (36 KB-sized requests per wave, 8 waves), and nothing in front of the barrier may wait for that --, slot u + FE_RING
+  // (36 requests of 1 KB per wave, 8 waves), and nothing in front of the barrier may wait for that --, slot u + FE_RING
   // as soon as slot u has been used
   constexpr int RING = 4;
   constexpr int Wd = WD;  // = ag.soa_w, 5 .. 8 (the launch picks the instance)
