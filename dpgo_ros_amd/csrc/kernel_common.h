@@ -132,26 +132,47 @@ __device__ __forceinline__ void spmm_row(const AgentDev &ag, int j, Src src, dou
   }
 }
 
-// G_j row a from the shared edges of public pose index q (a2)
+// G_j row a from the shared edges of public pose index q (a2).  The edges of a pose are taken four at a time: their
+// descriptors (one round trip), then their neighbour poses and coefficients (one more) -- a pose of the tunnels data has
+// up to 20 shared edges, and one edge after the other was 2 dependent round trips EACH (k_eval of a lockstep tick:
+// 25 us).  The sums run edge after edge, as before.
 template <int R>
 __device__ __forceinline__ void g_row_range(const AgentDev &ag, int e0, int e1, int a, int aux, int pull, double g[4]) {
   g[0] = g[1] = g[2] = g[3] = 0.0;
-  for (int e = e0; e < e1; ++e) {
-    const SharedEdgeDev &se = ag.se[e];
-    double *slab = ag.nbr[aux] + (size_t)se.slot * 4 * R;
-    double x[4];
-    const double *src = se.src[aux];
-    if (pull && src) {
+  for (int eb = e0; eb < e1; eb += 4) {
+    const double *xp[4];
+    double *slab[4];
+    bool copy[4];
 #pragma unroll
-      for (int cp = 0; cp < 4; ++cp) { x[cp] = src[cp * R + a]; slab[cp * R + a] = x[cp]; }
-    } else {
+    for (int u = 0; u < 4; ++u) {
+      const SharedEdgeDev &se = ag.se[min(eb + u, e1 - 1)];
+      slab[u] = ag.nbr[aux] + (size_t)se.slot * 4 * R;
+      const double *src = se.src[aux];
+      copy[u] = pull && src;
+      xp[u] = copy[u] ? src : slab[u];
+    }
+    double x[4][4], cf[4][16];
 #pragma unroll
-      for (int cp = 0; cp < 4; ++cp) x[cp] = slab[cp * R + a];
+    for (int u = 0; u < 4; ++u) {
+      const SharedEdgeDev &se = ag.se[min(eb + u, e1 - 1)];
+#pragma unroll
+      for (int cp = 0; cp < 4; ++cp) x[u][cp] = xp[u][cp * R + a];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) cf[u][i] = se.coef[i];
     }
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+    for (int u = 0; u < 4; ++u) {
+      if (eb + u < e1) {
+        if (copy[u]) {
 #pragma unroll
-      for (int cp = 0; cp < 4; ++cp) g[c] -= x[cp] * se.coef[cp + 4 * c];
+          for (int cp = 0; cp < 4; ++cp) slab[u][cp * R + a] = x[u][cp];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int cp = 0; cp < 4; ++cp) g[c] -= x[u][cp] * cf[u][cp + 4 * c];
+      }
+    }
   }
 }
 
