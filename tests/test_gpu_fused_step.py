@@ -85,6 +85,26 @@ def test_teams_the_one_launch_form_cannot_serve_keep_the_two_launch_sequence():
         t.close()
 
 
+def test_one_launch_iterations_across_weight_updates():
+    """GNC-TLS re-weighting between runs (the lane-ordered copy of the blocks is re-sent with the new values, the
+    structure stands): still bitwise the two-launch sequence"""
+    kw = dict(RGD, robust_cost_type=5, gnc_barc=5.0)
+    ta, tb = _team("sphere2500", 5, False, **kw), _team("sphere2500", 5, True, **kw)
+    for rnd in range(3):
+        for t in (ta, tb):
+            t.run(60)
+            t.synchronize()
+        for k in ta.ids:
+            assert np.array_equal(ta.agents[k].get_X(), tb.agents[k].get_X()), rnd
+        wa, wb = ta.update_weights(), tb.update_weights()
+        assert wa == wb
+        for k in ta.ids:
+            assert np.array_equal(ta.agents[k].measurements()["weight"], tb.agents[k].measurements()["weight"])
+    assert tb.counters()[7] == 3 * (60 - 5 - 1) and ta.counters()[7] == 0
+    ta.close()
+    tb.close()
+
+
 def test_rows_longer_than_the_ell_part_keep_the_two_launch_sequence():
     """a pose with more than 8 blocks in its row of Q (7 extra loop closures at one pose of robot 0): no lane-ordered copy of
     the blocks exists for that agent, the team runs the two-launch sequence -- and follows the oracle"""
