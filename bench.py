@@ -713,7 +713,8 @@ def main():
            "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
            "data": "bundled sphere2500.g2o (real dataset), odometry initial guess lifted with a fixed YLift",
            "config": {"workload": "sphere2500.g2o, 5 agents, synchronous round-robin RBCD, RGD(step 0.2, dense "
-                                  "preconditioner) + Nesterov (restart 20), r=5, library weighting",
+                                  "preconditioner) + Nesterov (restart 20), r=5, library weighting; mid-run iterations one "
+                                  "launch each (k_step_fe), hipGraphs of up to 256 iterations",
                       "agents": 5, "poses_per_agent": 500, "placement": "agent a on rank a % N"}}
     force_dist = os.environ.get("DPGO_BENCH_FORCE_DIST") == "1"  # exercise the N > 1 driver with one rank
     if args.gpus <= 1 and int(os.environ.get("WORLD_SIZE", "1")) <= 1 and not force_dist:
@@ -721,7 +722,10 @@ def main():
         out.update({"value": ms, "ms_per_step": ms, "timing": timing, "roofline": roof, "cpu_baseline": cpu, "convergence": conv,
                     "iters_to_relcost_1e-6": conv["rgd_nesterov"]["iters_to_relcost_1e-6"],
                     "counters": {"precond_launches": counters[0], "precond_bytes": counters[1],
-                                 "spmm_launches": counters[2], "spmm_bytes": counters[3], "iterations": counters[4]}})
+                                 "spmm_launches": counters[2], "spmm_bytes": counters[3], "iterations": counters[4],
+                                 "one_launch_iterations": counters[7],
+                                 "note": "of the main team since its creation; one_launch_iterations: iterations that ran as "
+                                         "k_step_fe (csrc/step_fused.hip), the others as k_eval_stats + k_precond<PM_RGD>"}})
         print(json.dumps(out))
     else:
         rank, ms, cost, roof, exchange, cp, asapp = multi_gpu(args)
