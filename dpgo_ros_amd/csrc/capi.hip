@@ -381,7 +381,14 @@ int dpgo_agent_iterate(dpgo_team_t *t, int id, int do_optimization) {
   if (a->state != DPGO_INITIALIZED || !a->has_X) { a->iter++; return DPGO_NOT_READY; }
   // iterate(false) reads no neighbour pose: what is staged on the host is not uploaded in front of it
   const bool defer_upload = !do_optimization && t->prm.acceleration && t->peers.empty();
-  if (defer_upload ? sync_descs_noflush(t) : sync_descs(t)) return DPGO_ERR;
+  // an accelerated iterate(true) opens with k_nest_pre, which scatters this agent's staged poses itself
+  const bool upload_in_first = do_optimization && t->prm.acceleration && t->peers.empty();
+  if ((defer_upload || upload_in_first) ? sync_descs_noflush(t) : sync_descs(t)) return DPGO_ERR;
+  if (upload_in_first) {
+    int n0 = 0, n1 = 0;
+    if (stage_to_pinned(t, *a, &n0, &n1)) return DPGO_ERR;
+    t->pend_up.slots = a->h_up_idx.p; t->pend_up.in = a->h_up.p; t->pend_up.n0 = n0; t->pend_up.n1 = n1;
+  }
   if (t->prm.robust_cost_type != DPGO_COST_L2) a->robust_inner_iter++;
   bool opt = do_optimization != 0;
   a->last_success = true;

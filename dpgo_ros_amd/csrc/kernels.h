@@ -17,6 +17,11 @@ struct LaunchCtx {
   const int *host_precond = nullptr;  // [local agent] DPGO_PRECOND_* it runs (host memory; selects the kernel variant)
   const AgentDev *host_agents = nullptr;  // [local agent] host copies of the descriptors (what d_agents holds)
   bool bake_desc = false;          // pass the agent's descriptor BY VALUE where the launch names its agent (baked graphs)
+  // neighbour poses staged on the host (pinned) that the FIRST launch of an iterate(true) scatters into the agent's slabs
+  // itself (launch_nest_pre; one launch less than k_upload2 in front of it): slots / values, counts per sequence
+  const int *up_slots = nullptr;
+  const double *up_in = nullptr;
+  int up_n0 = 0, up_n1 = 0;
   const NestState *nest_all = nullptr;  // the team's NestStates, [local agent]: lets a kernel read an agent's Nesterov
                                         // state from the agent index alone, next to (not behind) its descriptor
 };

@@ -60,10 +60,42 @@ __global__ __launch_bounds__(64) void k_raw_op(const double *X, const double *V,
   tile_out<R>(TA, out, j0, cnt, tid);
 }
 
+// staged neighbour poses, pinned host memory -> slabs: elements first, first + stride, ... of the (n0 + n1) * 4R doubles.
+// Reads from host memory cross PCIe (~2 us each): eight per lane are in flight before the first is stored (a plain loop
+// would wait for every one in turn).
+template <int R>
+__device__ __forceinline__ void upload_slice(const AgentDev &ag, const int *slots, const double *in, int n0, int n1, int first,
+                                             int stride) {
+  const int total = (n0 + n1) * 4 * R;
+  for (int base = first; base < total; base += 8 * stride) {
+    double v[8];
+    int sl[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int t = min(base + u * stride, total - 1);
+      v[u] = in[t];
+      sl[u] = slots[t / (4 * R)];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int t = base + u * stride;
+      if (t < total) {
+        const int q = t / (4 * R), k = t - q * 4 * R;
+        ag.nbr[q < n0 ? 0 : 1][(size_t)sl[u] * 4 * R + k] = v[u];
+      }
+    }
+  }
+}
+
 template <int R>
 __global__ __launch_bounds__(64) void k_nest_pre(const AgentDev *__restrict__ agents, TeamDev *team, int sel, int only_agent,
-                                                 int num_robots, int restart_interval, int fused_restart) {
+                                                 int num_robots, int restart_interval, int fused_restart, const int *up_slots,
+                                                 const double *up_in, int up_n0, int up_n1) {
   __shared__ Tile<R> TX, TV;
+  // (per-agent API, iterate(true): the neighbour poses staged on the host since the agent's last block update are
+  // scattered into its slabs here -- nothing in this launch reads them, the evaluation behind it does)
+  if (up_n0 + up_n1 > 0 && only_agent >= 0)
+    upload_slice<R>(agents[only_agent], up_slots, up_in, up_n0, up_n1, (int)blockIdx.x * 64 + (int)threadIdx.x, 64 * (int)gridDim.x);
   nest_pre_body<R>(agents, team, sel, only_agent, num_robots, restart_interval, (int)blockIdx.x, (int)blockIdx.y, TX, TV,
                    fused_restart);
 }
@@ -251,33 +283,6 @@ __global__ void k_unpack(double *slab, const int *slots, int count, const double
   if (t >= count * 4 * R) return;
   const int q = t / (4 * R), k = t - q * 4 * R;
   slab[(size_t)slots[q] * 4 * R + k] = in[t];
-}
-
-// staged neighbour poses, pinned host memory -> slabs: elements first, first + stride, ... of the (n0 + n1) * 4R doubles.
-// Reads from host memory cross PCIe (~2 us each): eight per lane are in flight before the first is stored (a plain loop
-// would wait for every one in turn).
-template <int R>
-__device__ __forceinline__ void upload_slice(const AgentDev &ag, const int *slots, const double *in, int n0, int n1, int first,
-                                             int stride) {
-  const int total = (n0 + n1) * 4 * R;
-  for (int base = first; base < total; base += 8 * stride) {
-    double v[8];
-    int sl[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int t = min(base + u * stride, total - 1);
-      v[u] = in[t];
-      sl[u] = slots[t / (4 * R)];
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int t = base + u * stride;
-      if (t < total) {
-        const int q = t / (4 * R), k = t - q * 4 * R;
-        ag.nbr[q < n0 ? 0 : 1][(size_t)sl[u] * 4 * R + k] = v[u];
-      }
-    }
-  }
 }
 
 // ---- the host boundary of the per-agent API (the path a ROS wrapper drives), without copy engines or stream-wide waits:
@@ -482,7 +487,7 @@ void launch_nest_pre(const LaunchCtx &c, int sel, int only_agent, int num_agents
                      int restart_interval, int fused_restart) {
   dim3 grid((max_n + 63) / 64, only_agent >= 0 ? 1 : num_agents);
   DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_nest_pre<R>, grid, dim3(64), 0, c.stream, c.agents, c.team, sel, only_agent,
-                                          num_robots, restart_interval, fused_restart));
+                                          num_robots, restart_interval, fused_restart, c.up_slots, c.up_in, c.up_n0, c.up_n1));
 }
 
 void launch_nest_post(const LaunchCtx &c, int sel, int max_n, int num_robots, int restart_interval) {

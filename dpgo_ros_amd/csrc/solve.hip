@@ -247,11 +247,16 @@ int enqueue_iterate(dpgo_team *t, int li, int do_opt, bool defer_advance) {
   fl.pull = t->peers.empty() ? 0 : 1;
   int rc = 0;
   a.rel_src = 0;
+  if (t->pend_up.n0 + t->pend_up.n1 > 0) {  // (dpgo_agent_iterate: the first launch below also scatters the staged poses)
+    c.up_slots = t->pend_up.slots; c.up_in = t->pend_up.in; c.up_n0 = t->pend_up.n0; c.up_n1 = t->pend_up.n1;
+    t->pend_up = dpgo_team::PendingUpload();
+  }
   if (do_opt == 2) {
     // iterate(true) while a neighbour's poses are still missing (the delayed-message case): no local solve, X stays
     // put; under acceleration Y, V and the periodic restart are updated as in any iteration
     if (p.acceleration) {
       launch_nest_pre(c, li, li, 1, a.n, p.num_robots, p.restart_interval, 2);
+      c.up_n0 = c.up_n1 = 0;
       launch_nest_post(c, li, a.n, p.num_robots, p.restart_interval);
       if (restart) launch_nest_reset(c, li, a.n);
     } else {
@@ -263,6 +268,7 @@ int enqueue_iterate(dpgo_team *t, int li, int do_opt, bool defer_advance) {
   }
   if (p.acceleration) {
     launch_nest_pre(c, do_opt ? li : -2, li, 1, a.n, p.num_robots, p.restart_interval);
+    c.up_n0 = c.up_n1 = 0;
     if (do_opt) {
       fl.aux = 1;
       rc = enqueue_optimize(t, li, fl);

@@ -213,6 +213,8 @@ struct dpgo_team {
   // [0, num_local), the two alternating buffers of the fused launches behind it -- and one arrival counter
   dpgo_host::DevBuf<unsigned long long> d_fe_sync;
   int use_fused_eval = 1;  // DPGO_FUSED_EVAL=0: every pipelined iteration takes the two-launch sequence
+  // staged neighbour poses of the agent whose iterate(true) is being enqueued: its first launch (k_nest_pre) scatters them
+  struct PendingUpload { const int *slots = nullptr; const double *in = nullptr; int n0 = 0, n1 = 0; } pend_up;
   int *h_bar_err = nullptr;
   int num_cus = 0;
   int max_lds = 160 * 1024;  // hipDeviceAttributeMaxSharedMemoryPerBlock
