@@ -953,7 +953,7 @@ static bool fused_eval_eligible(dpgo_team_t *t) {
   for (size_t k = 0; k < t->ag.size(); ++k) {
     const int n = t->ag[k]->n, grid = ((4 * n + 7) / 8 + 7) / 8 * 8;
     if (t->precond_of[k] != DPGO_PRECOND_DENSE || n <= 256 || n > 512 || grid > t->num_cus || !t->ag[k]->has_soa ||
-        t->h_descs[k].npub * p.r > 512 || t->h_descs[k].nshared > step_fe_max_edges())
+        t->h_descs[k].nshared > step_fe_max_edges())
       return false;
   }
   return true;

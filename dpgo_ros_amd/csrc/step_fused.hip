@@ -7,8 +7,8 @@
 //      coefficients) follow it into LDS, one double per lane and trip.
 //   2. one lane per pose: W_j = sum_i X_i Q_ij over the row -- the 4 x 4 blocks from a [tile of 64 poses][slot][16-byte
 //      chunk][lane] copy of the ELL part (every load of a wave is one contiguous KB; padded slots hold zero blocks),
-//      through a ring of four slots in registers; X_i gathered from LDS.  One lane per (public pose, row) forms the
-//      linear term G from LDS.  Tangent projection in registers; barrier; the result replaces X in LDS.
+//      through a ring of four slots in registers; X_i gathered from LDS.  Behind its row the lane of a pose with shared
+//      edges forms the linear term G_j from LDS.  Tangent projection in registers; barrier; the result replaces X in LDS.
 //   3. waves 0-3 request their 128 KB slab of M = (Q + shift I)^-1 in four parts, each as soon as a slot of the ring is
 //      free for good, then: slab x vector, partial sums, and exactly the tail of k_precond<PM_RGD>: wave 0 finishes the
 //      step of the two poses the workgroup owns (step, QF retraction, Nesterov V, look-ahead Y), wave 1 takes the
@@ -42,7 +42,7 @@
 //     (k_eval_stats, nest_copy).
 // Mid-run iterations only (ahead == 3: nothing a status query reads is left behind); the last iterations of a run take
 // the two-launch sequence, which leaves the statistics.  Dense agents of 257 .. 512 poses, r <= 5, rows of <= 8 blocks,
-// npub * r <= 512, <= 144 shared edges; DPGO_FUSED_EVAL=0 keeps the two-launch sequence everywhere.
+// <= 160 shared edges; DPGO_FUSED_EVAL=0 keeps the two-launch sequence everywhere.
 #include "kernel_common.h"
 #include <algorithm>
 
@@ -75,7 +75,8 @@ constexpr int FE_SPIN_LIMIT = 1 << 22;
 #define DPGO_FE_PARTS 4
 #endif
 constexpr int FE_PARTS = DPGO_FE_PARTS;  // the slab is requested in this many parts, behind the last blocks of the row
-constexpr int FE_MAX_EDGES = 144;  // shared edges of an agent whose operands fit the LDS left over (41 KB at r = 5)
+constexpr int FE_MAX_EDGES = 160;  // shared edges of an agent whose operands go through LDS (46 KB at r = 5; more would spill: the descriptors
+                                   // and values of 512-double trips live in registers in front of the rows)
 
 // one block of the row: W += X_i Q_ij, X_i gathered from the staged copy of X
 template <int R>
@@ -118,7 +119,6 @@ __global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ ag
   __shared__ double red[32 * (8 * R + 1)];
   __shared__ double Ysh[2 * 4 * R];
   __shared__ double Esh[2][2 * 4 * R];   // V, Yaux of the two poses
-  __shared__ double Gs[512 * 4];         // the linear term of the public poses, [public pose][c][a]
   __shared__ double Es[FE_MAX_EDGES * (4 * R + 16)];  // operands of the shared edges: neighbour pose, coefficients
   FE_TRACE_DECL
   FE_STAMP(0);
@@ -130,13 +130,12 @@ __global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ ag
   const int j = tid;
   const bool act = j < n;
   const int jj = act ? j : 0;
-  const int qi = ag.pub_index[jj];  // >= 0: the pose owns shared edges
   // The linear term G (the neighbours' poses through the shared edges): the operands of every shared edge -- the
   // neighbour's auxiliary pose, 4R doubles, and the edge's 16 coefficients -- are copied into LDS by all lanes, one double
-  // per lane and trip (consecutive lanes read consecutive doubles of an edge); then one lane per (public pose, row a)
-  // forms its four entries from LDS, edge after edge in g_row_range's order (the host checks npub * R <= 512 and
-  // nshared <= FE_MAX_EDGES).  The neighbour's pose comes straight from its agent's Y array where it is co-resident (or
-  // imported), from the neighbour slab otherwise (g_row_range, aux = 1, pull).
+  // per lane and trip (consecutive lanes read consecutive doubles of an edge); behind its row the lane of a pose with
+  // shared edges forms G_j from LDS, edge after edge in g_row_range's order (the host checks nshared <= FE_MAX_EDGES).
+  // The neighbour's pose comes straight from its agent's Y array where it is co-resident (or imported), from the
+  // neighbour slab otherwise (g_row_range, aux = 1, pull).
   constexpr int EPE = 4 * R + 16;                              // doubles per edge in LDS
   constexpr int NEI = (FE_MAX_EDGES * EPE + 511) / 512;        // trips that cover FE_MAX_EDGES edges
   const int nsh = ag.nshared, etotal = nsh * EPE;
@@ -150,14 +149,7 @@ __global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ ag
       esrc[i] = se.src[1]; eslot[i] = se.slot;
     }
   }
-  const int gq = tid / R, ga = tid - gq * R;
-  const bool gact = gq < ag.npub;
-  int ge0 = 0, ge1 = 0;
-  if (ag.npub > 0) {  // (uniform; lanes beyond the last item read the last one and drop it)
-    const int gqc = min(gq, ag.npub - 1);
-    ge0 = ag.pub_ptr[gqc]; ge1 = ag.pub_ptr[gqc + 1];
-  }
-  if (!gact) ge1 = ge0;
+  const int e0 = ag.pose_eptr[jj], e1 = ag.pose_eptr[jj + 1];  // the pose's shared edges (empty for most poses)
   // operands of the tail (consumed 10 us from here)
   const size_t own_off = (size_t)((tid >= 4 * R) ? max(pj1, 0) : pj0) * 4 * R + (size_t)(tid % (4 * R));
   double pre_x = 0, pre_v = 0, pre_y = 0;
@@ -229,6 +221,11 @@ __global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ ag
   const bool cact = col < N4 && tid < 256;
   const double *Mc = ag.M + (size_t)(cact ? col : 0) * N4;
   double2 mreg[MREG];
+  // the edge operands were requested in front of the ring and are back before its first slot: into LDS now (their
+  // registers are free for the row)
+#pragma unroll
+  for (int i = 0; i < NEI; ++i)
+    if (i * 512 < etotal) { const int t = tid + 512 * i; if (t < etotal) Es[t] = ev[i]; }
   double w[4 * R];
 #pragma unroll
   for (int i = 0; i < 4 * R; ++i) w[i] = 0.0;
@@ -252,37 +249,29 @@ __global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ ag
         mreg[m] = (cact && kk < N4) ? t : make_double2(0.0, 0.0);
       }
     }
-    if (u == 0) {
-      // the edge operands were requested in front of the ring: they are back with its first slot
-#pragma unroll
-      for (int i = 0; i < NEI; ++i)
-        if (i * 512 < etotal) { const int t = tid + 512 * i; if (t < etotal) Es[t] = ev[i]; }
-    }
-    if (u == 1) {
-      lds_barrier();  // #1a: the edge operands are in LDS
-      if (gact) {
-        // G of (pose gq, row ga): g[c] -= x[cp] coef[cp + 4c], edge after edge (g_row_range's order)
-        double g[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int e = ge0; e < ge1; ++e) {
-          const double *E = Es + (size_t)e * EPE;
-          double x[4];
-#pragma unroll
-          for (int cp = 0; cp < 4; ++cp) x[cp] = E[cp * R + ga];
-#pragma unroll
-          for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int cp = 0; cp < 4; ++cp) g[c] -= x[cp] * E[4 * R + cp + 4 * c];
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) Gs[gq * 4 * R + c * R + ga] = g[c];
-      }
-    }
+    if (u == 1) lds_barrier();  // #1a: the edge operands are in LDS
     __builtin_amdgcn_sched_barrier(0);
   }
-  lds_barrier();  // #1b: G of every public pose is in LDS
-  if (act && qi >= 0) {
+  if (act && e1 > e0) {
+    // G_j from LDS: g[c][a] -= x[cp][a] coef[cp + 4c], edge after edge and cp after cp for every entry (g_row_range's
+    // order), one column c at a time (the slab's registers are in flight: few are free)
 #pragma unroll
-    for (int i = 0; i < 4 * R; ++i) w[i] = w[i] + Gs[qi * 4 * R + i];
+    for (int c = 0; c < 4; ++c) {
+      double g[R];
+#pragma unroll
+      for (int a = 0; a < R; ++a) g[a] = 0.0;
+      for (int e = e0; e < e1; ++e) {
+        const double *E = Es + (size_t)e * EPE;
+#pragma unroll
+        for (int cp = 0; cp < 4; ++cp) {
+          const double cf = E[4 * R + cp + 4 * c];
+#pragma unroll
+          for (int a = 0; a < R; ++a) g[a] -= E[cp * R + a] * cf;
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < R; ++a) w[c * R + a] = w[c * R + a] + g[a];
+    }
   }
   FE_STAMP(2);
   {
