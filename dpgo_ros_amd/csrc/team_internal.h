@@ -188,7 +188,7 @@ struct dpgo_team {
   bool descs_dirty = true;
   int max_n = 0, max_npub = 0;
   dpgo::RtrState *h_state = nullptr;  // pinned
-  double *h_scal = nullptr;     // pinned [16]
+  double *h_scal = nullptr;     // pinned [16 x local agents] (fetch_scal uses the first 16)
   static constexpr int MAX_GRAPH_ITERS = 64;       // iterations captured in one graph (one graph per distinct count)
   static constexpr int MAX_PIPELINED_GRAPH_ITERS = 256;  // ... of the uniform pipelined accelerated-RGD sequence
   std::map<int, hipGraphExec_t> graphs;            // key: see dpgo_team_run
