@@ -1220,7 +1220,9 @@ int dpgo_team_run_simultaneous(dpgo_team_t *t, int ticks) {
       // taken in the last tick of every graph, two launches per tick otherwise
       if (rep == reps - 1) launch_copy(c, -3, -1, na, mn, B_X, B_XPREV, 0);
       launch_eval(c, sel, mn, B_X, B_EGRAD, B_GF, PART_C, eval_opts(t, 2, 0, 0));
-      launch_precond(c, sel, mn, PM_RGD_, B_X, B_GF, B_Z, 0, 0, p.rgd_stepsize, 0, p.num_robots, 0, p.restart_interval);
+      // (statistics -- X2 snapshot, |X - XPrev|^2 -- only from the last tick of a graph: nothing reads the others')
+      launch_precond(c, sel, mn, PM_RGD_, B_X, B_GF, B_Z, 0, 0, p.rgd_stepsize, 0, p.num_robots, 0, p.restart_interval,
+                     rep == reps - 1 ? 0 : 16);
     }
   };
   int left = ticks;

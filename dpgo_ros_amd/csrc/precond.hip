@@ -45,7 +45,8 @@ namespace dpgo {
 //               two poses; bit 1: the second wave takes it for the workgroup's share of the other agents' poses;
 //               bit 2: those steps also leave what a status query reads (XPrev, |Y' - X|^2 per pose); bit 3: this
 //               step leaves its statistics (X2 snapshot, |X - XPrev|^2).  Mid-run launches carry 3, the last two
-//               of a run 7 and 8.
+//               of a run 7 and 8.  bit 4 (lockstep ticks, advance = 0): this step leaves NO statistics (every tick but
+//               the last of a graph).
 // KC = rows of M (scalars of the input vector) handled per chunk: KC * R * 8 bytes of LDS and KC / 64
 // 16-byte registers per lane.  One 2048-row chunk covers a 500-pose agent in a single round trip with one
 // workgroup per CU; larger agents use 1024-row chunks so that 3 workgroups fit a CU and one workgroup's
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *__restrict__ ag
   // ahead bits: 1 look-ahead of this workgroup's poses, 2 look-ahead of the other agents' poses, 4 the look-ahead also
   // leaves what a status query needs (XPrev, |Y' - X|^2 per pose), 8 this step leaves its statistics (X2 snapshot,
   // |X - XPrev|^2).  Only the last two iterations of a run set 4 / 8: nothing reads those values in between.
-  const bool la_status = (ahead & 4) != 0, want_stats = (MODE != PM_RGD_) || advance != 2 || (ahead & 8) != 0;
+  const bool la_status = (ahead & 4) != 0, want_stats = (MODE != PM_RGD_) || (advance != 2 && !(ahead & 16)) || (ahead & 8) != 0;
   double pre_x = 0, pre_v = 0, pre_y = 0, pre_p = 0;
   double nest_gamma = 0;
   if (tid < npose * 4 * R) {
