@@ -33,11 +33,17 @@ void dpgo_default_params(dpgo_params_t *p, int r, int num_robots) {
   p->robust_opt_num_resets = 0;   // launch/PGOAgent.launch:33
   p->precond_mode = DPGO_PRECOND_AUTO;
   p->status_every_iterate = 0;
+  p->rgd_line_search = 0; p->rgd_ls_max_backoffs = 7; p->rgd_ls_shrink = 0.5; p->rgd_ls_sigma = 1e-4;
 }
 
 dpgo_team_t *dpgo_team_create(int device, const dpgo_params_t *p, int num_local, const int *agent_ids, void *stream) {
   if (p->d != 3 || p->r < 3 || p->r > 8) { set_err("d must be 3 and r in [3,8]"); return nullptr; }
   if (p->robust_opt_num_resets < 0) { set_err("robust_opt_num_resets must be >= 0"); return nullptr; }
+  if (p->rgd_line_search && (p->rgd_ls_max_backoffs < 0 || p->rgd_ls_max_backoffs >= LS_MAX_TRIALS || !(p->rgd_ls_shrink > 0.0) ||
+                             !(p->rgd_ls_shrink < 1.0) || !(p->rgd_ls_sigma > 0.0) || !(p->rgd_ls_sigma < 1.0))) {
+    set_err("rgd_line_search: rgd_ls_max_backoffs in [0, 7], rgd_ls_shrink and rgd_ls_sigma in (0, 1)");
+    return nullptr;
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
     set_err("no HIP device: libdpgo_hip has no CPU fallback");
@@ -369,8 +375,9 @@ static int report_after_iterate(dpgo_team_t *t, Agent *a, bool did_opt, bool adv
     a->opt.f_init = out[2]; a->opt.gradnorm_init = std::sqrt(out[3]);
     a->opt.f_opt = out[4]; a->opt.gradnorm_opt = std::sqrt(out[5]);
     a->opt.rtr_outer_iters = 0; a->opt.tcg_iters_total = 0; a->opt.hessvec_count = 0;
-    a->opt.precond_count = t->prm.rgd_use_preconditioner ? 1 : 0; a->opt.accepted = 1;
+    a->opt.precond_count = t->prm.rgd_use_preconditioner ? 1 : 0; a->opt.accepted = 1; a->opt.ls_backoffs = 0;
     a->opt_pending_rgd = false;
+    if (read_ls_record(t, *a)) return DPGO_ERR;  // (line search: back-offs / accepted from the agent's scalars)
   }
   return DPGO_OK;
 }
@@ -972,7 +979,10 @@ static int team_run_impl(dpgo_team_t *t, int iters, bool prepare_only) {
   }
   // look-ahead Nesterov steps need every workgroup's share of the other agents' poses to fit one wave, and one
   // double per pose in the PART_D region
-  bool pipelined = p.acceleration != 0 && (int)t->ag.size() <= LOOKAHEAD_MAX_AGENTS;
+  // (a line search decides the step after the whole agent's trial costs are known: its iterations are the un-fused
+  // launch sequence of enqueue_team_iteration, captured as it is)
+  const bool ls = p.rgd_line_search != 0;
+  bool pipelined = p.acceleration != 0 && (int)t->ag.size() <= LOOKAHEAD_MAX_AGENTS && !ls;
   {
     int total = 0;
     for (auto &a : t->ag) total += a->n;
@@ -1039,7 +1049,7 @@ static int team_run_impl(dpgo_team_t *t, int iters, bool prepare_only) {
                        ahead);
       }
       launch_eval_stats(c, mn, 0, 0, 1, p.num_robots, p.restart_interval, -1, sel_at(B - 1));
-    } else if (rc == 0 && B > 0 && p.acceleration) {
+    } else if (rc == 0 && B > 0 && p.acceleration && !ls) {
       // 3 launches per iteration: [statistics of iteration k-1 + Nesterov step of iteration k] in one
       // heterogeneous kernel, cost/gradient (+ G from the neighbours' Y), preconditioner + RGD step +
       // Nesterov V + bookkeeping
@@ -1110,10 +1120,10 @@ static int team_run_impl(dpgo_team_t *t, int iters, bool prepare_only) {
         account(sel);
         if (restart && q == 0) account(sel);  // the restart iteration solves twice (from Y, then from XPrev)
         // status of this block update: the fused step leaves PART_B[2], the un-fused restart iteration k_status tiles
-        mark_optimized(t, *t->ag[sel], (restart && q == 0) ? 5 : 1, true);
+        mark_optimized(t, *t->ag[sel], ((restart && q == 0) || ls) ? 5 : 1, true);
         if (q == batch - 1) {
           t->ag[sel]->opt_pending_rgd = true;
-          t->ag[sel]->rel_src = (fusedn > 0) ? 1 : 0;  // a lone restart iteration ends with k_status (PART_D tiles)
+          t->ag[sel]->rel_src = (fusedn > 0 && !ls) ? 1 : 0;  // a lone restart iteration ends with k_status (PART_D tiles)
         }
       }
     } else {
@@ -1198,8 +1208,8 @@ int dpgo_team_run_group(dpgo_team_t *t, int g, int count) {
 int dpgo_team_run_simultaneous(dpgo_team_t *t, int ticks) {
   if (sync_descs(t)) return DPGO_ERR;
   const dpgo_params_t &p = t->prm;
-  if (p.method != DPGO_METHOD_RGD || !p.rgd_use_preconditioner || p.acceleration) {
-    set_err("simultaneous updates: preconditioned RGD without acceleration (the ASAPP configuration)");
+  if (p.method != DPGO_METHOD_RGD || !p.rgd_use_preconditioner || p.acceleration || p.rgd_line_search) {
+    set_err("simultaneous updates: preconditioned RGD with the fixed step, without acceleration (the ASAPP configuration)");
     return DPGO_ERR;
   }
   for (auto &a : t->ag) if (!a->has_X) { set_err("run_simultaneous before set_initial"); return DPGO_NOT_READY; }

@@ -105,7 +105,8 @@ struct AgentDev {
   double *part;               // partial-sum scratch, [PART_STRIDE * MAX_PART]
   RtrState *st;               // [2]
   NestState *nest;            // [1]
-  double *scal;               // [16] misc scalars: 5 owned-edge cost, 6 gamma' of the running iteration (published by k_nest_pre)
+  double *scal;               // [16] misc scalars: 5 owned-edge cost, 6 gamma' of the running iteration (published by k_nest_pre),
+                              // 8..11 record of the last RGD line search (k_ls_apply: back-offs, accepted, f, step)
   double *resid;              // [nedges] residual scratch
 };
 

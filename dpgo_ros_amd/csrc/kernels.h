@@ -58,6 +58,12 @@ bool step_fe_supported(int r);
 int step_fe_max_edges();
 void launch_step_fe(const LaunchCtx &c, int sel, int next_sel, double step, int num_robots, int restart_interval,
                     const NestState *nest_src, NestState *nest_dst, unsigned long long *sync, unsigned long long target, int *err);
+// linesearch.hip: RGD with a backtracking (Armijo) line search -- all trial points, all trial costs from one pass over Q,
+// the decision re-derived by every workgroup of the apply (record in AgentDev::scal[8..11])
+constexpr int LS_MAX_TRIALS = 8;
+void launch_ls_trials(const LaunchCtx &c, int sel, int max_n, int dirb, double step0, double shrink, int ntrials);
+void launch_ls_cost(const LaunchCtx &c, int sel, int max_n, int dirb, int ntrials);
+void launch_ls_apply(const LaunchCtx &c, int sel, int max_n, double step0, double shrink, double sigma, int ntrials);
 void launch_tcg_hv(const LaunchCtx &c, int sel, int max_n, int sp, int max_inner);
 void launch_retract(const LaunchCtx &c, int sel, int max_n, int xb, int eb, double scale, int ob, int guard_state);
 void launch_project_raw(const LaunchCtx &c, const double *X, double *out, int n);

@@ -81,6 +81,8 @@ EvalOpts eval_opts(const dpgo_team *t, int gmode, int aux, int advance) {
   return o;
 }
 
+int ls_trials(const dpgo_params_t &p) { return std::max(1, std::min(p.rgd_ls_max_backoffs + 1, LS_MAX_TRIALS)); }
+
 double spmm_bytes_of(const dpgo_team *t, const Agent &a) {
   return 8.0 * (16.0 * a.col.size() + 3.0 * t->prm.r * 4 * a.n) + 4.0 * (a.col.size() + a.n + 1);
 }
@@ -93,6 +95,28 @@ int enqueue_optimize(dpgo_team *t, int sel, const OptFlags &fl) {
   const int gmode = fl.pull ? 2 : 1;
   if (p.method == DPGO_METHOD_RGD) {
     launch_eval(c, sel, mn, B_X, B_EGRAD, B_GF, PART_C, eval_opts(t, gmode, fl.aux, 0));
+    if (p.rgd_line_search) {
+      // backtracking line search (linesearch.hip): direction, every trial point, every trial cost in one pass over Q,
+      // decision + move, statistics at the new point -- blind launches, the decision stays on the device
+      const int ntr = ls_trials(p);
+      int dirb = B_GF;
+      if (p.rgd_use_preconditioner) {
+        launch_precond(c, sel, mn, PM_PLAIN_, B_X, B_GF, B_Z, 0, 0, 0.0, 0, p.num_robots);
+        dirb = B_Z;
+      }
+      launch_ls_trials(c, sel, mn, dirb, p.rgd_stepsize, p.rgd_ls_shrink, ntr);
+      launch_ls_cost(c, sel, mn, dirb, ntr);
+      launch_ls_apply(c, sel, mn, p.rgd_stepsize, p.rgd_ls_shrink, p.rgd_ls_sigma, ntr);
+      launch_eval(c, sel, mn, B_X, B_EGRAD, B_GF, PART_A, eval_opts(t, 0, 0, 0));
+      if (sel >= 0 && !fl.capture) {
+        Agent &a = *t->ag[sel];
+        if (p.rgd_use_preconditioner) { t->counters[0] += 1; t->counters[1] += precond_operator_bytes(a); }
+        const int passes = 2 + (ntr + 3) / 4;  // passes over the sparse operator
+        t->counters[2] += passes; t->counters[3] += passes * spmm_bytes_of(t, a);
+        a.opt_pending_rgd = true;
+      }
+      return 0;
+    }
     if (fl.fused && p.rgd_use_preconditioner) {
       // K3: preconditioner + RGD step + Nesterov V + |dX|^2 (+ the team's end-of-iteration bookkeeping);
       // K5: f_opt / gradnorm_opt on the snapshot B_X2 that K3 leaves behind
@@ -239,7 +263,7 @@ int enqueue_iterate(dpgo_team *t, int li, int do_opt, bool defer_advance) {
   LaunchCtx c = t->ctx();
   const dpgo_params_t &p = t->prm;
   const bool restart = p.acceleration && ((a.iter + 2) % p.restart_interval) == 0;
-  const bool fused = do_opt && p.method == DPGO_METHOD_RGD && p.rgd_use_preconditioner && !restart;
+  const bool fused = do_opt && p.method == DPGO_METHOD_RGD && p.rgd_use_preconditioner && !restart && !p.rgd_line_search;
   OptFlags fl;
   fl.fused = fused;
   // a team that imported peers (dpgo_team_import_peer) has no messages to fill the neighbour slabs from: its per-agent
@@ -331,6 +355,15 @@ int fetch_scal(dpgo_team *t, Agent &a) {
   return 0;
 }
 
+// the record k_ls_apply left in the agent's scalars (RGD line search)
+int read_ls_record(dpgo_team *t, Agent &a) {
+  if (!t->prm.rgd_line_search || t->prm.method != DPGO_METHOD_RGD) return 0;
+  if (fetch_scal(t, a)) return DPGO_ERR;
+  a.opt.ls_backoffs = (int)t->h_scal[8];
+  a.opt.accepted = (int)t->h_scal[9];
+  return 0;
+}
+
 int refresh_rgd_result(dpgo_team *t, Agent &a) {
   if (!a.opt_pending_rgd) return 0;
   const int ppb = 64 / t->prm.r, nb = (a.n + ppb - 1) / ppb;
@@ -343,9 +376,9 @@ int refresh_rgd_result(dpgo_team *t, Agent &a) {
   a.opt.f_init = sum(pc, 0); a.opt.gradnorm_init = std::sqrt(sum(pc, 1));
   a.opt.f_opt = sum(pa, 0); a.opt.gradnorm_opt = std::sqrt(sum(pa, 1));
   a.opt.rtr_outer_iters = 0; a.opt.tcg_iters_total = 0; a.opt.hessvec_count = 0;
-  a.opt.precond_count = t->prm.rgd_use_preconditioner ? 1 : 0; a.opt.accepted = 1;
+  a.opt.precond_count = t->prm.rgd_use_preconditioner ? 1 : 0; a.opt.accepted = 1; a.opt.ls_backoffs = 0;
   a.opt_pending_rgd = false;
-  return 0;
+  return read_ls_record(t, a);
 }
 
 double robust_weight(const dpgo_params_t &p, double mu, double residual) {
@@ -376,7 +409,7 @@ int enqueue_team_iteration(dpgo_team *t, bool capture, bool restart, int sel, in
   const dpgo_params_t &p = t->prm;
   const int na = (int)t->ag.size();
   const int mn = t->max_n;
-  const bool fused = p.method == DPGO_METHOD_RGD && p.rgd_use_preconditioner && !restart && sel != -2;
+  const bool fused = p.method == DPGO_METHOD_RGD && p.rgd_use_preconditioner && !restart && sel != -2 && !p.rgd_line_search;
   OptFlags fl;
   fl.pull = 1; fl.capture = capture; fl.fused = fused; fl.last_advances = fused;
   int rc = 0;
@@ -447,6 +480,12 @@ int enqueue_optimize_group(dpgo_team *t, int g) {
     launch_eval(c, sel, mn, B_X, B_EGRAD, B_GF, PART_C, eval_opts(t, 2, 0, 0));
     int dirb = B_GF;
     if (p.rgd_use_preconditioner) { launch_precond(c, sel, mn, PM_PLAIN_, B_X, B_GF, B_Z, 0, 0, 0.0, 0, p.num_robots); dirb = B_Z; }
+    if (p.rgd_line_search) {
+      const int ntr = ls_trials(p);
+      launch_ls_trials(c, sel, mn, dirb, p.rgd_stepsize, p.rgd_ls_shrink, ntr);
+      launch_ls_cost(c, sel, mn, dirb, ntr);
+      launch_ls_apply(c, sel, mn, p.rgd_stepsize, p.rgd_ls_shrink, p.rgd_ls_sigma, ntr);
+    } else
     launch_retract(c, sel, mn, B_X, dirb, -p.rgd_stepsize, B_X, -1);
     launch_eval(c, sel, mn, B_X, B_EGRAD, B_GF, PART_A, eval_opts(t, 0, 0, 0));
     for (int k : mem) {

@@ -295,6 +295,8 @@ void account_iteration(dpgo_team *t, int sel, bool fused);
 int enqueue_optimize_group(dpgo_team *t, int g);
 int fetch_scal(dpgo_team *t, Agent &a);
 int refresh_rgd_result(dpgo_team *t, Agent &a);
+int read_ls_record(dpgo_team *t, Agent &a);
+int ls_trials(const dpgo_params_t &p);
 int refresh_rtr_result(dpgo_team *t, Agent &a, bool drained = false);
 double robust_weight(const dpgo_params_t &p, double mu, double residual);
 int compute_residuals(dpgo_team *t, Agent &a, std::vector<double> &res);

@@ -265,6 +265,11 @@ struct ROptParameters {                                          // :85,90,96-10
   bool RGD_use_preconditioner = true;
   double RTR_initial_radius = 100;
   unsigned RTR_iterations = 3, RTR_tCG_iterations = 50;
+  // RGD with a backtracking (Armijo) line search from RGD_stepsize (dpgo_params_t::rgd_line_search; no wrapper call site
+  // writes these: src/PGOAgentROSNode.cpp:86-97 sets method, RGD_stepsize, RGD_use_preconditioner only)
+  bool RGD_line_search = false;
+  unsigned RGD_ls_max_backoffs = 7;
+  double RGD_ls_shrink = 0.5, RGD_ls_sigma = 1e-4;
 };
 struct ROPTResult {  // mLocalOptResult (:169-172)
   bool success = false;

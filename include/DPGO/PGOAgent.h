@@ -397,6 +397,9 @@ class PGOAgent {
     c.gradnorm_tol = p.localOptimizationParams.gradnorm_tol;
     c.rtr_initial_radius = p.localOptimizationParams.RTR_initial_radius;
     c.rtr_max_radius = 5 * c.rtr_initial_radius;
+    c.rgd_line_search = p.localOptimizationParams.RGD_line_search ? 1 : 0;
+    c.rgd_ls_max_backoffs = (int)p.localOptimizationParams.RGD_ls_max_backoffs;
+    c.rgd_ls_shrink = p.localOptimizationParams.RGD_ls_shrink; c.rgd_ls_sigma = p.localOptimizationParams.RGD_ls_sigma;
     c.acceleration = p.acceleration; c.restart_interval = (int)p.restartInterval;
     c.rel_change_tol = p.relChangeTol; c.max_num_iters = (int)p.maxNumIters;
     c.robust_cost_type = p.robustCostParams.costType == RobustCostParameters::Type::L2 ? DPGO_COST_L2 : DPGO_COST_GNC_TLS;

@@ -74,6 +74,16 @@ typedef struct {
                                * 2 block-Jacobi, 3 two-level for every agent */
   int status_every_iterate;   /* 0 (default): relativeChange / readyToTerminate describe the last iterate(true) of the
                                * agent [UPSTREAM-RECALL]; 1: refreshed by every iterate (round-1 behaviour) */
+  /* RGD with a backtracking (Armijo) line search on the retraction curve (north_star "RTR/RGD line search"; SURVEY App. B:
+   * "a backtracking variant exists" [UPSTREAM-RECALL]; no wrapper call site selects it -- src/PGOAgentROSNode.cpp:86-97
+   * writes method, RGD_stepsize, RGD_use_preconditioner only -- so it is off unless asked for).  Trial steps
+   * t_j = rgd_stepsize * rgd_ls_shrink^j, j = 0 .. rgd_ls_max_backoffs (at most 7: eight trial points, all evaluated by
+   * one pass over Q); the first j with f(Retr_x(-t_j d)) <= f(x) - rgd_ls_sigma t_j <grad f(x), d> is taken; none: x
+   * stays put (dpgo_opt_result_t.accepted = 0). */
+  int rgd_line_search;
+  int rgd_ls_max_backoffs;
+  double rgd_ls_shrink;
+  double rgd_ls_sigma;
 } dpgo_params_t;
 
 /* mLocalOptResult.{success,fInit,fOpt,gradNormInit,gradNormOpt} (src/PGOAgentROS.cpp:169-172) */
@@ -81,6 +91,7 @@ typedef struct {
   int success;
   double f_init, f_opt, gradnorm_init, gradnorm_opt;
   int rtr_outer_iters, tcg_iters_total, hessvec_count, precond_count, accepted;
+  int ls_backoffs; /* RGD line search: back-offs before the accepted step */
 } dpgo_opt_result_t;
 
 /* PGOAgentStatus(agentID,state,instanceNumber,iterationNumber,readyToTerminate,relativeChange)

@@ -71,12 +71,23 @@ typedef struct {
                                * [UPSTREAM-RECALL, and the only rule under which the leader's check at
                                * PGOAgentROS.cpp:206-214 is meaningful without acceleration: iterate(false) leaves
                                * X = XPrev]; 1: refreshed by every iterate (round-1 behaviour) */
+  /* RGD with a backtracking (Armijo) line search on the retraction curve [UPSTREAM-RECALL: the library has a line-search
+   * variant of its gradient step; no call site of the wrapper selects it (src/PGOAgentROSNode.cpp:86-97 writes method,
+   * RGD_stepsize, RGD_use_preconditioner only) and its constants are not recoverable here -- the textbook rule (Absil,
+   * Mahony, Sepulchre 2008, Def. 4.2.2) with its parameters as fields]:  trial step t_j = rgd_stepsize * shrink^j,
+   * j = 0 .. max_backoffs; the first j with  f(Retr_x(-t_j d)) <= f(x) - sigma t_j <grad f(x), d>  is taken (d = the
+   * preconditioned gradient or the gradient); if none qualifies x stays put. */
+  int rgd_line_search;        /* 0 (default): fixed step */
+  int rgd_ls_max_backoffs;    /* 7: eight trial steps */
+  double rgd_ls_shrink;       /* 0.5 */
+  double rgd_ls_sigma;        /* 1e-4 */
 } orc_params_t;
 
 typedef struct {
   int success;
   double f_init, f_opt, gradnorm_init, gradnorm_opt;
   int rtr_outer_iters, tcg_iters_total, hessvec_count, precond_count, accepted;
+  int ls_backoffs;  /* line search: back-offs before the accepted step (max_backoffs + 1 and accepted = 0: none qualified) */
 } orc_opt_result_t;
 
 typedef struct {

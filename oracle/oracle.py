@@ -39,14 +39,17 @@ class Params(C.Structure):
                 ("gnc_mu_step", C.c_double), ("gnc_init_mu", C.c_double),
                 ("robust_opt_num_weight_updates", C.c_int), ("robust_opt_inner_iters", C.c_int),
                 ("robust_opt_min_convergence_ratio", C.c_double), ("weights_as_float32", C.c_int),
-                ("robust_opt_num_resets", C.c_int), ("precond_mode", C.c_int), ("status_every_iterate", C.c_int)]
+                ("robust_opt_num_resets", C.c_int), ("precond_mode", C.c_int), ("status_every_iterate", C.c_int),
+                ("rgd_line_search", C.c_int), ("rgd_ls_max_backoffs", C.c_int), ("rgd_ls_shrink", C.c_double),
+                ("rgd_ls_sigma", C.c_double)]
 
 
 class OptResult(C.Structure):
     _fields_ = [("success", C.c_int), ("f_init", C.c_double), ("f_opt", C.c_double),
                 ("gradnorm_init", C.c_double), ("gradnorm_opt", C.c_double),
                 ("rtr_outer_iters", C.c_int), ("tcg_iters_total", C.c_int),
-                ("hessvec_count", C.c_int), ("precond_count", C.c_int), ("accepted", C.c_int)]
+                ("hessvec_count", C.c_int), ("precond_count", C.c_int), ("accepted", C.c_int),
+                ("ls_backoffs", C.c_int)]
 
 
 class Status(C.Structure):

@@ -42,6 +42,10 @@ void orc_default_params(orc_params_t *p, int r, int num_robots) {
   p->robust_opt_num_resets = 0;  /* launch/PGOAgent.launch:33 */
   p->precond_mode = 0;
   p->status_every_iterate = 0;
+  p->rgd_line_search = 0;
+  p->rgd_ls_max_backoffs = 7;
+  p->rgd_ls_shrink = 0.5;
+  p->rgd_ls_sigma = 1e-4;
 }
 
 struct orc_agent {

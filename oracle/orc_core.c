@@ -618,8 +618,28 @@ void orc_optimize(const orc_problem_t *P, const orc_params_t *prm, const double 
     double *dir = (double *)malloc(sizeof(double) * N);
     if (prm->rgd_use_preconditioner) { orc_problem_precond(P, X0, gf, dir); res->precond_count++; }
     else memcpy(dir, gf, sizeof(double) * N);
-    for (size_t i = 0; i < N; ++i) dir[i] *= -prm->rgd_stepsize;
-    orc_retract(X0, dir, r, n, Xout);
+    if (prm->rgd_line_search) {
+      /* Armijo backtracking along the retraction curve (Absil, Mahony, Sepulchre 2008, Def. 4.2.2): the first trial step
+       * t_j = stepsize * shrink^j with sufficient decrease; none within max_backoffs: no step */
+      double slope = orc_dot(gf, dir, N), step = prm->rgd_stepsize;
+      double *eta = (double *)malloc(sizeof(double) * N), *eg = (double *)malloc(sizeof(double) * N);
+      int j, ok = 0;
+      for (j = 0; j <= prm->rgd_ls_max_backoffs; ++j) {
+        for (size_t i = 0; i < N; ++i) eta[i] = -step * dir[i];
+        orc_retract(X0, eta, r, n, Xout);
+        double ft = orc_problem_f(P, Xout, eg);
+        if (ft <= f1 - prm->rgd_ls_sigma * step * slope) { ok = 1; break; }
+        step *= prm->rgd_ls_shrink;
+      }
+      if (!ok) memcpy(Xout, X0, sizeof(double) * N);
+      res->ls_backoffs = j;
+      res->accepted = ok;
+      free(eta); free(eg);
+    } else {
+      for (size_t i = 0; i < N; ++i) dir[i] *= -prm->rgd_stepsize;
+      orc_retract(X0, dir, r, n, Xout);
+      res->accepted = 1;
+    }
     free(dir);
   } else {
     double *x1 = (double *)malloc(sizeof(double) * N), *x2 = (double *)malloc(sizeof(double) * N);
