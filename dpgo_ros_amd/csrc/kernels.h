@@ -110,9 +110,12 @@ void launch_bsr_to_dense(hipStream_t s, const int *rowptr, const int *col, const
 
 // rtr_fused.hip: one launch per local RTR solve, the agent's preconditioner resident in LDS over the whole solve.
 // bar: RTR_BAR_WORDS zero-initialised 64-bit words owned by the AGENT (the arrival counts depend on its grid);
-// ws: RTR_WS_DOUBLES doubles of partial-sum scratch; err: pinned host word raised on a spin time-out.
+// ws: RTR_WS_DOUBLES doubles of partial-sum scratch + RTR_RING x (r x 4n) doubles of H delta ring; err: pinned host word raised on a spin time-out.
 constexpr int RTR_BAR_WORDS = 18 * 16 + 160;
 constexpr int RTR_WS_DOUBLES = 7 * 512;
+__host__ __device__ inline size_t rtr_ring_pitch(size_t doubles) { return (doubles + 31) / 32 * 32; }  // whole 256-byte blocks
+constexpr int RTR_RING = 32;  // H delta buffers (r x 4n doubles each) behind the partial sums: one per tCG iteration, reused
+                              // after RTR_RING iterations (rtr_fused.hip)
 bool rtr_fused_eligible(int r, int n, int num_cus);
 size_t rtr_fused_lds_bytes(int r, int n);  // LDS the solve of an n-pose agent needs (checked against the device's limit)
 // cum: 4 zero-initialised 64-bit words per agent: running totals {solves, Hessian-vector products, preconditioner

@@ -82,10 +82,18 @@ constexpr int RB_TRACE = 17 * RB_LINE + 2;
 struct GridBar {
   unsigned long long *bar;
   unsigned long long epoch;
-  int g, size_g, ngroups;
+  int g, size_g, ngroups, total;
   int *err;
   int *ok;  // LDS word: 0 once this workgroup's hand-off timed out
 };
+
+// DPGO_RTR_FLATBAR=1: every workgroup adds itself to its shard counter and leaves when the SUM of the eight shard
+// counters (read as one batch of L1-bypassing loads) has reached total x epoch -- the last arrival is one atomic and one
+// poll away from everybody, where the counter tree (shard -> top -> generation words) puts three dependent round trips
+// between them.  Measured against each other: profiles/r04_rtr_handoff.md.
+#ifndef DPGO_RTR_FLATBAR
+#define DPGO_RTR_FLATBAR 0
+#endif
 
 // every workgroup of the launch arrives, every workgroup leaves after the last arrival.  Callers publish with st_c
 // (write-through) and read the others' data with CVec loads afterwards.  Returns false when the hand-off timed out:
@@ -99,6 +107,41 @@ __device__ __forceinline__ bool grid_sync(GridBar &gb, unsigned long long *tr = 
   __syncthreads();
   if (tr && threadIdx.x == 0) tr[1] = wall_clock64();
   gb.epoch += 1ull;
+#if DPGO_RTR_FLATBAR
+  if (threadIdx.x == 0) {
+#if DPGO_RTR_PLAIN_ST
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    (void)__hip_atomic_fetch_add(&gb.bar[gb.g * RB_LINE], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tr) tr[2] = wall_clock64();
+    const unsigned long long target = (unsigned long long)gb.total * gb.epoch;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(gb.bar, 0, 8 * RB_LINE * 8, 0x00020000);
+    const long long t_start = (long long)wall_clock64();
+    while (true) {
+      v2u_t w[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) w[q] = __builtin_amdgcn_raw_buffer_load_b64(rs, q * RB_LINE * 8, 0, 16);  // sc1
+      unsigned long long sum = 0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) sum += ((unsigned long long)w[q].y << 32) | (unsigned long long)w[q].x;
+      if (sum >= target) break;
+      __builtin_amdgcn_s_sleep(1);
+      if ((long long)wall_clock64() - t_start > RB_TIMEOUT_TICKS) {
+        *gb.err = 2;
+        *gb.ok = 0;
+        __hip_atomic_store(&gb.bar[RB_ABORT], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+    if (tr) tr[3] = wall_clock64();
+#if DPGO_RTR_PLAIN_LD
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+  }
+  __syncthreads();
+  return *gb.ok != 0;
+#else
   if (threadIdx.x == 0) {
 #if DPGO_RTR_PLAIN_ST
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -133,6 +176,7 @@ __device__ __forceinline__ bool grid_sync(GridBar &gb, unsigned long long *tr = 
   }
   __syncthreads();
   return *gb.ok != 0;
+#endif
 }
 
 // sum of `count` contiguous partials published by the workgroups of THIS launch, same order in every wave
@@ -157,6 +201,18 @@ __device__ __forceinline__ void csum_finish(double (*v)[CSUM_U], int count, int 
   }
 }
 
+// A vector that is written ONCE per launch at its address (the ring of H delta buffers below) needs no L1-bypassing
+// loads: no stale copy of it can sit in this CU's L1 or this XCD's L2, so ordinary loads fetch it from the fabric once per
+// XCD and serve the XCD's other 31 workgroups from L2 (sc1 loads bring all 80 KB to every workgroup: 20 MB per apply).
+struct PVec {
+  const double *p;
+  __device__ __forceinline__ explicit PVec(const double *q) : p(q) {}
+  __device__ __forceinline__ double ld(int i) const { return p[i]; }
+  __device__ __forceinline__ double2 ld2(int i) const { return *reinterpret_cast<const double2 *>(p + i); }
+};
+constexpr int RTR_RING_MASK = RTR_RING - 1;
+static_assert((RTR_RING & RTR_RING_MASK) == 0, "ring size is a power of two");
+
 // zs[c * R + a] = sum_k V[k][a] * Ms[c][k]  for the 8 columns of the slab: lane t takes rows 2t, 2t+1 (+512 m) of V
 // for ALL 8 columns, so every row of V is fetched once per workgroup (16-byte L1-bypassing loads straight from L2,
 // no LDS staging) and the slab is read from LDS exactly once.  The 256 per-lane sums go through a quad reduction
@@ -164,8 +220,8 @@ __device__ __forceinline__ void csum_finish(double (*v)[CSUM_U], int count, int 
 constexpr int SLAB_MAXM = 4;
 // straight-line code: rows beyond N4 read row N4 - 2 again and are multiplied by zero (one wave per SIMD: nothing
 // hides a wait, so every load of a step is in flight before the first FMA)
-template <int R>
-__device__ __forceinline__ void slab_issue(int N4, const CVec &V, int tid, double2 (*v)[R]) {
+template <int R, class Vec>
+__device__ __forceinline__ void slab_issue(int N4, const Vec &V, int tid, double2 (*v)[R]) {
 #pragma unroll
   for (int m = 0; m < SLAB_MAXM; ++m) {
     const int k = 2 * tid + 512 * m, kk = min(k, N4 - 2);
@@ -218,10 +274,11 @@ __device__ __forceinline__ void slab_finish(const double *Ms, int N4, double2 (*
     double t[64];
 #pragma unroll
     for (int q = 0; q < 64; ++q) t[q] = red[q * (8 * R + 1) + tid];
-    double s = 0;
+    // four interleaved chains (one wave per SIMD: a chain of 64 dependent adds is 64 add latencies)
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
 #pragma unroll
-    for (int q = 0; q < 64; ++q) s += t[q];
-    zs[tid] = s;
+    for (int q = 0; q < 64; q += 4) { s0 += t[q]; s1 += t[q + 1]; s2 += t[q + 2]; s3 += t[q + 3]; }
+    zs[tid] = (s0 + s1) + (s2 + s3);
   }
   if (tid < 64) WSYNC();
 }
@@ -403,9 +460,9 @@ __device__ __forceinline__ void tls_reduce(double (*acc)[R], double *red, double
   }
   __syncthreads();
 }
-template <int R>
+template <int R, class Vec>
 __device__ __forceinline__ bool tl_product_lds(const double *Ms, const TLDev &tl, const TLWg &w, int b, const TLLane &ln,
-                                               const CVec &V, GridBar &gb, double *red, double *zs, int tid) {
+                                               const Vec &V, GridBar &gb, double *red, double *zs, int tid) {
   const int npre = 2 * w.pre_cnt, npost = 2 * tl.ns;
   const bool producer = b < tl.nA;
   double acc[8][R];
@@ -537,6 +594,7 @@ __global__ __launch_bounds__(TL ? TLS_NT : 256) void k_rtr_solve(const AgentDev 
   gb.g = bx & 7;
   gb.size_g = (nblk - gb.g + 7) / 8;
   gb.ngroups = min(8, nblk);
+  gb.total = nblk;
 #ifdef DPGO_RTR_TRACE
   if (tid == 0 && bx == 0) for (int k = 0; k < 60; ++k) bar[RB_TRACE + k] = 0ull;
 #endif
@@ -609,9 +667,17 @@ __global__ __launch_bounds__(TL ? TLS_NT : 256) void k_rtr_solve(const AgentDev 
   bool fine_on = false;
   (void)fine_on;
 
-  double *Zg = ag.buf[B_Z], *HDg = ag.buf[B_HD], *ETAg = ag.buf[B_ETA], *X2g = ag.buf[B_X2], *GFg = ag.buf[B_GF];
+  double *Zg = ag.buf[B_Z], *ETAg = ag.buf[B_ETA], *X2g = ag.buf[B_X2], *GFg = ag.buf[B_GF];
   const int NV8 = N4 * R;
-  const CVec cGF(GFg, NV8), cHD(HDg, NV8), cX2(X2g, NV8), cETA(ETAg, NV8), cWS(ws, RTR_WS_PITCH * 7);
+  const CVec cGF(GFg, NV8), cX2(X2g, NV8), cETA(ETAg, NV8), cWS(ws, RTR_WS_PITCH * 7);
+  // H delta of tCG iteration k of this launch lives in slot k mod RTR_RING of a ring behind the partial sums: an address
+  // is written once and only then read (ordinary loads, PVec); when the ring wraps every workgroup drops what its L1 / L2
+  // hold of the previous pass (one agent-scope acquire per RTR_RING iterations)
+  // (slots are padded to whole 256-byte blocks: a cache line shared by two slots would be fetched with the first and
+  // serve stale bytes of the second)
+  double *ring = ws + RTR_WS_DOUBLES;
+  const size_t ring_pitch = rtr_ring_pitch(NV8);
+  int hd_slot = 0;
   const double kappa = 0.1;  // tCG stop: |r| <= |r0| min(|r0|^theta, kappa) with theta = 1
 
   int gf_fresh = 0;  // the gradient at X was published as the candidate's gradient (GF2) by the evaluation just accepted
@@ -707,6 +773,7 @@ __global__ __launch_bounds__(TL ? TLS_NT : 256) void k_rtr_solve(const AgentDev 
         S.z_r = zr_new;
       }
       S.hv_count += 1; S.tcg_total += 1;
+      double *HDj = ring + (size_t)(hd_slot & RTR_RING_MASK) * ring_pitch;
       if (wave == 0) {
         double w[1][4] = {{0, 0, 0, 0}}, vrow[4] = {0, 0, 0, 0}, hrow[4] = {0, 0, 0, 0};
         if (rl) {
@@ -731,7 +798,7 @@ __global__ __launch_bounds__(TL ? TLS_NT : 256) void k_rtr_solve(const AgentDev 
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
             const size_t o = ((size_t)4 * j + c) * R + a;
-            st_c(HDg + o, hrow[c]);
+            st_c(HDj + o, hrow[c]);
             Ws[lp * 4 * R + c * R + a] = hrow[c];  // own rows of H delta for the residual update below
             d += vrow[c] * hrow[c];
           }
@@ -747,6 +814,9 @@ __global__ __launch_bounds__(TL ? TLS_NT : 256) void k_rtr_solve(const AgentDev 
 #endif
       RTR_FINE(9);
       RTR_STAMP(stamp++);
+      if (hd_slot >= RTR_RING && (hd_slot & RTR_RING_MASK) == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the ring wrapped
+      hd_slot += 1;
+      const PVec cHD(HDj);
 
       // ---- part 2 (k_precond<PM_TCG_STEP>): alpha, boundary test, eta += alpha delta, r += alpha H delta,
       //      z += alpha P(H delta M)

@@ -173,7 +173,7 @@ int enqueue_optimize(dpgo_team *t, int sel, const OptFlags &fl) {
     // running a persistent kernel on this GPU) is met with the launch-per-step sequence instead of an error.
     const int grid_key = tl_fused ? 100000000 + a.tl_plan.nwg - a.tl_plan.nS2 : a.n;  // the hand-off counters depend on the grid
     if (a.rtr_bar_n != grid_key) {
-      if (a.d_rtr_bar.alloc(RTR_BAR_WORDS) || a.d_rtr_ws.alloc(RTR_WS_DOUBLES) || a.h_rtr.alloc(1) || a.h_rtr_cum.alloc(4)) {
+      if (a.d_rtr_bar.alloc(RTR_BAR_WORDS) || a.d_rtr_ws.alloc(RTR_WS_DOUBLES + (size_t)RTR_RING * rtr_ring_pitch((size_t)4 * a.n * p.r)) || a.h_rtr.alloc(1) || a.h_rtr_cum.alloc(4)) {
         set_err("RTR scratch allocation failed"); return DPGO_ERR;
       }
       if (!a.d_rtr_cum.p) {

@@ -85,6 +85,10 @@ def test_agent_api_and_colour_classes():
     for _ in range(6):
         to.iterate()
     assert np.abs(th.global_X() - to.global_X()).max() < 1e-10
+    for b in range(2):  # (the sweep read its neighbours in place: the slabs the per-agent calls read are filled by messages)
+        for c in th.agents[b].neighbors():
+            ids, poses = th.agents[b].get_public_poses(c)
+            th.agents[c].update_neighbor_poses(b, ids, poses)
     for it in range(6):  # per-agent calls with host exchange
         sel = it % 2
         for b in range(2):

@@ -155,3 +155,36 @@ def test_one_launch_solve_with_the_two_level_preconditioner(dataset, N, r, accel
         assert (rf.rtr_outer_iters, rf.tcg_iters_total, rf.accepted) == (ro.rtr_outer_iters, ro.tcg_iters_total, ro.accepted)
     tf.close()
     ts.close()
+
+
+def test_h_delta_ring_wraps_within_one_solve():
+    """H delta of tCG iteration k sits in slot k mod 32 of a ring that is read with ordinary (cached) loads: solves of
+    more than 32 tCG iterations reuse slots (one agent-scope acquire per wrap), and slots of agents whose vectors are not
+    whole cache lines long are padded -- a line shared by two slots served stale bytes of the second (found by this file's
+    first test on 41-pose agents when the ring was introduced)."""
+    N, iters = 2, 8
+    kw = dict(method=capi.METHOD_RTR, acceleration=0, gradnorm_tol=1e-12, rtr_iterations=8, rtr_tcg_iterations=40)
+    for dataset, r in (("smallGrid3D", 5), ("smallGrid3D", 3), ("parking-garage", 5)):
+        m, mp, n = load(dataset, N if dataset == "smallGrid3D" else 5)
+        nr = N if dataset == "smallGrid3D" else 5
+        ph, po = params_pair(r=r, num_robots=nr, **kw)
+        T, Y = O.odometry_init(m, n), O.fixed_stiefel(r)
+        tf, ts = _team(mp, ph, True), _team(mp, ph, False)
+        to = O.Team(mp, n, po)
+        for t in (tf, ts, to):
+            t.set_initial(T, Y)
+        most = 0
+        for k in range(iters):
+            tf.run(1)
+            ts.run(1)
+            sel = to.iterate()
+            rf, rs, ro = tf.agents[sel].opt_result(), ts.agents[sel].opt_result(), to.agents[sel].opt_result()
+            assert (rf.rtr_outer_iters, rf.tcg_iters_total, rf.accepted) == (rs.rtr_outer_iters, rs.tcg_iters_total, rs.accepted)
+            assert (rf.rtr_outer_iters, rf.tcg_iters_total, rf.accepted) == (ro.rtr_outer_iters, ro.tcg_iters_total, ro.accepted)
+            most = max(most, rf.tcg_iters_total)
+        assert most > 40, most  # the ring did wrap
+        assert _handoffs(tf, 0) > 0
+        assert np.abs(tf.global_X() - ts.global_X()).max() < 1e-9
+        assert np.abs(tf.global_X() - to.global_X()).max() < 1e-7
+        tf.close()
+        ts.close()

@@ -37,14 +37,17 @@ def test_hip_path_reproduces_the_reference_weights():
     check_against_the_file(m, wfile, inl, rows_h)
     # HIP against the oracle beside it.  Each round is 400 RTR block updates that stop at gradnorm < 0.5 and accept on
     # rho > 0.1: a solve that lands within round-off of either threshold goes one way here and the other way there, and
-    # the paths then differ by one (small, near-converged) step -- measured on the MI355X: weights 1.2e-7 absolute after
-    # round 2 (1e-4 of a typical weight), which is two orders inside the 1 % at which either path agrees with the file.
+    # the paths then differ by one (small, near-converged) step.  Measured on the MI355X: weights 1.2e-7 / 7.0e-7 / 6.3e-7 /
+    # 2.6e-7 absolute after rounds 2 .. 5 (1e-4 .. 1e-3 of a typical weight, an order inside the 1 % at which either path
+    # agrees with the file); the iterates themselves end 3.8e-3 apart -- along the gauge directions of the team's cost,
+    # which nothing pulls back: the cost (gauge invariant) is the comparison that means something.
     dw = [float(np.abs(h["weights"] - o["weights"]).max()) for h, o in zip(rows_h, rows_o)]
     dx = float(np.abs(th.global_X() - to.global_X()).max())
-    print("max |w_hip - w_oracle| per round:", dw, " max |X_hip - X_oracle| at the end:", dx)
+    fh, fo = th.cost(), to.cost()
+    print("max |w_hip - w_oracle| per round:", dw, " max |X_hip - X_oracle| at the end:", dx, " costs", fh, fo)
     for rnd, (h, o) in enumerate(zip(rows_h, rows_o)):
         assert np.array_equal(h["fixed"], o["fixed"])
         assert (h["weights"] == 0).sum() == (o["weights"] == 0).sum(), rnd
         assert abs(h["median"] - o["median"]) < 2e-4 and abs(h["rest_median"] - o["rest_median"]) < 2e-4
-    assert max(dw) < 5e-6 and dx < 1e-3, (dw, dx)
+    assert dw[0] < 1e-12 and max(dw) < 5e-6 and dx < 5e-2 and abs(fh - fo) <= 1e-5 * abs(fo), (dw, dx, fh, fo)
     th.close()
