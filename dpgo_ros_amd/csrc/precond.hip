@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *__restrict__ ag
         w[2 * j] = t2.x; w[2 * j + 1] = t2.y;
       }
 #pragma unroll
-      for (int a = 0; a < R; ++a) acc[a] += w[a] * mreg[m].x + w[R + a] * mreg[m].y;
+      for (int a = 0; a < R; ++a) acc[a] = __builtin_fma(w[R + a], mreg[m].y, __builtin_fma(w[a], mreg[m].x, acc[a]));  // (two FMAs: the one-expression form is mul, fma, add)
     }
   }
   PC_STAMP(4);

@@ -230,8 +230,12 @@ __device__ __forceinline__ void slab_issue(int N4, const Vec &V, int tid, double
   }
 }
 template <int R>
-__device__ __forceinline__ void slab_finish(const double *Ms, int N4, double2 (*v)[R], double *red, double *zs, int tid) {
+__device__ __forceinline__ void slab_finish(const double *Ms, int N4, double2 (*v)[R], double *red, double *zs, int tid,
+                                            unsigned long long *tr = nullptr) {
   constexpr int MAXM = SLAB_MAXM;
+#ifdef DPGO_RTR_TRACE
+  if (tr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (tid == 0) tr[0] = wall_clock64(); }  // the vector has arrived
+#endif
   double acc[8][R];
 #pragma unroll
   for (int c = 0; c < 8; ++c)
@@ -247,12 +251,22 @@ __device__ __forceinline__ void slab_finish(const double *Ms, int N4, double2 (*
     double w[2 * R];
 #pragma unroll
     for (int q = 0; q < R; ++q) { w[2 * q] = v[m][q].x * live; w[2 * q + 1] = v[m][q].y * live; }
+    // two fused multiply-adds per accumulator, 8R independent accumulators: `acc += w0 * m.x + w1 * m.y` compiles to
+    // mul, fma, add through ONE temporary -- a dependent chain per accumulator that one wave per SIMD cannot hide
+    // (2.8 us of the 4.7 us this product took, profiles/r04_rtr_phases.md)
 #pragma unroll
     for (int c = 0; c < 8; ++c)
 #pragma unroll
-      for (int a = 0; a < R; ++a) acc[c][a] += w[a] * mm[c].x + w[R + a] * mm[c].y;
+      for (int a = 0; a < R; ++a) acc[c][a] = __builtin_fma(w[a], mm[c].x, acc[c][a]);
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+      for (int a = 0; a < R; ++a) acc[c][a] = __builtin_fma(w[R + a], mm[c].y, acc[c][a]);
   }
   const int lane = tid & 63, wave = tid >> 6;
+#ifdef DPGO_RTR_TRACE
+  if (tr && tid == 0) tr[1] = wall_clock64();  // products done
+#endif
 #pragma unroll
   for (int c = 0; c < 8; ++c)
 #pragma unroll
@@ -270,6 +284,9 @@ __device__ __forceinline__ void slab_finish(const double *Ms, int N4, double2 (*
       for (int a = 0; a < R; ++a) row[c * R + a] = acc[c][a];
   }
   __syncthreads();
+#ifdef DPGO_RTR_TRACE
+  if (tr && tid == 0) tr[2] = wall_clock64();  // quad sums in LDS, barrier passed
+#endif
   if (tid < 8 * R) {
     double t[64];
 #pragma unroll
@@ -842,7 +859,11 @@ __global__ __launch_bounds__(TL ? TLS_NT : 256) void k_rtr_solve(const AgentDev 
       if constexpr (TL) {
         if (!tl_product_lds<R>(Ms, ag.tl, tlw, tb, tln, cHD, gb, red, zs, tid)) return;
       } else {
+#ifdef DPGO_RTR_TRACE
+        slab_finish<R>(Ms, N4, vv, red, zs, tid, (bx == 0 && fine_on) ? bar + RB_TRACE + 64 + 20 : nullptr);
+#else
         slab_finish<R>(Ms, N4, vv, red, zs, tid);
+#endif
       }
       RTR_FINE(11);
       {

@@ -336,7 +336,7 @@ __global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ ag
       wv[2 * q] = t2.x; wv[2 * q + 1] = t2.y;
     }
 #pragma unroll
-    for (int a = 0; a < R; ++a) acc[a] += wv[a] * mreg[m].x + wv[R + a] * mreg[m].y;
+    for (int a = 0; a < R; ++a) acc[a] = __builtin_fma(wv[R + a], mreg[m].y, __builtin_fma(wv[a], mreg[m].x, acc[a]));  // (two FMAs: the one-expression form is mul, fma, add)
   }
   FE_STAMP(5);
 #pragma unroll

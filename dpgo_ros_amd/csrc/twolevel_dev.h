@@ -32,10 +32,16 @@ __device__ __forceinline__ void tl_fma(double (*acc)[R], const double2 *v, const
   double w[2 * R];
 #pragma unroll
   for (int q = 0; q < R; ++q) { w[2 * q] = v[q].x * live; w[2 * q + 1] = v[q].y * live; }
+  // (two fused multiply-adds per accumulator: the one-expression form is mul, fma, add through one temporary, a
+  // dependent chain per accumulator)
 #pragma unroll
   for (int c = 0; c < 8; ++c)
 #pragma unroll
-    for (int a = 0; a < R; ++a) acc[c][a] += w[a] * mm[c].x + w[R + a] * mm[c].y;
+    for (int a = 0; a < R; ++a) acc[c][a] = __builtin_fma(w[a], mm[c].x, acc[c][a]);
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int a = 0; a < R; ++a) acc[c][a] = __builtin_fma(w[R + a], mm[c].y, acc[c][a]);
 }
 
 // the 256 per-lane sums of the 8R outputs -> zs[c * R + a], valid in every wave on return.  red: TL_RED_DOUBLES(R)

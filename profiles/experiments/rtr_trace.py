@@ -22,3 +22,5 @@ fine = np.array(out[17 * 16 + 2 + 64:17 * 16 + 2 + 64 + 18], dtype=np.int64)
 print("fine (tCG iteration 1 of outer 0; us since its start): 0 start, 1 sums, 2 gathers, 3 hess tail, 4 stores, 5 drained, 6 wg barrier, 7 arrived, 8 released, 9 out,")
 print("   10 sum, 11 slab apply, 12 tail+stores, 13 drained, 14 wg barrier, 15 arrived, 16 released, 17 out")
 print(np.round((fine - fine[0]) / 100.0, 2).tolist())
+sl = np.array(out[17 * 16 + 2 + 64 + 20:17 * 16 + 2 + 64 + 23], dtype=np.int64)
+print("inside the slab product (us since the iteration's start): vector arrived, products done, quad sums in LDS + barrier:", np.round((sl - fine[0]) / 100.0, 2).tolist())

@@ -158,23 +158,22 @@ def test_one_launch_solve_with_the_two_level_preconditioner(dataset, N, r, accel
 
 
 def test_h_delta_ring_wraps_within_one_solve():
-    """H delta of tCG iteration k sits in slot k mod 32 of a ring that is read with ordinary (cached) loads: solves of
+    """H delta of tCG iteration k sits in slot k mod 32 of a ring that is read with ordinary (cached) loads: launches of
     more than 32 tCG iterations reuse slots (one agent-scope acquire per wrap), and slots of agents whose vectors are not
     whole cache lines long are padded -- a line shared by two slots served stale bytes of the second (found by this file's
-    first test on 41-pose agents when the ring was introduced)."""
-    N, iters = 2, 8
-    kw = dict(method=capi.METHOD_RTR, acceleration=0, gradnorm_tol=1e-12, rtr_iterations=8, rtr_tcg_iterations=40)
-    for dataset, r in (("smallGrid3D", 5), ("smallGrid3D", 3), ("parking-garage", 5)):
-        m, mp, n = load(dataset, N if dataset == "smallGrid3D" else 5)
-        nr = N if dataset == "smallGrid3D" else 5
-        ph, po = params_pair(r=r, num_robots=nr, **kw)
+    first test on 41-pose agents when the ring was introduced).  Many outer iterations per solve at a tolerance the first
+    block updates are far from, so that the counts do not hinge on round-off at a stop test."""
+    for dataset, N, r, outer in (("smallGrid3D", 3, 5, 8), ("smallGrid3D", 3, 3, 8), ("sphere2500", 7, 5, 12)):
+        kw = dict(method=capi.METHOD_RTR, acceleration=0, gradnorm_tol=1e-3, rtr_iterations=outer, rtr_tcg_iterations=30)
+        m, mp, n = load(dataset, N)
+        ph, po = params_pair(r=r, num_robots=N, **kw)
         T, Y = O.odometry_init(m, n), O.fixed_stiefel(r)
         tf, ts = _team(mp, ph, True), _team(mp, ph, False)
         to = O.Team(mp, n, po)
         for t in (tf, ts, to):
             t.set_initial(T, Y)
         most = 0
-        for k in range(iters):
+        for k in range(N):
             tf.run(1)
             ts.run(1)
             sel = to.iterate()
@@ -182,7 +181,7 @@ def test_h_delta_ring_wraps_within_one_solve():
             assert (rf.rtr_outer_iters, rf.tcg_iters_total, rf.accepted) == (rs.rtr_outer_iters, rs.tcg_iters_total, rs.accepted)
             assert (rf.rtr_outer_iters, rf.tcg_iters_total, rf.accepted) == (ro.rtr_outer_iters, ro.tcg_iters_total, ro.accepted)
             most = max(most, rf.tcg_iters_total)
-        assert most > 40, most  # the ring did wrap
+        assert most > 34, (dataset, most)  # the ring did wrap
         assert _handoffs(tf, 0) > 0
         assert np.abs(tf.global_X() - ts.global_X()).max() < 1e-9
         assert np.abs(tf.global_X() - to.global_X()).max() < 1e-7
