@@ -548,6 +548,7 @@ int sync_descs_noflush(dpgo_team *t) {
     const size_t B = (size_t)4 * t->prm.r;
     for (auto &d : a->se_host) {
       d.src[0] = d.src[1] = nullptr;
+      d.src_yalt = nullptr;
       if (d.src_agent_local < 0) {
         // a neighbour in another process whose X / Y arrays were imported: read it in place, like a co-resident one
         auto pit = t->peers.find(d.src_robot);
@@ -561,6 +562,7 @@ int sync_descs_noflush(dpgo_team *t) {
       if (!sa.dev.buf[B_X] || d.src_frame < 0 || d.src_frame >= sa.n) continue;
       d.src[0] = sa.dev.buf[B_X] + (size_t)d.src_frame * B;
       d.src[1] = sa.dev.buf[B_Y] + (size_t)d.src_frame * B;
+      d.src_yalt = sa.dev.buf[B_YALT] + (size_t)d.src_frame * B;
     }
     if (a->d_se.upload(a->se_host, t->stream)) { set_err("shared-edge upload failed"); return DPGO_ERR; }
     a->dev.se = a->d_se.p;

@@ -72,9 +72,8 @@ dpgo_team_t *dpgo_team_create(int device, const dpgo_params_t *p, int num_local,
     if (e2) t->use_fused_rtr = (e2[0] == '0') ? 0 : 1;
     const char *e5 = std::getenv("DPGO_FUSED_EVAL");
     if (e5) t->use_fused_eval = (e5[0] == '0') ? 0 : 1;
-    if (t->d_nest_all.alloc(3 * std::max(1, num_local)) || t->d_fe_sync.alloc(16) ||
+    if (t->d_nest_all.alloc(3 * std::max(1, num_local)) ||
         hipMemset(t->d_nest_all.p, 0, sizeof(NestState) * 3 * std::max(1, num_local)) != hipSuccess ||
-        hipMemset(t->d_fe_sync.p, 0, sizeof(unsigned long long) * 16) != hipSuccess ||
         hipHostMalloc((void **)&t->h_bar_err, sizeof(int)) != hipSuccess) {
       delete t; set_err("hand-off state allocation failed"); return nullptr;
     }
@@ -949,17 +948,18 @@ int dpgo_team_step_end(dpgo_team_t *t, int sel_id) {
 // (both alternating instances of each), execute nothing
 // the one-launch iteration (step_fused.hip) may serve this team: dense agents of 257 .. 512 poses whose rows fit the ELL
 // part, few enough public poses / shared edges for its LDS tables, the schedule and the descriptors baked into the
-// launches (period <= 8), every workgroup of a launch resident at once
+// launches (period <= 8), every neighbour co-resident (the twins of its poses are addressed through the shared-edge table)
 static bool fused_eval_eligible(dpgo_team_t *t) {
   const dpgo_params_t &p = t->prm;
   const int P = (int)t->sched.size();
   if (!(t->use_fused_eval && t->bake_sel && t->bake_desc && P >= 1 && P <= 8 && step_fe_supported(p.r) && p.acceleration &&
         p.method == DPGO_METHOD_RGD && p.rgd_use_preconditioner && (int)t->ag.size() <= LOOKAHEAD_MAX_AGENTS &&
-        t->h_descs.size() == t->ag.size() && t->precond_of.size() == t->ag.size()))
+        t->h_descs.size() == t->ag.size() && t->precond_of.size() == t->ag.size() && t->peers.empty() &&
+        (int)t->ag.size() == p.num_robots))
     return false;
   for (size_t k = 0; k < t->ag.size(); ++k) {
-    const int n = t->ag[k]->n, grid = ((4 * n + 7) / 8 + 7) / 8 * 8;
-    if (t->precond_of[k] != DPGO_PRECOND_DENSE || n <= 256 || n > 512 || grid > t->num_cus || !t->ag[k]->has_soa ||
+    const int n = t->ag[k]->n;
+    if (t->precond_of[k] != DPGO_PRECOND_DENSE || n <= 256 || n > 512 || !t->ag[k]->has_soa ||
         t->h_descs[k].nshared > step_fe_max_edges())
       return false;
   }
@@ -1003,9 +1003,8 @@ static int team_run_impl(dpgo_team_t *t, int iters, bool prepare_only) {
   const int P = (int)t->sched.size();
   const bool bake = t->bake_sel && P >= 1 && P <= 8;
   // One-launch iterations (step_fused.hip) for the mid-run part of a pipelined graph: dense agents of 257 .. 512 poses,
-  // the schedule and the descriptors baked in, every workgroup of a launch resident at once -- and, because their
-  // workgroups wait for each other before they store, only while this team holds the device's lock (as the one-launch
-  // RTR solve: two such grids on one device could starve each other)
+  // the schedule and the descriptors baked in.  Their launches alternate between the two copies of the poses (parity),
+  // so they need neither each other's company on the device nor its lock
   const bool fe_ok = pipelined && graphable && fused_eval_eligible(t);
   auto graph_for = [&](bool lead, int B, int iter0, bool fe, hipGraphExec_t *out) -> int {
     const int phase = bake ? iter0 % P : -1;
@@ -1030,17 +1029,15 @@ static int team_run_impl(dpgo_team_t *t, int iters, bool prepare_only) {
       // last block update of the run lies among them, and a status query reads it, a9), the look-aheads in front of
       // them leave XPrev and |Y' - X|^2; nothing reads these values earlier in the run
       const int L = std::min(B, (int)t->sched.size());
-      // iterations [0, nfe): one launch each (they are the ones that leave nothing behind: ahead == 3)
-      const int nfe = fe ? std::max(0, B - L - 1) : 0;
+      // iterations [0, nfe): one launch each (they are the ones that leave nothing behind: ahead == 3); an even number,
+      // so that the poses end in the primary arrays
+      const int nfe = fe ? (std::max(0, B - L - 1) & ~1) : 0;
       NestState *nest_own = t->d_nest_all.p, *nest_fe[2] = {t->d_nest_all.p + na, t->d_nest_all.p + 2 * na};
-      unsigned long long target = 0;
-      if (nfe > 0) HIPC(hipMemsetAsync(t->d_fe_sync.p, 0, sizeof(unsigned long long), t->stream));
       for (int rep = 0; rep < B; ++rep) {
         const int ahead = (rep + 1 < B ? 3 : 0) | ((rep + 1 < B && rep + 1 >= B - L) ? 4 : 0) | (rep >= B - L ? 8 : 0);
         if (rep < nfe) {
-          target += (unsigned long long)((4 * t->ag[sel_at(rep)]->n + 7) / 8);
           launch_step_fe(c, sel_at(rep), sel_at(rep + 1), p.rgd_stepsize, p.num_robots, p.restart_interval,
-                         rep == 0 ? nest_own : nest_fe[rep & 1], nest_fe[(rep + 1) & 1], t->d_fe_sync.p, target, t->h_bar_err);
+                         rep == 0 ? nest_own : nest_fe[rep & 1], nest_fe[(rep + 1) & 1], rep & 1);
           continue;
         }
         launch_eval_stats(c, mn, rep == 0, 1, 0, p.num_robots, p.restart_interval, sel_at(rep), -1,
@@ -1100,7 +1097,7 @@ static int team_run_impl(dpgo_team_t *t, int iters, bool prepare_only) {
       batch = fusedn + (restart ? 1 : 0);
       hipGraphExec_t ge = nullptr;
       // (prepared graphs are the ones a run will ask for: with the one-launch iterations if this team may take the lock)
-      const bool fe = fe_ok && fusedn > (int)t->sched.size() + 1 && (prepare_only || acquire_fused_rtr_lock(t));
+      const bool fe = fe_ok && fusedn > (int)t->sched.size() + 2;
       const int grc = graph_for(restart, fusedn, cur_iter, fe, &ge);
       if (grc) return grc;
       if (prepare_only) {
@@ -1112,7 +1109,7 @@ static int team_run_impl(dpgo_team_t *t, int iters, bool prepare_only) {
       }
       ++t->epoch;
       HIPC(hipGraphLaunch(ge, t->stream));
-      if (fe) t->counters[7] += std::max(0, fusedn - std::min(fusedn, (int)t->sched.size()) - 1);  // one-launch iterations
+      if (fe) t->counters[7] += std::max(0, fusedn - std::min(fusedn, (int)t->sched.size()) - 1) & ~1;  // one-launch iterations
       // after >= 2 pipelined iterations every agent took its last Nesterov step as a look-ahead (per-pose partials)
       for (auto &a : t->ag) a->rel_src = p.acceleration ? ((pipelined && fusedn >= 2) ? 4 : 0) : 2;
       for (int q = 0; q < batch; ++q) {
@@ -1724,7 +1721,7 @@ int dpgo_team_time_kernel(dpgo_team_t *t, int id, int which, int reps, double *a
       for (auto &b : t->ag) total += b->n;
       for (auto &b : t->ag) if ((total - b->n + precond_nblk(*b) - 1) / precond_nblk(*b) > 64) pipelined = false;
     }
-    if (!pipelined || !fused_eval_eligible(t) || !acquire_fused_rtr_lock(t)) { set_err("one-launch iteration not available for this team"); return DPGO_ERR; }
+    if (!pipelined || !fused_eval_eligible(t)) { set_err("one-launch iteration not available for this team"); return DPGO_ERR; }
     double others = 0;
     for (auto &b : t->ag) if (b.get() != a) others += 8.0 * r * 4 * b->n;
     *algorithmic_bytes = precond_operator_bytes(*a) + 7.0 * vec + 4.0 * others + spmm_bytes_of(t, *a);
@@ -1734,21 +1731,18 @@ int dpgo_team_time_kernel(dpgo_team_t *t, int id, int which, int reps, double *a
     cc.bake_desc = true;
     auto sel_at = [&](int rep) { return t->sched[(size_t)((t->iter + rep) % P)]; };
     NestState *nest_own = t->d_nest_all.p, *nest_fe[2] = {t->d_nest_all.p + na, t->d_nest_all.p + 2 * na};
-    unsigned long long target = 0;
     launch_nest_pre(cc, -1, -1, na, mn, p.num_robots, p.restart_interval, 1);
-    HIPC(hipMemsetAsync(t->d_fe_sync.p, 0, sizeof(unsigned long long), t->stream));
-    const int total_reps = reps + 8;
+    const int total_reps = ((reps + 1) & ~1) + 8;  // (even: the poses end in the primary arrays)
+    reps = total_reps - 8;
     for (int k = 0; k < total_reps; ++k) {
       if (k == 8) HIPC(hipEventRecord(e0, t->stream));
-      target += (unsigned long long)((4 * t->ag[sel_at(k)]->n + 7) / 8);
       launch_step_fe(cc, sel_at(k), sel_at(k + 1), p.rgd_stepsize, p.num_robots, p.restart_interval,
-                     k == 0 ? nest_own : nest_fe[k & 1], nest_fe[(k + 1) & 1], t->d_fe_sync.p, target, t->h_bar_err);
+                     k == 0 ? nest_own : nest_fe[k & 1], nest_fe[(k + 1) & 1], k & 1);
     }
     HIPC(hipEventRecord(e1, t->stream));
     launch_eval_stats(cc, mn, 0, 0, 1, p.num_robots, p.restart_interval, -1, sel_at(total_reps - 1), nest_fe[total_reps & 1]);
     HIPC(hipEventSynchronize(e1));
     HIPC(hipStreamSynchronize(t->stream));
-    release_fused_rtr_lock(t);
     t->iter += total_reps;
     float ms = 0;
     HIPC(hipEventElapsedTime(&ms, e0, e1));

@@ -9,8 +9,14 @@ enum Buf {
   B_X = 0, B_XPREV, B_Y, B_V, B_G,
   B_EGRAD, B_GF, B_Z, B_ETA, B_R0, B_R1, B_D0, B_D1, B_HD,
   B_X2, B_EGRAD2, B_GF2, B_HETA, B_T0, B_T1, B_T2,
+  // second copies of X and Y: the one-launch iteration (step_fused.hip) reads the poses of one parity and writes the
+  // other, so that no workgroup of a launch overwrites what another still reads.  Both sit B_ALT vectors behind their
+  // primaries (one displacement turns any pointer into a primary array into its twin)
+  B_XALT, B_ALTPAD_, B_YALT,
   NBUF
 };
+constexpr int B_ALT = B_XALT - B_X;
+static_assert(B_YALT - B_Y == B_ALT, "X and Y twins share one displacement");
 
 // one shared (inter-robot) edge as seen by the G assembly: G_i[:,c] -= sum_cp Xn[:,cp] coef[cp+4c]
 struct SharedEdgeDev {
@@ -22,6 +28,7 @@ struct SharedEdgeDev {
   const double *src[2];  // the neighbour's pose in its agent's X ([0]) / Y ([1]) array when co-resident -- or when the
                          // neighbour lives in another process whose arrays were imported (IPC, peer access over xGMI) --
                          // else null: one load instead of the agents[src].buf[...] descriptor round trip
+  const double *src_yalt;  // the same pose in the neighbour's B_YALT array (co-resident neighbours only, else null)
   double coef[16];
 };
 

@@ -52,14 +52,12 @@ void launch_eval_stats(const LaunchCtx &c, int max_n, int first, int has_eval, i
                        int restart_interval, int eval_sel = -1, int stats_sel = -1, const NestState *nest_copy = nullptr);
 // one launch per pipelined accelerated-RGD iteration (step_fused.hip): evaluation + preconditioned step + look-ahead.
 // sel / next_sel: the agents of this iteration and the next (baked); nest_src / nest_dst: the NestStates [local agent]
-// this launch reads / leaves advanced; sync[0] counts the workgroups whose evaluation is done, `target` = its value once
-// every workgroup of THIS launch has arrived (cumulative over the fused launches since sync was cleared)
+// this launch reads / leaves advanced; parity: which copy of the poses it reads (0: B_X / B_Y, 1: their twins) -- it
+// writes the other one, so consecutive launches alternate and a run of them has an even length
 bool step_fe_supported(int r);
 int step_fe_max_edges();
 void launch_step_fe(const LaunchCtx &c, int sel, int next_sel, double step, int num_robots, int restart_interval,
-                    const NestState *nest_src, NestState *nest_dst, unsigned long long *sync, unsigned long long target, int *err);
-// linesearch.hip: RGD with a backtracking (Armijo) line search -- all trial points, all trial costs from one pass over Q,
-// the decision re-derived by every workgroup of the apply (record in AgentDev::scal[8..11])
+                    const NestState *nest_src, NestState *nest_dst, int parity);
 constexpr int LS_MAX_TRIALS = 8;
 void launch_ls_trials(const LaunchCtx &c, int sel, int max_n, int dirb, double step0, double shrink, int ntrials);
 void launch_ls_cost(const LaunchCtx &c, int sel, int max_n, int dirb, int ntrials);

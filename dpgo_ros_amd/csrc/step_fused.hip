@@ -33,10 +33,12 @@
 //
 // What no longer holds "for free" behind a kernel boundary, and how it is kept:
 //   * the evaluation reads X of the whole agent and the neighbours' auxiliary poses, the tails / look-ahead steps of the
-//     SAME launch overwrite them: every workgroup counts itself in once its gradient is formed (one counter, cumulative
-//     target baked into the launch), and nobody stores a pose before the counter is complete.  All workgroups of the
-//     launch are resident at once (one per CU, checked by the host; the team holds the device's lock while such graphs
-//     run, as for the one-launch RTR solve); the stores come 5 us after the last arrival.
+//     SAME launch write poses.  Round 4: the poses live twice (B_X / B_Y and their twins B_XALT / B_YALT, dpgo_dev.h); a
+//     launch reads the copy of its parity and writes the other one -- every pose of every agent moves or is carried over,
+//     so the copy a launch leaves is complete -- and the next launch does the opposite; a run of one-launch iterations
+//     has an even length, so the state ends in the primary arrays.  (Round 3 kept one copy: every workgroup counted itself
+//     in once its gradient was formed and nobody stored before the counter was complete -- which needed every workgroup
+//     of a launch resident at once, the device's lock, and a spin that could only give up.)
 //   * the Nesterov scalars advance between iterations: they are double-buffered -- workgroup 0 writes the next state
 //     next to the one every workgroup of this launch reads; the launch that leaves the fused run copies it back
 //     (k_eval_stats, nest_copy).
@@ -70,7 +72,6 @@ namespace dpgo {
 #endif
 
 constexpr int FE_KC = 2048;
-constexpr int FE_SPIN_LIMIT = 1 << 22;
 #ifndef DPGO_FE_PARTS
 #define DPGO_FE_PARTS 4
 #endif
@@ -104,8 +105,16 @@ __device__ __forceinline__ void fe_pin(double *w) {
 template <int R, int WD>
 __global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ agents, TeamDev *team, int sel, int next_sel, double step,
                                                  int num_robots, int restart_interval, const NestState *nest_src, NestState *nest_dst,
-                                                 unsigned long long *sync, unsigned long long target, int *err, const AgentDev agv) {
+                                                 int parity, const AgentDev agv) {
   const AgentDev &ag = agv;
+  // The poses live twice (B_X / B_Y and their twins B_XALT / B_YALT): this launch reads the copy of its parity and writes
+  // the other one -- every pose of every agent, so the copy it leaves is complete -- and the next launch does the
+  // opposite.  Nobody overwrites what another workgroup of the same launch still reads: no arrival counter, no wait, no
+  // co-residency condition, no device lock (rounds 3's form counted the workgroups in and spun).
+  const double *__restrict__ Xr = ag.buf[parity ? B_XALT : B_X];
+  const double *__restrict__ Yr = ag.buf[parity ? B_YALT : B_Y];
+  double *__restrict__ Xw = ag.buf[parity ? B_X : B_XALT];
+  double *__restrict__ Yw = ag.buf[parity ? B_Y : B_YALT];
   // XCD-aware block order, as in k_precond
   const int hb = (int)blockIdx.x;
   const int bx = (hb % 8) * ((int)gridDim.x / 8) + hb / 8;
@@ -146,7 +155,7 @@ __global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ ag
     esrc[i] = nullptr; eslot[i] = 0;
     if (i * 512 < etotal) {  // (uniform; lanes beyond the last double re-read the last edge and drop it)
       const SharedEdgeDev &se = ag.se[min((tid + 512 * i) / EPE, nsh - 1)];
-      esrc[i] = se.src[1]; eslot[i] = se.slot;
+      esrc[i] = parity ? se.src_yalt : se.src[1]; eslot[i] = se.slot;
     }
   }
   const int e0 = ag.pose_eptr[jj], e1 = ag.pose_eptr[jj + 1];  // the pose's shared edges (empty for most poses)
@@ -154,16 +163,16 @@ __global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ ag
   const size_t own_off = (size_t)((tid >= 4 * R) ? max(pj1, 0) : pj0) * 4 * R + (size_t)(tid % (4 * R));
   double pre_x = 0, pre_v = 0, pre_y = 0;
   if (tid < npose * 4 * R) {
-    pre_x = ag.buf[B_X][own_off];
+    pre_x = Xr[own_off];
     pre_v = ag.buf[B_V][own_off];
-    pre_y = ag.buf[B_Y][own_off];
+    pre_y = Yr[own_off];
   }
   NestState ns = {};
   if (tid < 128) ns = nest_src[sel];
   constexpr int NSTG = (KC * R / 2 + 511) / 512;
   double2 xv[NSTG];
   {
-    const double *X = ag.buf[B_X];
+    const double *X = Xr;
 #pragma unroll
     for (int u = 0; u < NSTG; ++u) {
       const int tt = 2 * (tid + 512 * u);  // N4 * R is even
@@ -281,8 +290,7 @@ __global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ ag
     tangent_inplace<R>(y, w);
   }
   FE_STAMP(3);
-  lds_barrier();  // #2: nobody reads X in LDS any more; this workgroup's reads of X and of the neighbours' poses are done
-  if (tid == 0) __hip_atomic_fetch_add(&sync[0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  lds_barrier();  // #2: nobody reads X in LDS any more
   if (act) {
 #pragma unroll
     for (int i = 0; i < 4 * R; ++i) vs[(size_t)4 * R * j + i] = w[i];
@@ -356,23 +364,13 @@ __global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ ag
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
-  // nobody stores a pose before every workgroup has formed its gradient (the counter is long complete by then: the
-  // value is requested here and looked at in front of the first store)
-  unsigned long long seen = __hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  auto wait_all = [&]() {
-    int spins = 0;
-    while (seen < target) {
-      if (++spins > FE_SPIN_LIMIT) { *err = 5; break; }
-      seen = __hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  };
-
   if (tid >= 64) {
     // ---- look-ahead Nesterov step of iteration k+1 for this workgroup's share of the OTHER agents' poses (second wave;
     // k_precond<PM_RGD>, ahead bit 1, without the status outputs)
     const int self = sel;
     int pre[LOOKAHEAD_MAX_AGENTS + 1];
     double *px[LOOKAHEAD_MAX_AGENTS], *pv[LOOKAHEAD_MAX_AGENTS], *py[LOOKAHEAD_MAX_AGENTS];
+    long long dalt[LOOKAHEAD_MAX_AGENTS];  // doubles from a primary array of agent k to its twin
 #pragma unroll
     for (int k = 0; k <= LOOKAHEAD_MAX_AGENTS; ++k) pre[k] = team->pose_prefix[k];
     const int na = team->num_agents;
@@ -381,6 +379,7 @@ __global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ ag
       px[k] = (k < na) ? agents[k].buf[B_X] : nullptr;
       pv[k] = (k < na) ? agents[k].buf[B_V] : nullptr;
       py[k] = (k < na) ? agents[k].buf[B_Y] : nullptr;
+      dalt[k] = (long long)B_ALT * 4 * R * (pre[k + 1] - pre[k]);
     }
     const int total = pre[LOOKAHEAD_MAX_AGENTS] - n;
     const int per = (total + nblk - 1) / nblk;  // <= 64, checked by the host
@@ -393,28 +392,31 @@ __global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ ag
       const int gq = q < self_lo ? q : q + n;
       int a = 0, lo = 0;
       double *xa = px[0], *va = pv[0], *ya = py[0];
+      long long da = dalt[0];
 #pragma unroll
       for (int k = 1; k < LOOKAHEAD_MAX_AGENTS; ++k)
-        if (k < na && gq >= pre[k]) { a = k; lo = pre[k]; xa = px[k]; va = pv[k]; ya = py[k]; }
+        if (k < na && gq >= pre[k]) { a = k; lo = pre[k]; xa = px[k]; va = pv[k]; ya = py[k]; da = dalt[k]; }
+      // this launch's copy of the agent's poses (read) and the other one (written)
+      const double *xr = parity ? xa + da : xa, *yr = parity ? ya + da : ya;
+      double *oX = parity ? xa : xa + da, *oY = parity ? ya : ya + da, *oV = va;
       const int la_pose = gq - lo;
       const bool la_opt = next_sel == a;
       const size_t o = (size_t)la_pose * 4 * R;
       double la_x[4 * R], la_v[4 * R];
 #pragma unroll
-      for (int i = 0; i < 4 * R; ++i) { la_x[i] = xa[o + i]; la_v[i] = va[o + i]; }
-      double *oY = ya, *oX = xa, *oV = va;
+      for (int i = 0; i < 4 * R; ++i) { la_x[i] = xr[o + i]; la_v[i] = va[o + i]; }
       if (restart_next) {
-        wait_all();
+        // (X stays; Y = V = X unless the agent optimizes next -- then Y stays too: both are carried into the other copy)
 #pragma unroll
         for (int i = 0; i < 4 * R; ++i) {
-          if (!la_opt) { oY[o + i] = la_x[i]; oV[o + i] = la_x[i]; }
+          oX[o + i] = la_x[i];
+          if (!la_opt) { oY[o + i] = la_x[i]; oV[o + i] = la_x[i]; } else oY[o + i] = yr[o + i];
         }
       } else {
         double y[4 * R];
 #pragma unroll
         for (int i = 0; i < 4 * R; ++i) y[i] = (1.0 - ahead_alpha) * la_x[i] + ahead_alpha * la_v[i];
         polar_inplace<R>(y);
-        wait_all();
 #pragma unroll
         for (int i = 0; i < 4 * R; ++i) { oY[o + i] = y[i]; oX[o + i] = y[i]; }
       }
@@ -449,11 +451,11 @@ __global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ ag
     }
     FE_STAMP(8);
     if (restart_next) {
-      wait_all();
 #pragma unroll
       for (int i = 0; i < 4 * R; ++i) {
-        ag.buf[B_X][o + i] = x[i];
-        if (!ahead_opt) { ag.buf[B_Y][o + i] = x[i]; v[i] = x[i]; } else if (reset) ag.buf[B_Y][o + i] = x[i];
+        Xw[o + i] = x[i];
+        if (!ahead_opt) { Yw[o + i] = x[i]; v[i] = x[i]; }
+        else Yw[o + i] = reset ? x[i] : Esh[1][lp * 4 * R + i];  // (else Y stays: carried into the other copy)
       }
     } else {
       double y[4 * R];
@@ -461,9 +463,8 @@ __global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ ag
       for (int i = 0; i < 4 * R; ++i) y[i] = (1.0 - ahead_alpha) * x[i] + ahead_alpha * v[i];
       polar_inplace<R>(y);
       FE_STAMP(9);
-      wait_all();
 #pragma unroll
-      for (int i = 0; i < 4 * R; ++i) { ag.buf[B_Y][o + i] = y[i]; ag.buf[B_X][o + i] = y[i]; }
+      for (int i = 0; i < 4 * R; ++i) { Yw[o + i] = y[i]; Xw[o + i] = y[i]; }
     }
 #pragma unroll
     for (int i = 0; i < 4 * R; ++i) ag.buf[B_V][o + i] = v[i];
@@ -477,12 +478,12 @@ bool step_fe_supported(int r) { return r >= 3 && r <= 5; }
 int step_fe_max_edges() { return FE_MAX_EDGES; }
 
 void launch_step_fe(const LaunchCtx &c, int sel, int next_sel, double step, int num_robots, int restart_interval,
-                    const NestState *nest_src, NestState *nest_dst, unsigned long long *sync, unsigned long long target, int *err) {
+                    const NestState *nest_src, NestState *nest_dst, int parity) {
   const AgentDev &d = c.host_agents[sel];
   const int grid = ((d.N4 + 7) / 8 + 7) / 8 * 8;
 #define FE_LAUNCH(RR, WW)                                                                                              \
   hipLaunchKernelGGL((k_step_fe<RR, WW>), dim3(grid), dim3(512), 0, c.stream, c.agents, c.team, sel, next_sel, step, num_robots, \
-                     restart_interval, nest_src, nest_dst, sync, target, err, d)
+                     restart_interval, nest_src, nest_dst, parity, d)
 #define FE_LAUNCH_W(RR)                                                                                                \
   switch (d.soa_w) {                                                                                                   \
     case 5: FE_LAUNCH(RR, 5); break;                                                                                   \

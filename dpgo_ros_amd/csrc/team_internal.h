@@ -210,8 +210,7 @@ struct dpgo_team {
   dpgo_host::DevBuf<dpgo::NestState> d_nest_all;  // NestState of local agent k at [k]: one array, so that a kernel finds any agent's
                                                    // state from the agent index alone (no descriptor round trip)
   // one-launch iterations (step_fused.hip): d_nest_all holds three copies of the NestStates -- the team's own at
-  // [0, num_local), the two alternating buffers of the fused launches behind it -- and one arrival counter
-  dpgo_host::DevBuf<unsigned long long> d_fe_sync;
+  // [0, num_local), the two alternating buffers of the fused launches behind it
   int use_fused_eval = 1;  // DPGO_FUSED_EVAL=0: every pipelined iteration takes the two-launch sequence
   // staged neighbour poses of the agent whose iterate(true) is being enqueued: its first launch (k_nest_pre) scatters them
   struct PendingUpload { const int *slots = nullptr; const double *in = nullptr; int n0 = 0, n1 = 0; } pend_up;
