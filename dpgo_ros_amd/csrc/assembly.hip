@@ -90,9 +90,13 @@ void build_Q(Agent &a) {
     // same measurements, new weights (an UPDATE_WEIGHT round): the pattern stands, the blocks are accumulated in place --
     // in the order of the general path below, so the values are bitwise the same (the per-row maps were 1 ms of a round)
     std::fill(a.qval.begin(), a.qval.end(), 0.0);
+    bool pattern_ok = true;  // (a block the stored pattern does not have: fall through to the general path below)
     auto add = [&](int row, int colm, const double *v, bool transpose, double sign) {
+      if (row < 0 || row >= a.n) { pattern_ok = false; return; }
       int p = a.rowptr[row];
-      while (a.col[p] != colm) ++p;  // (present by construction: the pattern came from these measurements)
+      const int pe = a.rowptr[row + 1];
+      while (p < pe && a.col[p] != colm) ++p;
+      if (p >= pe) { pattern_ok = false; return; }
       double *blk = a.qval.data() + (size_t)16 * p;
       for (int cp = 0; cp < 4; ++cp)
         for (int c = 0; c < 4; ++c) blk[cp + 4 * c] += sign * (transpose ? v[c + 4 * cp] : v[cp + 4 * c]);
@@ -110,7 +114,8 @@ void build_Q(Agent &a) {
       if (m.r1 == a.id) add(m.p1, m.p1, TOT, false, 1.0);
       else add(m.p2, m.p2, Om, false, 1.0);
     }
-    return;
+    if (pattern_ok) return;
+    a.struct_uploaded = false;
   }
   std::vector<std::map<int, std::array<double, 16>>> rows(a.n);
   auto add = [&](int row, int colm, const double *v, bool transpose, double sign) {

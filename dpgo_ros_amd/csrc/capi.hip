@@ -4,6 +4,7 @@
 #include <atomic>
 #include <array>
 #include <chrono>
+#include <thread>
 #include <unordered_map>
 
 #include "team_internal.h"
@@ -106,20 +107,28 @@ void dpgo_team_destroy(dpgo_team_t *t) {
   delete t;
 }
 
+// An in-kernel exchange that timed out (codes: 2 hand-off of the one-launch RTR solve, 3 two-level preconditioner, 4 mailbox
+// of the device-side UPDATE token) leaves its code in a pinned word.  Every entry point that has just drained the team's
+// stream looks at it, so a time-out is an error at the next host read-back whichever call that is (advisor, round 3: only
+// dpgo_team_synchronize did, and the run_peer path never called it).
+static int check_exchange_error(dpgo_team_t *t) {
+  if (!t->h_bar_err || !*t->h_bar_err) return 0;
+  const int code = *t->h_bar_err;
+  *t->h_bar_err = 0;
+  for (auto &kv : t->graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);
+  t->graphs.clear(); t->graph_flip.clear();
+  set_err("an in-kernel exchange timed out (code " + std::to_string(code) + ": 2 hand-off of the one-launch RTR solve, 3 two-level "
+          "preconditioner, 4 mailbox of the device-side UPDATE token): the iterates since the last successful synchronisation are invalid");
+  return DPGO_ERR;
+}
+
 int dpgo_team_num_local(const dpgo_team_t *t) { return (int)t->ag.size(); }
 void *dpgo_team_stream(dpgo_team_t *t) { return (void *)t->stream; }
 int dpgo_team_synchronize(dpgo_team_t *t) {
   HIPC(hipStreamSynchronize(t->stream));
   release_fused_rtr_lock(t);
   for (auto &a : t->ag) if (a->opt_pending_rtr && refresh_rtr_result(t, *a)) return DPGO_ERR;
-  if (t->h_bar_err && *t->h_bar_err) {
-    *t->h_bar_err = 0;
-    for (auto &kv : t->graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);
-    t->graphs.clear(); t->graph_flip.clear();
-    set_err("an in-kernel exchange (two-level preconditioner / one-launch RTR solve / one-launch iteration) timed out: the iterates of this run are invalid");
-    return DPGO_ERR;
-  }
-  return 0;
+  return check_exchange_error(t);
 }
 
 int dpgo_agent_add_measurements(dpgo_team_t *t, int id, const dpgo_measurement_t *m, int count) {
@@ -217,7 +226,7 @@ int dpgo_agent_get_X(dpgo_team_t *t, int id, int which, double *X) {
   HIPC(hipMemcpyAsync(X, a->dev.buf[map[which]], sizeof(double) * (size_t)t->prm.r * 4 * a->n, hipMemcpyDeviceToHost,
                       t->stream));
   HIPC(hipStreamSynchronize(t->stream));
-  return 0;
+  return check_exchange_error(t);
 }
 
 int dpgo_agent_get_public_poses(dpgo_team_t *t, int id, int nbr, int aux, double *poses) {
@@ -337,11 +346,25 @@ static int report_after_iterate(dpgo_team_t *t, Agent *a, bool did_opt, bool adv
   {
     volatile unsigned long long *flag = reinterpret_cast<volatile unsigned long long *>(a->h_down.p);
     unsigned long long spins = 0;
-    while (*flag != expect) {
+    auto resync = [&]() {  // a report that never arrived must not leave the host one ahead of the device for good
+      a->report_seq = 0;
+      *flag = 0ull;
+      (void)hipMemsetAsync(a->d_report_seq.p, 0, 2 * sizeof(unsigned long long), t->stream);
+    };
+    while (*flag < expect) {
+#if defined(__x86_64__) || defined(__i386__)
       __builtin_ia32_pause();
+#else
+      std::this_thread::yield();
+#endif
       if (++spins > (1ull << 26)) {  // (seconds: something is wrong -- let the runtime say what)
-        HIPC(hipStreamSynchronize(t->stream));
-        if (*flag != expect) { set_err("report kernel did not deliver (sequence word not written)"); return DPGO_ERR; }
+        const hipError_t se = hipStreamSynchronize(t->stream);
+        if (se != hipSuccess || *flag < expect) {
+          resync();
+          set_err(se != hipSuccess ? std::string("report kernel failed: ") + hipGetErrorString(se)
+                                   : std::string("report kernel did not deliver (sequence word not written)"));
+          return DPGO_ERR;
+        }
       }
     }
     std::atomic_thread_fence(std::memory_order_acquire);
@@ -349,6 +372,7 @@ static int report_after_iterate(dpgo_team_t *t, Agent *a, bool did_opt, bool adv
   // diagnostics (dpgo_team_get_counters [5..6]): host time between the launch of a report and its arrival (us), reports
   t->counters[5] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tq0).count();
   t->counters[6] += 1;
+  if (check_exchange_error(t)) return DPGO_ERR;
   for (auto &b : t->ag) b->up_pending = false;  // this team's stream has drained past every upload enqueued before
   release_fused_rtr_lock(t);                    // ... and past any one-launch solve
   if (a->opt_pending_rtr && refresh_rtr_result(t, *a, true)) return DPGO_ERR;  // (its record is in pinned memory already)
@@ -439,6 +463,7 @@ int dpgo_agent_get_status(dpgo_team_t *t, int id, dpgo_status_t *s) {
         HIPC(hipMemcpyAsync(part.data(), a->dev.part + off, sizeof(double) * ((size_t)(cnt - 1) * PART_STRIDE + 1),
                             hipMemcpyDeviceToHost, t->stream));
         HIPC(hipStreamSynchronize(t->stream));
+        if (check_exchange_error(t)) return DPGO_ERR;
         for (int k = 0; k < cnt; ++k) sum += part[(size_t)k * PART_STRIDE];
       }
       a->opt_rel_change = std::sqrt(sum / a->n);
@@ -506,7 +531,12 @@ int dpgo_agent_preconditioner_info(dpgo_team_t *t, int id, double *out) {
 }
 
 int dpgo_two_level_plan(int n, const int *rowptr, const int *col, int max_sub, int *sub_of, double *info) {
-  if (n < 1 || !rowptr || !col) return DPGO_ERR;
+  if (n < 1 || !rowptr || !col) { set_err("two_level_plan: n >= 1, rowptr and col required"); return DPGO_ERR; }
+  if (rowptr[0] != 0) { set_err("two_level_plan: rowptr[0] must be 0"); return DPGO_ERR; }
+  for (int i = 0; i < n; ++i)
+    if (rowptr[i + 1] < rowptr[i]) { set_err("two_level_plan: rowptr must be non-decreasing"); return DPGO_ERR; }
+  for (int p = 0; p < rowptr[n]; ++p)
+    if (col[p] < 0 || col[p] >= n) { set_err("two_level_plan: column index out of range"); return DPGO_ERR; }
   const std::vector<int> rp(rowptr, rowptr + n + 1), cl(col, col + rowptr[n]);
   const dpgo_host::TLPlan pl = dpgo_host::tl_make_plan(n, rp, cl, max_sub);
   if (sub_of) for (int i = 0; i < n; ++i) sub_of[i] = pl.sub_of[i];
@@ -1071,9 +1101,11 @@ static int team_run_impl(dpgo_team_t *t, int iters, bool prepare_only) {
     *out = ge;
     return 0;
   };
-  auto account = [&](int sel) {
+  // evals: sparse evaluations of the iteration -- the gradient and the closing statistics of the two-launch form, the
+  // gradient alone in a one-launch iteration (it leaves no statistics); a line-search iteration adds its trial passes
+  auto account = [&](int sel, int evals) {
     t->counters[0] += 1; t->counters[1] += precond_operator_bytes(*t->ag[sel]);
-    t->counters[2] += 2; t->counters[3] += 2 * spmm_bytes_of(t, *t->ag[sel]);
+    t->counters[2] += evals; t->counters[3] += evals * spmm_bytes_of(t, *t->ag[sel]);
   };
   int k = 0;
   int cur_iter = t->iter;
@@ -1109,13 +1141,15 @@ static int team_run_impl(dpgo_team_t *t, int iters, bool prepare_only) {
       }
       ++t->epoch;
       HIPC(hipGraphLaunch(ge, t->stream));
-      if (fe) t->counters[7] += std::max(0, fusedn - std::min(fusedn, (int)t->sched.size()) - 1) & ~1;  // one-launch iterations
+      const int nfe_run = fe ? (std::max(0, fusedn - std::min(fusedn, (int)t->sched.size()) - 1) & ~1) : 0;
+      t->counters[7] += nfe_run;  // one-launch iterations
       // after >= 2 pipelined iterations every agent took its last Nesterov step as a look-ahead (per-pose partials)
       for (auto &a : t->ag) a->rel_src = p.acceleration ? ((pipelined && fusedn >= 2) ? 4 : 0) : 2;
       for (int q = 0; q < batch; ++q) {
         const int sel = t->sched[(t->iter + q) % t->sched.size()];
-        account(sel);
-        if (restart && q == 0) account(sel);  // the restart iteration solves twice (from Y, then from XPrev)
+        const int evals = ls ? 2 + (ls_trials(p) + 3) / 4 : ((q - (restart ? 1 : 0) < nfe_run && !(restart && q == 0)) ? 1 : 2);
+        account(sel, evals);
+        if (restart && q == 0) account(sel, evals);  // the restart iteration solves twice (from Y, then from XPrev)
         // status of this block update: the fused step leaves PART_B[2], the un-fused restart iteration k_status tiles
         mark_optimized(t, *t->ag[sel], ((restart && q == 0) || ls) ? 5 : 1, true);
         if (q == batch - 1) {
@@ -1314,6 +1348,7 @@ int dpgo_team_cost(dpgo_team_t *t, double *f) {
   for (auto &a : t->ag)
     HIPC(hipMemcpyAsync(t->h_scal + 16 * (size_t)a->local, a->dev.scal, sizeof(double) * 16, hipMemcpyDeviceToHost, t->stream));
   HIPC(hipStreamSynchronize(t->stream));
+  if (check_exchange_error(t)) return DPGO_ERR;
   for (auto &a : t->ag) total += t->h_scal[16 * (size_t)a->local + 5];  // (agent order: the sum is what it was)
   *f = total;
   return 0;
@@ -1478,7 +1513,21 @@ int dpgo_team_import_peer(dpgo_team_t *t, int robot_id, const unsigned char *han
 static int ensure_mailbox(dpgo_team_t *t) {
   const size_t words = 2 * (size_t)t->prm.num_robots;
   if (t->d_mail.p) return 0;
-  if (t->d_mail.alloc(words)) { set_err("mailbox allocation failed"); return DPGO_ERR; }
+  // fine-grained device memory: a peer GPU's system-scope store must become visible to a wait kernel that is ALREADY
+  // running here; HIP promises cross-device visibility of ordinary (coarse-grained) allocations at kernel boundaries only
+  // (advisor, round 3).  Falls back to an ordinary allocation where the runtime refuses (then the token path is only
+  // sound between processes on one device, which is how it has been tested).
+  {
+    void *pm = nullptr;
+    if (hipExtMallocWithFlags(&pm, sizeof(unsigned long long) * std::max<size_t>(words, 1), hipDeviceMallocFinegrained) == hipSuccess && pm) {
+      t->d_mail.p = (unsigned long long *)pm;
+      t->d_mail.n = std::max<size_t>(words, 1);
+      t->mail_finegrained = true;
+    } else {
+      (void)hipGetLastError();
+      if (t->d_mail.alloc(words)) { set_err("mailbox allocation failed"); return DPGO_ERR; }
+    }
+  }
   HIPC(hipMemsetAsync(t->d_mail.p, 0, sizeof(unsigned long long) * words, t->stream));
   HIPC(hipStreamSynchronize(t->stream));
   t->last_fin.assign(t->prm.num_robots, 0ull);
@@ -1523,6 +1572,7 @@ int dpgo_team_import_mailbox(dpgo_team_t *t, const unsigned char *handle64, cons
 // Without acceleration only block updates move poses: the token holder waits for fin[b] of every remote neighbour's last
 // block update (what it reads is final, and nobody still reads what it overwrites).
 int dpgo_team_run_peer(dpgo_team_t *t, const int *sel_ids, int iters) {
+  if (check_exchange_error(t)) return DPGO_ERR;  // (a time-out of an earlier run that nobody has looked at yet)
   if (sync_descs(t)) return DPGO_ERR;
   if (ensure_mailbox(t)) return DPGO_ERR;
   const dpgo_params_t &p = t->prm;

@@ -84,6 +84,15 @@ __device__ __forceinline__ double2 ld2_nt(const double *p) {
 #endif
 }
 
+// acc + a0 b0 + a1 b1 + a2 b2 + a3 b3 as four fused multiply-adds on the accumulator, in this order -- EVERY block
+// product of the library (k_eval, the Hessian kernels, the one-launch solve and the one-launch iteration) goes through
+// here, so they stay bitwise equal to each other.  (`acc += a0 * b0 + a1 * b1 + ...` compiles to mul, fma, fma, fma, add
+// through one temporary: five dependent instructions where four independent accumulators' chains interleave.)
+__device__ __forceinline__ double fma4(double a0, double b0, double a1, double b1, double a2, double b2, double a3, double b3,
+                                       double acc) {
+  return __builtin_fma(a3, b3, __builtin_fma(a2, b2, __builtin_fma(a1, b1, __builtin_fma(a0, b0, acc))));
+}
+
 // one group of up to 4 ELL slots: every index/block load is issued before the first use
 template <int R, int NV, class Src>
 __device__ __forceinline__ void ell_group(const AgentDev &ag, int j, int slot0, Src src, double (*acc)[4]) {
@@ -107,8 +116,8 @@ __device__ __forceinline__ void ell_group(const AgentDev &ag, int j, int slot0, 
     for (int v = 0; v < NV; ++v)
 #pragma unroll
       for (int c = 0; c < 4; ++c)
-        acc[v][c] += x[u][v][0] * B[u][2 * c].x + x[u][v][1] * B[u][2 * c].y + x[u][v][2] * B[u][2 * c + 1].x +
-                     x[u][v][3] * B[u][2 * c + 1].y;
+        acc[v][c] = fma4(x[u][v][0], B[u][2 * c].x, x[u][v][1], B[u][2 * c].y, x[u][v][2], B[u][2 * c + 1].x, x[u][v][3],
+                         B[u][2 * c + 1].y, acc[v][c]);
 }
 
 // acc[v][c] += sum_i sum_cp src_v(i, cp) * Q_ij[cp, c]   for output pose j, row a; NV vectors at once
@@ -127,7 +136,7 @@ __device__ __forceinline__ void spmm_row(const AgentDev &ag, int j, Src src, dou
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const double2 b01 = ld2(bp + 4 * c), b23 = ld2(bp + 4 * c + 2);
-        acc[v][c] += x[v][0] * b01.x + x[v][1] * b01.y + x[v][2] * b23.x + x[v][3] * b23.y;
+        acc[v][c] = fma4(x[v][0], b01.x, x[v][1], b01.y, x[v][2], b23.x, x[v][3], b23.y, acc[v][c]);
       }
   }
 }

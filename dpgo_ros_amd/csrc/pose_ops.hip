@@ -1,6 +1,8 @@
 // pose_ops.hip -- per-pose manifold kernels (retraction, raw manifold operations, Nesterov sequences; SURVEY 8a rows
 // a5, a6), status partials, the scalar trust-region state machine (a4), public-pose pack / unpack (a7), per-edge
 // residuals and the global cost (a8), dense assembly of Q + shift I.
+#include <cstdlib>
+
 #include "kernel_common.h"
 
 namespace dpgo {
@@ -373,6 +375,8 @@ __global__ __launch_bounds__(64) void k_iterate_false(const AgentDev *__restrict
     }
   }
   __threadfence_system();
+  __syncthreads();  // (one 64-thread workgroup is one wavefront on gfx950; the barrier keeps the ticket behind every lane's
+                    // stores whatever the wave size)
   unsigned int tk = 0;
   if (tid == 0) tk = (unsigned int)__hip_atomic_fetch_add(ticket, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
   tk = (unsigned int)__builtin_amdgcn_readfirstlane((int)tk);
@@ -443,13 +447,15 @@ __global__ void k_mail_signal(MailSignals s) {
   __hip_atomic_store(s.word[i], s.value[i], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-__global__ void k_mail_wait(const unsigned long long *mail, MailWaits w, int *err) {
+// timeout_ticks of the 100 MHz wall clock (DPGO_MAIL_TIMEOUT_S, default 20 s: a peer rank may be busy with dense
+// inversions, graph instantiation or its first code-object load when this rank starts to wait)
+__global__ void k_mail_wait(const unsigned long long *mail, MailWaits w, int *err, long long timeout_ticks) {
   const int i = threadIdx.x;
   if (i >= w.count) return;
   const long long t0 = (long long)wall_clock64();
   while (__hip_atomic_load(mail + w.index[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < w.value[i]) {
     __builtin_amdgcn_s_sleep(2);
-    if ((long long)wall_clock64() - t0 > 400000000ll) { *err = 4; break; }  // 4 s of the 100 MHz clock
+    if ((long long)wall_clock64() - t0 > timeout_ticks) { *err = 4; break; }
   }
 }
 
@@ -578,7 +584,12 @@ void launch_mail_signal(hipStream_t s, const MailSignals &sig) {
 }
 
 void launch_mail_wait(hipStream_t s, const unsigned long long *mail, const MailWaits &w, int *err) {
-  if (w.count > 0) hipLaunchKernelGGL(k_mail_wait, dim3(1), dim3(64), 0, s, mail, w, err);
+  static const long long ticks = [] {
+    const char *e = std::getenv("DPGO_MAIL_TIMEOUT_S");
+    const double sec = e ? std::atof(e) : 20.0;
+    return (long long)((sec > 0 ? sec : 20.0) * 1e8);
+  }();
+  if (w.count > 0) hipLaunchKernelGGL(k_mail_wait, dim3(1), dim3(64), 0, s, mail, w, err, ticks);
 }
 
 void launch_noop(const LaunchCtx &c, int grid, int block) {

@@ -367,7 +367,7 @@ __device__ __forceinline__ void spmm_row_finish(const AgentDev &ag, int j, const
     for (int v = 0; v < NV; ++v)
 #pragma unroll
       for (int c = 0; c < 4; ++c)
-        acc[v][c] += x[u][v][0] * B[4 * c] + x[u][v][1] * B[4 * c + 1] + x[u][v][2] * B[4 * c + 2] + x[u][v][3] * B[4 * c + 3];
+        acc[v][c] = fma4(x[u][v][0], B[4 * c], x[u][v][1], B[4 * c + 1], x[u][v][2], B[4 * c + 2], x[u][v][3], B[4 * c + 3], acc[v][c]);
   }
   // (matrix width and the CSR-tail range of the row come from the caller: read once per launch, not once per product)
   for (int s0 = RTR_SLOTS; s0 < ell_w; s0 += 4) ell_group<R, NV>(ag, j, s0, src, acc);
@@ -381,7 +381,7 @@ __device__ __forceinline__ void spmm_row_finish(const AgentDev &ag, int j, const
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const double2 b01 = ld2(bp + 4 * c), b23 = ld2(bp + 4 * c + 2);
-        acc[v][c] += xt[v][0] * b01.x + xt[v][1] * b01.y + xt[v][2] * b23.x + xt[v][3] * b23.y;
+        acc[v][c] = fma4(xt[v][0], b01.x, xt[v][1], b01.y, xt[v][2], b23.x, xt[v][3], b23.y, acc[v][c]);
       }
   }
 }

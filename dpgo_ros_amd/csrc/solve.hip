@@ -27,9 +27,12 @@ bool acquire_fused_rtr_lock(dpgo_team *t) {
     (void)hipDeviceGetPCIBusId(bus, sizeof bus, t->device);
     for (char *c = bus; *c; ++c) if (*c == ':' || *c == '.' || *c == '/') *c = '_';
     const std::string path = std::string("/dev/shm/dpgo_hip_rtr_") + bus + ".lock";
-    t->rtr_lock_fd = ::open(path.c_str(), O_CREAT | O_RDWR, 0666);  // (no /dev/shm: the in-process rule alone)
+    t->rtr_lock_fd = ::open(path.c_str(), O_CREAT | O_RDWR | O_NOFOLLOW | O_CLOEXEC, 0666);
   }
-  if (t->rtr_lock_fd >= 0 && ::flock(t->rtr_lock_fd, LOCK_EX | LOCK_NB) != 0) return false;  // another process runs one on this GPU
+  // (a lock file that cannot be opened -- another user's, a restrictive umask -- means exclusion across processes
+  // cannot be had: the launch-per-step sequence serves instead of an unprotected persistent grid)
+  if (t->rtr_lock_fd < 0) return false;
+  if (::flock(t->rtr_lock_fd, LOCK_EX | LOCK_NB) != 0) return false;  // another process runs one on this GPU
   g_rtr_owner[t->device] = t;
   t->rtr_lock_state = 1;
   return true;

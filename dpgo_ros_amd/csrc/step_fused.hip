@@ -90,7 +90,7 @@ __device__ __forceinline__ void fe_block(const double *Xs, int i, const double2 
   for (int c = 0; c < 4; ++c)
 #pragma unroll
     for (int a = 0; a < R; ++a)
-      W[c * R + a] += x[a] * B[2 * c].x + x[R + a] * B[2 * c].y + x[2 * R + a] * B[2 * c + 1].x + x[3 * R + a] * B[2 * c + 1].y;
+      W[c * R + a] = fma4(x[a], B[2 * c].x, x[R + a], B[2 * c].y, x[2 * R + a], B[2 * c + 1].x, x[3 * R + a], B[2 * c + 1].y, W[c * R + a]);
 }
 
 // the accumulators of a row as operands of an empty volatile asm: everything that feeds them is computed in front of it,

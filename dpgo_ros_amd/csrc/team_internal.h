@@ -203,6 +203,7 @@ struct dpgo_team {
   // iteration k" (k + 1), [num_robots + robot] "finished its block update of iteration k" (k + 1) -- written by the
   // teams that hold those robots; the mailboxes of the other teams, by robot they serve; every robot's last block update
   dpgo_host::DevBuf<unsigned long long> d_mail;
+  bool mail_finegrained = false;  // d_mail is fine-grained memory (visible to a running kernel of another device)
   std::map<int, unsigned long long *> peer_mail;      // robot id -> mailbox of the team that holds it
   std::vector<void *> mail_handles;                   // imported mappings (closed with the team)
   std::vector<unsigned long long> last_fin;           // [robot] k + 1 of its last block update in a run_peer schedule

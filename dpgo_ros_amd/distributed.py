@@ -152,7 +152,12 @@ class HipBackend:
             self.team.run_peer(sel_ids)
 
     def sync(self):
-        self.stream.synchronize()
+        """drain this rank's stream -- through the team, so that a time-out of an in-kernel exchange (mailbox wait of
+        the device-side token, two-level preconditioner) is raised here instead of yielding silently wrong iterates"""
+        if self.team is not None:
+            self.team.synchronize()
+        else:
+            self.stream.synchronize()
 
     def free_run(self, ticks):
         """`ticks` steps of every local agent back to back, each from whatever the neighbours' arrays hold when its

@@ -164,6 +164,9 @@ CASES = [
     ("smallGrid3D", 3, dict(method=1, acceleration=1, rgd_stepsize=0.2, restart_interval=4), 12),
     ("smallGrid3D", 2, dict(method=0, acceleration=1, restart_interval=5, gradnorm_tol=1e-2), 8),
     ("smallGrid3D", 4, dict(method=0, gradnorm_tol=1e-2, colored=1), 12),
+    # BASELINE configs[2] as bench.py's multi-rank leg runs it (config2_ranks_leg): sphere2500 over 8 agents, RTR 3 / 50 / 0.5,
+    # round robin, agent a on rank a % 2
+    ("sphere2500", 8, dict(method=0, gradnorm_tol=0.5, rtr_iterations=3, rtr_tcg_iterations=50), 16),
 ]
 
 

@@ -35,6 +35,10 @@ def test_bench_multi_rank_path_runs_under_rccl_at_world_size_one():
     assert d["n_gpus"] == 1 and 0 < d["value"] < 1.0 and d["exchange"].startswith("RCCL")
     assert np.isfinite(d["relcost_after_run"]) and d["colour_parallel_plain_rtr"]["classes"] == 2
     assert d["asapp_ticks_tunnels"]["ms_per_tick"] > 0
+    ex = d["exchange_timing"]
+    assert ex["rccl_world_size"] == 1 and ex["backend"] == "nccl" and len(ex["ranks"]) == 1 and ex["ranks"][0]["device"]
+    c2 = ex["config2_sphere2500_8_agents_rtr"]  # BASELINE configs[2] through the multi-rank driver
+    assert 0 < c2["ms_per_iter"] < 5.0 and np.isfinite(c2["relcost_after_run"]) and c2["rccl_point_to_point_ops_per_iter_this_rank"] == 0
 
 
 def _problem(mode):
