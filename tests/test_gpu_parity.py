@@ -368,8 +368,10 @@ def test_tunnels_eight_agents(mode, accel):
     th.run(16)
     for _ in range(16):
         to.iterate()
-    assert np.abs(th.global_X() - to.global_X()).max() < 1e-6
-    assert abs(th.cost() - to.cost()) <= 1e-8 * abs(to.cost()) and to.cost() < f0
+    # measured on the MI355X (profiles/experiments/tolerance_floor.py): 4.5e-13 / 5.1e-13 on iterates of magnitude 260,
+    # 2e-15 / 6e-15 relative on the cost
+    assert np.abs(th.global_X() - to.global_X()).max() < 1e-10
+    assert abs(th.cost() - to.cost()) <= 1e-12 * abs(to.cost()) and to.cost() < f0
     th.close()
     if accel:
         # the same inputs through the pipelined accelerated-RGD windows: 8 agents of 105..191 poses, so a
@@ -494,11 +496,12 @@ def test_config3_torus_eight_agents_gnc_with_outliers():
         th.run(8)
         for _ in range(8):
             to.iterate()
-        assert np.abs(th.global_X() - to.global_X()).max() < 1e-6, rnd
+        # measured (profiles/experiments/tolerance_floor.py): iterates 4.7e-14 / 2.6e-13, weights 1e-16 / 3.5e-16
+        assert np.abs(th.global_X() - to.global_X()).max() < 1e-10, rnd
         assert th.update_weights() == to.update_weights()
         wh = np.concatenate([th.agents[a].measurements()["weight"] for a in range(N)])
         wo = np.concatenate([to.agents[a].measurements()["weight"] for a in range(N)])
-        assert np.abs(wh - wo).max() < 1e-6
+        assert np.abs(wh - wo).max() < 1e-12
     th.close()
 
 
