@@ -1090,7 +1090,7 @@ static int team_run_impl(dpgo_team_t *t, int iters, bool prepare_only) {
       }
       launch_eval(c, -5, mn, B_X2, B_EGRAD2, B_GF2, PART_A, eval_opts(t, 0, 0, 0));
     } else if (rc == 0) {
-      for (int rep = 0; rep < B && !rc; ++rep) rc = enqueue_team_iteration(t, true, false, -1, 0);
+      for (int rep = 0; rep < B && !rc; ++rep) rc = enqueue_team_iteration(t, true, false, -1, 0, rep + 1 < B);
     }
     HIPC(hipStreamEndCapture(t->stream, &g));
     if (rc) { (void)hipGraphDestroy(g); return rc; }

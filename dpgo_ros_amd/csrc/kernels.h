@@ -61,7 +61,9 @@ void launch_step_fe(const LaunchCtx &c, int sel, int next_sel, double step, int 
 constexpr int LS_MAX_TRIALS = 8;
 void launch_ls_trials(const LaunchCtx &c, int sel, int max_n, int dirb, double step0, double shrink, int ntrials);
 void launch_ls_cost(const LaunchCtx &c, int sel, int max_n, int dirb, int ntrials);
-void launch_ls_apply(const LaunchCtx &c, int sel, int max_n, double step0, double shrink, double sigma, int ntrials);
+// tail: fold the rest of a non-restart team iteration into the launch (bit 1: Nesterov V update; status tiles + advance)
+void launch_ls_apply(const LaunchCtx &c, int sel, int max_n, double step0, double shrink, double sigma, int ntrials, int tail = 0,
+                     int num_robots = 1, int restart_interval = 1);
 void launch_tcg_hv(const LaunchCtx &c, int sel, int max_n, int sp, int max_inner);
 void launch_retract(const LaunchCtx &c, int sel, int max_n, int xb, int eb, double scale, int ob, int guard_state);
 void launch_project_raw(const LaunchCtx &c, const double *X, double *out, int n);

@@ -114,9 +114,14 @@ __global__ __launch_bounds__(64) void k_ls_cost(const AgentDev *__restrict__ age
 // the decision and the move.  Every workgroup sums the same partials in the same order: the first j with
 // f(X_j) <= f(X) - sigma t_j slope; X <- X_j (none: X stays).  Workgroup 0 leaves the record in the agent's scalars:
 // [8] back-offs taken (ntrials: none qualified), [9] accepted, [10] f at the accepted point, [11] the accepted step.
+// tail != 0 (the team schedule's non-restart iterations): the rest of the iteration rides in this launch, one lane per
+// pose of the tile -- bit 1: the Nesterov sequence V <- proj(V + gamma (X - Y)) (k_nest_post; gamma as k_nest_pre
+// published it in scal[6]); always: |X - XPrev|^2 of the tile into PART_D / PART_E (k_status, opt = 1); workgroup 0: the
+// Nesterov scalars of every agent and the team's iteration counter advance (k_advance) -- three launches less.
 template <int R>
-__global__ __launch_bounds__(64) void k_ls_apply(const AgentDev *__restrict__ agents, const TeamDev *team, int sel, double step0,
-                                                 double shrink, double sigma, int ntrials) {
+__global__ __launch_bounds__(64) void k_ls_apply(const AgentDev *__restrict__ agents, TeamDev *team, int sel, double step0,
+                                                 double shrink, double sigma, int ntrials, int tail, int num_robots,
+                                                 int restart_interval) {
   const AgentDev &ag = agents[sel_cur(team, sel)];
   const int j0 = blockIdx.x * 64, tid = threadIdx.x;
   if (j0 >= ag.n) return;
@@ -152,16 +157,59 @@ __global__ __launch_bounds__(64) void k_ls_apply(const AgentDev *__restrict__ ag
     ag.scal[10] = fsel;
     ag.scal[11] = tsel;
   }
-  if (chosen < 0) return;
   const int cnt = min(64, ag.n - j0);
-  const size_t lo = (size_t)j0 * 4 * R, len = (size_t)cnt * 4 * R;
-  const double *src = ag.buf[ls_buf(chosen)] + lo;
-  double *dst = ag.buf[B_X] + lo;
-  double tmp[4 * R];
+  if (!tail) {
+    if (chosen < 0) return;
+    const size_t lo = (size_t)j0 * 4 * R, len = (size_t)cnt * 4 * R;
+    const double *src = ag.buf[ls_buf(chosen)] + lo;
+    double *dst = ag.buf[B_X] + lo;
+    double tmp[4 * R];
 #pragma unroll
-  for (int k = 0; k < 4 * R; ++k) { const size_t e = tid + 64 * (size_t)k; tmp[k] = (e < len) ? src[e] : 0.0; }
+    for (int k = 0; k < 4 * R; ++k) { const size_t e = tid + 64 * (size_t)k; tmp[k] = (e < len) ? src[e] : 0.0; }
 #pragma unroll
-  for (int k = 0; k < 4 * R; ++k) { const size_t e = tid + 64 * (size_t)k; if (e < len) dst[e] = tmp[k]; }
+    for (int k = 0; k < 4 * R; ++k) { const size_t e = tid + 64 * (size_t)k; if (e < len) dst[e] = tmp[k]; }
+    return;
+  }
+  __shared__ Tile<R> TX, TV, TY, TP;
+  tile_in<R>(TX, ag.buf[chosen < 0 ? B_X : ls_buf(chosen)], j0, cnt, tid);
+  tile_in<R>(TP, ag.buf[B_XPREV], j0, cnt, tid);
+  if (tail & 2) {
+    tile_in<R>(TV, ag.buf[B_V], j0, cnt, tid);
+    tile_in<R>(TY, ag.buf[B_Y], j0, cnt, tid);
+  }
+  __syncthreads();
+  if (chosen >= 0) tile_out<R>(TX, ag.buf[B_X], j0, cnt, tid);
+  double rel = 0;
+  if (tid < cnt) {
+    double x[4 * R], q[4 * R];
+    tile_get<R>(TX, tid, x);
+    tile_get<R>(TP, tid, q);
+#pragma unroll
+    for (int i = 0; i < 4 * R; ++i) { const double d = x[i] - q[i]; rel += d * d; }
+    if (tail & 2) {
+      const double gamma = ag.scal[6];
+      double v[4 * R];
+      tile_get<R>(TV, tid, v);
+      tile_get<R>(TY, tid, q);
+#pragma unroll
+      for (int i = 0; i < 4 * R; ++i) v[i] += gamma * (x[i] - q[i]);
+      polar_inplace<R>(v);
+      tile_put<R>(TV, tid, v);
+    }
+  }
+  rel = wave_sum(rel);
+  if (tid == 0) {
+    ag.part[PART_D + (size_t)blockIdx.x * PART_STRIDE] = rel;
+    ag.part[PART_E + (size_t)blockIdx.x * PART_STRIDE] = rel;
+  }
+  if (tail & 2) {
+    __syncthreads();
+    tile_out<R>(TV, ag.buf[B_V], j0, cnt, tid);
+  }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+    for (int k = 0; k < team->num_agents; ++k) advance_agent(agents[k], (tail & 2) ? 1 : 0, num_robots, restart_interval);
+    team->iter += 1;
+  }
 }
 
 void launch_ls_trials(const LaunchCtx &c, int sel, int max_n, int dirb, double step0, double shrink, int ntrials) {
@@ -174,9 +222,10 @@ void launch_ls_cost(const LaunchCtx &c, int sel, int max_n, int dirb, int ntrial
                                           sel, dirb, ntrials));
 }
 
-void launch_ls_apply(const LaunchCtx &c, int sel, int max_n, double step0, double shrink, double sigma, int ntrials) {
+void launch_ls_apply(const LaunchCtx &c, int sel, int max_n, double step0, double shrink, double sigma, int ntrials, int tail,
+                     int num_robots, int restart_interval) {
   DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_ls_apply<R>, dim3((max_n + 63) / 64, c.ny), dim3(64), 0, c.stream, c.agents, c.team, sel,
-                                          step0, shrink, sigma, ntrials));
+                                          step0, shrink, sigma, ntrials, tail, num_robots, restart_interval));
 }
 
 }  // namespace dpgo

@@ -109,12 +109,12 @@ int enqueue_optimize(dpgo_team *t, int sel, const OptFlags &fl) {
       }
       launch_ls_trials(c, sel, mn, dirb, p.rgd_stepsize, p.rgd_ls_shrink, ntr);
       launch_ls_cost(c, sel, mn, dirb, ntr);
-      launch_ls_apply(c, sel, mn, p.rgd_stepsize, p.rgd_ls_shrink, p.rgd_ls_sigma, ntr);
-      launch_eval(c, sel, mn, B_X, B_EGRAD, B_GF, PART_A, eval_opts(t, 0, 0, 0));
+      launch_ls_apply(c, sel, mn, p.rgd_stepsize, p.rgd_ls_shrink, p.rgd_ls_sigma, ntr, fl.ls_tail, p.num_robots, p.restart_interval);
+      if (!fl.skip_stats) launch_eval(c, sel, mn, B_X, B_EGRAD, B_GF, PART_A, eval_opts(t, 0, 0, 0));
       if (sel >= 0 && !fl.capture) {
         Agent &a = *t->ag[sel];
         if (p.rgd_use_preconditioner) { t->counters[0] += 1; t->counters[1] += precond_operator_bytes(a); }
-        const int passes = 2 + (ntr + 3) / 4;  // passes over the sparse operator
+        const int passes = (fl.skip_stats ? 1 : 2) + (ntr + 3) / 4;  // passes over the sparse operator
         t->counters[2] += passes; t->counters[3] += passes * spmm_bytes_of(t, a);
         a.opt_pending_rgd = true;
       }
@@ -407,7 +407,7 @@ int compute_residuals(dpgo_team *t, Agent &a, std::vector<double> &res) {
 //        selected agent lives on another rank (every local agent runs iterate(false)).
 //   phase: 0 whole iteration; 1 = begin (everything before the neighbour exchange: Nesterov Y/X/V of all
 //          local agents); 2 = end (local solve of `sel` + bookkeeping).
-int enqueue_team_iteration(dpgo_team *t, bool capture, bool restart, int sel, int phase) {
+int enqueue_team_iteration(dpgo_team *t, bool capture, bool restart, int sel, int phase, bool mid_run) {
   LaunchCtx c = t->ctx();
   const dpgo_params_t &p = t->prm;
   const int na = (int)t->ag.size();
@@ -427,9 +427,13 @@ int enqueue_team_iteration(dpgo_team *t, bool capture, bool restart, int sel, in
     // RTR, non-restart iteration: the one-launch solve also takes the Nesterov V update, the status partials and the
     // end-of-iteration bookkeeping (three launches less); enqueue_optimize reports whether that solve ran
     if (p.method == DPGO_METHOD_RTR && sel >= 0 && !capture && !restart) fl.rtr_tail = p.acceleration ? 3 : 2;
+    // RGD with the line search, non-restart iteration: k_ls_apply also takes the Nesterov V update, the status tiles and
+    // the end-of-iteration bookkeeping; mid-run iterations of a graph leave out the statistics nobody reads
+    const bool ls_folded = p.method == DPGO_METHOD_RGD && p.rgd_line_search && !restart && phase == 0;
+    if (ls_folded) { fl.ls_tail = p.acceleration ? 3 : 1; fl.skip_stats = mid_run; }
     rc = enqueue_optimize(t, sel, fl);
     if (rc) return rc;
-    folded = p.method == DPGO_METHOD_RTR && t->last_rtr_folded;
+    folded = (p.method == DPGO_METHOD_RTR && t->last_rtr_folded) || ls_folded;
     if (!fused && !folded) {
       const int ns = (sel >= 0) ? t->ag[sel]->n : mn;
       if (p.acceleration) {
@@ -445,7 +449,7 @@ int enqueue_team_iteration(dpgo_team *t, bool capture, bool restart, int sel, in
     }
   }
   if (!fused && !folded) launch_advance(c, -1, na, p.acceleration, p.num_robots, p.restart_interval, 1);
-  t->last_iteration_folded = folded;
+  t->last_iteration_folded = folded && p.method == DPGO_METHOD_RTR;  // (status source: PART_B[2] for the folded RTR solve only)
   return 0;
 }
 

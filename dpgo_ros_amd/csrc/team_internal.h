@@ -284,13 +284,15 @@ struct OptFlags {
   int aux = 0, pull = 0;
   bool capture = false, fused = false, last_advances = false;
   int rtr_tail = 0;  // one-launch RTR solve: fold the rest of the iteration into it (bit 0: Nesterov V update; status + advance)
+  int ls_tail = 0;   // RGD line search: fold the rest of the iteration into k_ls_apply (1: status + advance, 3: + Nesterov V)
+  bool skip_stats = false;  // ... and leave out the closing statistics evaluation (mid-run iterations of a graph: nobody reads them)
 };
 bool neighbor_poses_ready(const Agent &a, int aux);
 EvalOpts eval_opts(const dpgo_team *t, int gmode, int aux, int advance);
 double spmm_bytes_of(const dpgo_team *t, const Agent &a);
 int enqueue_optimize(dpgo_team *t, int sel, const OptFlags &fl);
 int enqueue_iterate(dpgo_team *t, int li, int do_opt, bool defer_advance = false);
-int enqueue_team_iteration(dpgo_team *t, bool capture, bool restart, int sel, int phase);
+int enqueue_team_iteration(dpgo_team *t, bool capture, bool restart, int sel, int phase, bool mid_run = false);
 void account_iteration(dpgo_team *t, int sel, bool fused);
 int enqueue_optimize_group(dpgo_team *t, int g);
 int fetch_scal(dpgo_team *t, Agent &a);
