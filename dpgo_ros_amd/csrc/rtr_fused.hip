@@ -213,6 +213,58 @@ struct PVec {
 constexpr int RTR_RING_MASK = RTR_RING - 1;
 static_assert((RTR_RING & RTR_RING_MASK) == 0, "ring size is a power of two");
 
+// The NW x 64 per-lane sums of the 8R outputs of a slab product -> zs (valid in every wave on return).
+// Reduce-scatter across the four 16-lane rows of a wave with the gfx950 lane swaps: v_permlane32_swap exchanges the
+// upper half of one register with the lower half of another, so ONE add then leaves the two-half sum of output i in
+// lanes 0-31 and that of output i + 4R in lanes 32-63 (8R values -> 4R); v_permlane16_swap does the same for odd / even
+// rows (4R -> 2R).  Row r of the wave then holds outputs [2R (r & 1) + 4R (r >> 1), + 2R): a DPP butterfly over its 16
+// lanes, the first lane of each row stores 2R sums, and after ONE barrier one lane per output adds the NW wave totals.
+// (Round 3 / early round 4: a quad butterfly on all 8R values, 16 LDS rows per wave and a 64-term sum per output --
+// 4000 of the 5600 shader clocks of a product, profiles/experiments/slab_bench.hip.)
+__device__ __forceinline__ double swap_add_32(double x, double y) {
+  const auto l = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+  const auto h = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+  return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+}
+__device__ __forceinline__ double swap_add_16(double x, double y) {
+  const auto l = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+  const auto h = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+  return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+}
+template <int R, int NW>
+__device__ __forceinline__ void reduce_8R(double (*acc)[R], double *red, double *zs, int tid) {
+  constexpr int N = 8 * R, H = N / 2, Q = N / 4;
+  const int lane = tid & 63, wave = tid >> 6;
+  double s[H], u[Q];
+#pragma unroll
+  for (int i = 0; i < H; ++i) s[i] = swap_add_32(acc[i / R][i % R], acc[(i + H) / R][(i + H) % R]);
+#pragma unroll
+  for (int i = 0; i < Q; ++i) u[i] = swap_add_16(s[i], s[i + Q]);
+#pragma unroll
+  for (int i = 0; i < Q; ++i) {
+    double x = u[i];
+    x += dpp_move<0xB1>(x);   // quad_perm [1,0,3,2]
+    x += dpp_move<0x4E>(x);   // quad_perm [2,3,0,1]
+    x += dpp_move<0x141>(x);  // row_half_mirror
+    x += dpp_move<0x140>(x);  // row_mirror
+    u[i] = x;
+  }
+  if ((lane & 15) == 0) {
+    const int row = lane >> 4;
+    double *dst = red + wave * N + Q * (row & 1) + H * (row >> 1);
+#pragma unroll
+    for (int i = 0; i < Q; ++i) dst[i] = u[i];
+  }
+  __syncthreads();
+  if (tid < N) {
+    double t[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) t[w] = red[w * N + tid];
+    if constexpr (NW == 4) zs[tid] = (t[0] + t[1]) + (t[2] + t[3]);
+    else zs[tid] = t[0] + t[1];
+  }
+}
+
 // zs[c * R + a] = sum_k V[k][a] * Ms[c][k]  for the 8 columns of the slab: lane t takes rows 2t, 2t+1 (+512 m) of V
 // for ALL 8 columns, so every row of V is fetched once per workgroup (16-byte L1-bypassing loads straight from L2,
 // no LDS staging) and the slab is read from LDS exactly once.  The 256 per-lane sums go through a quad reduction
@@ -263,40 +315,13 @@ __device__ __forceinline__ void slab_finish(const double *Ms, int N4, double2 (*
 #pragma unroll
       for (int a = 0; a < R; ++a) acc[c][a] = __builtin_fma(w[R + a], mm[c].y, acc[c][a]);
   }
-  const int lane = tid & 63, wave = tid >> 6;
 #ifdef DPGO_RTR_TRACE
   if (tr && tid == 0) tr[1] = wall_clock64();  // products done
 #endif
-#pragma unroll
-  for (int c = 0; c < 8; ++c)
-#pragma unroll
-    for (int a = 0; a < R; ++a) {
-      double x = acc[c][a];
-      x += dpp_move<0xB1>(x);  // lanes ^ 1
-      x += dpp_move<0x4E>(x);  // lanes ^ 2
-      acc[c][a] = x;
-    }
-  if ((lane & 3) == 0) {
-    double *row = red + (size_t)(wave * 16 + (lane >> 2)) * (8 * R + 1);
-#pragma unroll
-    for (int c = 0; c < 8; ++c)
-#pragma unroll
-      for (int a = 0; a < R; ++a) row[c * R + a] = acc[c][a];
-  }
-  __syncthreads();
+  reduce_8R<R, 4>(acc, red, zs, tid);
 #ifdef DPGO_RTR_TRACE
-  if (tr && tid == 0) tr[2] = wall_clock64();  // quad sums in LDS, barrier passed
+  if (tr && tid == 0) tr[2] = wall_clock64();  // sums in zs
 #endif
-  if (tid < 8 * R) {
-    double t[64];
-#pragma unroll
-    for (int q = 0; q < 64; ++q) t[q] = red[q * (8 * R + 1) + tid];
-    // four interleaved chains (one wave per SIMD: a chain of 64 dependent adds is 64 add latencies)
-    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-#pragma unroll
-    for (int q = 0; q < 64; q += 4) { s0 += t[q]; s1 += t[q + 1]; s2 += t[q + 2]; s3 += t[q + 3]; }
-    zs[tid] = (s0 + s1) + (s2 + s3);
-  }
   if (tid < 64) WSYNC();
 }
 
@@ -445,36 +470,10 @@ struct TLLane {
   int voff[TLS_NPRE];     // offset (doubles) of the pair's two rows in an r x 4n vector
   double vlive[TLS_NPRE]; // 0 for lanes past the workgroup's rows
 };
-// the 128 per-lane sums of the 8R outputs -> zs (valid in both waves): quad reduction, 32 LDS rows, one lane per output
+// the 128 per-lane sums of the 8R outputs -> zs (valid in both waves): reduce_8R over two waves
 template <int R>
 __device__ __forceinline__ void tls_reduce(double (*acc)[R], double *red, double *zs, int tid) {
-  const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-  for (int c = 0; c < 8; ++c)
-#pragma unroll
-    for (int a = 0; a < R; ++a) {
-      double x = acc[c][a];
-      x += dpp_move<0xB1>(x);
-      x += dpp_move<0x4E>(x);
-      acc[c][a] = x;
-    }
-  if ((lane & 3) == 0) {
-    double *row = red + (size_t)(wave * 16 + (lane >> 2)) * (8 * R + 1);
-#pragma unroll
-    for (int c = 0; c < 8; ++c)
-#pragma unroll
-      for (int a = 0; a < R; ++a) row[c * R + a] = acc[c][a];
-  }
-  __syncthreads();
-  if (tid < 8 * R) {
-    double t[32];
-#pragma unroll
-    for (int q = 0; q < 32; ++q) t[q] = red[q * (8 * R + 1) + tid];
-    double s = 0;
-#pragma unroll
-    for (int q = 0; q < 32; ++q) s += t[q];
-    zs[tid] = s;
-  }
+  reduce_8R<R, 2>(acc, red, zs, tid);
   __syncthreads();
 }
 template <int R, class Vec>
