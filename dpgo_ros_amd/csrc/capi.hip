@@ -73,6 +73,7 @@ dpgo_team_t *dpgo_team_create(int device, const dpgo_params_t *p, int num_local,
     if (e2) t->use_fused_rtr = (e2[0] == '0') ? 0 : 1;
     const char *e5 = std::getenv("DPGO_FUSED_EVAL");
     if (e5) t->use_fused_eval = (e5[0] == '0') ? 0 : 1;
+    if (const char *e6 = std::getenv("DPGO_FE_MIN_N")) t->fe_min_n = std::max(32, std::atoi(e6));
     if (t->d_nest_all.alloc(3 * std::max(1, num_local)) ||
         hipMemset(t->d_nest_all.p, 0, sizeof(NestState) * 3 * std::max(1, num_local)) != hipSuccess ||
         hipHostMalloc((void **)&t->h_bar_err, sizeof(int)) != hipSuccess) {
@@ -976,7 +977,7 @@ int dpgo_team_step_end(dpgo_team_t *t, int sel_id) {
 
 // prepare_only: capture and instantiate every graph a run of `iters` iterations from the current state would replay
 // (both alternating instances of each), execute nothing
-// the one-launch iteration (step_fused.hip) may serve this team: dense agents of 257 .. 512 poses whose rows fit the ELL
+// the one-launch iteration (step_fused.hip) may serve this team: dense agents of fe_min_n (449: where it is faster) .. 512 poses whose rows fit the ELL
 // part, few enough public poses / shared edges for its LDS tables, the schedule and the descriptors baked into the
 // launches (period <= 8), every neighbour co-resident (the twins of its poses are addressed through the shared-edge table)
 static bool fused_eval_eligible(dpgo_team_t *t) {
@@ -989,7 +990,7 @@ static bool fused_eval_eligible(dpgo_team_t *t) {
     return false;
   for (size_t k = 0; k < t->ag.size(); ++k) {
     const int n = t->ag[k]->n;
-    if (t->precond_of[k] != DPGO_PRECOND_DENSE || n <= 256 || n > 512 || !t->ag[k]->has_soa ||
+    if (t->precond_of[k] != DPGO_PRECOND_DENSE || n < t->fe_min_n || n > 512 || !t->ag[k]->has_soa ||
         t->h_descs[k].nshared > step_fe_max_edges())
       return false;
   }
@@ -1032,7 +1033,7 @@ static int team_run_impl(dpgo_team_t *t, int iters, bool prepare_only) {
   // team->cur_sel / next_sel, one dependent round trip less in each prologue.
   const int P = (int)t->sched.size();
   const bool bake = t->bake_sel && P >= 1 && P <= 8;
-  // One-launch iterations (step_fused.hip) for the mid-run part of a pipelined graph: dense agents of 257 .. 512 poses,
+  // One-launch iterations (step_fused.hip) for the mid-run part of a pipelined graph: dense agents of 449 .. 512 poses,
   // the schedule and the descriptors baked in.  Their launches alternate between the two copies of the poses (parity),
   // so they need neither each other's company on the device nor its lock
   const bool fe_ok = pipelined && graphable && fused_eval_eligible(t);

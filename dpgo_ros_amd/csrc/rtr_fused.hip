@@ -286,7 +286,7 @@ __device__ __forceinline__ void slab_finish(const double *Ms, int N4, double2 (*
                                             unsigned long long *tr = nullptr) {
   constexpr int MAXM = SLAB_MAXM;
 #ifdef DPGO_RTR_TRACE
-  if (tr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (tid == 0) tr[0] = wall_clock64(); }  // the vector has arrived
+  if (tr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (tid == 0) { tr[0] = wall_clock64(); tr[3] = __builtin_amdgcn_s_memtime(); } }  // the vector has arrived
 #endif
   double acc[8][R];
 #pragma unroll
@@ -316,11 +316,20 @@ __device__ __forceinline__ void slab_finish(const double *Ms, int N4, double2 (*
       for (int a = 0; a < R; ++a) acc[c][a] = __builtin_fma(w[R + a], mm[c].y, acc[c][a]);
   }
 #ifdef DPGO_RTR_TRACE
-  if (tr && tid == 0) tr[1] = wall_clock64();  // products done
+  if (tr && tid == 0) { tr[1] = wall_clock64(); tr[4] = __builtin_amdgcn_s_memtime(); }  // products done
+#endif
+#if defined(DPGO_RTR_REPEAT) && defined(DPGO_RTR_REPEAT_PRODUCT_ONLY)
+  if (tr == reinterpret_cast<unsigned long long *>(1)) {  // (experiment: a repetition without the reduction)
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+      for (int a = 0; a < R; ++a) asm volatile("" :: "v"(acc[c][a]));
+    return;
+  }
 #endif
   reduce_8R<R, 4>(acc, red, zs, tid);
 #ifdef DPGO_RTR_TRACE
-  if (tr && tid == 0) tr[2] = wall_clock64();  // sums in zs
+  if (tr && tid == 0) { tr[2] = wall_clock64(); tr[5] = __builtin_amdgcn_s_memtime(); }  // sums in zs
 #endif
   if (tid < 64) WSYNC();
 }
@@ -550,7 +559,9 @@ __global__ __launch_bounds__(TL ? TLS_NT : 256) void k_rtr_solve(const AgentDev 
                                                    unsigned long long *host_cum, int *err, double Delta0, double tol, int max_outer, int max_inner,
                                                    double max_radius, TeamDev *team, int tail, int num_robots,
                                                    int restart_interval) {
-  extern __shared__ double Ms[];  // [8][N4]: this workgroup's columns of M
+  // (16-byte aligned: the static arrays in front of it end on an odd multiple of 8 bytes, and every 16-byte ds_read of a
+  // slab that starts there is split by the hardware -- the slab product ran at a sixth of its speed until round 4)
+  extern __shared__ __attribute__((aligned(16))) double Ms[];  // [8][N4]: this workgroup's columns of M
   __shared__ double red[(TL ? 32 : 64) * (8 * R + 1)];  // (the two-level solve runs 128 threads: 32 rows of partial sums)
   // own two poses, [pose][component c][row a]: X, Euclidean / Riemannian gradient at X; tCG residual, z, delta, eta;
   // scratch; candidate point and its gradients
@@ -862,6 +873,14 @@ __global__ __launch_bounds__(TL ? TLS_NT : 256) void k_rtr_solve(const AgentDev 
         slab_finish<R>(Ms, N4, vv, red, zs, tid, (bx == 0 && fine_on) ? bar + RB_TRACE + 64 + 20 : nullptr);
 #else
         slab_finish<R>(Ms, N4, vv, red, zs, tid);
+#ifdef DPGO_RTR_REPEAT  // (experiment: the in-situ cost of one product + reduction = the time added per repetition)
+#pragma unroll 1
+#ifdef DPGO_RTR_REPEAT_PRODUCT_ONLY
+        for (int rep = 1; rep < DPGO_RTR_REPEAT; ++rep) { asm volatile("" ::: "memory"); slab_finish<R>(Ms, N4, vv, red, zs, tid, reinterpret_cast<unsigned long long *>(1)); }
+#else
+        for (int rep = 1; rep < DPGO_RTR_REPEAT; ++rep) { __syncthreads(); slab_finish<R>(Ms, N4, vv, red, zs, tid); }
+#endif
+#endif
 #endif
       }
       RTR_FINE(11);

@@ -43,7 +43,7 @@
 //     next to the one every workgroup of this launch reads; the launch that leaves the fused run copies it back
 //     (k_eval_stats, nest_copy).
 // Mid-run iterations only (ahead == 3: nothing a status query reads is left behind); the last iterations of a run take
-// the two-launch sequence, which leaves the statistics.  Dense agents of 257 .. 512 poses, r <= 5, rows of <= 8 blocks,
+// the two-launch sequence, which leaves the statistics.  Dense agents of 449 (default: where this form is faster; any n >= 32 with DPGO_FE_MIN_N) .. 512 poses, r <= 5, rows of <= 8 blocks,
 // <= 160 shared edges; DPGO_FUSED_EVAL=0 keeps the two-launch sequence everywhere.
 #include "kernel_common.h"
 #include <algorithm>

@@ -24,3 +24,6 @@ print("   10 sum, 11 slab apply, 12 tail+stores, 13 drained, 14 wg barrier, 15 a
 print(np.round((fine - fine[0]) / 100.0, 2).tolist())
 sl = np.array(out[17 * 16 + 2 + 64 + 20:17 * 16 + 2 + 64 + 23], dtype=np.int64)
 print("inside the slab product (us since the iteration's start): vector arrived, products done, quad sums in LDS + barrier:", np.round((sl - fine[0]) / 100.0, 2).tolist())
+sc = np.array(out[17 * 16 + 2 + 64 + 23:17 * 16 + 2 + 64 + 26], dtype=np.int64)
+print("the same three points by the shader clock (s_memtime): products %d clocks, reduction %d clocks -> %.2f GHz" % (
+    sc[1] - sc[0], sc[2] - sc[1], (sc[2] - sc[0]) / max(1, (sl[2] - sl[0])) / 10.0))

@@ -18,7 +18,11 @@ RGD = dict(method=1, acceleration=1, rgd_stepsize=0.2, rgd_use_preconditioner=1,
 
 def _team(dataset, robots, fused, r=5, **kw):
     old = os.environ.get("DPGO_FUSED_EVAL")
+    old_min = os.environ.get("DPGO_FE_MIN_N")
     os.environ["DPGO_FUSED_EVAL"] = "1" if fused else "0"
+    # the one-launch form serves agents of 449 .. 512 poses by default (where it is faster); the tests run it on every
+    # size it can serve
+    os.environ["DPGO_FE_MIN_N"] = "32"
     try:
         m, mp, n = load(dataset, robots)
         prm = capi.default_params(r=r, num_robots=robots, **kw)
@@ -29,6 +33,10 @@ def _team(dataset, robots, fused, r=5, **kw):
             os.environ.pop("DPGO_FUSED_EVAL", None)
         else:
             os.environ["DPGO_FUSED_EVAL"] = old
+        if old_min is None:
+            os.environ.pop("DPGO_FE_MIN_N", None)
+        else:
+            os.environ["DPGO_FE_MIN_N"] = old_min
     return t
 
 
@@ -83,6 +91,20 @@ def test_teams_the_one_launch_form_cannot_serve_keep_the_two_launch_sequence():
         t.synchronize()
         assert t.counters()[7] == 0, (dataset, robots, kw)
         assert t.cost() < c0
+        t.close()
+
+
+def test_default_window_of_the_one_launch_form():
+    """by default the one-launch form serves agents of 449 .. 512 poses -- below that the two-launch sequence is faster
+    (profiles/experiments/fe_small.py); DPGO_FE_MIN_N widens it (every other test here runs it from 32 poses up)"""
+    assert os.environ.get("DPGO_FE_MIN_N") is None
+    for robots, served in ((5, True), (6, False), (8, False)):
+        m, mp, n = load("sphere2500", robots)
+        t = capi.Team.from_measurements(mp.view(capi.MEAS_DTYPE), capi.default_params(r=5, num_robots=robots, **RGD))
+        t.set_initial(O.odometry_init(m, n), O.fixed_stiefel(5))
+        t.run(64)
+        t.synchronize()
+        assert (t.counters()[7] > 0) == served, (robots, t.counters()[7])
         t.close()
 
 
