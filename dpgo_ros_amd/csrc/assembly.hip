@@ -257,6 +257,12 @@ int finalize_agent(dpgo_team *t, Agent &a, double *scratch) {
   std::vector<int> pose_eptr(n + 1, 0);
   for (const auto &d : se) pose_eptr[d.lpose + 1] += 1;
   for (int j = 0; j < n; ++j) pose_eptr[j + 1] += pose_eptr[j];
+  {
+    const int ppb = 64 / t->prm.r;
+    a.max_pose_edges = a.max_tile_edges = 0;
+    for (int j = 0; j < n; ++j) a.max_pose_edges = std::max(a.max_pose_edges, pose_eptr[j + 1] - pose_eptr[j]);
+    for (int j = 0; j < n; j += ppb) a.max_tile_edges = std::max(a.max_tile_edges, pose_eptr[std::min(n, j + ppb)] - pose_eptr[j]);
+  }
   a.se_host = se;  // the neighbour-pose pointers are filled in by sync_descs once every agent's buffers exist
   // edge records for residual / cost evaluation
   std::vector<EdgeDev> edges;
@@ -536,6 +542,15 @@ int sync_descs_noflush(dpgo_team *t) {
                      t_q, t_fin, t_inv, since(q3));
       t->dense_max_n = 0;
       for (auto &a : t->ag) if (a->precond == DPGO_PRECOND_DENSE) t->dense_max_n = std::max(t->dense_max_n, a->n);
+      // evaluations stage the shared edges' operands through LDS where a pose carries more than g_row_range's four at a
+      // time (two dependent round trips per four edges there, two in all here) and the fullest tile fits
+      {
+        int mp = 0, mt = 0;
+        for (auto &a : t->ag) { mp = std::max(mp, a->max_pose_edges); mt = std::max(mt, a->max_tile_edges); }
+        const char *env = std::getenv("DPGO_STAGED_EVAL");  // (read when the structure is built: a per-team choice in the tests)
+        const int min_edges = env ? std::atoi(env) : 5;  // DPGO_STAGED_EVAL=0: always, =1000000: never
+        t->stage_cap = (mp >= min_edges && mt > 0 && eval_staged_lds_bytes(t->prm.r, mt) <= (size_t)140 * 1024) ? mt : 0;
+      }
       t->precond_of.clear();
       for (auto &a : t->ag) t->precond_of.push_back(a->precond);
       t->tl_max_wg = 0;

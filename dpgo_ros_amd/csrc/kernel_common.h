@@ -185,6 +185,26 @@ __device__ __forceinline__ void g_row_range(const AgentDev &ag, int e0, int e1, 
   }
 }
 
+// the same sums from operands that k_eval_staged (spmm.hip) put into LDS: per edge [neighbour pose, 4R doubles][16
+// coefficients]; edge after edge, coefficient after coefficient, exactly g_row_range's order (bitwise the same G)
+template <int R>
+__device__ __forceinline__ void g_row_lds(const double *Eop, int e0, int e1, int a, double g[4]) {
+  constexpr int EPE = 4 * R + 16;
+  g[0] = g[1] = g[2] = g[3] = 0.0;
+  for (int e = e0; e < e1; ++e) {
+    const double *E = Eop + (size_t)e * EPE;
+    double x[4], cf[16];
+#pragma unroll
+    for (int cp = 0; cp < 4; ++cp) x[cp] = E[cp * R + a];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const double2 t = *reinterpret_cast<const double2 *>(E + 4 * R + 2 * i); cf[2 * i] = t.x; cf[2 * i + 1] = t.y; }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int cp = 0; cp < 4; ++cp) g[c] -= x[cp] * cf[cp + 4 * c];
+  }
+}
+
 template <int R>
 __device__ __forceinline__ void g_row(const AgentDev *__restrict__ agents, const AgentDev &ag, int q, int a, int aux, int pull,
                                       double g[4]) {
@@ -219,7 +239,7 @@ __device__ __forceinline__ void advance_agent(const AgentDev &ag, int accel, int
 template <int R, bool IN_WAVE = false, bool BAKED = false>
 __device__ __forceinline__ void eval_body(const AgentDev *__restrict__ agents, const TeamDev *team, int sel, int xb, int egb, int gfb,
                                           int poff, int gmode, int aux, int bx, double *Ysh, double *Wsh,
-                                          const AgentDev &agv) {
+                                          const AgentDev &agv, const double *Eop = nullptr, int ebase = 0) {
   const AgentDev &ag = pick_agent<BAKED>(agv, agents, BAKED ? 0 : (IN_WAVE ? sel : sel_cur(team, sel)));
   constexpr int PPB = 64 / R;
   const int lane = IN_WAVE ? (int)(threadIdx.x & 63) : (int)threadIdx.x, lp = lane / R, a = lane - lp * R;
@@ -237,6 +257,9 @@ __device__ __forceinline__ void eval_body(const AgentDev *__restrict__ agents, c
 #pragma unroll
       for (int cp = 0; cp < 4; ++cp) x[0][cp] = X[((size_t)4 * i + cp) * R + a];
     }, acc);
+    // (k_eval_staged: the helper waves have put the operands of the tile's shared edges into LDS meanwhile.  This wave is
+    // the only one of the workgroup in here and lane 0 is always active: the barrier executes once per wave)
+    if (Eop) __syncthreads();
     double g[4] = {0, 0, 0, 0};
     double *Gj = ag.buf[B_G] + (size_t)j * 4 * R;
     if (e1 > e0) {
@@ -244,7 +267,10 @@ __device__ __forceinline__ void eval_body(const AgentDev *__restrict__ agents, c
 #pragma unroll
         for (int c = 0; c < 4; ++c) g[c] = Gj[c * R + a];
       } else {
-        g_row_range<R>(ag, e0, e1, a, aux, gmode == 2, g);
+        // (Eop: the operands of this tile's shared edges are in LDS -- k_eval_staged -- and the pulled poses already
+        // went to the slab)
+        if (Eop) g_row_lds<R>(Eop, e0 - ebase, e1 - ebase, a, g);
+        else g_row_range<R>(ag, e0, e1, a, aux, gmode == 2, g);
 #pragma unroll
         for (int c = 0; c < 4; ++c) Gj[c * R + a] = g[c];
       }

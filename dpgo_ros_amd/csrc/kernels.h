@@ -22,6 +22,8 @@ struct LaunchCtx {
   const int *up_slots = nullptr;
   const double *up_in = nullptr;
   int up_n0 = 0, up_n1 = 0;
+  int stage_cap = 0;               // > 0: evaluations that assemble G stage the shared edges' operands through LDS
+                                   // (k_eval_staged); the most shared edges any tile of any agent of the team carries
   const NestState *nest_all = nullptr;  // the team's NestStates, [local agent]: lets a kernel read an agent's Nesterov
                                         // state from the agent index alone, next to (not behind) its descriptor
 };
@@ -40,6 +42,7 @@ struct EvalOpts {
 void launch_buildG(const LaunchCtx &c, int sel, int max_npub, int aux, int pull);
 void launch_pull(const LaunchCtx &c, int dst, int nshared);
 void launch_eval(const LaunchCtx &c, int sel, int max_n, int xb, int egb, int gfb, int poff, const EvalOpts &o);
+size_t eval_staged_lds_bytes(int r, int cap);
 void launch_hess(const LaunchCtx &c, int sel, int max_n, int xb, int egb, int vb, int ob, int poff);
 void launch_precond(const LaunchCtx &c, int sel, int max_n, int mode, int xb, int vb, int zb, int sp, int max_inner,
                     double step, int accel, int num_robots, int advance = 0, int restart_interval = 1, int ahead = 0);

@@ -45,6 +45,85 @@ __global__ __launch_bounds__(64) void k_eval(const AgentDev *__restrict__ agents
   eval_body<R>(agents, team, sel, xb, egb, gfb, poff, gmode, aux, (int)blockIdx.x, Ysh, Wsh, agents[0]);
 }
 
+// k_eval for agents whose poses carry MANY shared edges (the tunnels robots: up to 20 inter-robot loop closures per pose,
+// 3548 of the 4891 edges cross robots).  g_row_range chases them four at a time -- descriptor, then neighbour pose and
+// coefficients, two dependent round trips per four edges -- behind the lane's own SpMM.  Here three helper waves fetch the
+// operands of ALL shared edges of the tile into LDS while the tile's wave runs its SpMM: every 16-byte chunk of the
+// coefficients and every edge descriptor in one round trip, every chunk of the neighbours' poses in a second one,
+// whatever the number of edges; ONE barrier, the helpers leave, and the tile's lanes form G from LDS in g_row_range's
+// order (bitwise the same sums).  A pulled neighbour pose also goes to the slab, as g_row_range does.
+constexpr int EVS_NT = 256, EVS_NH = EVS_NT - 64;
+template <int R>
+__global__ __launch_bounds__(EVS_NT) void k_eval_staged(const AgentDev *__restrict__ agents, const TeamDev *team, int sel, int xb, int egb,
+                                                        int gfb, int poff, int gmode, int aux, int cap) {
+  constexpr int PPB = 64 / R, EPE = 4 * R + 16, XCH = 2 * R;  // XCH: 16-byte chunks of a neighbour pose
+  __shared__ double Ysh[PPB * 4 * R], Wsh[PPB * 4 * R];
+  extern __shared__ __attribute__((aligned(16))) double Eop[];  // [cap][EPE]
+#ifdef DPGO_EVS_TRACE
+  const unsigned long long ts0 = wall_clock64();
+#define EVS_STAMP(k) do { if ((threadIdx.x & 63) == 0) ag.part[PART_E + (4000 + (int)blockIdx.x) * PART_STRIDE + (k)] = (double)(wall_clock64() - ts0); } while (0)
+#else
+#define EVS_STAMP(k) do { } while (0)
+#endif
+  const AgentDev &ag = agents[sel_cur(team, sel)];
+  const int bx = (int)blockIdx.x;
+  const int j0 = bx * PPB;
+  if (j0 >= ag.n) return;
+  const int E0 = ag.pose_eptr[j0], E1 = ag.pose_eptr[min(j0 + PPB, ag.n)], cnt = E1 - E0;
+  if (threadIdx.x >= 64) {
+    if (cnt == 0) return;
+    const int t = (int)threadIdx.x - 64;
+    const bool pull = gmode == 2;
+    constexpr int CB = 8;  // chunks per lane and pass (the host keeps cap * XCH <= a few passes of EVS_NH * CB)
+    const int nco = cnt * 8, nx = cnt * XCH;
+    for (int base = 0; base < max(nco, nx); base += EVS_NH * CB) {
+      // coefficient chunks and the descriptors of the edges whose pose chunks this lane takes: addresses known from the
+      // edge index alone, one round trip
+      double2 vc[CB];
+      const double *src[CB];
+      int slot[CB], ed[CB], part[CB];
+#pragma unroll
+      for (int u = 0; u < CB; ++u) {
+        const int q = min(base + t + EVS_NH * u, nco - 1);
+        vc[u] = ld2(ag.se[E0 + (q >> 3)].coef + 2 * (q & 7));
+        const int qx = min(base + t + EVS_NH * u, nx - 1);
+        ed[u] = qx / XCH; part[u] = qx - ed[u] * XCH;
+        const SharedEdgeDev &se = ag.se[E0 + ed[u]];
+        src[u] = se.src[aux]; slot[u] = se.slot;
+      }
+      // the neighbours' poses: one more round trip
+      double2 vx[CB];
+      bool cp[CB];
+#pragma unroll
+      for (int u = 0; u < CB; ++u) {
+        cp[u] = pull && src[u];
+        const double *xp = cp[u] ? src[u] : ag.nbr[aux] + (size_t)slot[u] * 4 * R;
+        vx[u] = ld2(xp + 2 * part[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < CB; ++u) {
+        const int q = base + t + EVS_NH * u;
+        if (q < nco) *reinterpret_cast<double2 *>(Eop + (size_t)(q >> 3) * EPE + 4 * R + 2 * (q & 7)) = vc[u];
+      }
+#pragma unroll
+      for (int u = 0; u < CB; ++u) {
+        if (base + t + EVS_NH * u < nx) {
+          *reinterpret_cast<double2 *>(Eop + (size_t)ed[u] * EPE + 2 * part[u]) = vx[u];
+          if (cp[u]) *reinterpret_cast<double2 *>(ag.nbr[aux] + (size_t)slot[u] * 4 * R + 2 * part[u]) = vx[u];
+        }
+      }
+    }
+    EVS_STAMP(1 + (t >> 6));
+    __syncthreads();  // (pairs with the tile's wave: eval_body, behind its SpMM)
+    return;
+  }
+  eval_body<R>(agents, team, sel, xb, egb, gfb, poff, gmode, aux, bx, Ysh, Wsh, agents[0], cnt > 0 ? Eop : nullptr, E0);
+  EVS_STAMP(0);
+#ifdef DPGO_EVS_TRACE
+  if (threadIdx.x == 0) ag.part[PART_E + (4000 + (int)blockIdx.x) * PART_STRIDE + 4] = (double)cnt;
+#endif
+}
+
 // generic Riemannian Hessian-vector product at point xb with Euclidean gradient egb:  ob = Hess[vb]
 // partials: [0] <v, Hv>
 template <int R>
@@ -309,7 +388,24 @@ void launch_pull(const LaunchCtx &c, int dst, int nshared) {
   DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_pull<R>, dim3((len + 255) / 256), dim3(256), 0, c.stream, c.agents, dst));
 }
 
+size_t eval_staged_lds_bytes(int r, int cap) { return (size_t)cap * (4 * r + 16) * 8; }
+
 void launch_eval(const LaunchCtx &c, int sel, int max_n, int xb, int egb, int gfb, int poff, const EvalOpts &o) {
+  if (o.gmode != 0 && c.stage_cap > 0) {  // agents with many shared edges per pose: the edges' operands through LDS
+    const size_t dyn = eval_staged_lds_bytes(c.r, c.stage_cap);
+    hipError_t e = hipSuccess;
+    DPGO_DISPATCH_R(c.r, {
+      static bool configured = false;
+      if (!configured) {
+        e = hipFuncSetAttribute((const void *)k_eval_staged<R>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        configured = (e == hipSuccess);
+      }
+      if (e == hipSuccess)
+        hipLaunchKernelGGL(k_eval_staged<R>, dim3(spmm_grid(c.r, max_n), c.ny), dim3(EVS_NT), dyn, c.stream, c.agents, c.team, sel, xb,
+                           egb, gfb, poff, o.gmode, o.aux, c.stage_cap);
+    });
+    if (e == hipSuccess) return;
+  }
   DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_eval<R>, dim3(spmm_grid(c.r, max_n), c.ny), dim3(64), 0, c.stream, c.agents,
                                           c.team, sel, xb, egb, gfb, poff, o.gmode, o.aux));
 }

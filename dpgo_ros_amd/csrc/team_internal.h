@@ -84,6 +84,7 @@ struct Agent {
   bool index_dirty = true, data_dirty = true;
   bool struct_uploaded = false;  // the index arrays of the current measurement structure are on the device
   int n = 0;
+  int max_pose_edges = 0, max_tile_edges = 0;  // shared edges: most at one pose, most in one 64 / r-pose evaluation tile
   // neighbour pose dictionary (sorted (robot, frame)) and per-neighbour public ids
   std::vector<std::pair<int, int>> np;
   std::vector<char> np_has[2];
@@ -225,6 +226,7 @@ struct dpgo_team {
   std::vector<int> precond_of;  // [local agent] the form each agent runs (selects the preconditioner kernel's variant)
   std::vector<dpgo::AgentDev> h_descs;  // host copies of the uploaded descriptors (baked graphs pass them by value)
   int tl_max_wg = 0;            // most workgroups a two-level apply of this team runs
+  int stage_cap = 0;            // k_eval_staged: most shared edges a 64 / r-pose tile of any agent carries (0: the plain k_eval)
   int bake_sel = 1;  // DPGO_BAKE_SEL=0: the graphs of the pipelined iteration select their agent on the device only
   int bake_desc = 1; // DPGO_BAKE_DESC=0: ... and find its descriptor in the device array instead of in their arguments
   bool last_iteration_folded = false;  // ... and enqueue_team_iteration skipped k_nest_post / k_status / k_advance for it
@@ -246,6 +248,7 @@ struct dpgo_team {
     c.dense_max_n = dense_max_n;
     c.host_precond = precond_of.empty() ? nullptr : precond_of.data();
     c.tl_max_wg = tl_max_wg;
+    c.stage_cap = stage_cap;
     c.host_agents = h_descs.empty() ? nullptr : h_descs.data();
     for (int k : precond_of) if (k == DPGO_PRECOND_TWO_LEVEL) c.any_two_level = true;
     return c;

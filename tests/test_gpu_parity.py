@@ -767,3 +767,42 @@ def test_bench_configuration_against_the_live_oracle():
     assert abs(rh.f_opt - ro.f_opt) <= 1e-10 * abs(ro.f_opt) and abs(rh.gradnorm_opt - ro.gradnorm_opt) <= 1e-8 * max(1.0, ro.gradnorm_opt)
     print("bench configuration vs live oracle, 320 iterations: max |X, Y, V difference| = %.2e" % worst)
     th.close()
+
+
+@pytest.mark.parametrize("dataset", ["tunnels", "sphere2500"])
+def test_staged_shared_edge_evaluation_is_bitwise_the_plain_one(dataset, monkeypatch):
+    """k_eval_staged (helper waves put the operands of a tile's shared edges into LDS, csrc/spmm.hip) forms G in
+    g_row_range's order: lockstep ticks, RTR block updates and the cost are BITWISE those of the plain k_eval -- on tunnels
+    (up to 20 shared edges per pose: staged by default) and, forced, on sphere2500 / 5"""
+    from tests.util import load_tunnels
+
+    def team(staged, **kw):
+        monkeypatch.setenv("DPGO_STAGED_EVAL", "0" if staged else "1000000")
+        if dataset == "tunnels":
+            m = load_tunnels(1)
+            nk = [int(max(m["p1"][m["r1"] == k].max(), m["p2"][m["r2"] == k].max())) + 1 for k in range(8)]
+            Ts = []
+            for k in range(8):
+                odo = m[(m["r1"] == k) & (m["r2"] == k) & (m["p1"] + 1 == m["p2"])].copy()
+                odo["r1"] = 0
+                odo["r2"] = 0
+                Ts.append(O.odometry_init(odo, nk[k]))
+            T, N, mp = np.concatenate(Ts), 8, m
+        else:
+            m, mp, n = load(dataset, 5)
+            T, N = O.odometry_init(m, n), 5
+        t = capi.Team.from_measurements(mp.view(capi.MEAS_DTYPE), capi.default_params(r=5, num_robots=N, **kw))
+        t.set_initial(T, O.fixed_stiefel(5))
+        return t
+
+    for kw, run in ((dict(method=1, rgd_stepsize=0.2, acceleration=0), lambda t: t.run_simultaneous(40)),
+                    (dict(method=0, rtr_iterations=3, rtr_tcg_iterations=50, gradnorm_tol=0.5, acceleration=0), lambda t: t.run(16))):
+        ta, tb = team(False, **kw), team(True, **kw)
+        for t in (ta, tb):
+            run(t)
+            t.synchronize()
+        for k in ta.ids:
+            assert np.array_equal(ta.agents[k].get_X(), tb.agents[k].get_X()), (dataset, kw["method"], k)
+        assert ta.cost() == tb.cost()
+        ta.close()
+        tb.close()
