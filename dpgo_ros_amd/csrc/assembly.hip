@@ -201,11 +201,13 @@ static int choose_precond(dpgo_team *t, Agent &a, double &budget) {
     return DPGO_ERR;
   }
   if (mode == DPGO_PRECOND_AUTO) {
-    // RTR: an agent too large for the dense one-launch solve (its 8-column slabs do not fit LDS beyond 512 poses) keeps
-    // the solve in one launch with the two-level form, whose slabs do (rtr_fused.hip) -- worth more than the cheaper
-    // single apply of the dense inverse
+    // RTR: an agent too large for the dense one-launch solve with two poses per workgroup (its 8-column slabs do not fit
+    // LDS beyond 512 poses) keeps the solve in one launch with the two-level form, whose slabs do (rtr_fused.hip) -- worth
+    // more than the cheaper single apply of the dense inverse.  (The dense solve with THREE poses per workgroup, 513 .. 640
+    // poses, serves agents whose dense form is asked for: measured on the GNC torus3D schedule it is 8 % faster in all,
+    // 701 against 761 ms, but an UPDATE_WEIGHT round costs 14.7 instead of 5.9 ms -- the automatic mode keeps two-level.)
     const bool rtr_tl = t->prm.method == DPGO_METHOD_RTR && t->use_fused_rtr && tl_ok &&
-                        !(rtr_fused_eligible(t->prm.r, a.n, t->num_cus) && rtr_fused_lds_bytes(t->prm.r, a.n) <= (size_t)t->max_lds) &&
+                        !(rtr_fused_np(t->prm.r, a.n, t->num_cus) == 2 && rtr_fused_lds_bytes(t->prm.r, a.n) <= (size_t)t->max_lds) &&
                         a.tl_plan.prod_post &&
                         rtr_fused_tl_eligible(t->prm.r, a.tl_plan.nwg - a.tl_plan.nS2, tl_max_pre_poses(a.tl_plan), a.tl_plan.ns, t->num_cus, t->max_lds);
     if (rtr_tl) mode = DPGO_PRECOND_TWO_LEVEL;

@@ -120,6 +120,7 @@ __host__ __device__ inline size_t rtr_ring_pitch(size_t doubles) { return (doubl
 constexpr int RTR_RING = 32;  // H delta buffers (r x 4n doubles each) behind the partial sums: one per tCG iteration, reused
                               // after RTR_RING iterations (rtr_fused.hip)
 bool rtr_fused_eligible(int r, int n, int num_cus);
+int rtr_fused_np(int r, int n, int num_cus);  // poses per workgroup of the dense one-launch solve (2, 3) or 0
 size_t rtr_fused_lds_bytes(int r, int n);  // LDS the solve of an n-pose agent needs (checked against the device's limit)
 // cum: 4 zero-initialised 64-bit words per agent: running totals {solves, Hessian-vector products, preconditioner
 // applies, outer iterations} the kernel adds to; host_rec / host_cum: pinned host copies of the solve's record and of
@@ -127,7 +128,7 @@ size_t rtr_fused_lds_bytes(int r, int n);  // LDS the solve of an n-pose agent n
 int launch_rtr_solve(const LaunchCtx &c, int ai, int n, unsigned long long *bar, double *ws, unsigned long long *cum, RtrState *host_rec,
                      unsigned long long *host_cum, int *err, double Delta0,
                      double tol, int max_outer, int max_inner, double max_radius, int tail = 0, int num_robots = 1,
-                     int restart_interval = 1, int tl_nwg = 0, size_t tl_dyn = 0);
+                     int restart_interval = 1, int tl_nwg = 0, size_t tl_dyn = 0, int np = 2);
 // ... for an agent with the two-level preconditioner (tl_nwg workgroups, tl_dyn bytes of slab per workgroup)
 size_t rtr_fused_tl_lds_bytes(int r, int max_pre_poses, int ns);
 bool rtr_fused_tl_eligible(int r, int nwg, int max_pre_poses, int ns, int num_cus, int max_lds);

@@ -35,11 +35,11 @@ constexpr long long RB_TIMEOUT_TICKS = 50000000;  // 0.5 s of the 100 MHz wall c
 // No hand-off: every workgroup touches its own two poses only, and nothing here reads what the advance writes.
 template <int R>
 __device__ __forceinline__ void solve_tail(const AgentDev *__restrict__ agents, const AgentDev &ag, TeamDev *team, int tail,
-                                           int num_robots, int restart_interval, int bx, int npose, int tid, int pj0, int pj1) {
+                                           int num_robots, int restart_interval, int bx, int npose, int tid, int pj0, int pj1, int pj2 = -1) {
   if (tid < 64) {
     double rel = 0;
     if (tid < npose) {
-      const size_t o = (size_t)(tid ? pj1 : pj0) * 4 * R;
+      const size_t o = (size_t)(tid == 0 ? pj0 : (tid == 1 ? pj1 : pj2)) * 4 * R;
       double x[4 * R], xp[4 * R];
 #pragma unroll
       for (int i = 0; i < 4 * R; ++i) { x[i] = ag.buf[B_X][o + i]; xp[i] = ag.buf[B_XPREV][o + i]; }
@@ -231,9 +231,10 @@ __device__ __forceinline__ double swap_add_16(double x, double y) {
   const auto h = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
   return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
 }
-template <int R, int NW>
+template <int R, int NW, int NC = 8>
 __device__ __forceinline__ void reduce_8R(double (*acc)[R], double *red, double *zs, int tid) {
-  constexpr int N = 8 * R, H = N / 2, Q = N / 4;
+  constexpr int N = NC * R, H = N / 2, Q = N / 4;  // NC columns: 8 (two poses per workgroup) or 12 (three)
+  static_assert(N % 4 == 0, "two halvings");
   const int lane = tid & 63, wave = tid >> 6;
   double s[H], u[Q];
 #pragma unroll
@@ -272,62 +273,58 @@ __device__ __forceinline__ void reduce_8R(double (*acc)[R], double *red, double 
 constexpr int SLAB_MAXM = 4;
 // straight-line code: rows beyond N4 read row N4 - 2 again and are multiplied by zero (one wave per SIMD: nothing
 // hides a wait, so every load of a step is in flight before the first FMA)
-template <int R, class Vec>
+template <int R, int MAXM, class Vec>
 __device__ __forceinline__ void slab_issue(int N4, const Vec &V, int tid, double2 (*v)[R]) {
 #pragma unroll
-  for (int m = 0; m < SLAB_MAXM; ++m) {
+  for (int m = 0; m < MAXM; ++m) {
     const int k = 2 * tid + 512 * m, kk = min(k, N4 - 2);
 #pragma unroll
     for (int q = 0; q < R; ++q) v[m][q] = V.ld2(kk * R + 2 * q);
   }
 }
-template <int R>
-__device__ __forceinline__ void slab_finish(const double *Ms, int N4, double2 (*v)[R], double *red, double *zs, int tid,
-                                            unsigned long long *tr = nullptr) {
-  constexpr int MAXM = SLAB_MAXM;
+// NC columns (4 per own pose), the first CL of them in LDS, the others -- where the slab of a 3-pose workgroup does not
+// fit LDS -- in the lane's own registers (sreg[column - CL][m]: the lane only ever meets ITS rows of a column, so what
+// does not fit LDS needs no sharing at all)
+template <int R, int NC = 8, int CL = 8, int MAXM = SLAB_MAXM>
+__device__ __forceinline__ void slab_finish(const double *Ms, const double2 (*sreg)[MAXM], int N4, double2 (*v)[R], double *red,
+                                            double *zs, int tid, unsigned long long *tr = nullptr) {
 #ifdef DPGO_RTR_TRACE
   if (tr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (tid == 0) { tr[0] = wall_clock64(); tr[3] = __builtin_amdgcn_s_memtime(); } }  // the vector has arrived
 #endif
-  double acc[8][R];
+  double acc[NC][R];
 #pragma unroll
-  for (int c = 0; c < 8; ++c)
+  for (int c = 0; c < NC; ++c)
 #pragma unroll
     for (int a = 0; a < R; ++a) acc[c][a] = 0.0;
 #pragma unroll
   for (int m = 0; m < MAXM; ++m) {
     const int k = 2 * tid + 512 * m, kk = min(k, N4 - 2);
     const double live = (k < N4) ? 1.0 : 0.0;
-    double2 mm[8];
+    double2 mm[NC];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) mm[c] = *reinterpret_cast<const double2 *>(&Ms[(size_t)c * N4 + kk]);
+    for (int c = 0; c < CL; ++c) mm[c] = *reinterpret_cast<const double2 *>(&Ms[(size_t)c * N4 + kk]);
+    if constexpr (NC > CL) {
+#pragma unroll
+      for (int c = CL; c < NC; ++c) mm[c] = sreg[c - CL][m];
+    }
     double w[2 * R];
 #pragma unroll
     for (int q = 0; q < R; ++q) { w[2 * q] = v[m][q].x * live; w[2 * q + 1] = v[m][q].y * live; }
-    // two fused multiply-adds per accumulator, 8R independent accumulators: `acc += w0 * m.x + w1 * m.y` compiles to
+    // two fused multiply-adds per accumulator, NC x R independent accumulators: `acc += w0 * m.x + w1 * m.y` compiles to
     // mul, fma, add through ONE temporary -- a dependent chain per accumulator that one wave per SIMD cannot hide
-    // (2.8 us of the 4.7 us this product took, profiles/r04_rtr_phases.md)
 #pragma unroll
-    for (int c = 0; c < 8; ++c)
+    for (int c = 0; c < NC; ++c)
 #pragma unroll
       for (int a = 0; a < R; ++a) acc[c][a] = __builtin_fma(w[a], mm[c].x, acc[c][a]);
 #pragma unroll
-    for (int c = 0; c < 8; ++c)
+    for (int c = 0; c < NC; ++c)
 #pragma unroll
       for (int a = 0; a < R; ++a) acc[c][a] = __builtin_fma(w[R + a], mm[c].y, acc[c][a]);
   }
 #ifdef DPGO_RTR_TRACE
   if (tr && tid == 0) { tr[1] = wall_clock64(); tr[4] = __builtin_amdgcn_s_memtime(); }  // products done
 #endif
-#if defined(DPGO_RTR_REPEAT) && defined(DPGO_RTR_REPEAT_PRODUCT_ONLY)
-  if (tr == reinterpret_cast<unsigned long long *>(1)) {  // (experiment: a repetition without the reduction)
-#pragma unroll
-    for (int c = 0; c < 8; ++c)
-#pragma unroll
-      for (int a = 0; a < R; ++a) asm volatile("" :: "v"(acc[c][a]));
-    return;
-  }
-#endif
-  reduce_8R<R, 4>(acc, red, zs, tid);
+  reduce_8R<R, 4, NC>(acc, red, zs, tid);
 #ifdef DPGO_RTR_TRACE
   if (tr && tid == 0) { tr[2] = wall_clock64(); tr[5] = __builtin_amdgcn_s_memtime(); }  // sums in zs
 #endif
@@ -553,7 +550,11 @@ __device__ __forceinline__ bool tl_product_lds(const double *Ms, const TLDev &tl
 
 // TL: the agent runs the two-level form of the preconditioner (slab layout and ownership of twolevel.h; up to two
 // workgroups per CU) instead of the dense inverse
-template <int R, bool TL>
+// NP: poses per workgroup of the dense solve.  2: 8 columns of M in LDS (agents of up to 512 poses).  3: 12 columns, 7 of
+// them in LDS and 5 in the lanes' registers -- a lane of the slab product only ever meets its own rows of a column, so
+// the part of the slab that LDS cannot hold needs no sharing (agents of 513 .. 640 poses: the torus3D GNC size; round 4.
+// Until then those agents ran the two-level form below: one more hand-off and 17 instead of 12 us per tCG iteration)
+template <int R, bool TL, int NP = 2>
 __global__ __launch_bounds__(TL ? TLS_NT : 256) void k_rtr_solve(const AgentDev *__restrict__ agents, int ai, unsigned long long *bar, double *ws,
                                                    unsigned long long *cum, RtrState *host_rec,
                                                    unsigned long long *host_cum, int *err, double Delta0, double tol, int max_outer, int max_inner,
@@ -561,31 +562,35 @@ __global__ __launch_bounds__(TL ? TLS_NT : 256) void k_rtr_solve(const AgentDev 
                                                    int restart_interval) {
   // (16-byte aligned: the static arrays in front of it end on an odd multiple of 8 bytes, and every 16-byte ds_read of a
   // slab that starts there is split by the hardware -- the slab product ran at a sixth of its speed until round 4)
-  extern __shared__ __attribute__((aligned(16))) double Ms[];  // [8][N4]: this workgroup's columns of M
-  __shared__ double red[(TL ? 32 : 64) * (8 * R + 1)];  // (the two-level solve runs 128 threads: 32 rows of partial sums)
-  // own two poses, [pose][component c][row a]: X, Euclidean / Riemannian gradient at X; tCG residual, z, delta, eta;
+  static_assert(NP == 2 || (NP == 3 && !TL), "two poses per workgroup, or three in the dense solve");
+  constexpr int NC = 4 * NP, NO = NC * R;                 // columns of M / outputs of a slab product
+  constexpr int MAXM = NP == 3 ? 5 : SLAB_MAXM;           // row pairs per lane: N4 <= 512 MAXM
+  constexpr int CL = NP == 3 ? 7 : NC, CR = NC - CL;      // columns in LDS / in registers
+  extern __shared__ __attribute__((aligned(16))) double Ms[];  // [CL][N4]: this workgroup's columns of M
+  __shared__ double red[(TL ? 2 : 4) * NO];  // one row of wave totals per wave (reduce_8R)
+  // own poses, [pose][component c][row a]: X, Euclidean / Riemannian gradient at X; tCG residual, z, delta, eta;
   // scratch; candidate point and its gradients
-  __shared__ double zs[8 * R], Xs[8 * R], Es[8 * R], Gs[8 * R], Rs[8 * R], Zo[8 * R], Ds[8 * R], Et[8 * R], Ws[8 * R],
-      X2s[8 * R], E2s[8 * R], G2s[8 * R];
-  __shared__ double BL[2 * RTR_SLOTS * 16];  // the first ELL slots of the own two poses: 4 x 4 blocks and indices
-  __shared__ int idxL[2 * RTR_SLOTS];
-  __shared__ double Hcs[2 * 9];  // curvature blocks of the own two poses at the current X
+  __shared__ double zs[NO], Xs[NO], Es[NO], Gs[NO], Rs[NO], Zo[NO], Ds[NO], Et[NO], Ws[NO], X2s[NO], E2s[NO], G2s[NO];
+  __shared__ double BL[NP * RTR_SLOTS * 16];  // the first ELL slots of the own poses: 4 x 4 blocks and indices
+  __shared__ int idxL[NP * RTR_SLOTS];
+  __shared__ double Hcs[NP * 9];  // curvature blocks of the own poses at the current X
   const AgentDev &ag = agents[ai];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bx = (int)blockIdx.x, N4 = ag.N4, n = ag.n;
-  const int nblk = TL ? ag.tl.nwg - ag.tl.nS2 : (n + 1) / 2;  // == gridDim.x
+  const int nblk = TL ? ag.tl.nwg - ag.tl.nS2 : (n + NP - 1) / NP;  // == gridDim.x
   // the two poses this workgroup owns: consecutive ones, or the pair the two-level layout assigns.  Two-level: the
   // solve's workgroups are the layout's producers (one separator pose each: here they also take that pose's column of
   // Sc^-1, which their slabs carry, TLDev::prod_post) and its interior workgroups; `tb` is the workgroup's index in the
   // layout's tables (the nS2 workgroups that own the separator columns in a stand-alone apply are skipped)
   TLWg tlw = {};
   const int tb = (TL && bx >= ag.tl.nA) ? bx + ag.tl.nS2 : bx;
-  int pj0 = 2 * bx, pj1 = (2 * bx + 1 < n) ? 2 * bx + 1 : -1;
+  int pj0 = NP * bx, pj1 = (NP * bx + 1 < n) ? NP * bx + 1 : -1;
+  const int pj2 = (NP == 3 && NP * bx + 2 < n) ? NP * bx + 2 : -1;
   if constexpr (TL) { tlw = ag.tl.wg[tb]; pj0 = tlw.own[0]; pj1 = tlw.own[1]; }
-  const int npose = (pj1 >= 0) ? 2 : 1;
+  const int npose = (pj2 >= 0) ? 3 : ((pj1 >= 0) ? 2 : 1);
   const int lp = tid / R, a = tid - lp * R;
   const bool rl = tid < npose * R;  // row lanes: one per (own pose, row of the lifted pose), all in wave 0
-  const int j = (lp == 1 && pj1 >= 0) ? pj1 : pj0;
+  const int j = (lp == 2 && pj2 >= 0) ? pj2 : ((lp == 1 && pj1 >= 0) ? pj1 : pj0);
   constexpr int CSUM_U = TL ? 8 : 4;
   double *wsA = ws, *wsB0 = ws + RTR_WS_PITCH, *wsB1 = ws + 2 * RTR_WS_PITCH, *wsC = ws + 3 * RTR_WS_PITCH;
 
@@ -608,7 +613,7 @@ __global__ __launch_bounds__(TL ? TLS_NT : 256) void k_rtr_solve(const AgentDev 
       *host_rec = T;
       for (int k = 0; k < 4; ++k) host_cum[k] = cum[k];
     }
-    if (tail) solve_tail<R>(agents, ag, team, tail, num_robots, restart_interval, bx, npose, tid, pj0, pj1);
+    if (tail) solve_tail<R>(agents, ag, team, tail, num_robots, restart_interval, bx, npose, tid, pj0, pj1, pj2);
     return;
   }
   __shared__ int bar_ok;
@@ -650,7 +655,7 @@ __global__ __launch_bounds__(TL ? TLS_NT : 256) void k_rtr_solve(const AgentDev 
       tln.voff[m] = (4 * rp[qq >> 1] + 2 * (qq & 1)) * R;
       tln.vlive[m] = q < npre ? 1.0 : 0.0;
     }
-  } else {
+  } else if constexpr (NP == 2) {
     // ... or 8 contiguous columns of the dense M
     const int tot2 = 2 * npose * N4;  // double2 elements of the valid columns
     const double *Msrc = ag.M + (size_t)8 * bx * N4;
@@ -666,6 +671,32 @@ __global__ __launch_bounds__(TL ? TLS_NT : 256) void k_rtr_solve(const AgentDev 
       if (i < 4 * N4) *reinterpret_cast<double2 *>(&Ms[2 * (size_t)i]) = (i < tot2) ? t[u] : make_double2(0.0, 0.0);
     }
   }
+  // ... or 12: the first CL columns into LDS (three passes of 12 x 16 bytes per lane), the lane's rows of the other CR
+  // into its registers for the whole solve
+  double2 sreg[CR > 0 ? CR : 1][MAXM];
+  if constexpr (NP == 3) {
+    const int valid2 = 2 * npose * N4;               // double2 elements of the columns that exist (the last workgroup)
+    const int tot2 = CL * (N4 / 2);                  // double2 elements of the LDS part
+    const double *Msrc = ag.M + (size_t)NC * bx * N4;
+    for (int base = 0; base < tot2; base += 256 * 12) {
+      double2 t[12];
+#pragma unroll
+      for (int u = 0; u < 12; ++u) t[u] = ld2_nt(Msrc + 2 * (size_t)min(base + tid + 256 * u, min(tot2, valid2) - 1));
+#pragma unroll
+      for (int u = 0; u < 12; ++u) {
+        const int i = base + tid + 256 * u;
+        if (i < tot2) *reinterpret_cast<double2 *>(&Ms[2 * (size_t)i]) = (i < valid2) ? t[u] : make_double2(0.0, 0.0);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < CR; ++u)
+#pragma unroll
+      for (int m = 0; m < MAXM; ++m) {
+        const int c = CL + u, cc = min(c, 4 * npose - 1), kk = min(2 * tid + 512 * m, N4 - 2);
+        const double2 t = ld2_nt(Msrc + (size_t)cc * N4 + kk);
+        sreg[u][m] = (c < 4 * npose) ? t : make_double2(0.0, 0.0);
+      }
+  }
   if (rl) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -678,11 +709,10 @@ __global__ __launch_bounds__(TL ? TLS_NT : 256) void k_rtr_solve(const AgentDev 
   }
   const int ellw = ag.ell_w, Wc = min(ellw, RTR_SLOTS);
   const int tp0 = rl ? ag.trowptr[j] : 0, tp1 = rl ? ag.trowptr[j + 1] : 0;
-  static_assert(2 * RTR_SLOTS * 16 == 256, "one thread per cached block element");
 #pragma unroll
-  for (int q = tid; q < 2 * RTR_SLOTS * 16; q += (TL ? TLS_NT : 256)) {
+  for (int q = tid; q < NP * RTR_SLOTS * 16; q += (TL ? TLS_NT : 256)) {
     const int pl = q / (RTR_SLOTS * 16), u = (q / 16) % RTR_SLOTS, e = q % 16;
-    const int jj = (pl == 1 && pj1 >= 0) ? pj1 : pj0;
+    const int jj = (pl == 2 && pj2 >= 0) ? pj2 : ((pl == 1 && pj1 >= 0) ? pj1 : pj0);
     const bool have = pl < npose && u < Wc;
     BL[q] = have ? ag.ell_val[((size_t)u * n + jj) * 16 + e] : 0.0;
     if (e == 0) idxL[pl * RTR_SLOTS + u] = have ? ag.ell_col[(size_t)u * n + jj] : jj;
@@ -721,9 +751,9 @@ __global__ __launch_bounds__(TL ? TLS_NT : 256) void k_rtr_solve(const AgentDev 
       if constexpr (TL) {
         if (!tl_product_lds<R>(Ms, ag.tl, tlw, tb, tln, cSrc, gb, red, zs, tid)) return;
       } else {
-        double2 vv[SLAB_MAXM][R];
-        slab_issue<R>(N4, cSrc, tid, vv);
-        slab_finish<R>(Ms, N4, vv, red, zs, tid);
+        double2 vv[MAXM][R];
+        slab_issue<R, MAXM>(N4, cSrc, tid, vv);
+        slab_finish<R, NC, CL, MAXM>(Ms, sreg, N4, vv, red, zs, tid);
       }
     }
     {
@@ -781,7 +811,7 @@ __global__ __launch_bounds__(TL ? TLS_NT : 256) void k_rtr_solve(const AgentDev 
       double sv[2][CSUM_U], sb[2];
       csum_issue<2, CSUM_U>(cWS, 1, nblk, lane, sv);
       double rawA[RTR_SLOTS][2][4];
-      if (wave == 0) gather_issue<2>(idxL + min(lp, 1) * RTR_SLOTS, ldA, rawA);
+      if (wave == 0) gather_issue<2>(idxL + min(lp, NP - 1) * RTR_SLOTS, ldA, rawA);
       csum_finish<2, CSUM_U>(sv, nblk, lane, sb);
       const double zr_new = sb[0], rr_new = sb[1];
       RTR_FINE(1);
@@ -818,7 +848,7 @@ __global__ __launch_bounds__(TL ? TLS_NT : 256) void k_rtr_solve(const AgentDev 
           }
         }
         RTR_FINE(2);
-        hess_tail_w<R>(Xs + lp * 4 * R, Hcs + min(lp, 1) * 9, Ws + lp * 4 * R, a, w[0], vrow, hrow, rl);
+        hess_tail_w<R>(Xs + lp * 4 * R, Hcs + min(lp, NP - 1) * 9, Ws + lp * 4 * R, a, w[0], vrow, hrow, rl);
         RTR_FINE(3);
         double d = 0;
         if (rl) {
@@ -849,8 +879,8 @@ __global__ __launch_bounds__(TL ? TLS_NT : 256) void k_rtr_solve(const AgentDev 
       //      z += alpha P(H delta M)
       double sv1[1][CSUM_U], d_Hd;
       csum_issue<1, CSUM_U>(cWS, 0, nblk, lane, sv1);
-      double2 vv[TL ? 1 : SLAB_MAXM][R];
-      if constexpr (!TL) slab_issue<R>(N4, cHD, tid, vv);  // (speculative: the boundary test below needs the sum)
+      double2 vv[TL ? 1 : MAXM][R];
+      if constexpr (!TL) slab_issue<R, MAXM>(N4, cHD, tid, vv);  // (speculative: the boundary test below needs the sum)
       csum_finish<1, CSUM_U>(sv1, nblk, lane, &d_Hd);
       RTR_FINE(10);
       const double alpha = S.z_r / d_Hd;
@@ -870,17 +900,9 @@ __global__ __launch_bounds__(TL ? TLS_NT : 256) void k_rtr_solve(const AgentDev 
         if (!tl_product_lds<R>(Ms, ag.tl, tlw, tb, tln, cHD, gb, red, zs, tid)) return;
       } else {
 #ifdef DPGO_RTR_TRACE
-        slab_finish<R>(Ms, N4, vv, red, zs, tid, (bx == 0 && fine_on) ? bar + RB_TRACE + 64 + 20 : nullptr);
+        slab_finish<R, NC, CL, MAXM>(Ms, sreg, N4, vv, red, zs, tid, (bx == 0 && fine_on) ? bar + RB_TRACE + 64 + 20 : nullptr);
 #else
-        slab_finish<R>(Ms, N4, vv, red, zs, tid);
-#ifdef DPGO_RTR_REPEAT  // (experiment: the in-situ cost of one product + reduction = the time added per repetition)
-#pragma unroll 1
-#ifdef DPGO_RTR_REPEAT_PRODUCT_ONLY
-        for (int rep = 1; rep < DPGO_RTR_REPEAT; ++rep) { asm volatile("" ::: "memory"); slab_finish<R>(Ms, N4, vv, red, zs, tid, reinterpret_cast<unsigned long long *>(1)); }
-#else
-        for (int rep = 1; rep < DPGO_RTR_REPEAT; ++rep) { __syncthreads(); slab_finish<R>(Ms, N4, vv, red, zs, tid); }
-#endif
-#endif
+        slab_finish<R, NC, CL, MAXM>(Ms, sreg, N4, vv, red, zs, tid);
 #endif
       }
       RTR_FINE(11);
@@ -994,7 +1016,7 @@ __global__ __launch_bounds__(TL ? TLS_NT : 256) void k_rtr_solve(const AgentDev 
         for (int c = 0; c < 4; ++c) vrow[c] = Et[lp * 4 * R + c * R + a];
       }
       WSYNC();
-      hess_tail_w<R>(Xs + lp * 4 * R, Hcs + min(lp, 1) * 9, Ws + lp * 4 * R, a, acc[1], vrow, hrow, rl);
+      hess_tail_w<R>(Xs + lp * 4 * R, Hcs + min(lp, NP - 1) * 9, Ws + lp * 4 * R, a, acc[1], vrow, hrow, rl);
       if (rl) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -1065,20 +1087,30 @@ __global__ __launch_bounds__(TL ? TLS_NT : 256) void k_rtr_solve(const AgentDev 
   if (tail) {
     // (the accepted point's own rows went to B_X with plain stores from this workgroup's row lanes)
     __syncthreads();
-    solve_tail<R>(agents, ag, team, tail, num_robots, restart_interval, bx, npose, tid, pj0, pj1);
+    solve_tail<R>(agents, ag, team, tail, num_robots, restart_interval, bx, npose, tid, pj0, pj1, pj2);
   }
 }
 
-static size_t rtr_static_lds(int r, bool tl = false) {
-  return sizeof(double) * ((size_t)(tl ? 32 : 64) * (8 * r + 1) + 12 * 8 * r + 2 * RTR_SLOTS * 16) + sizeof(int) * 2 * RTR_SLOTS + 256;
+static size_t rtr_static_lds(int r, bool tl = false, int np = 2) {
+  const size_t no = (size_t)4 * np * r;  // outputs of a slab product
+  return sizeof(double) * ((tl ? 2 : 4) * no + 12 * no + (size_t)np * RTR_SLOTS * 16 + (size_t)np * 9) + sizeof(int) * np * RTR_SLOTS + 256;
 }
 
-size_t rtr_fused_lds_bytes(int r, int n) { return (size_t)64 * 4 * n + rtr_static_lds(r); }
-
-bool rtr_fused_eligible(int r, int n, int num_cus) {
-  if (n < 1 || (n + 1) / 2 > num_cus || (n + 1) / 2 > 256 || 4 * n > 2048) return false;
-  return (size_t)64 * 4 * n + rtr_static_lds(r) <= (size_t)160 * 1024;
+// poses per workgroup of the dense one-launch solve: 2 (slab in LDS: up to 512 poses), 3 (7 of the 12 columns in LDS, 5 in
+// registers: up to 640 poses, r <= 5), 0: not eligible
+int rtr_fused_np(int r, int n, int num_cus) {
+  if (n < 1) return 0;
+  const int cus = std::min(num_cus, 256);
+  if ((n + 1) / 2 <= cus && 4 * n <= 2048 && (size_t)64 * 4 * n + rtr_static_lds(r, false, 2) <= (size_t)160 * 1024) return 2;
+  if (r <= 5 && (n + 2) / 3 <= cus && 4 * n <= 2560 && (size_t)7 * 32 * n + rtr_static_lds(r, false, 3) <= (size_t)160 * 1024) return 3;
+  return 0;
 }
+
+size_t rtr_fused_lds_bytes(int r, int n) {
+  return 4 * n <= 2048 ? (size_t)64 * 4 * n + rtr_static_lds(r, false, 2) : (size_t)7 * 32 * n + rtr_static_lds(r, false, 3);
+}
+
+bool rtr_fused_eligible(int r, int n, int num_cus) { return rtr_fused_np(r, n, num_cus) != 0; }
 
 // the same for an agent with the two-level preconditioner: nwg workgroups (separator / subdomain parts of the ownership
 // order, each padded to even), max_rows = the most rows (poses) any workgroup's slab meets before the exchange.  Two
@@ -1099,8 +1131,9 @@ bool rtr_fused_tl_eligible(int r, int nwg, int max_pre_poses, int ns, int num_cu
 
 int launch_rtr_solve(const LaunchCtx &c, int ai, int n, unsigned long long *bar, double *ws, unsigned long long *cum, RtrState *host_rec, unsigned long long *host_cum,
                      int *err, double Delta0, double tol, int max_outer, int max_inner, double max_radius, int tail,
-                     int num_robots, int restart_interval, int tl_nwg, size_t tl_dyn) {
-  const size_t dyn = tl_nwg > 0 ? tl_dyn : (size_t)64 * 4 * n;  // the two-level slab, or 8 columns x N4 doubles
+                     int num_robots, int restart_interval, int tl_nwg, size_t tl_dyn, int np) {
+  // the two-level slab, 8 columns x N4 doubles, or the 7 columns of a 3-pose workgroup that live in LDS
+  const size_t dyn = tl_nwg > 0 ? tl_dyn : (np == 3 ? (size_t)7 * 32 * n : (size_t)64 * 4 * n);
   hipError_t e = hipSuccess;
   DPGO_DISPATCH_R(c.r, {
     static bool configured = false;
@@ -1108,13 +1141,22 @@ int launch_rtr_solve(const LaunchCtx &c, int ai, int n, unsigned long long *bar,
       e = hipFuncSetAttribute((const void *)k_rtr_solve<R, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)rtr_static_lds(R));
       if (e == hipSuccess)
         e = hipFuncSetAttribute((const void *)k_rtr_solve<R, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)rtr_static_lds(R, true));
+      if constexpr (R <= 5) {
+        if (e == hipSuccess)
+          e = hipFuncSetAttribute((const void *)k_rtr_solve<R, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)rtr_static_lds(R, false, 3));
+      }
       configured = (e == hipSuccess);
     }
     if (e == hipSuccess) {
       if (tl_nwg > 0)
         hipLaunchKernelGGL((k_rtr_solve<R, true>), dim3(tl_nwg), dim3(TLS_NT), dyn, c.stream, c.agents, ai, bar, ws, cum, host_rec, host_cum, err,
                            Delta0, tol, max_outer, max_inner, max_radius, c.team, tail, num_robots, restart_interval);
-      else
+      else if (np == 3) {
+        if constexpr (R <= 5)
+          hipLaunchKernelGGL((k_rtr_solve<R, false, 3>), dim3((n + 2) / 3), dim3(256), dyn, c.stream, c.agents, ai, bar, ws, cum, host_rec, host_cum, err,
+                             Delta0, tol, max_outer, max_inner, max_radius, c.team, tail, num_robots, restart_interval);
+        else e = hipErrorInvalidValue;
+      } else
         hipLaunchKernelGGL((k_rtr_solve<R, false>), dim3((n + 1) / 2), dim3(256), dyn, c.stream, c.agents, ai, bar, ws, cum, host_rec, host_cum, err,
                            Delta0, tol, max_outer, max_inner, max_radius, c.team, tail, num_robots, restart_interval);
     }

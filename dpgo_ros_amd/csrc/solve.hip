@@ -189,7 +189,8 @@ int enqueue_optimize(dpgo_team *t, int sel, const OptFlags &fl) {
     if (launch_rtr_solve(c, sel, a.n, a.d_rtr_bar.p, a.d_rtr_ws.p, a.d_rtr_cum.p, a.h_rtr.p, a.h_rtr_cum.p, t->h_bar_err, p.rtr_initial_radius,
                          p.gradnorm_tol, p.rtr_iterations, p.rtr_tcg_iterations, p.rtr_max_radius, fl.rtr_tail, p.num_robots,
                          p.restart_interval, tl_fused ? a.tl_plan.nwg - a.tl_plan.nS2 : 0,
-                         tl_fused ? (size_t)128 * (2 * tl_max_pre_poses(a.tl_plan) + 2 * a.tl_plan.ns) : 0)) {
+                         tl_fused ? (size_t)128 * (2 * tl_max_pre_poses(a.tl_plan) + 2 * a.tl_plan.ns) : 0,
+                         tl_fused ? 2 : rtr_fused_np(p.r, a.n, t->num_cus))) {
       // (LDS attribute or launch refused on this device / partition mode: the launch-per-step sequence below serves)
       t->use_fused_rtr = 0;
       goto per_step;

@@ -157,6 +157,39 @@ def test_one_launch_solve_with_the_two_level_preconditioner(dataset, N, r, accel
     ts.close()
 
 
+@pytest.mark.parametrize("dataset,N,r,accel", [("torus3D", 8, 5, 1), ("sphere2500", 4, 3, 0), ("sphere2500", 4, 5, 1)])
+def test_one_launch_dense_solve_with_three_poses_per_workgroup(dataset, N, r, accel):
+    """agents of 513 .. 640 poses whose DENSE preconditioner is asked for (precond_mode 1) keep the solve in one launch:
+    three poses = 12 columns of M per workgroup, 7 of them in LDS and 5 in the lanes' own registers (rtr_fused.hip,
+    k_rtr_solve<R, false, 3>).  The oracle's counts and iterates, and the launch-per-step sequence's"""
+    iters = 2 * N
+    kw = dict(method=capi.METHOD_RTR, acceleration=accel, restart_interval=5, gradnorm_tol=1e-2, rtr_iterations=3,
+              rtr_tcg_iterations=12, precond_mode=capi.PRECOND_DENSE)
+    m, mp, n = load(dataset, N)
+    ph, po = params_pair(r=r, num_robots=N, **kw)
+    po.precond_mode = 0
+    T, Y = O.odometry_init(m, n), O.fixed_stiefel(r)
+    tf, ts = _team(mp, ph, True), _team(mp, ph, False)
+    to = O.Team(mp, n, po)
+    for t in (tf, ts, to):
+        t.set_initial(T, Y)
+    assert all(a.preconditioner() == capi.PRECOND_DENSE for a in tf.agents.values()) and 512 < n // N <= 640
+    tf.run(iters)
+    tf.synchronize()
+    ts.run(iters)
+    for _ in range(iters):
+        to.iterate()
+    assert _handoffs(tf, 0) > 0 and _handoffs(ts, 0) == 0
+    scale = max(1.0, np.abs(to.global_X()).max())
+    assert np.abs(tf.global_X() - ts.global_X()).max() < 1e-8 * scale
+    assert np.abs(tf.global_X() - to.global_X()).max() < 1e-7 * scale
+    for a in range(N):
+        rf, ro = tf.agents[a].opt_result(), to.agents[a].opt_result()
+        assert (rf.rtr_outer_iters, rf.tcg_iters_total, rf.accepted) == (ro.rtr_outer_iters, ro.tcg_iters_total, ro.accepted)
+    tf.close()
+    ts.close()
+
+
 def test_h_delta_ring_wraps_within_one_solve():
     """H delta of tCG iteration k sits in slot k mod 32 of a ring that is read with ordinary (cached) loads: launches of
     more than 32 tCG iterations reuse slots (one agent-scope acquire per wrap), and slots of agents whose vectors are not
