@@ -426,10 +426,10 @@ def gnc_leg(capi):
 
 # HBM traffic per launch (KB) from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in
 # separate runs of this command, profiles/collect.sh; FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md)
-PMC = {"source": "profiles/r03_pmc_fetch.md, profiles/r03_pmc_write.md",
-       "dense": {"step": (16560.5, 851.7), "apply": (16081.5, 85.9),       # k_precond<5,3,2048,false,true,true>, k_precond<5,0,2048,false,false,false>
-                 "fused_step": (18035.0, 860.6)},                           # k_step_fe<5,5>: + the sparse operator and X once per XCD L2
-       "two_level": {"step": (5476.2, 891.1), "apply": (4950.5, 125.3)}}   # k_precond<5,3,0,true,true,true>, k_precond<5,0,0,true,false,false>
+PMC = {"source": "profiles/r04_pmc_fetch.md, profiles/r04_pmc_write.md",
+       "dense": {"step": (16543.6, 851.7), "apply": (16067.4, 85.9),       # k_precond<5,3,2048,false,true,true>, k_precond<5,0,2048,false,false,false>
+                 "fused_step": (18013.5, 869.8)},                           # k_step_fe<5,5>: + the sparse operator and X once per XCD L2
+       "two_level": {"step": (5471.4, 891.0), "apply": (4935.8, 125.3)}}   # k_precond<5,3,0,true,true,true>, k_precond<5,0,0,true,false,false>
 
 
 def roofline_leg(team, agent_id, form="dense"):
