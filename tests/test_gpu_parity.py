@@ -769,11 +769,11 @@ def test_bench_configuration_against_the_live_oracle():
     th.close()
 
 
-@pytest.mark.parametrize("dataset", ["tunnels", "sphere2500"])
-def test_staged_shared_edge_evaluation_is_bitwise_the_plain_one(dataset, monkeypatch):
+@pytest.mark.parametrize("dataset,r", [("tunnels", 5), ("sphere2500", 5), ("tunnels", 3), ("sphere2500", 8)])
+def test_staged_shared_edge_evaluation_is_bitwise_the_plain_one(dataset, r, monkeypatch):
     """k_eval_staged (helper waves put the operands of a tile's shared edges into LDS, csrc/spmm.hip) forms G in
     g_row_range's order: lockstep ticks, RTR block updates and the cost are BITWISE those of the plain k_eval -- on tunnels
-    (up to 20 shared edges per pose: staged by default) and, forced, on sphere2500 / 5"""
+    (up to 20 shared edges per pose: staged by default) and, forced, on sphere2500 / 5; ranks 3, 5, 8"""
     from tests.util import load_tunnels
 
     def team(staged, **kw):
@@ -791,8 +791,8 @@ def test_staged_shared_edge_evaluation_is_bitwise_the_plain_one(dataset, monkeyp
         else:
             m, mp, n = load(dataset, 5)
             T, N = O.odometry_init(m, n), 5
-        t = capi.Team.from_measurements(mp.view(capi.MEAS_DTYPE), capi.default_params(r=5, num_robots=N, **kw))
-        t.set_initial(T, O.fixed_stiefel(5))
+        t = capi.Team.from_measurements(mp.view(capi.MEAS_DTYPE), capi.default_params(r=r, num_robots=N, **kw))
+        t.set_initial(T, O.fixed_stiefel(r))
         return t
 
     for kw, run in ((dict(method=1, rgd_stepsize=0.2, acceleration=0), lambda t: t.run_simultaneous(40)),
