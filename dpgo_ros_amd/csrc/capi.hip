@@ -125,8 +125,24 @@ static int check_exchange_error(dpgo_team_t *t) {
 
 int dpgo_team_num_local(const dpgo_team_t *t) { return (int)t->ag.size(); }
 void *dpgo_team_stream(dpgo_team_t *t) { return (void *)t->stream; }
+// hipStreamSynchronize parks the calling thread and pays its wake-up (tens of microseconds, more than a 20-iteration
+// graph's launch): the stream is polled first, for as long as a short run takes, and only a long wait blocks
+static hipError_t stream_wait(hipStream_t s) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const hipError_t e = hipStreamQuery(s);
+    if (e != hipErrorNotReady) return e;
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) return hipStreamSynchronize(s);
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#else
+    std::this_thread::yield();
+#endif
+  }
+}
+
 int dpgo_team_synchronize(dpgo_team_t *t) {
-  HIPC(hipStreamSynchronize(t->stream));
+  HIPC(stream_wait(t->stream));
   release_fused_rtr_lock(t);
   for (auto &a : t->ag) if (a->opt_pending_rtr && refresh_rtr_result(t, *a)) return DPGO_ERR;
   return check_exchange_error(t);
