@@ -114,7 +114,7 @@ void launch_bsr_to_dense(hipStream_t s, const int *rowptr, const int *col, const
 // rtr_fused.hip: one launch per local RTR solve, the agent's preconditioner resident in LDS over the whole solve.
 // bar: RTR_BAR_WORDS zero-initialised 64-bit words owned by the AGENT (the arrival counts depend on its grid);
 // ws: RTR_WS_DOUBLES doubles of partial-sum scratch + RTR_RING x (r x 4n) doubles of H delta ring; err: pinned host word raised on a spin time-out.
-constexpr int RTR_BAR_WORDS = 18 * 16 + 160;
+constexpr int RTR_BAR_WORDS = 37 * 16;  // (hand-off counters, trace stamps, the two-level exchange counters: rtr_fused.hip)
 constexpr int RTR_WS_DOUBLES = 7 * 512;
 __host__ __device__ inline size_t rtr_ring_pitch(size_t doubles) { return (doubles + 31) / 32 * 32; }  // whole 256-byte blocks
 constexpr int RTR_RING = 32;  // H delta buffers (r x 4n doubles each) behind the partial sums: one per tCG iteration, reused

@@ -79,9 +79,12 @@ constexpr int RB_TRACE = 17 * RB_LINE + 2;
 #define RTR_FINE(k) do { } while (0)
 #endif
 
+constexpr int RB_TLX = 28 * RB_LINE;        // two-level exchange: one arrival counter per XCD at RB_TLX + g * RB_LINE
+constexpr int RB_TLX_EPOCH = 36 * RB_LINE;  // exchanges completed so far (carried across launches)
 struct GridBar {
   unsigned long long *bar;
   unsigned long long epoch;
+  unsigned long long tlx_epoch;  // two-level solve: exchanges of u so far
   int g, size_g, ngroups, total;
   int *err;
   int *ok;  // LDS word: 0 once this workgroup's hand-off timed out
@@ -177,6 +180,36 @@ __device__ __forceinline__ bool grid_sync(GridBar &gb, unsigned long long *tr = 
   __syncthreads();
   return *gb.ok != 0;
 #endif
+}
+
+// The exchange inside a two-level apply is not a barrier: the nA producers publish u, everybody needs all of u, nobody
+// needs anything from the consumers.  Producers count themselves in on eight counters (one per XCD, fire and forget);
+// every workgroup polls its XCD's counter -- consumers arrive nowhere and wait for nobody but the producers (a full grid
+// hand-off here until round 4: an atomic round trip, the counter tree and the generation words for 400 workgroups).
+// u is rewritten by the next apply only behind at least one full hand-off of the solve, so no reader is overtaken.
+__device__ __forceinline__ bool tl_exchange(GridBar &gb, bool producer, int nA) {
+  gb.tlx_epoch += 1ull;
+  if (producer) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this workgroup's write-through stores of u have left the CU
+    __syncthreads();
+    if (threadIdx.x < 8)
+      (void)__hip_atomic_fetch_add(&gb.bar[RB_TLX + threadIdx.x * RB_LINE], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (threadIdx.x == 0) {
+    const unsigned long long target = (unsigned long long)nA * gb.tlx_epoch;
+    const long long t_start = (long long)wall_clock64();
+    while (__hip_atomic_load(&gb.bar[RB_TLX + gb.g * RB_LINE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if ((long long)wall_clock64() - t_start > RB_TIMEOUT_TICKS) {
+        *gb.err = 3;
+        *gb.ok = 0;
+        __hip_atomic_store(&gb.bar[RB_ABORT], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  return *gb.ok != 0;
 }
 
 // sum of `count` contiguous partials published by the workgroups of THIS launch, same order in every wave
@@ -523,7 +556,7 @@ __device__ __forceinline__ bool tl_product_lds(const double *Ms, const TLDev &tl
     }
     tl_zero<R>(acc);
   }
-  if (!grid_sync(gb)) return false;
+  if (!tl_exchange(gb, producer, tl.nA)) return false;
   const CVec cu(tl.u, 4 * tl.ns * R);
   const double *post = Ms + (size_t)npre * 16;
 #pragma unroll 1
@@ -623,6 +656,7 @@ __global__ __launch_bounds__(TL ? TLS_NT : 256) void k_rtr_solve(const AgentDev 
   GridBar gb;
   gb.bar = bar; gb.err = err; gb.ok = &bar_ok;
   gb.epoch = bar[RB_EPOCH];
+  gb.tlx_epoch = TL ? bar[RB_TLX_EPOCH] : 0ull;
   gb.g = bx & 7;
   gb.size_g = (nblk - gb.g + 7) / 8;
   gb.ngroups = min(8, nblk);
@@ -1077,6 +1111,7 @@ __global__ __launch_bounds__(TL ? TLS_NT : 256) void k_rtr_solve(const AgentDev 
     const RtrState T = to_record(S);
     ag.st[0] = T; ag.st[1] = T;
     bar[RB_EPOCH] = gb.epoch;
+    if constexpr (TL) bar[RB_TLX_EPOCH] = gb.tlx_epoch;
     // running totals of this agent's solves: the host reads them (and the record) whenever it next synchronises
     cum[0] += 1ull; cum[1] += (unsigned long long)S.hv_count; cum[2] += (unsigned long long)S.pc_count;
     cum[3] += (unsigned long long)S.outer_count;

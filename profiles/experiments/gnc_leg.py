@@ -24,4 +24,6 @@ for rep in range(2):
     total = time.perf_counter() - t0
     print("precond_mode %d (agents run form %d): total %.1f ms, UPDATE_WEIGHT %.2f ms per round, cost %.10f" % (
         mode, t.agents[0].preconditioner(), total * 1e3, upd / 3 * 1e3, t.cost()))
+    c = t.counters()
+    print("   preconditioner applies %.1f, sparse evaluations %.1f per iteration over %d iterations" % (c[0] / c[4], c[2] / c[4], int(c[4])))
     t.close()
