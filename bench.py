@@ -142,6 +142,9 @@ def single_gpu(args):
     # ---- convergence leg (untimed): iterations to (f_k - f*)/f* <= 1e-6
     conv = {}
     Tch = capi.chordal_init(m, n)  # GPU chordal relaxation of the whole graph
+    c0 = time.perf_counter()
+    Tch = capi.chordal_init(m, n)  # (timed on the second call: the first one loads the code objects)
+    conv["chordal_init_ms"] = (time.perf_counter() - c0) * 1e3
     # RGD legs: the gap is checked every 100 iterations until it is below 3e-6, then after every iteration
     for name, cfg, cap, T0, coarse in (("rgd_nesterov", RGD, 20000, T, 100), ("rgd_nesterov_chordal_init", RGD, 20000, Tch, 100),
                                        ("rtr_nesterov", RTR, 1500, T, 1), ("rtr_nesterov_chordal_init", RTR, 1500, Tch, 1)):
