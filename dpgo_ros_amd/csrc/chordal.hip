@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <vector>
@@ -96,22 +97,36 @@ struct DBuf {
   bool alloc(size_t bytes) { return hipMalloc(&p, std::max<size_t>(bytes, 8)) == hipSuccess; }
 };
 
-// solve  X A = B  for X (rr x N) with A given by merged triplets; returns X on the host
+
+// solve  X A = B  for X (rr x N) with A given by merged triplets; returns X on the host.
+// The right-hand sides ride in the factorisation as RR extra rows of the matrix (dense_spd_solve, augmented): with
+// A' = [A B^T; B C I] the last rows of the Cholesky factor are (L^-1 b_a)^T -- the forward substitution for free --, C only
+// has to keep A' positive definite (C > b_a^T A^-1 b_a) and touches nothing but the appended block itself.
 template <int RR>
-int dense_solve(hipStream_t s, const std::vector<Trip> &trips, int N, const std::vector<double> &B,
+int dense_solve(hipStream_t s, const std::vector<Trip> &trips_in, int N, const std::vector<double> &B,
                 std::vector<double> &X) {
+  static const bool aug = !(std::getenv("DPGO_CHORDAL_AUG") && std::getenv("DPGO_CHORDAL_AUG")[0] == '0');  // (0: forward substitution as launches)
+  const int Np = aug ? N + RR : N;
+  std::vector<Trip> trips = trips_in;
+  if (aug)
+  for (int k = 0; k < N; ++k)
+    for (int a = 0; a < RR; ++a) {
+      const double v = B[(size_t)k * RR + a];
+      if (v != 0.0) trips.push_back(Trip{N + a, k, v});  // (the factorisation reads the lower triangle only)
+    }
+  if (aug) for (int a = 0; a < RR; ++a) trips.push_back(Trip{N + a, N + a, 1e40});
+  // (keeping the N^2 buffer between calls was measured and is SLOWER: 26.5 against 23.3 ms per call on sphere2500)
   DBuf dT, dA, dB, dX;
-  const size_t NN = (size_t)N * N * sizeof(double);
-  if (!dT.alloc(sizeof(Trip) * trips.size()) || !dA.alloc(NN) || !dB.alloc(sizeof(double) * RR * N) ||
-      !dX.alloc(sizeof(double) * RR * N)) return -1;
+  const size_t NN = (size_t)Np * Np * sizeof(double);
+  if (!dT.alloc(sizeof(Trip) * trips.size()) || !dA.alloc(NN) || !dB.alloc(sizeof(double) * RR * Np) ||
+      !dX.alloc(sizeof(double) * RR * Np)) return -1;
   if (hipMemcpyAsync(dT.p, trips.data(), sizeof(Trip) * trips.size(), hipMemcpyHostToDevice, s) != hipSuccess) return -1;
-  if (hipMemcpyAsync(dB.p, B.data(), sizeof(double) * RR * N, hipMemcpyHostToDevice, s) != hipSuccess) return -1;
+  if (!aug && hipMemcpyAsync(dB.p, B.data(), sizeof(double) * RR * N, hipMemcpyHostToDevice, s) != hipSuccess) return -1;
   if (hipMemsetAsync(dA.p, 0, NN, s) != hipSuccess) return -1;
   hipLaunchKernelGGL(k_scatter, dim3(((int)trips.size() + 255) / 256), dim3(256), 0, s, (const Trip *)dT.p, (int)trips.size(),
-                     (double *)dA.p, N);
-  // the system is applied to its RR right-hand sides exactly once: Cholesky factor + two block substitutions, a third of
-  // the arithmetic of the inverse (and one N^2 buffer instead of three)
-  if (dense_spd_solve<RR>(s, (double *)dA.p, N, (double *)dB.p, (double *)dX.p) != 0) return -2;
+                     (double *)dA.p, Np);
+  // Cholesky factor + ONE block substitution (backward): a third of the arithmetic of the inverse, one N^2 buffer
+  if (dense_spd_solve<RR>(s, (double *)dA.p, Np, (double *)dB.p, (double *)dX.p, aug) != 0) return -2;
   X.resize((size_t)RR * N);
   if (hipMemcpyAsync(X.data(), dB.p, sizeof(double) * RR * N, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
   if (hipStreamSynchronize(s) != hipSuccess) return -1;

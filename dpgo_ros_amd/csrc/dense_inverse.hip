@@ -581,8 +581,21 @@ __global__ __launch_bounds__(256) void k_solve_bwd(const InvJob *jobs, int kb, d
   if (blockIdx.x == gridDim.x - 1 && tid < nb * RR) Xk[(size_t)k0 * RR + tid] = xs[tid / RR][tid % RR];
 }
 
+// y of an AUGMENTED system: the caller appended the RR right-hand sides to A as rows N - RR .. N - 1 (with a huge diagonal
+// behind them), so the factorisation's own panel solves and trailing updates have carried them along and row N - RR + a
+// of the factor is y_a = L^-1 b_a -- the forward substitution without its launches (314 of them, 2 ms, for the chordal
+// relaxation's 7500^2 system).  Rows of the appended block get y = 0: the backward substitution then leaves the first
+// N - RR unknowns as they should be.
 template <int RR>
-int dense_spd_solve(hipStream_t stream, double *A, int N, double *B, double *Y) {
+__global__ void k_aug_extract(const double *A, int N, double *Y) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= N) return;
+#pragma unroll
+  for (int a = 0; a < RR; ++a) Y[(size_t)k * RR + a] = (k < N - RR) ? A[(size_t)k * N + (N - RR) + a] : 0.0;
+}
+
+template <int RR>
+int dense_spd_solve(hipStream_t stream, double *A, int N, double *B, double *Y, bool augmented) {
   InvJob job;
   job.A = A; job.W = nullptr; job.M = nullptr; job.N = N; job.nblk = (N + NB - 1) / NB;
   double *Linv = nullptr;
@@ -609,9 +622,13 @@ int dense_spd_solve(hipStream_t stream, double *A, int N, double *B, double *Y) 
         hipLaunchKernelGGL(k_syrk_sb, dim3(nt, nt, 1), dim3(256), 0, stream, job_d, sb0, sb1 - sb0, s0, N, kb + 1, fail_d);
     }
   }
-  for (int kb = 0; kb < job.nblk; ++kb) {
-    const int below = N - std::min(N, (kb + 1) * NB);
-    hipLaunchKernelGGL(k_solve_fwd<RR>, dim3(std::max(1, (below + 255) / 256)), dim3(256), 0, stream, job_d, kb, B, Y);
+  if (augmented) {
+    hipLaunchKernelGGL(k_aug_extract<RR>, dim3((N + 255) / 256), dim3(256), 0, stream, A, N, Y);
+  } else {
+    for (int kb = 0; kb < job.nblk; ++kb) {
+      const int below = N - std::min(N, (kb + 1) * NB);
+      hipLaunchKernelGGL(k_solve_fwd<RR>, dim3(std::max(1, (below + 255) / 256)), dim3(256), 0, stream, job_d, kb, B, Y);
+    }
   }
   for (int kb = job.nblk - 1; kb >= 0; --kb)
     hipLaunchKernelGGL(k_solve_bwd<RR>, dim3(std::max(1, (kb * NB + 255) / 256)), dim3(256), 0, stream, job_d, kb, Y, B);
@@ -621,7 +638,7 @@ int dense_spd_solve(hipStream_t stream, double *A, int N, double *B, double *Y) 
   (void)hipFree(Linv); (void)hipFree(fail_d); (void)hipFree(job_d);
   return fail;
 }
-template int dense_spd_solve<3>(hipStream_t, double *, int, double *, double *);
+template int dense_spd_solve<3>(hipStream_t, double *, int, double *, double *, bool);
 
 int dense_spd_inverse(hipStream_t stream, double *A, double *work, double *M, int N) {
   return dense_spd_inverse_batched(stream, 1, &A, &work, &M, &N) & 0xffffff;

@@ -145,6 +145,7 @@ int dense_spd_inverse_batched(hipStream_t stream, int count, double *const *A, d
 // A X^T = B^T for RR right-hand sides from the Cholesky factor only (A destroyed; the solution overwrites B [N][RR];
 // Y [N][RR] is scratch).  Returns 0, or the (1-based) failing pivot.
 template <int RR>
-int dense_spd_solve(hipStream_t stream, double *A, int N, double *B, double *Y);
+// augmented: A is (N x N) with the RR right-hand sides appended as its last RR rows (N counts them), see k_aug_extract
+int dense_spd_solve(hipStream_t stream, double *A, int N, double *B, double *Y, bool augmented = false);
 
 }  // namespace dpgo
