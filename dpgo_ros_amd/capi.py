@@ -84,7 +84,10 @@ dpgo_error_threshold_at_quantile dpgo_team_set_schedule dpgo_team_set_initial dp
 dpgo_agent_pull_local dpgo_team_time_kernel dpgo_team_run dpgo_team_get_coloring dpgo_team_run_colored dpgo_team_set_groups dpgo_team_run_group dpgo_team_step_begin dpgo_team_step_end dpgo_team_iteration dpgo_team_cost dpgo_team_update_weights dpgo_team_get_counters
 dpgo_write_measurements_csv dpgo_write_g2o dpgo_write_trajectory_csv dpgo_robust_frame_alignment dpgo_robust_local_init dpgo_team_run_simultaneous
 dpgo_team_should_terminate dpgo_team_run_schedule dpgo_agent_compute_residuals dpgo_agent_set_measurement_weights
-dpgo_agent_reset_acceleration dpgo_team_prepare dpgo_agent_read_partials dpgo_agent_preconditioner dpgo_agent_preconditioner_info dpgo_agent_preconditioner_residual dpgo_two_level_plan dpgo_agent_export_state dpgo_team_import_peer dpgo_team_export_mailbox dpgo_team_import_mailbox dpgo_team_run_peer dpgo_agent_read_rtr_handoff""".split()
+dpgo_agent_reset_acceleration dpgo_team_prepare dpgo_agent_read_partials dpgo_agent_preconditioner dpgo_agent_preconditioner_info dpgo_agent_preconditioner_residual dpgo_two_level_plan dpgo_agent_export_state dpgo_team_import_peer dpgo_team_export_mailbox dpgo_team_import_mailbox dpgo_team_run_peer dpgo_agent_read_rtr_handoff
+dpgo_comm_unique_id dpgo_comm_create dpgo_comm_destroy dpgo_comm_rank dpgo_comm_world dpgo_comm_library
+dpgo_comm_allreduce_sum dpgo_comm_allreduce_max dpgo_team_attach_comm dpgo_team_detach_comm dpgo_team_exchange_all_ranks
+dpgo_team_run_ranks dpgo_comm_global_cost dpgo_team_comm_counters""".split()
 
 
 class DpgoError(RuntimeError):
@@ -102,6 +105,7 @@ def lib():
         L.dpgo_last_error.restype = C.c_char_p
         L.dpgo_team_create.restype = C.c_void_p
         L.dpgo_team_stream.restype = C.c_void_p
+        L.dpgo_comm_create.restype = C.c_void_p
         L.dpgo_agent_robust_weight.restype = C.c_double
         L.dpgo_error_threshold_at_quantile.restype = C.c_double
         _LIB = L
@@ -429,6 +433,53 @@ class Agent:
         return _chk(lib().dpgo_agent_unpack_neighbor_poses_device(self.t, self.id, nbr, int(aux), C.c_void_p(dev_ptr)), "unpack")
 
 
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """DPGO_COMM_ID_BYTES bytes that name a new RCCL communicator: obtained on ONE rank, handed to every rank (any channel)"""
+    b = (C.c_ubyte * COMM_ID_BYTES)()
+    _chk(lib().dpgo_comm_unique_id(b), "comm_unique_id")
+    return bytes(b)
+
+
+def comm_library():
+    """(path, version code) of the RCCL the library bound at run time"""
+    buf = C.create_string_buffer(512)
+    v = _chk(lib().dpgo_comm_library(buf, 512), "comm_library")
+    return buf.value.decode(), v
+
+
+class Comm:
+    """RCCL communicator owned by the library (csrc/rank_exchange.cpp): one per process, every rank takes part in its
+    creation -- also the ranks that own no robot."""
+
+    def __init__(self, unique_id, rank, world, device=0):
+        b = (C.c_ubyte * COMM_ID_BYTES).from_buffer_copy(unique_id)
+        h = lib().dpgo_comm_create(device, b, rank, world)
+        if not h:
+            raise DpgoError("dpgo_comm_create: " + lib().dpgo_last_error().decode())
+        self.h = C.c_void_p(h)
+        self.rank, self.world, self.device = rank, world, device
+
+    def allreduce(self, values, op="sum", stream=None):
+        v = np.ascontiguousarray(values, dtype=np.float64).copy()
+        fn = lib().dpgo_comm_allreduce_sum if op == "sum" else lib().dpgo_comm_allreduce_max
+        _chk(fn(self.h, C.c_void_p(stream) if stream else None, _d(v), len(v)), "comm_allreduce")
+        return v
+
+    def global_cost(self, team=None, stream=None):
+        f = C.c_double()
+        _chk(lib().dpgo_comm_global_cost(self.h, team.h if team is not None else None, C.c_void_p(stream) if stream else None,
+                                         C.byref(f)), "comm_global_cost")
+        return f.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().dpgo_comm_destroy(self.h)
+            self.h = None
+
+
 class Team:
     """The agents resident on one GPU.  With every agent of the problem local, `run` executes the
     synchronous RBCD schedule entirely on the device."""
@@ -523,6 +574,33 @@ class Team:
         synchronisation; remote neighbours are read in place and ordered by the device-side mailboxes"""
         ids = np.ascontiguousarray(sel_ids, dtype=np.int32)
         _chk(lib().dpgo_team_run_peer(self.h, _d(ids), len(ids)), "run_peer")
+
+    def attach_comm(self, comm, owner_of_robot, max_delayed_iterations=0, loopback=False):
+        """from here on run_ranks / exchange_all_ranks move the public poses between ranks with ncclSend / ncclRecv enqueued
+        by the library on the team stream (include/dpgo_hip.h); loopback (world size 1): every pair as a self-send"""
+        o = np.ascontiguousarray(owner_of_robot, dtype=np.int32)
+        assert len(o) == self.params.num_robots
+        _chk(lib().dpgo_team_attach_comm(self.h, comm.h, _d(o), int(max_delayed_iterations), int(bool(loopback))), "attach_comm")
+        self._comm = comm  # (keeps the communicator alive as long as the team uses it)
+
+    def detach_comm(self):
+        _chk(lib().dpgo_team_detach_comm(self.h), "detach_comm")
+        self._comm = None
+
+    def exchange_all_ranks(self):
+        _chk(lib().dpgo_team_exchange_all_ranks(self.h), "exchange_all_ranks")
+
+    def run_ranks(self, sel_ids):
+        """len(sel_ids) global iterations with robot sel_ids[q] holding the token in the q-th; the exchange is RCCL
+        point-to-point inside the library, nothing synchronises with the host"""
+        ids = np.ascontiguousarray(sel_ids, dtype=np.int32)
+        _chk(lib().dpgo_team_run_ranks(self.h, _d(ids), len(ids)), "run_ranks")
+
+    def comm_counters(self):
+        """messages sent / received by this rank and their bytes"""
+        out = np.zeros(4)
+        _chk(lib().dpgo_team_comm_counters(self.h, _d(out)), "comm_counters")
+        return dict(messages_sent=int(out[0]), messages_received=int(out[1]), bytes_sent=out[2], bytes_received=out[3])
 
     def should_terminate(self):
         """PGOAgent::shouldTerminate() as the leader evaluates it (src/PGOAgentROS.cpp:208)"""

@@ -551,7 +551,7 @@ int sync_descs_noflush(dpgo_team *t) {
         for (auto &a : t->ag) { mp = std::max(mp, a->max_pose_edges); mt = std::max(mt, a->max_tile_edges); }
         const char *env = std::getenv("DPGO_STAGED_EVAL");  // (read when the structure is built: a per-team choice in the tests)
         const int min_edges = env ? std::atoi(env) : 5;  // DPGO_STAGED_EVAL=0: always, =1000000: never
-        t->stage_cap = (mp >= min_edges && mt > 0 && eval_staged_lds_bytes(t->prm.r, mt) <= (size_t)140 * 1024) ? mt : 0;
+        t->stage_cap = (mp >= min_edges && mt > 0 && eval_staged_lds_bytes(t->prm.r, mt) + EVS_STATIC_LDS <= (size_t)t->max_lds) ? mt : 0;
       }
       t->precond_of.clear();
       for (auto &a : t->ag) t->precond_of.push_back(a->precond);
@@ -571,7 +571,7 @@ int sync_descs_noflush(dpgo_team *t) {
     for (auto &d : a->se_host) {
       d.src[0] = d.src[1] = nullptr;
       d.src_yalt = nullptr;
-      if (d.src_agent_local < 0) {
+      if (d.src_agent_local < 0 || t->isolated) {  // (isolated: co-resident neighbours are served by messages as well)
         // a neighbour in another process whose X / Y arrays were imported: read it in place, like a co-resident one
         auto pit = t->peers.find(d.src_robot);
         if (pit != t->peers.end() && d.src_frame >= 0 && d.src_frame < pit->second.n) {

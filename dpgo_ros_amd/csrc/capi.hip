@@ -389,9 +389,10 @@ static int report_after_iterate(dpgo_team_t *t, Agent *a, bool did_opt, bool adv
   // diagnostics (dpgo_team_get_counters [5..6]): host time between the launch of a report and its arrival (us), reports
   t->counters[5] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tq0).count();
   t->counters[6] += 1;
-  if (check_exchange_error(t)) return DPGO_ERR;
   for (auto &b : t->ag) b->up_pending = false;  // this team's stream has drained past every upload enqueued before
-  release_fused_rtr_lock(t);                    // ... and past any one-launch solve
+  release_fused_rtr_lock(t);                    // ... and past any one-launch solve (also when it timed out: the device lock
+                                                // must not stay with a team that is about to report an error)
+  if (check_exchange_error(t)) return DPGO_ERR;
   if (a->opt_pending_rtr && refresh_rtr_result(t, *a, true)) return DPGO_ERR;  // (its record is in pinned memory already)
   const double *out = a->h_down.p, *pub = out + 8;
   if (npub) {
@@ -966,7 +967,7 @@ int dpgo_team_exchange_all(dpgo_team_t *t) {
   for (auto &a : t->ag) {
     launch_pull(c, a->local, (int)a->shared.size());
     for (size_t q = 0; q < a->np.size(); ++q)
-      if (t->id2local.count(a->np[q].first)) { a->np_has[0][q] = 1; a->np_has[1][q] = 1; }
+      if (t->id2local.count(a->np[q].first) && !t->isolated) { a->np_has[0][q] = 1; a->np_has[1][q] = 1; }
   }
   HIPC(hipStreamSynchronize(t->stream));
   return 0;
@@ -1003,7 +1004,7 @@ static bool fused_eval_eligible(dpgo_team_t *t) {
   const int P = (int)t->sched.size();
   if (!(t->use_fused_eval && t->bake_sel && t->bake_desc && P >= 1 && P <= 8 && step_fe_supported(p.r) && p.acceleration &&
         p.method == DPGO_METHOD_RGD && p.rgd_use_preconditioner && (int)t->ag.size() <= LOOKAHEAD_MAX_AGENTS &&
-        t->h_descs.size() == t->ag.size() && t->precond_of.size() == t->ag.size() && t->peers.empty() &&
+        t->h_descs.size() == t->ag.size() && t->precond_of.size() == t->ag.size() && t->peers.empty() && !t->isolated &&
         (int)t->ag.size() == p.num_robots))
     return false;
   for (size_t k = 0; k < t->ag.size(); ++k) {
@@ -1706,7 +1707,7 @@ int dpgo_agent_pull_local(dpgo_team_t *t, int id) {
   if (sync_descs(t)) return DPGO_ERR;
   launch_pull(t->ctx(), a->local, (int)a->shared.size());
   for (size_t q = 0; q < a->np.size(); ++q)
-    if (t->id2local.count(a->np[q].first)) { a->np_has[0][q] = 1; a->np_has[1][q] = 1; }
+    if (t->id2local.count(a->np[q].first) && !t->isolated) { a->np_has[0][q] = 1; a->np_has[1][q] = 1; }
   return 0;
 }
 

@@ -248,18 +248,21 @@ __device__ __forceinline__ void eval_body(const AgentDev *__restrict__ agents, c
   const bool act = lp < PPB && j < ag.n;
   const double *X = ag.buf[xb];
   double fpart = 0, gpart = 0, eg3 = 0;
+  int e0 = 0, e1 = 0;
+  double acc[1][4] = {{0, 0, 0, 0}};
   if (act) {
     // shared edges of this pose, requested in front of the SpMM so that the two chains of dependent round trips
     // (index -> X gather, edge range -> edge -> neighbour pose) run side by side
-    const int e0 = ag.pose_eptr[j], e1 = ag.pose_eptr[j + 1];
-    double acc[1][4] = {{0, 0, 0, 0}};
+    e0 = ag.pose_eptr[j]; e1 = ag.pose_eptr[j + 1];
     spmm_row<R, 1>(ag, j, [&](int i, double(*x)[4]) {
 #pragma unroll
       for (int cp = 0; cp < 4; ++cp) x[0][cp] = X[((size_t)4 * i + cp) * R + a];
     }, acc);
-    // (k_eval_staged: the helper waves have put the operands of the tile's shared edges into LDS meanwhile.  This wave is
-    // the only one of the workgroup in here and lane 0 is always active: the barrier executes once per wave)
-    if (Eop) __syncthreads();
+  }
+  // (k_eval_staged: the helper waves have put the operands of the tile's shared edges into LDS meanwhile.  The barrier
+  // sits in uniform control flow: every wave of the workgroup -- this one and the helpers -- reaches it exactly once)
+  if (Eop) __syncthreads();
+  if (act) {
     double g[4] = {0, 0, 0, 0};
     double *Gj = ag.buf[B_G] + (size_t)j * 4 * R;
     if (e1 > e0) {

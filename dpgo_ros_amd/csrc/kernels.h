@@ -22,6 +22,7 @@ struct LaunchCtx {
   const int *up_slots = nullptr;
   const double *up_in = nullptr;
   int up_n0 = 0, up_n1 = 0;
+  int max_lds = 160 * 1024;        // hipDeviceAttributeMaxSharedMemoryPerBlock of the team's device
   int stage_cap = 0;               // > 0: evaluations that assemble G stage the shared edges' operands through LDS
                                    // (k_eval_staged); the most shared edges any tile of any agent of the team carries
   const NestState *nest_all = nullptr;  // the team's NestStates, [local agent]: lets a kernel read an agent's Nesterov
@@ -43,6 +44,7 @@ void launch_buildG(const LaunchCtx &c, int sel, int max_npub, int aux, int pull)
 void launch_pull(const LaunchCtx &c, int dst, int nshared);
 void launch_eval(const LaunchCtx &c, int sel, int max_n, int xb, int egb, int gfb, int poff, const EvalOpts &o);
 size_t eval_staged_lds_bytes(int r, int cap);
+constexpr int EVS_STATIC_LDS = 8 * 1024;  // room left for k_eval_staged's static arrays under the device's LDS limit
 void launch_hess(const LaunchCtx &c, int sel, int max_n, int xb, int egb, int vb, int ob, int poff);
 void launch_precond(const LaunchCtx &c, int sel, int max_n, int mode, int xb, int vb, int zb, int sp, int max_inner,
                     double step, int accel, int num_robots, int advance = 0, int restart_interval = 1, int ahead = 0);
@@ -87,6 +89,18 @@ void launch_rtr_accept(const LaunchCtx &c, int sel, int max_n, int sp, double to
 void launch_pack(const LaunchCtx &c, const double *X, const int *frames, int count, double *out);
 void launch_pack2(const LaunchCtx &c, const double *X, const double *Y, const int *frames, int count, double *out);
 void launch_unpack(const LaunchCtx &c, double *slab, const int *slots, int count, const double *in);
+// several pack / unpack jobs in ONE launch (grid.y = job): the slabs of one batch of rank-to-rank messages
+// (rank_exchange.cpp).  pack: buf[j] <- src[j] poses idx[j][0 .. count[j]); unpack: src[j] slots idx[j][...] <- buf[j]
+constexpr int XFER_MAX_SEGS = 16;
+struct XferSegs {
+  double *src[XFER_MAX_SEGS];
+  const int *idx[XFER_MAX_SEGS];
+  double *buf[XFER_MAX_SEGS];
+  int count[XFER_MAX_SEGS];
+  int n;
+};
+void launch_pack_multi(const LaunchCtx &c, const XferSegs &sg);
+void launch_unpack_multi(const LaunchCtx &c, const XferSegs &sg);
 // the host boundary of the per-agent API: staged neighbour poses read straight from pinned host memory; public poses,
 // status / result sums and a sequence word written straight into it (see pose_ops.hip)
 void launch_upload2(const LaunchCtx &c, double *slab0, double *slab1, const int *host_slots, const double *host_in, int n0, int n1);

@@ -14,6 +14,9 @@
 
 namespace dpgo {
 
+// the trial costs of one tile occupy one block of partials (PART_A[tile][0 .. J)), the slope PART_C[tile][2]
+static_assert(LS_MAX_TRIALS <= PART_STRIDE, "a tile's trial costs must fit one block of partial sums");
+
 // trial points live in work vectors that only the trust-region solve uses
 __host__ __device__ __forceinline__ int ls_buf(int j) {
   switch (j) {

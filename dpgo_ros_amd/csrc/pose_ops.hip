@@ -287,6 +287,18 @@ __global__ void k_unpack(double *slab, const int *slots, int count, const double
   slab[(size_t)slots[q] * 4 * R + k] = in[t];
 }
 
+// the slabs of one batch of rank-to-rank messages (rank_exchange.cpp): job blockIdx.y packs (UNPACK: scatters) count[j]
+// poses between a pose array / neighbour slab and its place in the staging buffer of the message
+template <int R, bool UNPACK>
+__global__ void k_xfer_multi(XferSegs sg) {
+  const int j = blockIdx.y;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= sg.count[j] * 4 * R) return;
+  const int q = t / (4 * R), k = t - q * 4 * R;
+  if (UNPACK) sg.src[j][(size_t)sg.idx[j][q] * 4 * R + k] = sg.buf[j][t];
+  else sg.buf[j][t] = sg.src[j][(size_t)sg.idx[j][q] * 4 * R + k];
+}
+
 // ---- the host boundary of the per-agent API (the path a ROS wrapper drives), without copy engines or stream-wide waits:
 // neighbour poses staged by updateNeighborPoses are scattered into the slabs straight FROM pinned host memory
 // (slots / in: host pointers; counts[2]: poses of the main / auxiliary sequence, in that order)
@@ -549,6 +561,24 @@ void launch_unpack(const LaunchCtx &c, double *slab, const int *slots, int count
   const int len = count * 4 * c.r;
   DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_unpack<R>, dim3((len + 255) / 256), dim3(256), 0, c.stream, slab, slots,
                                           count, in));
+}
+
+static int xfer_max_len(const XferSegs &sg, int r) {
+  int m = 0;
+  for (int j = 0; j < sg.n; ++j) m = std::max(m, sg.count[j] * 4 * r);
+  return m;
+}
+
+void launch_pack_multi(const LaunchCtx &c, const XferSegs &sg) {
+  const int len = xfer_max_len(sg, c.r);
+  if (sg.n <= 0 || len <= 0) return;
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL((k_xfer_multi<R, false>), dim3((len + 255) / 256, sg.n), dim3(256), 0, c.stream, sg));
+}
+
+void launch_unpack_multi(const LaunchCtx &c, const XferSegs &sg) {
+  const int len = xfer_max_len(sg, c.r);
+  if (sg.n <= 0 || len <= 0) return;
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL((k_xfer_multi<R, true>), dim3((len + 255) / 256, sg.n), dim3(256), 0, c.stream, sg));
 }
 
 void launch_upload2(const LaunchCtx &c, double *slab0, double *slab1, const int *host_slots, const double *host_in, int n0, int n1) {

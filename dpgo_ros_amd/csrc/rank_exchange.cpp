@@ -1,0 +1,411 @@
+// rank_exchange.cpp -- the public-pose exchange between processes, one process per GPU, carried by RCCL point-to-point
+// operations that THIS LIBRARY enqueues on the team stream (no host language in the loop).
+//
+// Replaces, for one-process-per-GPU runs, the ROS transport of the reference for this path:
+//   * `PublicPoses` messages -- sent by publishPublicPoses (src/PGOAgentROS.cpp:662-690), received by
+//     publicPosesCallback (:1255-1284) -- become packed r x 4 fp64 slabs (the layout of dpgo_agent_pack_public_poses_device)
+//     moved with ncclSend / ncclRecv, one message per pair of ranks and direction;
+//   * the staleness gate of :136-149 (maxDelayedIterations, include/dpgo_ros/PGOAgentROS.h:83) decides which slabs are
+//     SENT: on this lossless transport a neighbour's copy is re-sent only when it is more than max_delayed_iterations
+//     behind the neighbour's latest change;
+//   * the UPDATE token (:443-504, 1161-1189) needs no message: every rank is handed the same list of token holders.
+// dpgo_team_run_ranks enqueues K whole iterations per host call: [iterate(false) part of every local robot] -> [pack,
+// grouped ncclSend / ncclRecv, unpack] -> [block update of the token holder], all on the team stream.
+//
+// RCCL is bound at run time (dlopen of librccl.so.1): a process that has already loaded RCCL -- torch.distributed's copy
+// carries the same soname -- shares that copy, single-GPU users of libdpgo_hip.so never map it, and the library has no
+// link-time dependency on it.  Declarations come from <rccl/rccl.h>; no function of it is linked.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <tuple>
+
+#include "team_internal.h"
+
+using namespace dpgo_host;
+
+namespace {
+
+struct RcclApi {
+  void *handle = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclGetVersion) GetVersion = nullptr;
+  std::string path;
+};
+
+RcclApi *rccl() {
+  static RcclApi api;
+  static bool tried = false;
+  if (tried) return api.handle ? &api : nullptr;
+  tried = true;
+  const char *names[] = {std::getenv("DPGO_RCCL_LIBRARY"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (const char *nm : names) {
+    if (!nm || !*nm) continue;
+    api.handle = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+    if (api.handle) { api.path = nm; break; }
+  }
+  if (!api.handle) { set_err(std::string("RCCL is not loadable: ") + (dlerror() ? dlerror() : "librccl.so.1 not found")); return nullptr; }
+  bool ok = true;
+  auto sym = [&](const char *nm) { void *p = dlsym(api.handle, nm); if (!p) ok = false; return p; };
+  api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
+  api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
+  api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+  api.Send = (decltype(api.Send))sym("ncclSend");
+  api.Recv = (decltype(api.Recv))sym("ncclRecv");
+  api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
+  api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
+  api.AllReduce = (decltype(api.AllReduce))sym("ncclAllReduce");
+  api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+  api.GetVersion = (decltype(api.GetVersion))sym("ncclGetVersion");
+  if (!ok) { set_err("RCCL library lacks an expected entry point"); dlclose(api.handle); api.handle = nullptr; return nullptr; }
+  return &api;
+}
+
+}  // namespace
+
+struct dpgo_comm {
+  ncclComm_t comm = nullptr;
+  int device = 0, rank = 0, world = 1;
+  double *d_red = nullptr;  // scratch of the small reductions
+};
+
+#define NCCLC(expr)                                                                                          \
+  do {                                                                                                       \
+    ncclResult_t r_ = (expr);                                                                                \
+    if (r_ != ncclSuccess) {                                                                                 \
+      set_err(std::string(#expr) + ": " + api->GetErrorString(r_) + " @" + std::to_string(__LINE__));        \
+      return DPGO_ERR;                                                                                       \
+    }                                                                                                        \
+  } while (0)
+
+extern "C" {
+
+int dpgo_comm_unique_id(unsigned char *id128) {
+  RcclApi *api = rccl();
+  if (!api) return DPGO_ERR;
+  static_assert(sizeof(ncclUniqueId) == DPGO_COMM_ID_BYTES, "ncclUniqueId size");
+  ncclUniqueId id;
+  NCCLC(api->GetUniqueId(&id));
+  std::memcpy(id128, &id, sizeof id);
+  return DPGO_OK;
+}
+
+dpgo_comm_t *dpgo_comm_create(int device, const unsigned char *id128, int rank, int world) {
+  RcclApi *api = rccl();
+  if (!api) return nullptr;
+  if (world < 1 || rank < 0 || rank >= world) { set_err("comm_create: bad rank / world size"); return nullptr; }
+  if (hipSetDevice(device) != hipSuccess) { set_err("comm_create: no HIP device " + std::to_string(device)); return nullptr; }
+  auto *c = new dpgo_comm();
+  c->device = device; c->rank = rank; c->world = world;
+  ncclUniqueId id;
+  std::memcpy(&id, id128, sizeof id);
+  const ncclResult_t r = api->CommInitRank(&c->comm, world, id, rank);
+  if (r != ncclSuccess) { set_err(std::string("ncclCommInitRank: ") + api->GetErrorString(r)); delete c; return nullptr; }
+  if (hipMalloc((void **)&c->d_red, sizeof(double) * 64) != hipSuccess) { set_err("comm_create: allocation failed"); (void)api->CommDestroy(c->comm); delete c; return nullptr; }
+  return c;
+}
+
+void dpgo_comm_destroy(dpgo_comm_t *c) {
+  if (!c) return;
+  RcclApi *api = rccl();
+  if (c->d_red) (void)hipFree(c->d_red);
+  if (api && c->comm) (void)api->CommDestroy(c->comm);
+  delete c;
+}
+
+int dpgo_comm_rank(const dpgo_comm_t *c) { return c ? c->rank : -1; }
+int dpgo_comm_world(const dpgo_comm_t *c) { return c ? c->world : -1; }
+
+int dpgo_comm_library(char *out, int cap) {
+  RcclApi *api = rccl();
+  if (!api) return DPGO_ERR;
+  int v = 0;
+  (void)api->GetVersion(&v);
+  std::snprintf(out, cap, "%s (version code %d)", api->path.c_str(), v);
+  return v;
+}
+
+int dpgo_comm_allreduce_sum(dpgo_comm_t *c, void *stream, double *inout, int n) {
+  RcclApi *api = rccl();
+  if (!api || !c) return DPGO_ERR;
+  if (n < 0 || n > 64) { set_err("allreduce_sum: at most 64 doubles"); return DPGO_ERR; }
+  hipStream_t s = (hipStream_t)stream;
+  HIPC(hipMemcpyAsync(c->d_red, inout, sizeof(double) * n, hipMemcpyHostToDevice, s));
+  NCCLC(api->AllReduce(c->d_red, c->d_red, (size_t)n, ncclDouble, ncclSum, c->comm, s));
+  HIPC(hipMemcpyAsync(inout, c->d_red, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+  HIPC(hipStreamSynchronize(s));
+  return DPGO_OK;
+}
+
+int dpgo_comm_allreduce_max(dpgo_comm_t *c, void *stream, double *inout, int n) {
+  RcclApi *api = rccl();
+  if (!api || !c) return DPGO_ERR;
+  if (n < 0 || n > 64) { set_err("allreduce_max: at most 64 doubles"); return DPGO_ERR; }
+  hipStream_t s = (hipStream_t)stream;
+  HIPC(hipMemcpyAsync(c->d_red, inout, sizeof(double) * n, hipMemcpyHostToDevice, s));
+  NCCLC(api->AllReduce(c->d_red, c->d_red, (size_t)n, ncclDouble, ncclMax, c->comm, s));
+  HIPC(hipMemcpyAsync(inout, c->d_red, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+  HIPC(hipStreamSynchronize(s));
+  return DPGO_OK;
+}
+
+int dpgo_team_attach_comm(dpgo_team_t *t, dpgo_comm_t *c, const int *owner_rank_of_robot, int max_delayed_iterations, int loopback) {
+  if (!t || !c || !owner_rank_of_robot) { set_err("attach_comm: bad arguments"); return DPGO_ERR; }
+  if (c->device != t->device) { set_err("attach_comm: the communicator lives on another device"); return DPGO_ERR; }
+  auto &x = t->rx;
+  const int NR = t->prm.num_robots;
+  x.owner.assign(owner_rank_of_robot, owner_rank_of_robot + NR);
+  for (int a = 0; a < NR; ++a)
+    if (x.owner[a] < 0 || x.owner[a] >= c->world) { set_err("attach_comm: owner rank out of range"); return DPGO_ERR; }
+  for (auto &a : t->ag)
+    if (x.owner[a->id] != c->rank) { set_err("attach_comm: robot " + std::to_string(a->id) + " lives in this team but is owned by rank " + std::to_string(x.owner[a->id])); return DPGO_ERR; }
+  if (loopback && c->world != 1) { set_err("attach_comm: loopback needs world size 1"); return DPGO_ERR; }
+  x.comm = c;
+  x.max_delay = std::max(0, max_delayed_iterations);
+  x.loopback = loopback != 0;
+  x.version.assign(NR, 0);
+  x.sent.clear();
+  // loopback: every neighbour is treated as living in another process -- no pose is read in place, each one crosses
+  // RCCL as a self-send -- so that the message path is exercised end to end on a one-GPU box
+  if (t->isolated != x.loopback) { t->isolated = x.loopback; t->descs_dirty = true; t->graph_valid = false; }
+  if (x.loopback)
+    for (auto &a : t->ag) { std::fill(a->np_has[0].begin(), a->np_has[0].end(), 0); std::fill(a->np_has[1].begin(), a->np_has[1].end(), 0); }
+  return DPGO_OK;
+}
+
+int dpgo_team_detach_comm(dpgo_team_t *t) {
+  if (!t) return DPGO_ERR;
+  if (t->stream) (void)hipStreamSynchronize(t->stream);
+  if (t->isolated) { t->isolated = false; t->descs_dirty = true; t->graph_valid = false; }
+  t->rx = dpgo_team::RankExchange{};
+  return DPGO_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+struct Pair { int b, a; unsigned seqs; };  // public poses of robot b (sequences: bit 0 X, bit 1 Y) -> robot a
+
+inline bool crosses(const dpgo_team_t *t, int b, int a) { return t->rx.loopback || t->rx.owner[b] != t->rx.owner[a]; }
+
+// One batch: every listed slab crosses in ONE group of point-to-point operations, one message per peer rank and direction;
+// inside a message the slabs are ordered by (receiving robot, sending robot, sequence), which both ends derive alike.
+int exchange_pairs(dpgo_team_t *t, std::vector<Pair> pairs) {
+  RcclApi *api = rccl();
+  if (!api) return DPGO_ERR;
+  auto &x = t->rx;
+  if (pairs.empty()) return 0;
+  std::sort(pairs.begin(), pairs.end(), [](const Pair &p, const Pair &q) { return std::tie(p.a, p.b) < std::tie(q.a, q.b); });
+  const size_t B = (size_t)4 * t->prm.r;
+  const int me = x.comm->rank;
+  struct Msg { size_t off = 0, len = 0; };
+  std::map<int, Msg> out, in;  // by peer rank
+  // sizes first (the staging buffers may have to grow before any kernel is given a pointer into them)
+  for (const Pair &p : pairs) {
+    const int nq = (p.seqs & 1) + ((p.seqs >> 1) & 1);
+    if (Agent *sb = t->id2local.count(p.b) ? t->ag[t->id2local[p.b]].get() : nullptr) {
+      auto it = sb->n_pubframes.find(p.a);
+      if (it != sb->n_pubframes.end()) out[x.owner[p.a]].len += (size_t)nq * it->second * B;
+    }
+    if (Agent *ra = t->id2local.count(p.a) ? t->ag[t->id2local[p.a]].get() : nullptr) {
+      auto it = ra->n_nbrslots.find(p.b);
+      if (it != ra->n_nbrslots.end()) in[x.owner[p.b]].len += (size_t)nq * it->second * B;
+    }
+  }
+  size_t tot_out = 0, tot_in = 0;
+  for (auto &kv : out) { kv.second.off = tot_out; tot_out += kv.second.len; }
+  for (auto &kv : in) { kv.second.off = tot_in; tot_in += kv.second.len; }
+  if (tot_out > x.d_send.n || tot_in > x.d_recv.n) {
+    HIPC(hipStreamSynchronize(t->stream));  // (operations of an earlier batch may still read / write the old buffers)
+    if (x.d_send.alloc(tot_out + tot_out / 2) || x.d_recv.alloc(tot_in + tot_in / 2)) { set_err("exchange: allocation failed"); return DPGO_ERR; }
+  }
+  // pack
+  std::map<int, size_t> cur;
+  for (auto &kv : out) cur[kv.first] = kv.second.off;
+  XferSegs sg{};
+  auto flush_pack = [&]() { if (sg.n) launch_pack_multi(t->ctx(), sg); sg.n = 0; };
+  for (const Pair &p : pairs) {
+    auto il = t->id2local.find(p.b);
+    if (il == t->id2local.end()) continue;
+    Agent &sb = *t->ag[il->second];
+    if (!sb.has_X) { set_err("exchange: robot " + std::to_string(sb.id) + " has no iterate yet"); return DPGO_NOT_READY; }
+    auto itf = sb.d_pubframes.find(p.a);
+    if (itf == sb.d_pubframes.end()) continue;
+    const int cnt = sb.n_pubframes[p.a];
+    size_t &at = cur[x.owner[p.a]];
+    for (int q = 0; q < 2; ++q) {
+      if (!((p.seqs >> q) & 1)) continue;
+      if (sg.n == XFER_MAX_SEGS) flush_pack();
+      sg.src[sg.n] = sb.dev.buf[q ? B_Y : B_X]; sg.idx[sg.n] = itf->second->p; sg.count[sg.n] = cnt; sg.buf[sg.n] = x.d_send.p + at;
+      ++sg.n;
+      at += (size_t)cnt * B;
+    }
+  }
+  flush_pack();
+  // the messages
+  NCCLC(api->GroupStart());
+  for (auto &kv : out)
+    if (kv.second.len) {
+      NCCLC(api->Send(x.d_send.p + kv.second.off, kv.second.len, ncclDouble, kv.first, x.comm->comm, t->stream));
+      x.counters[0] += 1; x.counters[2] += 8.0 * kv.second.len;
+    }
+  for (auto &kv : in)
+    if (kv.second.len) {
+      NCCLC(api->Recv(x.d_recv.p + kv.second.off, kv.second.len, ncclDouble, kv.first, x.comm->comm, t->stream));
+      x.counters[1] += 1; x.counters[3] += 8.0 * kv.second.len;
+    }
+  NCCLC(api->GroupEnd());
+  // unpack
+  cur.clear();
+  for (auto &kv : in) cur[kv.first] = kv.second.off;
+  auto flush_unpack = [&]() { if (sg.n) launch_unpack_multi(t->ctx(), sg); sg.n = 0; };
+  for (const Pair &p : pairs) {
+    auto il = t->id2local.find(p.a);
+    if (il == t->id2local.end()) continue;
+    Agent &ra = *t->ag[il->second];
+    auto its = ra.d_nbrslots.find(p.b);
+    if (its == ra.d_nbrslots.end()) continue;
+    const int cnt = ra.n_nbrslots[p.b];
+    size_t &at = cur[x.owner[p.b]];
+    for (int q = 0; q < 2; ++q) {
+      if (!((p.seqs >> q) & 1)) continue;
+      if (sg.n == XFER_MAX_SEGS) flush_unpack();
+      sg.src[sg.n] = ra.dev.nbr[q]; sg.idx[sg.n] = its->second->p; sg.count[sg.n] = cnt; sg.buf[sg.n] = x.d_recv.p + at;
+      ++sg.n;
+      at += (size_t)cnt * B;
+      for (size_t s = 0; s < ra.np.size(); ++s) if (ra.np[s].first == p.b) ra.np_has[q][s] = 1;
+    }
+  }
+  flush_unpack();
+  (void)me;
+  return 0;
+}
+
+// every ordered pair (b -> a) of neighbouring robots that touches this team and crosses ranks
+std::vector<Pair> all_pairs(dpgo_team_t *t, unsigned seqs) {
+  std::vector<Pair> v;
+  for (auto &ag : t->ag)
+    for (int nb : ag->neighbors) {
+      if (!crosses(t, nb, ag->id)) continue;
+      v.push_back({nb, ag->id, seqs});                                   // this team receives
+      if (!t->id2local.count(nb)) v.push_back({ag->id, nb, seqs});      // ... and sends (a local nb lists the pair itself)
+    }
+  return v;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dpgo_team_exchange_all_ranks(dpgo_team_t *t) {
+  if (!t->rx.comm) { set_err("exchange_all_ranks: no communicator attached"); return DPGO_ERR; }
+  if (sync_descs(t)) return DPGO_ERR;
+  auto &x = t->rx;
+  // co-resident neighbours are read in place
+  if (!t->isolated) {
+    LaunchCtx c = t->ctx();
+    for (auto &a : t->ag) {
+      launch_pull(c, a->local, (int)a->shared.size());
+      for (size_t q = 0; q < a->np.size(); ++q)
+        if (t->id2local.count(a->np[q].first)) { a->np_has[0][q] = 1; a->np_has[1][q] = 1; }
+    }
+  }
+  std::vector<Pair> v = all_pairs(t, 3u);
+  for (const Pair &p : v) { x.sent[{p.b, p.a, 0}] = x.version[p.b]; x.sent[{p.b, p.a, 1}] = x.version[p.b]; }
+  return exchange_pairs(t, v);
+}
+
+// `iters` global iterations in which robot sel_ids[q] holds the UPDATE token.  Every rank that owns a robot calls this with
+// the same list.  Same iterates as dpgo_team_step_begin / [messages] / dpgo_team_step_end driven from the host per step.
+int dpgo_team_run_ranks(dpgo_team_t *t, const int *sel_ids, int iters) {
+  auto &x = t->rx;
+  if (!x.comm) { set_err("run_ranks: no communicator attached"); return DPGO_ERR; }
+  const dpgo_params_t &p = t->prm;
+  const int NR = p.num_robots;
+  for (int q = 0; q < iters; ++q) if (sel_ids[q] < 0 || sel_ids[q] >= NR) { set_err("run_ranks: bad robot id in the schedule"); return DPGO_ERR; }
+  if (sync_descs(t)) return DPGO_ERR;
+  for (auto &a : t->ag) if (!a->has_X) { set_err("run_ranks before set_initial"); return DPGO_NOT_READY; }
+  // nothing crosses a rank: the device-resident schedule (hipGraphs, one launch per iteration) serves, provided the list
+  // is the team's own schedule from where it stands
+  bool any_cross = false;
+  for (auto &a : t->ag) for (int nb : a->neighbors) any_cross = any_cross || crosses(t, nb, a->id);
+  if (!any_cross && (int)t->ag.size() == NR && !t->sched.empty()) {
+    bool same = true;
+    const int P = (int)t->sched.size();
+    for (int q = 0; q < iters && same; ++q) same = t->ag[t->sched[(t->iter + q) % P]]->id == sel_ids[q];
+    if (same) {
+      const int rc = dpgo_team_run(t, iters);
+      if (rc == 0) for (int q = 0; q < iters; ++q) x.version[sel_ids[q]] = t->iter;  // (conservative: anything sent later is sent whole)
+      return rc;
+    }
+  }
+  const unsigned seqs = p.acceleration ? 3u : 1u;
+  for (int q = 0; q < iters; ++q) {
+    const int sel_id = sel_ids[q];
+    auto it = t->id2local.find(sel_id);
+    const int sel = (it == t->id2local.end()) ? -2 : it->second;
+    const long long k = t->iter;
+    const bool restart = p.acceleration && ((t->iter + 2) % p.restart_interval) == 0;
+    // iterate(false) moves X and Y of everyone but the token holder BEFORE the token holder's neighbours publish them
+    if (p.acceleration) for (int a = 0; a < NR; ++a) if (a != sel_id) x.version[a] = k + 1;
+    int rc = enqueue_team_iteration(t, false, restart, sel, 1);
+    if (rc) return rc;
+    // the neighbours of the token holder that live elsewhere publish to it -- those whose copy there is too old
+    std::vector<Pair> v;
+    auto consider = [&](int b) {
+      if (!crosses(t, b, sel_id)) return;
+      for (const Pair &e : v) if (e.b == b) return;
+      long long behind = 0;
+      bool missing = false;
+      for (int s = 0; s < 2; ++s) {
+        if (!((seqs >> s) & 1)) continue;
+        auto f = x.sent.find({b, sel_id, s});
+        if (f == x.sent.end()) missing = true;
+        else behind = std::max(behind, x.version[b] - f->second);
+      }
+      if (!missing && (behind == 0 || behind <= x.max_delay)) return;  // current, or fresh enough for the staleness gate
+      for (int s = 0; s < 2; ++s) if ((seqs >> s) & 1) x.sent[{b, sel_id, s}] = x.version[b];
+      v.push_back({b, sel_id, seqs});
+    };
+    if (sel >= 0) for (int b : t->ag[sel]->neighbors) consider(b);
+    for (auto &a : t->ag) if (a->id != sel_id && std::binary_search(a->neighbors.begin(), a->neighbors.end(), sel_id)) consider(a->id);
+    rc = exchange_pairs(t, v);
+    if (rc) return rc;
+    if (sel >= 0 && !neighbor_poses_ready(*t->ag[sel], p.acceleration ? 1 : 0)) { set_err("run_ranks: neighbour poses missing (call dpgo_team_exchange_all_ranks once after set_initial)"); return DPGO_NOT_READY; }
+    rc = enqueue_team_iteration(t, false, restart, sel, 2);
+    if (rc) return rc;
+    const bool fused = p.method == DPGO_METHOD_RGD && p.rgd_use_preconditioner && !restart && sel >= 0 && !p.rgd_line_search;
+    account_iteration(t, sel, fused || t->last_iteration_folded);
+    x.version[sel_id] = k + 1;
+  }
+  return DPGO_OK;
+}
+
+/* global cost across ranks: owned-edge partial sums of this team (NULL: a rank without robots contributes 0) + one
+ * 1-double all-reduce.  Collective over the communicator. */
+int dpgo_comm_global_cost(dpgo_comm_t *c, dpgo_team_t *t, void *stream, double *f) {
+  double part = 0;
+  if (t) {
+    if (t->rx.comm && dpgo_team_exchange_all_ranks(t)) return DPGO_ERR;
+    if (dpgo_team_cost(t, &part)) return DPGO_ERR;
+  }
+  if (dpgo_comm_allreduce_sum(c, t ? (void *)t->stream : stream, &part, 1)) return DPGO_ERR;
+  *f = part;
+  return DPGO_OK;
+}
+
+int dpgo_team_comm_counters(dpgo_team_t *t, double *out4) {
+  for (int k = 0; k < 4; ++k) out4[k] = t->rx.counters[k];
+  return DPGO_OK;
+}
+
+}  // extern "C"

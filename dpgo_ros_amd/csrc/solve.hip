@@ -116,7 +116,9 @@ int enqueue_optimize(dpgo_team *t, int sel, const OptFlags &fl) {
         if (p.rgd_use_preconditioner) { t->counters[0] += 1; t->counters[1] += precond_operator_bytes(a); }
         const int passes = (fl.skip_stats ? 1 : 2) + (ntr + 3) / 4;  // passes over the sparse operator
         t->counters[2] += passes; t->counters[3] += passes * spmm_bytes_of(t, a);
-        a.opt_pending_rgd = true;
+        // (without the closing evaluation PART_A holds the trial costs of k_ls_cost, not f_opt / |grad|^2: nothing may
+        // read them as the solve's result)
+        a.opt_pending_rgd = !fl.skip_stats;
       }
       return 0;
     }
@@ -174,8 +176,13 @@ int enqueue_optimize(dpgo_team *t, int sel, const OptFlags &fl) {
     // host memory, read by refresh_rtr_result() whenever somebody asks (opt result, counters) -- except for the very first
     // solve on this device, which is checked at once so that a grid that is not resident at once (another process
     // running a persistent kernel on this GPU) is met with the launch-per-step sequence instead of an error.
-    const int grid_key = tl_fused ? 100000000 + a.tl_plan.nwg - a.tl_plan.nS2 : a.n;  // the hand-off counters depend on the grid
-    if (a.rtr_bar_n != grid_key) {
+    // The hand-off counters depend on the grid (and, two-level, on the number of producers: the exchange counters run
+    // to nA x epoch); the H-delta ring behind the partial sums is sized by 4 n r.  Zero / regrow whenever any of them
+    // moved -- a re-finalised agent with more poses or a rebuilt plan on the same grid included (advisor, round 4).
+    const int grid_key = tl_fused ? 100000000 + a.tl_plan.nwg - a.tl_plan.nS2 : a.n;
+    const long long key[4] = {grid_key, a.n, tl_fused ? a.tl_plan.nA : 0, tl_fused ? a.tl_plan_serial : -1};
+    if (a.rtr_bar_n != grid_key || std::memcmp(key, a.rtr_key, sizeof key) != 0) {
+      std::memcpy(a.rtr_key, key, sizeof key);
       if (a.d_rtr_bar.alloc(RTR_BAR_WORDS) || a.d_rtr_ws.alloc(RTR_WS_DOUBLES + (size_t)RTR_RING * rtr_ring_pitch((size_t)4 * a.n * p.r)) || a.h_rtr.alloc(1) || a.h_rtr_cum.alloc(4)) {
         set_err("RTR scratch allocation failed"); return DPGO_ERR;
       }

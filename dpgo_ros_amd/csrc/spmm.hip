@@ -71,7 +71,9 @@ __global__ __launch_bounds__(EVS_NT) void k_eval_staged(const AgentDev *__restri
   if (j0 >= ag.n) return;
   const int E0 = ag.pose_eptr[j0], E1 = ag.pose_eptr[min(j0 + PPB, ag.n)], cnt = E1 - E0;
   if (threadIdx.x >= 64) {
-    if (cnt == 0) return;
+    // (every wave of the workgroup meets the same barriers: the one behind the staging when the tile has shared edges,
+    // and eval_body's in front of the tangent projection -- no wave leaves a barrier behind it for the others)
+    if (cnt == 0) { __syncthreads(); return; }
     const int t = (int)threadIdx.x - 64;
     const bool pull = gmode == 2;
     constexpr int CB = 8;  // chunks per lane and pass (the host keeps cap * XCH <= a few passes of EVS_NH * CB)
@@ -115,6 +117,7 @@ __global__ __launch_bounds__(EVS_NT) void k_eval_staged(const AgentDev *__restri
     }
     EVS_STAMP(1 + (t >> 6));
     __syncthreads();  // (pairs with the tile's wave: eval_body, behind its SpMM)
+    __syncthreads();  // (... and with eval_body's barrier in front of the tangent projection)
     return;
   }
   eval_body<R>(agents, team, sel, xb, egb, gfb, poff, gmode, aux, bx, Ysh, Wsh, agents[0], cnt > 0 ? Eop : nullptr, E0);
@@ -388,6 +391,8 @@ void launch_pull(const LaunchCtx &c, int dst, int nshared) {
   DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_pull<R>, dim3((len + 255) / 256), dim3(256), 0, c.stream, c.agents, dst));
 }
 
+// (k_eval_staged's static LDS -- Ysh, Wsh: 2 x 64 x 4 doubles at most -- rounded up; assembly.hip admits a tile when its
+// operands fit beside it in the device's limit)
 size_t eval_staged_lds_bytes(int r, int cap) { return (size_t)cap * (4 * r + 16) * 8; }
 
 void launch_eval(const LaunchCtx &c, int sel, int max_n, int xb, int egb, int gfb, int poff, const EvalOpts &o) {
@@ -397,7 +402,7 @@ void launch_eval(const LaunchCtx &c, int sel, int max_n, int xb, int egb, int gf
     DPGO_DISPATCH_R(c.r, {
       static bool configured = false;
       if (!configured) {
-        e = hipFuncSetAttribute((const void *)k_eval_staged<R>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        e = hipFuncSetAttribute((const void *)k_eval_staged<R>, hipFuncAttributeMaxDynamicSharedMemorySize, c.max_lds - EVS_STATIC_LDS);
         configured = (e == hipSuccess);
       }
       if (e == hipSuccess)

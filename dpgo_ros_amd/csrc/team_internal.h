@@ -14,6 +14,7 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <tuple>
 #include <utility>
 #include <vector>
 
@@ -129,6 +130,7 @@ struct Agent {
   DevBuf<unsigned long long> d_rtr_bar;
   DevBuf<double> d_rtr_ws;
   int rtr_bar_n = -1;  // pose count the counters were zeroed for
+  long long rtr_key[4] = {-1, -1, -1, -1};  // {grid, poses, two-level producers, plan generation} the scratch was sized / zeroed for
   DevBuf<unsigned long long> d_rtr_cum;      // running totals {solves, Hess-vecs, preconditioner applies, outer iterations}
   PinnedBuf<unsigned long long> h_rtr_cum;   // host copy of the totals + of the last solve's record (asynchronous read-back)
   PinnedBuf<dpgo::RtrState> h_rtr;
@@ -168,6 +170,7 @@ struct Agent {
 
 }  // namespace dpgo_host
 
+struct dpgo_comm;
 struct dpgo_team {
   int device = 0;
   dpgo_params_t prm{};
@@ -240,6 +243,19 @@ struct dpgo_team {
   // that does not get the lock runs the launch-per-step sequence.  1: held.
   int rtr_lock_state = 0;
   int rtr_lock_fd = -1;
+  // one process per GPU with the exchange carried by RCCL from inside the library (rank_exchange.cpp): the communicator,
+  // who owns which robot, the staleness gate, and what every receiver holds of every sender
+  struct RankExchange {
+    dpgo_comm *comm = nullptr;
+    std::vector<int> owner;                                   // [robot] rank that holds it
+    int max_delay = 0;                                        // maxDelayedIterations (src/PGOAgentROS.cpp:136-149)
+    bool loopback = false;                                    // world size 1: every neighbour pair crosses RCCL as a self-send
+    std::vector<long long> version;                           // [robot] iteration at which its public poses last changed
+    std::map<std::tuple<int, int, int>, long long> sent;      // (b, a, sequence) -> version of b's poses that a's rank holds
+    dpgo_host::DevBuf<double> d_send, d_recv;                 // staging of one batch of messages
+    double counters[4] = {0, 0, 0, 0};                        // messages sent / received, bytes sent / received (this rank)
+  } rx;
+  bool isolated = false;  // no neighbour is read in place, co-resident ones included (rx.loopback)
   unsigned long long epoch = 1;  // bumped by everything that enqueues device work (every launch goes through ctx())
   dpgo::LaunchCtx ctx() {
     ++epoch;
@@ -249,6 +265,7 @@ struct dpgo_team {
     c.host_precond = precond_of.empty() ? nullptr : precond_of.data();
     c.tl_max_wg = tl_max_wg;
     c.stage_cap = stage_cap;
+    c.max_lds = max_lds;
     c.host_agents = h_descs.empty() ? nullptr : h_descs.data();
     for (int k : precond_of) if (k == DPGO_PRECOND_TWO_LEVEL) c.any_two_level = true;
     return c;

@@ -288,6 +288,42 @@ int dpgo_team_import_peer(dpgo_team_t *t, int robot_id, const unsigned char *han
 int dpgo_team_export_mailbox(dpgo_team_t *t, unsigned char *handle64);
 int dpgo_team_import_mailbox(dpgo_team_t *t, const unsigned char *handle64, const int *robot_ids, int count);
 int dpgo_team_run_peer(dpgo_team_t *t, const int *sel_ids, int iters);
+/* ---- one process per GPU, the exchange carried by RCCL from inside the library (csrc/rank_exchange.cpp) ----
+ * Replaces the ROS transport of this path: PublicPoses messages (msg/PublicPoses.msg:1-8; sent src/PGOAgentROS.cpp:662-690,
+ * received :1255-1284) become packed r x 4 fp64 slabs moved by ncclSend / ncclRecv that the library enqueues on the team
+ * stream; the staleness gate (:136-149, maxDelayedIterations include/dpgo_ros/PGOAgentROS.h:83) decides which slabs are
+ * sent; the UPDATE token (:443-504, 1161-1189) is the list of token holders every rank is handed.
+ * RCCL is bound at run time (dlopen librccl.so.1; DPGO_RCCL_LIBRARY overrides): single-GPU users never load it.
+ * A communicator is an object of its own because ranks that own no robot (5 robots on 8 GPUs) still take part in its
+ * creation and in the reductions.  id128: DPGO_COMM_ID_BYTES bytes obtained on ONE rank and handed to all (any channel). */
+#define DPGO_COMM_ID_BYTES 128
+typedef struct dpgo_comm dpgo_comm_t;
+int dpgo_comm_unique_id(unsigned char *id128);
+dpgo_comm_t *dpgo_comm_create(int device, const unsigned char *id128, int rank, int world); /* collective; NULL on error */
+void dpgo_comm_destroy(dpgo_comm_t *c);
+int dpgo_comm_rank(const dpgo_comm_t *c);
+int dpgo_comm_world(const dpgo_comm_t *c);
+/* which RCCL was bound: path + version code into out; returns the version code (<0 on error) */
+int dpgo_comm_library(char *out, int cap);
+/* small collectives (<= 64 doubles, host in/out, synchronous) on `stream` (hipStream_t or NULL) */
+int dpgo_comm_allreduce_sum(dpgo_comm_t *c, void *stream, double *inout, int n);
+int dpgo_comm_allreduce_max(dpgo_comm_t *c, void *stream, double *inout, int n);
+/* owner_rank_of_robot[num_robots]: the rank that holds each robot (every robot of this team must map to the communicator's
+ * rank).  max_delayed_iterations: the staleness gate.  loopback (world size 1 only): every neighbour pair -- co-resident
+ * ones included -- exchanges through RCCL self-sends and nothing is read in place: the message path end to end on one GPU. */
+int dpgo_team_attach_comm(dpgo_team_t *t, dpgo_comm_t *c, const int *owner_rank_of_robot, int max_delayed_iterations, int loopback);
+int dpgo_team_detach_comm(dpgo_team_t *t);
+/* every neighbour pair that crosses ranks, both directions, X and Y (after set_initial; before a cost evaluation) */
+int dpgo_team_exchange_all_ranks(dpgo_team_t *t);
+/* `iters` global iterations, robot sel_ids[q] holding the token in the q-th: per iteration the iterate(false) part of every
+ * local robot (:1183-1186), the token holder's neighbours' public poses by ncclSend / ncclRecv (one message per pair of
+ * ranks), the block update (:160).  Nothing synchronises with the host; every rank that owns a robot passes the same
+ * list.  Iterates equal dpgo_team_step_begin / messages / dpgo_team_step_end bit for bit. */
+int dpgo_team_run_ranks(dpgo_team_t *t, const int *sel_ids, int iters);
+/* global cost: this team's owned-edge partial sums (t may be NULL on a rank without robots) + a 1-double all-reduce */
+int dpgo_comm_global_cost(dpgo_comm_t *c, dpgo_team_t *t, void *stream, double *f);
+/* out[4]: point-to-point messages sent / received by this rank, bytes sent / received */
+int dpgo_team_comm_counters(dpgo_team_t *t, double *out4);
 /* diagnostic: hand-off words of an agent's one-launch RTR solve (rtr_fused.hip; phase stamps in trace builds) */
 int dpgo_agent_read_rtr_handoff(dpgo_team_t *t, int id, unsigned long long *out, int n);
 /* diagnostic: `n` doubles of an agent's device-side partial-sum scratch (csrc/dpgo_dev.h PART_*) from `offset` */
