@@ -601,6 +601,11 @@ def multi_gpu(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # a bare `python bench.py` with DPGO_BENCH_FORCE_DIST=1 (world size 1, no launcher): the rendezvous is local
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(free_port()))
+    os.environ.setdefault("RANK", str(rank))
+    os.environ.setdefault("WORLD_SIZE", str(world))
     torch.cuda.set_device(local_rank)
     dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     # every rank takes part in one collective before the first point-to-point batch: the RCCL communicator of
@@ -630,6 +635,13 @@ def multi_gpu(args):
             be.team.set_initial(T, Y, offsets=np.array([a * per for a in mine], dtype=np.int32))
     drv = DistributedRBCD(dist, be, mp, NA, RGD["acceleration"], rank, world)
     drv.exchange_all()
+    # the data path proper: a communicator owned by libdpgo_hip.so (its 128-byte id travels over the control plane), the
+    # public-pose slabs moved by ncclSend / ncclRecv that the library enqueues on the team stream, K iterations per call
+    uid = [capi.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(uid, src=0)
+    comm = capi.Comm(uid[0], rank, world, device=local_rank)
+    drv.enable_library_exchange(comm)
+
     def timed(step_k):
         """W untimed + K timed steps, barrier + synchronize on both sides, MAX over ranks -> ms per step"""
         step_k(args.warmup)
@@ -645,7 +657,15 @@ def multi_gpu(args):
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             return tmax.item() / args.steps * 1e3
 
-    # (1) PublicPoses as RCCL point-to-point messages, one host-driven exchange per iteration
+    # (0) PublicPoses as RCCL point-to-point messages enqueued by the library (dpgo_team_run_ranks): no host language in
+    # the loop, one host call for all K iterations
+    c0 = be.team.comm_counters() if be.team is not None else None
+    ms_lib = timed(lambda k: drv.run_library(k))
+    lib_msgs = None
+    if be.team is not None:
+        c1 = be.team.comm_counters()
+        lib_msgs = {k: (c1[k] - c0[k]) / float(args.warmup + args.steps) for k in c1}
+    # (1) the same messages driven from the host, one exchange per iteration (torch.distributed isend / irecv)
     m0 = drv.messages
     ms_rccl = timed(lambda k: [drv.step() for _ in range(k)])
     msgs = (drv.messages - m0) / float(args.warmup + args.steps)
@@ -659,13 +679,21 @@ def multi_gpu(args):
             ms_peer = timed(lambda k: drv.run_peer(k))
         else:
             peer_err = drv.peer_error
-    ms = ms_peer if ms_peer is not None else ms_rccl
-    exchange = {"ms_per_step_rccl_messages": ms_rccl, "rccl_point_to_point_ops_per_step_this_rank": msgs,
+    ms = ms_lib
+    lib_path, lib_version = capi.comm_library()
+    exchange = {"ms_per_step_rccl_in_library": ms_lib, "rccl_in_library_per_step_this_rank": lib_msgs,
+                "rccl_library": lib_path, "rccl_version_code": lib_version,
+                "ms_per_step_rccl_messages_host_driven": ms_rccl, "rccl_point_to_point_ops_per_step_this_rank": msgs,
                 "ms_per_step_peer_access_device_token": ms_peer, "peer_access_error": peer_err,
-                "value_is": "peer_access_device_token" if ms_peer is not None else "rccl_messages",
+                "value_is": "rccl_in_library (dpgo_team_run_ranks: ncclSend / ncclRecv enqueued by libdpgo_hip.so, K iterations "
+                            "per host call; at world size 1 nothing crosses a rank and the list goes to the device-resident schedule)",
                 "rccl_world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks": devices,
                 "rccl_point_to_point_ops_total_this_rank": drv.messages}
-    cost = drv.global_cost(torch, "cuda")
+    if world == 1:
+        exchange["loopback"] = loopback_leg(capi, mp, T, Y, comm, args)
+    cost = comm.global_cost(be.team, stream=be.stream.cuda_stream)
+    cost_check = drv.global_cost(torch, "cuda")   # (the host-driven all-reduce of the same partial sums)
+    exchange["global_cost_library_vs_torch_rel_diff"] = abs(cost - cost_check) / abs(cost_check)
     roof = None
     if rank == 0 and be.team is not None:  # the same kernel-level leg as at N = 1, on rank 0's first agent
         with be.stream_context():
@@ -753,7 +781,8 @@ def multi_gpu(args):
         free["error"] = drv3.peer_error
     dist.barrier()
     be3.close()
-    exchange["config2_sphere2500_8_agents_rtr"] = config2_ranks_leg(args, capi, dist, torch, m, n, T, Y, rank, local_rank, world)
+    exchange["config2_sphere2500_8_agents_rtr"] = config2_ranks_leg(args, capi, dist, torch, m, n, T, Y, rank, local_rank, world, comm)
+    comm.close()
     dist.destroy_process_group()
     return rank, ms, cost, roof, exchange, {"ms_per_block_update": cp_ms, "classes": len(drv2.groups),
                             "relcost_after_45_sweeps": (cp_cost - F_STAR[WORKLOAD["dataset"]]) / F_STAR[WORKLOAD["dataset"]]}, \
@@ -761,7 +790,31 @@ def multi_gpu(args):
          "ms_per_tick": tick_ms, "cost_initial": c0, "cost_after_220_ticks": c1, **free}
 
 
-def config2_ranks_leg(args, capi, dist, torch, m, n, T, Y, rank, local_rank, world):
+def loopback_leg(capi, mp, T, Y, comm, args):
+    """World size 1 only: the headline workload with EVERY neighbour pair exchanging through RCCL self-sends (nothing read
+    in place; tests/test_gpu_rank_exchange.py checks the bits) -- what the message path costs per iteration on one GPU,
+    launches and all, beside the device-resident schedule."""
+    NA = WORKLOAD["num_robots"]
+    t = capi.Team.from_measurements(mp, capi.default_params(r=WORKLOAD["r"], num_robots=NA, **RGD), device=comm.device)
+    t.set_initial(T, Y)
+    t.attach_comm(comm, [0] * NA, loopback=True)
+    t.exchange_all_ranks()
+    sel = lambda k0, k: [(k0 + q) % NA for q in range(k)]
+    t.run_ranks(sel(0, args.warmup))
+    t.synchronize()
+    c0 = t.comm_counters()
+    a0 = time.perf_counter()
+    t.run_ranks(sel(args.warmup, args.steps))
+    t.synchronize()
+    ms = (time.perf_counter() - a0) / args.steps * 1e3
+    c1 = t.comm_counters()
+    t.close()
+    return {"ms_per_step": ms, "messages_per_step": (c1["messages_sent"] - c0["messages_sent"]) / args.steps,
+            "bytes_per_step": (c1["bytes_sent"] - c0["bytes_sent"]) / args.steps,
+            "note": "sphere2500 / 5 agents, RGD + Nesterov, every pair a grouped ncclSend / ncclRecv to self"}
+
+
+def config2_ranks_leg(args, capi, dist, torch, m, n, T, Y, rank, local_rank, world, comm):
     """BASELINE configs[2]: sphere2500 split over 8 agents (7 x 312 + 316), RBCD with the RTR 3 / 50 / 0.5 inner solve of
     launch/dpgo_demo.launch:33-35, round robin, agent a on rank a % N (one agent per GPU at N = 8), PublicPoses as RCCL
     point-to-point messages (src/PGOAgentROS.cpp:662-690, 1255-1284).  The synchronous schedule is sequential (SURVEY
@@ -778,26 +831,89 @@ def config2_ranks_leg(args, capi, dist, torch, m, n, T, Y, rank, local_rank, wor
             be.team.set_initial(T, Y, offsets=np.array([a * per for a in mine], dtype=np.int32))
     drv = DistributedRBCD(dist, be, mp8, N, 0, rank, world)
     drv.exchange_all()
+    drv.enable_library_exchange(comm)
     warm, steps = 2 * N, max(N, min(args.steps, 25 * N))
-    for _ in range(warm):
-        drv.step()
+    drv.run_library(warm)
     dist.barrier()
     torch.cuda.synchronize()
-    m0, t0 = drv.messages, time.perf_counter()
-    for _ in range(steps):
-        drv.step()
+    c0 = be.team.comm_counters() if be.team is not None else None
+    t0 = time.perf_counter()
+    drv.run_library(steps)
     dist.barrier()
     torch.cuda.synchronize()
     with be.stream_context():
         tmax = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    cost = drv.global_cost(torch, "cuda")
+    msgs = (be.team.comm_counters()["messages_sent"] - c0["messages_sent"]) / float(steps) if be.team is not None else 0.0
+    cost = comm.global_cost(be.team, stream=be.stream.cuda_stream)
     dist.barrier()
     be.close()
-    return {"workload": "sphere2500, 8 agents on %d rank(s) (agent a on rank a %% N), RBCD + RTR 3/50/0.5, round robin" % world,
+    return {"workload": "sphere2500, 8 agents on %d rank(s) (agent a on rank a %% N), RBCD + RTR 3/50/0.5, round robin, "
+                        "exchange by ncclSend / ncclRecv inside the library" % world,
             "ms_per_iter": tmax.item() / steps * 1e3, "iterations": steps,
-            "rccl_point_to_point_ops_per_iter_this_rank": (drv.messages - m0) / float(steps),
+            "rccl_point_to_point_ops_per_iter_this_rank": msgs,
             "relcost_after_run": (cost - F_STAR["sphere2500"]) / F_STAR["sphere2500"]}
+
+
+def free_port():
+    import socket
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        return s_.getsockname()[1]
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks here -- one process per GPU, RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in their environment, exactly what `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1` hands them -- forward rank 0's JSON line, fail if any rank fails.  A rank
+    that dies or hangs takes the others with it (each child is killed by its own PID)."""
+    n = args.gpus
+    port = free_port()
+    limit = float(os.environ.get("DPGO_BENCH_SPAWN_TIMEOUT", "2400"))
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", DPGO_BENCH_SPAWNED="1")
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(n), "--steps", str(args.steps), "--warmup", str(args.warmup)]
+        if args.spawn_check:
+            cmd.append("--spawn-check")
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
+    t0, rc, out0 = time.time(), 0, ""
+    try:
+        out0, _ = procs[0].communicate(timeout=limit)
+        rc = procs[0].returncode
+        for p in procs[1:]:
+            p.wait(timeout=max(1.0, limit - (time.time() - t0)))
+            rc = rc or p.returncode
+    except subprocess.TimeoutExpired:
+        rc = 124
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    sys.stdout.write(out0 or "")
+    sys.stdout.flush()
+    return rc
+
+
+def spawn_check():
+    """--spawn-check: rendezvous + one reduction per rank, no GPU work (the CPU test of the spawner, gloo at N = 2:
+    DPGO_BENCH_BACKEND=gloo)"""
+    import torch
+    import torch.distributed as dist
+    backend = os.environ.get("DPGO_BENCH_BACKEND", "nccl")
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    if backend == "nccl":
+        torch.cuda.set_device(int(os.environ["LOCAL_RANK"]))
+    dist.init_process_group(backend)
+    t = torch.tensor([float(rank + 1)], device="cuda" if backend == "nccl" else "cpu")
+    dist.all_reduce(t)
+    ranks = [None] * world
+    dist.all_gather_object(ranks, {"rank": rank, "local_rank": int(os.environ["LOCAL_RANK"]), "pid": os.getpid()})
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"spawn_check": True, "world_size": world, "backend": backend, "sum_of_rank_plus_one": t.item(), "ranks": ranks}))
+    dist.destroy_process_group()
 
 
 def main():
@@ -805,7 +921,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--spawn-check", action="store_true", help="rendezvous test of the built-in launcher, no GPU work")
     args = ap.parse_args()
+    # N > 1 without a launcher (no RANK in the environment): this process becomes the launcher
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args))
+    if args.spawn_check:
+        return spawn_check()
     out = {"metric": "ms/RBCD-iteration + iterations-to-1e-6-relcost, sphere2500 5-agent",
            "unit": "ms", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
            "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
@@ -832,9 +954,11 @@ def main():
             out.update({"value": ms, "ms_per_step": ms, "roofline": roof, "cpu_baseline": None,
                         "relcost_after_run": (cost - fstar) / fstar, "colour_parallel_plain_rtr": cp,
                         "asapp_ticks_tunnels": asapp,
-                        "exchange": "RCCL isend/irecv of packed public-pose slabs (X and Y), pull-before-use; or, where "
-                                    "HIP IPC works between the ranks, neighbours read in place over peer access with the "
-                                    "UPDATE token in device-side mailboxes (no host in the loop)",
+                        "launched_by": "bench.py (built-in launcher)" if os.environ.get("DPGO_BENCH_SPAWNED") else
+                                       ("torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "environment"),
+                        "exchange": "RCCL ncclSend / ncclRecv of packed public-pose slabs (X and Y) enqueued by libdpgo_hip.so on "
+                                    "the team stream, K iterations per host call, pull-before-use with the staleness gate in "
+                                    "the library (csrc/rank_exchange.cpp)",
                         "exchange_timing": exchange})
             print(json.dumps(out))
 

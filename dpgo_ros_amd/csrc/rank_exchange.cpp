@@ -173,6 +173,7 @@ int dpgo_team_attach_comm(dpgo_team_t *t, dpgo_comm_t *c, const int *owner_rank_
   x.loopback = loopback != 0;
   x.version.assign(NR, 0);
   x.sent.clear();
+  x.iter_seen = t->iter;
   // loopback: every neighbour is treated as living in another process -- no pose is read in place, each one crosses
   // RCCL as a self-send -- so that the message path is exercised end to end on a one-GPU box
   if (t->isolated != x.loopback) { t->isolated = x.loopback; t->descs_dirty = true; t->graph_valid = false; }
@@ -320,6 +321,8 @@ int dpgo_team_exchange_all_ranks(dpgo_team_t *t) {
     }
   }
   std::vector<Pair> v = all_pairs(t, 3u);
+  if (x.iter_seen != t->iter) x.sent.clear();  // (the team moved outside dpgo_team_run_ranks: only what is sent now is known)
+  x.iter_seen = t->iter;
   for (const Pair &p : v) { x.sent[{p.b, p.a, 0}] = x.version[p.b]; x.sent[{p.b, p.a, 1}] = x.version[p.b]; }
   return exchange_pairs(t, v);
 }
@@ -344,10 +347,13 @@ int dpgo_team_run_ranks(dpgo_team_t *t, const int *sel_ids, int iters) {
     for (int q = 0; q < iters && same; ++q) same = t->ag[t->sched[(t->iter + q) % P]]->id == sel_ids[q];
     if (same) {
       const int rc = dpgo_team_run(t, iters);
-      if (rc == 0) for (int q = 0; q < iters; ++q) x.version[sel_ids[q]] = t->iter;  // (conservative: anything sent later is sent whole)
+      if (rc == 0) { for (int a = 0; a < NR; ++a) x.version[a] = t->iter; x.iter_seen = t->iter; }
       return rc;
     }
   }
+  // iterations driven by anything else since the bookkeeping was last valid (host-driven steps, dpgo_team_run): what the
+  // receivers hold is unknown -- every slab is sent once
+  if (x.iter_seen != t->iter) x.sent.clear();
   const unsigned seqs = p.acceleration ? 3u : 1u;
   for (int q = 0; q < iters; ++q) {
     const int sel_id = sel_ids[q];
@@ -386,6 +392,7 @@ int dpgo_team_run_ranks(dpgo_team_t *t, const int *sel_ids, int iters) {
     const bool fused = p.method == DPGO_METHOD_RGD && p.rgd_use_preconditioner && !restart && sel >= 0 && !p.rgd_line_search;
     account_iteration(t, sel, fused || t->last_iteration_folded);
     x.version[sel_id] = k + 1;
+    x.iter_seen = t->iter;
   }
   return DPGO_OK;
 }

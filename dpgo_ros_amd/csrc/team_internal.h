@@ -253,6 +253,8 @@ struct dpgo_team {
     std::vector<long long> version;                           // [robot] iteration at which its public poses last changed
     std::map<std::tuple<int, int, int>, long long> sent;      // (b, a, sequence) -> version of b's poses that a's rank holds
     dpgo_host::DevBuf<double> d_send, d_recv;                 // staging of one batch of messages
+    long long iter_seen = -1;                                 // team iteration this bookkeeping is valid for (anything else that
+                                                              // advanced the team in between invalidates `sent`)
     double counters[4] = {0, 0, 0, 0};                        // messages sent / received, bytes sent / received (this rank)
   } rx;
   bool isolated = false;  // no neighbour is read in place, co-resident ones included (rx.loopback)

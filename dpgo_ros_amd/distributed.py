@@ -151,6 +151,16 @@ class HipBackend:
         if self.team is not None:
             self.team.run_peer(sel_ids)
 
+    # ---- the exchange carried by RCCL from inside the library (csrc/rank_exchange.cpp): K iterations per host call
+    def attach_comm(self, comm, owner_of_robot, max_delayed_iterations=0):
+        if self.team is not None:
+            self.team.attach_comm(comm, owner_of_robot, max_delayed_iterations)
+            self.team.exchange_all_ranks()
+
+    def run_ranks(self, sel_ids):
+        if self.team is not None:
+            self.team.run_ranks(sel_ids)
+
     def sync(self):
         """drain this rank's stream -- through the team, so that a time-out of an in-kernel exchange (mailbox wait of
         the device-side token, two-level preconditioner) is raised here instead of yielding silently wrong iterates"""
@@ -415,6 +425,26 @@ class DistributedRBCD:
         sels = [self.schedule[(self.k + q) % len(self.schedule)] for q in range(iters)]
         with self._ctx():
             self.be.run_peer(sels)
+        self.k += iters
+        self.version = [self.k] * self.N  # (conservative: a later step() sends everything once)
+        self.sent = {}
+        return sels
+
+    def enable_library_exchange(self, comm):
+        """hand the exchange to the library: from here on run_library() enqueues whole iterations -- the public-pose slabs
+        by ncclSend / ncclRecv on the team stream, the staleness gate evaluated in the library -- K per host call.  `comm`:
+        capi.Comm created collectively by every rank (also those without robots)."""
+        with self._ctx():
+            self.be.attach_comm(comm, self.owner, self.max_delay)
+        self.library_exchange = True
+
+    def run_library(self, iters):
+        """`iters` iterations of the synchronous schedule with NO host language in the loop (dpgo_team_run_ranks): same
+        iterates as step(), bit for bit (tests/test_gpu_rank_exchange.py).  Returns without synchronising."""
+        assert getattr(self, "library_exchange", False), "run_library needs enable_library_exchange()"
+        sels = [self.schedule[(self.k + q) % len(self.schedule)] for q in range(iters)]
+        with self._ctx():
+            self.be.run_ranks(sels)
         self.k += iters
         self.version = [self.k] * self.N  # (conservative: a later step() sends everything once)
         self.sent = {}

@@ -37,8 +37,24 @@ def test_bench_multi_rank_path_runs_under_rccl_at_world_size_one():
     assert d["asapp_ticks_tunnels"]["ms_per_tick"] > 0
     ex = d["exchange_timing"]
     assert ex["rccl_world_size"] == 1 and ex["backend"] == "nccl" and len(ex["ranks"]) == 1 and ex["ranks"][0]["device"]
+    # the value is the library-side RCCL path; at world size 1 it must sit with the single-GPU headline (hipGraphs), and
+    # the loopback leg shows one grouped self-send per iteration really crossing RCCL
+    assert ex["value_is"].startswith("rccl_in_library") and d["value"] == ex["ms_per_step_rccl_in_library"] < 0.05
+    assert ex["loopback"]["messages_per_step"] == 1.0 and ex["loopback"]["bytes_per_step"] > 0
+    assert ex["global_cost_library_vs_torch_rel_diff"] < 1e-12 and ex["rccl_version_code"] > 0
     c2 = ex["config2_sphere2500_8_agents_rtr"]  # BASELINE configs[2] through the multi-rank driver
     assert 0 < c2["ms_per_iter"] < 5.0 and np.isfinite(c2["relcost_after_run"]) and c2["rccl_point_to_point_ops_per_iter_this_rank"] == 0
+
+
+def test_bench_multi_rank_path_starts_without_a_launcher():
+    """no torchrun, no RANK / MASTER_ADDR in the environment: `python bench.py` with the N > 1 driver forced at world size 1"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(DPGO_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "40", "--warmup", "10"], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["exchange_timing"]["rccl_world_size"] == 1 and 0 < d["value"] < 1.0
 
 
 def _problem(mode):
