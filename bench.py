@@ -305,12 +305,15 @@ def agent_api_leg(capi, mp, n, T, Y):
 
         def iteration(k):
             sel = k % NA
+            # (separate processes in the reference: every robot's iterate(false) + publishStatus runs at the same time,
+            # then each publishes from its own runOnce -- one valid interleaving of that)
             for b in range(NA):
                 if b != sel:
                     ags[b].iterate(False)
                     ags[b].status()
-                    if ags[b].publish_requested(True):
-                        publish(b)
+            for b in range(NA):
+                if b != sel and ags[b].publish_requested(True):
+                    publish(b)
             ags[sel].iterate(True)
             ags[sel].status()
             ags[sel].opt_result()
@@ -341,7 +344,7 @@ def agent_api_leg(capi, mp, n, T, Y):
                                           text=True, timeout=300)
             j = json.loads(out.strip().splitlines()[-1])
             res[name]["ms_per_iterate_cxx"] = j["ms_per_iteration"]
-            res[name]["cxx_host_us"] = {k: j[k] for k in ("us_per_iterate_false", "us_per_iterate_true", "us_other_per_iteration", "us_report_wait")}
+            res[name]["cxx_host_us"] = {k: j[k] for k in ("us_per_iterate_false", "us_per_iterate_true", "us_other_per_iteration", "us_get_public_poses_per_iteration", "us_update_neighbor_poses_per_iteration", "us_report_wait")}
     except Exception as e:  # (the figure is additional: a box without g++ still gets the ctypes one)
         res["cxx_error"] = repr(e)
     return res
@@ -592,7 +595,27 @@ def host_cpu():
     return {"model": model, "logical_cores": os.cpu_count()}
 
 
+class stdout_to_stderr:
+    """RCCL prints a version banner on file descriptor 1 when a communicator is created; rank 0's stdout must carry ONE
+    JSON line.  Everything inside goes to stderr instead."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def multi_gpu(args):
+    with stdout_to_stderr():
+        return multi_gpu_impl(args)
+
+
+def multi_gpu_impl(args):
     import torch
     import torch.distributed as dist
     from dpgo_ros_amd import capi
@@ -903,14 +926,15 @@ def spawn_check():
     import torch.distributed as dist
     backend = os.environ.get("DPGO_BENCH_BACKEND", "nccl")
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    if backend == "nccl":
-        torch.cuda.set_device(int(os.environ["LOCAL_RANK"]))
-    dist.init_process_group(backend)
-    t = torch.tensor([float(rank + 1)], device="cuda" if backend == "nccl" else "cpu")
-    dist.all_reduce(t)
-    ranks = [None] * world
-    dist.all_gather_object(ranks, {"rank": rank, "local_rank": int(os.environ["LOCAL_RANK"]), "pid": os.getpid()})
-    dist.barrier()
+    with stdout_to_stderr():
+        if backend == "nccl":
+            torch.cuda.set_device(int(os.environ["LOCAL_RANK"]))
+        dist.init_process_group(backend)
+        t = torch.tensor([float(rank + 1)], device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t)
+        ranks = [None] * world
+        dist.all_gather_object(ranks, {"rank": rank, "local_rank": int(os.environ["LOCAL_RANK"]), "pid": os.getpid()})
+        dist.barrier()
     if rank == 0:
         print(json.dumps({"spawn_check": True, "world_size": world, "backend": backend, "sum_of_rank_plus_one": t.item(), "ranks": ranks}))
     dist.destroy_process_group()

@@ -87,7 +87,7 @@ dpgo_team_should_terminate dpgo_team_run_schedule dpgo_agent_compute_residuals d
 dpgo_agent_reset_acceleration dpgo_team_prepare dpgo_agent_read_partials dpgo_agent_preconditioner dpgo_agent_preconditioner_info dpgo_agent_preconditioner_residual dpgo_two_level_plan dpgo_agent_export_state dpgo_team_import_peer dpgo_team_export_mailbox dpgo_team_import_mailbox dpgo_team_run_peer dpgo_agent_read_rtr_handoff
 dpgo_comm_unique_id dpgo_comm_create dpgo_comm_destroy dpgo_comm_rank dpgo_comm_world dpgo_comm_library
 dpgo_comm_allreduce_sum dpgo_comm_allreduce_max dpgo_team_attach_comm dpgo_team_detach_comm dpgo_team_exchange_all_ranks
-dpgo_team_run_ranks dpgo_comm_global_cost dpgo_team_comm_counters""".split()
+dpgo_team_run_ranks dpgo_comm_global_cost dpgo_team_comm_counters dpgo_team_set_iteration_log""".split()
 
 
 class DpgoError(RuntimeError):
@@ -612,6 +612,10 @@ class Team:
         term, rounds = C.c_int(0), C.c_int(0)
         done = _chk(lib().dpgo_team_run_schedule(self.h, int(max_iters), C.byref(term), C.byref(rounds)), "run_schedule")
         return done, bool(term.value), rounds.value
+
+    def set_iteration_log(self, directory):
+        """one CSV per local robot in the reference's column order + global_cost (include/dpgo_hip.h); None closes"""
+        _chk(lib().dpgo_team_set_iteration_log(self.h, str(directory).encode() if directory is not None else None), "set_iteration_log")
 
     def run_simultaneous(self, ticks):
         """every agent takes `ticks` RGD steps, all agents per tick in the same launches (ASAPP, clocks in lockstep)"""

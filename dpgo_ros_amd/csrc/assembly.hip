@@ -490,7 +490,11 @@ int sync_descs_noflush(dpgo_team *t) {
   {
     size_t total = 0;
     size_t free_b = 0, total_b = 0;
-    (void)hipMemGetInfo(&free_b, &total_b);
+    // (the memory query is a driver call of several microseconds and this function opens every entry point of the
+    // per-agent API: asked only when something is about to be built)
+    bool will_build = false;
+    for (auto &a : t->ag) will_build = will_build || a->index_dirty || a->data_dirty;
+    if (will_build) (void)hipMemGetInfo(&free_b, &total_b);
     double budget = (double)free_b + 8.0 * (double)t->d_tmp.n;  // the scratch of an earlier pass is reused
     bool any_dirty = false;
     static const bool timing = std::getenv("DPGO_TIMING") != nullptr;

@@ -90,10 +90,13 @@ dpgo_team_t *dpgo_team_create(int device, const dpgo_params_t *p, int num_local,
   return t;
 }
 
+static void close_iteration_log(dpgo_team_t *t);
+
 void dpgo_team_destroy(dpgo_team_t *t) {
   if (!t) return;
   (void)hipSetDevice(t->device);
   (void)hipStreamSynchronize(t->stream);
+  close_iteration_log(t);
   release_fused_rtr_lock(t);
   if (t->rtr_lock_fd >= 0) { ::close(t->rtr_lock_fd); t->rtr_lock_fd = -1; }
   for (auto &kv : t->graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);
@@ -246,12 +249,15 @@ int dpgo_agent_get_X(dpgo_team_t *t, int id, int which, double *X) {
   return check_exchange_error(t);
 }
 
+static int finish_report(dpgo_team_t *t, Agent *a);
+
 int dpgo_agent_get_public_poses(dpgo_team_t *t, int id, int nbr, int aux, double *poses) {
   Agent *a = find_agent(t, id);
   if (!a) return DPGO_ERR;
   if (!a->has_X) return DPGO_NOT_READY;
   if (sync_descs_noflush(t)) return DPGO_ERR;  // (reads this agent's own poses: staged neighbour poses stay staged)
   if (a->d_pubframes.find(nbr) == a->d_pubframes.end()) return 0;
+  if (a->rep.pending && finish_report(t, a)) return DPGO_ERR;  // (the report of an iterate(false) carries these poses)
   if (a->pub_epoch != t->epoch) {
     // the wrapper asks per neighbour and per sequence (:666-668), right after an iterate: pack everything this agent
     // publishes (all neighbours, X and Y) into one buffer, ONE copy and ONE synchronisation; later calls are served
@@ -272,6 +278,19 @@ int dpgo_agent_get_public_poses(dpgo_team_t *t, int id, int nbr, int aux, double
       off += cnt;
     }
     a->pub_epoch = t->epoch;
+    a->pub_pinned = false;
+  }
+  if (a->pub_pinned) {
+    // layout of k_report / k_iterate_false: [8 scalars][X of every neighbour's public frames, neighbour order][Y likewise]
+    const size_t B = (size_t)4 * t->prm.r;
+    size_t off = 0;
+    for (auto &kv : a->d_pubframes) {
+      if (kv.first == nbr) break;
+      off += (size_t)a->n_pubframes[kv.first];
+    }
+    const double *src = a->h_down.p + 8 + ((size_t)((aux && !a->pub_one_seq) ? 1 : 0) * a->n_pub_all + off) * B;
+    std::memcpy(poses, src, sizeof(double) * (size_t)a->n_pubframes[nbr] * B);
+    return 0;
   }
   const std::vector<double> &c = a->pub_cache[aux ? 1 : 0][nbr];
   std::copy(c.begin(), c.end(), poses);
@@ -329,12 +348,80 @@ int dpgo_agent_unpack_neighbor_poses_device(dpgo_team_t *t, int id, int nbr, int
   return a->n_nbrslots[nbr];
 }
 
+// finish_report: wait for the sequence word of the agent's outstanding report and move what it carries into the host copies
+static int finish_report(dpgo_team_t *t, Agent *a) {
+  if (!a->rep.pending) return DPGO_OK;
+  const Agent::PendingReport rp = a->rep;
+  a->rep.pending = false;
+  const size_t npub = 2 * (size_t)a->n_pub_all * 4 * t->prm.r;
+  {
+    volatile unsigned long long *flag = reinterpret_cast<volatile unsigned long long *>(a->h_down.p);
+    unsigned long long spins = 0;
+    auto resync = [&]() {  // a report that never arrived must not leave the host one ahead of the device for good
+      a->report_seq = 0;
+      *flag = 0ull;
+      (void)hipMemsetAsync(a->d_report_seq.p, 0, 2 * sizeof(unsigned long long), t->stream);
+    };
+    while (*flag < rp.expect) {
+#if defined(__x86_64__) || defined(__i386__)
+      __builtin_ia32_pause();
+#else
+      std::this_thread::yield();
+#endif
+      if (++spins > (1ull << 26)) {  // (seconds: something is wrong -- let the runtime say what)
+        const hipError_t se = hipStreamSynchronize(t->stream);
+        if (se != hipSuccess || *flag < rp.expect) {
+          resync();
+          set_err(se != hipSuccess ? std::string("report kernel failed: ") + hipGetErrorString(se)
+                                   : std::string("report kernel did not deliver (sequence word not written)"));
+          return DPGO_ERR;
+        }
+      }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+  }
+  // diagnostics (dpgo_team_get_counters [5..6]): host time between the launch of a report and its arrival (us), reports
+  t->counters[5] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - rp.t_launch).count();
+  t->counters[6] += 1;
+  for (auto &b : t->ag) b->up_pending = false;  // this team's stream has drained past every upload enqueued before
+  release_fused_rtr_lock(t);                    // ... and past any one-launch solve (also when it timed out: the device lock
+                                                // must not stay with a team that is about to report an error)
+  if (check_exchange_error(t)) return DPGO_ERR;
+  if (a->opt_pending_rtr && refresh_rtr_result(t, *a, true)) return DPGO_ERR;  // (its record is in pinned memory already)
+  const double *out = a->h_down.p;
+  if (npub) {
+    // the getters answer straight from the pinned image while it is current (nothing enqueued on this team since the
+    // report's launch; a later report would rewrite it): no second host copy
+    a->pub_epoch = rp.epoch;
+    a->pub_pinned = true;
+    a->pub_one_seq = rp.one_seq;
+  }
+  if (rp.want_status) {
+    a->opt_rel_change = std::sqrt(out[1] / a->n);
+    a->opt_cached = true;
+  }
+  if (rp.want_opt) {
+    a->opt.success = 1;
+    a->opt.f_init = out[2]; a->opt.gradnorm_init = std::sqrt(out[3]);
+    a->opt.f_opt = out[4]; a->opt.gradnorm_opt = std::sqrt(out[5]);
+    a->opt.rtr_outer_iters = 0; a->opt.tcg_iters_total = 0; a->opt.hessvec_count = 0;
+    a->opt.precond_count = t->prm.rgd_use_preconditioner ? 1 : 0; a->opt.accepted = 1; a->opt.ls_backoffs = 0;
+    a->opt_pending_rgd = false;
+    if (read_ls_record(t, *a)) return DPGO_ERR;  // (line search: back-offs / accepted from the agent's scalars)
+  }
+  return DPGO_OK;
+}
+
 // Everything the wrapper asks for right after an iterate -- the public poses of all neighbours and both sequences
 // (:666-668), the status of the block update (:616) and the result of a local RGD solve (:169-172) -- is written by ONE
 // kernel behind the iterate's launches straight into pinned host memory, followed by a sequence word; the host polls
 // that word (no copy engine, no stream-wide wait) and the getters then answer from the host copies.
+// wait = false (iterate(false), src/PGOAgentROS.cpp:1183-1186): the report is only ENQUEUED -- nothing the wrapper reads
+// right after iterate(false) (publishStatus: the status of the last iterate(true), the iteration number) comes from it;
+// the first getter that needs its payload (get*SharedPoseDictWithNeighbor from runOnce, :109-113) waits for it, by which
+// time it has usually landed.
 static int report_after_iterate(dpgo_team_t *t, Agent *a, bool did_opt, bool advance, bool upload, bool one_seq = false,
-                                bool whole_iterate_false = false) {
+                                bool whole_iterate_false = false, bool wait = true) {
   const size_t B = (size_t)4 * t->prm.r;
   const size_t npub = 2 * (size_t)a->n_pub_all * B;
   const bool want_status = did_opt && !t->prm.status_every_iterate && (a->opt_rel_src == 1 || a->opt_rel_src == 5);
@@ -342,6 +429,10 @@ static int report_after_iterate(dpgo_team_t *t, Agent *a, bool did_opt, bool adv
   const int scnt = want_status ? (tiles ? (a->n + 63) / 64 : precond_nblk(*a)) : 0;
   const int ppb = 64 / t->prm.r, nb = (a->n + ppb - 1) / ppb;
   const bool want_opt = did_opt && a->opt_pending_rgd;
+  // (an earlier report nobody asked for is superseded: this one rewrites the same pinned image behind it on the stream;
+  // the image may only be re-allocated once the stream is past the earlier kernel)
+  if (a->rep.pending && 8 + npub > a->h_down.n && finish_report(t, a)) return DPGO_ERR;
+  a->rep.pending = false;
   if (a->h_down.alloc(8 + npub, true)) { set_err("pinned allocation failed"); return DPGO_ERR; }
   if (!a->d_report_seq.p) {
     if (a->d_report_seq.alloc(2)) { set_err("device allocation failed"); return DPGO_ERR; }
@@ -360,67 +451,9 @@ static int report_after_iterate(dpgo_team_t *t, Agent *a, bool did_opt, bool adv
   launch_report(t->ctx(), a->local, a->d_pub_all.p, a->n_pub_all, a->h_down.p, tiles ? PART_E : PART_B + 2, scnt, PART_STRIDE,
                 want_opt ? nb : 0, a->d_report_seq.p, advance ? 1 : 0, t->prm.acceleration, t->prm.num_robots,
                 t->prm.restart_interval, a->h_up_idx.p, a->h_up.p, up0, up1, one_seq ? 1 : 0);
-  {
-    volatile unsigned long long *flag = reinterpret_cast<volatile unsigned long long *>(a->h_down.p);
-    unsigned long long spins = 0;
-    auto resync = [&]() {  // a report that never arrived must not leave the host one ahead of the device for good
-      a->report_seq = 0;
-      *flag = 0ull;
-      (void)hipMemsetAsync(a->d_report_seq.p, 0, 2 * sizeof(unsigned long long), t->stream);
-    };
-    while (*flag < expect) {
-#if defined(__x86_64__) || defined(__i386__)
-      __builtin_ia32_pause();
-#else
-      std::this_thread::yield();
-#endif
-      if (++spins > (1ull << 26)) {  // (seconds: something is wrong -- let the runtime say what)
-        const hipError_t se = hipStreamSynchronize(t->stream);
-        if (se != hipSuccess || *flag < expect) {
-          resync();
-          set_err(se != hipSuccess ? std::string("report kernel failed: ") + hipGetErrorString(se)
-                                   : std::string("report kernel did not deliver (sequence word not written)"));
-          return DPGO_ERR;
-        }
-      }
-    }
-    std::atomic_thread_fence(std::memory_order_acquire);
-  }
-  // diagnostics (dpgo_team_get_counters [5..6]): host time between the launch of a report and its arrival (us), reports
-  t->counters[5] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tq0).count();
-  t->counters[6] += 1;
-  for (auto &b : t->ag) b->up_pending = false;  // this team's stream has drained past every upload enqueued before
-  release_fused_rtr_lock(t);                    // ... and past any one-launch solve (also when it timed out: the device lock
-                                                // must not stay with a team that is about to report an error)
-  if (check_exchange_error(t)) return DPGO_ERR;
-  if (a->opt_pending_rtr && refresh_rtr_result(t, *a, true)) return DPGO_ERR;  // (its record is in pinned memory already)
-  const double *out = a->h_down.p, *pub = out + 8;
-  if (npub) {
-    size_t off = 0;
-    for (auto &kv : a->d_pubframes) {
-      const size_t cnt = (size_t)a->n_pubframes[kv.first];
-      for (int s = 0; s < 2; ++s) {
-        const double *src = pub + ((size_t)(one_seq ? 0 : s) * a->n_pub_all + off) * B;
-        a->pub_cache[s][kv.first].assign(src, src + cnt * B);
-      }
-      off += cnt;
-    }
-    a->pub_epoch = t->epoch;
-  }
-  if (want_status) {
-    a->opt_rel_change = std::sqrt(out[1] / a->n);
-    a->opt_cached = true;
-  }
-  if (want_opt) {
-    a->opt.success = 1;
-    a->opt.f_init = out[2]; a->opt.gradnorm_init = std::sqrt(out[3]);
-    a->opt.f_opt = out[4]; a->opt.gradnorm_opt = std::sqrt(out[5]);
-    a->opt.rtr_outer_iters = 0; a->opt.tcg_iters_total = 0; a->opt.hessvec_count = 0;
-    a->opt.precond_count = t->prm.rgd_use_preconditioner ? 1 : 0; a->opt.accepted = 1; a->opt.ls_backoffs = 0;
-    a->opt_pending_rgd = false;
-    if (read_ls_record(t, *a)) return DPGO_ERR;  // (line search: back-offs / accepted from the agent's scalars)
-  }
-  return DPGO_OK;
+  a->rep.pending = true; a->rep.expect = expect; a->rep.epoch = t->epoch; a->rep.one_seq = one_seq;
+  a->rep.want_status = want_status; a->rep.want_opt = want_opt; a->rep.t_launch = tq0;
+  return wait ? finish_report(t, a) : DPGO_OK;
 }
 
 int dpgo_agent_iterate(dpgo_team_t *t, int id, int do_optimization) {
@@ -456,7 +489,10 @@ int dpgo_agent_iterate(dpgo_team_t *t, int id, int do_optimization) {
     // (an accelerated iterate(false) leaves X = Y at every pose: one sequence crosses the bus)
     // (what updateNeighborPoses staged stays on the host across iterate(false) calls -- nothing reads the slabs until
     // this agent's next iterate(true), whose first launch scatters the latest value of every slot)
-    const int rr = report_after_iterate(t, a, opt, true, defer_upload && !one_launch, !do_optimization && t->prm.acceleration, one_launch);
+    // iterate(false) only ENQUEUES its report (see report_after_iterate); iterate(true) waits: the wrapper reads
+    // mLocalOptResult and the status right behind it (:160-172)
+    const int rr = report_after_iterate(t, a, opt, true, defer_upload && !one_launch, !do_optimization && t->prm.acceleration, one_launch,
+                                        do_optimization != 0);
     if (rr) return rr;
   }
   return a->last_success ? DPGO_OK : DPGO_NOT_READY;
@@ -1461,6 +1497,56 @@ int dpgo_team_should_terminate(dpgo_team_t *t) {
   return 1;
 }
 
+// ---- per-iteration log.  The reference's wrapper writes one CSV per robot -- a header (createIterationLog,
+// src/PGOAgentROS.cpp:853-867), one row after every iterate(true) of the robot (logIteration, :869-894, called at :189),
+// and the strings UPDATE_WEIGHT (:1217) / TERMINATE (:1042) when those commands arrive.  Same columns in the same order here,
+// followed by the global cost the reference lacks.
+static void close_iteration_log(dpgo_team_t *t) {
+  for (FILE *f : t->ilog.f) if (f) std::fclose(f);
+  t->ilog.f.clear();
+  t->ilog.bytes_received.clear();
+}
+
+int dpgo_team_set_iteration_log(dpgo_team_t *t, const char *directory) {
+  close_iteration_log(t);
+  if (!directory) return DPGO_OK;
+  for (auto &a : t->ag) {
+    const std::string path = std::string(directory) + "/dpgo_log_robot" + std::to_string(a->id) + ".csv";
+    FILE *f = std::fopen(path.c_str(), "w");
+    if (!f) { close_iteration_log(t); set_err("cannot open " + path); return DPGO_ERR; }
+    std::fputs("robot_id, cluster_id, num_active_robots, iteration, num_poses, bytes_received, "
+               "iter_time_sec, total_time_sec, rel_change, global_cost \n", f);
+    std::fflush(f);
+    t->ilog.f.push_back(f);
+  }
+  t->ilog.bytes_received.assign(t->ag.size(), 0.0);
+  t->ilog.t0 = std::chrono::steady_clock::now();
+  return DPGO_OK;
+}
+
+static void log_string_all(dpgo_team_t *t, const char *s) {
+  for (FILE *f : t->ilog.f) { std::fputs(s, f); std::fputc('\n', f); std::fflush(f); }
+}
+
+// one row in the log of the robot that just optimized (local index sel), after the stream has drained
+static int log_iteration_row(dpgo_team_t *t, int sel, double iter_sec) {
+  Agent &a = *t->ag[sel];
+  dpgo_status_t st;
+  if (dpgo_agent_get_status(t, a.id, &st) != DPGO_OK) return DPGO_ERR;
+  double f = 0;
+  if (dpgo_team_cost(t, &f)) return DPGO_ERR;
+  // what a PublicPoses message per neighbour and sequence would have carried for this block update (msg/PublicPoses.msg:
+  // float64[] of r x 4 per pose; the reference counts the serialized message, :1283)
+  const int nseq = t->prm.acceleration ? 2 : 1;
+  t->ilog.bytes_received[sel] += 8.0 * 4 * t->prm.r * (double)a.np.size() * nseq;
+  const double total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t->ilog.t0).count();
+  FILE *fp = t->ilog.f[sel];
+  std::fprintf(fp, "%d,%d,%d,%d,%d,%.0f,%.9g,%.9g,%.17g,%.17g\n", a.id, 0, t->prm.num_robots, a.iter, a.n, t->ilog.bytes_received[sel],
+               iter_sec, total, st.relative_change, f);
+  std::fflush(fp);
+  return DPGO_OK;
+}
+
 int dpgo_team_run_schedule(dpgo_team_t *t, int max_iters, int *terminated, int *weight_rounds) {
   if (sync_descs(t)) return DPGO_ERR;
   auto itl = t->id2local.find(0);
@@ -1476,14 +1562,29 @@ int dpgo_team_run_schedule(dpgo_team_t *t, int max_iters, int *terminated, int *
     while (t->sched[(t->iter + chunk - 1) % len] != lead) ++chunk;
     const bool reaches_leader = chunk <= max_iters - done;
     chunk = std::min(chunk, max_iters - done);
-    const int rc = dpgo_team_run(t, chunk);
-    if (rc) return rc;
+    if (t->ilog.f.empty()) {
+      const int rc = dpgo_team_run(t, chunk);
+      if (rc) return rc;
+    } else {
+      // logging: one iteration per host round trip, a row in the log of the robot that optimized
+      for (int q = 0; q < chunk; ++q) {
+        const int sel = t->sched[t->iter % len];
+        const auto a0 = std::chrono::steady_clock::now();
+        int rc = dpgo_team_run(t, 1);
+        if (rc) return rc;
+        rc = dpgo_team_synchronize(t);
+        if (rc) return rc;
+        const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - a0).count();
+        if (log_iteration_row(t, sel, sec)) return DPGO_ERR;
+      }
+    }
     done += chunk;
     if (!reaches_leader) break;
     const int st = dpgo_team_should_terminate(t);
     if (st < 0) return st;
-    if (st) { term = 1; break; }
+    if (st) { term = 1; if (!t->ilog.f.empty()) log_string_all(t, "TERMINATE"); break; }
     if (dpgo_agent_should_update_weights(t, 0) == 1) {
+      if (!t->ilog.f.empty()) log_string_all(t, "UPDATE_WEIGHT");
       const int wr = dpgo_team_update_weights(t);
       if (wr < 0) return wr;
       ++rounds;

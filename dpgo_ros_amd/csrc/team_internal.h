@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -145,6 +146,7 @@ struct Agent {
   // are fetched with ONE copy and served from this cache until the team launches anything again; neighbour poses
   // handed over by updateNeighborPoses are staged here and uploaded with one copy at the next use
   unsigned long long pub_epoch = 0;
+  bool pub_pinned = false, pub_one_seq = false;  // the current public poses sit in the pinned report image (h_down), not in pub_cache
   std::map<int, std::vector<double>> pub_cache[2];
   std::vector<int> stage_slots[2];
   std::vector<int> stage_pos[2];  // [slot] position of a staged pose in stage_slots / stage_data, -1: not staged
@@ -156,6 +158,12 @@ struct Agent {
   DevBuf<unsigned long long> d_report_seq;  // [0] sequence number of the agent's reports (device side), [1] tile ticket of k_iterate_false
   DevBuf<int> d_pubpos_ptr, d_pubpos;       // per public pose: its places in the packed report (one per neighbour sharing it)
   unsigned long long report_seq = 0;        // ... and what the host expects next
+  // a report that was enqueued and not yet read (iterate(false) does not wait for its own): what to look for and what it carries
+  struct PendingReport {
+    bool pending = false, one_seq = false, want_status = false, want_opt = false;
+    unsigned long long expect = 0, epoch = 0;
+    std::chrono::steady_clock::time_point t_launch{};
+  } rep;
   int opt_rel_src = -1;
   bool opt_success = false, opt_cached = false;
   double opt_ratio = 1.0, opt_rel_change = 0.0;
@@ -257,6 +265,13 @@ struct dpgo_team {
                                                               // advanced the team in between invalidates `sent`)
     double counters[4] = {0, 0, 0, 0};                        // messages sent / received, bytes sent / received (this rank)
   } rx;
+  // per-iteration log: one CSV per local robot in the reference's column order (src/PGOAgentROS.cpp:863-864,
+  // 883-891) + global_cost; written by dpgo_team_run_schedule, which then runs one iteration per host round trip
+  struct IterLog {
+    std::vector<FILE *> f;                 // [local agent], empty: logging off
+    std::vector<double> bytes_received;    // [local agent] public-pose payload its block updates have consumed so far
+    std::chrono::steady_clock::time_point t0{};
+  } ilog;
   bool isolated = false;  // no neighbour is read in place, co-resident ones included (rx.loopback)
   unsigned long long epoch = 1;  // bumped by everything that enqueues device work (every launch goes through ctx())
   dpgo::LaunchCtx ctx() {

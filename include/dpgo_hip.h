@@ -264,6 +264,13 @@ int dpgo_team_should_terminate(dpgo_team_t *t);
  * shouldUpdateMeasurementWeights() (:210), else pass the token (:213).  Returns the number of iterations executed
  * (<= max_iters) or <0; *terminated / *weight_rounds may be NULL. */
 int dpgo_team_run_schedule(dpgo_team_t *t, int max_iters, int *terminated, int *weight_rounds);
+/* per-iteration log (createIterationLog / logIteration / logString, src/PGOAgentROS.cpp:853-909): one CSV per
+ * local robot, <directory>/dpgo_log_robot<id>.csv, the reference's header and column order -- robot_id, cluster_id,
+ * num_active_robots, iteration, num_poses, bytes_received, iter_time_sec, total_time_sec, rel_change -- followed by
+ * global_cost; a row after every block update of the robot (:189), the strings UPDATE_WEIGHT (:1217) and TERMINATE (:1042)
+ * in every robot's file.  Written by dpgo_team_run_schedule, which runs one iteration per host round trip while a log is
+ * open.  directory = NULL closes the files. */
+int dpgo_team_set_iteration_log(dpgo_team_t *t, const char *directory);
 /* refresh this agent's neighbour slabs from co-resident agents (device-to-device) */
 int dpgo_agent_pull_local(dpgo_team_t *t, int id);
 /* average HIP-event duration of one launch of a hot kernel on the team stream.

@@ -1,7 +1,8 @@
 // agent_api_bench.cpp -- the drop-in path timed from C++ (no interpreter in the loop): one single-agent team per
 // robot, the way the ROS wrapper runs one PGOAgent per process; every RBCD iteration is
-//   iterate(false) + getStatus + [get*SharedPoseDictWithNeighbor -> updateNeighborPoses of the neighbours] on every robot
-//   but the token holder, then iterate(true) + getStatus + mLocalOptResult + publish on the token holder
+//   iterate(false) + getStatus on every robot but the token holder (concurrent processes in the reference: all of them
+//   first), then their [get*SharedPoseDictWithNeighbor -> updateNeighborPoses of the neighbours], then
+//   iterate(true) + getStatus + mLocalOptResult + publish on the token holder
 // (src/PGOAgentROS.cpp:109-113,160,183-186,616,662-690,1255-1284), all exchange through HOST buffers.
 // Usage: agent_api_bench <g2o> <robots> <method 0 RTR | 1 RGD> <accel> <iterations> [stepsize] [restart] [gradnorm_tol]
 // Prints one JSON object.  Used by bench.py (convergence.agent_api.*.ms_per_iterate_cxx) and tests/test_facade.py.
@@ -59,12 +60,17 @@ int main(int argc, char **argv) {
     }
   }
   buf.resize(maxp * 4 * r);
+  double t_get = 0, t_upd = 0;
   auto publish = [&](int b) -> int {
     for (size_t q = 0; q < nbrs[b].size(); ++q) {
       const int c = nbrs[b][q];
       for (int aux = 0; aux <= (accel ? 1 : 0); ++aux) {
+        const auto g0 = std::chrono::steady_clock::now();
         CK(dpgo_agent_get_public_poses(team[b], b, c, aux, buf.data()));
+        const auto g1 = std::chrono::steady_clock::now();
         CK(dpgo_agent_update_neighbor_poses(team[c], c, b, aux, (int)ids[b][q].size(), ids[b][q].data(), buf.data()));
+        t_get += std::chrono::duration<double, std::micro>(g1 - g0).count();
+        t_upd += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - g1).count();
       }
     }
     return 0;
@@ -79,6 +85,10 @@ int main(int argc, char **argv) {
   auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
     return std::chrono::duration<double, std::micro>(b - a).count();
   };
+  // The robots are separate processes in the reference: on an UPDATE command every robot but the token holder runs
+  // iterate(false) + publishStatus AT THE SAME TIME (:1183-1186), then publishes from its own runOnce (:109-113).  This
+  // single thread plays one valid interleaving of that: every robot's iterate(false) + getStatus first (iterate(false)
+  // only enqueues -- its kernels run side by side on the robots' streams), then every robot's publish.
   auto iteration = [&](int k) -> int {
     const int sel = k % N;
     for (int b = 0; b < N; ++b) {
@@ -87,6 +97,9 @@ int main(int argc, char **argv) {
       CK(dpgo_agent_iterate(team[b], b, 0));
       t_false += us(a0, now());
       CK(dpgo_agent_get_status(team[b], b, &st));
+    }
+    for (int b = 0; b < N; ++b) {
+      if (b == sel) continue;
       if (dpgo_agent_publish_requested(team[b], b, 1) > 0 && publish(b)) return 1;
     }
     const auto a0 = now();
@@ -100,7 +113,7 @@ int main(int argc, char **argv) {
   };
   const int warm = 2 * N;
   for (int k = 0; k < warm; ++k) if (iteration(k)) return 1;
-  t_false = t_true = 0;
+  t_false = t_true = 0; t_get = t_upd = 0;
   const auto t0 = std::chrono::steady_clock::now();
   for (int k = warm; k < warm + iters; ++k) if (iteration(k)) return 1;
   for (int a = 0; a < N; ++a) CK(dpgo_team_synchronize(team[a]));
@@ -121,8 +134,8 @@ int main(int argc, char **argv) {
     for (double v : Xa) checksum += std::fabs(v);
   }
   std::printf("{\"ms_per_iteration\": %.6f, \"iterations\": %d, \"us_per_iterate_false\": %.2f, \"us_per_iterate_true\": %.2f, "
-              "\"us_other_per_iteration\": %.2f, \"us_report_wait\": %.2f, \"f_opt_last\": %.12g, \"relchange_sum\": %.12g, \"checksum\": %.15g}\n",
-              ms, iters, t_false / ((double)iters * (N - 1)), t_true / iters, 1e3 * ms - (t_false + t_true) / iters, reports > 0 ? wait_us / reports : 0.0, res.f_opt, rel_sum,
+              "\"us_other_per_iteration\": %.2f, \"us_get_public_poses_per_iteration\": %.2f, \"us_update_neighbor_poses_per_iteration\": %.2f, \"us_report_wait\": %.2f, \"f_opt_last\": %.12g, \"relchange_sum\": %.12g, \"checksum\": %.15g}\n",
+              ms, iters, t_false / ((double)iters * (N - 1)), t_true / iters, 1e3 * ms - (t_false + t_true) / iters, t_get / iters, t_upd / iters, reports > 0 ? wait_us / reports : 0.0, res.f_opt, rel_sum,
               checksum);
   for (int a = 0; a < N; ++a) dpgo_team_destroy(team[a]);
   dpgo_free(m);

@@ -201,3 +201,57 @@ def test_iterate_true_with_a_missing_neighbour_pose_keeps_x(accel, restart):
         assert not sh.ready_to_terminate and not so.ready_to_terminate
         assert abs(sh.relative_change - so.relative_change) < 1e-12 and sh.iteration_number == so.iteration_number
     th.close()
+
+
+def test_iteration_log_of_a_real_gnc_run(tmp_path):
+    """dpgo_team_run_schedule writes the reference's per-robot iteration log (createIterationLog /
+    logIteration / logString, src/PGOAgentROS.cpp:853-909) -- same header text, same column order, one row per block
+    update of the robot, the UPDATE_WEIGHT / TERMINATE strings in every robot's file -- plus global_cost.  The logged run
+    must be the un-logged run (same iterates, same decisions), and every logged figure must be the solver's own."""
+    N = 3
+    m, _, n = load("smallGrid3D", 1)
+    mo = add_outliers(m, n, frac=0.1, seed=0)
+    mp = O.partition(mo, n, N)
+    T, Y = O.odometry_init(mo, n), O.fixed_stiefel(5)
+    kw = dict(r=5, num_robots=N, method=capi.METHOD_RTR, gradnorm_tol=1e-2, robust_cost_type=capi.COST_GNC_TLS,
+              gnc_barc=3.0, gnc_mu_step=2.0, gnc_init_mu=1e-2, robust_opt_num_weight_updates=3,
+              robust_opt_inner_iters=2 * N, robust_opt_min_convergence_ratio=0.97, rel_change_tol=0.05, max_num_iters=200)
+    ph, po = params_pair(**kw)
+    plain = capi.Team.from_measurements(mp.view(capi.MEAS_DTYPE), ph)
+    plain.set_initial(T, Y)
+    r_plain = plain.run_schedule(300)
+    logged = capi.Team.from_measurements(mp.view(capi.MEAS_DTYPE), ph)
+    logged.set_initial(T, Y)
+    logged.set_iteration_log(tmp_path)
+    r_log = logged.run_schedule(300)
+    assert r_log == r_plain and r_log[1] and r_log[2] == 3
+    assert np.array_equal(logged.global_X(), plain.global_X())
+    final_cost = logged.cost()
+    logged.set_iteration_log(None)
+    ref_header = ("robot_id, cluster_id, num_active_robots, iteration, num_poses, bytes_received, "
+                  "iter_time_sec, total_time_sec, rel_change")  # src/PGOAgentROS.cpp:863-864, verbatim
+    rows_total, last = 0, None
+    for a in range(N):
+        lines = open(os.path.join(tmp_path, "dpgo_log_robot%d.csv" % a)).read().split("\n")
+        assert lines[0] == ref_header + ", global_cost "
+        body = [l for l in lines[1:] if l]
+        assert body.count("UPDATE_WEIGHT") == 3 and body[-1] == "TERMINATE" and body.count("TERMINATE") == 1
+        rows = [l.split(",") for l in body if l[0].isdigit()]
+        assert all(len(r) == 10 for r in rows)
+        its = [int(r[3]) for r in rows]
+        # robot a optimizes in global iterations a + 1, a + 1 + N, ...: its iteration_number() at those moments
+        assert its == [a + 1 + N * k for k in range(len(rows))]
+        assert all(int(r[0]) == a and int(r[1]) == 0 and int(r[2]) == N and int(r[4]) == logged.agents[a].n for r in rows)
+        br = [float(r[5]) for r in rows]
+        assert br[0] > 0 and all(y > x for x, y in zip(br, br[1:]))  # cumulative payload received
+        tt = [float(r[7]) for r in rows]
+        assert all(y >= x for x, y in zip(tt, tt[1:])) and all(float(r[6]) > 0 for r in rows)
+        st = logged.agents[a].status()
+        assert abs(float(rows[-1][8]) - st.relative_change) <= 1e-15 * max(1.0, st.relative_change)
+        rows_total += len(rows)
+        if last is None or its[-1] > last[0]:
+            last = (its[-1], float(rows[-1][9]))
+    assert rows_total == r_log[0]            # one row per global iteration, in the file of the robot that optimized
+    assert abs(last[1] - final_cost) <= 1e-12 * abs(final_cost)   # the last row's global_cost is the final cost
+    plain.close()
+    logged.close()
