@@ -145,9 +145,25 @@ def single_gpu(args):
     c0 = time.perf_counter()
     Tch = capi.chordal_init(m, n)  # (timed on the second call: the first one loads the code objects)
     conv["chordal_init_ms"] = (time.perf_counter() - c0) * 1e3
-    # RGD legs: the gap is checked every 100 iterations until it is below 3e-6, then after every iteration
-    for name, cfg, cap, T0, coarse in (("rgd_nesterov", RGD, 20000, T, 100), ("rgd_nesterov_chordal_init", RGD, 20000, Tch, 100),
-                                       ("rtr_nesterov", RTR, 1500, T, 1), ("rtr_nesterov_chordal_init", RTR, 1500, Tch, 1)):
+    c0 = time.perf_counter()
+    capi.odometry_init(m, n)
+    odo_ms = (time.perf_counter() - c0) * 1e3
+    # the CPU restatement's initialisations beside them (its chordal relaxation is a sparse Cholesky solve, one core)
+    from oracle import oracle as O_
+    mo_, no_ = O_.read_g2o(os.path.join(ROOT, "data", WORKLOAD["dataset"] + ".g2o"))
+    c0 = time.perf_counter()
+    O_.chordal_init(mo_, no_)
+    conv["chordal_init_cpu_ms"] = (time.perf_counter() - c0) * 1e3
+    c0 = time.perf_counter()
+    O_.odometry_init(mo_, no_)
+    odo_cpu_ms = (time.perf_counter() - c0) * 1e3
+    # Four routes to the 1e-6 relative cost gap.  First pass: WHERE the gap is reached (checked every 100 iterations until
+    # it is below 3e-6, then after every iteration; RTR: every iteration).  Second pass: a fresh team runs exactly that many
+    # iterations as ONE call between two synchronisations -- ms_to_relcost_1e-6 = initialisation + that run.
+    for name, cfg, cap, T0, coarse, init_ms in (("rgd_nesterov", RGD, 20000, T, 100, odo_ms), ("rgd_nesterov_chordal_init", RGD, 20000, Tch, 100, None),
+                                                ("rtr_nesterov", RTR, 1500, T, 1, odo_ms), ("rtr_nesterov_chordal_init", RTR, 1500, Tch, 1, None)):
+        if init_ms is None:
+            init_ms = conv["chordal_init_ms"]
         p2 = capi.default_params(r=WORKLOAD["r"], num_robots=WORKLOAD["num_robots"], **cfg)
         t2 = capi.Team.from_measurements(mp, p2, device=0)
         t2.set_initial(T0, Y)
@@ -167,10 +183,50 @@ def single_gpu(args):
         conv[name] = {"iters_to_relcost_1e-6": hit, "relcost_at_stop": gap, "iters_run": k,
                       "ms_per_iter_synced": tt / k * 1e3}
         t2.close()
+        if hit:
+            t2 = capi.Team.from_measurements(mp, p2, device=0)
+            t2.set_initial(T0, Y)
+            t2.prepare(hit)
+            t2.synchronize()
+            a0 = time.perf_counter()
+            t2.run(hit)
+            t2.synchronize()
+            run_ms = (time.perf_counter() - a0) * 1e3
+            gap2 = (t2.cost() - fstar) / fstar
+            t2.close()
+            conv[name].update({"init_ms": init_ms, "run_ms": run_ms, "ms_to_relcost_1e-6": init_ms + run_ms,
+                               "relcost_after_timed_run": gap2})
+    conv["_init"] = {"odometry_init_ms": odo_ms, "odometry_init_cpu_ms": odo_cpu_ms}
 
+    conv["rgd_nesterov_restart_50"] = restart50_leg(capi, mp, n, T, Y, fstar)
     conv["rgd_nesterov_line_search"] = line_search_leg(capi, mp, T, Y, fstar)
     cpu = cpu_baseline(mp, n, T, Y)
     cpu["rtr_nesterov"] = cpu_baseline(mp, n, T, Y, cfg=RTR, seconds=6.0)
+    # the CPU restatement's time to the same gap beside each route: the iteration counts are the GPU's (the iterates agree to
+    # 1e-10, tests/test_gpu_parity.py), the per-iteration time is the bounded sample's -- except the shortest route, which is
+    # run to the gap for real
+    for name, cfg, init_key in (("rgd_nesterov", None, "odometry_init_cpu_ms"), ("rgd_nesterov_chordal_init", None, "chordal"),
+                                ("rtr_nesterov", "rtr", "odometry_init_cpu_ms"), ("rtr_nesterov_chordal_init", "rtr", "chordal")):
+        hit = conv[name].get("iters_to_relcost_1e-6")
+        if not hit:
+            continue
+        per = cpu["rtr_nesterov"]["value"] if cfg == "rtr" else cpu["value"]
+        init_cpu = conv["chordal_init_cpu_ms"] if init_key == "chordal" else conv["_init"][init_key]
+        conv[name]["cpu_ms_to_relcost_1e-6"] = {"value": init_cpu + hit * per, "kind": "port", "cores": 1,
+                                                "how": "initialisation measured + %d iterations x %.3f ms (bounded sample)" % (hit, per)}
+    hit = conv["rtr_nesterov_chordal_init"].get("iters_to_relcost_1e-6")
+    if hit:
+        po_ = O_.default_params(r=WORKLOAD["r"], num_robots=WORKLOAD["num_robots"], **RTR)
+        to_ = O_.Team(mp.view(O_.MEAS_DTYPE), n, po_)
+        a0 = time.perf_counter()
+        Tc_ = O_.chordal_init(mo_, no_)
+        to_.set_initial(Tc_, Y)
+        for _ in range(hit):
+            to_.iterate()
+        cpu_total = (time.perf_counter() - a0) * 1e3
+        conv["rtr_nesterov_chordal_init"]["cpu_ms_to_relcost_1e-6"] = {
+            "value": cpu_total, "kind": "port", "cores": 1, "relcost": (to_.cost() - fstar) / fstar,
+            "how": "measured end to end: chordal initialisation + %d iterations of the oracle" % hit}
     team.close()
     conv["rtr_nesterov"]["timed"] = rtr
     conv["config2_sphere2500_8_agents_rtr"] = config2_leg(capi, m, n, T, Y)
@@ -203,6 +259,41 @@ def single_gpu(args):
     conv["asapp_tunnels"] = asapp_leg(capi)
     conv["gnc_torus3D"] = gnc_leg(capi)
     return ms, roof, conv, cpu, counters, timing
+
+
+def restart50_leg(capi, mp, n, T, Y, fstar):
+    """The launch-default restart interval 50 (launch/PGOAgent.launch:25) with the largest step of the sweep in
+    profiles/experiments/restart50_sweep.py that converges on this problem: 0.18 (0.2, the README's value, diverges at
+    restart 50 on the GPU and on the oracle alike -- the reason the headline keeps restart 20).  GPU to the gap; the oracle
+    beside it for a bounded number of iterations from the same guess (cost after them on both sides)."""
+    from oracle import oracle as O
+    cfg = dict(RGD, restart_interval=50, rgd_stepsize=0.18)
+    t = capi.Team.from_measurements(mp, capi.default_params(r=WORKLOAD["r"], num_robots=WORKLOAD["num_robots"], **cfg), device=0)
+    t.set_initial(T, Y)
+    check = 400
+    t.run(check)
+    t.synchronize()
+    f_gpu = t.cost()
+    hit, gap, k, tt = None, float("inf"), check, 0.0
+    while k < 30000:
+        a0 = time.perf_counter()
+        t.run(100)
+        t.synchronize()
+        tt += time.perf_counter() - a0
+        k += 100
+        gap = (t.cost() - fstar) / fstar
+        if gap <= 1e-6:
+            hit = k
+            break
+    t.close()
+    to = O.Team(mp.view(O.MEAS_DTYPE), n, O.default_params(r=WORKLOAD["r"], num_robots=WORKLOAD["num_robots"], **cfg))
+    to.set_initial(T, Y)
+    for _ in range(check):
+        to.iterate()
+    f_cpu = to.cost()
+    return {"rgd_stepsize": 0.18, "restart_interval": 50, "iters_to_relcost_1e-6": hit, "relcost_at_stop": gap,
+            "ms_per_iter": tt / max(k - check, 1) * 1e3, "oracle_check": {"iterations": check, "cost_gpu": f_gpu, "cost_oracle": f_cpu,
+                                                                          "rel_diff": abs(f_gpu - f_cpu) / abs(f_cpu)}}
 
 
 def line_search_leg(capi, mp, T, Y, fstar):
@@ -963,7 +1054,11 @@ def main():
     force_dist = os.environ.get("DPGO_BENCH_FORCE_DIST") == "1"  # exercise the N > 1 driver with one rank
     if args.gpus <= 1 and int(os.environ.get("WORLD_SIZE", "1")) <= 1 and not force_dist:
         ms, roof, conv, cpu, counters, timing = single_gpu(args)
-        out.update({"value": ms, "ms_per_step": ms, "timing": timing, "roofline": roof, "cpu_baseline": cpu, "convergence": conv,
+        out["config"]["value_is"] = ("ms per step of ONE run of R x K steps (R x K >= 2000: at least 50 ms of replays) between two "
+                                     "synchronisations; the single K-step region of the contract is ms_per_step_k_region")
+        out.update({"value": ms, "ms_per_step": ms, "ms_per_step_k_region": timing["ms_per_step_single_run_of_K"],
+                    "ms_per_step_k_region_mean_of_15": timing["ms_per_step_runs_of_K"]["mean"],
+                    "timing": timing, "roofline": roof, "cpu_baseline": cpu, "convergence": conv,
                     "iters_to_relcost_1e-6": conv["rgd_nesterov"]["iters_to_relcost_1e-6"],
                     "counters": {"precond_launches": counters[0], "precond_bytes": counters[1],
                                  "spmm_launches": counters[2], "spmm_bytes": counters[3], "iterations": counters[4],

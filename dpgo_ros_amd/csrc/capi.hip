@@ -246,6 +246,7 @@ int dpgo_agent_get_X(dpgo_team_t *t, int id, int which, double *X) {
   HIPC(hipMemcpyAsync(X, a->dev.buf[map[which]], sizeof(double) * (size_t)t->prm.r * 4 * a->n, hipMemcpyDeviceToHost,
                       t->stream));
   HIPC(hipStreamSynchronize(t->stream));
+  release_fused_rtr_lock(t);  // (the stream has drained: another team of this device may take the one-launch solve)
   return check_exchange_error(t);
 }
 
@@ -1404,6 +1405,7 @@ int dpgo_team_cost(dpgo_team_t *t, double *f) {
   for (auto &a : t->ag)
     HIPC(hipMemcpyAsync(t->h_scal + 16 * (size_t)a->local, a->dev.scal, sizeof(double) * 16, hipMemcpyDeviceToHost, t->stream));
   HIPC(hipStreamSynchronize(t->stream));
+  release_fused_rtr_lock(t);
   if (check_exchange_error(t)) return DPGO_ERR;
   for (auto &a : t->ag) total += t->h_scal[16 * (size_t)a->local + 5];  // (agent order: the sum is what it was)
   *f = total;

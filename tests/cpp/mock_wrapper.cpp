@@ -26,6 +26,32 @@ class MockAgentROS : public PGOAgent {
   void setIteration(unsigned k) { mIterationNumber = k; }
   bool hasYLift() const { return YLift.has_value(); }
   void reset() override { PGOAgent::reset(); }
+  // the wrapper's own iteration log (src/PGOAgentROS.cpp:853-909), fed from the SAME facade members it reads there:
+  // getID(), numActiveRobots(), iteration_number(), num_poses(), mStatus.relativeChange, mParams.logData / logDirectory
+  bool openLog() {
+    if (!mParams.logData) return false;
+    log_ = std::fopen((mParams.logDirectory + "dpgo_log_robot" + std::to_string(getID()) + ".csv").c_str(), "w");
+    if (!log_) return false;
+    std::fputs("robot_id, cluster_id, num_active_robots, iteration, num_poses, bytes_received, "
+               "iter_time_sec, total_time_sec, rel_change \n", log_);
+    t0_ = std::chrono::steady_clock::now();
+    return true;
+  }
+  void countBytes(size_t b) { bytes_ += b; }
+  void logIteration(double iter_ms) {
+    if (!mParams.logData || !log_) return;
+    const double total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0_).count();
+    std::fprintf(log_, "%u,%u,%zu,%u,%u,%zu,%.9g,%.9g,%.17g\n", getID(), 0u, (size_t)numActiveRobots(), iteration_number(), num_poses(),
+                 bytes_, iter_ms / 1e3, total, mStatus.relativeChange);
+    std::fflush(log_);
+  }
+  void logString(const char *s) { if (mParams.logData && log_) { std::fprintf(log_, "%s\n", s); std::fflush(log_); } }
+  ~MockAgentROS() override { if (log_) std::fclose(log_); }
+
+ private:
+  FILE *log_ = nullptr;
+  size_t bytes_ = 0;
+  std::chrono::steady_clock::time_point t0_{};
 };
 
 static void publish(std::vector<std::unique_ptr<MockAgentROS>> &team, unsigned b, bool aux) {
@@ -33,6 +59,7 @@ static void publish(std::vector<std::unique_ptr<MockAgentROS>> &team, unsigned b
     PoseDict map;
     if (!(aux ? team[b]->getAuxSharedPoseDictWithNeighbor(map, nbr) : team[b]->getSharedPoseDictWithNeighbor(map, nbr))) continue;
     if (aux) team[nbr]->updateAuxNeighborPoses(b, map); else team[nbr]->updateNeighborPoses(b, map);
+    team[nbr]->countBytes(map.size() * 8 * 4 * 5);  // (float64[] r x 4 per pose, msg/PublicPoses.msg; :1283 counts the message)
   }
 }
 
@@ -92,8 +119,10 @@ int main(int argc, char **argv) {
     params.robustOptNumWeightUpdates = 4;
     params.robustOptInnerIters = 5;
   }
+  if (const char *dir = std::getenv("MOCK_LOG_DIR")) { params.logData = true; params.logDirectory = std::string(dir) + "/"; }
   std::vector<std::unique_ptr<MockAgentROS>> team;
   for (unsigned k = 0; k < N; ++k) team.emplace_back(new MockAgentROS(k, params));
+  for (auto &a : team) a->openLog();
   for (auto &a : team) for (unsigned k = 0; k < N; ++k) a->setRobotActive(k, true);  // setActiveRobots() (:380-390)
   // src/PGODatasetPublisherNode.cpp:84-135 partition; every robot ends with all edges incident to it
   const unsigned per = (unsigned)num_poses / N;
@@ -134,7 +163,9 @@ int main(int argc, char **argv) {
     const unsigned sel = (unsigned)k % N;  // RoundRobin token (:464-473)
     for (unsigned b = 0; b < N; ++b)
       if (b != sel) { team[b]->iterate(false); if (team[b]->publishRequested()) { publish(team, b, false); if (accel) publish(team, b, true); } }
+    const auto it0 = std::chrono::steady_clock::now();
     if (!team[sel]->iterate(true)) { std::fprintf(stderr, "iterate failed\n"); return 6; }
+    team[sel]->logIteration(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - it0).count());  // :185-189
     if (team[sel]->publishRequested()) { publish(team, sel, false); if (accel) publish(team, sel, true); }
     for (auto &a : team) for (auto &b : team) if (a != b) a->setNeighborStatus(b->getStatus());
     const bool term = team[0]->shouldTerminate();
@@ -142,8 +173,9 @@ int main(int argc, char **argv) {
                 team[sel]->relChange(), team[sel]->optResult().fInit - team[sel]->optResult().fOpt, (int)term);
     if (mode == 5 && sel == 0) {
       // the leader's decision after its own block update (src/PGOAgentROS.cpp:206-214)
-      if (term) { std::printf("TERMINATE at %d\n", k + 1); break; }
+      if (term) { std::printf("TERMINATE at %d\n", k + 1); for (auto &a : team) a->logString("TERMINATE"); break; }  // :1042
       if (team[0]->shouldUpdateMeasurementWeights()) {
+        for (auto &a : team) a->logString("UPDATE_WEIGHT");  // :1217
         // UPDATE_WEIGHT (:1211-1233): every robot re-weights what it owns, sends shared-edge weights to the higher-ID
         // endpoint (:721-754), which applies them and clears its data matrices (:1315-1353); public poses follow
         for (auto &a : team) a->updateMeasurementWeights();

@@ -4,6 +4,7 @@ oracle started from the same (replicated) multi-robot initialisation."""
 import os
 import re
 import subprocess
+import tempfile
 
 import numpy as np
 import pytest
@@ -136,9 +137,25 @@ def test_mock_wrapper_accelerated_gnc_schedule():
     every weight update): costs, the iterations of the weight rounds and the terminate flag follow the oracle."""
     _compile()
     N, iters = 3, 60
-    out = subprocess.check_output([BIN, os.path.join(DATA, "smallGrid3D.g2o"), str(N), str(iters), "5"], text=True)
+    logdir = tempfile.mkdtemp()
+    out = subprocess.check_output([BIN, os.path.join(DATA, "smallGrid3D.g2o"), str(N), str(iters), "5"], text=True,
+                                  env=dict(os.environ, MOCK_LOG_DIR=logdir))
     init = float(re.search(r"init cost (\S+)", out).group(1))
     rows = re.findall(r"iter (\d+) robot \d+ cost (\S+) relchange \S+ fdec \S+ terminate (\d)", out)
+    # the wrapper's own iteration log (createIterationLog / logIteration / logString, src/PGOAgentROS.cpp:853-909) written
+    # from the facade members it reads there: a row per iterate(true) of the robot carrying what the run printed
+    printed = {int(a): float(b) for a, b in re.findall(r"iter (\d+) robot \d+ cost \S+ relchange (\S+)", out)}
+    n_weight_rounds = len(re.findall(r"UPDATE_WEIGHT at", out))
+    for a in range(N):
+        lines = [l for l in open(os.path.join(logdir, "dpgo_log_robot%d.csv" % a)).read().split("\n") if l]
+        assert lines[0] == ("robot_id, cluster_id, num_active_robots, iteration, num_poses, bytes_received, "
+                            "iter_time_sec, total_time_sec, rel_change ")
+        assert lines.count("UPDATE_WEIGHT") == n_weight_rounds
+        data = [l.split(",") for l in lines[1:] if l[0].isdigit()]
+        assert len(data) == len([k for k in printed if (k - 1) % N == a])
+        for r in data:
+            assert int(r[0]) == a and int(r[2]) == N and (int(r[3]) - 1) % N == a and int(r[5]) > 0
+            assert abs(float(r[8]) - printed[int(r[3])]) <= 1e-6 * max(1.0, printed[int(r[3])])  # (printed with 7 digits)
     rounds = [(int(a), float(b)) for a, b in re.findall(r"UPDATE_WEIGHT at (\d+) cost (\S+)", out)]
     m, mp, n = load("smallGrid3D", N)
     T = _replicated_initial_guess(m, mp, n, N, robust=True)

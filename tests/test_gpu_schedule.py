@@ -220,6 +220,7 @@ def test_iteration_log_of_a_real_gnc_run(tmp_path):
     plain = capi.Team.from_measurements(mp.view(capi.MEAS_DTYPE), ph)
     plain.set_initial(T, Y)
     r_plain = plain.run_schedule(300)
+    plain.synchronize()  # (gives the device's one-launch-solve lock back: the second team must take the same solve path)
     logged = capi.Team.from_measurements(mp.view(capi.MEAS_DTYPE), ph)
     logged.set_initial(T, Y)
     logged.set_iteration_log(tmp_path)
