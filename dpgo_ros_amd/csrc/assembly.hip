@@ -1,6 +1,7 @@
 // assembly.hip -- measurement lists -> block-CSR / ELL structure, data matrices Q and G, the dense
 // preconditioner and the device descriptors of a team (PoseGraph of the reference: constructQ/constructG,
 // SURVEY 8a rows 'PoseGraph data matrices').
+#include <mutex>
 #include "team_internal.h"
 #include <chrono>
 #include <cstdio>
@@ -9,6 +10,95 @@
 using namespace dpgo;
 
 namespace dpgo_host {
+
+// ---- the pool of device buffers behind DevBuf (team_internal.h)
+namespace {
+struct BufPool {
+  std::mutex mu;
+  std::map<std::pair<int, size_t>, std::vector<void *>> kept;  // (device, rounded bytes) -> idle buffers
+  size_t held = 0;
+};
+BufPool &pool() { static BufPool *p = new BufPool; return *p; }  // (never destroyed: the HIP runtime may be gone by then)
+constexpr size_t POOL_CAP = (size_t)4 << 30;
+}  // namespace
+
+size_t pool_round(size_t bytes) {
+  // sizes rounded up to three significant bits (at most 12.5 % over), 256 bytes at least
+  size_t b = std::max<size_t>(bytes, 256);
+  int top = 63 - __builtin_clzll((unsigned long long)b);
+  const size_t step = (size_t)1 << std::max(0, top - 3);
+  return (b + step - 1) / step * step;
+}
+
+void *pool_take(size_t rounded) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  BufPool &P = pool();
+  std::lock_guard<std::mutex> g(P.mu);
+  auto it = P.kept.find({dev, rounded});
+  if (it == P.kept.end() || it->second.empty()) return nullptr;
+  void *p = it->second.back();
+  it->second.pop_back();
+  P.held -= rounded;
+  return p;
+}
+
+void pool_give(void *p, size_t rounded) {
+  static const bool off = std::getenv("DPGO_NO_POOL") != nullptr;
+  hipPointerAttribute_t at{};
+  int dev = -1;
+  if (!off && hipPointerGetAttributes(&at, p) == hipSuccess) dev = at.device;
+  BufPool &P = pool();
+  {
+    std::lock_guard<std::mutex> g(P.mu);
+    if (dev >= 0 && P.held + rounded <= POOL_CAP) {
+      P.kept[{dev, rounded}].push_back(p);
+      P.held += rounded;
+      return;
+    }
+  }
+  (void)hipFree(p);
+}
+
+namespace {
+struct PinPool {
+  std::mutex mu;
+  std::map<std::pair<int, size_t>, std::vector<void *>> kept;  // (coherent, rounded bytes)
+  size_t held = 0;
+};
+PinPool &pin_pool() { static PinPool *p = new PinPool; return *p; }
+}  // namespace
+
+void *pinned_take(size_t rounded, bool coherent) {
+  PinPool &P = pin_pool();
+  {
+    std::lock_guard<std::mutex> g(P.mu);
+    auto it = P.kept.find({coherent ? 1 : 0, rounded});
+    if (it != P.kept.end() && !it->second.empty()) {
+      void *p = it->second.back();
+      it->second.pop_back();
+      P.held -= rounded;
+      return p;
+    }
+  }
+  void *p = nullptr;
+  if (hipHostMalloc(&p, rounded, coherent ? hipHostMallocCoherent : hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+
+void pinned_give(void *p, size_t rounded, bool coherent) {
+  static const bool off = std::getenv("DPGO_NO_POOL") != nullptr;
+  PinPool &P = pin_pool();
+  if (!off && rounded) {
+    std::lock_guard<std::mutex> g(P.mu);
+    if (P.held + rounded <= ((size_t)256 << 20)) {
+      P.kept[{coherent ? 1 : 0, rounded}].push_back(p);
+      P.held += rounded;
+      return;
+    }
+  }
+  (void)hipHostFree(p);
+}
 
 Agent *find_agent(dpgo_team *t, int id) {
   auto it = t->id2local.find(id);
@@ -172,7 +262,7 @@ static int choose_precond(dpgo_team *t, Agent &a, double &budget) {
       // RTR: prefer a dissection whose slabs fit the one-launch solve (two workgroups per CU) over the one that streams
       // the fewest bytes per stand-alone apply
       const bool rtr = t->prm.method == DPGO_METHOD_RTR && t->use_fused_rtr;
-      a.tl_plan = tl_make_plan(a.n, a.rowptr, a.col, 0, rtr ? rtr_fused_tl_fit_pairs(t->prm.r) : 0, rtr ? std::min(512, 2 * t->num_cus) : 0);
+      a.tl_plan = tl_make_plan(a.n, a.rowptr, a.col, t->tl_max_sub, rtr ? rtr_fused_tl_fit_pairs(t->prm.r) : 0, rtr ? std::min(512, 2 * t->num_cus) : 0);
       a.tl_rowptr = a.rowptr; a.tl_col = a.col;
       a.tl_plan_serial += 1;
     }

@@ -7,6 +7,7 @@
 #include <thread>
 #include <unordered_map>
 
+#include <mutex>
 #include "team_internal.h"
 
 using namespace dpgo;
@@ -37,6 +38,28 @@ void dpgo_default_params(dpgo_params_t *p, int r, int num_robots) {
   p->rgd_line_search = 0; p->rgd_ls_max_backoffs = 7; p->rgd_ls_shrink = 0.5; p->rgd_ls_sigma = 1e-4;
 }
 
+// library-owned streams of finished teams are kept (drained) for the next team of the same device
+namespace {
+struct StreamPool { std::mutex mu; std::map<int, std::vector<hipStream_t>> kept; };
+StreamPool &stream_pool() { static StreamPool *p = new StreamPool; return *p; }
+hipStream_t stream_take(int device) {
+  StreamPool &P = stream_pool();
+  {
+    std::lock_guard<std::mutex> g(P.mu);
+    auto &v = P.kept[device];
+    if (!v.empty()) { hipStream_t s = v.back(); v.pop_back(); return s; }
+  }
+  hipStream_t s = nullptr;
+  return hipStreamCreate(&s) == hipSuccess ? s : nullptr;
+}
+void stream_give(int device, hipStream_t s) {
+  StreamPool &P = stream_pool();
+  std::lock_guard<std::mutex> g(P.mu);
+  auto &v = P.kept[device];
+  if (v.size() < 16) v.push_back(s); else (void)hipStreamDestroy(s);
+}
+}  // namespace
+
 dpgo_team_t *dpgo_team_create(int device, const dpgo_params_t *p, int num_local, const int *agent_ids, void *stream) {
   if (p->d != 3 || p->r < 3 || p->r > 8) { set_err("d must be 3 and r in [3,8]"); return nullptr; }
   if (p->robust_opt_num_resets < 0) { set_err("robust_opt_num_resets must be >= 0"); return nullptr; }
@@ -54,11 +77,20 @@ dpgo_team_t *dpgo_team_create(int device, const dpgo_params_t *p, int num_local,
   auto *t = new dpgo_team();
   t->device = device; t->prm = *p;
   if (stream) t->stream = (hipStream_t)stream;
-  else { if (hipStreamCreate(&t->stream) != hipSuccess) { delete t; set_err("hipStreamCreate failed"); return nullptr; } t->own_stream = true; }
-  if (hipHostMalloc((void **)&t->h_states, sizeof(RtrState) * std::max(1, num_local)) != hipSuccess ||
-      hipHostMalloc((void **)&t->h_state, sizeof(RtrState)) != hipSuccess ||
-      hipHostMalloc((void **)&t->h_scal, sizeof(double) * 16 * std::max(1, num_local)) != hipSuccess) {
-    delete t; set_err("pinned allocation failed"); return nullptr;
+  else { t->stream = stream_take(device); if (!t->stream) { delete t; set_err("hipStreamCreate failed"); return nullptr; } t->own_stream = true; }
+  // (one pinned block for the team's small read-back areas, from the pool of team_internal.h)
+  {
+    const size_t nl = (size_t)std::max(1, num_local);
+    const size_t b_states = sizeof(RtrState) * nl, b_state = sizeof(RtrState), b_scal = sizeof(double) * 16 * nl;
+    auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+    t->h_block_bytes = pool_round(up(b_states) + up(b_state) + up(b_scal) + 256);
+    t->h_block = (char *)pinned_take(t->h_block_bytes, false);
+    if (!t->h_block) { delete t; set_err("pinned allocation failed"); return nullptr; }
+    std::memset(t->h_block, 0, t->h_block_bytes);
+    t->h_states = (RtrState *)t->h_block;
+    t->h_state = (RtrState *)(t->h_block + up(b_states));
+    t->h_scal = (double *)(t->h_block + up(b_states) + up(b_state));
+    t->h_bar_err = (int *)(t->h_block + up(b_states) + up(b_state) + up(b_scal));
   }
   {
     int cus = 0;
@@ -75,8 +107,7 @@ dpgo_team_t *dpgo_team_create(int device, const dpgo_params_t *p, int num_local,
     if (e5) t->use_fused_eval = (e5[0] == '0') ? 0 : 1;
     if (const char *e6 = std::getenv("DPGO_FE_MIN_N")) t->fe_min_n = std::max(32, std::atoi(e6));
     if (t->d_nest_all.alloc(3 * std::max(1, num_local)) ||
-        hipMemset(t->d_nest_all.p, 0, sizeof(NestState) * 3 * std::max(1, num_local)) != hipSuccess ||
-        hipHostMalloc((void **)&t->h_bar_err, sizeof(int)) != hipSuccess) {
+        hipMemset(t->d_nest_all.p, 0, sizeof(NestState) * 3 * std::max(1, num_local)) != hipSuccess) {
       delete t; set_err("hand-off state allocation failed"); return nullptr;
     }
     *t->h_bar_err = 0;
@@ -103,11 +134,8 @@ void dpgo_team_destroy(dpgo_team_t *t) {
   for (auto &kv : t->peers) if (kv.second.base) (void)hipIpcCloseMemHandle(kv.second.base);
   for (void *p : t->mail_handles) if (p) (void)hipIpcCloseMemHandle(p);
   t->ag.clear();
-  if (t->h_state) (void)hipHostFree(t->h_state);
-  if (t->h_states) (void)hipHostFree(t->h_states);
-  if (t->h_scal) (void)hipHostFree(t->h_scal);
-  if (t->h_bar_err) (void)hipHostFree(t->h_bar_err);
-  if (t->own_stream) (void)hipStreamDestroy(t->stream);
+  if (t->h_block) pinned_give(t->h_block, t->h_block_bytes, false);
+  if (t->own_stream) stream_give(t->device, t->stream);  // (drained above)
   delete t;
 }
 

@@ -11,6 +11,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -20,6 +22,7 @@
 #include "../../include/dpgo_hip.h"
 #include "device_math.h"
 #include "kernels.h"
+#include "team_internal.h"
 
 namespace dpgo {
 
@@ -174,12 +177,124 @@ bool has_parallel_edges(const dpgo_measurement_t *m, int nm, int n) {
 
 }  // namespace
 
+// ---- the relaxation through the solver's own machinery (round 5) -------------------------------------------------------
+// With every measured translation set to zero the SE(3) connection Laplacian Q of the solver (assembly.hip) falls apart
+// into exactly the two matrices above: its rotation rows / columns are the rotation connection Laplacian of stage 1
+// (kappa I on the diagonal, -kappa R~ off it), its translation entries the scalar graph Laplacian of stage 2 (tau).  Pinning
+// pose 0 is what a SHARED edge does: pose 0 is handed to a second "robot", so the first robot's Q holds the diagonal terms
+// of the edges into pose 0 and its linear term G the right-hand side (R_0 = I) -- stage 1 is X = -G Q^-1 on the rotation
+// entries, stage 2 the same operator on the translation entries with a right-hand side built from the projected rotations.
+// Q^-1 is the preconditioner with shift 0, which the library builds in its two-level (nested dissection / Schur) form for a
+// graph of this size: 20 subdomain blocks of <= 700^2 and one separator block of ~1200^2 for sphere2500 -- a chain of
+// ~80 block steps in batched launches where the dense Cholesky of the 7500^2 system walks 312 --, applied with one launch.
+// One step of iterative refinement (residual through the sparse operator) brings the explicit-inverse form to the
+// accuracy of a triangular solve.  DPGO_CHORDAL_DENSE=1 keeps the dense path above.
+static int chordal_via_team(int device, const dpgo_measurement_t *m, int nm, int n, double *T) {
+  const int r = 3, n1 = n - 1;
+  std::vector<dpgo_measurement_t> mm;
+  mm.reserve(nm);
+  for (int e = 0; e < nm; ++e) {
+    if (m[e].p1 == m[e].p2) continue;
+    dpgo_measurement_t q = m[e];
+    q.t[0] = q.t[1] = q.t[2] = 0.0;
+    q.r1 = q.p1 == 0 ? 1 : 0; q.p1 = q.p1 == 0 ? 0 : q.p1 - 1;
+    q.r2 = q.p2 == 0 ? 1 : 0; q.p2 = q.p2 == 0 ? 0 : q.p2 - 1;
+    mm.push_back(q);
+  }
+  dpgo_params_t p;
+  dpgo_default_params(&p, r, 2);
+  p.precond_shift = 0.0;
+  const int id0 = 0;
+  static const bool timing = std::getenv("DPGO_TIMING") != nullptr;
+  auto tq = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    if (!timing) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "chordal: %-28s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - tq).count());
+    tq = now;
+  };
+  dpgo_team_t *t = dpgo_team_create(device, &p, 1, &id0, nullptr);
+  if (!t) return DPGO_ERR;
+  t->tl_max_sub = 200;  // (a fixed dissection: the search for the cheapest apply costs more than this whole relaxation)
+  lap("team_create");
+  int rc = DPGO_ERR;
+  const size_t len = (size_t)r * 4 * n1;
+  std::vector<double> Z(len), V(len, 0.0), G(len), W(len), zero(len, 0.0);
+  auto solve = [&](std::vector<double> &rhs, std::vector<double> &out) -> int {  // out = rhs Q^-1, refined once
+    if (dpgo_agent_precondition(t, 0, zero.data(), rhs.data(), out.data())) return -1;
+    if (dpgo_agent_hessvec(t, 0, zero.data(), out.data(), W.data())) return -1;   // (at X = 0: W = out Q)
+    for (size_t i = 0; i < len; ++i) W[i] = rhs[i] - W[i];
+    if (dpgo_agent_precondition(t, 0, zero.data(), W.data(), G.data())) return -1;
+    for (size_t i = 0; i < len; ++i) out[i] += G[i];
+    return 0;
+  };
+  do {
+    if (dpgo_agent_add_measurements(t, 0, mm.data(), (int)mm.size()) < 0) break;
+    if (dpgo_agent_num_poses(t, 0) != n1) break;  // (a pose no edge reaches: the dense path reports it as a failed pivot)
+    double I34[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+    const int f0 = 0;
+    if (dpgo_agent_update_neighbor_poses(t, 0, 1, 0, 1, &f0, I34) < 0) break;
+    lap("add measurements");
+    if (dpgo_agent_set_X(t, 0, zero.data())) break;
+    lap("set_X (structure, Q, Q^-1)");
+    if (dpgo_agent_build_problem(t, 0, 0)) break;
+    if (dpgo_agent_get_G(t, 0, G.data())) break;
+    for (size_t i = 0; i < len; ++i) V[i] = -G[i];
+    lap("G");
+    if (solve(V, Z)) break;
+    lap("rotation solve");
+    // rotations: pose 0 = I, pose i = the 3 x 3 block of Z (column c of the block = column c of R_i), projected to SO(3)
+    std::vector<double> R((size_t)9 * n);
+    for (int c = 0; c < 3; ++c) for (int a = 0; a < 3; ++a) R[3 * c + a] = (a == c) ? 1.0 : 0.0;
+    for (int i = 1; i < n; ++i) std::memcpy(R.data() + (size_t)9 * i, Z.data() + (size_t)12 * (i - 1), sizeof(double) * 9);
+    {
+      DBuf dR;
+      hipStream_t s = (hipStream_t)dpgo_team_stream(t);
+      if (!dR.alloc(sizeof(double) * 9 * n)) break;
+      if (hipMemcpyAsync(dR.p, R.data(), sizeof(double) * 9 * n, hipMemcpyHostToDevice, s) != hipSuccess) break;
+      hipLaunchKernelGGL(k_project_so3, dim3((n + 63) / 64), dim3(64), 0, s, (double *)dR.p, n);
+      if (hipMemcpyAsync(R.data(), dR.p, sizeof(double) * 9 * n, hipMemcpyDeviceToHost, s) != hipSuccess) break;
+      if (hipStreamSynchronize(s) != hipSuccess) break;
+    }
+    std::memset(T, 0, sizeof(double) * 12 * (size_t)n);
+    for (int i = 0; i < n; ++i) std::memcpy(T + (size_t)12 * i, R.data() + (size_t)9 * i, sizeof(double) * 9);
+    // translations: minimise sum tau |t_j - t_i - R_i t~|^2, t_0 = 0 -- right-hand side on the translation entries
+    std::fill(V.begin(), V.end(), 0.0);
+    for (int e = 0; e < nm; ++e) {
+      const int i = m[e].p1, j = m[e].p2;
+      if (i == j) continue;
+      const double tau = m[e].weight * m[e].tau;
+      const double *Ri = T + (size_t)12 * i;
+      for (int a = 0; a < 3; ++a) {
+        double v = 0;
+        for (int b = 0; b < 3; ++b) v += Ri[3 * b + a] * m[e].t[b];
+        if (i != 0) V[((size_t)4 * (i - 1) + 3) * 3 + a] -= tau * v;
+        if (j != 0) V[((size_t)4 * (j - 1) + 3) * 3 + a] += tau * v;
+      }
+    }
+    lap("projection + rhs");
+    if (solve(V, Z)) break;
+    lap("translation solve");
+    for (int i = 1; i < n; ++i) for (int a = 0; a < 3; ++a) T[(size_t)12 * i + 9 + a] = Z[((size_t)4 * (i - 1) + 3) * 3 + a];
+    rc = DPGO_OK;
+  } while (false);
+  dpgo_team_destroy(t);
+  lap("team_destroy");
+  return rc;
+}
+
 extern "C" int dpgo_chordal_init(int device, const dpgo_measurement_t *m, int nm, int num_poses, double *T) {
   if (!m || nm < 0 || num_poses <= 0 || !T) return DPGO_ERR;
   for (int e = 0; e < nm; ++e)  // single-robot numbering: every endpoint inside [0, num_poses)
     if (m[e].p1 < 0 || m[e].p1 >= num_poses || m[e].p2 < 0 || m[e].p2 >= num_poses) return DPGO_ERR;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || hipSetDevice(device) != hipSuccess) return DPGO_ERR;
+  {
+    static const bool dense_only = std::getenv("DPGO_CHORDAL_DENSE") && std::getenv("DPGO_CHORDAL_DENSE")[0] == '1';
+    // (needs at least one edge into pose 0 -- the pin is a shared edge -- and falls back to the dense path on any failure)
+    if (!dense_only && num_poses >= 2 && num_poses <= DPGO_MAX_POSE_INDEX && chordal_via_team(device, m, nm, num_poses, T) == DPGO_OK)
+      return DPGO_OK;
+  }
   hipStream_t s;
   if (hipStreamCreate(&s) != hipSuccess) return DPGO_ERR;
   const int n = num_poses;

@@ -39,16 +39,31 @@ inline void set_err(const std::string &s) { g_err = s; }
     }                                                                                      \
   } while (0)
 
+// Device buffers that a finished owner gives back are kept (per device, by rounded size, up to 4 GB in all) and handed to
+// the next owner instead of going through hipFree / hipMalloc: unmapping and mapping the 150 MB of slabs and scratch of a
+// 2500-pose two-level set-up was 7 of the 17 ms of a chordal initialisation, which builds and drops a whole team per call.
+// Only buffers whose owner is DONE come here (a team is destroyed behind a drained stream; temporaries end behind a
+// synchronisation): a buffer that is regrown mid-life still goes through hipFree, whose implicit device synchronisation
+// the launch sequences rely on.  assembly.hip holds the pool.
+size_t pool_round(size_t bytes);
+void *pool_take(size_t rounded_bytes);              // nullptr: nothing of that size is kept
+void pool_give(void *p, size_t rounded_bytes);
+
 template <class T>
 struct DevBuf {
   T *p = nullptr;
   size_t n = 0;
-  ~DevBuf() { if (p) (void)hipFree(p); }
+  size_t cap_bytes = 0;  // rounded size the allocation was made with (0: not poolable, e.g. adopted memory)
+  ~DevBuf() { if (p) { if (cap_bytes) pool_give(p, cap_bytes); else (void)hipFree(p); } }
   int alloc(size_t count) {
     if (count <= n && p) return 0;
     if (p) (void)hipFree(p);
-    p = nullptr; n = 0;
-    if (hipMalloc(&p, sizeof(T) * std::max<size_t>(count, 1)) != hipSuccess) return -1;
+    p = nullptr; n = 0; cap_bytes = 0;
+    const size_t want = pool_round(sizeof(T) * std::max<size_t>(count, 1));
+    void *q = pool_take(want);
+    if (!q && hipMalloc(&q, want) != hipSuccess) return -1;
+    p = (T *)q;
+    cap_bytes = want;
     n = std::max<size_t>(count, 1);
     return 0;
   }
@@ -61,19 +76,28 @@ struct DevBuf {
 
 // grow-only pinned host buffer: copies to / from it are truly asynchronous (a pageable source or destination makes
 // hipMemcpyAsync stage the transfer and block the host for every call)
+// the same for pinned host memory (hipHostMalloc / hipHostFree are a fraction of a millisecond each; a team holds several)
+void *pinned_take(size_t rounded_bytes, bool coherent);  // from the pool or fresh; nullptr on failure
+void pinned_give(void *p, size_t rounded_bytes, bool coherent);
+
 template <class T>
 struct PinnedBuf {
   T *p = nullptr;
   size_t n = 0;
-  ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+  size_t cap_bytes = 0;
+  bool coh = false;
+  ~PinnedBuf() { if (p) pinned_give(p, cap_bytes, coh); }
   // coherent: fine-grained memory -- what a kernel stores there (behind a system-scope fence) becomes visible to a host
   // that polls it while the kernel's stream is still busy
   int alloc(size_t count, bool coherent = false) {
     if (count <= n && p) return 0;
-    if (p) (void)hipHostFree(p);
+    if (p) pinned_give(p, cap_bytes, coh);
     p = nullptr; n = 0;
     const size_t want = std::max<size_t>(count + count / 2, 64);
-    if (hipHostMalloc((void **)&p, sizeof(T) * want, coherent ? hipHostMallocCoherent : hipHostMallocDefault) != hipSuccess) return -1;
+    const size_t bytes = pool_round(sizeof(T) * want);
+    p = (T *)pinned_take(bytes, coherent);
+    if (!p) return -1;
+    cap_bytes = bytes; coh = coherent;
     std::memset(p, 0, sizeof(T) * want);
     n = want;
     return 0;
@@ -193,6 +217,8 @@ struct dpgo_team {
   std::vector<int> color_of;
   int all_group = 0;                     // index (behind the colour classes) of the class holding every local agent
   bool user_groups = false;              // groups supplied by dpgo_team_set_groups (global colouring)
+  char *h_block = nullptr;                     // the pinned block h_states / h_state / h_scal / h_bar_err live in
+  size_t h_block_bytes = 0;
   dpgo::RtrState *h_states = nullptr;          // pinned, one per local agent
   dpgo_host::DevBuf<double> d_tmp;  // scratch for raw manifold ops / dense factorisation
   std::vector<int> sched;
@@ -272,6 +298,9 @@ struct dpgo_team {
     std::vector<double> bytes_received;    // [local agent] public-pose payload its block updates have consumed so far
     std::chrono::steady_clock::time_point t0{};
   } ilog;
+  int tl_max_sub = 0;     // largest subdomain of the two-level dissection (0: search for the size that streams the fewest bytes per
+                          // apply -- tens of milliseconds on a 2500-pose graph; the chordal relaxation, which applies its
+                          // operator twice, asks for a fixed size instead)
   bool isolated = false;  // no neighbour is read in place, co-resident ones included (rx.loopback)
   unsigned long long epoch = 1;  // bumped by everything that enqueues device work (every launch goes through ctx())
   dpgo::LaunchCtx ctx() {
