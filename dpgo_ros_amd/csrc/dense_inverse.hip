@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "kernels.h"
+#include "team_internal.h"
 
 namespace dpgo {
 
@@ -456,12 +457,14 @@ int dense_spd_inverse_batched(hipStream_t stream, int count, double *const *A, d
     max_n = N[b] > max_n ? N[b] : max_n;
     max_blk = jobs[b].nblk > max_blk ? jobs[b].nblk : max_blk;
   }
-  double *LinvAll = nullptr;
-  int *fail_d = nullptr;
-  InvJob *jobs_d = nullptr;
-  if (hipMalloc(&LinvAll, sizeof(double) * linv_total) != hipSuccess) return -1;
-  if (hipMalloc(&fail_d, sizeof(int) * count) != hipSuccess) { (void)hipFree(LinvAll); return -1; }
-  if (hipMalloc(&jobs_d, sizeof(InvJob) * count) != hipSuccess) { (void)hipFree(LinvAll); (void)hipFree(fail_d); return -1; }
+  // (scratch from the pool of team_internal.h: three hipMalloc / hipFree pairs per call were a tenth of a weight update)
+  dpgo_host::DevBuf<double> b_linv;
+  dpgo_host::DevBuf<int> b_fail;
+  dpgo_host::DevBuf<InvJob> b_jobs;
+  if (b_linv.alloc(linv_total) || b_fail.alloc(count) || b_jobs.alloc(count)) return -1;
+  double *LinvAll = b_linv.p;
+  int *fail_d = b_fail.p;
+  InvJob *jobs_d = b_jobs.p;
   {
     size_t off = 0;
     for (int b = 0; b < count; ++b) { jobs[b].Linv = LinvAll + off; off += (size_t)jobs[b].nblk * NB * NB; }
@@ -491,10 +494,7 @@ int dense_spd_inverse_batched(hipStream_t stream, int count, double *const *A, d
   hipLaunchKernelGGL(k_wtw, dim3(nt, nt, nz), dim3(256), 0, stream, jobs_d);
   std::vector<int> fail(count, 0);
   (void)hipMemcpyAsync(fail.data(), fail_d, sizeof(int) * count, hipMemcpyDeviceToHost, stream);
-  (void)hipStreamSynchronize(stream);
-  (void)hipFree(LinvAll);
-  (void)hipFree(fail_d);
-  (void)hipFree(jobs_d);
+  (void)hipStreamSynchronize(stream);  // (the scratch goes back to the pool behind this: nothing queued still reads it)
   for (int b = 0; b < count; ++b) if (fail[b]) return fail[b] + (b << 24);
   return 0;
 }

@@ -257,6 +257,138 @@ __device__ __forceinline__ void tangent_row(const double *Yp, const double *Wp, 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Lane-parallel forms of the three routines above: ONE pose on a group of 16 lanes of one wave (sub-lane s = 0 .. 15), the
+// pose in LDS.  Every scalar is produced by the SAME expression as in the serial routine, evaluated by one lane -- the
+// Gram entries each keep their sequential sum over the rows, the entries of a product each their own three-term
+// expression -- so the results are bitwise those of the serial code; what changes is that the six Gram sums run side by
+// side instead of one after the other (R instead of 6R dependent multiply-adds) and the 3R entries of a product on 3R
+// lanes.  A lane group executes its LDS operations in order (one wave); the fences only pin the compiler.  Groups of one
+// wave may diverge from each other (their loops end at different trip counts): each touches its own LDS area.
+// The rare branches (a block far from the manifold) fall back to the serial routine on sub-lane 0.
+__device__ __forceinline__ void lanes_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// S (9 doubles of LDS) = A^T A of the R x 3 block A (LDS)
+template <int R>
+__device__ __forceinline__ void gram3_lanes(const double *A, double *S, int s) {
+  if (s < 6) {
+    const int i = (s < 3) ? 0 : ((s < 5) ? 1 : 2), j = (s < 3) ? s : ((s < 5) ? s - 2 : 2);
+    double acc = 0;
+#pragma unroll
+    for (int a = 0; a < R; ++a) acc += A[i * R + a] * A[j * R + a];
+    S[3 * i + j] = acc;
+    S[3 * j + i] = acc;
+  }
+  lanes_sync();
+}
+
+template <int R>
+__device__ __forceinline__ void polar_lanes(double *A, double *S, int s) {
+  gram3_lanes<R>(A, S, s);
+  double e0 = 1.0 - S[0], e1 = 1.0 - S[4], e2 = 1.0 - S[8];
+  double dev = e0 * e0 + e1 * e1 + e2 * e2 + 2.0 * (S[1] * S[1] + S[2] * S[2] + S[5] * S[5]);
+  if (!(dev < 0.1)) {
+    lanes_sync();
+    if (s == 0) {
+      double a[3 * R];
+#pragma unroll
+      for (int i = 0; i < 3 * R; ++i) a[i] = A[i];
+      polar_inplace<R>(a);
+#pragma unroll
+      for (int i = 0; i < 3 * R; ++i) A[i] = a[i];
+    }
+    lanes_sync();
+    return;
+  }
+  double d = dev;
+  const int j = (s < 3 * R) ? s / R : 0, a = (s < 3 * R) ? s - j * R : 0;
+#pragma unroll 1
+  for (int it = 0; it < 8 && d > 1e-31; ++it) {
+    double T[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) T[k] = -0.5 * S[3 * k + j];
+    if (j == 0) T[0] += 1.5;
+    if (j == 1) T[1] += 1.5;
+    if (j == 2) T[2] += 1.5;
+    const double b = A[a] * T[0] + A[R + a] * T[1] + A[2 * R + a] * T[2];
+    lanes_sync();
+    if (s < 3 * R) A[s] = b;
+    lanes_sync();
+    if (d * d <= 1e-31) break;
+    gram3_lanes<R>(A, S, s);
+    const double f0 = 1.0 - S[0], f1 = 1.0 - S[4], f2 = 1.0 - S[8];
+    d = f0 * f0 + f1 * f1 + f2 * f2 + 2.0 * (S[1] * S[1] + S[2] * S[2] + S[5] * S[5]);
+  }
+}
+
+// Q factor of the R x 3 block A (LDS) in place; G: 6 doubles of LDS
+template <int R>
+__device__ __forceinline__ void qf_lanes(double *A, double *G, int s) {
+  if (s < 6) {
+    const int i = (s < 3) ? 0 : ((s < 5) ? 1 : 2), j = (s < 3) ? s : ((s < 5) ? s - 2 : 2);
+    double acc = 0;
+#pragma unroll
+    for (int a = 0; a < R; ++a) acc += A[i * R + a] * A[j * R + a];
+    G[s] = acc;  // g00 g01 g02 g11 g12 g22
+  }
+  lanes_sync();
+  const double g00 = G[0], g01 = G[1], g02 = G[2], g11 = G[3], g12 = G[4], g22 = G[5];
+  const double e0 = 1.0 - g00, e1 = 1.0 - g11, e2 = 1.0 - g22;
+  const double dev = e0 * e0 + e1 * e1 + e2 * e2 + 2.0 * (g01 * g01 + g02 * g02 + g12 * g12);
+  if (dev < 0.05) {
+    const double i0 = rsqrt(g00);
+    const double r01 = g01 * i0, r02 = g02 * i0;
+    const double i1 = rsqrt(g11 - r01 * r01);
+    const double r12 = (g12 - r01 * r02) * i1;
+    const double i2 = rsqrt(g22 - r02 * r02 - r12 * r12);
+    if (s < R) {
+      const int a = s;
+      const double q0 = A[a] * i0;
+      const double q1 = (A[R + a] - r01 * q0) * i1;
+      const double q2 = (A[2 * R + a] - r02 * q0 - r12 * q1) * i2;
+      A[a] = q0; A[R + a] = q1; A[2 * R + a] = q2;
+    }
+    lanes_sync();
+    return;
+  }
+  if (s == 0) {
+    double a[3 * R];
+#pragma unroll
+    for (int i = 0; i < 3 * R; ++i) a[i] = A[i];
+    qf_inplace<R>(a);
+#pragma unroll
+    for (int i = 0; i < 3 * R; ++i) A[i] = a[i];
+  }
+  lanes_sync();
+}
+
+// W <- W - Y sym(Y^T W) on the rotation block; Y, W: R x 3 blocks in LDS, S: 9 doubles of LDS
+template <int R>
+__device__ __forceinline__ void tangent_lanes(const double *Y, double *W, double *S, int s) {
+  if (s < 9) {
+    const int p = s / 3, q = s - 3 * p;
+    double acc = 0;
+#pragma unroll
+    for (int a = 0; a < R; ++a) acc += Y[p * R + a] * W[q * R + a];
+    S[3 * p + q] = acc;
+  }
+  lanes_sync();
+  double t = 0;
+  if (s < 3 * R) {
+    const int q = s / R, a = s - q * R;
+    t = W[q * R + a];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) t -= Y[p * R + a] * 0.5 * (S[3 * p + q] + S[3 * q + p]);
+  }
+  lanes_sync();
+  if (s < 3 * R) W[s] = t;
+  lanes_sync();
+}
+
 // wave-wide sum, every lane receives the result (fixed order -> bitwise reproducible).  DPP path: quad swaps, half-row
 // and row mirrors, then the four row totals read back with v_readlane and added in row order -- ~0.1 us where a
 // ds_bpermute xor butterfly costs 0.6 with one wave per SIMD (the sparse kernels run one 64-thread workgroup per CU and

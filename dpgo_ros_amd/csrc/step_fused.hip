@@ -129,6 +129,7 @@ __global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ ag
   __shared__ double Ysh[2 * 4 * R];
   __shared__ double Esh[2][2 * 4 * R];   // V, Yaux of the two poses
   __shared__ double Es[FE_MAX_EDGES * (4 * R + 16)];  // operands of the shared edges: neighbour pose, coefficients
+  __shared__ double tl_x[2 * 4 * R], tl_v[2 * 4 * R], tl_y[2 * 4 * R], tl_s[2 * 16];  // the two poses of the tail, lane-parallel
   FE_TRACE_DECL
   FE_STAMP(0);
   const int pj0 = 2 * bx, pj1 = (2 * bx + 1 < n) ? 2 * bx + 1 : -1;
@@ -426,48 +427,63 @@ __global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ ag
     return;
   }
 
-  // ---- one lane per pose finishes the step in registers (k_precond<PM_RGD>, advance = 2, ahead bit 0, no statistics)
-  if (tid < npose) {
-    const int lp = tid;
-    const size_t o = (size_t)(lp ? pj1 : pj0) * 4 * R;
-    double x[4 * R], z[4 * R];
-#pragma unroll
-    for (int i = 0; i < 4 * R; ++i) { x[i] = Ysh[lp * 4 * R + i]; z[i] = zs[lp * 4 * R + i]; }
-    tangent_inplace<R>(x, z);
-#pragma unroll
-    for (int i = 0; i < 4 * R; ++i) x[i] -= step * z[i];
-    qf_inplace<R>(x);
-    FE_STAMP(7);
-    const bool reset = restart_now;  // restart iteration: V = Y = X
-    double v[4 * R];
-    if (reset) {
-#pragma unroll
-      for (int i = 0; i < 4 * R; ++i) v[i] = x[i];
-    } else {
-      const double gamma = nest_gamma;
-#pragma unroll
-      for (int i = 0; i < 4 * R; ++i) v[i] = Esh[0][lp * 4 * R + i] + gamma * (x[i] - Esh[1][lp * 4 * R + i]);
-      polar_inplace<R>(v);
-    }
-    FE_STAMP(8);
-    if (restart_next) {
-#pragma unroll
-      for (int i = 0; i < 4 * R; ++i) {
-        Xw[o + i] = x[i];
-        if (!ahead_opt) { Yw[o + i] = x[i]; v[i] = x[i]; }
-        else Yw[o + i] = reset ? x[i] : Esh[1][lp * 4 * R + i];  // (else Y stays: carried into the other copy)
+  // ---- the step of the workgroup's two poses (k_precond<PM_RGD>, advance = 2, ahead bit 0, no statistics): one pose on 16
+  // lanes, the pose in LDS (device_math.h, lane-parallel forms: bitwise the serial routines) -- the six Gram sums of a QF /
+  // polar factor side by side, the entries of a product on 3R lanes.  Serial, this tail was 2.2 us of dependent fp64
+  // arithmetic on two lanes of the wave.  (The look-ahead wave next to it keeps one lane per pose: its single polar factor
+  // is off the critical path -- spreading it over lanes as well was measured and changes nothing.)
+  {
+    const int lp = tid >> 4, s = tid & 15;
+    if (lp < npose) {
+      const size_t o = (size_t)(lp ? pj1 : pj0) * 4 * R;
+      double *xs = tl_x + lp * 4 * R, *vsv = tl_v + lp * 4 * R, *ys = tl_y + lp * 4 * R, *Ss = tl_s + lp * 16;
+      double *zz = zs + lp * 4 * R;
+      const double *x0 = Ysh + lp * 4 * R, *v0 = Esh[0] + lp * 4 * R, *y0 = Esh[1] + lp * 4 * R;
+      const int i0 = s, i1 = s + 16;  // the (at most two) entries of the pose this lane moves
+      const bool h0 = i0 < 4 * R, h1 = i1 < 4 * R;
+      tangent_lanes<R>(x0, zz, Ss, s);
+      if (h0) xs[i0] = x0[i0] - step * zz[i0];
+      if (h1) xs[i1] = x0[i1] - step * zz[i1];
+      lanes_sync();
+      qf_lanes<R>(xs, Ss, s);
+      FE_STAMP(7);
+      const bool reset = restart_now;  // restart iteration: V = Y = X
+      if (reset) {
+        if (h0) vsv[i0] = xs[i0];
+        if (h1) vsv[i1] = xs[i1];
+        lanes_sync();
+      } else {
+        const double gamma = nest_gamma;
+        if (h0) vsv[i0] = v0[i0] + gamma * (xs[i0] - y0[i0]);
+        if (h1) vsv[i1] = v0[i1] + gamma * (xs[i1] - y0[i1]);
+        lanes_sync();
+        polar_lanes<R>(vsv, Ss, s);
       }
-    } else {
-      double y[4 * R];
-#pragma unroll
-      for (int i = 0; i < 4 * R; ++i) y[i] = (1.0 - ahead_alpha) * x[i] + ahead_alpha * v[i];
-      polar_inplace<R>(y);
-      FE_STAMP(9);
-#pragma unroll
-      for (int i = 0; i < 4 * R; ++i) { Yw[o + i] = y[i]; Xw[o + i] = y[i]; }
+      FE_STAMP(8);
+      if (restart_next) {
+        if (h0) {
+          Xw[o + i0] = xs[i0];
+          if (!ahead_opt) { Yw[o + i0] = xs[i0]; vsv[i0] = xs[i0]; }
+          else Yw[o + i0] = reset ? xs[i0] : y0[i0];  // (else Y stays: carried into the other copy)
+        }
+        if (h1) {
+          Xw[o + i1] = xs[i1];
+          if (!ahead_opt) { Yw[o + i1] = xs[i1]; vsv[i1] = xs[i1]; }
+          else Yw[o + i1] = reset ? xs[i1] : y0[i1];
+        }
+      } else {
+        if (h0) ys[i0] = (1.0 - ahead_alpha) * xs[i0] + ahead_alpha * vsv[i0];
+        if (h1) ys[i1] = (1.0 - ahead_alpha) * xs[i1] + ahead_alpha * vsv[i1];
+        lanes_sync();
+        polar_lanes<R>(ys, Ss, s);
+        FE_STAMP(9);
+        if (h0) { Yw[o + i0] = ys[i0]; Xw[o + i0] = ys[i0]; }
+        if (h1) { Yw[o + i1] = ys[i1]; Xw[o + i1] = ys[i1]; }
+      }
+      lanes_sync();
+      if (h0) ag.buf[B_V][o + i0] = vsv[i0];
+      if (h1) ag.buf[B_V][o + i1] = vsv[i1];
     }
-#pragma unroll
-    for (int i = 0; i < 4 * R; ++i) ag.buf[B_V][o + i] = v[i];
   }
   FE_STAMP(15);
   FE_FLUSH();

@@ -1,0 +1,134 @@
+"""tunnels_stale_hypothesis.py -- TEST INFRASTRUCTURE / EXPERIMENT (CPU oracle only; nothing of the product imports it).
+
+VERDICT round 4, item 8: the 132 loop closures between robots 1 and 2 are the one group of the recorded tunnels weights
+(data/tunnels/robot*/measurements.csv, column 15) that the restatement does not reproduce (file residuals 5 - 30 x ours).
+Hypothesis: in the recorded 8-process ROS run robot 1 -- the owner of those weights (lower ID, src/PGOAgentROS.cpp:732) --
+held STALE PublicPoses of robot 2 when it re-weighted (dropped or delayed messages, :136-149, :1255-1284).
+
+This script replays the demo schedule (oracle/tunnels_gnc_pin.py) through the per-agent API with the messages 2 -> 1
+(optionally 1 -> 2 as well) delayed by D block updates or frozen at the initial guess, everything else fresh, and reports the
+third-update deviation of the pair 1-2 and of the rest.  `python -m oracle.tunnels_stale_hypothesis`
+"""
+import sys
+
+import numpy as np
+
+from oracle import tunnels_gnc_pin as P
+
+N = P.NUM_ROBOTS
+
+
+def replay(m, nk, T, wfile, delay=0, frozen=False, both=False, rounds=3, inner=400):
+    team = P.oracle_team(m, nk, T, robust_opt_num_weight_updates=rounds + 2)
+    ag = team.agents
+    nbrs = {a: [int(b) for b in ag[a].neighbors()] for a in range(N)}
+    ids = {(b, a): ag[b].public_pose_ids(a) for a in range(N) for b in nbrs[a]}
+    slow = {(2, 1)} | ({(1, 2)} if both else set())
+    hist = {pair: [ag[pair[0]].get_public_poses(pair[1])[1].copy()] for pair in slow}  # snapshot per block update
+
+    def deliver(b, a):
+        if (b, a) in slow:
+            h = hist[(b, a)]
+            pose = h[0] if frozen else h[max(0, len(h) - 1 - delay)]
+        else:
+            pose = ag[b].get_public_poses(a)[1]
+        ag[a].update_neighbor_poses(b, ids[(b, a)], pose)
+
+    k = 0
+    out = []
+    for rnd in range(rounds):
+        todo = inner + 1 if rnd == 0 else inner  # (the leader decides when it holds the token again: run_rounds)
+        for _ in range(todo):
+            sel = k % N
+            for b in nbrs[sel]:
+                deliver(b, sel)
+            for a in range(N):
+                ag[a].iterate(a == sel)
+            for pair in slow:
+                hist[pair].append(ag[pair[0]].get_public_poses(pair[1])[1].copy())
+            k += 1
+        # UPDATE_WEIGHT (src/PGOAgentROS.cpp:1211-1233): public poses first, then every robot re-weights what it owns, the
+        # weights of shared edges go to the higher-ID endpoint, which clears its data matrices
+        for a in range(N):
+            for b in nbrs[a]:
+                deliver(b, a)
+        for a in range(N):
+            ag[a].update_measurement_weights()
+        for a in range(N):
+            for e in ag[a].measurements():
+                r1, r2 = int(e["r1"]), int(e["r2"])
+                if r1 == r2 or min(r1, r2) != a:
+                    continue
+                other = max(r1, r2)
+                ag[other].set_measurement_weight(r1, int(e["p1"]), r2, int(e["p2"]), float(e["weight"]), bool(e["fixed_weight"]))
+        for a in range(N):
+            ag[a].clear_data_matrices()
+        out.append(P.summarize(team, m, wfile))
+    return out
+
+
+def replay_without_pair(m, nk, T, wfile, rounds=3, inner=400):
+    """second hypothesis: robots 1 and 2 never were neighbours in the recorded run (no PublicPoses in either direction, so
+    neither used the 132 edges in its block updates), yet robot 1 weighted them from whatever poses it had at the end of the
+    round: the edges are taken out of the optimisation (weight 0, fixed) and weighted from the fresh poses at every update"""
+    team = P.oracle_team(m, nk, T, robust_opt_num_weight_updates=rounds + 2)
+    ag = team.agents
+    pid = P.robot_pair(m)
+    idx = np.nonzero((pid == P.ANOMALOUS_PAIR) & ~np.asarray([bool(e["fixed_weight"]) for e in m]))[0]
+    for q in idx:
+        e = m[q]
+        for a in (1, 2):
+            ag[a].set_measurement_weight(int(e["r1"]), int(e["p1"]), int(e["r2"]), int(e["p2"]), 0.0, True)
+    for a in (1, 2):
+        ag[a].clear_data_matrices()
+    team.exchange_all()
+    out = []
+    for rnd in range(rounds):
+        todo = inner + 1 if rnd == 0 else inner
+        for _ in range(todo):
+            team.iterate()
+        team.exchange_all()
+        w12 = np.array([ag[1].robust_weight(ag[1].compute_residual(m[q])) for q in idx])  # (mu of this update)
+        team.update_weights()
+        w, fixed = P.team_weights(team, m)
+        w[idx] = w12
+        fixed[idx] = False
+        free = ~fixed
+        res = P.compare(w, wfile, free)
+        rest = P.compare(w, wfile, free & (pid != P.ANOMALOUS_PAIR))
+        res.update({"rest_" + k: v for k, v in rest.items()})
+        res["weights"], res["fixed"] = w, fixed
+        out.append(res)
+    return out
+
+
+def main():
+    m, wfile, inl, nk = P.load()
+    T = P.aligned_odometry_guess(m, nk)
+    cases = [("fresh (control: must equal the pinned table)", dict()),
+             ("2 -> 1 delayed by 8 block updates (one sweep)", dict(delay=8)),
+             ("2 -> 1 delayed by 80", dict(delay=80)),
+             ("2 -> 1 delayed by 400 (one whole round)", dict(delay=400)),
+             ("2 -> 1 frozen at the initial guess", dict(frozen=True)),
+             ("2 <-> 1 both delayed by 400", dict(delay=400, both=True)),
+             ("2 <-> 1 both frozen at the initial guess", dict(frozen=True, both=True))]
+    print("| messages between robots 1 and 2 | pair 1-2: median | p90 | signed median | rest: median | p90 | all: median | p90 |")
+    print("|---|---|---|---|---|---|---|---|")
+    for name, kw in ([] if "--only-pair" in sys.argv else cases):
+        rows = replay(m, nk, T, wfile, **kw)
+        r3 = rows[2]
+        pp = P.per_pair(r3["weights"], wfile, m, ~r3["fixed"])
+        cnt, med, p90, sg = pp[P.ANOMALOUS_PAIR]
+        print("| %s | %.1f %% | %.1f %% | %+.1f %% | %.2f %% | %.2f %% | %.2f %% | %.2f %% |" % (
+            name, 100 * med, 100 * p90, 100 * sg, 100 * r3["rest_median"], 100 * r3["rest_p90"], 100 * r3["median"], 100 * r3["p90"]))
+        sys.stdout.flush()
+    rows = replay_without_pair(m, nk, T, wfile)
+    r3 = rows[2]
+    pp = P.per_pair(r3["weights"], wfile, m, ~r3["fixed"])
+    cnt, med, p90, sg = pp[P.ANOMALOUS_PAIR]
+    print("| edges 1-2 out of the optimisation, weighted from fresh poses | %.1f %% | %.1f %% | %+.1f %% | %.2f %% | %.2f %% | %.2f %% | %.2f %% |" % (
+        100 * med, 100 * p90, 100 * sg, 100 * r3["rest_median"], 100 * r3["rest_p90"], 100 * r3["median"], 100 * r3["p90"]))
+
+
+if __name__ == "__main__":
+    main()
