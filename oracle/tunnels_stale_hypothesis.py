@@ -88,7 +88,7 @@ def replay_without_pair(m, nk, T, wfile, rounds=3, inner=400):
         for _ in range(todo):
             team.iterate()
         team.exchange_all()
-        w12 = np.array([ag[1].robust_weight(ag[1].compute_residual(m[q])) for q in idx])  # (mu of this update)
+        w12 = np.array([ag[1].robust_weight(ag[1].compute_residual(m[q])[1]) for q in idx])  # (mu of this update)
         team.update_weights()
         w, fixed = P.team_weights(team, m)
         w[idx] = w12

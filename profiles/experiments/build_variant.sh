@@ -12,11 +12,11 @@ for f in spmm precond step_fused rtr_fused linesearch pose_ops dense_inverse two
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=on $flags -c $src/$f.hip -o $out/$f.o &
   objs="$objs $out/$f.o"
 done
-for f in loader frame_align twolevel_plan; do
+for f in loader frame_align twolevel_plan rank_exchange; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=on $flags -x hip -c $src/$f.cpp -o $out/$f.o &
   objs="$objs $out/$f.o"
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out/libdpgo_hip.so $objs
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out/libdpgo_hip.so $objs -ldl
 rm -f $out/*.o
 echo $out/libdpgo_hip.so

@@ -29,3 +29,6 @@ t0 = allb[:, 0, 0].min()
 st = (allb[:, 0, 0] - t0) / 100.0
 e0 = (allb[:, 0, 1] - t0) / 100.0
 print("workgroup start: min %.2f max %.2f | wave-0 end: min %.2f median %.2f max %.2f" % (st.min(), st.max(), e0.min(), np.median(e0), e0.max()))
+ms, b = team.time_kernel(1, 14, reps=500)
+print("k_step_fe in this build: %.2f us per launch (HIP events)" % (ms * 1e3))
+import ctypes
