@@ -133,3 +133,49 @@ def test_world_size_one_without_loopback_is_the_device_resident_schedule():
     a.close()
     b.close()
     comm.close()
+
+
+def test_loopback_with_seven_peers_per_robot_tunnels():
+    """BASELINE configs[4]'s graph (MIT tunnels, 8 robots, every robot a neighbour of the seven others, 85 - 137 public
+    poses each way): the batches of a full exchange carry more slabs than one pack / unpack launch takes (16), and an
+    accelerated iteration moves 14 of them to one receiver.  Same bits as the in-place schedule."""
+    from tests.util import load_tunnels
+    N = 8
+    m = load_tunnels(1)
+    nk = [0] * N
+    for e in m:
+        nk[e["r1"]] = max(nk[e["r1"]], int(e["p1"]) + 1)
+        nk[e["r2"]] = max(nk[e["r2"]], int(e["p2"]) + 1)
+    Ts = []
+    for k in range(N):
+        odo = m[(m["r1"] == k) & (m["r2"] == k) & (m["p1"] + 1 == m["p2"])].copy()
+        odo["r1"] = 0
+        odo["r2"] = 0
+        Ts.append(O.odometry_init(odo, nk[k]))
+    T, Y = np.concatenate(Ts), O.fixed_stiefel(5)
+    prm = capi.default_params(r=5, num_robots=N, method=1, acceleration=1, rgd_stepsize=0.2, restart_interval=9)
+
+    def make():
+        t = capi.Team.from_measurements(m.view(capi.MEAS_DTYPE), prm)
+        t.set_initial(T, Y)
+        return t
+    sels = [(3 * k) % N for k in range(26)]  # (not round robin: the gate's bookkeeping sees uneven gaps)
+    ref = make()
+    _host_driven_schedule(ref, sels)
+    Xref = ref.global_X()
+    ref.close()
+    comm = capi.Comm(capi.comm_unique_id(), 0, 1, device=0)
+    t = make()
+    t.attach_comm(comm, [0] * N, loopback=True)
+    t.exchange_all_ranks()
+    t.run_ranks(sels)
+    t.synchronize()
+    assert np.array_equal(t.global_X(), Xref)
+    c = t.comm_counters()
+    assert c["messages_sent"] == 1 + len(sels)
+    # the full exchange: every ordered pair of neighbours, both sequences
+    npub = sum(len(t.agents[a].public_pose_ids(b)) for a in range(N) for b in t.agents[a].neighbors())
+    per_iter = [sum(len(t.agents[b].public_pose_ids(s)) for b in t.agents[s].neighbors()) for s in sels]
+    assert c["bytes_sent"] == 8 * 4 * 5 * 2 * (npub + sum(per_iter))
+    t.close()
+    comm.close()
