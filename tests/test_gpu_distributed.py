@@ -57,6 +57,21 @@ def test_bench_multi_rank_path_starts_without_a_launcher():
     assert d["exchange_timing"]["rccl_world_size"] == 1 and 0 < d["value"] < 1.0
 
 
+def test_bench_multi_rank_line_survives_a_stuck_extra_leg():
+    """the legs behind the main measurement have never met a peer on another device: if they do not finish within
+    DPGO_BENCH_EXTRAS_TIMEOUT, rank 0 still prints ONE JSON line with the library-side RCCL value and exits 0"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(DPGO_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0", DPGO_BENCH_EXTRAS_TIMEOUT="0.2")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "40", "--warmup", "10"], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["extras"].startswith("timed out") and 0 < d["value"] < 1.0 and d["metric"].startswith("ms/RBCD-iteration")
+    assert d["exchange_timing"]["rccl_world_size"] == 1 and np.isfinite(d["relcost_after_run"])
+
+
 def _problem(mode):
     N = 3
     m, _, n = load("smallGrid3D", 1)
