@@ -867,13 +867,14 @@ def multi_gpu_impl(args):
             be2.team.set_initial(T, Y, offsets=np.array([a * per for a in mine], dtype=np.int32))
     drv2 = DistributedRBCD(dist, be2, mp, NA, 0, rank, world)
     drv2.exchange_all()
+    drv2.enable_library_exchange(comm)  # (the classes' slabs by ncclSend / ncclRecv inside the library)
     for _ in range(5):
-        drv2.sweep_colored()
+        drv2.sweep_colored_library()
     dist.barrier()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     for _ in range(40):
-        drv2.sweep_colored()
+        drv2.sweep_colored_library()
     dist.barrier()
     torch.cuda.synchronize()
     with be2.stream_context():
@@ -898,13 +899,12 @@ def multi_gpu_impl(args):
     drv3 = DistributedRBCD(dist, be3, mt, 8, 0, rank, world)
     drv3.exchange_all()
     c0 = drv3.global_cost(torch, "cuda")
-    for _ in range(20):
-        drv3.tick_simultaneous()
+    drv3.enable_library_exchange(comm)  # (one batch of ncclSend / ncclRecv per tick, enqueued by the library)
+    drv3.tick_library(20)
     dist.barrier()
     torch.cuda.synchronize()
     t3 = time.perf_counter()
-    for _ in range(200):
-        drv3.tick_simultaneous()
+    drv3.tick_library(200)
     dist.barrier()
     torch.cuda.synchronize()
     with be3.stream_context():

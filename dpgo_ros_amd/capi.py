@@ -87,7 +87,8 @@ dpgo_team_should_terminate dpgo_team_run_schedule dpgo_agent_compute_residuals d
 dpgo_agent_reset_acceleration dpgo_team_prepare dpgo_agent_read_partials dpgo_agent_preconditioner dpgo_agent_preconditioner_info dpgo_agent_preconditioner_residual dpgo_two_level_plan dpgo_agent_export_state dpgo_team_import_peer dpgo_team_export_mailbox dpgo_team_import_mailbox dpgo_team_run_peer dpgo_agent_read_rtr_handoff
 dpgo_comm_unique_id dpgo_comm_create dpgo_comm_destroy dpgo_comm_rank dpgo_comm_world dpgo_comm_library
 dpgo_comm_allreduce_sum dpgo_comm_allreduce_max dpgo_team_attach_comm dpgo_team_detach_comm dpgo_team_exchange_all_ranks
-dpgo_team_run_ranks dpgo_comm_global_cost dpgo_team_comm_counters dpgo_team_set_iteration_log""".split()
+dpgo_team_run_ranks dpgo_comm_global_cost dpgo_team_comm_counters dpgo_team_set_iteration_log dpgo_team_run_simultaneous_ranks
+dpgo_team_run_group_ranks""".split()
 
 
 class DpgoError(RuntimeError):
@@ -595,6 +596,14 @@ class Team:
         point-to-point inside the library, nothing synchronises with the host"""
         ids = np.ascontiguousarray(sel_ids, dtype=np.int32)
         _chk(lib().dpgo_team_run_ranks(self.h, _d(ids), len(ids)), "run_ranks")
+
+    def run_simultaneous_ranks(self, ticks):
+        """lockstep ASAPP ticks with the boundary slabs moved by the library (one batch of ncclSend / ncclRecv per tick)"""
+        _chk(lib().dpgo_team_run_simultaneous_ranks(self.h, int(ticks)), "run_simultaneous_ranks")
+
+    def run_group_ranks(self, g, count):
+        """one colour class across ranks: members receive what moved, then update at once (set_groups first)"""
+        _chk(lib().dpgo_team_run_group_ranks(self.h, int(g), int(count)), "run_group_ranks")
 
     def comm_counters(self):
         """messages sent / received by this rank and their bytes"""

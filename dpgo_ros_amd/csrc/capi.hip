@@ -1274,9 +1274,11 @@ int dpgo_team_get_coloring(dpgo_team_t *t, int *color_of_agent) {
 // of the problem: the colouring must be global so that no two agents updated together share an edge
 int dpgo_team_set_groups(dpgo_team_t *t, int num_groups, const int *group_ptr, const int *member_ids) {
   t->groups.assign(num_groups, {});
+  t->group_ids.assign(num_groups, {});
   t->color_of.assign(t->ag.size(), -1);
   for (int g = 0; g < num_groups; ++g)
     for (int q = group_ptr[g]; q < group_ptr[g + 1]; ++q) {
+      t->group_ids[g].push_back(member_ids[q]);  // (global ids, non-local members included: rank_exchange.cpp sends to them)
       auto it = t->id2local.find(member_ids[q]);
       if (it == t->id2local.end()) continue;
       t->groups[g].push_back(it->second);

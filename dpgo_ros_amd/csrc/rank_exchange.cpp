@@ -397,6 +397,60 @@ int dpgo_team_run_ranks(dpgo_team_t *t, const int *sel_ids, int iters) {
   return DPGO_OK;
 }
 
+// BASELINE configs[4] across ranks, the lockstep instance of the asynchronous (ASAPP) mode (src/PGOAgentROS.cpp:119-127):
+// per tick every boundary slab (X only) crosses the ranks in ONE batch of point-to-point operations, then every rank steps
+// all its robots in the same launches (dpgo_team_run_simultaneous).  Every rank that owns a robot calls it with the same count.
+int dpgo_team_run_simultaneous_ranks(dpgo_team_t *t, int ticks) {
+  auto &x = t->rx;
+  if (!x.comm) { set_err("run_simultaneous_ranks: no communicator attached"); return DPGO_ERR; }
+  if (sync_descs(t)) return DPGO_ERR;
+  for (int k = 0; k < ticks; ++k) {
+    int rc = exchange_pairs(t, all_pairs(t, 1u));
+    if (rc) return rc;
+    rc = dpgo_team_run_simultaneous(t, 1);
+    if (rc) return rc;
+  }
+  for (auto &v : x.version) v = t->iter;
+  x.sent.clear();  // (X crossed, Y did not: a later accelerated schedule sends both)
+  x.iter_seen = t->iter;
+  return DPGO_OK;
+}
+
+// one colour class of a colour-parallel sweep across ranks: every member -- on whatever rank it lives --
+// receives its neighbours' public poses (those that moved since it last got them), then all members take their block
+// update at once (dpgo_team_run_group).  Needs dpgo_team_set_groups with the GLOBAL classes; `count` = global size of the
+// class.  Every rank that owns a robot calls it with the same arguments.
+int dpgo_team_run_group_ranks(dpgo_team_t *t, int g, int count) {
+  auto &x = t->rx;
+  if (!x.comm) { set_err("run_group_ranks: no communicator attached"); return DPGO_ERR; }
+  if (g < 0 || g >= (int)t->group_ids.size()) { set_err("run_group_ranks: bad group (dpgo_team_set_groups first)"); return DPGO_ERR; }
+  if (sync_descs(t)) return DPGO_ERR;
+  if (x.iter_seen != t->iter) x.sent.clear();
+  const std::vector<int> &members = t->group_ids[g];
+  auto is_member = [&](int id) { return std::find(members.begin(), members.end(), id) != members.end(); };
+  std::vector<Pair> v;
+  auto consider = [&](int b, int a) {  // b's public poses -> member a
+    if (!crosses(t, b, a)) return;
+    for (const Pair &e : v) if (e.b == b && e.a == a) return;
+    auto f = x.sent.find({b, a, 0});
+    if (f != x.sent.end() && x.version[b] - f->second <= (long long)x.max_delay) return;
+    x.sent[{b, a, 0}] = x.version[b];
+    v.push_back({b, a, 1u});
+  };
+  for (auto &ag : t->ag)
+    for (int nb : ag->neighbors) {
+      if (is_member(ag->id)) consider(nb, ag->id);     // a local member receives
+      if (is_member(nb)) consider(ag->id, nb);          // a local robot sends to a member (wherever it lives)
+    }
+  int rc = exchange_pairs(t, v);
+  if (rc) return rc;
+  rc = dpgo_team_run_group(t, g, count);
+  if (rc) return rc;
+  for (int id : members) x.version[id] = t->iter;
+  x.iter_seen = t->iter;
+  return DPGO_OK;
+}
+
 /* global cost across ranks: owned-edge partial sums of this team (NULL: a rank without robots contributes 0) + one
  * 1-double all-reduce.  Collective over the communicator. */
 int dpgo_comm_global_cost(dpgo_comm_t *c, dpgo_team_t *t, void *stream, double *f) {

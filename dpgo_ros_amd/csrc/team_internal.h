@@ -214,6 +214,7 @@ struct dpgo_team {
   dpgo_host::DevBuf<dpgo::TeamDev> d_team;
   dpgo_host::DevBuf<int> d_sched, d_group_ptr, d_group_members;
   std::vector<std::vector<int>> groups;  // colour classes (local agent indices), greedy colouring
+  std::vector<std::vector<int>> group_ids;  // the same classes as global robot ids, members that live elsewhere included (dpgo_team_set_groups)
   std::vector<int> color_of;
   int all_group = 0;                     // index (behind the colour classes) of the class holding every local agent
   bool user_groups = false;              // groups supplied by dpgo_team_set_groups (global colouring)

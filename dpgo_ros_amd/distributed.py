@@ -161,6 +161,14 @@ class HipBackend:
         if self.team is not None:
             self.team.run_ranks(sel_ids)
 
+    def run_simultaneous_ranks(self, ticks):
+        if self.team is not None:
+            self.team.run_simultaneous_ranks(ticks)
+
+    def run_group_ranks(self, g, members):
+        if self.team is not None:
+            self.team.run_group_ranks(g, len(members))
+
     def sync(self):
         """drain this rank's stream -- through the team, so that a time-out of an in-kernel exchange (mailbox wait of
         the device-side token, two-level preconditioner) is raised here instead of yielding silently wrong iterates"""
@@ -449,6 +457,29 @@ class DistributedRBCD:
         self.version = [self.k] * self.N  # (conservative: a later step() sends everything once)
         self.sent = {}
         return sels
+
+    def tick_library(self, ticks=1):
+        """tick_simultaneous() with the slabs moved by the library (dpgo_team_run_simultaneous_ranks): `ticks` lockstep
+        ticks per host call, one batch of ncclSend / ncclRecv each"""
+        assert getattr(self, "library_exchange", False), "tick_library needs enable_library_exchange()"
+        with self._ctx():
+            self.be.run_simultaneous_ranks(ticks)
+        self.k += self.N * ticks
+        self.version = [self.k] * self.N
+        self.sent = {}
+
+    def sweep_colored_library(self):
+        """sweep_colored() with the slabs moved by the library (dpgo_team_run_group_ranks): no host-driven message"""
+        assert getattr(self, "library_exchange", False), "sweep_colored_library needs enable_library_exchange()"
+        if not hasattr(self, "groups"):
+            self.groups = greedy_coloring(self.nbrs, self.N)
+            self.be.set_groups(self.groups)
+        with self._ctx():
+            for g, members in enumerate(self.groups):
+                self.be.run_group_ranks(g, members)
+                self.k += len(members)
+        self.version = [self.k] * self.N
+        self.sent = {}
 
     def free_run(self, ticks):
         """The asynchronous (ASAPP) mode across ranks, src/PGOAgentROS.cpp:119-127: every rank steps its agents `ticks`

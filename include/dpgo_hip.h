@@ -327,6 +327,10 @@ int dpgo_team_exchange_all_ranks(dpgo_team_t *t);
  * ranks), the block update (:160).  Nothing synchronises with the host; every rank that owns a robot passes the same
  * list.  Iterates equal dpgo_team_step_begin / messages / dpgo_team_step_end bit for bit. */
 int dpgo_team_run_ranks(dpgo_team_t *t, const int *sel_ids, int iters);
+/* the lockstep ASAPP ticks (dpgo_team_run_simultaneous) and the classes of a colour-parallel sweep (dpgo_team_run_group, after
+ * dpgo_team_set_groups with the global classes) with their boundary slabs moved by the library in the same way */
+int dpgo_team_run_simultaneous_ranks(dpgo_team_t *t, int ticks);
+int dpgo_team_run_group_ranks(dpgo_team_t *t, int group, int count);
 /* global cost: this team's owned-edge partial sums (t may be NULL on a rank without robots) + a 1-double all-reduce */
 int dpgo_comm_global_cost(dpgo_comm_t *c, dpgo_team_t *t, void *stream, double *f);
 /* out[4]: point-to-point messages sent / received by this rank, bytes sent / received */

@@ -179,3 +179,64 @@ def test_loopback_with_seven_peers_per_robot_tunnels():
     assert c["bytes_sent"] == 8 * 4 * 5 * 2 * (npub + sum(per_iter))
     t.close()
     comm.close()
+
+
+def test_library_side_ticks_and_colour_classes_in_loopback():
+    """the other two multi-rank schedules with their slabs moved by the library: lockstep ASAPP ticks on the tunnels graph
+    (dpgo_team_run_simultaneous_ranks) and the classes of a colour-parallel sweep on sphere2500 / 5
+    (dpgo_team_run_group_ranks) -- loopback self-sends against the in-place single-team runs, bit for bit"""
+    from tests.util import load_tunnels
+    # ---- ticks
+    N = 8
+    m = load_tunnels(1)
+    nk = [0] * N
+    for e in m:
+        nk[e["r1"]] = max(nk[e["r1"]], int(e["p1"]) + 1)
+        nk[e["r2"]] = max(nk[e["r2"]], int(e["p2"]) + 1)
+    Ts = []
+    for k in range(N):
+        odo = m[(m["r1"] == k) & (m["r2"] == k) & (m["p1"] + 1 == m["p2"])].copy()
+        odo["r1"] = 0
+        odo["r2"] = 0
+        Ts.append(O.odometry_init(odo, nk[k]))
+    T, Y = np.concatenate(Ts), O.fixed_stiefel(5)
+    prm = capi.default_params(r=5, num_robots=N, method=1, acceleration=0, rgd_stepsize=0.2)
+    a = capi.Team.from_measurements(m.view(capi.MEAS_DTYPE), prm)
+    a.set_initial(T, Y)
+    for _ in range(12):
+        a.run_simultaneous(1)
+    a.synchronize()
+    comm = capi.Comm(capi.comm_unique_id(), 0, 1, device=0)
+    b = capi.Team.from_measurements(m.view(capi.MEAS_DTYPE), prm)
+    b.set_initial(T, Y)
+    b.attach_comm(comm, [0] * N, loopback=True)
+    b.exchange_all_ranks()
+    b.run_simultaneous_ranks(5)
+    b.run_simultaneous_ranks(7)
+    b.synchronize()
+    assert np.array_equal(a.global_X(), b.global_X())
+    assert b.comm_counters()["messages_sent"] == 1 + 12
+    a.close()
+    b.close()
+    # ---- colour classes
+    N = 5
+    kw = dict(method=0, acceleration=0, rtr_iterations=3, rtr_tcg_iterations=50, gradnorm_tol=1e-2)
+    make, mp, n, T, Y = _teams("sphere2500", N, **kw)
+    a = make()
+    nc, col = a.coloring()
+    groups = [[k for k in range(N) if col[k] == c] for c in range(nc)]
+    a.run_colored(3)
+    a.synchronize()
+    b = make()
+    b.attach_comm(comm, [0] * N, loopback=True)
+    b.exchange_all_ranks()
+    b.set_groups(groups)
+    for _ in range(3):
+        for g, mem in enumerate(groups):
+            b.run_group_ranks(g, len(mem))
+    b.synchronize()
+    assert np.array_equal(a.global_X(), b.global_X())
+    assert abs(comm.global_cost(b) - a.cost()) <= 1e-12 * abs(a.cost())
+    a.close()
+    b.close()
+    comm.close()
