@@ -88,7 +88,7 @@ dpgo_agent_reset_acceleration dpgo_team_prepare dpgo_agent_read_partials dpgo_ag
 dpgo_comm_unique_id dpgo_comm_create dpgo_comm_destroy dpgo_comm_rank dpgo_comm_world dpgo_comm_library
 dpgo_comm_allreduce_sum dpgo_comm_allreduce_max dpgo_team_attach_comm dpgo_team_detach_comm dpgo_team_exchange_all_ranks
 dpgo_team_run_ranks dpgo_comm_global_cost dpgo_team_comm_counters dpgo_team_set_iteration_log dpgo_team_run_simultaneous_ranks
-dpgo_team_run_group_ranks""".split()
+dpgo_team_run_group_ranks dpgo_rank_plan_simulate""".split()
 
 
 class DpgoError(RuntimeError):
@@ -449,6 +449,19 @@ def comm_library():
     buf = C.create_string_buffer(512)
     v = _chk(lib().dpgo_comm_library(buf, 512), "comm_library")
     return buf.value.decode(), v
+
+
+def rank_plan_simulate(owner, npub, rank, world, sel_ids, acceleration=1, max_delayed_iterations=0, r=5):
+    """the exchange's planning layer replayed for one rank (host arithmetic only): array [1 + iters, world, 4] of
+    {doubles sent, doubles received, hash of the sent slabs, hash of the received slabs} per batch and peer rank"""
+    owner = np.ascontiguousarray(owner, dtype=np.int32)
+    N = len(owner)
+    npub = np.ascontiguousarray(npub, dtype=np.int32).reshape(N, N)
+    sel = np.ascontiguousarray(sel_ids, dtype=np.int32)
+    out = np.zeros((1 + len(sel), world, 4), dtype=np.int64)
+    _chk(lib().dpgo_rank_plan_simulate(N, int(world), int(rank), _d(owner), _d(npub), int(acceleration), int(max_delayed_iterations), int(r),
+                                       _d(sel), len(sel), _d(out)), "rank_plan_simulate")
+    return out
 
 
 class Comm:

@@ -18,6 +18,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <functional>
 #include <tuple>
 
 #include "team_internal.h"
@@ -198,110 +199,166 @@ struct Pair { int b, a; unsigned seqs; };  // public poses of robot b (sequences
 
 inline bool crosses(const dpgo_team_t *t, int b, int a) { return t->rx.loopback || t->rx.owner[b] != t->rx.owner[a]; }
 
-// One batch: every listed slab crosses in ONE group of point-to-point operations, one message per peer rank and direction;
-// inside a message the slabs are ordered by (receiving robot, sending robot, sequence), which both ends derive alike.
+// ---- the planning layer: WHO sends WHAT to WHOM in WHICH order -- host arithmetic on what a rank knows of the topology,
+// shared by the real path below and by dpgo_rank_plan_simulate (the CPU test replays every rank of a world and checks that
+// each send meets a receive of the same length and content order on the other side: no box here holds two GPUs).
+struct Topo {
+  int me = 0;
+  bool loopback = false;
+  const std::vector<int> *owner = nullptr;
+  std::vector<int> local;                                        // robots that live on this rank, ascending
+  std::function<const std::vector<int> &(int)> nbrs;            // neighbours (ascending) of a LOCAL robot
+  std::function<int(int, int)> count;                           // public poses of b that a needs (b or a local); <0: no such edge
+  bool is_local(int id) const { return std::binary_search(local.begin(), local.end(), id); }
+  bool crosses(int b, int a) const { return loopback || (*owner)[b] != (*owner)[a]; }
+};
+struct Book {  // what every receiver holds of every sender (dpgo_team::RankExchange carries the same fields)
+  int max_delay = 0;
+  std::vector<long long> *version = nullptr;
+  std::map<std::tuple<int, int, int>, long long> *sent = nullptr;
+};
+struct PlanSeg { int b, a, q, count; };
+struct PlanMsg { size_t off = 0, len = 0; std::vector<PlanSeg> segs; };
+struct Plan { std::map<int, PlanMsg> out, in; size_t tot_out = 0, tot_in = 0; };
+
+// One batch: one message per peer rank and direction; inside a message the slabs are ordered by (receiving robot,
+// sending robot, sequence), which both ends derive alike.
+Plan make_plan(const Topo &T, std::vector<Pair> pairs, size_t B) {
+  std::sort(pairs.begin(), pairs.end(), [](const Pair &p, const Pair &q) { return std::tie(p.a, p.b) < std::tie(q.a, q.b); });
+  Plan P;
+  for (const Pair &p : pairs)
+    for (int q = 0; q < 2; ++q) {
+      if (!((p.seqs >> q) & 1)) continue;
+      if (T.is_local(p.b)) {
+        const int c = T.count(p.b, p.a);
+        if (c >= 0) { PlanMsg &m = P.out[(*T.owner)[p.a]]; m.segs.push_back({p.b, p.a, q, c}); m.len += (size_t)c * B; }
+      }
+      if (T.is_local(p.a)) {
+        const int c = T.count(p.b, p.a);
+        if (c >= 0) { PlanMsg &m = P.in[(*T.owner)[p.b]]; m.segs.push_back({p.b, p.a, q, c}); m.len += (size_t)c * B; }
+      }
+    }
+  for (auto &kv : P.out) { kv.second.off = P.tot_out; P.tot_out += kv.second.len; }
+  for (auto &kv : P.in) { kv.second.off = P.tot_in; P.tot_in += kv.second.len; }
+  return P;
+}
+
+// every ordered pair (b -> a) of neighbouring robots that touches this rank and crosses ranks
+std::vector<Pair> all_pairs_of(const Topo &T, unsigned seqs) {
+  std::vector<Pair> v;
+  for (int a : T.local)
+    for (int nb : T.nbrs(a)) {
+      if (!T.crosses(nb, a)) continue;
+      v.push_back({nb, a, seqs});                          // this rank receives
+      if (!T.is_local(nb)) v.push_back({a, nb, seqs});     // ... and sends (a local nb lists the pair itself)
+    }
+  return v;
+}
+
+// the neighbours of the token holder that live elsewhere publish to it -- those whose copy there is too old (the staleness
+// gate, per sequence, evaluated alike on both ends: a deterministic function of the schedule).  Updates the book.
+std::vector<Pair> token_pairs(const Topo &T, Book &K, int sel_id, unsigned seqs) {
+  std::vector<Pair> v;
+  auto consider = [&](int b) {
+    if (!T.crosses(b, sel_id)) return;
+    for (const Pair &e : v) if (e.b == b) return;
+    long long behind = 0;
+    bool missing = false;
+    for (int s = 0; s < 2; ++s) {
+      if (!((seqs >> s) & 1)) continue;
+      auto f = K.sent->find({b, sel_id, s});
+      if (f == K.sent->end()) missing = true;
+      else behind = std::max(behind, (*K.version)[b] - f->second);
+    }
+    if (!missing && (behind == 0 || behind <= K.max_delay)) return;  // current, or fresh enough for the staleness gate
+    for (int s = 0; s < 2; ++s) if ((seqs >> s) & 1) (*K.sent)[{b, sel_id, s}] = (*K.version)[b];
+    v.push_back({b, sel_id, seqs});
+  };
+  if (T.is_local(sel_id)) for (int b : T.nbrs(sel_id)) consider(b);
+  for (int a : T.local) {
+    if (a == sel_id) continue;
+    const std::vector<int> &nb = T.nbrs(a);
+    if (std::binary_search(nb.begin(), nb.end(), sel_id)) consider(a);
+  }
+  return v;
+}
+
+Topo topo_of(dpgo_team_t *t) {
+  Topo T;
+  T.me = t->rx.comm ? t->rx.comm->rank : 0;
+  T.loopback = t->rx.loopback;
+  T.owner = &t->rx.owner;
+  for (auto &a : t->ag) T.local.push_back(a->id);
+  std::sort(T.local.begin(), T.local.end());
+  T.nbrs = [t](int id) -> const std::vector<int> & { return t->ag[t->id2local[id]]->neighbors; };
+  T.count = [t](int b, int a) -> int {
+    auto ib = t->id2local.find(b);
+    if (ib != t->id2local.end()) { auto &m = t->ag[ib->second]->n_pubframes; auto f = m.find(a); return f == m.end() ? -1 : f->second; }
+    auto ia = t->id2local.find(a);
+    if (ia != t->id2local.end()) { auto &m = t->ag[ia->second]->n_nbrslots; auto f = m.find(b); return f == m.end() ? -1 : f->second; }
+    return -1;
+  };
+  return T;
+}
+Book book_of(dpgo_team_t *t) { Book K; K.max_delay = t->rx.max_delay; K.version = &t->rx.version; K.sent = &t->rx.sent; return K; }
+
+// executes one planned batch on the team stream: ONE pack launch per 16 slabs, one grouped ncclSend / ncclRecv per peer rank
+// and direction, ONE unpack launch per 16 slabs
 int exchange_pairs(dpgo_team_t *t, std::vector<Pair> pairs) {
   RcclApi *api = rccl();
   if (!api) return DPGO_ERR;
   auto &x = t->rx;
   if (pairs.empty()) return 0;
-  std::sort(pairs.begin(), pairs.end(), [](const Pair &p, const Pair &q) { return std::tie(p.a, p.b) < std::tie(q.a, q.b); });
   const size_t B = (size_t)4 * t->prm.r;
-  const int me = x.comm->rank;
-  struct Msg { size_t off = 0, len = 0; };
-  std::map<int, Msg> out, in;  // by peer rank
-  // sizes first (the staging buffers may have to grow before any kernel is given a pointer into them)
-  for (const Pair &p : pairs) {
-    const int nq = (p.seqs & 1) + ((p.seqs >> 1) & 1);
-    if (Agent *sb = t->id2local.count(p.b) ? t->ag[t->id2local[p.b]].get() : nullptr) {
-      auto it = sb->n_pubframes.find(p.a);
-      if (it != sb->n_pubframes.end()) out[x.owner[p.a]].len += (size_t)nq * it->second * B;
-    }
-    if (Agent *ra = t->id2local.count(p.a) ? t->ag[t->id2local[p.a]].get() : nullptr) {
-      auto it = ra->n_nbrslots.find(p.b);
-      if (it != ra->n_nbrslots.end()) in[x.owner[p.b]].len += (size_t)nq * it->second * B;
-    }
-  }
-  size_t tot_out = 0, tot_in = 0;
-  for (auto &kv : out) { kv.second.off = tot_out; tot_out += kv.second.len; }
-  for (auto &kv : in) { kv.second.off = tot_in; tot_in += kv.second.len; }
-  if (tot_out > x.d_send.n || tot_in > x.d_recv.n) {
+  const Plan P = make_plan(topo_of(t), std::move(pairs), B);
+  // (the staging buffers may have to grow before any kernel is given a pointer into them)
+  if (P.tot_out > x.d_send.n || P.tot_in > x.d_recv.n) {
     HIPC(hipStreamSynchronize(t->stream));  // (operations of an earlier batch may still read / write the old buffers)
-    if (x.d_send.alloc(tot_out + tot_out / 2) || x.d_recv.alloc(tot_in + tot_in / 2)) { set_err("exchange: allocation failed"); return DPGO_ERR; }
+    if (x.d_send.alloc(P.tot_out + P.tot_out / 2) || x.d_recv.alloc(P.tot_in + P.tot_in / 2)) { set_err("exchange: allocation failed"); return DPGO_ERR; }
   }
-  // pack
-  std::map<int, size_t> cur;
-  for (auto &kv : out) cur[kv.first] = kv.second.off;
   XferSegs sg{};
   auto flush_pack = [&]() { if (sg.n) launch_pack_multi(t->ctx(), sg); sg.n = 0; };
-  for (const Pair &p : pairs) {
-    auto il = t->id2local.find(p.b);
-    if (il == t->id2local.end()) continue;
-    Agent &sb = *t->ag[il->second];
-    if (!sb.has_X) { set_err("exchange: robot " + std::to_string(sb.id) + " has no iterate yet"); return DPGO_NOT_READY; }
-    auto itf = sb.d_pubframes.find(p.a);
-    if (itf == sb.d_pubframes.end()) continue;
-    const int cnt = sb.n_pubframes[p.a];
-    size_t &at = cur[x.owner[p.a]];
-    for (int q = 0; q < 2; ++q) {
-      if (!((p.seqs >> q) & 1)) continue;
+  for (auto &kv : P.out) {
+    size_t at = kv.second.off;
+    for (const PlanSeg &g : kv.second.segs) {
+      Agent &sb = *t->ag[t->id2local[g.b]];
+      if (!sb.has_X) { set_err("exchange: robot " + std::to_string(sb.id) + " has no iterate yet"); return DPGO_NOT_READY; }
       if (sg.n == XFER_MAX_SEGS) flush_pack();
-      sg.src[sg.n] = sb.dev.buf[q ? B_Y : B_X]; sg.idx[sg.n] = itf->second->p; sg.count[sg.n] = cnt; sg.buf[sg.n] = x.d_send.p + at;
+      sg.src[sg.n] = sb.dev.buf[g.q ? B_Y : B_X]; sg.idx[sg.n] = sb.d_pubframes[g.a]->p; sg.count[sg.n] = g.count; sg.buf[sg.n] = x.d_send.p + at;
       ++sg.n;
-      at += (size_t)cnt * B;
+      at += (size_t)g.count * B;
     }
   }
   flush_pack();
-  // the messages
   NCCLC(api->GroupStart());
-  for (auto &kv : out)
+  for (auto &kv : P.out)
     if (kv.second.len) {
       NCCLC(api->Send(x.d_send.p + kv.second.off, kv.second.len, ncclDouble, kv.first, x.comm->comm, t->stream));
       x.counters[0] += 1; x.counters[2] += 8.0 * kv.second.len;
     }
-  for (auto &kv : in)
+  for (auto &kv : P.in)
     if (kv.second.len) {
       NCCLC(api->Recv(x.d_recv.p + kv.second.off, kv.second.len, ncclDouble, kv.first, x.comm->comm, t->stream));
       x.counters[1] += 1; x.counters[3] += 8.0 * kv.second.len;
     }
   NCCLC(api->GroupEnd());
-  // unpack
-  cur.clear();
-  for (auto &kv : in) cur[kv.first] = kv.second.off;
   auto flush_unpack = [&]() { if (sg.n) launch_unpack_multi(t->ctx(), sg); sg.n = 0; };
-  for (const Pair &p : pairs) {
-    auto il = t->id2local.find(p.a);
-    if (il == t->id2local.end()) continue;
-    Agent &ra = *t->ag[il->second];
-    auto its = ra.d_nbrslots.find(p.b);
-    if (its == ra.d_nbrslots.end()) continue;
-    const int cnt = ra.n_nbrslots[p.b];
-    size_t &at = cur[x.owner[p.b]];
-    for (int q = 0; q < 2; ++q) {
-      if (!((p.seqs >> q) & 1)) continue;
+  for (auto &kv : P.in) {
+    size_t at = kv.second.off;
+    for (const PlanSeg &g : kv.second.segs) {
+      Agent &ra = *t->ag[t->id2local[g.a]];
       if (sg.n == XFER_MAX_SEGS) flush_unpack();
-      sg.src[sg.n] = ra.dev.nbr[q]; sg.idx[sg.n] = its->second->p; sg.count[sg.n] = cnt; sg.buf[sg.n] = x.d_recv.p + at;
+      sg.src[sg.n] = ra.dev.nbr[g.q]; sg.idx[sg.n] = ra.d_nbrslots[g.b]->p; sg.count[sg.n] = g.count; sg.buf[sg.n] = x.d_recv.p + at;
       ++sg.n;
-      at += (size_t)cnt * B;
-      for (size_t s = 0; s < ra.np.size(); ++s) if (ra.np[s].first == p.b) ra.np_has[q][s] = 1;
+      at += (size_t)g.count * B;
+      for (size_t sl = 0; sl < ra.np.size(); ++sl) if (ra.np[sl].first == g.b) ra.np_has[g.q][sl] = 1;
     }
   }
   flush_unpack();
-  (void)me;
   return 0;
 }
 
-// every ordered pair (b -> a) of neighbouring robots that touches this team and crosses ranks
-std::vector<Pair> all_pairs(dpgo_team_t *t, unsigned seqs) {
-  std::vector<Pair> v;
-  for (auto &ag : t->ag)
-    for (int nb : ag->neighbors) {
-      if (!crosses(t, nb, ag->id)) continue;
-      v.push_back({nb, ag->id, seqs});                                   // this team receives
-      if (!t->id2local.count(nb)) v.push_back({ag->id, nb, seqs});      // ... and sends (a local nb lists the pair itself)
-    }
-  return v;
-}
+std::vector<Pair> all_pairs(dpgo_team_t *t, unsigned seqs) { return all_pairs_of(topo_of(t), seqs); }
 
 }  // namespace
 
@@ -366,24 +423,8 @@ int dpgo_team_run_ranks(dpgo_team_t *t, const int *sel_ids, int iters) {
     int rc = enqueue_team_iteration(t, false, restart, sel, 1);
     if (rc) return rc;
     // the neighbours of the token holder that live elsewhere publish to it -- those whose copy there is too old
-    std::vector<Pair> v;
-    auto consider = [&](int b) {
-      if (!crosses(t, b, sel_id)) return;
-      for (const Pair &e : v) if (e.b == b) return;
-      long long behind = 0;
-      bool missing = false;
-      for (int s = 0; s < 2; ++s) {
-        if (!((seqs >> s) & 1)) continue;
-        auto f = x.sent.find({b, sel_id, s});
-        if (f == x.sent.end()) missing = true;
-        else behind = std::max(behind, x.version[b] - f->second);
-      }
-      if (!missing && (behind == 0 || behind <= x.max_delay)) return;  // current, or fresh enough for the staleness gate
-      for (int s = 0; s < 2; ++s) if ((seqs >> s) & 1) x.sent[{b, sel_id, s}] = x.version[b];
-      v.push_back({b, sel_id, seqs});
-    };
-    if (sel >= 0) for (int b : t->ag[sel]->neighbors) consider(b);
-    for (auto &a : t->ag) if (a->id != sel_id && std::binary_search(a->neighbors.begin(), a->neighbors.end(), sel_id)) consider(a->id);
+    Book K = book_of(t);
+    std::vector<Pair> v = token_pairs(topo_of(t), K, sel_id, seqs);
     rc = exchange_pairs(t, v);
     if (rc) return rc;
     if (sel >= 0 && !neighbor_poses_ready(*t->ag[sel], p.acceleration ? 1 : 0)) { set_err("run_ranks: neighbour poses missing (call dpgo_team_exchange_all_ranks once after set_initial)"); return DPGO_NOT_READY; }
@@ -448,6 +489,55 @@ int dpgo_team_run_group_ranks(dpgo_team_t *t, int g, int count) {
   if (rc) return rc;
   for (int id : members) x.version[id] = t->iter;
   x.iter_seen = t->iter;
+  return DPGO_OK;
+}
+
+// The planning layer replayed WITHOUT a device for one rank of a world (host arithmetic only): the full exchange that
+// follows set_initial, then `iters` iterations of the token schedule with the staleness gate.  npub[b * N + a] = public poses
+// of robot b that robot a needs (0: not neighbours).  out[(1 + iters) x world x 4]: per batch and peer rank {doubles sent,
+// doubles received, hash of the sent slabs' (b, a, sequence, count) in order, hash of the received ones'}.  A test calls it for
+// every rank and checks that what r sends to p is what p receives from r, batch by batch.
+int dpgo_rank_plan_simulate(int num_robots, int world, int rank, const int *owner, const int *npub, int acceleration,
+                            int max_delayed_iterations, int r, const int *sel_ids, int iters, long long *out) {
+  if (num_robots <= 0 || world <= 0 || rank < 0 || rank >= world || !owner || !npub || !out) { set_err("plan_simulate: bad arguments"); return DPGO_ERR; }
+  const int N = num_robots;
+  std::vector<int> own(owner, owner + N);
+  std::vector<std::vector<int>> nb(N);
+  for (int a = 0; a < N; ++a) for (int b = 0; b < N; ++b) if (a != b && (npub[a * N + b] > 0 || npub[b * N + a] > 0)) nb[a].push_back(b);
+  Topo T;
+  T.me = rank; T.loopback = false; T.owner = &own;
+  for (int a = 0; a < N; ++a) if (own[a] == rank) T.local.push_back(a);
+  T.nbrs = [&nb](int id) -> const std::vector<int> & { return nb[id]; };
+  T.count = [&](int b, int a) -> int { return npub[b * N + a] > 0 ? npub[b * N + a] : -1; };
+  std::vector<long long> version(N, 0);
+  std::map<std::tuple<int, int, int>, long long> sent;
+  Book K; K.max_delay = std::max(0, max_delayed_iterations); K.version = &version; K.sent = &sent;
+  const size_t B = (size_t)4 * r;
+  auto record = [&](int row, const Plan &P) {
+    long long *o = out + (size_t)row * world * 4;
+    for (int p = 0; p < world * 4; ++p) o[p] = 0;
+    auto hash = [](const PlanMsg &m) {
+      unsigned long long h = 1469598103934665603ull;
+      for (const PlanSeg &g : m.segs) for (int v : {g.b, g.a, g.q, g.count}) { h ^= (unsigned long long)(unsigned)v; h *= 1099511628211ull; }
+      return (long long)(h >> 1);
+    };
+    for (auto &kv : P.out) { o[kv.first * 4 + 0] = (long long)kv.second.len; o[kv.first * 4 + 2] = hash(kv.second); }
+    for (auto &kv : P.in) { o[kv.first * 4 + 1] = (long long)kv.second.len; o[kv.first * 4 + 3] = hash(kv.second); }
+  };
+  {
+    std::vector<Pair> v = all_pairs_of(T, 3u);
+    for (const Pair &p : v) { sent[{p.b, p.a, 0}] = version[p.b]; sent[{p.b, p.a, 1}] = version[p.b]; }
+    record(0, make_plan(T, v, B));
+  }
+  const unsigned seqs = acceleration ? 3u : 1u;
+  for (int q = 0; q < iters; ++q) {
+    const int sel_id = sel_ids[q];
+    if (sel_id < 0 || sel_id >= N) { set_err("plan_simulate: bad robot id in the schedule"); return DPGO_ERR; }
+    const long long k = q;
+    if (acceleration) for (int a = 0; a < N; ++a) if (a != sel_id) version[a] = k + 1;
+    record(1 + q, make_plan(T, token_pairs(T, K, sel_id, seqs), B));
+    version[sel_id] = k + 1;
+  }
   return DPGO_OK;
 }
 

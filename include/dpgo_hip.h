@@ -331,6 +331,13 @@ int dpgo_team_run_ranks(dpgo_team_t *t, const int *sel_ids, int iters);
  * dpgo_team_set_groups with the global classes) with their boundary slabs moved by the library in the same way */
 int dpgo_team_run_simultaneous_ranks(dpgo_team_t *t, int ticks);
 int dpgo_team_run_group_ranks(dpgo_team_t *t, int group, int count);
+/* the planning layer of the exchange replayed for ONE rank of a world, host arithmetic only (no device, no RCCL): the full
+ * exchange, then `iters` iterations of the token schedule with the staleness gate.  npub[b * num_robots + a] = public poses of
+ * robot b that robot a needs (0: not neighbours).  out[(1 + iters) * world * 4]: per batch and peer rank {doubles sent, doubles
+ * received, hash of the sent slabs in order, hash of the received slabs in order} -- what rank r sends to p must be what p
+ * receives from r (tests/test_rank_plan.py replays every rank of worlds of 2 .. 8). */
+int dpgo_rank_plan_simulate(int num_robots, int world, int rank, const int *owner, const int *npub, int acceleration,
+                            int max_delayed_iterations, int r, const int *sel_ids, int iters, long long *out);
 /* global cost: this team's owned-edge partial sums (t may be NULL on a rank without robots) + a 1-double all-reduce */
 int dpgo_comm_global_cost(dpgo_comm_t *c, dpgo_team_t *t, void *stream, double *f);
 /* out[4]: point-to-point messages sent / received by this rank, bytes sent / received */
