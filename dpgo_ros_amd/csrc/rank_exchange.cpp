@@ -428,7 +428,7 @@ int dpgo_team_run_ranks(dpgo_team_t *t, const int *sel_ids, int iters) {
     rc = exchange_pairs(t, v);
     if (rc) return rc;
     if (sel >= 0 && !neighbor_poses_ready(*t->ag[sel], p.acceleration ? 1 : 0)) { set_err("run_ranks: neighbour poses missing (call dpgo_team_exchange_all_ranks once after set_initial)"); return DPGO_NOT_READY; }
-    rc = enqueue_team_iteration(t, false, restart, sel, 2);
+    rc = enqueue_team_iteration(t, false, restart, sel, 2, /* mid_run: no statistics but for the last of the call */ q + 1 < iters);
     if (rc) return rc;
     const bool fused = p.method == DPGO_METHOD_RGD && p.rgd_use_preconditioner && !restart && sel >= 0 && !p.rgd_line_search;
     account_iteration(t, sel, fused || t->last_iteration_folded);

@@ -127,7 +127,8 @@ int enqueue_optimize(dpgo_team *t, int sel, const OptFlags &fl) {
       // K5: f_opt / gradnorm_opt on the snapshot B_X2 that K3 leaves behind
       launch_precond(c, sel, mn, PM_RGD_, B_X, B_GF, B_Z, 0, 0, p.rgd_stepsize, p.acceleration, p.num_robots,
                      fl.last_advances ? 1 : 0, p.restart_interval);
-      launch_eval(c, sel, mn, B_X2, B_EGRAD2, B_GF2, PART_A, eval_opts(t, 0, 0, 0));
+      // (mid-run iterations of a run of many -- dpgo_team_run_ranks -- leave the statistics out: nobody reads them)
+      if (!fl.skip_stats) launch_eval(c, sel, mn, B_X2, B_EGRAD2, B_GF2, PART_A, eval_opts(t, 0, 0, 0));
     } else {
       int dirb = B_GF;
       if (p.rgd_use_preconditioner) {
@@ -140,8 +141,9 @@ int enqueue_optimize(dpgo_team *t, int sel, const OptFlags &fl) {
     if (sel >= 0 && !fl.capture) {
       Agent &a = *t->ag[sel];
       if (p.rgd_use_preconditioner) { t->counters[0] += 1; t->counters[1] += precond_operator_bytes(a); }
-      t->counters[2] += 2; t->counters[3] += 2 * spmm_bytes_of(t, a);
-      a.opt_pending_rgd = true;
+      const bool stats = !(fl.skip_stats && fl.fused && p.rgd_use_preconditioner);
+      t->counters[2] += stats ? 2 : 1; t->counters[3] += (stats ? 2 : 1) * spmm_bytes_of(t, a);
+      a.opt_pending_rgd = stats;  // (without them PART_A still holds an older solve's sums: nothing may read it as this one's)
     }
     return 0;
   }
@@ -439,6 +441,7 @@ int enqueue_team_iteration(dpgo_team *t, bool capture, bool restart, int sel, in
     // the end-of-iteration bookkeeping; mid-run iterations of a graph leave out the statistics nobody reads
     const bool ls_folded = p.method == DPGO_METHOD_RGD && p.rgd_line_search && !restart && phase == 0;
     if (ls_folded) { fl.ls_tail = p.acceleration ? 3 : 1; fl.skip_stats = mid_run; }
+    if (fused && phase == 2) fl.skip_stats = mid_run;  // (the split iteration of the multi-rank runs)
     rc = enqueue_optimize(t, sel, fl);
     if (rc) return rc;
     folded = (p.method == DPGO_METHOD_RTR && t->last_rtr_folded) || ls_folded;
