@@ -88,7 +88,7 @@ dpgo_agent_reset_acceleration dpgo_team_prepare dpgo_agent_read_partials dpgo_ag
 dpgo_comm_unique_id dpgo_comm_create dpgo_comm_destroy dpgo_comm_rank dpgo_comm_world dpgo_comm_library
 dpgo_comm_allreduce_sum dpgo_comm_allreduce_max dpgo_team_attach_comm dpgo_team_detach_comm dpgo_team_exchange_all_ranks
 dpgo_team_run_ranks dpgo_comm_global_cost dpgo_team_comm_counters dpgo_team_set_iteration_log dpgo_team_run_simultaneous_ranks
-dpgo_team_run_group_ranks dpgo_rank_plan_simulate""".split()
+dpgo_team_run_group_ranks dpgo_rank_plan_simulate dpgo_team_set_uniform_schedule""".split()
 
 
 class DpgoError(RuntimeError):
@@ -539,6 +539,13 @@ class Team:
     def set_schedule(self, order):
         o = np.ascontiguousarray(order, dtype=np.int32)
         _chk(lib().dpgo_team_set_schedule(self.h, _d(o), len(o)), "set_schedule")
+
+    def set_uniform_schedule(self, seed, length):
+        """UpdateRule::Uniform (src/PGOAgentROS.cpp:446-463) with a given seed: draws `length` token holders, installs them as
+        the schedule and returns them"""
+        order = np.zeros(int(length), dtype=np.int32)
+        _chk(lib().dpgo_team_set_uniform_schedule(self.h, C.c_uint(int(seed)), int(length), _d(order)), "set_uniform_schedule")
+        return order
 
     def set_initial(self, T, YLift, offsets=None):
         off = self.offsets() if offsets is None else np.ascontiguousarray(offsets, dtype=np.int32)

@@ -8,6 +8,7 @@
 #include <unordered_map>
 
 #include <mutex>
+#include <random>
 #include "team_internal.h"
 
 using namespace dpgo;
@@ -1012,6 +1013,26 @@ int dpgo_team_set_schedule(dpgo_team_t *t, const int *order, int len) {
   t->descs_dirty = true;
   t->graph_valid = false;  // (captured runs bake the schedule into their launches)
   return 0;
+}
+
+// PGOAgentROSParameters::UpdateRule::Uniform (include/dpgo_ros/PGOAgentROS.h:35-41, the struct's default :76; selected at
+// src/PGOAgentROS.cpp:446-463): after every iteration the next token holder is drawn uniformly -- std::discrete_distribution
+// with equal weights over the active, initialised robots, a std::mt19937 -- with replacement, so a robot may follow itself
+// (:476 only warns).  The wrapper seeds from std::random_device; here the seed is given, and the draws are those the
+// wrapper's own lines make from an engine of that seed.  The order is installed as the team's schedule (period `length`).
+int dpgo_team_set_uniform_schedule(dpgo_team_t *t, unsigned seed, int length, int *order_out) {
+  if (length <= 0) { set_err("set_uniform_schedule: length must be positive"); return DPGO_ERR; }
+  std::vector<unsigned> active;
+  for (auto &a : t->ag) active.push_back((unsigned)a->id);
+  std::sort(active.begin(), active.end());
+  if (active.empty()) { set_err("set_uniform_schedule: the team holds no robot"); return DPGO_ERR; }
+  std::vector<double> weights(active.size(), 1.0);
+  std::discrete_distribution<int> distribution(weights.begin(), weights.end());
+  std::mt19937 gen(seed);
+  std::vector<int> order((size_t)length);
+  for (int k = 0; k < length; ++k) order[k] = (int)active[distribution(gen)];
+  if (order_out) std::copy(order.begin(), order.end(), order_out);
+  return dpgo_team_set_schedule(t, order.data(), length);
 }
 
 int dpgo_team_set_initial(dpgo_team_t *t, const double *T, const double *YLift, const int *offsets) {

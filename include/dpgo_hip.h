@@ -227,6 +227,10 @@ double dpgo_error_threshold_at_quantile(double quantile, int dim);
 /* ---- synchronous schedule on the device (src/PGOAgentROS.cpp:129-220,443-504,1161-1189):
  *      all agents of the problem live in this team; exchange is device-to-device ---- */
 int dpgo_team_set_schedule(dpgo_team_t *t, const int *order, int len);
+/* UpdateRule::Uniform (include/dpgo_ros/PGOAgentROS.h:35-41,76; src/PGOAgentROS.cpp:446-463): `length` token holders drawn
+ * uniformly with replacement by the wrapper's own recipe (std::discrete_distribution over the robots, std::mt19937) from an
+ * engine of the given seed (the wrapper seeds from std::random_device), installed as the schedule; order_out may be NULL */
+int dpgo_team_set_uniform_schedule(dpgo_team_t *t, unsigned seed, int length, int *order_out);
 int dpgo_team_set_initial(dpgo_team_t *t, const double *T, const double *YLift, const int *offsets);
 int dpgo_team_exchange_all(dpgo_team_t *t);
 /* run `iters` global RBCD iterations without host synchronisation (RGD: one hipGraph replay each) */

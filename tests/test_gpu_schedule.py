@@ -256,3 +256,36 @@ def test_iteration_log_of_a_real_gnc_run(tmp_path):
     assert abs(last[1] - final_cost) <= 1e-12 * abs(final_cost)   # the last row's global_cost is the final cost
     plain.close()
     logged.close()
+
+
+def _libstdcxx_uniform_draws(seed, n, length):
+    """std::discrete_distribution<int> with n equal weights fed by std::mt19937(seed), as libstdc++ evaluates it:
+    generate_canonical<double, 53> = (x0 + x1 * 2^32) / 2^64 from two engine outputs, then the first cumulative probability
+    that is not below it.  numpy's legacy RandomState seeds its MT19937 with the same init_genrand as std::mt19937."""
+    rs = np.random.RandomState(seed)
+    raw = rs.randint(0, 2 ** 32, size=2 * length, dtype=np.uint64)  # raw 32-bit outputs in engine order
+    cp = np.cumsum(np.full(n, 1.0 / n))[:-1]  # (libstdc++ keeps n - 1 partial sums of the normalised weights)
+    out = []
+    for k in range(length):
+        u = (float(raw[2 * k]) + float(raw[2 * k + 1]) * 4294967296.0) / 18446744073709551616.0
+        out.append(int(np.searchsorted(cp, u, side="left")))
+    return out
+
+
+def test_uniform_update_rule_follows_the_oracle_on_the_same_draws():
+    """UpdateRule::Uniform (include/dpgo_ros/PGOAgentROS.h:35-41, the struct default; src/PGOAgentROS.cpp:446-463): token
+    holders drawn with replacement by the wrapper's own recipe from a seeded engine -- the draws equal an independent replay
+    of that recipe, a robot may follow itself, and the run on that order follows the oracle"""
+    N = 5
+    kw = dict(method=capi.METHOD_RTR, acceleration=1, restart_interval=9, gradnorm_tol=1e-2, rtr_iterations=3, rtr_tcg_iterations=50)
+    th, to, n = make_pair("sphere2500", N, **kw)
+    order = th.set_uniform_schedule(2024, 64)
+    assert list(order) == _libstdcxx_uniform_draws(2024, N, 64)
+    assert set(order) == set(range(N)) and any(order[k] == order[k + 1] for k in range(63))
+    to.set_schedule(order)
+    th.run(64)
+    for _ in range(64):
+        to.iterate()
+    assert np.abs(th.global_X() - to.global_X()).max() < 1e-8
+    assert abs(th.cost() - to.cost()) <= 1e-10 * abs(to.cost())
+    th.close()
