@@ -493,6 +493,12 @@ class Comm:
             lib().dpgo_comm_destroy(self.h)
             self.h = None
 
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
 
 class Team:
     """The agents resident on one GPU.  With every agent of the problem local, `run` executes the

@@ -90,3 +90,17 @@ def test_bad_rank_rejected():
     p = capi.default_params(r=2, num_robots=1)
     with pytest.raises(capi.DpgoError):
         capi.Team(p, [0])
+
+
+def test_rank_exchange_fails_loudly_without_a_device():
+    """no CPU fallback in the multi-rank path either: without a HIP device a communicator cannot be created (the error says
+    why), and the planning layer -- host arithmetic -- rejects a rank outside its world"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(capi.DpgoError, match="no HIP device|RCCL"):
+        capi.Comm(b"\0" * capi.COMM_ID_BYTES, 0, 1, device=0)
+    with pytest.raises(capi.DpgoError, match="bad arguments"):
+        capi.rank_plan_simulate([0, 1], [[0, 3], [3, 0]], 5, 2, [0, 1])
+    lib_path, version = capi.comm_library()   # RCCL is bound at run time, also here
+    assert version > 20000 and "rccl" in lib_path
