@@ -562,9 +562,11 @@ def test_colour_parallel_sweeps_equal_the_permuted_sequential_schedule(dataset, 
     th.close()
 
 
-@pytest.mark.parametrize("dataset", ["tinyGrid3D", "smallGrid3D", "sphere2500"])
+@pytest.mark.parametrize("dataset", ["tinyGrid3D", "smallGrid3D", "sphere2500", "torus3D", "parking-garage"])
 def test_chordal_initialisation(dataset):
-    """8f-1: chordal relaxation on the GPU (dense SPD solves) vs the oracle's sparse-Cholesky version."""
+    """8f-1: chordal relaxation on the GPU vs the oracle's sparse-Cholesky version.  Round 5: through the solver's own
+    machinery (csrc/chordal.hip: the translation-free connection Laplacian in its dense or two-level form, pose 0 pinned as
+    a shared edge, one refinement step)."""
     m, _, n = load(dataset, 1)
     Th = capi.chordal_init(m.view(capi.MEAS_DTYPE), n)
     To = O.chordal_init(m, n)
@@ -575,6 +577,30 @@ def test_chordal_initialisation(dataset):
     if dataset == "sphere2500":
         c = 2 * O.measurement_cost(m, O.lift(Th, n, O.fixed_stiefel(5), 5), 5)
         assert abs(c - 1971.175) < 0.01  # SE-Sync's chordal-initialisation cost for sphere2500
+
+
+def test_chordal_initialisation_paths_agree_and_honour_weights():
+    """the team path and the dense fallback (DPGO_CHORDAL_DENSE=1, a fresh process: the switch is read once) give the same
+    poses, also with GNC-style edge weights (weight x kappa / tau is what both stages use) and a backward edge into pose 0"""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    from tests.util import ROOT
+    m, _, n = load("smallGrid3D", 1)
+    rng = np.random.default_rng(3)
+    mw = m.copy()
+    mw["weight"] = np.where(mw["p1"] + 1 == mw["p2"], 1.0, rng.uniform(0.05, 1.0, len(mw)))
+    To = O.chordal_init(mw, n)
+    Th = capi.chordal_init(mw.view(capi.MEAS_DTYPE), n)
+    assert np.abs(Th - To).max() < 1e-9 * max(1.0, np.abs(To).max())
+    with tempfile.TemporaryDirectory() as d:
+        np.save(os.path.join(d, "m.npy"), mw)
+        code = ("import numpy as np, sys; sys.path.insert(0, %r); from dpgo_ros_amd import capi; m = np.load(%r); "
+                "np.save(%r, capi.chordal_init(m.view(capi.MEAS_DTYPE), %d))" % (ROOT, os.path.join(d, "m.npy"), os.path.join(d, "T.npy"), n))
+        subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, DPGO_CHORDAL_DENSE="1"), timeout=300)
+        Td = np.load(os.path.join(d, "T.npy"))
+    assert np.abs(Td - Th).max() < 1e-9 * max(1.0, np.abs(To).max())
 
 
 def _oracle_robust_local_init(mo, n, kw):
