@@ -169,6 +169,7 @@ def single_gpu(args):
         t2.set_initial(T0, Y)
         hit, gap, k = None, float("inf"), 0
         tt = 0.0
+        trace = [[0, (t2.cost() - fstar) / fstar]]   # global cost vs iteration (north_star): [iteration, (f - f*) / f*]
         while k < cap:
             chunk = coarse if gap > 3e-6 else 1
             a0 = time.perf_counter()
@@ -177,11 +178,15 @@ def single_gpu(args):
             tt += time.perf_counter() - a0
             k += chunk
             gap = (t2.cost() - fstar) / fstar
+            if chunk > 1 or k % 10 == 0 or gap <= 1e-6:
+                trace.append([k, gap])
             if gap <= 1e-6:
                 hit = k
                 break
+        if len(trace) > 160:  # (keep the line readable: every other point of a long trace, the ends kept)
+            trace = trace[:1] + trace[1:-1][::max(1, len(trace) // 80)] + trace[-1:]
         conv[name] = {"iters_to_relcost_1e-6": hit, "relcost_at_stop": gap, "iters_run": k,
-                      "ms_per_iter_synced": tt / k * 1e3}
+                      "ms_per_iter_synced": tt / k * 1e3, "relcost_vs_iteration": trace}
         t2.close()
         if hit:
             t2 = capi.Team.from_measurements(mp, p2, device=0)
