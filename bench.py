@@ -811,6 +811,7 @@ def multi_gpu_impl(args):
 
     # (0) PublicPoses as RCCL point-to-point messages enqueued by the library (dpgo_team_run_ranks): no host language in
     # the loop, one host call for all K iterations
+    cost_start = comm.global_cost(be.team, stream=be.stream.cuda_stream)   # global cost vs iteration: before ...
     c0 = be.team.comm_counters() if be.team is not None else None
     ms_lib = timed(lambda k: drv.run_library(k))
     lib_msgs = None
@@ -823,6 +824,8 @@ def multi_gpu_impl(args):
     fstar_ = F_STAR[WORKLOAD["dataset"]]
     arm_extras_watchdog(rank, {"value": ms_lib, "ms_per_step": ms_lib, "cpu_baseline": None, "roofline": None,
                                "relcost_after_run": (cost_main - fstar_) / fstar_,
+                               "relcost_vs_iteration": [[0, (cost_start - fstar_) / fstar_],
+                                                        [args.warmup + args.steps, (cost_main - fstar_) / fstar_]],
                                "exchange_timing": {"ms_per_step_rccl_in_library": ms_lib, "rccl_in_library_per_step_this_rank": lib_msgs,
                                                    "rccl_library": lib_path, "rccl_version_code": lib_version,
                                                    "rccl_world_size": dist.get_world_size(), "backend": dist.get_backend(),
@@ -853,6 +856,8 @@ def multi_gpu_impl(args):
     if world == 1:
         exchange["loopback"] = loopback_leg(capi, mp, T, Y, comm, args)
     cost = comm.global_cost(be.team, stream=be.stream.cuda_stream)
+    exchange["relcost_vs_iteration"] = [[0, (cost_start - fstar_) / fstar_], [args.warmup + args.steps, (cost_main - fstar_) / fstar_],
+                                        [drv.k, (cost - fstar_) / fstar_]]
     cost_check = drv.global_cost(torch, "cuda")   # (the host-driven all-reduce of the same partial sums)
     exchange["global_cost_library_vs_torch_rel_diff"] = abs(cost - cost_check) / abs(cost_check)
     roof = None

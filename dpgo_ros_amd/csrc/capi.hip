@@ -1203,6 +1203,7 @@ static int team_run_impl(dpgo_team_t *t, int iters, bool prepare_only) {
     hipGraphExec_t ge = nullptr;
     HIPC(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
     (void)hipGraphDestroy(g);
+    (void)hipGraphUpload(ge, t->stream);  // (the first replay of a prepared graph then costs what the later ones do)
     t->graphs[key] = ge;
     *out = ge;
     return 0;
