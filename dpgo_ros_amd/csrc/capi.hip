@@ -107,6 +107,7 @@ dpgo_team_t *dpgo_team_create(int device, const dpgo_params_t *p, int num_local,
     const char *e5 = std::getenv("DPGO_FUSED_EVAL");
     if (e5) t->use_fused_eval = (e5[0] == '0') ? 0 : 1;
     if (const char *e6 = std::getenv("DPGO_FE_MIN_N")) t->fe_min_n = std::max(32, std::atoi(e6));
+    if (const char *e7 = std::getenv("DPGO_FE_CARRY")) t->use_fe_carry = (e7[0] == '0') ? 0 : 1;
     if (t->d_nest_all.alloc(3 * std::max(1, num_local)) ||
         hipMemset(t->d_nest_all.p, 0, sizeof(NestState) * 3 * std::max(1, num_local)) != hipSuccess) {
       delete t; set_err("hand-off state allocation failed"); return nullptr;
@@ -1102,6 +1103,27 @@ static bool fused_eval_eligible(dpgo_team_t *t) {
   return true;
 }
 
+// Carried rows of the one-launch iterations (step_fused.hip): launch `rep` of a run of nfe one-launch iterations finds the
+// row products of its agent formed by launch rep - 1, from the evaluation point launch rep - 2 left -- which takes the
+// agents of the three iterations to be three different ones (the point is formed while the agent rests) and both earlier
+// launches to be part of the same run.  The first two launches of a run form their row products themselves.
+static int fe_carry_flags(dpgo_team_t *t, int rep, int nfe, const std::function<int(int)> &sel_at) {
+  if (!t->use_fe_carry) return 0;
+  auto consumes = [&](int q) {
+    if (q < 2 || q >= nfe) return false;
+    const int a = sel_at(q - 2), b = sel_at(q - 1), c = sel_at(q);
+    if (a < 0 || a == b || a == c || b == c) return false;
+    // (the poses of agent c are spread over the workgroups of the launch of agent b)
+    const int nblk = precond_nblk(*t->ag[b]);
+    if ((t->ag[c]->n + nblk - 1) / nblk > step_fe_carry_max_poses()) return false;
+    // (a gradient wave of the launch of agent c fetches the shared edges of its 128 poses with two descriptors per lane)
+    for (int g = 0; g < 4; ++g)
+      if (t->ag[c]->dev.fe_eptr[g + 1] - t->ag[c]->dev.fe_eptr[g] > 128) return false;
+    return true;
+  };
+  return (consumes(rep) ? FE_CARRY_IN : 0) | (consumes(rep + 1) ? FE_CARRY_W : 0) | (consumes(rep + 2) ? FE_CARRY_Y : 0);
+}
+
 static int team_run_impl(dpgo_team_t *t, int iters, bool prepare_only) {
   if (sync_descs(t)) return DPGO_ERR;
   const dpgo_params_t &p = t->prm;
@@ -1173,7 +1195,8 @@ static int team_run_impl(dpgo_team_t *t, int iters, bool prepare_only) {
         const int ahead = (rep + 1 < B ? 3 : 0) | ((rep + 1 < B && rep + 1 >= B - L) ? 4 : 0) | (rep >= B - L ? 8 : 0);
         if (rep < nfe) {
           launch_step_fe(c, sel_at(rep), sel_at(rep + 1), p.rgd_stepsize, p.num_robots, p.restart_interval,
-                         rep == 0 ? nest_own : nest_fe[rep & 1], nest_fe[(rep + 1) & 1], rep & 1);
+                         rep == 0 ? nest_own : nest_fe[rep & 1], nest_fe[(rep + 1) & 1], rep & 1, sel_at(rep + 2),
+                         fe_carry_flags(t, rep, nfe, sel_at));
           continue;
         }
         launch_eval_stats(c, mn, rep == 0, 1, 0, p.num_robots, p.restart_interval, sel_at(rep), -1,
@@ -1976,7 +1999,8 @@ int dpgo_team_time_kernel(dpgo_team_t *t, int id, int which, int reps, double *a
     for (int k = 0; k < total_reps; ++k) {
       if (k == 8) HIPC(hipEventRecord(e0, t->stream));
       launch_step_fe(cc, sel_at(k), sel_at(k + 1), p.rgd_stepsize, p.num_robots, p.restart_interval,
-                     k == 0 ? nest_own : nest_fe[k & 1], nest_fe[(k + 1) & 1], k & 1);
+                     k == 0 ? nest_own : nest_fe[k & 1], nest_fe[(k + 1) & 1], k & 1, sel_at(k + 2),
+                     fe_carry_flags(t, k, total_reps, sel_at));
     }
     HIPC(hipEventRecord(e1, t->stream));
     launch_eval_stats(cc, mn, 0, 0, 1, p.num_robots, p.restart_interval, -1, sel_at(total_reps - 1), nest_fe[total_reps & 1]);

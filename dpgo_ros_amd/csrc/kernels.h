@@ -62,7 +62,8 @@ void launch_eval_stats(const LaunchCtx &c, int max_n, int first, int has_eval, i
 bool step_fe_supported(int r);
 int step_fe_max_edges();
 void launch_step_fe(const LaunchCtx &c, int sel, int next_sel, double step, int num_robots, int restart_interval,
-                    const NestState *nest_src, NestState *nest_dst, int parity);
+                    const NestState *nest_src, NestState *nest_dst, int parity, int next2_sel = -1, int carry = 0);
+int step_fe_carry_max_poses();
 constexpr int LS_MAX_TRIALS = 8;
 void launch_ls_trials(const LaunchCtx &c, int sel, int max_n, int dirb, double step0, double shrink, int ntrials);
 void launch_ls_cost(const LaunchCtx &c, int sel, int max_n, int dirb, int ntrials);

@@ -72,6 +72,10 @@ namespace dpgo {
 #endif
 
 constexpr int FE_KC = 2048;
+#ifndef DPGO_FE_HEAD
+#define DPGO_FE_HEAD 8
+#endif
+constexpr int FE_HEAD = DPGO_FE_HEAD;  // carried rows: 16-byte loads per lane of the slab requested before the gradient waves' second trip
 #ifndef DPGO_FE_PARTS
 #define DPGO_FE_PARTS 4
 #endif
@@ -102,11 +106,14 @@ __device__ __forceinline__ void fe_pin(double *w) {
   asm volatile("" ::: "memory");
 }
 
+// WD = ag.soa_w (5 .. 8): the launch forms the row products itself.  WD = 0: "carried rows" -- W_j = sum_i X_i Q_ij of this
+// agent was left in B_CARRY_W by the PREVIOUS launch (flags & FE_CARRY_W there), see the head of the file.
 template <int R, int WD>
 __global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ agents, TeamDev *team, int sel, int next_sel, double step,
                                                  int num_robots, int restart_interval, const NestState *nest_src, NestState *nest_dst,
-                                                 int parity, const AgentDev agv) {
+                                                 int parity, const AgentDev agv, int next2_sel, int flags, const AgentDev agn) {
   const AgentDev &ag = agv;
+  constexpr bool CARRIED = WD == 0;
   // The poses live twice (B_X / B_Y and their twins B_XALT / B_YALT): this launch reads the copy of its parity and writes
   // the other one -- every pose of every agent, so the copy it leaves is complete -- and the next launch does the
   // opposite.  Nobody overwrites what another workgroup of the same launch still reads: no arrival counter, no wait, no
@@ -129,12 +136,145 @@ __global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ ag
   __shared__ double Ysh[2 * 4 * R];
   __shared__ double Esh[2][2 * 4 * R];   // V, Yaux of the two poses
   __shared__ double Es[FE_MAX_EDGES * (4 * R + 16)];  // operands of the shared edges: neighbour pose, coefficients
+  __shared__ double Ptab[CARRIED ? FE_MAX_EDGES : 1];  // carried rows: where the neighbour pose of each shared edge lives
   __shared__ double tl_x[2 * 4 * R], tl_v[2 * 4 * R], tl_y[2 * 4 * R], tl_s[2 * 16];  // the two poses of the tail, lane-parallel
   FE_TRACE_DECL
   FE_STAMP(0);
   const int pj0 = 2 * bx, pj1 = (2 * bx + 1 < n) ? 2 * bx + 1 : -1;
   const int npose = (pj1 >= 0) ? 2 : 1;
 
+  // operands of the tail (consumed 10 us from here)
+  const size_t own_off = (size_t)((tid >= 4 * R) ? max(pj1, 0) : pj0) * 4 * R + (size_t)(tid % (4 * R));
+  double pre_x = 0, pre_v = 0, pre_y = 0;
+  if (tid < npose * 4 * R) {
+    pre_x = Xr[own_off];
+    pre_v = ag.buf[B_V][own_off];
+    pre_y = Yr[own_off];
+  }
+  NestState ns = {};
+  if (tid < 128) ns = nest_src[sel];
+  constexpr int EPE = 4 * R + 16;                              // doubles per shared edge in LDS: neighbour pose, coefficients
+  const int cg = (tid >> 5) & 7, kl = tid & 31;
+  const int col = 8 * bx + cg;
+  const bool cact = col < N4 && tid < 256;
+  const double *Mc = ag.M + (size_t)(cact ? col : 0) * N4;
+  double2 mreg[MREG];
+  if constexpr (CARRIED) {
+    // ================================================================ carried rows (WD = 0): two kinds of waves from the
+    // first instruction on.
+    //   * waves 0-3 (stream): request their 128 KB slab of M AT ONCE.  A wave stays at the issue of its loads for as long
+    //     as the CU's memory pipe is full, i.e. until most of the slab has landed (traced in round 5: with the slab requested
+    //     behind barrier 1 by all waves, the next instruction of every wave ran 5 us later) -- so these waves take part in
+    //     nothing else until the product, and nothing they would have to wait at lies between here and there.
+    //   * waves 4-7 (gradient): two poses per lane (wave g: poses 128 g .. 128 g + 127).  W_j and X_j arrive as [entry][pose]
+    //     arrays left by the previous launch (coalesced 8-byte loads, no LDS staging of X, no barrier); the operands of the
+    //     shared edges of ITS OWN poses are fetched by each wave for itself -- descriptors (one trip), then neighbour poses
+    //     and coefficients straight into LDS (global_load_lds, one dword per lane: no staging registers, no second pass) --
+    //     so the four waves never wait for each other either.  G_j, tangent projection, gradient into LDS.
+    // One barrier: the gradient is in LDS.
+    const int cwv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (cwv < 4) {
+      for (int t = N4 * R + tid; t < KC * R; t += 256) vs[t] = 0.0;  // rows of the vector beyond the agent's
+#pragma unroll
+      for (int m = 0; m < FE_HEAD; ++m) mreg[m] = ld2_nt(Mc + min(2 * kl + 64 * m, N4 - 2));
+      lds_barrier();  // A: the gradient waves have requested everything they need; the rest of the slab goes behind it
+#pragma unroll
+      for (int m = FE_HEAD; m < MREG; ++m) mreg[m] = ld2_nt(Mc + min(2 * kl + 64 * m, N4 - 2));
+    } else {
+      const int g = cwv - 4, ln = tid & 63;
+      const int jA = 128 * g + ln, jB = jA + 64;
+      const bool actA = jA < n, actB = jB < n;
+      const int cA = actA ? jA : 0, cB = actB ? jB : 0;
+      const int t0 = ag.fe_eptr[g], t1 = ag.fe_eptr[g + 1], ne = t1 - t0;  // this wave's shared edges (uniform; <= 128, host)
+      // trip 1: where the neighbour poses of these edges live
+      const double *ep[2] = {nullptr, nullptr};
+      int es[2] = {0, 0};
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        if (64 * q < ne) {  // (uniform)
+          const SharedEdgeDev &se = ag.se[t0 + min(ln + 64 * q, ne - 1)];
+          ep[q] = parity ? se.src_yalt : se.src[1]; es[q] = se.slot;
+        }
+      const int e0A = ag.pose_eptr[cA], e1A = ag.pose_eptr[cA + 1], e0B = ag.pose_eptr[cB], e1B = ag.pose_eptr[cB + 1];
+      const double *Wc = ag.buf[B_CARRY_W], *Xc = ag.buf[B_CARRY_X];
+      double wA[4 * R], xA[4 * R], wB[4 * R], xB[4 * R];
+#pragma unroll
+      for (int i = 0; i < 4 * R; ++i) { wA[i] = Wc[(size_t)i * n + cA]; xA[i] = Xc[(size_t)i * n + cA]; }
+#pragma unroll
+      for (int i = 0; i < 4 * R; ++i) { wB[i] = Wc[(size_t)i * n + cB]; xB[i] = Xc[(size_t)i * n + cB]; }
+      double *ptab = Ptab;  // [edge] resolved address of the neighbour pose
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        if (64 * q < ne) {
+          const double *xp = ep[q] ? ep[q] : ag.nbr[1] + (size_t)es[q] * 4 * R;
+          if (ln + 64 * q < ne) reinterpret_cast<const double **>(ptab)[t0 + ln + 64 * q] = xp;
+        }
+      WSYNC();
+      // trip 2: 16 bytes per lane and instruction, landing in LDS in lane order (the record of an edge is EPE / 2 such units:
+      // 2R of the neighbour pose, 8 of coefficients); four instructions' addresses are looked up before the four are issued
+      {
+        constexpr int UPE = EPE / 2;
+        const int nun = ne * UPE;
+        const double *const *ptd = reinterpret_cast<const double *const *>(ptab);
+        for (int c0 = 0; c0 < nun; c0 += 256) {
+          const double *src[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int d = min(c0 + 64 * q + ln, nun - 1);
+            const int er = d / UPE, k = d - er * UPE;
+            src[q] = (k < 2 * R) ? ptd[t0 + er] + 2 * k : ag.se[t0 + er].coef + 2 * (k - 2 * R);
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (c0 + 64 * q < nun) {  // (uniform)
+              if (c0 + 64 * q + ln < nun)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src[q],
+                                                 (__attribute__((address_space(3))) void *)(Es + (size_t)t0 * EPE + 2 * (c0 + 64 * q)), 16, 0, 0);
+            }
+        }
+      }
+      lds_barrier();  // A (see the stream waves)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      WSYNC();
+      FE_STAMP(1);
+      auto g_term = [&](int e0, int e1, double *w) {
+        // G_j from LDS: g[c][a] -= x[cp][a] coef[cp + 4c], edge after edge and cp after cp for every entry (g_row_range's order)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          double gg[R];
+#pragma unroll
+          for (int a = 0; a < R; ++a) gg[a] = 0.0;
+          for (int e = e0; e < e1; ++e) {
+            const double *E = Es + (size_t)e * EPE;
+#pragma unroll
+            for (int cp = 0; cp < 4; ++cp) {
+              const double cf = E[4 * R + cp + 4 * c];
+#pragma unroll
+              for (int a = 0; a < R; ++a) gg[a] -= E[cp * R + a] * cf;
+            }
+          }
+#pragma unroll
+          for (int a = 0; a < R; ++a) w[c * R + a] = w[c * R + a] + gg[a];
+        }
+      };
+      if (actA && e1A > e0A) g_term(e0A, e1A, wA);
+      if (actB && e1B > e0B) g_term(e0B, e1B, wB);
+      FE_STAMP(2);
+      tangent_inplace<R>(xA, wA);
+      tangent_inplace<R>(xB, wB);
+      FE_STAMP(3);
+      if (actA) {
+#pragma unroll
+        for (int i = 0; i < 4 * R; ++i) vs[(size_t)4 * R * jA + i] = wA[i];
+      }
+      if (actB) {
+#pragma unroll
+        for (int i = 0; i < 4 * R; ++i) vs[(size_t)4 * R * jB + i] = wB[i];
+      }
+    }
+    lds_barrier();  // the gradient is in LDS
+  } else {
+  const int kslab = (tid < 256) ? 2 * kl : 0, kstep = (tid < 256) ? 64 : 0;  // (waves 4-7: always row 0)
   // ================================================================ the evaluation: one lane per pose, all 8 waves
   // W_j = sum_i X_i Q_ij + G_j (see the head of the file)
   const int j = tid;
@@ -146,7 +286,6 @@ __global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ ag
   // shared edges forms G_j from LDS, edge after edge in g_row_range's order (the host checks nshared <= FE_MAX_EDGES).
   // The neighbour's pose comes straight from its agent's Y array where it is co-resident (or imported), from the
   // neighbour slab otherwise (g_row_range, aux = 1, pull).
-  constexpr int EPE = 4 * R + 16;                              // doubles per edge in LDS
   constexpr int NEI = (FE_MAX_EDGES * EPE + 511) / 512;        // trips that cover FE_MAX_EDGES edges
   const int nsh = ag.nshared, etotal = nsh * EPE;
   const double *esrc[NEI];
@@ -160,16 +299,6 @@ __global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ ag
     }
   }
   const int e0 = ag.pose_eptr[jj], e1 = ag.pose_eptr[jj + 1];  // the pose's shared edges (empty for most poses)
-  // operands of the tail (consumed 10 us from here)
-  const size_t own_off = (size_t)((tid >= 4 * R) ? max(pj1, 0) : pj0) * 4 * R + (size_t)(tid % (4 * R));
-  double pre_x = 0, pre_v = 0, pre_y = 0;
-  if (tid < npose * 4 * R) {
-    pre_x = Xr[own_off];
-    pre_v = ag.buf[B_V][own_off];
-    pre_y = Yr[own_off];
-  }
-  NestState ns = {};
-  if (tid < 128) ns = nest_src[sel];
   constexpr int NSTG = (KC * R / 2 + 511) / 512;
   double2 xv[NSTG];
   {
@@ -226,11 +355,6 @@ __global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ ag
   // the slab of M (waves 0-3): requested in four parts, each as soon as a slot of the ring is free for good -- behind
   // every load of the evaluation in the CU's queue (a slab requested earlier holds them back until it has landed:
   // measured, X staged at 6.5 us instead of 2), and as early as the registers allow: it streams under the rest of the row
-  const int cg = (tid >> 5) & 7, kl = tid & 31;
-  const int col = 8 * bx + cg;
-  const bool cact = col < N4 && tid < 256;
-  const double *Mc = ag.M + (size_t)(cact ? col : 0) * N4;
-  double2 mreg[MREG];
   // the edge operands were requested in front of the ring and are back before its first slot: into LDS now (their
   // registers are free for the row)
 #pragma unroll
@@ -249,15 +373,17 @@ __global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ ag
       idx[k] = ct[(u + RING) * 64];
 #pragma unroll
       for (int q = 0; q < 8; ++q) B[k][q] = ld2(qt + ((u + RING) * 8 + q) * 128);
-    } else if (tid < 256 && u >= WD - FE_PARTS) {  // (wave-uniform)
+    } else if (u >= WD - FE_PARTS) {
+      // EVERY wave issues these loads, and nothing is selected on their data here.  Under `tid < 256` the compiler's wait
+      // counts behind the join are those of the path that skipped the loads: every block of the row behind a slab part
+      // then waited for that part to LAND, and a select on the loaded value inside the branch waited for it on the spot --
+      // the stream ran as four exposed round trips (round 5, read off the ISA).  Waves 4-7 read one 16-byte word of M over
+      // and over (their copies are never used); rows k >= N4 meet zeros of the vector, columns beyond the last pose feed
+      // sums nobody reads.
       constexpr int PART = MREG / FE_PARTS;
       const int part = u - (WD - FE_PARTS);  // 0 .. FE_PARTS - 1
 #pragma unroll
-      for (int m = part * PART; m < (part + 1) * PART; ++m) {
-        const int kk = 2 * kl + 64 * m;
-        const double2 t = ld2_nt(Mc + min(kk, N4 - 2));
-        mreg[m] = (cact && kk < N4) ? t : make_double2(0.0, 0.0);
-      }
+      for (int m = part * PART; m < (part + 1) * PART; ++m) mreg[m] = ld2_nt(Mc + min(kslab + kstep * m, N4 - 2));
     }
     if (u == 1) lds_barrier();  // #1a: the edge operands are in LDS
     __builtin_amdgcn_sched_barrier(0);
@@ -297,6 +423,7 @@ __global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ ag
     for (int i = 0; i < 4 * R; ++i) vs[(size_t)4 * R * j + i] = w[i];
   }
   lds_barrier();  // #3: the gradient is in LDS
+  }
   FE_STAMP(4);
   if (tid >= 256) {
     if (bx == 0 && tid == 256) {
@@ -320,6 +447,31 @@ __global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ ag
       team->next_sel = next_sel;
       team->cur_sel = next_sel;
     }
+    if (flags & FE_CARRY_W) {
+      // ---- the row products of the NEXT agent (carried rows): W_p = sum_i X_i Q_ip at the point the next launch will
+      // evaluate at -- B_CARRY_Y, left complete by the launch before this one -- for this workgroup's share of its poses,
+      // one (pose, entry) per lane: fe_block's expression slot after slot, so the sums are BITWISE the ones the next launch
+      // would form itself.  Two short round trips behind the slab in this CU's queue; the stream waves are busy with their
+      // product for longer than that.
+      const int l = tid - 256;
+      const int npw = (agn.n + nblk - 1) / nblk;  // (<= 12, checked by the host)
+      const int lp = l / (4 * R), e = l - lp * (4 * R);
+      const int pw = bx * npw + lp;
+      if (lp < npw && pw < agn.n) {
+        const int c = e / R, a = e - c * R;
+        const int tile = pw >> 6, pl = pw & 63, wdn = agn.soa_w;
+        const double *__restrict__ Y2 = agn.buf[B_CARRY_Y];
+        double acc = 0.0;
+        for (int u = 0; u < wdn; ++u) {
+          const int i = agn.soa_col[((size_t)tile * wdn + u) * 64 + pl];
+          const double *xp = Y2 + (size_t)4 * R * i + a;
+          const double *bp = agn.soa_val + ((size_t)tile * wdn + u) * 1024 + (2 * c) * 128 + 2 * pl;
+          acc = fma4(xp[0], bp[0], xp[R], bp[1], xp[2 * R], bp[128], xp[3 * R], bp[129], acc);
+        }
+        agn.buf[B_CARRY_W][(size_t)e * agn.n + pw] = acc;
+        agn.buf[B_CARRY_X][(size_t)e * agn.n + pw] = Y2[(size_t)4 * R * pw + e];  // (the point itself, [entry][pose])
+      }
+    }
     lds_barrier();  // #4: (the stream waves' partial sums)
     FE_FLUSH();
     return;
@@ -331,6 +483,11 @@ __global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ ag
   const double nest_gamma = restart_now ? 0.0 : (1.0 + sqrt(1.0 + 4.0 * Nr * Nr * ns.gamma * ns.gamma)) / (2.0 * Nr);
   const double g2 = (1.0 + sqrt(1.0 + 4.0 * Nr * Nr * nest_gamma * nest_gamma)) / (2.0 * Nr);
   const double ahead_alpha = 1.0 / (g2 * Nr);
+  // (two iterations ahead, carried rows: the scalars the NEXT launch will look ahead with)
+  const bool restart_next2 = ((ns.iter + 4) % restart_interval) == 0;
+  const double gamma_next = restart_next ? 0.0 : g2;
+  const double g3 = (1.0 + sqrt(1.0 + 4.0 * Nr * Nr * gamma_next * gamma_next)) / (2.0 * Nr);
+  const double ahead2_alpha = 1.0 / (g3 * Nr);
   const bool ahead_opt = next_sel == sel;
   double acc[R];
 #pragma unroll
@@ -382,6 +539,7 @@ __global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ ag
       py[k] = (k < na) ? agents[k].buf[B_Y] : nullptr;
       dalt[k] = (long long)B_ALT * 4 * R * (pre[k + 1] - pre[k]);
     }
+    double *py2 = (flags & FE_CARRY_Y) ? agents[next2_sel].buf[B_CARRY_Y] : nullptr;
     const int total = pre[LOOKAHEAD_MAX_AGENTS] - n;
     const int per = (total + nblk - 1) / nblk;  // <= 64, checked by the host
     const int l1 = tid - 64;
@@ -411,7 +569,7 @@ __global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ ag
 #pragma unroll
         for (int i = 0; i < 4 * R; ++i) {
           oX[o + i] = la_x[i];
-          if (!la_opt) { oY[o + i] = la_x[i]; oV[o + i] = la_x[i]; } else oY[o + i] = yr[o + i];
+          if (!la_opt) { oY[o + i] = la_x[i]; oV[o + i] = la_x[i]; la_v[i] = la_x[i]; } else oY[o + i] = yr[o + i];
         }
       } else {
         double y[4 * R];
@@ -419,7 +577,24 @@ __global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ ag
         for (int i = 0; i < 4 * R; ++i) y[i] = (1.0 - ahead_alpha) * la_x[i] + ahead_alpha * la_v[i];
         polar_inplace<R>(y);
 #pragma unroll
-        for (int i = 0; i < 4 * R; ++i) { oY[o + i] = y[i]; oX[o + i] = y[i]; }
+        for (int i = 0; i < 4 * R; ++i) { oY[o + i] = y[i]; oX[o + i] = y[i]; la_x[i] = y[i]; }
+      }
+      if (py2 && a == next2_sel) {
+        // carried rows, first half: the point the agent of iteration k+2 will be evaluated at -- what the look-ahead wave of
+        // the NEXT launch will leave in its X array (the same expressions on the same operands: bitwise) -- is formed one
+        // launch early, so that the next launch finds it complete and can form the row products on the side.  (The agent
+        // moves in neither launch: it is neither this launch's nor the next one's.  la_x / la_v hold its X and V after
+        // iteration k+1 here.)
+        if (!restart_next2) {
+          double y[4 * R];
+#pragma unroll
+          for (int i = 0; i < 4 * R; ++i) y[i] = (1.0 - ahead2_alpha) * la_x[i] + ahead2_alpha * la_v[i];
+          polar_inplace<R>(y);
+#pragma unroll
+          for (int i = 0; i < 4 * R; ++i) la_x[i] = y[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4 * R; ++i) py2[o + i] = la_x[i];
       }
     }
     FE_STAMP(15);
@@ -493,15 +668,23 @@ __global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ ag
 bool step_fe_supported(int r) { return r >= 3 && r <= 5; }
 int step_fe_max_edges() { return FE_MAX_EDGES; }
 
+int step_fe_carry_max_poses() { return 256 / 20; }  // poses of the next agent a workgroup can take (one (pose, entry) per lane of waves 4-7)
+
+// carry: FE_CARRY_IN -- the row products of `sel` wait in its B_CARRY_W (the previous launch ran with FE_CARRY_W);
+// FE_CARRY_W -- form the row products of next_sel from its B_CARRY_Y (left by the launch before this one, FE_CARRY_Y there);
+// FE_CARRY_Y -- leave the evaluation point of next2_sel in its B_CARRY_Y
 void launch_step_fe(const LaunchCtx &c, int sel, int next_sel, double step, int num_robots, int restart_interval,
-                    const NestState *nest_src, NestState *nest_dst, int parity) {
+                    const NestState *nest_src, NestState *nest_dst, int parity, int next2_sel, int carry) {
   const AgentDev &d = c.host_agents[sel];
+  const AgentDev &dn = c.host_agents[(carry & FE_CARRY_W) ? next_sel : sel];
   const int grid = ((d.N4 + 7) / 8 + 7) / 8 * 8;
+  const int flags = carry & (FE_CARRY_W | FE_CARRY_Y);
 #define FE_LAUNCH(RR, WW)                                                                                              \
   hipLaunchKernelGGL((k_step_fe<RR, WW>), dim3(grid), dim3(512), 0, c.stream, c.agents, c.team, sel, next_sel, step, num_robots, \
-                     restart_interval, nest_src, nest_dst, parity, d)
+                     restart_interval, nest_src, nest_dst, parity, d, next2_sel, flags, dn)
 #define FE_LAUNCH_W(RR)                                                                                                \
-  switch (d.soa_w) {                                                                                                   \
+  switch ((carry & FE_CARRY_IN) ? 0 : d.soa_w) {                                                                       \
+    case 0: FE_LAUNCH(RR, 0); break;                                                                                   \
     case 5: FE_LAUNCH(RR, 5); break;                                                                                   \
     case 6: FE_LAUNCH(RR, 6); break;                                                                                   \
     case 7: FE_LAUNCH(RR, 7); break;                                                                                   \

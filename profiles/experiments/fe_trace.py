@@ -25,10 +25,14 @@ for rep in range(3):
 allb = np.zeros(8 * 2 * 256)
 capi.lib().dpgo_agent_read_partials(team.h, 4, PART_E + 4100 * 8, capi._d(allb), allb.size)
 allb = allb.reshape(256, 2, 8)[:250]
+allb = allb[allb[:, 0, 0] > 0]
 t0 = allb[:, 0, 0].min()
 st = (allb[:, 0, 0] - t0) / 100.0
 e0 = (allb[:, 0, 1] - t0) / 100.0
-print("workgroup start: min %.2f max %.2f | wave-0 end: min %.2f median %.2f max %.2f" % (st.min(), st.max(), e0.min(), np.median(e0), e0.max()))
+print("workgroups %d start: min %.2f max %.2f | wave-0 end: min %.2f median %.2f max %.2f" % (len(st), st.min(), st.max(), e0.min(), np.median(e0), e0.max()))
+order = np.argsort(e0)
+print("latest wave-0 ends:", " ".join("%d:%.2f(start %.2f)" % (i, e0[i], st[i]) for i in order[-8:]))
+print("earliest:", " ".join("%d:%.2f" % (i, e0[i]) for i in order[:8]))
 ms, b = team.time_kernel(1, 14, reps=500)
 print("k_step_fe in this build: %.2f us per launch (HIP events)" % (ms * 1e3))
 import ctypes
