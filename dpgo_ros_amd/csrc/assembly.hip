@@ -355,7 +355,7 @@ int finalize_agent(dpgo_team *t, Agent &a, double *scratch) {
     for (int j = 0; j < n; ++j) a.max_pose_edges = std::max(a.max_pose_edges, pose_eptr[j + 1] - pose_eptr[j]);
     for (int j = 0; j < n; j += ppb) a.max_tile_edges = std::max(a.max_tile_edges, pose_eptr[std::min(n, j + ppb)] - pose_eptr[j]);
   }
-  for (int g = 0; g < 5; ++g) a.dev.fe_eptr[g] = pose_eptr[std::min(128 * g, n)];
+  for (int g = 0; g < 5; ++g) a.dev.fe_eptr[g] = pub_ptr[std::min(64 * g, a.npub)];
   a.dev.fe_pad_ = 0;
   a.se_host = se;  // the neighbour-pose pointers are filled in by sync_descs once every agent's buffers exist
   // edge records for residual / cost evaluation

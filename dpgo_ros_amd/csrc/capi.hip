@@ -1116,7 +1116,8 @@ static int fe_carry_flags(dpgo_team_t *t, int rep, int nfe, const std::function<
     // (the poses of agent c are spread over the workgroups of the launch of agent b)
     const int nblk = precond_nblk(*t->ag[b]);
     if ((t->ag[c]->n + nblk - 1) / nblk > step_fe_carry_max_poses()) return false;
-    // (a gradient wave of the launch of agent c fetches the shared edges of its 128 poses with two descriptors per lane)
+    // (a gradient wave of the launch of agent c finishes 64 public poses and fetches their shared edges, two per lane)
+    if (t->ag[c]->npub > 256) return false;
     for (int g = 0; g < 4; ++g)
       if (t->ag[c]->dev.fe_eptr[g + 1] - t->ag[c]->dev.fe_eptr[g] > 128) return false;
     return true;

@@ -19,6 +19,7 @@ enum Buf {
 // ([pose][4r]) and the row products formed from it ([entry][pose]).  They live inside one captured run of one-launch
 // iterations only, in two work vectors of the trust-region solver that an RGD team never touches meanwhile.
 constexpr int B_CARRY_Y = B_R0, B_CARRY_W = B_R1, B_CARRY_X = B_D0;  // (B_CARRY_X: the evaluation point once more as [entry][pose])
+constexpr int B_CARRY_G = B_D1;  // tangent projection of the row products at the point, [pose][4r]: the gradient of a pose without shared edges
 constexpr int FE_CARRY_IN = 1, FE_CARRY_W = 2, FE_CARRY_Y = 4;
 constexpr int B_ALT = B_XALT - B_X;
 static_assert(B_YALT - B_Y == B_ALT, "X and Y twins share one displacement");
@@ -105,8 +106,8 @@ struct AgentDev {
   const int *pub_index;       // [n] index into pub_pose/pub_ptr or -1
   const int *pose_eptr;       // [n+1] CSR of `se` by local pose: the shared edges of pose j are [pose_eptr[j], pose_eptr[j+1])
                               // (the evaluation finds them with one round trip instead of pub_index -> pub_ptr)
-  int fe_eptr[5], fe_pad_;    // pose_eptr[min(128 g, n)], g = 0 .. 4 (agents of <= 512 poses): the shared edges of the 128 poses a
-                              // gradient wave of the carried one-launch iteration owns, known without a round trip
+  int fe_eptr[5], fe_pad_;    // pub_ptr[min(64 g, npub)], g = 0 .. 4: the shared edges of the 64 public poses a gradient wave of
+                              // the carried one-launch iteration finishes, known without a round trip
   const double *M;            // dense (Q + shift I)^-1, N4 x N4 column-major (symmetric); null: block-Jacobi agent
   const double *Dinv;         // block-Jacobi agents: the inverted 4 x 4 diagonal blocks of Q + shift I, [n][16] column-major
   TLDev tl;                   // two-level agents (tl.nwg > 0; M and Dinv null)

@@ -136,7 +136,6 @@ __global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ ag
   __shared__ double Ysh[2 * 4 * R];
   __shared__ double Esh[2][2 * 4 * R];   // V, Yaux of the two poses
   __shared__ double Es[FE_MAX_EDGES * (4 * R + 16)];  // operands of the shared edges: neighbour pose, coefficients
-  __shared__ double Ptab[CARRIED ? FE_MAX_EDGES : 1];  // carried rows: where the neighbour pose of each shared edge lives
   __shared__ double tl_x[2 * 4 * R], tl_v[2 * 4 * R], tl_y[2 * 4 * R], tl_s[2 * 16];  // the two poses of the tail, lane-parallel
   FE_TRACE_DECL
   FE_STAMP(0);
@@ -162,114 +161,135 @@ __global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ ag
   if constexpr (CARRIED) {
     // ================================================================ carried rows (WD = 0): two kinds of waves from the
     // first instruction on.
-    //   * waves 0-3 (stream): request their 128 KB slab of M AT ONCE.  A wave stays at the issue of its loads for as long
-    //     as the CU's memory pipe is full, i.e. until most of the slab has landed (traced in round 5: with the slab requested
-    //     behind barrier 1 by all waves, the next instruction of every wave ran 5 us later) -- so these waves take part in
-    //     nothing else until the product, and nothing they would have to wait at lies between here and there.
-    //   * waves 4-7 (gradient): two poses per lane (wave g: poses 128 g .. 128 g + 127).  W_j and X_j arrive as [entry][pose]
-    //     arrays left by the previous launch (coalesced 8-byte loads, no LDS staging of X, no barrier); the operands of the
-    //     shared edges of ITS OWN poses are fetched by each wave for itself -- descriptors (one trip), then neighbour poses
-    //     and coefficients straight into LDS (global_load_lds, one dword per lane: no staging registers, no second pass) --
-    //     so the four waves never wait for each other either.  G_j, tangent projection, gradient into LDS.
-    // One barrier: the gradient is in LDS.
+    //   * waves 0-3 (stream): request the head of their 128 KB slab of M at once, the rest behind barrier A.  A wave stays
+    //     at the issue of its loads for as long as the CU's memory pipe is full, i.e. until most of what it asked for has
+    //     landed (traced in round 5: with the slab requested behind barrier 1 by all waves, the next instruction of every
+    //     wave ran 5 us later) -- so these waves take part in nothing else until the product.
+    //   * waves 4-7 (gradient).  The previous launch left, for every pose of this agent, the tangent projection of its row
+    //     product at the evaluation point -- which IS the Riemannian gradient of a pose without shared edges, bit for bit
+    //     (B_CARRY_G, [pose][4r]: the layout of the vector in LDS) -- and the row products and the point themselves as
+    //     [entry][pose] arrays.  Trip 1: B_CARRY_G into LDS (coalesced 16-byte loads); the descriptors and coefficients of the
+    //     shared edges, one edge per lane; the public pose each lane is to finish.  Trip 2 (behind it, before barrier A):
+    //     the neighbour pose of the lane's edge; W_j and X_j of the lane's public pose.  Then G_j, the projection, and the
+    //     row of the vector in LDS is overwritten.  A wave fetches the edges of ITS OWN 64 public poses (fe_eptr: known
+    //     without a trip): the four waves never wait for each other.
+    // Barrier A: the gradient waves have requested all they need (the bulk of the slab queues behind it, not in front);
+    // barrier B: the gradient is in LDS.
     const int cwv = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (cwv < 4) {
       for (int t = N4 * R + tid; t < KC * R; t += 256) vs[t] = 0.0;  // rows of the vector beyond the agent's
 #pragma unroll
       for (int m = 0; m < FE_HEAD; ++m) mreg[m] = ld2_nt(Mc + min(2 * kl + 64 * m, N4 - 2));
-      lds_barrier();  // A: the gradient waves have requested everything they need; the rest of the slab goes behind it
+      FE_STAMP(10);
+      lds_barrier();  // A
+      FE_STAMP(11);
 #pragma unroll
       for (int m = FE_HEAD; m < MREG; ++m) mreg[m] = ld2_nt(Mc + min(2 * kl + 64 * m, N4 - 2));
+      FE_STAMP(12);
     } else {
-      const int g = cwv - 4, ln = tid & 63;
-      const int jA = 128 * g + ln, jB = jA + 64;
-      const bool actA = jA < n, actB = jB < n;
-      const int cA = actA ? jA : 0, cB = actB ? jB : 0;
-      const int t0 = ag.fe_eptr[g], t1 = ag.fe_eptr[g + 1], ne = t1 - t0;  // this wave's shared edges (uniform; <= 128, host)
-      // trip 1: where the neighbour poses of these edges live
+      const int g = cwv - 4, ln = tid & 63, l = tid - 256;
+      const int npub = ag.npub;
+      const int t0 = ag.fe_eptr[g], t1 = ag.fe_eptr[g + 1], ne = t1 - t0;  // shared edges of this wave's public poses (uniform; <= 128, host)
+      // ---- trip 1
+      // the lane's edges (ln, ln + 64 of the wave's): where the neighbour pose lives, the 16 coefficients
       const double *ep[2] = {nullptr, nullptr};
       int es[2] = {0, 0};
+      double2 cf[2][8];
 #pragma unroll
       for (int q = 0; q < 2; ++q)
         if (64 * q < ne) {  // (uniform)
           const SharedEdgeDev &se = ag.se[t0 + min(ln + 64 * q, ne - 1)];
           ep[q] = parity ? se.src_yalt : se.src[1]; es[q] = se.slot;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) cf[q][k] = ld2(se.coef + 2 * k);
         }
-      const int e0A = ag.pose_eptr[cA], e1A = ag.pose_eptr[cA + 1], e0B = ag.pose_eptr[cB], e1B = ag.pose_eptr[cB + 1];
-      const double *Wc = ag.buf[B_CARRY_W], *Xc = ag.buf[B_CARRY_X];
-      double wA[4 * R], xA[4 * R], wB[4 * R], xB[4 * R];
+      // the lane's public pose and its edges
+      const int pq = 64 * g + ln;
+      const bool pact = pq < npub;
+      const int pj = ag.pub_pose[pact ? pq : 0];
+      const int pe0 = ag.pub_ptr[pact ? pq : 0], pe1 = ag.pub_ptr[pact ? pq + 1 : 0];
+      // the carried gradient: 16 bytes per lane and load, straight into the vector's layout
+      constexpr int NG = (KC * R / 2 + 255) / 256;
+      double2 gv[NG];
+      {
+        const double *Gc = ag.buf[B_CARRY_G];
 #pragma unroll
-      for (int i = 0; i < 4 * R; ++i) { wA[i] = Wc[(size_t)i * n + cA]; xA[i] = Xc[(size_t)i * n + cA]; }
+        for (int u = 0; u < NG; ++u) gv[u] = ld2(Gc + min(2 * (l + 256 * u), N4 * R - 2));
+      }
+      FE_STAMP(13);
+      // the carried gradient and the coefficients are back: into LDS (their registers are the second trip's)
 #pragma unroll
-      for (int i = 0; i < 4 * R; ++i) { wB[i] = Wc[(size_t)i * n + cB]; xB[i] = Xc[(size_t)i * n + cB]; }
-      double *ptab = Ptab;  // [edge] resolved address of the neighbour pose
+      for (int u = 0; u < NG; ++u) {
+        const int tt = 2 * (l + 256 * u);
+        if (tt < N4 * R) *reinterpret_cast<double2 *>(&vs[tt]) = gv[u];
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        if (64 * q < ne && ln + 64 * q < ne) {
+          double *E = Es + (size_t)(t0 + ln + 64 * q) * EPE + 4 * R;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) *reinterpret_cast<double2 *>(E + 2 * k) = cf[q][k];
+        }
+      // ---- trip 2
+      double2 xe[2][2 * R];
 #pragma unroll
       for (int q = 0; q < 2; ++q)
         if (64 * q < ne) {
+          asm volatile("" : "+v"(ep[q]), "+v"(es[q]));
           const double *xp = ep[q] ? ep[q] : ag.nbr[1] + (size_t)es[q] * 4 * R;
-          if (ln + 64 * q < ne) reinterpret_cast<const double **>(ptab)[t0 + ln + 64 * q] = xp;
-        }
-      WSYNC();
-      // trip 2: 16 bytes per lane and instruction, landing in LDS in lane order (the record of an edge is EPE / 2 such units:
-      // 2R of the neighbour pose, 8 of coefficients); four instructions' addresses are looked up before the four are issued
-      {
-        constexpr int UPE = EPE / 2;
-        const int nun = ne * UPE;
-        const double *const *ptd = reinterpret_cast<const double *const *>(ptab);
-        for (int c0 = 0; c0 < nun; c0 += 256) {
-          const double *src[4];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int d = min(c0 + 64 * q + ln, nun - 1);
-            const int er = d / UPE, k = d - er * UPE;
-            src[q] = (k < 2 * R) ? ptd[t0 + er] + 2 * k : ag.se[t0 + er].coef + 2 * (k - 2 * R);
+          for (int k = 0; k < 2 * R; ++k) {
+            const v2d_t t = *(const __attribute__((address_space(1))) v2d_t *)(xp + 2 * k);
+            xe[q][k] = make_double2(t.x, t.y);
           }
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (c0 + 64 * q < nun) {  // (uniform)
-              if (c0 + 64 * q + ln < nun)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src[q],
-                                                 (__attribute__((address_space(3))) void *)(Es + (size_t)t0 * EPE + 2 * (c0 + 64 * q)), 16, 0, 0);
-            }
         }
+      double w[4 * R], x[4 * R];
+      {
+        const double *Wc = ag.buf[B_CARRY_W], *Xc = ag.buf[B_CARRY_X];
+        asm volatile("" : "+v"(Wc), "+v"(Xc));  // (behind the neighbour poses in the queue, as written)
+#pragma unroll
+        for (int i = 0; i < 4 * R; ++i) { w[i] = Wc[(size_t)i * n + pj]; x[i] = Xc[(size_t)i * n + pj]; }
       }
-      lds_barrier();  // A (see the stream waves)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      FE_STAMP(10);
+      lds_barrier();  // A
+      FE_STAMP(11);
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        if (64 * q < ne && ln + 64 * q < ne) {
+          double *E = Es + (size_t)(t0 + ln + 64 * q) * EPE;
+#pragma unroll
+          for (int k = 0; k < 2 * R; ++k) *reinterpret_cast<double2 *>(E + 2 * k) = xe[q][k];
+        }
       WSYNC();
       FE_STAMP(1);
-      auto g_term = [&](int e0, int e1, double *w) {
-        // G_j from LDS: g[c][a] -= x[cp][a] coef[cp + 4c], edge after edge and cp after cp for every entry (g_row_range's order)
+      if (pact) {
+        // G_j from LDS: g[c][a] -= x[cp][a] coef[cp + 4c], edge after edge and cp after cp for every entry (g_row_range's
+        // order); the operands of an edge are read once
+        double gg[4 * R];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          double gg[R];
+        for (int i = 0; i < 4 * R; ++i) gg[i] = 0.0;
+        for (int e = pe0; e < pe1; ++e) {
+          const double *E = Es + (size_t)e * EPE;
+          double xn[4 * R];
 #pragma unroll
-          for (int a = 0; a < R; ++a) gg[a] = 0.0;
-          for (int e = e0; e < e1; ++e) {
-            const double *E = Es + (size_t)e * EPE;
+          for (int i = 0; i < 2 * R; ++i) { const double2 t = *reinterpret_cast<const double2 *>(E + 2 * i); xn[2 * i] = t.x; xn[2 * i + 1] = t.y; }
 #pragma unroll
-            for (int cp = 0; cp < 4; ++cp) {
-              const double cf = E[4 * R + cp + 4 * c];
+          for (int c = 0; c < 4; ++c) {
+            const double2 c01 = *reinterpret_cast<const double2 *>(E + 4 * R + 4 * c), c23 = *reinterpret_cast<const double2 *>(E + 4 * R + 4 * c + 2);
+            const double cfc[4] = {c01.x, c01.y, c23.x, c23.y};
 #pragma unroll
-              for (int a = 0; a < R; ++a) gg[a] -= E[cp * R + a] * cf;
-            }
+            for (int cp = 0; cp < 4; ++cp)
+#pragma unroll
+              for (int a = 0; a < R; ++a) gg[c * R + a] -= xn[cp * R + a] * cfc[cp];
           }
-#pragma unroll
-          for (int a = 0; a < R; ++a) w[c * R + a] = w[c * R + a] + gg[a];
         }
-      };
-      if (actA && e1A > e0A) g_term(e0A, e1A, wA);
-      if (actB && e1B > e0B) g_term(e0B, e1B, wB);
-      FE_STAMP(2);
-      tangent_inplace<R>(xA, wA);
-      tangent_inplace<R>(xB, wB);
-      FE_STAMP(3);
-      if (actA) {
 #pragma unroll
-        for (int i = 0; i < 4 * R; ++i) vs[(size_t)4 * R * jA + i] = wA[i];
-      }
-      if (actB) {
+        for (int i = 0; i < 4 * R; ++i) w[i] = w[i] + gg[i];
+        FE_STAMP(2);
+        tangent_inplace<R>(x, w);
+        FE_STAMP(3);
 #pragma unroll
-        for (int i = 0; i < 4 * R; ++i) vs[(size_t)4 * R * jB + i] = wB[i];
+        for (int i = 0; i < 4 * R; ++i) vs[(size_t)4 * R * pj + i] = w[i];
       }
     }
     lds_barrier();  // the gradient is in LDS
@@ -450,14 +470,18 @@ __global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ ag
     if (flags & FE_CARRY_W) {
       // ---- the row products of the NEXT agent (carried rows): W_p = sum_i X_i Q_ip at the point the next launch will
       // evaluate at -- B_CARRY_Y, left complete by the launch before this one -- for this workgroup's share of its poses,
-      // one (pose, entry) per lane: fe_block's expression slot after slot, so the sums are BITWISE the ones the next launch
-      // would form itself.  Two short round trips behind the slab in this CU's queue; the stream waves are busy with their
-      // product for longer than that.
-      const int l = tid - 256;
+      // one (pose, entry) per lane, three poses per wave: fe_block's expression slot after slot, so the sums are BITWISE the
+      // ones the next launch would form itself.  Then, one lane per pose, their tangent projection at the point: the
+      // gradient of a pose without shared edges as the next launch would form it (it adds G_j to W_j only where there are
+      // edges).  Two short round trips behind the slab in this CU's queue, next to the stream waves' product.
+      const int l = tid - 256, lw = l & 63, wq = l >> 6;
       const int npw = (agn.n + nblk - 1) / nblk;  // (<= 12, checked by the host)
-      const int lp = l / (4 * R), e = l - lp * (4 * R);
+      const int ls = lw / (4 * R), e = lw - ls * (4 * R);
+      const int lp = 3 * wq + ls;
       const int pw = bx * npw + lp;
-      if (lp < npw && pw < agn.n) {
+      const bool pv = ls < 3 && lp < npw && pw < agn.n;
+      double *Ex = Es + (size_t)wq * 2 * 3 * 4 * R;  // (the edge operands are not needed any more: this wave's exchange space)
+      if (pv) {
         const int c = e / R, a = e - c * R;
         const int tile = pw >> 6, pl = pw & 63, wdn = agn.soa_w;
         const double *__restrict__ Y2 = agn.buf[B_CARRY_Y];
@@ -468,8 +492,21 @@ __global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ ag
           const double *bp = agn.soa_val + ((size_t)tile * wdn + u) * 1024 + (2 * c) * 128 + 2 * pl;
           acc = fma4(xp[0], bp[0], xp[R], bp[1], xp[2 * R], bp[128], xp[3 * R], bp[129], acc);
         }
+        const double xe_ = Y2[(size_t)4 * R * pw + e];
         agn.buf[B_CARRY_W][(size_t)e * agn.n + pw] = acc;
-        agn.buf[B_CARRY_X][(size_t)e * agn.n + pw] = Y2[(size_t)4 * R * pw + e];  // (the point itself, [entry][pose])
+        agn.buf[B_CARRY_X][(size_t)e * agn.n + pw] = xe_;  // (the point itself, [entry][pose])
+        Ex[ls * 4 * R + e] = acc;
+        Ex[3 * 4 * R + ls * 4 * R + e] = xe_;
+      }
+      WSYNC();
+      if (pv && e == 0) {
+        double w[4 * R], x[4 * R];
+#pragma unroll
+        for (int i = 0; i < 4 * R; ++i) { w[i] = Ex[ls * 4 * R + i]; x[i] = Ex[3 * 4 * R + ls * 4 * R + i]; }
+        tangent_inplace<R>(x, w);
+        double *Gn = agn.buf[B_CARRY_G] + (size_t)4 * R * pw;
+#pragma unroll
+        for (int i = 0; i < 4 * R; ++i) Gn[i] = w[i];
       }
     }
     lds_barrier();  // #4: (the stream waves' partial sums)
