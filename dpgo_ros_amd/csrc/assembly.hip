@@ -356,7 +356,7 @@ int finalize_agent(dpgo_team *t, Agent &a, double *scratch) {
     for (int j = 0; j < n; j += ppb) a.max_tile_edges = std::max(a.max_tile_edges, pose_eptr[std::min(n, j + ppb)] - pose_eptr[j]);
   }
   for (int g = 0; g < 5; ++g) a.dev.fe_eptr[g] = pub_ptr[std::min(64 * g, a.npub)];
-  a.dev.fe_pad_ = 0;
+  a.dev.fe_code_ok = 0;
   a.se_host = se;  // the neighbour-pose pointers are filled in by sync_descs once every agent's buffers exist
   // edge records for residual / cost evaluation
   std::vector<EdgeDev> edges;
@@ -684,6 +684,17 @@ int sync_descs_noflush(dpgo_team *t) {
     }
     if (a->d_se.upload(a->se_host, t->stream)) { set_err("shared-edge upload failed"); return DPGO_ERR; }
     a->dev.se = a->d_se.p;
+    // (carried one-launch iteration: the same pointers as 16-bit codes in the descriptor)
+    a->dev.fe_code_ok = (int)a->se_host.size() <= FE_MAX_EDGES && !t->isolated;
+    for (int q = 0; q < FE_MAX_EDGES / 2; ++q) a->dev.fe_code[q] = 0;
+    for (size_t e = 0; e < a->se_host.size() && a->dev.fe_code_ok; ++e) {
+      const auto &d = a->se_host[e];
+      if (d.src_agent_local < 0 || d.src_agent_local >= LOOKAHEAD_MAX_AGENTS || d.src_frame < 0 || d.src_frame >= 4096 || !d.src_yalt) {
+        a->dev.fe_code_ok = 0;
+        break;
+      }
+      a->dev.fe_code[e >> 1] |= (unsigned)(d.src_frame | (d.src_agent_local << 12)) << (16 * (e & 1));
+    }
   }
   std::vector<AgentDev> descs;
   t->max_n = 0; t->max_npub = 0;

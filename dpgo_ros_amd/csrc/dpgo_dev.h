@@ -18,9 +18,10 @@ enum Buf {
 // carried rows of the one-launch iteration (step_fused.hip): the evaluation point of the agent two iterations ahead
 // ([pose][4r]) and the row products formed from it ([entry][pose]).  They live inside one captured run of one-launch
 // iterations only, in two work vectors of the trust-region solver that an RGD team never touches meanwhile.
-constexpr int B_CARRY_Y = B_R0, B_CARRY_W = B_R1, B_CARRY_X = B_D0;  // (B_CARRY_X: the evaluation point once more as [entry][pose])
+constexpr int B_CARRY_Y = B_R0, B_CARRY_W = B_R1, B_CARRY_X = B_D0;  // (W / X: row products and point of the PUBLIC poses, [entry][public pose])
 constexpr int B_CARRY_G = B_D1;  // tangent projection of the row products at the point, [pose][4r]: the gradient of a pose without shared edges
 constexpr int FE_CARRY_IN = 1, FE_CARRY_W = 2, FE_CARRY_Y = 4;
+constexpr int FE_MAX_EDGES = 160;  // shared edges of an agent whose operands the one-launch iteration keeps in LDS (46 KB at r = 5)
 constexpr int B_ALT = B_XALT - B_X;
 static_assert(B_YALT - B_Y == B_ALT, "X and Y twins share one displacement");
 
@@ -106,8 +107,11 @@ struct AgentDev {
   const int *pub_index;       // [n] index into pub_pose/pub_ptr or -1
   const int *pose_eptr;       // [n+1] CSR of `se` by local pose: the shared edges of pose j are [pose_eptr[j], pose_eptr[j+1])
                               // (the evaluation finds them with one round trip instead of pub_index -> pub_ptr)
-  int fe_eptr[5], fe_pad_;    // pub_ptr[min(64 g, npub)], g = 0 .. 4: the shared edges of the 64 public poses a gradient wave of
+  int fe_eptr[5], fe_code_ok; // pub_ptr[min(64 g, npub)], g = 0 .. 4: the shared edges of the 64 public poses a gradient wave of
                               // the carried one-launch iteration finishes, known without a round trip
+  unsigned fe_code[FE_MAX_EDGES / 2];  // where the neighbour pose of shared edge e lives, 16 bits each (two per word): frame |
+                              // local agent << 12 (teams whose neighbours are all co-resident, <= 160 edges: fe_code_ok) -- the
+                              // carried one-launch iteration turns it into an address without a descriptor round trip
   const double *M;            // dense (Q + shift I)^-1, N4 x N4 column-major (symmetric); null: block-Jacobi agent
   const double *Dinv;         // block-Jacobi agents: the inverted 4 x 4 diagonal blocks of Q + shift I, [n][16] column-major
   TLDev tl;                   // two-level agents (tl.nwg > 0; M and Dinv null)
@@ -139,6 +143,12 @@ constexpr int PART_E = 4 * MAX_PART * PART_STRIDE;    // |X - XPrev|^2 tiles of 
 constexpr int PART_TOTAL = 5 * MAX_PART * PART_STRIDE;
 
 constexpr int LOOKAHEAD_MAX_AGENTS = 8;  // look-ahead Nesterov steps locate a pose's agent with one 9-int fetch
+
+// carried one-launch iteration: the Y array of every local agent and its pose count (by value in the launch)
+struct FeBases {
+  const double *ybase[LOOKAHEAD_MAX_AGENTS];
+  int npose[LOOKAHEAD_MAX_AGENTS];
+};
 
 struct TeamDev {
   int num_agents;

@@ -16,6 +16,7 @@ struct LaunchCtx {
   int tl_max_wg = 0;               // ... and the most workgroups one of their applies runs
   const int *host_precond = nullptr;  // [local agent] DPGO_PRECOND_* it runs (host memory; selects the kernel variant)
   const AgentDev *host_agents = nullptr;  // [local agent] host copies of the descriptors (what d_agents holds)
+  int num_agents = 0;                     // ... and how many
   bool bake_desc = false;          // pass the agent's descriptor BY VALUE where the launch names its agent (baked graphs)
   // neighbour poses staged on the host (pinned) that the FIRST launch of an iterate(true) scatters into the agent's slabs
   // itself (launch_nest_pre; one launch less than k_upload2 in front of it): slots / values, counts per sequence

@@ -80,8 +80,6 @@ constexpr int FE_HEAD = DPGO_FE_HEAD;  // carried rows: 16-byte loads per lane o
 #define DPGO_FE_PARTS 4
 #endif
 constexpr int FE_PARTS = DPGO_FE_PARTS;  // the slab is requested in this many parts, behind the last blocks of the row
-constexpr int FE_MAX_EDGES = 160;  // shared edges of an agent whose operands go through LDS (46 KB at r = 5; more would spill: the descriptors
-                                   // and values of 512-double trips live in registers in front of the rows)
 
 // one block of the row: W += X_i Q_ij, X_i gathered from the staged copy of X
 template <int R>
@@ -111,7 +109,7 @@ __device__ __forceinline__ void fe_pin(double *w) {
 template <int R, int WD>
 __global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ agents, TeamDev *team, int sel, int next_sel, double step,
                                                  int num_robots, int restart_interval, const NestState *nest_src, NestState *nest_dst,
-                                                 int parity, const AgentDev agv, int next2_sel, int flags, const AgentDev agn) {
+                                                 int parity, const AgentDev agv, int next2_sel, int flags, const AgentDev agn, const FeBases fb) {
   const AgentDev &ag = agv;
   constexpr bool CARRIED = WD == 0;
   // The poses live twice (B_X / B_Y and their twins B_XALT / B_YALT): this launch reads the copy of its parity and writes
@@ -160,95 +158,91 @@ __global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ ag
   double2 mreg[MREG];
   if constexpr (CARRIED) {
     // ================================================================ carried rows (WD = 0): two kinds of waves from the
-    // first instruction on.
-    //   * waves 0-3 (stream): request the head of their 128 KB slab of M at once, the rest behind barrier A.  A wave stays
-    //     at the issue of its loads for as long as the CU's memory pipe is full, i.e. until most of what it asked for has
-    //     landed (traced in round 5: with the slab requested behind barrier 1 by all waves, the next instruction of every
-    //     wave ran 5 us later) -- so these waves take part in nothing else until the product.
-    //   * waves 4-7 (gradient).  The previous launch left, for every pose of this agent, the tangent projection of its row
-    //     product at the evaluation point -- which IS the Riemannian gradient of a pose without shared edges, bit for bit
-    //     (B_CARRY_G, [pose][4r]: the layout of the vector in LDS) -- and the row products and the point themselves as
-    //     [entry][pose] arrays.  Trip 1: B_CARRY_G into LDS (coalesced 16-byte loads); the descriptors and coefficients of the
-    //     shared edges, one edge per lane; the public pose each lane is to finish.  Trip 2 (behind it, before barrier A):
-    //     the neighbour pose of the lane's edge; W_j and X_j of the lane's public pose.  Then G_j, the projection, and the
-    //     row of the vector in LDS is overwritten.  A wave fetches the edges of ITS OWN 64 public poses (fe_eptr: known
-    //     without a trip): the four waves never wait for each other.
+    // first instruction on, and ONE round trip in front of the stream.
+    //   * waves 0-3 (stream): request the head of their 128 KB slab of M and the carried gradient at once, the rest of the
+    //     slab behind barrier A.  A wave stays at the issue of its loads for as long as the CU's memory pipe is full, i.e.
+    //     until most of what it asked for has landed (traced in round 5: with the slab requested behind barrier 1 by all
+    //     waves, the next instruction of every wave ran 5 us later) -- so these waves take part in nothing else until the
+    //     product.  The carried gradient -- the previous launch left, for every pose of this agent, the tangent projection of
+    //     its row product at the evaluation point, which IS the Riemannian gradient of a pose without shared edges, bit for
+    //     bit (B_CARRY_G, [pose][4r]: the layout of the vector in LDS) -- goes into LDS when they are through.
+    //   * waves 4-7 (gradient) finish the public poses, one per lane (wave g: public poses 64 g ..): W_j and X_j from the
+    //     [entry][public pose] arrays the previous launch left, the coefficients of the lane's shared edges (one or two edges
+    //     per lane: the edges of the wave's 64 public poses, fe_eptr) and the neighbour poses they meet -- whose addresses
+    //     come out of the 16-bit codes in the descriptor (scalar loads and a select chain: no descriptor round trip).
+    //     Everything is requested in front of barrier A; G_j, the projection, and behind barrier B the row of the vector in
+    //     LDS is overwritten.
     // Barrier A: the gradient waves have requested all they need (the bulk of the slab queues behind it, not in front);
-    // barrier B: the gradient is in LDS.
+    // B: the carried gradient is in LDS; B2: the rows of the public poses are.
     const int cwv = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (cwv < 4) {
       for (int t = N4 * R + tid; t < KC * R; t += 256) vs[t] = 0.0;  // rows of the vector beyond the agent's
 #pragma unroll
       for (int m = 0; m < FE_HEAD; ++m) mreg[m] = ld2_nt(Mc + min(2 * kl + 64 * m, N4 - 2));
+      constexpr int NG = (KC * R / 2 + 255) / 256;
+      double2 gv[NG];
+      {
+        const double *Gc = ag.buf[B_CARRY_G];
+#pragma unroll
+        for (int u = 0; u < NG; ++u) gv[u] = ld2(Gc + min(2 * (tid + 256 * u), N4 * R - 2));
+      }
       FE_STAMP(10);
       lds_barrier();  // A
       FE_STAMP(11);
 #pragma unroll
       for (int m = FE_HEAD; m < MREG; ++m) mreg[m] = ld2_nt(Mc + min(2 * kl + 64 * m, N4 - 2));
       FE_STAMP(12);
+#pragma unroll
+      for (int u = 0; u < NG; ++u) {
+        const int tt = 2 * (tid + 256 * u);
+        if (tt < N4 * R) *reinterpret_cast<double2 *>(&vs[tt]) = gv[u];
+      }
+      lds_barrier();  // B
     } else {
-      const int g = cwv - 4, ln = tid & 63, l = tid - 256;
+      const int g = cwv - 4, ln = tid & 63;
       const int npub = ag.npub;
       const int t0 = ag.fe_eptr[g], t1 = ag.fe_eptr[g + 1], ne = t1 - t0;  // shared edges of this wave's public poses (uniform; <= 128, host)
-      // ---- trip 1
-      // the lane's edges (ln, ln + 64 of the wave's): where the neighbour pose lives, the 16 coefficients
-      const double *ep[2] = {nullptr, nullptr};
-      int es[2] = {0, 0};
-      double2 cf[2][8];
+      // the lane's edges (ln, ln + 64 of the wave's): the neighbour pose from its code, the 16 coefficients
+      double2 cf[2][8], xe[2][2 * R];
 #pragma unroll
       for (int q = 0; q < 2; ++q)
         if (64 * q < ne) {  // (uniform)
-          const SharedEdgeDev &se = ag.se[t0 + min(ln + 64 * q, ne - 1)];
-          ep[q] = parity ? se.src_yalt : se.src[1]; es[q] = se.slot;
+          const int ei = t0 + min(ln + 64 * q, ne - 1);
+          // word ei >> 1 of the code table: the wave's words sit in scalar registers, the lane picks its own
+          const int wbase = (t0 + 64 * q) >> 1, wrel = (ei >> 1) - wbase;  // 0 .. 32
+          unsigned wsel = 0;
 #pragma unroll
-          for (int k = 0; k < 8; ++k) cf[q][k] = ld2(se.coef + 2 * k);
-        }
-      // the lane's public pose and its edges
-      const int pq = 64 * g + ln;
-      const bool pact = pq < npub;
-      const int pj = ag.pub_pose[pact ? pq : 0];
-      const int pe0 = ag.pub_ptr[pact ? pq : 0], pe1 = ag.pub_ptr[pact ? pq + 1 : 0];
-      // the carried gradient: 16 bytes per lane and load, straight into the vector's layout
-      constexpr int NG = (KC * R / 2 + 255) / 256;
-      double2 gv[NG];
-      {
-        const double *Gc = ag.buf[B_CARRY_G];
+          for (int k = 0; k <= 32; ++k) {
+            const unsigned wk = ag.fe_code[min(wbase + k, FE_MAX_EDGES / 2 - 1)];
+            wsel = (wrel == k) ? wk : wsel;
+          }
+          const unsigned code = (ei & 1) ? (wsel >> 16) : (wsel & 0xffffu);
+          const int sa = (int)(code >> 12), sf = (int)(code & 0xfffu);
+          const double *yb = fb.ybase[0];
+          int yn = fb.npose[0];
 #pragma unroll
-        for (int u = 0; u < NG; ++u) gv[u] = ld2(Gc + min(2 * (l + 256 * u), N4 * R - 2));
-      }
-      FE_STAMP(13);
-      // the carried gradient and the coefficients are back: into LDS (their registers are the second trip's)
-#pragma unroll
-      for (int u = 0; u < NG; ++u) {
-        const int tt = 2 * (l + 256 * u);
-        if (tt < N4 * R) *reinterpret_cast<double2 *>(&vs[tt]) = gv[u];
-      }
-#pragma unroll
-      for (int q = 0; q < 2; ++q)
-        if (64 * q < ne && ln + 64 * q < ne) {
-          double *E = Es + (size_t)(t0 + ln + 64 * q) * EPE + 4 * R;
-#pragma unroll
-          for (int k = 0; k < 8; ++k) *reinterpret_cast<double2 *>(E + 2 * k) = cf[q][k];
-        }
-      // ---- trip 2
-      double2 xe[2][2 * R];
-#pragma unroll
-      for (int q = 0; q < 2; ++q)
-        if (64 * q < ne) {
-          asm volatile("" : "+v"(ep[q]), "+v"(es[q]));
-          const double *xp = ep[q] ? ep[q] : ag.nbr[1] + (size_t)es[q] * 4 * R;
+          for (int k = 1; k < LOOKAHEAD_MAX_AGENTS; ++k) { yb = (sa == k) ? fb.ybase[k] : yb; yn = (sa == k) ? fb.npose[k] : yn; }
+          const double *xp = yb + (parity ? (size_t)B_ALT * 4 * R * yn : (size_t)0) + (size_t)sf * 4 * R;
 #pragma unroll
           for (int k = 0; k < 2 * R; ++k) {
             const v2d_t t = *(const __attribute__((address_space(1))) v2d_t *)(xp + 2 * k);
             xe[q][k] = make_double2(t.x, t.y);
           }
+          const double *cp_ = ag.se[ei].coef;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) cf[q][k] = ld2(cp_ + 2 * k);
         }
+      // the lane's public pose: its row products and the point, its edges
+      const int pq = 64 * g + ln;
+      const bool pact = pq < npub;
+      const int pqc = pact ? pq : 0;
+      const int pj = ag.pub_pose[pqc];
+      const int pe0 = ag.pub_ptr[pqc], pe1 = ag.pub_ptr[pqc + (pact ? 1 : 0)];
       double w[4 * R], x[4 * R];
       {
         const double *Wc = ag.buf[B_CARRY_W], *Xc = ag.buf[B_CARRY_X];
-        asm volatile("" : "+v"(Wc), "+v"(Xc));  // (behind the neighbour poses in the queue, as written)
 #pragma unroll
-        for (int i = 0; i < 4 * R; ++i) { w[i] = Wc[(size_t)i * n + pj]; x[i] = Xc[(size_t)i * n + pj]; }
+        for (int i = 0; i < 4 * R; ++i) { w[i] = Wc[(size_t)i * npub + pqc]; x[i] = Xc[(size_t)i * npub + pqc]; }
       }
       FE_STAMP(10);
       lds_barrier();  // A
@@ -259,6 +253,8 @@ __global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ ag
           double *E = Es + (size_t)(t0 + ln + 64 * q) * EPE;
 #pragma unroll
           for (int k = 0; k < 2 * R; ++k) *reinterpret_cast<double2 *>(E + 2 * k) = xe[q][k];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) *reinterpret_cast<double2 *>(E + 4 * R + 2 * k) = cf[q][k];
         }
       WSYNC();
       FE_STAMP(1);
@@ -288,11 +284,14 @@ __global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ ag
         FE_STAMP(2);
         tangent_inplace<R>(x, w);
         FE_STAMP(3);
+      }
+      lds_barrier();  // B
+      if (pact) {
 #pragma unroll
         for (int i = 0; i < 4 * R; ++i) vs[(size_t)4 * R * pj + i] = w[i];
       }
     }
-    lds_barrier();  // the gradient is in LDS
+    lds_barrier();  // B2: the gradient is in LDS
   } else {
   const int kslab = (tid < 256) ? 2 * kl : 0, kstep = (tid < 256) ? 64 : 0;  // (waves 4-7: always row 0)
   // ================================================================ the evaluation: one lane per pose, all 8 waves
@@ -493,8 +492,11 @@ __global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ ag
           acc = fma4(xp[0], bp[0], xp[R], bp[1], xp[2 * R], bp[128], xp[3 * R], bp[129], acc);
         }
         const double xe_ = Y2[(size_t)4 * R * pw + e];
-        agn.buf[B_CARRY_W][(size_t)e * agn.n + pw] = acc;
-        agn.buf[B_CARRY_X][(size_t)e * agn.n + pw] = xe_;  // (the point itself, [entry][pose])
+        const int qi = agn.pub_index[pw];
+        if (qi >= 0) {  // (a public pose: the next launch finishes it -- row product and point, [entry][public pose])
+          agn.buf[B_CARRY_W][(size_t)e * agn.npub + qi] = acc;
+          agn.buf[B_CARRY_X][(size_t)e * agn.npub + qi] = xe_;
+        }
         Ex[ls * 4 * R + e] = acc;
         Ex[3 * 4 * R + ls * 4 * R + e] = xe_;
       }
@@ -716,9 +718,11 @@ void launch_step_fe(const LaunchCtx &c, int sel, int next_sel, double step, int 
   const AgentDev &dn = c.host_agents[(carry & FE_CARRY_W) ? next_sel : sel];
   const int grid = ((d.N4 + 7) / 8 + 7) / 8 * 8;
   const int flags = carry & (FE_CARRY_W | FE_CARRY_Y);
+  FeBases fb = {};
+  for (int k = 0; k < c.num_agents && k < LOOKAHEAD_MAX_AGENTS; ++k) { fb.ybase[k] = c.host_agents[k].buf[B_Y]; fb.npose[k] = c.host_agents[k].n; }
 #define FE_LAUNCH(RR, WW)                                                                                              \
   hipLaunchKernelGGL((k_step_fe<RR, WW>), dim3(grid), dim3(512), 0, c.stream, c.agents, c.team, sel, next_sel, step, num_robots, \
-                     restart_interval, nest_src, nest_dst, parity, d, next2_sel, flags, dn)
+                     restart_interval, nest_src, nest_dst, parity, d, next2_sel, flags, dn, fb)
 #define FE_LAUNCH_W(RR)                                                                                                \
   switch ((carry & FE_CARRY_IN) ? 0 : d.soa_w) {                                                                       \
     case 0: FE_LAUNCH(RR, 0); break;                                                                                   \

@@ -315,6 +315,7 @@ struct dpgo_team {
     c.stage_cap = stage_cap;
     c.max_lds = max_lds;
     c.host_agents = h_descs.empty() ? nullptr : h_descs.data();
+    c.num_agents = (int)h_descs.size();
     for (int k : precond_of) if (k == DPGO_PRECOND_TWO_LEVEL) c.any_two_level = true;
     return c;
   }
