@@ -445,6 +445,9 @@ __global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ ag
   }
   FE_STAMP(4);
   if (tid >= 256) {
+    // (waves 4-7 meet the stream waves' barrier first: neither the bookkeeping nor the carried rows below may hold the
+    // product's partial sums back -- workgroup 0, which keeps the books, used to finish 1.6 us behind all the others)
+    lds_barrier();  // #4: (the stream waves' partial sums)
     if (bx == 0 && tid == 256) {
       // what the bookkeeping workgroup of the next k_eval_stats would do (advance_agent, accelerated): into the OTHER
       // state buffer -- every workgroup of this launch reads nest_src
@@ -511,7 +514,6 @@ __global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ ag
         for (int i = 0; i < 4 * R; ++i) Gn[i] = w[i];
       }
     }
-    lds_barrier();  // #4: (the stream waves' partial sums)
     FE_FLUSH();
     return;
   }
