@@ -688,8 +688,8 @@ class Team:
         return _chk(lib().dpgo_team_update_weights(self.h), "team_update_weights")
 
     def counters(self):
-        out = np.zeros(8)
-        lib().dpgo_team_get_counters(self.h, _d(out), 8)
+        out = np.zeros(10)
+        lib().dpgo_team_get_counters(self.h, _d(out), 10)
         return out
 
     def stream(self):

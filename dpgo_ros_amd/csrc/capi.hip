@@ -1274,6 +1274,11 @@ static int team_run_impl(dpgo_team_t *t, int iters, bool prepare_only) {
       HIPC(hipGraphLaunch(ge, t->stream));
       const int nfe_run = fe ? (std::max(0, fusedn - std::min(fusedn, (int)t->sched.size()) - 1) & ~1) : 0;
       t->counters[7] += nfe_run;  // one-launch iterations
+      {
+        const int P_ = (int)t->sched.size(), it0 = t->iter;
+        const std::function<int(int)> sel_run = [&](int rep) { return t->sched[(size_t)((it0 + rep) % P_)]; };
+        for (int q = 0; q < nfe_run; ++q) t->counters[8] += (fe_carry_flags(t, q, nfe_run, sel_run) & FE_CARRY_IN) ? 1 : 0;  // ... with carried rows
+      }
       // after >= 2 pipelined iterations every agent took its last Nesterov step as a look-ahead (per-pose partials)
       for (auto &a : t->ag) a->rel_src = p.acceleration ? ((pipelined && fusedn >= 2) ? 4 : 0) : 2;
       for (int q = 0; q < batch; ++q) {
@@ -1876,7 +1881,7 @@ int dpgo_agent_read_partials(dpgo_team_t *t, int id, int offset, double *out, in
 
 int dpgo_team_get_counters(dpgo_team_t *t, double *out, int n) {
   for (auto &a : t->ag) if (refresh_rtr_result(t, *a)) return DPGO_ERR;
-  for (int k = 0; k < n && k < 8; ++k) out[k] = t->counters[k];
+  for (int k = 0; k < n && k < 10; ++k) out[k] = t->counters[k];
   return 0;
 }
 

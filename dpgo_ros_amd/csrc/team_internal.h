@@ -233,7 +233,7 @@ struct dpgo_team {
   std::map<int, hipGraphExec_t> graphs;            // key: see dpgo_team_run
   std::map<int, int> graph_flip;
   bool graph_valid = false;
-  double counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double counters[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   // X / Y arrays of robots that live in other processes, imported through HIP IPC (dpgo_team_import_peer): their
   // public poses are read in place over peer access instead of travelling as messages
   struct Peer { double *base = nullptr; size_t off_x = 0, off_y = 0; int n = 0; };

@@ -353,7 +353,8 @@ int dpgo_agent_read_partials(dpgo_team_t *t, int id, int offset, double *out, in
 /* counters for the roofline report: launches and algorithmic bytes of the dominant kernels ([0] preconditioner applies,
  * [1] their bytes, [2] sparse evaluations, [3] their bytes, [4] iterations); diagnostics of the per-agent API: [5] host
  * microseconds between the launch of a report kernel and the arrival of its sequence word, [6] reports; [7] iterations
- * of dpgo_team_run that took the one-launch form (csrc/step_fused.hip) */
+ * of dpgo_team_run that took the one-launch form (csrc/step_fused.hip), [8] those of them that found the row products of
+ * their agent formed by the previous launch (carried rows) */
 int dpgo_team_get_counters(dpgo_team_t *t, double *out, int n);
 
 #ifdef __cplusplus

@@ -11,7 +11,7 @@ from dpgo_ros_amd import capi
 m0, n = capi.read_g2o(os.path.join(bench.ROOT, "data", "sphere2500.g2o"))
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 cases = int(sys.argv[2]) if len(sys.argv) > 2 else 40
-taken = 0
+taken = carried = 0
 for case in range(cases):
     robots = int(rng.integers(5, 10))
     r = int(rng.choice([3, 4, 5]))
@@ -45,10 +45,11 @@ for case in range(cases):
         assert d == 0.0, (case, robots, r, extra, kw, int(chunk), d)
         if robust:
             assert teams[0].update_weights() == teams[1].update_weights()
-    c7 = teams[1].counters()[7]
+    c7, c8 = teams[1].counters()[7], teams[1].counters()[8]
     taken += c7 > 0
-    print("case %2d: %d robots r=%d +%3d edges restart %2d step %.2f robust %d -> one-launch iterations %d, bitwise equal"
-          % (case, robots, r, extra, kw["restart_interval"], kw["rgd_stepsize"], robust, c7), flush=True)
+    carried += c8 > 0
+    print("case %2d: %d robots r=%d +%3d edges restart %2d step %.2f robust %d -> one-launch iterations %d (%d with carried rows), bitwise equal"
+          % (case, robots, r, extra, kw["restart_interval"], kw["rgd_stepsize"], robust, c7, c8), flush=True)
     for t in teams:
         t.close()
-print("fuzz ok: %d cases, one-launch form taken in %d" % (cases, taken))
+print("fuzz ok: %d cases, one-launch form taken in %d, carried rows in %d" % (cases, taken, carried))

@@ -60,6 +60,10 @@ def test_one_launch_iterations_bitwise_equal_the_two_launch_sequence(robots, r):
     P = robots
     expect = sum(max(0, b - P - 1) & ~1 for b in (23, 256, 44, 64, 7, 129))
     assert tb.counters()[7] == expect, (tb.counters()[7], expect)
+    # carried rows: all but the first two one-launch iterations of every graph find the row products of their agent formed
+    # by the launch before (round robin over >= 3 robots: three different agents in a row)
+    carried = sum(max(0, (max(0, b - P - 1) & ~1) - 2) for b in (23, 256, 44, 64, 7, 129))
+    assert tb.counters()[8] == carried, (tb.counters()[8], carried)
     assert np.isclose(ta.cost(), tb.cost(), rtol=0, atol=0)
     ta.close()
     tb.close()
@@ -203,3 +207,55 @@ def test_dispatch_to_dispatch_timing_entry():
     with pytest.raises(capi.DpgoError):
         tc.time_kernel(0, 14, reps=4)
     tc.close()
+
+
+def test_carried_rows_can_be_switched_off_and_change_no_bit():
+    """DPGO_FE_CARRY=0: every one-launch iteration forms the row products of its agent itself (round 3's form); the same
+    bits either way, restarts inside the runs"""
+    old = os.environ.get("DPGO_FE_CARRY")
+    os.environ["DPGO_FE_CARRY"] = "0"
+    try:
+        ta = _team("sphere2500", 5, True, **RGD)
+    finally:
+        if old is None:
+            os.environ.pop("DPGO_FE_CARRY", None)
+        else:
+            os.environ["DPGO_FE_CARRY"] = old
+    tb = _team("sphere2500", 5, True, **RGD)
+    for iters in (300, 41, 600):
+        ta.run(iters)
+        tb.run(iters)
+        ta.synchronize()
+        tb.synchronize()
+        for k in ta.ids:
+            assert np.array_equal(ta.agents[k].get_X(), tb.agents[k].get_X()), (iters, k)
+    assert ta.counters()[7] == tb.counters()[7] > 0
+    assert ta.counters()[8] == 0 and tb.counters()[8] > 0
+    ta.close()
+    tb.close()
+
+
+def test_carried_rows_need_three_different_agents_in_a_row():
+    """a schedule that repeats an agent within three iterations (0 1 0 2 3 4, period 6): the launches whose agent moved one
+    or two iterations earlier form their row products themselves, the others take the carried ones; bitwise the two-launch
+    sequence.  Two robots (smallGrid3D): nothing is carried"""
+    ta, tb = _team("sphere2500", 5, False, **RGD), _team("sphere2500", 5, True, **RGD)
+    order = [0, 1, 0, 2, 3, 4]
+    for t in (ta, tb):
+        t.set_schedule(order)
+    for iters in (100, 257):
+        ta.run(iters)
+        tb.run(iters)
+        ta.synchronize()
+        tb.synchronize()
+        for k in ta.ids:
+            assert np.array_equal(ta.agents[k].get_X(), tb.agents[k].get_X()), (iters, k)
+    c = tb.counters()
+    assert 0 < c[8] < c[7] - 4, (c[7], c[8])
+    ta.close()
+    tb.close()
+    t2 = _team("smallGrid3D", 2, True, **RGD)
+    t2.run(100)
+    t2.synchronize()
+    assert t2.counters()[8] == 0
+    t2.close()
