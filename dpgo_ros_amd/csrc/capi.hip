@@ -1081,28 +1081,6 @@ int dpgo_team_step_end(dpgo_team_t *t, int sel_id) {
   return 0;
 }
 
-// prepare_only: capture and instantiate every graph a run of `iters` iterations from the current state would replay
-// (both alternating instances of each), execute nothing
-// the one-launch iteration (step_fused.hip) may serve this team: dense agents of fe_min_n (449: where it is faster) .. 512 poses whose rows fit the ELL
-// part, few enough public poses / shared edges for its LDS tables, the schedule and the descriptors baked into the
-// launches (period <= 8), every neighbour co-resident (the twins of its poses are addressed through the shared-edge table)
-static bool fused_eval_eligible(dpgo_team_t *t) {
-  const dpgo_params_t &p = t->prm;
-  const int P = (int)t->sched.size();
-  if (!(t->use_fused_eval && t->bake_sel && t->bake_desc && P >= 1 && P <= 8 && step_fe_supported(p.r) && p.acceleration &&
-        p.method == DPGO_METHOD_RGD && p.rgd_use_preconditioner && (int)t->ag.size() <= LOOKAHEAD_MAX_AGENTS &&
-        t->h_descs.size() == t->ag.size() && t->precond_of.size() == t->ag.size() && t->peers.empty() && !t->isolated &&
-        (int)t->ag.size() == p.num_robots))
-    return false;
-  for (size_t k = 0; k < t->ag.size(); ++k) {
-    const int n = t->ag[k]->n;
-    if (t->precond_of[k] != DPGO_PRECOND_DENSE || n < t->fe_min_n || n > 512 || !t->ag[k]->has_soa ||
-        t->h_descs[k].nshared > step_fe_max_edges())
-      return false;
-  }
-  return true;
-}
-
 // Carried rows of the one-launch iterations (step_fused.hip): launch `rep` of a run of nfe one-launch iterations finds the
 // row products of its agent formed by launch rep - 1, from the evaluation point launch rep - 2 left -- which takes the
 // agents of the three iterations to be three different ones (the point is formed while the agent rests) and both earlier
@@ -1123,6 +1101,41 @@ static int fe_carry_flags(dpgo_team_t *t, int rep, int nfe, const std::function<
     return true;
   };
   return (consumes(rep) ? FE_CARRY_IN : 0) | (consumes(rep + 1) ? FE_CARRY_W : 0) | (consumes(rep + 2) ? FE_CARRY_Y : 0);
+}
+
+// every one-launch iteration of a long run finds carried rows (every three consecutive agents of the schedule differ)
+static bool fe_carry_everywhere(dpgo_team_t *t) {
+  const int P = (int)t->sched.size();
+  if (P < 3) return false;
+  const std::function<int(int)> sel_at = [&](int rep) { return t->sched[(size_t)(rep % P)]; };
+  for (int q = 2; q < P + 2; ++q)
+    if (!(fe_carry_flags(t, q, 1 << 30, sel_at) & FE_CARRY_IN)) return false;
+  return true;
+}
+
+// prepare_only: capture and instantiate every graph a run of `iters` iterations from the current state would replay
+// (both alternating instances of each), execute nothing
+// the one-launch iteration (step_fused.hip) may serve this team: dense agents of fe_min_n (449: where it is faster) .. 512 poses whose rows fit the ELL
+// part, few enough public poses / shared edges for its LDS tables, the schedule and the descriptors baked into the
+// launches (period <= 8), every neighbour co-resident (the twins of its poses are addressed through the shared-edge table)
+static bool fused_eval_eligible(dpgo_team_t *t) {
+  const dpgo_params_t &p = t->prm;
+  const int P = (int)t->sched.size();
+  if (!(t->use_fused_eval && t->bake_sel && t->bake_desc && P >= 1 && P <= 8 && step_fe_supported(p.r) && p.acceleration &&
+        p.method == DPGO_METHOD_RGD && p.rgd_use_preconditioner && (int)t->ag.size() <= LOOKAHEAD_MAX_AGENTS &&
+        t->h_descs.size() == t->ag.size() && t->precond_of.size() == t->ag.size() && t->peers.empty() && !t->isolated &&
+        (int)t->ag.size() == p.num_robots))
+    return false;
+  // (with carried rows the one-launch form is the faster one at every size it was measured at, 41 .. 500 poses; without them
+  // only from about 450 poses up -- profiles/experiments/fe_small.py)
+  const int min_n = t->fe_min_n > 0 ? t->fe_min_n : (fe_carry_everywhere(t) ? 32 : 449);
+  for (size_t k = 0; k < t->ag.size(); ++k) {
+    const int n = t->ag[k]->n;
+    if (t->precond_of[k] != DPGO_PRECOND_DENSE || n < min_n || n > 512 || !t->ag[k]->has_soa ||
+        t->h_descs[k].nshared > step_fe_max_edges())
+      return false;
+  }
+  return true;
 }
 
 static int team_run_impl(dpgo_team_t *t, int iters, bool prepare_only) {

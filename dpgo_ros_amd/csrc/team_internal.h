@@ -253,7 +253,8 @@ struct dpgo_team {
   // [0, num_local), the two alternating buffers of the fused launches behind it
   int use_fused_eval = 1;  // DPGO_FUSED_EVAL=0: every pipelined iteration takes the two-launch sequence
   int use_fe_carry = 1;    // DPGO_FE_CARRY=0: every one-launch iteration forms the row products of its agent itself (no carried rows)
-  int fe_min_n = 449;      // smallest agent the one-launch iteration serves by default (DPGO_FE_MIN_N; any n >= 32 works, bitwise):
+  int fe_min_n = 0;        // smallest agent the one-launch iteration serves (DPGO_FE_MIN_N; any n >= 32 works, bitwise).  0 = by
+                           // measurement: 32 where every iteration finds carried rows (round 5), else 449 -- without carried rows:
                            // measured per iteration, two-launch | one-launch (profiles/experiments/fe_small.py, sphere2500, r = 5):
                            // 312 poses 0.0180 | 0.0192, 357: 0.0191 | 0.0197, 416: 0.0199 | 0.0202, 500: 0.0214 | 0.0207 ms
   // staged neighbour poses of the agent whose iterate(true) is being enqueued: its first launch (k_nest_pre) scatters them

@@ -13,7 +13,8 @@ def team(ds, N, fused, r=5):
     t = capi.Team.from_measurements(mp, capi.default_params(r=r, num_robots=N, **RGD))
     t.set_initial(capi.odometry_init(m, n), capi.fixed_stiefel(r))
     return t
-for ds, N, r in (("sphere2500", 5, 5), ("sphere2500", 6, 5), ("sphere2500", 7, 5), ("sphere2500", 8, 5), ("sphere2500", 6, 4), ("sphere2500", 5, 3)):
+for ds, N, r in (("sphere2500", 5, 5), ("sphere2500", 6, 5), ("sphere2500", 7, 5), ("sphere2500", 8, 5), ("sphere2500", 6, 4), ("sphere2500", 5, 3),
+                 ("torus3D", 10, 5), ("parking-garage", 4, 5), ("parking-garage", 6, 5), ("smallGrid3D", 3, 5)):
     ta, tb = team(ds, N, False, r), team(ds, N, True, r)
     ok = True
     for iters in (23, 300, 64, 7, 129):

@@ -99,17 +99,28 @@ def test_teams_the_one_launch_form_cannot_serve_keep_the_two_launch_sequence():
 
 
 def test_default_window_of_the_one_launch_form():
-    """by default the one-launch form serves agents of 449 .. 512 poses -- below that the two-launch sequence is faster
-    (profiles/experiments/fe_small.py); DPGO_FE_MIN_N widens it (every other test here runs it from 32 poses up)"""
+    """by default the one-launch form serves agents of 32 .. 512 poses where every iteration finds carried rows (round 5:
+    faster than the two-launch sequence at every size measured), and agents of 449 .. 512 poses where it does not (there the
+    two-launch sequence is the faster one below; profiles/experiments/fe_small.py); DPGO_FE_MIN_N sets the bound by hand
+    (every other test here runs it from 32 poses up)"""
     assert os.environ.get("DPGO_FE_MIN_N") is None
-    for robots, served in ((5, True), (6, False), (8, False)):
-        m, mp, n = load("sphere2500", robots)
-        t = capi.Team.from_measurements(mp.view(capi.MEAS_DTYPE), capi.default_params(r=5, num_robots=robots, **RGD))
-        t.set_initial(O.odometry_init(m, n), O.fixed_stiefel(5))
-        t.run(64)
-        t.synchronize()
-        assert (t.counters()[7] > 0) == served, (robots, t.counters()[7])
-        t.close()
+    old = os.environ.get("DPGO_FE_CARRY")
+    try:
+        for carry, cases in (("1", ((5, True), (6, True), (8, True))), ("0", ((5, True), (6, False), (8, False)))):
+            os.environ["DPGO_FE_CARRY"] = carry
+            for robots, served in cases:
+                m, mp, n = load("sphere2500", robots)
+                t = capi.Team.from_measurements(mp.view(capi.MEAS_DTYPE), capi.default_params(r=5, num_robots=robots, **RGD))
+                t.set_initial(O.odometry_init(m, n), O.fixed_stiefel(5))
+                t.run(64)
+                t.synchronize()
+                assert (t.counters()[7] > 0) == served, (carry, robots, t.counters()[7])
+                t.close()
+    finally:
+        if old is None:
+            os.environ.pop("DPGO_FE_CARRY", None)
+        else:
+            os.environ["DPGO_FE_CARRY"] = old
 
 
 def test_one_launch_iterations_across_weight_updates():
