@@ -530,9 +530,9 @@ def gnc_leg(capi):
 # HBM traffic per launch (KB) from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in
 # separate runs of this command, profiles/collect.sh; FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md)
 PMC = {"source": "profiles/r05_pmc_fetch.md, profiles/r05_pmc_write.md",
-       "dense": {"step": (16543.6, 851.7), "apply": (16067.4, 85.9),       # k_precond<5,3,2048,false,true,true>, k_precond<5,0,2048,false,false,false>
-                 "fused_step": (18003.1, 869.0)},                           # k_step_fe<5,5>: + the sparse operator and X once per XCD L2
-       "two_level": {"step": (5471.4, 891.1), "apply": (4936.0, 125.3)}}   # k_precond<5,3,0,true,true,true>, k_precond<5,0,0,true,false,false>
+       "dense": {"step": (16541.5, 851.7), "apply": (16068.2, 85.9),       # k_precond<5,3,2048,false,true,true>, k_precond<5,0,2048,false,false,false>
+                 "fused_step": (17092.5, 1049.1)},                          # k_step_fe<5,0> (carried rows; <5,5>, every workgroup forming the rows: 18168.6, 997.6)
+       "two_level": {"step": (5469.3, 891.0), "apply": (4937.6, 125.3)}}   # k_precond<5,3,0,true,true,true>, k_precond<5,0,0,true,false,false>
 
 
 def roofline_leg(team, agent_id, form="dense"):
@@ -574,8 +574,9 @@ def roofline_leg(team, agent_id, form="dense"):
         if o_ms:
             two = {k: roof[k] for k in ("kernel", "achieved", "frac", "traffic", "bytes_per_launch", "us_per_launch",
                                         "us_per_launch_back_to_back", "timing_note")}
-            roof.update({"kernel": "k_step_fe<5,5> (one launch per iteration: cost gradient + preconditioner stream + RGD step "
-                                   "+ Nesterov V + look-ahead Nesterov step of all agents)",
+            roof.update({"kernel": "k_step_fe<5,0> (one launch per iteration, carried rows: Riemannian gradient from the row "
+                                   "products the previous launch left + preconditioner stream + RGD step + Nesterov V + "
+                                   "look-ahead Nesterov step of all agents + the row products of the next agent)",
                          "achieved": o_bytes / (o_ms * 1e-3) / 1e9, "bytes_per_launch": o_bytes, "us_per_launch": o_ms * 1e3,
                          "traffic": (2 * PMC[form]["fused_step"][0] + PMC[form]["fused_step"][1]) * 1024,
                          "timing_note": "HIP events around 500 eager one-launch iterations (dispatch to dispatch); "
@@ -1102,7 +1103,8 @@ def main():
            "data": "bundled sphere2500.g2o (real dataset), odometry initial guess lifted with a fixed YLift",
            "config": {"workload": "sphere2500.g2o, 5 agents, synchronous round-robin RBCD, RGD(step 0.2, dense "
                                   "preconditioner) + Nesterov (restart 20), r=5, library weighting; mid-run iterations one "
-                                  "launch each (k_step_fe), hipGraphs of up to 256 iterations",
+                                  "launch each (k_step_fe, the row products of an agent formed on the side by the launch "
+                                  "before its own), hipGraphs of up to 256 iterations",
                       "agents": 5, "poses_per_agent": 500, "placement": "agent a on rank a % N"}}
     _OUT = out
     force_dist = os.environ.get("DPGO_BENCH_FORCE_DIST") == "1"  # exercise the N > 1 driver with one rank
@@ -1116,9 +1118,10 @@ def main():
                     "iters_to_relcost_1e-6": conv["rgd_nesterov"]["iters_to_relcost_1e-6"],
                     "counters": {"precond_launches": counters[0], "precond_bytes": counters[1],
                                  "spmm_launches": counters[2], "spmm_bytes": counters[3], "iterations": counters[4],
-                                 "one_launch_iterations": counters[7],
+                                 "one_launch_iterations": counters[7], "with_carried_rows": counters[8],
                                  "note": "of the main team since its creation; one_launch_iterations: iterations that ran as "
-                                         "k_step_fe (csrc/step_fused.hip), the others as k_eval_stats + k_precond<PM_RGD>"}})
+                                         "k_step_fe (csrc/step_fused.hip), the others as k_eval_stats + k_precond<PM_RGD>; "
+                                         "with_carried_rows: those whose row products the previous launch had formed"}})
         print(json.dumps(out))
     else:
         rank, ms, cost, roof, exchange, cp, asapp = multi_gpu(args)
