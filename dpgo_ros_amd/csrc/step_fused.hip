@@ -1,35 +1,63 @@
 // step_fused.hip -- ONE launch per pipelined accelerated-RGD iteration: the step
 // kernel of precond.hip with the evaluation of spmm.hip's k_eval_stats folded in, without any hand-off between
-// workgroups.  Every workgroup (512 threads, one per CU) forms the WHOLE Riemannian gradient of the selected agent
-// itself, straight into its LDS -- the vector its slab of the dense inverse is about to meet:
+// workgroups.  Every workgroup (512 threads, one per CU) holds the WHOLE Riemannian gradient of the selected agent in its
+// LDS -- the vector its slab of the dense inverse is about to meet -- and there are two ways it gets there.
 //
+// k_step_fe<R, WD>, WD = 5 .. 8 (round 3; the first two one-launch iterations of a run, and teams that cannot carry rows):
 //   1. X of the agent (80 KB at 500 poses) is staged in LDS; the operands of the shared edges (neighbour poses,
 //      coefficients) follow it into LDS, one double per lane and trip.
 //   2. one lane per pose: W_j = sum_i X_i Q_ij over the row -- the 4 x 4 blocks from a [tile of 64 poses][slot][16-byte
 //      chunk][lane] copy of the ELL part (every load of a wave is one contiguous KB; padded slots hold zero blocks),
 //      through a ring of four slots in registers; X_i gathered from LDS.  Behind its row the lane of a pose with shared
 //      edges forms the linear term G_j from LDS.  Tangent projection in registers; barrier; the result replaces X in LDS.
-//   3. waves 0-3 request their 128 KB slab of M = (Q + shift I)^-1 in four parts, each as soon as a slot of the ring is
-//      free for good, then: slab x vector, partial sums, and exactly the tail of k_precond<PM_RGD>: wave 0 finishes the
-//      step of the two poses the workgroup owns (step, QF retraction, Nesterov V, look-ahead Y), wave 1 takes the
-//      look-ahead step of its share of the other agents' poses.
+//   3. the 128 KB slab of M = (Q + shift I)^-1 is requested in four parts, each as soon as a slot of the ring is free for
+//      good, then: slab x vector, partial sums, and exactly the tail of k_precond<PM_RGD>: wave 0 finishes the step of
+//      the two poses the workgroup owns (step, QF retraction, Nesterov V, look-ahead Y), wave 1 takes the look-ahead step
+//      of its share of the other agents' poses.
 //
-// The sparse operator is 0.3 MB and L2 resident: 250 workgroups reading it again replace a launch whose 6.6 us were a
-// chain of dependent round trips plus a kernel boundary.  The arithmetic of the gradient is eval_body's (same
-// expressions, same order): the iterates are BITWISE those of the two-launch sequence (tests/test_gpu_fused_step.py).
+// k_step_fe<R, 0>, "carried rows" (round 5; every other one-launch iteration of a run over >= 3 agents):
+//   The row products W_j = sum_i X_i Q_ij of an agent depend on that agent's own poses only, and between two of its
+//   turns those move by the look-ahead Nesterov step -- a per-pose map of X, V and scalars that follow a fixed recurrence.
+//   So the point agent c will be evaluated at in iteration k is known two launches earlier, and its row products one
+//   launch earlier:
+//     launch k - 2  (look-ahead wave, FE_CARRY_Y): for the poses of c = sel(k) it applies the look-ahead map a second time
+//                   -- the same expressions the look-ahead wave of launch k - 1 will run, on the same operands -- and leaves
+//                   the point in B_CARRY_Y.  (c rests in k - 2 and k - 1: three different agents in a row.)
+//     launch k - 1  (waves 4-7 behind the partial-sum barrier, FE_CARRY_W): every workgroup forms the row products of ITS
+//                   SHARE of c's poses (two or three poses, one (pose, entry) per lane, fe_block's expression slot after
+//                   slot) from the complete B_CARRY_Y, and their tangent projection at the point: B_CARRY_G, the gradient
+//                   of a pose without shared edges as launch k would form it, bit for bit.  For the public poses it
+//                   leaves W_j and the point itself as [entry][public pose] arrays.
+//     launch k      (FE_CARRY_IN): waves 0-3 request the head of the slab and B_CARRY_G at once, the bulk of the slab behind
+//                   barrier A, and do nothing else until the product; waves 4-7 finish the public poses, one per lane --
+//                   W_j + G_j, projection -- from operands whose addresses need no descriptor round trip (16-bit codes in
+//                   the launch's descriptor) and overwrite their rows of the vector.  ONE round trip in front of the stream
+//                   instead of three; the sparse operator is read once per launch instead of once per workgroup.
+//   Same arithmetic on the same operands in the same order: the iterates are still BITWISE those of the two-launch sequence
+//   (tests/test_gpu_fused_step.py, profiles/experiments/fe_fuzz.py).  19.8 -> 14.6 us per launch on sphere2500 / 5
+//   (profiles/r05_carried_rows.md has the phase traces and what each step bought).
 //
-// What was learned building it (profiles/r03_fused_step.md has the phase traces):
+// What was learned building it (profiles/r03_fused_step.md, profiles/r05_carried_rows.md):
 //   * a CU serves its vector-memory requests in order.  A slab requested first holds every later load of the same CU
 //     back until it has landed (X staged at 6.5 us instead of 2): the evaluation cannot hide under the stream, its loads
-//     must be IN FRONT of the slab's in the queue.  Loads under a divergent predicate are waited for at the end of
-//     their block, a pointer that was loaded from memory makes a flat load (waited for with vmcnt(0)), and a value the
-//     compiler may resolve early (src ? src : slab) is resolved -- and waited for -- early: every one of these turns
-//     "requested now, used later" into a wait for the whole queue (asm volatile pins below).
+//     must be IN FRONT of the slab's in the queue.  A pointer that was loaded from memory makes a flat load (waited for
+//     with vmcnt(0)), and a value the compiler may resolve early (src ? src : slab) is resolved -- and waited for -- early:
+//     every one of these turns "requested now, used later" into a wait for the whole queue (asm volatile pins below).
+//   * loads under a wave-uniform `if` cost twice (round 5, read off the ISA): a select on the loaded value inside the
+//     branch is waited for inside the branch, and behind the join the compiler's wait counts are those of the path that
+//     skipped the loads -- every later wait for an OLDER load then waits for these as well.  Rounds 3-4 requested the slab
+//     under `tid < 256`: the stream ran as four exposed round trips.  Every wave issues the same loads now (<R, WD>), or
+//     takes one of two whole code paths (<R, 0>).
+//   * a wave stays at the issue of its loads for as long as the CU's memory pipe is full: a wave that requests 32 KB
+//     executes its next instruction when most of that has landed.  Whoever requests the slab takes part in nothing else
+//     until the product; whoever must get a request in front of the slab's bulk does so before barrier A.
 //   * __syncthreads() waits for every global load in flight (one counter for loads and stores on gfx9): the barriers
 //     here order LDS only (lds_barrier).
 //   * one lane per pose reading 128-byte blocks touches 64 cache lines per load instruction: the blocks are stored
 //     once more in the order the lanes read them (4x on the evaluation).
 //   * the scheduler hoists every gather above the first multiply and spills: the accumulators are pinned per block.
+//   * the workgroup that keeps the books must not keep them in front of a barrier the stream waves wait at: workgroup 0
+//     finished 1.6 us behind the other 249, and a launch lasts as long as its last workgroup.
 //
 // What no longer holds "for free" behind a kernel boundary, and how it is kept:
 //   * the evaluation reads X of the whole agent and the neighbours' auxiliary poses, the tails / look-ahead steps of the
@@ -38,13 +66,16 @@
 //     so the copy a launch leaves is complete -- and the next launch does the opposite; a run of one-launch iterations
 //     has an even length, so the state ends in the primary arrays.  (Round 3 kept one copy: every workgroup counted itself
 //     in once its gradient was formed and nobody stored before the counter was complete -- which needed every workgroup
-//     of a launch resident at once, the device's lock, and a spin that could only give up.)
+//     of a launch resident at once, the device's lock, and a spin that could only give up.)  The carried arrays are
+//     written for one agent and read for another in any one launch, and live inside one captured run.
 //   * the Nesterov scalars advance between iterations: they are double-buffered -- workgroup 0 writes the next state
 //     next to the one every workgroup of this launch reads; the launch that leaves the fused run copies it back
 //     (k_eval_stats, nest_copy).
 // Mid-run iterations only (ahead == 3: nothing a status query reads is left behind); the last iterations of a run take
-// the two-launch sequence, which leaves the statistics.  Dense agents of 449 (default: where this form is faster; any n >= 32 with DPGO_FE_MIN_N) .. 512 poses, r <= 5, rows of <= 8 blocks,
-// <= 160 shared edges; DPGO_FUSED_EVAL=0 keeps the two-launch sequence everywhere.
+// the two-launch sequence, which leaves the statistics.  Dense agents of 32 .. 512 poses where every iteration finds carried
+// rows, 449 .. 512 otherwise (the bound where each form beats two launches; DPGO_FE_MIN_N sets it by hand), r <= 5, rows
+// of <= 8 blocks, <= 160 shared edges; DPGO_FUSED_EVAL=0 keeps the two-launch sequence everywhere, DPGO_FE_CARRY=0 the
+// round-3 form of the one-launch iteration.
 #include "kernel_common.h"
 #include <algorithm>
 
