@@ -84,6 +84,23 @@ __device__ __forceinline__ double2 ld2_nt(const double *p) {
 #endif
 }
 
+// the same two loads from an address KNOWN to be global memory.  A pointer that was itself loaded from memory (a descriptor
+// read from the agents array) is a generic pointer to the compiler: its loads are flat loads, which may return out of
+// order and are therefore waited for with vmcnt(0) lgkmcnt(0) -- all of them before the first use of any of them.
+typedef const __attribute__((address_space(1))) v2d_t *gv2d_ptr;
+__device__ __forceinline__ double2 ld2g(const double *p) {
+  const v2d_t v = *(gv2d_ptr)p;
+  return make_double2(v.x, v.y);
+}
+__device__ __forceinline__ double2 ld2g_nt(const double *p) {
+#if DPGO_M_NT
+  const v2d_t v = __builtin_nontemporal_load((gv2d_ptr)p);
+  return make_double2(v.x, v.y);
+#else
+  return ld2g(p);
+#endif
+}
+
 // acc + a0 b0 + a1 b1 + a2 b2 + a3 b3 as four fused multiply-adds on the accumulator, in this order -- EVERY block
 // product of the library (k_eval, the Hessian kernels, the one-launch solve and the one-launch iteration) goes through
 // here, so they stay bitwise equal to each other.  (`acc += a0 * b0 + a1 * b1 + ...` compiles to mul, fma, fma, fma, add

@@ -290,14 +290,18 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *__restrict__ ag
 #pragma unroll
     for (int m = 0; m < MPRE; ++m) {
       const int k = 2 * kl + 64 * m;
-      mreg[m] = (cact && k < kn) ? ld2_nt(Mc + k0 + k) : make_double2(0.0, 0.0);
+      // (an unconditional load from a clamped address: a load under a lane-varying condition is a branch of its own, and
+      // behind 32 of them the compiler waits for the whole slab before the first multiply -- round 5, read off the ISA.
+      // Rows beyond the chunk meet zeros of the staged vector; columns beyond the last pose feed sums nobody reads.)
+      mreg[m] = ld2g_nt(Mc + min(k0 + k, N4 - 2));
     }
     {
       double2 v[NSTG];
 #pragma unroll
       for (int u = 0; u < NSTG; ++u) {
         const int tt = 2 * (tid + 256 * u);  // kn * R is even
-        v[u] = (tt < kn * R) ? ld2(Vstage + (size_t)k0 * R + tt) : make_double2(0.0, 0.0);
+        const double2 t2 = ld2g(Vstage + (size_t)k0 * R + min(tt, kn * R - 2));
+        v[u] = (tt < kn * R) ? t2 : make_double2(0.0, 0.0);
       }
 #pragma unroll
       for (int u = 0; u < NSTG; ++u) {
@@ -310,7 +314,7 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *__restrict__ ag
 #pragma unroll
     for (int m = MPRE; m < MREG; ++m) {
       const int k = 2 * kl + 64 * m;
-      mreg[m] = (cact && k < kn) ? ld2_nt(Mc + k0 + k) : make_double2(0.0, 0.0);
+      mreg[m] = ld2g_nt(Mc + min(k0 + k, N4 - 2));
     }
     PC_STAMP(3);
 #pragma unroll
