@@ -204,7 +204,9 @@ __global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ ag
     //     Everything is requested in front of barrier A; G_j, the projection, and behind barrier B the row of the vector in
     //     LDS is overwritten.
     // Barrier A: the gradient waves have requested all they need (the bulk of the slab queues behind it, not in front);
-    // B: the carried gradient is in LDS; B2: the rows of the public poses are.
+    // B: the carried gradient is in LDS; B2: the rows of the public poses are.  (The two kinds of waves are whole waves --
+    // the branch below is on the wave index -- and each meets exactly A, B and B2, from its own code path: the two paths
+    // cannot share the barriers' program points without keeping both register sets alive at once.)
     const int cwv = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (cwv < 4) {
       for (int t = N4 * R + tid; t < KC * R; t += 256) vs[t] = 0.0;  // rows of the vector beyond the agent's
