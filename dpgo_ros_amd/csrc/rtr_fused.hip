@@ -592,7 +592,7 @@ __global__ __launch_bounds__(TL ? TLS_NT : 256) void k_rtr_solve(const AgentDev 
                                                    unsigned long long *cum, RtrState *host_rec,
                                                    unsigned long long *host_cum, int *err, double Delta0, double tol, int max_outer, int max_inner,
                                                    double max_radius, TeamDev *team, int tail, int num_robots,
-                                                   int restart_interval) {
+                                                   int restart_interval, const AgentDev agv) {
   // (16-byte aligned: the static arrays in front of it end on an odd multiple of 8 bytes, and every 16-byte ds_read of a
   // slab that starts there is split by the hardware -- the slab product ran at a sixth of its speed until round 4)
   static_assert(NP == 2 || (NP == 3 && !TL), "two poses per workgroup, or three in the dense solve");
@@ -607,7 +607,14 @@ __global__ __launch_bounds__(TL ? TLS_NT : 256) void k_rtr_solve(const AgentDev 
   __shared__ double BL[NP * RTR_SLOTS * 16];  // the first ELL slots of the own poses: 4 x 4 blocks and indices
   __shared__ int idxL[NP * RTR_SLOTS];
   __shared__ double Hcs[NP * 9];  // curvature blocks of the own poses at the current X
+  // (the agent's descriptor BY VALUE: pointers read from the agents array are generic pointers to the compiler, their
+  // loads flat loads -- out of order, so every wait for one of them is a wait for all loads and LDS operations in flight;
+  // 245 of them in this kernel until round 5)
+#ifdef DPGO_RTR_DESC_MEM
   const AgentDev &ag = agents[ai];
+#else
+  const AgentDev &ag = agv;
+#endif
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bx = (int)blockIdx.x, N4 = ag.N4, n = ag.n;
   const int nblk = TL ? ag.tl.nwg - ag.tl.nS2 : (n + NP - 1) / NP;  // == gridDim.x
@@ -1185,15 +1192,15 @@ int launch_rtr_solve(const LaunchCtx &c, int ai, int n, unsigned long long *bar,
     if (e == hipSuccess) {
       if (tl_nwg > 0)
         hipLaunchKernelGGL((k_rtr_solve<R, true>), dim3(tl_nwg), dim3(TLS_NT), dyn, c.stream, c.agents, ai, bar, ws, cum, host_rec, host_cum, err,
-                           Delta0, tol, max_outer, max_inner, max_radius, c.team, tail, num_robots, restart_interval);
+                           Delta0, tol, max_outer, max_inner, max_radius, c.team, tail, num_robots, restart_interval, c.host_agents[ai]);
       else if (np == 3) {
         if constexpr (R <= 5)
           hipLaunchKernelGGL((k_rtr_solve<R, false, 3>), dim3((n + 2) / 3), dim3(256), dyn, c.stream, c.agents, ai, bar, ws, cum, host_rec, host_cum, err,
-                             Delta0, tol, max_outer, max_inner, max_radius, c.team, tail, num_robots, restart_interval);
+                             Delta0, tol, max_outer, max_inner, max_radius, c.team, tail, num_robots, restart_interval, c.host_agents[ai]);
         else e = hipErrorInvalidValue;
       } else
         hipLaunchKernelGGL((k_rtr_solve<R, false>), dim3((n + 1) / 2), dim3(256), dyn, c.stream, c.agents, ai, bar, ws, cum, host_rec, host_cum, err,
-                           Delta0, tol, max_outer, max_inner, max_radius, c.team, tail, num_robots, restart_interval);
+                           Delta0, tol, max_outer, max_inner, max_radius, c.team, tail, num_robots, restart_interval, c.host_agents[ai]);
     }
   });
   return e == hipSuccess ? 0 : -1;
