@@ -67,9 +67,19 @@ __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-__device__ __forceinline__ double2 ld2(const double *p) { return *reinterpret_cast<const double2 *>(p); }
-
 typedef double v2d_t __attribute__((ext_vector_type(2)));
+
+// Loads from GLOBAL memory, said so.  A pointer that was itself read from memory (a field of a descriptor in the agents
+// array) is a generic pointer to the compiler and its loads are flat loads: they may return out of order, so a wait for
+// one of them is `vmcnt(0) lgkmcnt(0)` -- a wait for every load and every LDS operation in flight.  The row products,
+// the linear term and the statistics kernels carried 130 .. 300 of them each until round 5.  gp(p)[i] is p[i] as a
+// global load; ld2 / ld2_nt are 16-byte global loads.  (Never for LDS.)
+template <class T>
+__device__ __forceinline__ __attribute__((address_space(1))) T *gp(T *p) { return (__attribute__((address_space(1))) T *)p; }
+__device__ __forceinline__ double2 ld2(const double *p) {
+  const v2d_t v = *(const __attribute__((address_space(1))) v2d_t *)p;
+  return make_double2(v.x, v.y);
+}
 
 #ifndef DPGO_M_NT
 #define DPGO_M_NT 1
@@ -77,29 +87,15 @@ typedef double v2d_t __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ double2 ld2_nt(const double *p) {
 #if DPGO_M_NT
-  const v2d_t v = __builtin_nontemporal_load(reinterpret_cast<const v2d_t *>(p));
+  const v2d_t v = __builtin_nontemporal_load((const __attribute__((address_space(1))) v2d_t *)p);
   return make_double2(v.x, v.y);
 #else
-  return *reinterpret_cast<const double2 *>(p);
+  return ld2(p);
 #endif
 }
 
-// the same two loads from an address KNOWN to be global memory.  A pointer that was itself loaded from memory (a descriptor
-// read from the agents array) is a generic pointer to the compiler: its loads are flat loads, which may return out of
-// order and are therefore waited for with vmcnt(0) lgkmcnt(0) -- all of them before the first use of any of them.
-typedef const __attribute__((address_space(1))) v2d_t *gv2d_ptr;
-__device__ __forceinline__ double2 ld2g(const double *p) {
-  const v2d_t v = *(gv2d_ptr)p;
-  return make_double2(v.x, v.y);
-}
-__device__ __forceinline__ double2 ld2g_nt(const double *p) {
-#if DPGO_M_NT
-  const v2d_t v = __builtin_nontemporal_load((gv2d_ptr)p);
-  return make_double2(v.x, v.y);
-#else
-  return ld2g(p);
-#endif
-}
+__device__ __forceinline__ double2 ld2g(const double *p) { return ld2(p); }
+__device__ __forceinline__ double2 ld2g_nt(const double *p) { return ld2_nt(p); }
 
 // acc + a0 b0 + a1 b1 + a2 b2 + a3 b3 as four fused multiply-adds on the accumulator, in this order -- EVERY block
 // product of the library (k_eval, the Hessian kernels, the one-launch solve and the one-launch iteration) goes through
@@ -119,7 +115,7 @@ __device__ __forceinline__ void ell_group(const AgentDev &ag, int j, int slot0, 
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const bool valid = slot0 + u < W;
-    idx[u] = valid ? ag.ell_col[(size_t)(slot0 + u) * n + j] : j;
+    idx[u] = valid ? gp(ag.ell_col)[(size_t)(slot0 + u) * n + j] : j;
     const double *bp = ag.ell_val + ((size_t)(valid ? slot0 + u : 0) * n + j) * 16;
 #pragma unroll
     for (int q = 0; q < 8; ++q) B[u][q] = valid ? ld2(bp + 2 * q) : make_double2(0.0, 0.0);
@@ -142,9 +138,9 @@ template <int R, int NV, class Src>
 __device__ __forceinline__ void spmm_row(const AgentDev &ag, int j, Src src, double (*acc)[4]) {
   ell_group<R, NV>(ag, j, 0, src, acc);
   if (ag.ell_w > 4) ell_group<R, NV>(ag, j, 4, src, acc);
-  const int p0 = ag.trowptr[j], p1 = ag.trowptr[j + 1];
+  const int p0 = gp(ag.trowptr)[j], p1 = gp(ag.trowptr)[j + 1];
   for (int p = p0; p < p1; ++p) {
-    const int i = ag.tcol[p];
+    const int i = gp(ag.tcol)[p];
     const double *bp = ag.tval + (size_t)16 * p;
     double x[NV][4];
     src(i, x);
@@ -171,27 +167,27 @@ __device__ __forceinline__ void g_row_range(const AgentDev &ag, int e0, int e1, 
     bool copy[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const SharedEdgeDev &se = ag.se[min(eb + u, e1 - 1)];
-      slab[u] = ag.nbr[aux] + (size_t)se.slot * 4 * R;
-      const double *src = se.src[aux];
+      const auto *se = gp(ag.se) + min(eb + u, e1 - 1);
+      slab[u] = ag.nbr[aux] + (size_t)se->slot * 4 * R;
+      const double *src = se->src[aux];
       copy[u] = pull && src;
       xp[u] = copy[u] ? src : slab[u];
     }
     double x[4][4], cf[4][16];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const SharedEdgeDev &se = ag.se[min(eb + u, e1 - 1)];
+      const auto *se = gp(ag.se) + min(eb + u, e1 - 1);
 #pragma unroll
-      for (int cp = 0; cp < 4; ++cp) x[u][cp] = xp[u][cp * R + a];
+      for (int cp = 0; cp < 4; ++cp) x[u][cp] = gp(xp[u])[cp * R + a];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) cf[u][i] = se.coef[i];
+      for (int i = 0; i < 16; ++i) cf[u][i] = se->coef[i];
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       if (eb + u < e1) {
         if (copy[u]) {
 #pragma unroll
-          for (int cp = 0; cp < 4; ++cp) slab[u][cp * R + a] = x[u][cp];
+          for (int cp = 0; cp < 4; ++cp) gp(slab[u])[cp * R + a] = x[u][cp];
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c)
@@ -270,10 +266,10 @@ __device__ __forceinline__ void eval_body(const AgentDev *__restrict__ agents, c
   if (act) {
     // shared edges of this pose, requested in front of the SpMM so that the two chains of dependent round trips
     // (index -> X gather, edge range -> edge -> neighbour pose) run side by side
-    e0 = ag.pose_eptr[j]; e1 = ag.pose_eptr[j + 1];
+    e0 = gp(ag.pose_eptr)[j]; e1 = gp(ag.pose_eptr)[j + 1];
     spmm_row<R, 1>(ag, j, [&](int i, double(*x)[4]) {
 #pragma unroll
-      for (int cp = 0; cp < 4; ++cp) x[0][cp] = X[((size_t)4 * i + cp) * R + a];
+      for (int cp = 0; cp < 4; ++cp) x[0][cp] = gp(X)[((size_t)4 * i + cp) * R + a];
     }, acc);
   }
   // (k_eval_staged: the helper waves have put the operands of the tile's shared edges into LDS meanwhile.  The barrier
@@ -285,23 +281,23 @@ __device__ __forceinline__ void eval_body(const AgentDev *__restrict__ agents, c
     if (e1 > e0) {
       if (gmode == 0) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) g[c] = Gj[c * R + a];
+        for (int c = 0; c < 4; ++c) g[c] = gp(Gj)[c * R + a];
       } else {
         // (Eop: the operands of this tile's shared edges are in LDS -- k_eval_staged -- and the pulled poses already
         // went to the slab)
         if (Eop) g_row_lds<R>(Eop, e0 - ebase, e1 - ebase, a, g);
         else g_row_range<R>(ag, e0, e1, a, aux, gmode == 2, g);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) Gj[c * R + a] = g[c];
+        for (int c = 0; c < 4; ++c) gp(Gj)[c * R + a] = g[c];
       }
     }
     double *EG = ag.buf[egb] + (size_t)j * 4 * R;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const double xr = X[((size_t)4 * j + c) * R + a];
+      const double xr = gp(X)[((size_t)4 * j + c) * R + a];
       fpart += (0.5 * acc[0][c] + g[c]) * xr;
       const double eg = acc[0][c] + g[c];
-      EG[c * R + a] = eg;
+      gp(EG)[c * R + a] = eg;
       Ysh[lp * 4 * R + c * R + a] = xr;
       Wsh[lp * 4 * R + c * R + a] = eg;
       if (c == 3) eg3 = eg;
@@ -322,18 +318,18 @@ __device__ __forceinline__ void eval_body(const AgentDev *__restrict__ agents, c
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       if (IN_WAVE) __hip_atomic_store(GF + c * R + a, o[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      else GF[c * R + a] = o[c];
+      else gp(GF)[c * R + a] = o[c];
       gpart += o[c] * o[c];
     }
     if (IN_WAVE) __hip_atomic_store(GF + 3 * R + a, eg3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else GF[3 * R + a] = eg3;
+    else gp(GF)[3 * R + a] = eg3;
     gpart += eg3 * eg3;
   }
   fpart = wave_sum(fpart);
   gpart = wave_sum(gpart);
   if (lane == 0) {
     double *P = ag.part + poff + (size_t)bx * PART_STRIDE;
-    P[0] = fpart; P[1] = gpart;
+    gp(P)[0] = fpart; gp(P)[1] = gpart;
   }
 }
 
