@@ -8,6 +8,12 @@
 
 namespace dpgo {
 
+typedef double v2d_t __attribute__((ext_vector_type(2)));
+
+// p[i] as a load from / store to GLOBAL memory: gp(p)[i] (kernel_common.h says why; never for LDS)
+template <class T>
+__device__ __forceinline__ __attribute__((address_space(1))) T *gp(T *p) { return (__attribute__((address_space(1))) T *)p; }
+
 // 3x3 symmetric eigen-decomposition by cyclic Jacobi.  S row-major; V columns = eigenvectors.
 __device__ __forceinline__ void sym3_eig(const double S[9], double w[3], double V[9]) {
   double A[9];
@@ -423,7 +429,7 @@ __device__ __forceinline__ double sum_partials(const double *p, int count, int s
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int i = base + lane + 64 * u;
-      v[u] = (i < count) ? p[(size_t)i * stride] : 0.0;
+      v[u] = (i < count) ? gp(p)[(size_t)i * stride] : 0.0;
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) s += v[u];
@@ -439,7 +445,7 @@ __device__ __forceinline__ void sum_partials2(const double *p, int count, int st
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int i = base + lane + 64 * u;
-      v[u] = (i < count) ? *reinterpret_cast<const double2 *>(p + (size_t)i * stride) : make_double2(0.0, 0.0);
+      if (i < count) { const v2d_t t = *(const __attribute__((address_space(1))) v2d_t *)(p + (size_t)i * stride); v[u] = make_double2(t.x, t.y); } else v[u] = make_double2(0.0, 0.0);
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) { a += v[u].x; b += v[u].y; }

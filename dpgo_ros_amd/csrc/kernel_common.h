@@ -67,15 +67,11 @@ __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-typedef double v2d_t __attribute__((ext_vector_type(2)));
-
 // Loads from GLOBAL memory, said so.  A pointer that was itself read from memory (a field of a descriptor in the agents
 // array) is a generic pointer to the compiler and its loads are flat loads: they may return out of order, so a wait for
 // one of them is `vmcnt(0) lgkmcnt(0)` -- a wait for every load and every LDS operation in flight.  The row products,
 // the linear term and the statistics kernels carried 130 .. 300 of them each until round 5.  gp(p)[i] is p[i] as a
 // global load; ld2 / ld2_nt are 16-byte global loads.  (Never for LDS.)
-template <class T>
-__device__ __forceinline__ __attribute__((address_space(1))) T *gp(T *p) { return (__attribute__((address_space(1))) T *)p; }
 __device__ __forceinline__ double2 ld2(const double *p) {
   const v2d_t v = *(const __attribute__((address_space(1))) v2d_t *)p;
   return make_double2(v.x, v.y);

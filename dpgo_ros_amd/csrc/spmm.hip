@@ -69,7 +69,7 @@ __global__ __launch_bounds__(EVS_NT) void k_eval_staged(const AgentDev *__restri
   const int bx = (int)blockIdx.x;
   const int j0 = bx * PPB;
   if (j0 >= ag.n) return;
-  const int E0 = ag.pose_eptr[j0], E1 = ag.pose_eptr[min(j0 + PPB, ag.n)], cnt = E1 - E0;
+  const int E0 = gp(ag.pose_eptr)[j0], E1 = gp(ag.pose_eptr)[min(j0 + PPB, ag.n)], cnt = E1 - E0;
   if (threadIdx.x >= 64) {
     // (every wave of the workgroup meets the same barriers: the one behind the staging when the tile has shared edges,
     // and eval_body's in front of the tangent projection -- no wave leaves a barrier behind it for the others)
@@ -90,8 +90,8 @@ __global__ __launch_bounds__(EVS_NT) void k_eval_staged(const AgentDev *__restri
         vc[u] = ld2(ag.se[E0 + (q >> 3)].coef + 2 * (q & 7));
         const int qx = min(base + t + EVS_NH * u, nx - 1);
         ed[u] = qx / XCH; part[u] = qx - ed[u] * XCH;
-        const SharedEdgeDev &se = ag.se[E0 + ed[u]];
-        src[u] = se.src[aux]; slot[u] = se.slot;
+        const auto *se = gp(ag.se) + (E0 + ed[u]);
+        src[u] = se->src[aux]; slot[u] = se->slot;
       }
       // the neighbours' poses: one more round trip
       double2 vx[CB];
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(EVS_NT) void k_eval_staged(const AgentDev *__restri
       for (int u = 0; u < CB; ++u) {
         if (base + t + EVS_NH * u < nx) {
           *reinterpret_cast<double2 *>(Eop + (size_t)ed[u] * EPE + 2 * part[u]) = vx[u];
-          if (cp[u]) *reinterpret_cast<double2 *>(ag.nbr[aux] + (size_t)slot[u] * 4 * R + 2 * part[u]) = vx[u];
+          if (cp[u]) { const v2d_t tv = {vx[u].x, vx[u].y}; *(__attribute__((address_space(1))) v2d_t *)(ag.nbr[aux] + (size_t)slot[u] * 4 * R + 2 * part[u]) = tv; }
         }
       }
     }
@@ -144,13 +144,13 @@ __global__ __launch_bounds__(64) void k_hess(const AgentDev *__restrict__ agents
   if (act) {
     spmm_row<R, 1>(ag, j, [&](int i, double(*x)[4]) {
 #pragma unroll
-      for (int cp = 0; cp < 4; ++cp) x[0][cp] = V[((size_t)4 * i + cp) * R + a];
+      for (int cp = 0; cp < 4; ++cp) x[0][cp] = gp(V)[((size_t)4 * i + cp) * R + a];
     }, w);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      vrow[c] = V[((size_t)4 * j + c) * R + a];
-      Ysh[lp * 4 * R + c * R + a] = ag.buf[xb][((size_t)4 * j + c) * R + a];
-      Esh[lp * 4 * R + c * R + a] = ag.buf[egb][((size_t)4 * j + c) * R + a];
+      vrow[c] = gp(V)[((size_t)4 * j + c) * R + a];
+      Ysh[lp * 4 * R + c * R + a] = gp(ag.buf[xb])[((size_t)4 * j + c) * R + a];
+      Esh[lp * 4 * R + c * R + a] = gp(ag.buf[egb])[((size_t)4 * j + c) * R + a];
     }
   }
   __syncthreads();
@@ -159,10 +159,10 @@ __global__ __launch_bounds__(64) void k_hess(const AgentDev *__restrict__ agents
   if (act) {
     double *O = ag.buf[ob] + (size_t)j * 4 * R;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) { O[c * R + a] = hrow[c]; d += vrow[c] * hrow[c]; }
+    for (int c = 0; c < 4; ++c) { gp(O)[c * R + a] = hrow[c]; d += vrow[c] * hrow[c]; }
   }
   d = wave_sum(d);
-  if (lane == 0) ag.part[poff + (size_t)blockIdx.x * PART_STRIDE] = d;
+  if (lane == 0) gp(ag.part)[poff + (size_t)blockIdx.x * PART_STRIDE] = d;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -221,16 +221,16 @@ __global__ __launch_bounds__(64) void k_tcg_hv(const AgentDev *__restrict__ agen
 #pragma unroll
       for (int cp = 0; cp < 4; ++cp) {
         const size_t o = ((size_t)4 * i + cp) * R + a;
-        x[0][cp] = fresh ? Dnew[o] : (-Z[o] + beta * Dold[o]);
+        x[0][cp] = fresh ? gp(Dnew)[o] : (-gp(Z)[o] + beta * gp(Dold)[o]);
       }
     }, w);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const size_t o = ((size_t)4 * j + c) * R + a;
-      vrow[c] = fresh ? Dnew[o] : (-Z[o] + beta * Dold[o]);
-      if (!fresh) Dnew[o] = vrow[c];
-      Ysh[lp * 4 * R + c * R + a] = ag.buf[B_X][o];
-      Esh[lp * 4 * R + c * R + a] = ag.buf[B_EGRAD][o];
+      vrow[c] = fresh ? gp(Dnew)[o] : (-gp(Z)[o] + beta * gp(Dold)[o]);
+      if (!fresh) gp(Dnew)[o] = vrow[c];
+      Ysh[lp * 4 * R + c * R + a] = gp(ag.buf[B_X])[o];
+      Esh[lp * 4 * R + c * R + a] = gp(ag.buf[B_EGRAD])[o];
     }
   }
   __syncthreads();
@@ -239,10 +239,10 @@ __global__ __launch_bounds__(64) void k_tcg_hv(const AgentDev *__restrict__ agen
   if (act) {
     double *O = ag.buf[B_HD] + (size_t)j * 4 * R;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) { O[c * R + a] = hrow[c]; d += vrow[c] * hrow[c]; }
+    for (int c = 0; c < 4; ++c) { gp(O)[c * R + a] = hrow[c]; d += vrow[c] * hrow[c]; }
   }
   d = wave_sum(d);
-  if (lane == 0) ag.part[PART_A + (size_t)blockIdx.x * PART_STRIDE] = d;
+  if (lane == 0) gp(ag.part)[PART_A + (size_t)blockIdx.x * PART_STRIDE] = d;
 }
 
 // Heterogeneous launch that closes iteration k and opens iteration k+1 inside captured graphs: the first
