@@ -18,10 +18,7 @@ enum Buf {
 // carried rows of the one-launch iteration (step_fused.hip): the evaluation point of the agent two iterations ahead
 // ([pose][4r]) and the row products formed from it ([entry][pose]).  They live inside one captured run of one-launch
 // iterations only, in two work vectors of the trust-region solver that an RGD team never touches meanwhile.
-constexpr int B_CARRY_Y = B_R0, B_CARRY_W = B_R1, B_CARRY_X = B_D0;  // (W: row product and point of the PUBLIC poses as pairs,
-                                                                      // [entry][public pose][W, X]; 2 * 4r * npub doubles: it runs on into
-                                                                      // B_CARRY_X, the next vector in memory)
-static_assert(B_CARRY_X == B_CARRY_W + 1, "the [W, X] pairs of the public poses span two consecutive work vectors");
+constexpr int B_CARRY_Y = B_R0, B_CARRY_W = B_R1, B_CARRY_X = B_D0;  // (W / X: row products and point of the PUBLIC poses, [entry][public pose])
 constexpr int B_CARRY_G = B_D1;  // tangent projection of the row products at the point, [pose][4r]: the gradient of a pose without shared edges
 constexpr int FE_CARRY_IN = 1, FE_CARRY_W = 2, FE_CARRY_Y = 4;
 constexpr int FE_MAX_EDGES = 160;  // shared edges of an agent whose operands the one-launch iteration keeps in LDS (46 KB at r = 5)

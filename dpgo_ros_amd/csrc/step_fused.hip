@@ -273,9 +273,9 @@ __global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ ag
       const int pe0 = ag.pub_ptr[pqc], pe1 = ag.pub_ptr[pqc + (pact ? 1 : 0)];
       double w[4 * R], x[4 * R];
       {
-        const double *WX = ag.buf[B_CARRY_W];  // [entry][public pose][W, X]: one 16-byte load per entry
+        const double *Wc = ag.buf[B_CARRY_W], *Xc = ag.buf[B_CARRY_X];
 #pragma unroll
-        for (int i = 0; i < 4 * R; ++i) { const double2 t = ld2(WX + 2 * ((size_t)i * npub + pqc)); w[i] = t.x; x[i] = t.y; }
+        for (int i = 0; i < 4 * R; ++i) { w[i] = Wc[(size_t)i * npub + pqc]; x[i] = Xc[(size_t)i * npub + pqc]; }
       }
       FE_STAMP(10);
       lds_barrier();  // A
@@ -530,8 +530,8 @@ __global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ ag
         const double xe_ = Y2[(size_t)4 * R * pw + e];
         const int qi = agn.pub_index[pw];
         if (qi >= 0) {  // (a public pose: the next launch finishes it -- row product and point, [entry][public pose])
-          double *WX = agn.buf[B_CARRY_W] + 2 * ((size_t)e * agn.npub + qi);
-          WX[0] = acc; WX[1] = xe_;
+          agn.buf[B_CARRY_W][(size_t)e * agn.npub + qi] = acc;
+          agn.buf[B_CARRY_X][(size_t)e * agn.npub + qi] = xe_;
         }
         Ex[ls * 4 * R + e] = acc;
         Ex[3 * 4 * R + ls * 4 * R + e] = xe_;
