@@ -1095,7 +1095,7 @@ static int fe_carry_flags(dpgo_team_t *t, int rep, int nfe, const std::function<
     const int nblk = precond_nblk(*t->ag[b]);
     if ((t->ag[c]->n + nblk - 1) / nblk > step_fe_carry_max_poses()) return false;
     // (a gradient wave of the launch of agent c finishes 64 public poses and fetches their shared edges, two per lane)
-    if (t->ag[c]->npub > 256 || !t->ag[c]->dev.fe_code_ok) return false;
+    if (t->ag[c]->npub < 1 || t->ag[c]->npub > 256 || !t->ag[c]->dev.fe_code_ok) return false;  // (no public pose: no table to read)
     for (int g = 0; g < 4; ++g)
       if (t->ag[c]->dev.fe_eptr[g + 1] - t->ag[c]->dev.fe_eptr[g] > 128) return false;
     return true;
