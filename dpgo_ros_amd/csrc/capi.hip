@@ -1405,7 +1405,7 @@ int dpgo_team_run_simultaneous(dpgo_team_t *t, int ticks) {
   }
   LaunchCtx c = t->ctx();
   c.ny = na;
-  const int sel = SEL_GROUP0 - t->all_group, mn = t->max_n;
+  const int sel = SEL_ALL, mn = t->max_n;  // (= the class t->all_group: the local agents in index order)
   auto body = [&](int reps) {
     for (int rep = 0; rep < reps; ++rep) {
       // XPrev only feeds the status of the LAST tick of a run (|X - XPrev|^2 left by its step kernel): the copy is

@@ -167,5 +167,7 @@ struct TeamDev {
 };
 
 constexpr int SEL_GROUP0 = -16;  // sel <= SEL_GROUP0 selects colour class (SEL_GROUP0 - sel), member blockIdx.y
+constexpr int SEL_ALL = SEL_GROUP0 - 4096;  // every local agent, agent blockIdx.y (the class behind the colouring, without its
+                                            // two dependent table look-ups at the head of every kernel of a lockstep tick)
 
 }  // namespace dpgo

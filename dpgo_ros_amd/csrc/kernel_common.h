@@ -38,6 +38,7 @@ __device__ __forceinline__ int sel_cur(const TeamDev *team, int sel) {
   if (sel == -5) return team->stats_sel;
   if (sel == -6) return team->next_sel;
   if (sel > SEL_GROUP0) return team->cur_sel;
+  if (sel == SEL_ALL) return (int)blockIdx.y;
   return team->group_members[team->group_ptr[SEL_GROUP0 - sel] + blockIdx.y];  // colour-parallel update
 }
 
