@@ -92,6 +92,9 @@ double spmm_bytes_of(const dpgo_team *t, const Agent &a) {
 
 int enqueue_optimize(dpgo_team *t, int sel, const OptFlags &fl) {
   LaunchCtx c = t->ctx();
+  // (an eager launch that names its agent: the descriptor by value -- the host copy is current right now -- spares the step
+  // kernel one dependent cold round trip; captured sequences keep the device array, their descriptors may move under them)
+  c.bake_desc = sel >= 0 && !fl.capture && t->bake_desc;
   const dpgo_params_t &p = t->prm;
   const int mn = (sel >= 0) ? t->ag[sel]->n : t->max_n;
   const int N4 = 4 * mn;
