@@ -270,3 +270,61 @@ def test_carried_rows_need_three_different_agents_in_a_row():
     t2.synchronize()
     assert t2.counters()[8] == 0
     t2.close()
+
+
+@pytest.mark.parametrize("seed", [3, 11, 29, 57])
+def test_random_teams_take_carried_rows_and_stay_bitwise(seed):
+    """profiles/experiments/fe_fuzz.py with fixed seeds: sphere2500 over 5 .. 8 robots, r = 3 / 4 / 5, up to 110 extra loop
+    closures between random poses (more shared edges, longer rows), a random restart interval (3 .. 36) and step, GNC
+    re-weighting between the runs for half of the cases; one-launch iterations with carried rows against the two-launch
+    sequence, bit for bit after every run"""
+    rng = np.random.default_rng(seed)
+    m0, _, n = load("sphere2500", 5)
+    robots = int(rng.integers(5, 9))
+    r = int(rng.choice([3, 4, 5]))
+    extra = int(rng.integers(0, 110))
+    m = m0.copy()
+    if extra:
+        add = m[rng.integers(0, len(m), extra)].copy()
+        for e in add:
+            i, j = rng.integers(0, n, 2)
+            while abs(int(i) - int(j)) < 2:
+                i, j = rng.integers(0, n, 2)
+            e["p1"], e["p2"] = min(i, j), max(i, j)
+        m = np.concatenate([m, add])
+    mp = capi.partition(m.view(capi.MEAS_DTYPE), n, robots)
+    kw = dict(method=1, acceleration=1, rgd_stepsize=float(rng.choice([0.05, 0.1, 0.2])), rgd_use_preconditioner=1,
+              restart_interval=int(rng.integers(3, 37)))
+    robust = bool(rng.integers(0, 2))
+    if robust:
+        kw.update(robust_cost_type=5, gnc_barc=5.0)
+    T, Y = O.odometry_init(m0, n), O.fixed_stiefel(r)
+    teams = []
+    old = {k: os.environ.get(k) for k in ("DPGO_FUSED_EVAL", "DPGO_FE_MIN_N")}
+    try:
+        os.environ["DPGO_FE_MIN_N"] = "32"
+        for fe in ("0", "1"):
+            os.environ["DPGO_FUSED_EVAL"] = fe
+            t = capi.Team.from_measurements(mp, capi.default_params(r=r, num_robots=robots, **kw))
+            t.set_initial(T, Y)
+            teams.append(t)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    for chunk in rng.integers(20, 400, 3):
+        for t in teams:
+            t.run(int(chunk))
+            t.synchronize()
+        for k in teams[0].ids:
+            assert np.array_equal(teams[0].agents[k].get_X(), teams[1].agents[k].get_X()), (seed, robots, r, extra, kw, int(chunk), k)
+        if robust:
+            assert teams[0].update_weights() == teams[1].update_weights()
+    c = teams[1].counters()
+    assert teams[0].counters()[7] == 0
+    if c[7] > 0:   # (teams the one-launch form serves: every one of them also carries rows)
+        assert c[8] > 0, (seed, robots, r, extra, c[7], c[8])
+    for t in teams:
+        t.close()
