@@ -384,7 +384,8 @@ __device__ __forceinline__ void tile_in(Tile<R> &t, const double *g, int j0, int
 #pragma unroll
   for (int k = 0; k < 4 * R; ++k) {
     const int e = tid + 64 * k;
-    tmp[k] = (e < total) ? src[e] : 0.0;
+    const double v = gp(src)[min(e, total - 1)];  // (an unconditional global load from a clamped index: no branch per element)
+    tmp[k] = (e < total) ? v : 0.0;
   }
 #pragma unroll
   for (int k = 0; k < 4 * R; ++k) {
@@ -400,7 +401,7 @@ __device__ __forceinline__ void tile_out(const Tile<R> &t, double *g, int j0, in
 #pragma unroll
   for (int k = 0; k < 4 * R; ++k) {
     const int e = tid + 64 * k;
-    if (e < total) dst[e] = t.d[(e / (4 * R)) * Tile<R>::P + e % (4 * R)];
+    if (e < total) gp(dst)[e] = t.d[(e / (4 * R)) * Tile<R>::P + e % (4 * R)];
   }
 }
 

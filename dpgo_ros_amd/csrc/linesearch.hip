@@ -75,10 +75,10 @@ __global__ __launch_bounds__(64) void k_ls_cost(const AgentDev *__restrict__ age
   double f[8] = {0, 0, 0, 0, 0, 0, 0, 0}, slope = 0;
   if (act) {
     double g[4] = {0, 0, 0, 0};
-    if (ag.pub_index[j] >= 0) {
+    if (gp(ag.pub_index)[j] >= 0) {
       const double *G = ag.buf[B_G] + (size_t)j * 4 * R;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) g[c] = G[c * R + a];
+      for (int c = 0; c < 4; ++c) g[c] = gp(G)[c * R + a];
     }
     for (int t0 = 0; t0 < ntrials; t0 += 4) {
       const double *Xt[4];
@@ -89,19 +89,19 @@ __global__ __launch_bounds__(64) void k_ls_cost(const AgentDev *__restrict__ age
 #pragma unroll
         for (int v = 0; v < 4; ++v)
 #pragma unroll
-          for (int cp = 0; cp < 4; ++cp) x[v][cp] = Xt[v][((size_t)4 * i + cp) * R + a];
+          for (int cp = 0; cp < 4; ++cp) x[v][cp] = gp(Xt[v])[((size_t)4 * i + cp) * R + a];
       }, acc);
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         double s = 0;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) s += (0.5 * acc[v][c] + g[c]) * Xt[v][((size_t)4 * j + c) * R + a];
+        for (int c = 0; c < 4; ++c) s += (0.5 * acc[v][c] + g[c]) * gp(Xt[v])[((size_t)4 * j + c) * R + a];
         if (t0 + v < ntrials) f[t0 + v] = s;
       }
     }
     const double *GF = ag.buf[B_GF] + (size_t)j * 4 * R, *D = ag.buf[dirb] + (size_t)j * 4 * R;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) slope += GF[c * R + a] * D[c * R + a];
+    for (int c = 0; c < 4; ++c) slope += gp(GF)[c * R + a] * gp(D)[c * R + a];
   }
 #pragma unroll
   for (int t = 0; t < 8; ++t) f[t] = wave_sum(f[t]);
@@ -109,8 +109,8 @@ __global__ __launch_bounds__(64) void k_ls_cost(const AgentDev *__restrict__ age
   if (lane == 0) {
     double *P = ag.part + PART_A + (size_t)blockIdx.x * PART_STRIDE;
 #pragma unroll
-    for (int t = 0; t < 8; ++t) P[t] = f[t];
-    ag.part[PART_C + (size_t)blockIdx.x * PART_STRIDE + 2] = slope;
+    for (int t = 0; t < 8; ++t) gp(P)[t] = f[t];
+    gp(ag.part)[PART_C + (size_t)blockIdx.x * PART_STRIDE + 2] = slope;
   }
 }
 
@@ -137,9 +137,9 @@ __global__ __launch_bounds__(64) void k_ls_apply(const AgentDev *__restrict__ ag
     const double *pa = ag.part + PART_A + (size_t)(in ? b : 0) * PART_STRIDE;
     const double w = in ? 1.0 : 0.0;
     double v[8];
-    const double c0 = pc[0], c2 = pc[2];
+    const double c0 = gp(pc)[0], c2 = gp(pc)[2];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) v[t] = pa[t];
+    for (int t = 0; t < 8; ++t) v[t] = gp(pa)[t];
     f0 += w * c0; sl += w * c2;
 #pragma unroll
     for (int t = 0; t < 8; ++t) fj[t] += w * v[t];
