@@ -20,8 +20,8 @@ namespace dpgo {
 #endif
 #ifdef DPGO_PC_TRACE
 #define PC_TRACE_ON true
-#define PC_STAMP(k) do { if (MODE == PM_RGD_ && (threadIdx.x & 63) == 0 && blockIdx.x == DPGO_PC_TRACE_BLOCK) ag.part[PART_E + 4000 * PART_STRIDE + ((threadIdx.x >> 6) * 16) + (k)] = (double)wall_clock64(); \
-    if (MODE == PM_RGD_ && threadIdx.x < 128 && (threadIdx.x & 63) == 0 && ((k) == 0 || (k) == 7)) ag.part[PART_E + (4100 + 2 * (int)blockIdx.x + (int)(threadIdx.x >> 6)) * PART_STRIDE + ((k) ? 1 : 0)] = (double)wall_clock64(); } while (0)
+#define PC_STAMP(k) do { if (MODE == PM_RGD_ && (threadIdx.x & 63) == 0 && blockIdx.x == DPGO_PC_TRACE_BLOCK) gp(ag.part)[PART_E + 4000 * PART_STRIDE + ((threadIdx.x >> 6) * 16) + (k)] = (double)wall_clock64(); \
+    if (MODE == PM_RGD_ && threadIdx.x < 128 && (threadIdx.x & 63) == 0 && ((k) == 0 || (k) == 7)) gp(ag.part)[PART_E + (4100 + 2 * (int)blockIdx.x + (int)(threadIdx.x >> 6)) * PART_STRIDE + ((k) ? 1 : 0)] = (double)wall_clock64(); } while (0)
 #else
 #define PC_TRACE_ON false
 #define PC_STAMP(k) do { } while (0)
@@ -194,9 +194,9 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *__restrict__ ag
   if (tid < npose * 4 * R) {
     pre_x = ag.buf[xb][own_off];
     if (MODE == PM_RGD_) {
-      pre_v = ag.buf[B_V][own_off];
-      pre_y = ag.buf[B_Y][own_off];
-      if (want_stats) pre_p = ag.buf[B_XPREV][own_off];
+      pre_v = gp(ag.buf[B_V])[own_off];
+      pre_y = gp(ag.buf[B_Y])[own_off];
+      if (want_stats) pre_p = gp(ag.buf[B_XPREV])[own_off];
     }
   }
   double ahead_alpha = 0;
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *__restrict__ ag
       la_opt = team->sched[(team->iter + 1) % team->sched_len] == a;
       const size_t o = (size_t)la_pose * 4 * R;
 #pragma unroll
-      for (int i = 0; i < 4 * R; ++i) { la_x[i] = xa[o + i]; la_v[i] = va[o + i]; }
+      for (int i = 0; i < 4 * R; ++i) { la_x[i] = gp(xa)[o + i]; la_v[i] = gp(va)[o + i]; }
     }
   }
 
@@ -408,10 +408,10 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *__restrict__ ag
         // iteration k+1 restarts: XPrev = X, and V = Y = X for the agents that do not optimize (X does not move)
 #pragma unroll
         for (int i = 0; i < 4 * R; ++i) {
-          if (la_status) oa.buf[B_XPREV][o + i] = la_x[i];
-          if (!la_opt) { oa.buf[B_Y][o + i] = la_x[i]; oa.buf[B_V][o + i] = la_x[i]; }
+          if (la_status) gp(oa.buf[B_XPREV])[o + i] = la_x[i];
+          if (!la_opt) { gp(oa.buf[B_Y])[o + i] = la_x[i]; gp(oa.buf[B_V])[o + i] = la_x[i]; }
         }
-        if (la_status && !la_opt) oa.part[PART_D + la_pose] = 0.0;
+        if (la_status && !la_opt) gp(oa.part)[PART_D + la_pose] = 0.0;
       } else {
         // V of an agent that does not optimize is re-projected by the reference (V = proj(V)); V left its last update
         // as a polar factor, so the projection is the identity up to round-off and V is neither read nor written here
@@ -423,13 +423,13 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *__restrict__ ag
           double r2 = 0;
 #pragma unroll
           for (int i = 0; i < 4 * R; ++i) { const double d = y[i] - la_x[i]; r2 += d * d; }
-          oa.part[PART_D + la_pose] = r2;
+          gp(oa.part)[PART_D + la_pose] = r2;
         }
 #pragma unroll
         for (int i = 0; i < 4 * R; ++i) {
-          if (la_status) oa.buf[B_XPREV][o + i] = la_x[i];
-          oa.buf[B_Y][o + i] = y[i];
-          oa.buf[B_X][o + i] = y[i];
+          if (la_status) gp(oa.buf[B_XPREV])[o + i] = la_x[i];
+          gp(oa.buf[B_Y])[o + i] = y[i];
+          gp(oa.buf[B_X])[o + i] = y[i];
         }
       }
     }
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *__restrict__ ag
       if (want_stats) {
 #pragma unroll
         for (int i = 0; i < 4 * R; ++i) {
-          ag.buf[B_X2][o + i] = x[i];  // snapshot for the final-statistics evaluation of this iteration
+          gp(ag.buf[B_X2])[o + i] = x[i];  // snapshot for the final-statistics evaluation of this iteration
           const double d = x[i] - Esh[2][lp * 4 * R + i];
           rel += d * d;
         }
@@ -481,15 +481,15 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *__restrict__ ag
         //   k+1 restarts: V = Y = X unless this agent is selected again (X does not move)
         if (la_status) {
 #pragma unroll
-          for (int i = 0; i < 4 * R; ++i) ag.buf[B_XPREV][o + i] = x[i];
+          for (int i = 0; i < 4 * R; ++i) gp(ag.buf[B_XPREV])[o + i] = x[i];
         }
         if (restart_next) {
 #pragma unroll
           for (int i = 0; i < 4 * R; ++i) {
-            ag.buf[B_X][o + i] = x[i];
-            if (!ahead_opt) { ag.buf[B_Y][o + i] = x[i]; v[i] = x[i]; } else if (reset) ag.buf[B_Y][o + i] = x[i];
+            gp(ag.buf[B_X])[o + i] = x[i];
+            if (!ahead_opt) { gp(ag.buf[B_Y])[o + i] = x[i]; v[i] = x[i]; } else if (reset) gp(ag.buf[B_Y])[o + i] = x[i];
           }
-          if (la_status && !ahead_opt) ag.part[PART_D + (lp ? pj1 : pj0)] = 0.0;
+          if (la_status && !ahead_opt) gp(ag.part)[PART_D + (lp ? pj1 : pj0)] = 0.0;
         } else {
           double y[4 * R];
 #pragma unroll
@@ -497,26 +497,26 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *__restrict__ ag
           polar_inplace<R>(y);
           PC_STAMP(11);
 #pragma unroll
-          for (int i = 0; i < 4 * R; ++i) { ag.buf[B_Y][o + i] = y[i]; ag.buf[B_X][o + i] = y[i]; }
+          for (int i = 0; i < 4 * R; ++i) { gp(ag.buf[B_Y])[o + i] = y[i]; gp(ag.buf[B_X])[o + i] = y[i]; }
           if (la_status && !ahead_opt) {
             double rel2 = 0;
 #pragma unroll
             for (int i = 0; i < 4 * R; ++i) { const double d = y[i] - x[i]; rel2 += d * d; }
-            ag.part[PART_D + (lp ? pj1 : pj0)] = rel2;  // look-ahead steps leave |Y' - X|^2 per pose
+            gp(ag.part)[PART_D + (lp ? pj1 : pj0)] = rel2;  // look-ahead steps leave |Y' - X|^2 per pose
           }
         }
       } else {
 #pragma unroll
-        for (int i = 0; i < 4 * R; ++i) { ag.buf[B_X][o + i] = x[i]; if (reset) ag.buf[B_Y][o + i] = x[i]; }
+        for (int i = 0; i < 4 * R; ++i) { gp(ag.buf[B_X])[o + i] = x[i]; if (reset) gp(ag.buf[B_Y])[o + i] = x[i]; }
       }
       if (accel) {
 #pragma unroll
-        for (int i = 0; i < 4 * R; ++i) ag.buf[B_V][o + i] = v[i];
+        for (int i = 0; i < 4 * R; ++i) gp(ag.buf[B_V])[o + i] = v[i];
       }
     }
     if (tid < 64 && want_stats) {  // (mid-run launches leave no statistics: nothing reads them)
       rel = wave_sum(rel);
-      if (tid == 0) ag.part[PART_B + (size_t)bx * PART_STRIDE + 2] = rel;
+      if (tid == 0) gp(ag.part)[PART_B + (size_t)bx * PART_STRIDE + 2] = rel;
     }
     PC_STAMP(7);
     return;
@@ -540,9 +540,9 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *__restrict__ ag
         z[c] = Z[o + c * R + a] + alpha * z[c];         // z_new = z_old + alpha P(Hd M)
       }
       if (MODE == PM_TCG_INIT_) {
-        ag.buf[B_R0][o + c * R + a] = v;
-        ag.buf[B_ETA][o + c * R + a] = 0.0;
-        ag.buf[B_D0][o + c * R + a] = -z[c];
+        gp(ag.buf[B_R0])[o + c * R + a] = v;
+        gp(ag.buf[B_ETA])[o + c * R + a] = 0.0;
+        gp(ag.buf[B_D0])[o + c * R + a] = -z[c];
       }
       Z[o + c * R + a] = z[c];
       zr += z[c] * v;
