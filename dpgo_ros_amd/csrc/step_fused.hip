@@ -481,12 +481,12 @@ __global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ ag
     // (waves 4-7 meet the stream waves' barrier first: neither the bookkeeping nor the carried rows below may hold the
     // product's partial sums back -- workgroup 0, which keeps the books, used to finish 1.6 us behind all the others)
     lds_barrier();  // #4: (the stream waves' partial sums)
-    if (bx == 0 && tid == 256) {
+    if (bx == 0 && tid < 256 + LOOKAHEAD_MAX_AGENTS) {
       // what the bookkeeping workgroup of the next k_eval_stats would do (advance_agent, accelerated): into the OTHER
-      // state buffer -- every workgroup of this launch reads nest_src
-      const int na = team->num_agents;
+      // state buffer -- every workgroup of this launch reads nest_src.  One lane per agent (one round trip for all of them)
+      const int na = team->num_agents, k = tid - 256;
       const double Nr = (double)num_robots;
-      for (int k = 0; k < na; ++k) {
+      if (k < na) {
         NestState s2 = nest_src[k];
         const bool restart = ((s2.iter + 2) % restart_interval) == 0;
         if (restart) { s2.gamma = 0; s2.alpha = 0; }
@@ -497,10 +497,12 @@ __global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ ag
         s2.iter += 1;
         nest_dst[k] = s2;
       }
-      team->iter += 1;
-      team->stats_sel = sel;
-      team->next_sel = next_sel;
-      team->cur_sel = next_sel;
+      if (k == 0) {
+        team->iter += 1;
+        team->stats_sel = sel;
+        team->next_sel = next_sel;
+        team->cur_sel = next_sel;
+      }
     }
     if (flags & FE_CARRY_W) {
       // ---- the row products of the NEXT agent (carried rows): W_p = sum_i X_i Q_ip at the point the next launch will
@@ -520,12 +522,24 @@ __global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ ag
         const int c = e / R, a = e - c * R;
         const int tile = pw >> 6, pl = pw & 63, wdn = agn.soa_w;
         const double *__restrict__ Y2 = agn.buf[B_CARRY_Y];
+        // (all indices, then all operands, then the sums: two round trips for the row instead of two per slot -- this wave
+        // must not be the last one of its workgroup to leave)
+        int ii[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) ii[u] = gp(agn.soa_col)[((size_t)tile * wdn + min(u, wdn - 1)) * 64 + pl];
+        double xv[8][4], bv[8][4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const double *xp = Y2 + (size_t)4 * R * ii[u] + a;
+          const double *bp = agn.soa_val + ((size_t)tile * wdn + min(u, wdn - 1)) * 1024 + (2 * c) * 128 + 2 * pl;
+          xv[u][0] = gp(xp)[0]; xv[u][1] = gp(xp)[R]; xv[u][2] = gp(xp)[2 * R]; xv[u][3] = gp(xp)[3 * R];
+          bv[u][0] = gp(bp)[0]; bv[u][1] = gp(bp)[1]; bv[u][2] = gp(bp)[128]; bv[u][3] = gp(bp)[129];
+        }
         double acc = 0.0;
-        for (int u = 0; u < wdn; ++u) {
-          const int i = agn.soa_col[((size_t)tile * wdn + u) * 64 + pl];
-          const double *xp = Y2 + (size_t)4 * R * i + a;
-          const double *bp = agn.soa_val + ((size_t)tile * wdn + u) * 1024 + (2 * c) * 128 + 2 * pl;
-          acc = fma4(xp[0], bp[0], xp[R], bp[1], xp[2 * R], bp[128], xp[3 * R], bp[129], acc);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const double t = fma4(xv[u][0], bv[u][0], xv[u][1], bv[u][1], xv[u][2], bv[u][2], xv[u][3], bv[u][3], acc);
+          acc = (u < wdn) ? t : acc;
         }
         const double xe_ = Y2[(size_t)4 * R * pw + e];
         const int qi = agn.pub_index[pw];
@@ -547,6 +561,7 @@ __global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ ag
         for (int i = 0; i < 4 * R; ++i) Gn[i] = w[i];
       }
     }
+    FE_STAMP(14);
     FE_FLUSH();
     return;
   }

@@ -10,7 +10,7 @@ prm = capi.default_params(r=5, num_robots=5, **bench.RGD)
 team = capi.Team.from_measurements(mp, prm, device=0)
 team.set_initial(T, Y)
 PART_E = 4 * 32768 * 8
-sname = ["start", "X staged|edges staged", "G done", "tangent done", "gradient in LDS", "product done", "reduced", "qf done", "V polar", "Y polar", "at A", "past A", "slab issued", "trip1 issued", "", "end"]
+sname = ["start", "X staged|edges staged", "G done", "tangent done", "gradient in LDS", "product done", "reduced", "qf done", "V polar", "Y polar", "at A", "past A", "slab issued", "trip1 issued", "rows of the next agent left", "end"]
 gname = sname
 for rep in range(3):
     team.run(56)   # iterations 0 .. 49 are one-launch iterations; the last of them (49) belongs to agent 4
