@@ -531,7 +531,7 @@ def gnc_leg(capi):
 # separate runs of this command, profiles/collect.sh; FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md)
 PMC = {"source": "profiles/r05_pmc_fetch.md, profiles/r05_pmc_write.md",
        "dense": {"step": (16541.5, 851.7), "apply": (16068.2, 85.9),       # k_precond<5,3,2048,false,true,true>, k_precond<5,0,2048,false,false,false>
-                 "fused_step": (17092.5, 1049.1)},                          # k_step_fe<5,0> (carried rows; <5,5>, every workgroup forming the rows: 18168.6, 997.6)
+                 "fused_step": (17108.2, 1049.1)},                          # k_step_fe<5,0> (carried rows; <5,5>, every workgroup forming the rows: 18160.0, 997.6)
        "two_level": {"step": (5469.3, 891.0), "apply": (4937.6, 125.3)}}   # k_precond<5,3,0,true,true,true>, k_precond<5,0,0,true,false,false>
 
 

@@ -34,7 +34,7 @@
 //                   the launch's descriptor) and overwrite their rows of the vector.  ONE round trip in front of the stream
 //                   instead of three; the sparse operator is read once per launch instead of once per workgroup.
 //   Same arithmetic on the same operands in the same order: the iterates are still BITWISE those of the two-launch sequence
-//   (tests/test_gpu_fused_step.py, profiles/experiments/fe_fuzz.py).  19.8 -> 14.6 us per launch on sphere2500 / 5
+//   (tests/test_gpu_fused_step.py, profiles/experiments/fe_fuzz.py).  19.8 -> 14.1 us per launch on sphere2500 / 5
 //   (profiles/r05_carried_rows.md has the phase traces and what each step bought).
 //
 // What was learned building it (profiles/r03_fused_step.md, profiles/r05_carried_rows.md):

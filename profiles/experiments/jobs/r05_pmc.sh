@@ -1,4 +1,4 @@
-ROOT=$(pwd); OUT=$ROOT/gpurun_out/r05; SCR=/tmp/prof_r05; mkdir -p $OUT $SCR
+ROOT=$(pwd); OUT=$ROOT/gpurun_out/r05e; SCR=/tmp/prof_r05e; mkdir -p $OUT $SCR
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   L=$(echo $C | tr A-Z a-z | sed 's/_size//')
