@@ -357,6 +357,17 @@ int finalize_agent(dpgo_team *t, Agent &a, double *scratch) {
   }
   for (int g = 0; g < 5; ++g) a.dev.fe_eptr[g] = pub_ptr[std::min(64 * g, a.npub)];
   a.dev.fe_code_ok = 0;
+  {
+    // order of the 64-row chunks of the dense stream (dpgo_dev.h, fe_ord): private chunks first
+    bool pub_chunk[32];
+    for (int m = 0; m < 32; ++m) pub_chunk[m] = 16 * (m + 1) > n;  // (the chunk that holds the last rows, and every one beyond it)
+    for (int p : pub_pose) if (p / 16 < 32) pub_chunk[p / 16] = true;
+    int q = 0;
+    for (int m = 0; m < 32; ++m) if (!pub_chunk[m]) a.dev.fe_ord[q++] = (unsigned char)m;
+    a.dev.fe_npriv = q;
+    for (int m = 0; m < 32; ++m) if (pub_chunk[m]) a.dev.fe_ord[q++] = (unsigned char)m;
+    if (n > 512) { for (int m = 0; m < 32; ++m) a.dev.fe_ord[m] = (unsigned char)m; a.dev.fe_npriv = 0; }
+  }
   a.se_host = se;  // the neighbour-pose pointers are filled in by sync_descs once every agent's buffers exist
   // edge records for residual / cost evaluation
   std::vector<EdgeDev> edges;

@@ -108,6 +108,7 @@ dpgo_team_t *dpgo_team_create(int device, const dpgo_params_t *p, int num_local,
     if (e5) t->use_fused_eval = (e5[0] == '0') ? 0 : 1;
     if (const char *e6 = std::getenv("DPGO_FE_MIN_N")) t->fe_min_n = std::max(32, std::atoi(e6));
     if (const char *e7 = std::getenv("DPGO_FE_CARRY")) t->use_fe_carry = (e7[0] == '0') ? 0 : 1;
+    if (const char *e8 = std::getenv("DPGO_FE_DEEP")) t->use_fe_deep = (e8[0] == '0') ? 0 : 1;
     if (t->d_nest_all.alloc(3 * std::max(1, num_local)) ||
         hipMemset(t->d_nest_all.p, 0, sizeof(NestState) * 3 * std::max(1, num_local)) != hipSuccess) {
       delete t; set_err("hand-off state allocation failed"); return nullptr;
@@ -1138,6 +1139,54 @@ static bool fused_eval_eligible(dpgo_team_t *t) {
   return true;
 }
 
+// The deep-carried form (step_deep.hip) may serve this team: the private part of every agent's product is formed one launch
+// early, its row products two, its evaluation point three -- so every FOUR consecutive agents of the schedule differ; the
+// first chunks of every agent's order are private (their number, 24 or 20, is returned; 0: not this team); an agent's
+// public poses fit two waves, its shared edges three edge slots of 64, and the partial sums have their buffers.
+static int fe_deep_m0(dpgo_team_t *t) {
+  if (!t->use_fe_deep || !t->use_fe_carry || !fused_eval_eligible(t)) return 0;
+  const int P = (int)t->sched.size();
+  if (P < 4) return 0;
+  for (int q = 0; q < P; ++q)
+    for (int u = 1; u < 4; ++u)
+      if (t->sched[(size_t)q] == t->sched[(size_t)((q + u) % P)]) return 0;
+  int min_priv = 32, nblk_all = 0, total = 0;
+  for (auto &a : t->ag) {
+    if (a->npub < 1 || a->npub > 128 || !a->dev.fe_code_ok || (int)a->se_host.size() > FE_MAX_EDGES) return 0;
+    min_priv = std::min(min_priv, a->dev.fe_npriv);
+    nblk_all = std::max(nblk_all, (4 * a->n + 7) / 8);
+    total += a->n;
+  }
+  for (auto &a : t->ag)
+    if ((total - a->n + nblk_all - 1) / nblk_all > 64) return 0;
+  const int m0 = step_fd_pick_m0(min_priv);
+  if (m0 == 0) return 0;
+  const size_t want = (size_t)2 * nblk_all * t->prm.r * 256;
+  if (t->d_fd_pacc.n < want && t->d_fd_pacc.alloc(want)) return 0;
+  return m0;
+}
+
+// one run of nfe deep-carried one-launch iterations from the state k_nest_pre leaves: the points of the first three agents,
+// two launches that only produce (the row products of sel(0); then its private partial sums and the row products of
+// sel(1)), then the iterations -- each consuming what the three launches before it left
+static void enqueue_fe_deep(dpgo_team_t *t, const LaunchCtx &c, int m0, int nfe, const std::function<int(int)> &sel_at,
+                            NestState *nest_own, NestState *const nest_fe[2]) {
+  const dpgo_params_t &p = t->prm;
+  int nblk_all = 0;
+  for (auto &a : t->ag) nblk_all = std::max(nblk_all, (4 * a->n + 7) / 8);
+  double *pacc[2] = {t->d_fd_pacc.p, t->d_fd_pacc.p + (size_t)nblk_all * p.r * 256};
+  const int s0 = sel_at(0), s1 = sel_at(1), s2 = sel_at(2);
+  launch_fd_prime(c, s0, s1, s2, t->max_n, p.num_robots, p.restart_interval, nest_own);
+  launch_step_fd(c, m0, s0, s0, s0, s0, p.rgd_stepsize, p.num_robots, p.restart_interval, nest_own, nest_fe[1], 0, FD_W, pacc[0], pacc[1]);
+  launch_step_fd(c, m0, s0, s0, s1, s0, p.rgd_stepsize, p.num_robots, p.restart_interval, nest_own, nest_fe[1], 0, FD_P | FD_W, pacc[1], pacc[0]);
+  for (int rep = 0; rep < nfe; ++rep) {
+    const int flags = FD_IN | (rep + 1 < nfe ? FD_P : 0) | (rep + 2 < nfe ? FD_W : 0) | (rep + 3 < nfe ? FD_Y : 0);
+    launch_step_fd(c, m0, sel_at(rep), sel_at(rep + 1), sel_at(rep + 2), sel_at(rep + 3), p.rgd_stepsize, p.num_robots,
+                   p.restart_interval, rep == 0 ? nest_own : nest_fe[rep & 1], nest_fe[(rep + 1) & 1], rep & 1, flags,
+                   pacc[rep & 1], pacc[(rep + 1) & 1]);
+  }
+}
+
 static int team_run_impl(dpgo_team_t *t, int iters, bool prepare_only) {
   if (sync_descs(t)) return DPGO_ERR;
   const dpgo_params_t &p = t->prm;
@@ -1178,6 +1227,7 @@ static int team_run_impl(dpgo_team_t *t, int iters, bool prepare_only) {
   // the schedule and the descriptors baked in.  Their launches alternate between the two copies of the poses (parity),
   // so they need neither each other's company on the device nor its lock
   const bool fe_ok = pipelined && graphable && fused_eval_eligible(t);
+  const int fd_m0 = fe_ok ? fe_deep_m0(t) : 0;  // > 0: runs of one-launch iterations take the deep-carried form (step_deep.hip)
   auto graph_for = [&](bool lead, int B, int iter0, bool fe, hipGraphExec_t *out) -> int {
     const int phase = bake ? iter0 % P : -1;
     const int base = ((((lead ? 1 : 0) + 2 * B) * 16 + phase + 1) * 2 + (fe ? 1 : 0)) * 2;
@@ -1205,7 +1255,9 @@ static int team_run_impl(dpgo_team_t *t, int iters, bool prepare_only) {
       // so that the poses end in the primary arrays
       const int nfe = fe ? (std::max(0, B - L - 1) & ~1) : 0;
       NestState *nest_own = t->d_nest_all.p, *nest_fe[2] = {t->d_nest_all.p + na, t->d_nest_all.p + 2 * na};
-      for (int rep = 0; rep < B; ++rep) {
+      const bool deep = fd_m0 > 0 && nfe >= 4;
+      if (deep) enqueue_fe_deep(t, c, fd_m0, nfe, sel_at, nest_own, nest_fe);
+      for (int rep = deep ? nfe : 0; rep < B; ++rep) {
         const int ahead = (rep + 1 < B ? 3 : 0) | ((rep + 1 < B && rep + 1 >= B - L) ? 4 : 0) | (rep >= B - L ? 8 : 0);
         if (rep < nfe) {
           launch_step_fe(c, sel_at(rep), sel_at(rep + 1), p.rgd_stepsize, p.num_robots, p.restart_interval,
@@ -1290,6 +1342,8 @@ static int team_run_impl(dpgo_team_t *t, int iters, bool prepare_only) {
       {
         const int P_ = (int)t->sched.size(), it0 = t->iter;
         const std::function<int(int)> sel_run = [&](int rep) { return t->sched[(size_t)((it0 + rep) % P_)]; };
+        if (fd_m0 > 0 && nfe_run >= 4) { t->counters[8] += nfe_run; t->counters[9] += nfe_run; }  // ... deep-carried: every one of them
+        else
         for (int q = 0; q < nfe_run; ++q) t->counters[8] += (fe_carry_flags(t, q, nfe_run, sel_run) & FE_CARRY_IN) ? 1 : 0;  // ... with carried rows
       }
       // after >= 2 pipelined iterations every agent took its last Nesterov step as a look-ahead (per-pose partials)
@@ -2015,6 +2069,24 @@ int dpgo_team_time_kernel(dpgo_team_t *t, int id, int which, int reps, double *a
     launch_nest_pre(cc, -1, -1, na, mn, p.num_robots, p.restart_interval, 1);
     const int total_reps = ((reps + 1) & ~1) + 8;  // (even: the poses end in the primary arrays)
     reps = total_reps - 8;
+    const int fd_m0 = fe_deep_m0(t);
+    if (fd_m0 > 0) {
+      // the deep-carried form (step_deep.hip), as a run's graph enqueues it
+      int nblk_all = 0;
+      for (auto &b : t->ag) nblk_all = std::max(nblk_all, (4 * b->n + 7) / 8);
+      double *pacc[2] = {t->d_fd_pacc.p, t->d_fd_pacc.p + (size_t)nblk_all * p.r * 256};
+      const int s0 = sel_at(0), s1 = sel_at(1), s2 = sel_at(2);
+      launch_fd_prime(cc, s0, s1, s2, mn, p.num_robots, p.restart_interval, nest_own);
+      launch_step_fd(cc, fd_m0, s0, s0, s0, s0, p.rgd_stepsize, p.num_robots, p.restart_interval, nest_own, nest_fe[1], 0, FD_W, pacc[0], pacc[1]);
+      launch_step_fd(cc, fd_m0, s0, s0, s1, s0, p.rgd_stepsize, p.num_robots, p.restart_interval, nest_own, nest_fe[1], 0, FD_P | FD_W, pacc[1], pacc[0]);
+      for (int k = 0; k < total_reps; ++k) {
+        if (k == 8) HIPC(hipEventRecord(e0, t->stream));
+        const int flags = FD_IN | (k + 1 < total_reps ? FD_P : 0) | (k + 2 < total_reps ? FD_W : 0) | (k + 3 < total_reps ? FD_Y : 0);
+        launch_step_fd(cc, fd_m0, sel_at(k), sel_at(k + 1), sel_at(k + 2), sel_at(k + 3), p.rgd_stepsize, p.num_robots,
+                       p.restart_interval, k == 0 ? nest_own : nest_fe[k & 1], nest_fe[(k + 1) & 1], k & 1, flags,
+                       pacc[k & 1], pacc[(k + 1) & 1]);
+      }
+    } else
     for (int k = 0; k < total_reps; ++k) {
       if (k == 8) HIPC(hipEventRecord(e0, t->stream));
       launch_step_fe(cc, sel_at(k), sel_at(k + 1), p.rgd_stepsize, p.num_robots, p.restart_interval,

@@ -112,6 +112,12 @@ struct AgentDev {
   unsigned fe_code[FE_MAX_EDGES / 2];  // where the neighbour pose of shared edge e lives, 16 bits each (two per word): frame |
                               // local agent << 12 (teams whose neighbours are all co-resident, <= 160 edges: fe_code_ok) -- the
                               // carried one-launch iteration turns it into an address without a descriptor round trip
+  unsigned char fe_ord[32];   // dense agents of <= 512 poses (one 2048-row pass of the stream): the order in which the 64-row
+                              // chunks (16 poses each) of a column of M meet the vector -- chunks whose poses are all PRIVATE
+                              // (no shared edge) first, the others behind them, each group ascending.  Every kernel that
+                              // streams such an agent's M follows it (k_precond, k_step_fe), so their sums stay bitwise
+                              // equal; the deep-carried one-launch iteration forms the private part one launch early
+  int fe_npriv, fe_pad_;      // how many leading entries of fe_ord are private chunks
   const double *M;            // dense (Q + shift I)^-1, N4 x N4 column-major (symmetric); null: block-Jacobi agent
   const double *Dinv;         // block-Jacobi agents: the inverted 4 x 4 diagonal blocks of Q + shift I, [n][16] column-major
   TLDev tl;                   // two-level agents (tl.nwg > 0; M and Dinv null)
@@ -148,6 +154,24 @@ constexpr int LOOKAHEAD_MAX_AGENTS = 8;  // look-ahead Nesterov steps locate a p
 struct FeBases {
   const double *ybase[LOOKAHEAD_MAX_AGENTS];
   int npose[LOOKAHEAD_MAX_AGENTS];
+};
+
+// deep-carried one-launch iteration (step_deep.hip): what a launch needs of the agents one and two iterations ahead (by value)
+constexpr int FD_IN = 1, FD_P = 2, FD_W = 4, FD_Y = 8;
+struct FdNext {
+  // d = the agent of the next iteration: the private part of its product is formed here
+  const double *Md;            // its dense inverse
+  const double *Gd;            // its B_CARRY_G (chunk-ordered)
+  int N4d, nblk_d;
+  unsigned char ord_d[32];     // its chunk order (AgentDev::fe_ord)
+  // e = the agent two iterations ahead: its row products are formed here
+  int n_e, soa_w_e, npub_e, pad_;
+  const int *soa_col_e;
+  const double *soa_val_e;
+  const int *pub_index_e;
+  const double *Ye;            // B_CARRY_Y: its evaluation point, [pose][4r]
+  double *We, *Xe, *Ge;        // B_CARRY_W / B_CARRY_X ([entry][public pose]) and B_CARRY_G (chunk-ordered [place][16 poses][4r])
+  unsigned char ord_e[32];
 };
 
 struct TeamDev {

@@ -65,6 +65,14 @@ int step_fe_max_edges();
 void launch_step_fe(const LaunchCtx &c, int sel, int next_sel, double step, int num_robots, int restart_interval,
                     const NestState *nest_src, NestState *nest_dst, int parity, int next2_sel = -1, int carry = 0);
 int step_fe_carry_max_poses();
+// step_deep.hip: the one-launch iteration with the private part of the product formed one launch early (flags FD_*:
+// dpgo_dev.h).  m0: leading chunks of every agent's order that are private (step_fd_pick_m0 of the team's minimum; 0: the
+// team cannot run it).  pacc_in / pacc_out: the partial sums this launch continues / leaves, [workgroup][r][256]
+int step_fd_pick_m0(int min_private_chunks);
+void launch_fd_prime(const LaunchCtx &c, int s0, int s1, int s2, int max_n, int num_robots, int restart_interval, const NestState *nest_src);
+void launch_step_fd(const LaunchCtx &c, int m0, int sel, int next_sel, int next2_sel, int next3_sel, double step, int num_robots,
+                    int restart_interval, const NestState *nest_src, NestState *nest_dst, int parity, int flags,
+                    const double *pacc_in, double *pacc_out);
 constexpr int LS_MAX_TRIALS = 8;
 void launch_ls_trials(const LaunchCtx &c, int sel, int max_n, int dirb, double step0, double shrink, int ntrials);
 void launch_ls_cost(const LaunchCtx &c, int sel, int max_n, int dirb, int ntrials);

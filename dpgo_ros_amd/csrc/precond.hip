@@ -57,6 +57,15 @@ namespace dpgo {
 // BAKED: the agent's descriptor arrives by value with the launch (pick_agent, kernel_common.h)
 // LEAN: a mid-run step of the pipelined sequence (accelerated, advance = 2, ahead = 3: nothing a status query reads is
 // left behind) -- the flags become compile-time constants and the tail loses its statistics paths
+// the m-th 64-row chunk of a column of M a lane takes: agents of <= 512 poses (one 2048-row pass) follow the agent's
+// chunk order -- private chunks first (dpgo_dev.h, fe_ord; uniform: scalar loads) --, which keeps this kernel's sums
+// bitwise those of the one-launch iteration that forms the private part a launch early (step_fused.hip)
+template <int KC>
+__device__ __forceinline__ int chunk_of(const AgentDev &ag, int m) {
+  if constexpr (KC == 2048) return (int)ag.fe_ord[m];
+  else return m;
+}
+
 template <int R, int MODE, int KC, bool TLC, bool BAKED, bool LEAN = false>
 __global__ __launch_bounds__(256) void k_precond(const AgentDev *__restrict__ agents, TeamDev *team, int sel, int xb, int vb,
                                                  int zb, int sp, int max_inner, double step, int accel,
@@ -289,7 +298,7 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *__restrict__ ag
     double2 mreg[MREG];
 #pragma unroll
     for (int m = 0; m < MPRE; ++m) {
-      const int k = 2 * kl + 64 * m;
+      const int k = 2 * kl + 64 * chunk_of<KC>(ag, m);
       // (an unconditional load from a clamped address: a load under a lane-varying condition is a branch of its own, and
       // behind 32 of them the compiler waits for the whole slab before the first multiply -- round 5, read off the ISA.
       // Rows beyond the chunk meet zeros of the staged vector; columns beyond the last pose feed sums nobody reads.)
@@ -313,13 +322,13 @@ __global__ __launch_bounds__(256) void k_precond(const AgentDev *__restrict__ ag
     PC_STAMP(2);
 #pragma unroll
     for (int m = MPRE; m < MREG; ++m) {
-      const int k = 2 * kl + 64 * m;
+      const int k = 2 * kl + 64 * chunk_of<KC>(ag, m);
       mreg[m] = ld2g_nt(Mc + min(k0 + k, N4 - 2));
     }
     PC_STAMP(3);
 #pragma unroll
     for (int m = 0; m < MREG; ++m) {
-      const int k = 2 * kl + 64 * m;
+      const int k = 2 * kl + 64 * chunk_of<KC>(ag, m);
       double w[2 * R];
 #pragma unroll
       for (int j = 0; j < R; ++j) {

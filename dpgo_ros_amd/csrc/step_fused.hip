@@ -211,7 +211,7 @@ __global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ ag
     if (cwv < 4) {
       for (int t = N4 * R + tid; t < KC * R; t += 256) vs[t] = 0.0;  // rows of the vector beyond the agent's
 #pragma unroll
-      for (int m = 0; m < FE_HEAD; ++m) mreg[m] = ld2_nt(Mc + min(2 * kl + 64 * m, N4 - 2));
+      for (int m = 0; m < FE_HEAD; ++m) mreg[m] = ld2_nt(Mc + min(2 * kl + 64 * (int)ag.fe_ord[m], N4 - 2));
       constexpr int NG = (KC * R / 2 + 255) / 256;
       double2 gv[NG];
       {
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ ag
       lds_barrier();  // A
       FE_STAMP(11);
 #pragma unroll
-      for (int m = FE_HEAD; m < MREG; ++m) mreg[m] = ld2_nt(Mc + min(2 * kl + 64 * m, N4 - 2));
+      for (int m = FE_HEAD; m < MREG; ++m) mreg[m] = ld2_nt(Mc + min(2 * kl + 64 * (int)ag.fe_ord[m], N4 - 2));
       FE_STAMP(12);
 #pragma unroll
       for (int u = 0; u < NG; ++u) {
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ ag
       constexpr int PART = MREG / FE_PARTS;
       const int part = u - (WD - FE_PARTS);  // 0 .. FE_PARTS - 1
 #pragma unroll
-      for (int m = part * PART; m < (part + 1) * PART; ++m) mreg[m] = ld2_nt(Mc + min(kslab + kstep * m, N4 - 2));
+      for (int m = part * PART; m < (part + 1) * PART; ++m) mreg[m] = ld2_nt(Mc + min(kslab + kstep * (int)ag.fe_ord[m], N4 - 2));
     }
     if (u == 1) lds_barrier();  // #1a: the edge operands are in LDS
     __builtin_amdgcn_sched_barrier(0);
@@ -583,7 +583,7 @@ __global__ __launch_bounds__(512) void k_step_fe(const AgentDev *__restrict__ ag
   for (int a = 0; a < R; ++a) acc[a] = 0;
 #pragma unroll
   for (int m = 0; m < MREG; ++m) {
-    const int k = 2 * kl + 64 * m;
+    const int k = 2 * kl + 64 * (int)ag.fe_ord[m];  // (the agent's chunk order, as k_precond)
     double wv[2 * R];
 #pragma unroll
     for (int q = 0; q < R; ++q) {

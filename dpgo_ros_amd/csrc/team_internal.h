@@ -253,6 +253,8 @@ struct dpgo_team {
   // [0, num_local), the two alternating buffers of the fused launches behind it
   int use_fused_eval = 1;  // DPGO_FUSED_EVAL=0: every pipelined iteration takes the two-launch sequence
   int use_fe_carry = 1;    // DPGO_FE_CARRY=0: every one-launch iteration forms the row products of its agent itself (no carried rows)
+  int use_fe_deep = 1;     // DPGO_FE_DEEP=0: no deep-carried one-launch iterations (step_deep.hip): k_step_fe serves every run
+  dpgo_host::DevBuf<double> d_fd_pacc;  // their partial sums: two alternating buffers of [workgroup][r][256] doubles
   int fe_min_n = 0;        // smallest agent the one-launch iteration serves (DPGO_FE_MIN_N; any n >= 32 works, bitwise).  0 = by
                            // measurement: 32 where every iteration finds carried rows (round 5), else 449 -- without carried rows:
                            // measured per iteration, two-launch | one-launch (profiles/experiments/fe_small.py, sphere2500, r = 5):

@@ -1,0 +1,4 @@
+#!/bin/bash
+OUT=gpurun_out/r06b; mkdir -p $OUT
+timeout 300 python profiles/experiments/fd_check.py 5 5 > $OUT/fd_5_5.log 2>&1; tail -9 $OUT/fd_5_5.log
+DPGO_HIP_LIB=profiles/experiments/build/fd/libdpgo_hip.so timeout 300 python profiles/experiments/fd_trace.py > $OUT/fd_trace.log 2>&1; tail -9 $OUT/fd_trace.log
