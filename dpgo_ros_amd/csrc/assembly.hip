@@ -695,6 +695,12 @@ int sync_descs_noflush(dpgo_team *t) {
     }
     if (a->d_se.upload(a->se_host, t->stream)) { set_err("shared-edge upload failed"); return DPGO_ERR; }
     a->dev.se = a->d_se.p;
+    {
+      std::vector<double> packed(16 * a->se_host.size());
+      for (size_t e = 0; e < a->se_host.size(); ++e) std::memcpy(&packed[16 * e], a->se_host[e].coef, 16 * sizeof(double));
+      if (a->d_fe_coef.upload(packed, t->stream)) { set_err("shared-edge upload failed"); return DPGO_ERR; }
+      a->dev.fe_coef = a->d_fe_coef.p;
+    }
     // (carried one-launch iteration: the same pointers as 16-bit codes in the descriptor)
     a->dev.fe_code_ok = (int)a->se_host.size() <= FE_MAX_EDGES && !t->isolated;
     for (int q = 0; q < FE_MAX_EDGES / 2; ++q) a->dev.fe_code[q] = 0;

@@ -124,6 +124,7 @@ struct AgentDev {
   const int *pub_pose;        // [npub] local poses that own >= 1 shared edge
   const int *pub_ptr;         // [npub+1] CSR into se
   const SharedEdgeDev *se;    // [nshared] sorted by lpose
+  const double *fe_coef;      // [nshared][16]: their coefficients, packed
   const EdgeDev *edges;       // [nedges] all measurements of this agent
   double *nbr[2];             // neighbour pose slabs (0 main, 1 auxiliary), [nnp][4r]
   double *buf[NBUF];

@@ -28,11 +28,20 @@
 // (gradient of the public poses -> product over the last chunks -> tail) must not meet the streamers again.  So only
 // barrier A is an s_barrier (it orders the requests: everything the chain needs is in the CU's memory queue in front of
 // the stream); every later hand-off is a counter in LDS that only the waves concerned wait at:
-//     waves 0-3  streamers: carried gradient of c's last chunks -> LDS (C); then the whole P part on their own
-//     waves 4-5  the chain: one public pose per lane (G_j from LDS, projection) (D) -> product over the last chunks, two
-//                columns per lane (F) -> wave 4: reduction, step of the two poses on 16 lanes each (as k_step_fe)
-//     wave 6     operands of the shared edges -> LDS (E); W; the books
-//     wave 7     operands of the shared edges -> LDS (E); look-ahead of the other agents' poses + Y
+//     waves 0-3  streamers: the carried gradient of c's last chunks -> LDS (C); then the whole P part on their own (N: their
+//                own hand-off; they start their product behind F, the chain's -- the two share the LDS)
+//     waves 4-5  the chain: one public pose per lane (G_j from LDS, projection; rows -> LDS: D) -> their quarters of the
+//                product over the last chunks (F) -> wave 4: reduction, step of the two poses on 16 lanes each (as
+//                k_step_fe); wave 5: W
+//     wave 6     neighbour poses of the shared edges -> LDS (E); its quarter of the product behind D (F); the books
+//     wave 7     coefficients of the shared edges -> LDS (E); its quarter of the product (F); look-ahead of the other
+//                agents' poses + Y
+//   Waves 4-7 run at raised priority while they are on the chain.
+// Where a launch's 12.5 us go (profiles/r06_deep_carry.md): 2.8 until everything is requested (134 KB per CU in front of
+// barrier A -- every workgroup finishes ALL public poses itself, the price of no exchange inside the launch), 1.0 until the
+// edges' operands have landed, 1.9 gradient of the public poses, 0.9 product over the last chunks, 0.5 reduction, 3.2 tail,
+// 2.2 from the last workgroup's end to the next launch's first instruction.  The stream (128 KB per CU) lands under all
+// of it: the streamers are done 3 us before the tail.
 // Same arithmetic on the same operands in the same order as k_step_fe / the two-launch sequence: the iterates are BITWISE
 // theirs (tests/test_gpu_fused_step.py, profiles/experiments/fe_fuzz.py).
 #include "kernel_common.h"
@@ -59,6 +68,9 @@ namespace dpgo {
 constexpr int FD_KC = 2048;
 #ifndef DPGO_FD_HEAD
 #define DPGO_FD_HEAD 0
+#endif
+#ifndef DPGO_FD_GC_LATE
+#define DPGO_FD_GC_LATE 0
 #endif
 constexpr int FD_HEAD = DPGO_FD_HEAD;  // 16-byte loads per lane of the NEXT agent's private chunks requested in front of barrier A
 
@@ -87,30 +99,34 @@ __device__ __forceinline__ int fd_pos_off(const unsigned char *ord, int pose) {
   return p * 64 * R + (pose & 15) * 4 * R;
 }
 
-// the operands of NQ shared edges per lane (edge slots base + ln, base + 128 + ln): the neighbour pose from its 16-bit
-// code in the descriptor (no descriptor round trip), the 16 coefficients.  Wave 6 takes edges 0 .. 63 and 128 .. 191 (two
-// per lane; few agents have that many), wave 7 edges 64 .. 127 (one per lane: it also carries the look-ahead operands)
-template <int R, int NQ>
-struct FdEdgeRegs {
-  double2 cf[NQ][8], xe[NQ][2 * R];
+// The operands of the shared edges go to LDS, [edge][neighbour pose 4r | 16 coefficients].
+//   * wave 6, neighbour poses: one lane per edge (edges l, 64 + l, 128 + l), 2r loads of 16 bytes each.  Where the neighbour
+//     lives comes from the edge's 16-bit code (frame | agent << 12) in the descriptor -- scalar registers and a select
+//     chain, no descriptor round trip (k_step_fe).  (Measured and dropped, round 6: 64 consecutive 16-byte parts per load --
+//     a quarter of the cache-line requests -- with the address handed from the edge's lane by ds_bpermute: the wave reached
+//     barrier A 1.5 us LATER; and with the codes looked up per part: scalar loads inside every trip, 4 us later.)
+//   * wave 7, coefficients: the packed copy [edge][16] (AgentDev::fe_coef) read straight through, 1 KB per load -- 100
+//     cache-line requests where one lane per edge asked for 800 (the kernel's first microseconds are a count of such
+//     requests: ~4400 per CU in front of barrier A, and a CU's texture path takes about one a cycle).
+template <int R>
+struct FdXn {
+  double2 v[3][2 * R];
 };
 
-template <int R, int NQ>
-__device__ __forceinline__ void fd_edges_request(const AgentDev &ag, const FeBases &fb, int parity, int base, int ln, FdEdgeRegs<R, NQ> &er) {
+template <int R>
+__device__ __forceinline__ void fd_xn_request(const AgentDev &ag, const FeBases &fb, int parity, int ln, FdXn<R> &xr) {
   const int nsh = ag.nshared;
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    const int e0 = base + 128 * q;
-    if (e0 < nsh) {  // (uniform)
-      const int ei = min(e0 + ln, nsh - 1);
-      const int wbase = e0 >> 1, wrel = (ei >> 1) - wbase;  // 0 .. 31
+  for (int q = 0; q < 3; ++q) {
+    if (64 * q < nsh) {  // (uniform)
       unsigned wsel = 0;
 #pragma unroll
       for (int k = 0; k < 32; ++k) {
-        const unsigned wk = ag.fe_code[min(wbase + k, FE_MAX_EDGES / 2 - 1)];
-        wsel = (wrel == k) ? wk : wsel;
+        const unsigned wk = ag.fe_code[(32 * q + k < FE_MAX_EDGES / 2) ? 32 * q + k : FE_MAX_EDGES / 2 - 1];
+        wsel = ((ln >> 1) == k) ? wk : wsel;
       }
-      const unsigned code = (ei & 1) ? (wsel >> 16) : (wsel & 0xffffu);
+      // (lanes beyond the last edge read the pose of an edge that exists: words beyond the last edge hold zeros = agent 0, frame 0)
+      const unsigned code = (ln & 1) ? (wsel >> 16) : (wsel & 0xffffu);
       const int sa = (int)(code >> 12), sf = (int)(code & 0xfffu);
       const double *yb = fb.ybase[0];
       int yn = fb.npose[0];
@@ -118,28 +134,45 @@ __device__ __forceinline__ void fd_edges_request(const AgentDev &ag, const FeBas
       for (int k = 1; k < LOOKAHEAD_MAX_AGENTS; ++k) { yb = (sa == k) ? fb.ybase[k] : yb; yn = (sa == k) ? fb.npose[k] : yn; }
       const double *xp = yb + (parity ? (size_t)B_ALT * 4 * R * yn : (size_t)0) + (size_t)sf * 4 * R;
 #pragma unroll
-      for (int k = 0; k < 2 * R; ++k) er.xe[q][k] = ld2(xp + 2 * k);
-      const double *cp_ = ag.se[ei].coef;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) er.cf[q][k] = ld2(cp_ + 2 * k);
+      for (int k = 0; k < 2 * R; ++k) xr.v[q][k] = ld2(xp + 2 * k);
     }
   }
 }
 
-template <int R, int NQ>
-__device__ __forceinline__ void fd_edges_to_lds(const AgentDev &ag, int base, int ln, const FdEdgeRegs<R, NQ> &er, double *Es) {
+template <int R>
+__device__ __forceinline__ void fd_xn_to_lds(const AgentDev &ag, int ln, const FdXn<R> &xr, double *Es) {
   constexpr int EPE = 4 * R + 16;
   const int nsh = ag.nshared;
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    const int e0 = base + 128 * q;
-    if (e0 < nsh && e0 + ln < nsh) {
-      double *E = Es + (size_t)(e0 + ln) * EPE;
+  for (int q = 0; q < 3; ++q) {
+    if (64 * q < nsh && 64 * q + ln < nsh) {
+      double *E = Es + (size_t)(64 * q + ln) * EPE;
 #pragma unroll
-      for (int k = 0; k < 2 * R; ++k) *reinterpret_cast<double2 *>(E + 2 * k) = er.xe[q][k];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) *reinterpret_cast<double2 *>(E + 4 * R + 2 * k) = er.cf[q][k];
+      for (int k = 0; k < 2 * R; ++k) *reinterpret_cast<double2 *>(E + 2 * k) = xr.v[q][k];
     }
+  }
+}
+
+struct FdCf {
+  static constexpr int TRIPS = FE_MAX_EDGES * 8 / 64;
+  double2 v[TRIPS];
+};
+
+__device__ __forceinline__ void fd_cf_request(const AgentDev &ag, int ln, FdCf &cr) {
+  const int nit = ag.nshared * 8;
+#pragma unroll
+  for (int j = 0; j < FdCf::TRIPS; ++j)
+    if (64 * j < nit) cr.v[j] = ld2(ag.fe_coef + 2 * min(64 * j + ln, nit - 1));
+}
+
+template <int R>
+__device__ __forceinline__ void fd_cf_to_lds(const AgentDev &ag, int ln, const FdCf &cr, double *Es) {
+  constexpr int EPE = 4 * R + 16;
+  const int nit = ag.nshared * 8;
+#pragma unroll
+  for (int j = 0; j < FdCf::TRIPS; ++j) {
+    const int t = 64 * j + ln;
+    if (64 * j < nit && t < nit) *reinterpret_cast<double2 *>(Es + (size_t)(t >> 3) * EPE + 4 * R + 2 * (t & 7)) = cr.v[j];
   }
 }
 
@@ -258,11 +291,13 @@ __global__ __launch_bounds__(512) void k_step_fd(TeamDev *team, int sel, int nex
     // the rows of this agent's carried gradient that the last NC chunks meet: positions [M0 * 64 R, N4 R)
     constexpr int NGC = ((KC - 64 * M0) * R / 2 + 255) / 256;
     double2 gc[NGC];
+#if !DPGO_FD_GC_LATE
     {
       const double *Gc = ag.buf[B_CARRY_G];
 #pragma unroll
       for (int u = 0; u < NGC; ++u) gc[u] = ld2(Gc + min(M0 * 64 * R + 2 * (tid + 256 * u), N4 * R - 2));
     }
+#endif
     const int cold = 8 * bx + cg;
     const int N4d = nx.N4d;
     const double *Md = nx.Md + (size_t)((cold < N4d) ? cold : 0) * N4d;
@@ -273,6 +308,13 @@ __global__ __launch_bounds__(512) void k_step_fd(TeamDev *team, int sel, int nex
     lds_barrier();  // A
     FD_STAMP(11);
     __builtin_amdgcn_sched_barrier(0);
+#if DPGO_FD_GC_LATE
+    {
+      const double *Gc = ag.buf[B_CARRY_G];
+#pragma unroll
+      for (int u = 0; u < NGC; ++u) gc[u] = ld2(Gc + min(M0 * 64 * R + 2 * (tid + 256 * u), N4 * R - 2));
+    }
+#endif
 #pragma unroll
     for (int u = 0; u < NGC; ++u) {
       const int tt = M0 * 64 * R + 2 * (tid + 256 * u);
@@ -530,15 +572,15 @@ __global__ __launch_bounds__(512) void k_step_fd(TeamDev *team, int sel, int nex
   // then the row products of the agent two iterations ahead (6) / the look-ahead of the other agents' poses (7)
   const int h = cwv - 6;
   if (h == 0) {
-    FdEdgeRegs<R, 2> er;
-    fd_edges_request<R, 2>(ag, fb, parity, 0, ln, er);
+    FdXn<R> er;
+    fd_xn_request<R>(ag, fb, parity, ln, er);
     FdCur<R, NC> cu;
     fd_cur_request<R, M0, NC>(ag, pacc_in, bx, nblk, tid - 256, cu);
     FD_STAMP(10);
     lds_barrier();  // A
     FD_STAMP(11);
     __builtin_amdgcn_s_setprio(3);
-    fd_edges_to_lds<R, 2>(ag, 0, ln, er, Es);
+    fd_xn_to_lds<R>(ag, ln, er, Es);
     fd_signal(&sy[FD_SY_E]);
     fd_wait(&sy[FD_SY_D], 2);  // this wave's quarter of the product over the last chunks
     fd_cur_product<R, M0, NC>(cu, vs, red, tid - 256);
@@ -573,8 +615,8 @@ __global__ __launch_bounds__(512) void k_step_fd(TeamDev *team, int sel, int nex
   // ---- wave 7: look-ahead Nesterov step of iteration k+1 for this workgroup's share of the OTHER agents' poses (one lane
   // per pose, k_step_fe's second wave), every address from the launch's arguments
   {
-    FdEdgeRegs<R, 1> er;
-    fd_edges_request<R, 1>(ag, fb, parity, 64, ln, er);
+    FdCf er;
+    fd_cf_request(ag, ln, er);
     FdCur<R, NC> cu;
     fd_cur_request<R, M0, NC>(ag, pacc_in, bx, nblk, tid - 256, cu);
     int pre[LOOKAHEAD_MAX_AGENTS + 1];
@@ -606,13 +648,16 @@ __global__ __launch_bounds__(512) void k_step_fd(TeamDev *team, int sel, int nex
     const size_t o = (size_t)la_pose * 4 * R;
     double la_x[4 * R], la_v[4 * R];
 #pragma unroll
-    for (int i = 0; i < 4 * R; ++i) { la_x[i] = gp(xr)[o + i]; la_v[i] = gp(va)[o + i]; }
+    for (int i = 0; i < 2 * R; ++i) {
+      const double2 tx = ld2(xr + o + 2 * i), tv = ld2(va + o + 2 * i);
+      la_x[2 * i] = tx.x; la_x[2 * i + 1] = tx.y; la_v[2 * i] = tv.x; la_v[2 * i + 1] = tv.y;
+    }
     const NestState ns = nest_src[sel];
     FD_STAMP(10);
     lds_barrier();  // A
     FD_STAMP(11);
     __builtin_amdgcn_s_setprio(3);
-    fd_edges_to_lds<R, 1>(ag, 64, ln, er, Es);
+    fd_cf_to_lds<R>(ag, ln, er, Es);
     fd_signal(&sy[FD_SY_E]);
     fd_wait(&sy[FD_SY_D], 2);  // this wave's quarter of the product over the last chunks
     fd_cur_product<R, M0, NC>(cu, vs, red, tid - 256);

@@ -192,6 +192,7 @@ struct Agent {
   bool opt_success = false, opt_cached = false;
   double opt_ratio = 1.0, opt_rel_change = 0.0;
   DevBuf<SharedEdgeDev> d_se;
+  DevBuf<double> d_fe_coef;  // the coefficients of the shared edges once more, packed [edge][16] (step_deep.hip reads them with whole-line loads)
   std::vector<SharedEdgeDev> se_host;
   DevBuf<int> d_pose_eptr;
   DevBuf<EdgeDev> d_edges;

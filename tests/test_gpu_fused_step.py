@@ -16,10 +16,13 @@ pytestmark = pytest.mark.gpu
 RGD = dict(method=1, acceleration=1, rgd_stepsize=0.2, rgd_use_preconditioner=1, restart_interval=20)
 
 
-def _team(dataset, robots, fused, r=5, **kw):
+def _team(dataset, robots, fused, r=5, deep=True, **kw):
     old = os.environ.get("DPGO_FUSED_EVAL")
     old_min = os.environ.get("DPGO_FE_MIN_N")
+    old_deep = os.environ.get("DPGO_FE_DEEP")
     os.environ["DPGO_FUSED_EVAL"] = "1" if fused else "0"
+    # round 6: runs over >= 4 robots take the deep-carried form (csrc/step_deep.hip) unless DPGO_FE_DEEP=0
+    os.environ["DPGO_FE_DEEP"] = "1" if deep else "0"
     # the one-launch form serves agents of 449 .. 512 poses by default (where it is faster); the tests run it on every
     # size it can serve
     os.environ["DPGO_FE_MIN_N"] = "32"
@@ -37,14 +40,20 @@ def _team(dataset, robots, fused, r=5, **kw):
             os.environ.pop("DPGO_FE_MIN_N", None)
         else:
             os.environ["DPGO_FE_MIN_N"] = old_min
+        if old_deep is None:
+            os.environ.pop("DPGO_FE_DEEP", None)
+        else:
+            os.environ["DPGO_FE_DEEP"] = old_deep
     return t
 
 
+@pytest.mark.parametrize("deep", [True, False])
 @pytest.mark.parametrize("robots,r", [(5, 5), (8, 5), (5, 3), (6, 4)])
-def test_one_launch_iterations_bitwise_equal_the_two_launch_sequence(robots, r):
+def test_one_launch_iterations_bitwise_equal_the_two_launch_sequence(robots, r, deep):
     """sphere2500 over 5 / 6 / 8 robots (500 / 416 / 312 poses), runs of several lengths: whole graphs of 256 iterations,
-    short graphs, restarts (every 20 iterations) inside and at the edges of the one-launch part"""
-    ta, tb = _team("sphere2500", robots, False, r=r, **RGD), _team("sphere2500", robots, True, r=r, **RGD)
+    short graphs, restarts (every 20 iterations) inside and at the edges of the one-launch part.  deep: the deep-carried
+    form of round 6 (k_step_fd: the private part of the product formed one launch early); otherwise round 5's k_step_fe"""
+    ta, tb = _team("sphere2500", robots, False, r=r, **RGD), _team("sphere2500", robots, True, r=r, deep=deep, **RGD)
     for iters in (23, 300, 64, 7, 129):
         ta.run(iters)
         ta.synchronize()
@@ -63,7 +72,15 @@ def test_one_launch_iterations_bitwise_equal_the_two_launch_sequence(robots, r):
     # carried rows: all but the first two one-launch iterations of every graph find the row products of their agent formed
     # by the launch before (round robin over >= 3 robots: three different agents in a row)
     carried = sum(max(0, (max(0, b - P - 1) & ~1) - 2) for b in (23, 256, 44, 64, 7, 129))
-    assert tb.counters()[8] == carried, (tb.counters()[8], carried)
+    # the deep-carried form needs the first 20 (or 24) 64-row chunks of every agent's order to be private: 500-pose agents
+    # of sphere2500 have 24 .. 28, 416-pose agents 18, 312-pose agents 12 -- those keep round 5's form
+    assert (tb.counters()[9] > 0) == (deep and robots == 5)
+    if tb.counters()[9] > 0:
+        # every one-launch iteration of a deep-carried run consumes what the three launches before it left (the run opens
+        # with k_fd_prime and two producing launches)
+        assert tb.counters()[8] == expect and tb.counters()[9] == expect, (tb.counters()[8], tb.counters()[9], expect)
+    else:
+        assert tb.counters()[8] == carried and tb.counters()[9] == 0, (tb.counters()[8], carried)
     assert np.isclose(ta.cost(), tb.cost(), rtol=0, atol=0)
     ta.close()
     tb.close()
@@ -300,11 +317,13 @@ def test_random_teams_take_carried_rows_and_stay_bitwise(seed):
         kw.update(robust_cost_type=5, gnc_barc=5.0)
     T, Y = O.odometry_init(m0, n), O.fixed_stiefel(r)
     teams = []
-    old = {k: os.environ.get(k) for k in ("DPGO_FUSED_EVAL", "DPGO_FE_MIN_N")}
+    old = {k: os.environ.get(k) for k in ("DPGO_FUSED_EVAL", "DPGO_FE_MIN_N", "DPGO_FE_DEEP")}
     try:
         os.environ["DPGO_FE_MIN_N"] = "32"
-        for fe in ("0", "1"):
+        # two-launch sequence | one-launch, deep-carried where the team allows it (round 6) | one-launch, round 5's form
+        for fe, deep in (("0", "1"), ("1", "1"), ("1", "0")):
             os.environ["DPGO_FUSED_EVAL"] = fe
+            os.environ["DPGO_FE_DEEP"] = deep
             t = capi.Team.from_measurements(mp, capi.default_params(r=r, num_robots=robots, **kw))
             t.set_initial(T, Y)
             teams.append(t)
@@ -319,12 +338,16 @@ def test_random_teams_take_carried_rows_and_stay_bitwise(seed):
             t.run(int(chunk))
             t.synchronize()
         for k in teams[0].ids:
-            assert np.array_equal(teams[0].agents[k].get_X(), teams[1].agents[k].get_X()), (seed, robots, r, extra, kw, int(chunk), k)
+            x0 = teams[0].agents[k].get_X()
+            assert np.array_equal(x0, teams[1].agents[k].get_X()), (seed, robots, r, extra, kw, int(chunk), k)
+            assert np.array_equal(x0, teams[2].agents[k].get_X()), (seed, robots, r, extra, kw, int(chunk), k)
         if robust:
-            assert teams[0].update_weights() == teams[1].update_weights()
+            assert teams[0].update_weights() == teams[1].update_weights() == teams[2].update_weights()
     c = teams[1].counters()
-    assert teams[0].counters()[7] == 0
+    assert teams[0].counters()[7] == 0 and teams[2].counters()[9] == 0
     if c[7] > 0:   # (teams the one-launch form serves: every one of them also carries rows)
         assert c[8] > 0, (seed, robots, r, extra, c[7], c[8])
+        assert teams[2].counters()[8] > 0
+    print("seed %d: %d robots, r = %d, %d extra edges: one-launch %d, deep-carried %d" % (seed, robots, r, extra, c[7], c[9]))
     for t in teams:
         t.close()
