@@ -21,6 +21,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the CPU legs time the oracle built for THIS host with the reference's own flags (-O3 -march=native,
+# /root/reference/CMakeLists.txt:9; oracle/oracle.py build_native): the in-tree liboracle.so is the portable x86-64-v2 build
+os.environ.setdefault("DPGO_ORACLE_NATIVE", "1")
 
 import numpy as np  # noqa: E402
 
@@ -574,9 +577,14 @@ def roofline_leg(team, agent_id, form="dense"):
         if o_ms:
             two = {k: roof[k] for k in ("kernel", "achieved", "frac", "traffic", "bytes_per_launch", "us_per_launch",
                                         "us_per_launch_back_to_back", "timing_note")}
-            roof.update({"kernel": "k_step_fe<5,0> (one launch per iteration, carried rows: Riemannian gradient from the row "
-                                   "products the previous launch left + preconditioner stream + RGD step + Nesterov V + "
-                                   "look-ahead Nesterov step of all agents + the row products of the next agent)",
+            deep = team.counters()[9] > 0
+            roof.update({"kernel": ("k_step_fd<5,24> (one launch per iteration, deep-carried: gradient of the public poses + the "
+                                    "last 8 of 32 chunks of the preconditioner product on top of the partial sums the previous "
+                                    "launch left + RGD step + Nesterov V + look-ahead of all agents; beside it the first 24 chunks "
+                                    "of the NEXT agent's product, the row products of the agent after that)") if deep else
+                                   ("k_step_fe<5,0> (one launch per iteration, carried rows: Riemannian gradient from the row "
+                                    "products the previous launch left + preconditioner stream + RGD step + Nesterov V + "
+                                    "look-ahead Nesterov step of all agents + the row products of the next agent)"),
                          "achieved": o_bytes / (o_ms * 1e-3) / 1e9, "bytes_per_launch": o_bytes, "us_per_launch": o_ms * 1e3,
                          "traffic": (2 * PMC[form]["fused_step"][0] + PMC[form]["fused_step"][1]) * 1024,
                          "timing_note": "HIP events around 500 eager one-launch iterations (dispatch to dispatch); "
@@ -675,6 +683,7 @@ def cpu_baseline(mp, n, T, Y, cfg=None, seconds=12.0):
         iters += chunk
     dt = time.perf_counter() - t0
     return {"value": dt / iters * 1e3, "unit": "ms/RBCD-iteration", "cores": 1, "kind": "port", "host": host_cpu(),
+            "compiler": O.BUILD["compiler"], "flags": O.BUILD["flags"],
             "sample": "%d iterations of the same 5-agent %s+Nesterov workload (~%d s), oracle/liboracle.so"
                       % (iters, "RGD" if cfg["method"] == 1 else "RTR", int(seconds))}
 
@@ -1103,8 +1112,9 @@ def main():
            "data": "bundled sphere2500.g2o (real dataset), odometry initial guess lifted with a fixed YLift",
            "config": {"workload": "sphere2500.g2o, 5 agents, synchronous round-robin RBCD, RGD(step 0.2, dense "
                                   "preconditioner) + Nesterov (restart 20), r=5, library weighting; mid-run iterations one "
-                                  "launch each (k_step_fe, the row products of an agent formed on the side by the launch "
-                                  "before its own), hipGraphs of up to 256 iterations",
+                                  "launch each (k_step_fd: the private part of an agent's preconditioner product formed by the "
+                                  "launch before its own, its row products by the one before that), hipGraphs of up to 256 "
+                                  "iterations",
                       "agents": 5, "poses_per_agent": 500, "placement": "agent a on rank a % N"}}
     _OUT = out
     force_dist = os.environ.get("DPGO_BENCH_FORCE_DIST") == "1"  # exercise the N > 1 driver with one rank
@@ -1112,6 +1122,7 @@ def main():
         ms, roof, conv, cpu, counters, timing = single_gpu(args)
         out["config"]["value_is"] = ("ms per step of ONE run of R x K steps (R x K >= 2000: at least 50 ms of replays) between two "
                                      "synchronisations; the single K-step region of the contract is ms_per_step_k_region")
+        out["config"]["ms_per_step_k_region"] = timing["ms_per_step_single_run_of_K"]
         out.update({"value": ms, "ms_per_step": ms, "ms_per_step_k_region": timing["ms_per_step_single_run_of_K"],
                     "ms_per_step_k_region_mean_of_15": timing["ms_per_step_runs_of_K"]["mean"],
                     "timing": timing, "roofline": roof, "cpu_baseline": cpu, "convergence": conv,
@@ -1119,9 +1130,11 @@ def main():
                     "counters": {"precond_launches": counters[0], "precond_bytes": counters[1],
                                  "spmm_launches": counters[2], "spmm_bytes": counters[3], "iterations": counters[4],
                                  "one_launch_iterations": counters[7], "with_carried_rows": counters[8],
+                                 "deep_carried": counters[9],
                                  "note": "of the main team since its creation; one_launch_iterations: iterations that ran as "
-                                         "k_step_fe (csrc/step_fused.hip), the others as k_eval_stats + k_precond<PM_RGD>; "
-                                         "with_carried_rows: those whose row products the previous launch had formed"}})
+                                         "k_step_fd / k_step_fe (csrc/step_deep.hip, step_fused.hip), the others as k_eval_stats + "
+                                         "k_precond<PM_RGD>; with_carried_rows: those whose row products an earlier launch had "
+                                         "formed; deep_carried: those that also found the private part of their product formed"}})
         print(json.dumps(out))
     else:
         rank, ms, cost, roof, exchange, cp, asapp = multi_gpu(args)

@@ -44,7 +44,7 @@ class Params(C.Structure):
                 ("robust_opt_min_convergence_ratio", C.c_double), ("weights_as_float32", C.c_int),
                 ("robust_opt_num_resets", C.c_int), ("precond_mode", C.c_int), ("status_every_iterate", C.c_int),
                 ("rgd_line_search", C.c_int), ("rgd_ls_max_backoffs", C.c_int), ("rgd_ls_shrink", C.c_double),
-                ("rgd_ls_sigma", C.c_double)]
+                ("rgd_ls_sigma", C.c_double), ("tls_threshold", C.c_double), ("huber_threshold", C.c_double)]
 
 
 class OptResult(C.Structure):
@@ -62,7 +62,7 @@ class Status(C.Structure):
 
 
 METHOD_RTR, METHOD_RGD = 0, 1
-COST_L2, COST_GNC_TLS = 0, 5
+COST_L2, COST_L1, COST_HUBER, COST_TLS, COST_GM, COST_GNC_TLS = 0, 1, 2, 3, 4, 5
 WEIGHT_LIBRARY, WEIGHT_WRAPPER = 0, 1
 OK, NOT_READY, ERR = 0, 1, -1
 PRECOND_AUTO, PRECOND_DENSE, PRECOND_BLOCK_JACOBI, PRECOND_TWO_LEVEL = 0, 1, 2, 3

@@ -30,6 +30,7 @@ void dpgo_default_params(dpgo_params_t *p, int r, int num_robots) {
   p->rel_change_tol = 0.1; p->max_num_iters = 1000;             // :37-38
   p->robust_cost_type = DPGO_COST_L2;
   p->gnc_barc = 5.0; p->gnc_mu_step = 2.0; p->gnc_init_mu = 1e-5;
+  p->tls_threshold = 10.0; p->huber_threshold = 3.0;
   p->robust_opt_num_weight_updates = 4; p->robust_opt_inner_iters = 10 * num_robots;
   p->robust_opt_min_convergence_ratio = 0.8;
   p->weights_as_float32 = 0;
@@ -64,6 +65,14 @@ void stream_give(int device, hipStream_t s) {
 dpgo_team_t *dpgo_team_create(int device, const dpgo_params_t *p, int num_local, const int *agent_ids, void *stream) {
   if (p->d != 3 || p->r < 3 || p->r > 8) { set_err("d must be 3 and r in [3,8]"); return nullptr; }
   if (p->robust_opt_num_resets < 0) { set_err("robust_opt_num_resets must be >= 0"); return nullptr; }
+  if (p->robust_cost_type < DPGO_COST_L2 || p->robust_cost_type > DPGO_COST_GNC_TLS) {
+    set_err("robust_cost_type: one of DPGO_COST_L2 / L1 / HUBER / TLS / GM / GNC_TLS");
+    return nullptr;
+  }
+  if ((p->robust_cost_type == DPGO_COST_TLS && !(p->tls_threshold > 0.0)) || (p->robust_cost_type == DPGO_COST_HUBER && !(p->huber_threshold > 0.0))) {
+    set_err("tls_threshold / huber_threshold must be > 0");
+    return nullptr;
+  }
   if (p->rgd_line_search && (p->rgd_ls_max_backoffs < 0 || p->rgd_ls_max_backoffs >= LS_MAX_TRIALS || !(p->rgd_ls_shrink > 0.0) ||
                              !(p->rgd_ls_shrink < 1.0) || !(p->rgd_ls_sigma > 0.0) || !(p->rgd_ls_sigma < 1.0))) {
     set_err("rgd_line_search: rgd_ls_max_backoffs in [0, 7], rgd_ls_shrink and rgd_ls_sigma in (0, 1)");

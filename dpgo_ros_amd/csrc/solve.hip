@@ -398,7 +398,14 @@ int refresh_rgd_result(dpgo_team *t, Agent &a) {
 }
 
 double robust_weight(const dpgo_params_t &p, double mu, double residual) {
-  if (p.robust_cost_type == DPGO_COST_L2) return 1.0;
+  switch (p.robust_cost_type) {
+    case DPGO_COST_L2: return 1.0;
+    case DPGO_COST_L1: return 1.0 / residual;
+    case DPGO_COST_HUBER: return residual < p.huber_threshold ? 1.0 : p.huber_threshold / residual;
+    case DPGO_COST_TLS: return residual < p.tls_threshold ? 1.0 : 0.0;
+    case DPGO_COST_GM: { const double a = 1.0 + residual * residual; return 1.0 / (a * a); }
+    default: break;  // GNC_TLS
+  }
   const double r2 = residual * residual, b2 = p.gnc_barc * p.gnc_barc;
   const double upper = (mu + 1.0) / mu * b2, lower = mu / (mu + 1.0) * b2;
   if (r2 >= upper) return 0.0;

@@ -280,6 +280,7 @@ struct RobustCostParameters {  // :178-188, 196-210
   Type costType = Type::L2;
   unsigned GNCMaxNumIters = 10000;
   double GNCBarc = 5.0, GNCMuStep = 1.4, GNCInitMu = 1e-4;
+  double TLSThreshold = 10.0, HuberThreshold = 3.0;  // [UPSTREAM-RECALL]; no wrapper call site writes them
 };
 
 }  // namespace DPGO

@@ -402,7 +402,12 @@ class PGOAgent {
     c.rgd_ls_shrink = p.localOptimizationParams.RGD_ls_shrink; c.rgd_ls_sigma = p.localOptimizationParams.RGD_ls_sigma;
     c.acceleration = p.acceleration; c.restart_interval = (int)p.restartInterval;
     c.rel_change_tol = p.relChangeTol; c.max_num_iters = (int)p.maxNumIters;
-    c.robust_cost_type = p.robustCostParams.costType == RobustCostParameters::Type::L2 ? DPGO_COST_L2 : DPGO_COST_GNC_TLS;
+    // (Type's enumerators are declared in the order of DPGO_COST_*: L2, L1, Huber, TLS, GM, GNC_TLS)
+    static_assert((int)RobustCostParameters::Type::L1 == DPGO_COST_L1 && (int)RobustCostParameters::Type::Huber == DPGO_COST_HUBER &&
+                      (int)RobustCostParameters::Type::TLS == DPGO_COST_TLS && (int)RobustCostParameters::Type::GM == DPGO_COST_GM &&
+                      (int)RobustCostParameters::Type::GNC_TLS == DPGO_COST_GNC_TLS, "RobustCostParameters::Type follows DPGO_COST_*");
+    c.robust_cost_type = (int)p.robustCostParams.costType;
+    c.tls_threshold = p.robustCostParams.TLSThreshold; c.huber_threshold = p.robustCostParams.HuberThreshold;
     c.gnc_barc = p.robustCostParams.GNCBarc; c.gnc_mu_step = p.robustCostParams.GNCMuStep; c.gnc_init_mu = p.robustCostParams.GNCInitMu;
     c.robust_opt_num_weight_updates = (int)p.robustOptNumWeightUpdates; c.robust_opt_inner_iters = (int)p.robustOptInnerIters;
     c.robust_opt_num_resets = (int)p.robustOptNumResets; c.robust_opt_min_convergence_ratio = p.robustOptMinConvergenceRatio;

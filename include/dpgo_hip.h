@@ -30,7 +30,11 @@ typedef struct {
 } dpgo_measurement_t;
 
 enum { DPGO_METHOD_RTR = 0, DPGO_METHOD_RGD = 1 };       /* ROptParameters::ROptMethod */
-enum { DPGO_COST_L2 = 0, DPGO_COST_GNC_TLS = 5 };         /* RobustCostParameters::Type */
+/* RobustCostParameters::Type, the six names src/PGOAgentROSNode.cpp:178-188 accepts.  Weight functions w(r) of the residual
+ * r (dpgo_agent_robust_weight; [UPSTREAM-RECALL] mit-acl/dpgo src/DPGO_robust.cpp, the library is absent from the mount):
+ *   L2 1 | L1 1 / r | Huber r < huber_threshold ? 1 : huber_threshold / r | TLS r < tls_threshold ? 1 : 0 |
+ *   GM 1 / (1 + r^2)^2 | GNC_TLS Yang et al. RA-L 2020 with the running mu */
+enum { DPGO_COST_L2 = 0, DPGO_COST_L1 = 1, DPGO_COST_HUBER = 2, DPGO_COST_TLS = 3, DPGO_COST_GM = 4, DPGO_COST_GNC_TLS = 5 };
 enum { DPGO_WAIT_FOR_DATA = 0, DPGO_WAIT_FOR_INITIALIZATION = 1, DPGO_INITIALIZED = 2 }; /* msg/Status.msg:1-3 */
 enum { DPGO_WEIGHT_LIBRARY = 0, DPGO_WEIGHT_WRAPPER = 1 }; /* info-matrix vs kappa=1e4,tau=1e2 */
 enum { DPGO_OK = 0, DPGO_NOT_READY = 1, DPGO_ERR = -1 };
@@ -84,6 +88,8 @@ typedef struct {
   int rgd_ls_max_backoffs;
   double rgd_ls_shrink;
   double rgd_ls_sigma;
+  double tls_threshold;       /* RobustCostParameters::TLSThreshold [UPSTREAM-RECALL: 10]; no wrapper call site writes it */
+  double huber_threshold;     /* RobustCostParameters::HuberThreshold [UPSTREAM-RECALL: 3]; likewise */
 } dpgo_params_t;
 
 /* mLocalOptResult.{success,fInit,fOpt,gradNormInit,gradNormOpt} (src/PGOAgentROS.cpp:169-172) */

@@ -37,7 +37,7 @@ typedef struct {
 } orc_meas_t;
 
 enum { ORC_METHOD_RTR = 0, ORC_METHOD_RGD = 1 };
-enum { ORC_COST_L2 = 0, ORC_COST_GNC_TLS = 5 };
+enum { ORC_COST_L2 = 0, ORC_COST_L1 = 1, ORC_COST_HUBER = 2, ORC_COST_TLS = 3, ORC_COST_GM = 4, ORC_COST_GNC_TLS = 5 };
 enum { ORC_STATE_WAIT_FOR_DATA = 0, ORC_STATE_WAIT_FOR_INITIALIZATION = 1, ORC_STATE_INITIALIZED = 2 };
 enum { ORC_WEIGHT_LIBRARY = 0, ORC_WEIGHT_WRAPPER = 1 };
 
@@ -56,7 +56,7 @@ typedef struct {
   int restart_interval;       /* :130 */
   double rel_change_tol;      /* :134 */
   int max_num_iters;          /* :228-232 */
-  int robust_cost_type;       /* :175-188 */
+  int robust_cost_type;       /* :175-188: ORC_COST_* */
   double gnc_barc, gnc_mu_step, gnc_init_mu; /* :196-210 */
   int robust_opt_num_weight_updates, robust_opt_inner_iters; /* :212-221 */
   double robust_opt_min_convergence_ratio;
@@ -81,6 +81,8 @@ typedef struct {
   int rgd_ls_max_backoffs;    /* 7: eight trial steps */
   double rgd_ls_shrink;       /* 0.5 */
   double rgd_ls_sigma;        /* 1e-4 */
+  double tls_threshold;       /* [UPSTREAM-RECALL] RobustCostParameters::TLSThreshold, 10 */
+  double huber_threshold;     /* [UPSTREAM-RECALL] RobustCostParameters::HuberThreshold, 3 */
 } orc_params_t;
 
 typedef struct {

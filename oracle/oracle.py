@@ -41,7 +41,7 @@ class Params(C.Structure):
                 ("robust_opt_min_convergence_ratio", C.c_double), ("weights_as_float32", C.c_int),
                 ("robust_opt_num_resets", C.c_int), ("precond_mode", C.c_int), ("status_every_iterate", C.c_int),
                 ("rgd_line_search", C.c_int), ("rgd_ls_max_backoffs", C.c_int), ("rgd_ls_shrink", C.c_double),
-                ("rgd_ls_sigma", C.c_double)]
+                ("rgd_ls_sigma", C.c_double), ("tls_threshold", C.c_double), ("huber_threshold", C.c_double)]
 
 
 class OptResult(C.Structure):
@@ -59,11 +59,38 @@ class Status(C.Structure):
 
 
 METHOD_RTR, METHOD_RGD = 0, 1
-COST_L2, COST_GNC_TLS = 0, 5
+COST_L2, COST_L1, COST_HUBER, COST_TLS, COST_GM, COST_GNC_TLS = 0, 1, 2, 3, 4, 5
 WEIGHT_LIBRARY, WEIGHT_WRAPPER = 0, 1
 
 
+# flags of the library in use (bench.py prints them next to the CPU baseline)
+BUILD = {"compiler": "gcc", "flags": "-O3 -march=x86-64-v2 -std=gnu99 -fno-fast-math (oracle/Makefile)"}
+
+
+def build_native():
+    """the same sources built FOR THE HOST THAT RUNS THEM (-O3 -march=native, the reference's own flags:
+    /root/reference/CMakeLists.txt:9), outside the tree: the timed CPU legs of bench.py use this one (DPGO_ORACLE_NATIVE=1).
+    The in-tree liboracle.so stays portable (x86-64-v2): it is built in one container and run on another host."""
+    import tempfile
+    out_dir = os.path.join(tempfile.gettempdir(), "dpgo_oracle_native_%d" % os.getuid())
+    os.makedirs(out_dir, exist_ok=True)
+    so = os.path.join(out_dir, "liboracle.so")
+    flags = ["-O3", "-march=native", "-std=gnu99", "-fPIC", "-fno-fast-math"]
+    srcs = [os.path.join(_HERE, f) for f in ("orc_io.c", "orc_core.c", "orc_agent.c", "orc_align.c")]
+    deps = srcs + [os.path.join(_HERE, f) for f in ("dpgo_oracle.h", "orc_internal.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+        subprocess.check_call(["gcc"] + flags + ["-shared", "-o", so] + srcs + ["-lm"])
+    try:
+        ver = subprocess.check_output(["gcc", "--version"], text=True).splitlines()[0]
+    except Exception:
+        ver = "gcc"
+    BUILD.update({"compiler": ver, "flags": " ".join(flags)})
+    return so
+
+
 def build(force=False):
+    if os.environ.get("DPGO_ORACLE_NATIVE") == "1":
+        return build_native()
     so = os.path.join(_HERE, "liboracle.so")
     srcs = [os.path.join(_HERE, f) for f in ("orc_io.c", "orc_core.c", "orc_agent.c",
                                              "dpgo_oracle.h", "orc_internal.h")]

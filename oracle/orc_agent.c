@@ -46,6 +46,8 @@ void orc_default_params(orc_params_t *p, int r, int num_robots) {
   p->rgd_ls_max_backoffs = 7;
   p->rgd_ls_shrink = 0.5;
   p->rgd_ls_sigma = 1e-4;
+  p->tls_threshold = 10.0;
+  p->huber_threshold = 3.0;
 }
 
 struct orc_agent {
@@ -470,7 +472,16 @@ int orc_agent_compute_residual(const orc_agent_t *a, const orc_meas_t *m, double
 }
 
 double orc_robust_weight(const orc_agent_t *a, double residual) {
-  if (a->prm.robust_cost_type == ORC_COST_L2) return 1.0;
+  /* the six types the wrapper names (PGOAgentROSNode.cpp:178-188); formulas [UPSTREAM-RECALL] mit-acl/dpgo
+   * src/DPGO_robust.cpp RobustCost::weight -- the library is absent from the mount */
+  switch (a->prm.robust_cost_type) {
+    case ORC_COST_L2: return 1.0;
+    case ORC_COST_L1: return 1.0 / residual;
+    case ORC_COST_HUBER: return residual < a->prm.huber_threshold ? 1.0 : a->prm.huber_threshold / residual;
+    case ORC_COST_TLS: return residual < a->prm.tls_threshold ? 1.0 : 0.0;
+    case ORC_COST_GM: { double s = 1.0 + residual * residual; return 1.0 / (s * s); }
+    default: break; /* GNC_TLS */
+  }
   double r2 = residual * residual, b2 = a->prm.gnc_barc * a->prm.gnc_barc, mu = a->mu;
   double upper = (mu + 1.0) / mu * b2, lower = mu / (mu + 1.0) * b2;
   if (r2 >= upper) return 0.0;

@@ -9,7 +9,7 @@ mkdir -p $OUT $SCR
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $SCR/trace -o bench -- python $ROOT/bench.py --steps 1000 --warmup 100 > $OUT/bench_traced.log 2>&1
 python $ROOT/profiles/prof_query.py $SCR/trace/bench_results.db > $OUT/kernel_stats.md
-python $ROOT/profiles/prof_query.py $SCR/trace/bench_results.db k_step_fe 24 | tail -24 > $OUT/timeline.txt
+python $ROOT/profiles/prof_query.py $SCR/trace/bench_results.db k_step_fd 24 | tail -24 > $OUT/timeline.txt
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $SCR/pmc_fetch -o bench -- python $ROOT/bench.py --steps 200 --warmup 20 > $OUT/pmc_fetch.log 2>&1
 python $ROOT/profiles/pmc_query.py $SCR/pmc_fetch/bench_results.db > $OUT/pmc_fetch.md
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $SCR/pmc_write -o bench -- python $ROOT/bench.py --steps 200 --warmup 20 > $OUT/pmc_write.log 2>&1

@@ -341,6 +341,44 @@ def test_gnc_tls_reweighting_rounds():
         th.close()
 
 
+@pytest.mark.parametrize("kind,kw", [(capi.COST_L1, {}), (capi.COST_HUBER, dict(huber_threshold=1.0)),
+                                     (capi.COST_TLS, dict(tls_threshold=2.5)), (capi.COST_GM, {})])
+def test_other_robust_cost_types_reweighting_rounds(kind, kw):
+    """the robust cost types besides L2 / GNC_TLS that the node accepts (src/PGOAgentROSNode.cpp:178-188): the weight function
+    in closed form through the C-ABI, then two UPDATE_WEIGHT rounds against the oracle (weights, iterates, cost)"""
+    from tests.util import add_outliers
+    N = 3
+    m, _, n = load("smallGrid3D", 1)
+    mo = add_outliers(m, n, frac=0.1, seed=1)
+    mp = O.partition(mo, n, N)
+    T = O.odometry_init(mo, n)
+    prm = dict(method=capi.METHOD_RTR, gradnorm_tol=1e-2, robust_cost_type=kind, robust_opt_num_weight_updates=2,
+               robust_opt_inner_iters=6, **kw)
+    th, to = _pair_from(mp, n, N, T, **prm)
+    for r in (0.25, 0.999, 1.0, 2.5, 3.0, 9.0, 40.0):
+        expect = {capi.COST_L1: 1.0 / r, capi.COST_HUBER: 1.0 if r < 1.0 else 1.0 / r, capi.COST_TLS: 1.0 if r < 2.5 else 0.0,
+                  capi.COST_GM: 1.0 / ((1.0 + r * r) ** 2)}[kind]
+        assert th.agents[0].robust_weight(r) == expect and to.agents[0].robust_weight(r) == expect
+    for rnd in range(2):
+        th.run(6)
+        for _ in range(6):
+            to.iterate()
+        assert np.abs(th.global_X() - to.global_X()).max() < 1e-7, rnd
+        assert th.update_weights() == to.update_weights()
+        moved = 0
+        for a in range(N):
+            wh, wo = th.agents[a].measurements(), to.agents[a].measurements()
+            assert np.abs(wh["weight"] - wo["weight"]).max() <= 1e-7 * max(1.0, np.abs(wo["weight"]).max())
+            moved += int((wo["weight"] != 1).sum())
+        assert moved > 0
+    th.run(4)
+    for _ in range(4):
+        to.iterate()
+    assert np.abs(th.global_X() - to.global_X()).max() < 1e-6
+    assert abs(th.cost() - to.cost()) <= 1e-7 * abs(to.cost())
+    th.close()
+
+
 @pytest.mark.parametrize("mode,accel", [(capi.WEIGHT_WRAPPER, 0), (capi.WEIGHT_LIBRARY, 1)])
 def test_tunnels_eight_agents(mode, accel):
     """BASELINE configs[4] inputs (8 robots, all-to-all neighbours, 700-1000 shared edges per agent) under

@@ -213,3 +213,19 @@ def test_gnc_tls_weight_function():
     assert ag.robust_weight(np.sqrt(mu / (mu + 1) * b2) - 1e-9) == 1.0
     r = 3.0
     assert abs(ag.robust_weight(r) - (np.sqrt(b2 * mu * (mu + 1) / r ** 2) - mu)) < 1e-15
+
+
+def test_other_robust_weight_functions():
+    """the other five names src/PGOAgentROSNode.cpp:178-188 accepts, closed forms ([UPSTREAM-RECALL] RobustCost::weight;
+    thresholds TLS 10, Huber 3): L2 1, L1 1 / r, Huber min(1, c / r), TLS step at c, GM 1 / (1 + r^2)^2"""
+    def w(kind, r, **kw):
+        return O.Agent(0, O.default_params(r=R, num_robots=1, robust_cost_type=kind, **kw)).robust_weight(r)
+    for r in (0.3, 2.9999, 3.0, 7.5, 10.0, 25.0):
+        assert w(O.COST_L2, r) == 1.0
+        assert w(O.COST_L1, r) == 1.0 / r
+        assert w(O.COST_HUBER, r) == (1.0 if r < 3.0 else 3.0 / r)
+        assert w(O.COST_TLS, r) == (1.0 if r < 10.0 else 0.0)
+        assert w(O.COST_GM, r) == 1.0 / ((1.0 + r * r) * (1.0 + r * r))
+    assert w(O.COST_HUBER, 4.0, huber_threshold=2.0) == 0.5
+    assert w(O.COST_TLS, 4.0, tls_threshold=2.0) == 0.0
+
