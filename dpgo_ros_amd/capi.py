@@ -7,6 +7,7 @@ loudly when the HIP extension has not been built, and every compute call needs a
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -102,6 +103,14 @@ def lib():
             raise ImportError(
                 "libdpgo_hip.so is missing (%s): build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C dpgo_ros_amd/csrc`; there is no CPU fallback" % LIB_PATH)
+        # One HIP runtime per process: torch ships its own libamdhip64 / librccl under /opt/rocm's sonames; loaded AFTER this
+        # library (which binds /opt/rocm's) the process holds two runtimes and aborts at exit.  So where torch exists and has
+        # not been imported yet, it goes first -- this library then binds to torch's copies through the sonames, whatever the
+        # user's import order (DPGO_TORCH_FIRST=0: do not; dpgo_ros_amd.distributed needs torch anyway)
+        if "torch" not in sys.modules and os.environ.get("DPGO_TORCH_FIRST", "1") != "0":
+            import importlib.util
+            if importlib.util.find_spec("torch") is not None:
+                import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         L.dpgo_last_error.restype = C.c_char_p
         L.dpgo_team_create.restype = C.c_void_p

@@ -30,9 +30,7 @@ size_t pool_round(size_t bytes) {
   return (b + step - 1) / step * step;
 }
 
-void *pool_take(size_t rounded) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+void *pool_take(size_t rounded, int dev) {
   BufPool &P = pool();
   std::lock_guard<std::mutex> g(P.mu);
   auto it = P.kept.find({dev, rounded});
@@ -58,6 +56,32 @@ void pool_give(void *p, size_t rounded) {
     }
   }
   (void)hipFree(p);
+}
+
+size_t pool_flush(int dev) {
+  BufPool &P = pool();
+  std::vector<void *> drop;
+  size_t bytes = 0;
+  {
+    std::lock_guard<std::mutex> g(P.mu);
+    for (auto &kv : P.kept)
+      if (kv.first.first == dev) {
+        for (void *q : kv.second) { drop.push_back(q); bytes += kv.first.second; }
+        kv.second.clear();
+      }
+    P.held -= bytes;
+  }
+  for (void *q : drop) (void)hipFree(q);  // (hipFree synchronises the device: whoever still had work on one of them is done)
+  return bytes;
+}
+
+size_t pool_held(int dev) {
+  BufPool &P = pool();
+  std::lock_guard<std::mutex> g(P.mu);
+  size_t bytes = 0;
+  for (auto &kv : P.kept)
+    if (kv.first.first == dev) bytes += kv.first.second * kv.second.size();
+  return bytes;
 }
 
 namespace {
@@ -598,7 +622,10 @@ int sync_descs_noflush(dpgo_team *t) {
     bool will_build = false;
     for (auto &a : t->ag) will_build = will_build || a->index_dirty || a->data_dirty;
     if (will_build) (void)hipMemGetInfo(&free_b, &total_b);
-    double budget = (double)free_b + 8.0 * (double)t->d_tmp.n;  // the scratch of an earlier pass is reused
+    // (the scratch of an earlier pass is reused; idle pooled buffers count as used memory but are one pool_flush away from
+    // free -- DevBuf::alloc gives them back when hipMalloc fails --, so the choice of preconditioner does not depend on what
+    // earlier teams of the process happened to allocate)
+    double budget = (double)free_b + 8.0 * (double)t->d_tmp.n + (will_build ? (double)pool_held(t->device) : 0.0);
     bool any_dirty = false;
     static const bool timing = std::getenv("DPGO_TIMING") != nullptr;
     const auto q0 = std::chrono::steady_clock::now();

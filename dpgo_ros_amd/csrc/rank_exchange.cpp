@@ -19,6 +19,7 @@
 #include <rccl/rccl.h>
 
 #include <functional>
+#include <mutex>
 #include <tuple>
 
 #include "team_internal.h"
@@ -42,18 +43,30 @@ struct RcclApi {
   std::string path;
 };
 
+// (one attempt per process, whichever thread comes first; a failed attempt keeps its message for every later caller)
+static bool rccl_load(RcclApi &api, std::string &why);
+
 RcclApi *rccl() {
   static RcclApi api;
-  static bool tried = false;
-  if (tried) return api.handle ? &api : nullptr;
-  tried = true;
+  static std::string why;
+  static std::once_flag once;
+  std::call_once(once, [] { if (!rccl_load(api, why)) api.handle = nullptr; });
+  if (!api.handle) { set_err(why.empty() ? std::string("RCCL is not loadable") : why); return nullptr; }
+  return &api;
+}
+
+static bool rccl_load(RcclApi &api, std::string &why) {
   const char *names[] = {std::getenv("DPGO_RCCL_LIBRARY"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   for (const char *nm : names) {
     if (!nm || !*nm) continue;
     api.handle = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
     if (api.handle) { api.path = nm; break; }
   }
-  if (!api.handle) { set_err(std::string("RCCL is not loadable: ") + (dlerror() ? dlerror() : "librccl.so.1 not found")); return nullptr; }
+  if (!api.handle) {
+    const char *e = dlerror();  // (ONE call: dlerror() clears its state, a second call returns null)
+    why = std::string("RCCL is not loadable: ") + (e ? e : "librccl.so.1 not found");
+    return false;
+  }
   bool ok = true;
   auto sym = [&](const char *nm) { void *p = dlsym(api.handle, nm); if (!p) ok = false; return p; };
   api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
@@ -66,8 +79,8 @@ RcclApi *rccl() {
   api.AllReduce = (decltype(api.AllReduce))sym("ncclAllReduce");
   api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
   api.GetVersion = (decltype(api.GetVersion))sym("ncclGetVersion");
-  if (!ok) { set_err("RCCL library lacks an expected entry point"); dlclose(api.handle); api.handle = nullptr; return nullptr; }
-  return &api;
+  if (!ok) { why = "RCCL library lacks an expected entry point"; dlclose(api.handle); api.handle = nullptr; return false; }
+  return true;
 }
 
 }  // namespace
@@ -187,7 +200,11 @@ int dpgo_team_detach_comm(dpgo_team_t *t) {
   if (!t) return DPGO_ERR;
   if (t->stream) (void)hipStreamSynchronize(t->stream);
   if (t->isolated) { t->isolated = false; t->descs_dirty = true; t->graph_valid = false; }
-  t->rx = dpgo_team::RankExchange{};
+  // (the staging buffers go back to their pool; everything else starts over)
+  auto &x = t->rx;
+  x.d_send.release(); x.d_recv.release();
+  x.comm = nullptr; x.owner.clear(); x.max_delay = 0; x.loopback = false; x.version.clear(); x.sent.clear(); x.iter_seen = -1;
+  for (double &c : x.counters) c = 0;
   return DPGO_OK;
 }
 
@@ -311,6 +328,13 @@ int exchange_pairs(dpgo_team_t *t, std::vector<Pair> pairs) {
   if (pairs.empty()) return 0;
   const size_t B = (size_t)4 * t->prm.r;
   const Plan P = make_plan(topo_of(t), std::move(pairs), B);
+  // (everything that can fail on this rank alone is checked before anything is packed or posted: a rank that leaves between
+  // its pack and its sends would let its peers wait in ncclRecv for ever)
+  for (auto &kv : P.out)
+    for (const PlanSeg &g : kv.second.segs) {
+      const Agent &sb = *t->ag[t->id2local[g.b]];
+      if (!sb.has_X) { set_err("exchange: robot " + std::to_string(sb.id) + " has no iterate yet"); return DPGO_NOT_READY; }
+    }
   // (the staging buffers may have to grow before any kernel is given a pointer into them)
   if (P.tot_out > x.d_send.n || P.tot_in > x.d_recv.n) {
     HIPC(hipStreamSynchronize(t->stream));  // (operations of an earlier batch may still read / write the old buffers)
@@ -322,7 +346,6 @@ int exchange_pairs(dpgo_team_t *t, std::vector<Pair> pairs) {
     size_t at = kv.second.off;
     for (const PlanSeg &g : kv.second.segs) {
       Agent &sb = *t->ag[t->id2local[g.b]];
-      if (!sb.has_X) { set_err("exchange: robot " + std::to_string(sb.id) + " has no iterate yet"); return DPGO_NOT_READY; }
       if (sg.n == XFER_MAX_SEGS) flush_pack();
       sg.src[sg.n] = sb.dev.buf[g.q ? B_Y : B_X]; sg.idx[sg.n] = sb.d_pubframes[g.a]->p; sg.count[sg.n] = g.count; sg.buf[sg.n] = x.d_send.p + at;
       ++sg.n;
@@ -331,17 +354,23 @@ int exchange_pairs(dpgo_team_t *t, std::vector<Pair> pairs) {
   }
   flush_pack();
   NCCLC(api->GroupStart());
-  for (auto &kv : P.out)
-    if (kv.second.len) {
-      NCCLC(api->Send(x.d_send.p + kv.second.off, kv.second.len, ncclDouble, kv.first, x.comm->comm, t->stream));
-      x.counters[0] += 1; x.counters[2] += 8.0 * kv.second.len;
-    }
-  for (auto &kv : P.in)
-    if (kv.second.len) {
-      NCCLC(api->Recv(x.d_recv.p + kv.second.off, kv.second.len, ncclDouble, kv.first, x.comm->comm, t->stream));
-      x.counters[1] += 1; x.counters[3] += 8.0 * kv.second.len;
-    }
-  NCCLC(api->GroupEnd());
+  {
+    // (a failing call inside the group still closes it: an open group swallows every later RCCL call of the process)
+    ncclResult_t bad = ncclSuccess;
+    for (auto &kv : P.out)
+      if (kv.second.len && bad == ncclSuccess) {
+        bad = api->Send(x.d_send.p + kv.second.off, kv.second.len, ncclDouble, kv.first, x.comm->comm, t->stream);
+        x.counters[0] += 1; x.counters[2] += 8.0 * kv.second.len;
+      }
+    for (auto &kv : P.in)
+      if (kv.second.len && bad == ncclSuccess) {
+        bad = api->Recv(x.d_recv.p + kv.second.off, kv.second.len, ncclDouble, kv.first, x.comm->comm, t->stream);
+        x.counters[1] += 1; x.counters[3] += 8.0 * kv.second.len;
+      }
+    const ncclResult_t end = api->GroupEnd();
+    NCCLC(bad);
+    NCCLC(end);
+  }
   auto flush_unpack = [&]() { if (sg.n) launch_unpack_multi(t->ctx(), sg); sg.n = 0; };
   for (auto &kv : P.in) {
     size_t at = kv.second.off;
@@ -544,13 +573,20 @@ int dpgo_rank_plan_simulate(int num_robots, int world, int rank, const int *owne
 /* global cost across ranks: owned-edge partial sums of this team (NULL: a rank without robots contributes 0) + one
  * 1-double all-reduce.  Collective over the communicator. */
 int dpgo_comm_global_cost(dpgo_comm_t *c, dpgo_team_t *t, void *stream, double *f) {
+  // (a rank whose own part fails still takes part in the reduction -- its peers are already waiting in it -- and contributes
+  // NaN: every rank then sees that the sum is not one)
   double part = 0;
+  bool failed = false;
   if (t) {
-    if (t->rx.comm && dpgo_team_exchange_all_ranks(t)) return DPGO_ERR;
-    if (dpgo_team_cost(t, &part)) return DPGO_ERR;
+    if (t->rx.comm && dpgo_team_exchange_all_ranks(t)) failed = true;
+    if (!failed && dpgo_team_cost(t, &part)) failed = true;
   }
+  const std::string why = failed ? g_err : std::string();
+  if (failed) part = std::nan("");
   if (dpgo_comm_allreduce_sum(c, t ? (void *)t->stream : stream, &part, 1)) return DPGO_ERR;
   *f = part;
+  if (failed) { set_err(why); return DPGO_ERR; }
+  if (part != part) { set_err("global cost: another rank failed to evaluate its part"); return DPGO_ERR; }
   return DPGO_OK;
 }
 

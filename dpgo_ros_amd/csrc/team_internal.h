@@ -46,22 +46,44 @@ inline void set_err(const std::string &s) { g_err = s; }
 // synchronisation): a buffer that is regrown mid-life still goes through hipFree, whose implicit device synchronisation
 // the launch sequences rely on.  assembly.hip holds the pool.
 size_t pool_round(size_t bytes);
-void *pool_take(size_t rounded_bytes);              // nullptr: nothing of that size is kept
+void *pool_take(size_t rounded_bytes, int device);  // nullptr: nothing of that size is kept for that device
 void pool_give(void *p, size_t rounded_bytes);
+size_t pool_flush(int device);                      // hipFree everything kept for the device; bytes given back
+size_t pool_held(int device);                       // bytes kept idle for the device (hipMemGetInfo counts them as used)
 
 template <class T>
 struct DevBuf {
   T *p = nullptr;
   size_t n = 0;
   size_t cap_bytes = 0;  // rounded size the allocation was made with (0: not poolable, e.g. adopted memory)
-  ~DevBuf() { if (p) { if (cap_bytes) pool_give(p, cap_bytes); else (void)hipFree(p); } }
+  DevBuf() = default;
+  // an owner: a copy would hand the same pointer to the pool twice
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n), cap_bytes(o.cap_bytes) { o.p = nullptr; o.n = 0; o.cap_bytes = 0; }
+  DevBuf &operator=(DevBuf &&o) noexcept {
+    if (this != &o) { release(); p = o.p; n = o.n; cap_bytes = o.cap_bytes; o.p = nullptr; o.n = 0; o.cap_bytes = 0; }
+    return *this;
+  }
+  ~DevBuf() { release(); }
+  // the owner is DONE with the buffer (its stream has drained): back to the pool
+  void release() {
+    if (p) { if (cap_bytes) pool_give(p, cap_bytes); else (void)hipFree(p); }
+    p = nullptr; n = 0; cap_bytes = 0;
+  }
   int alloc(size_t count) {
     if (count <= n && p) return 0;
     if (p) (void)hipFree(p);
     p = nullptr; n = 0; cap_bytes = 0;
     const size_t want = pool_round(sizeof(T) * std::max<size_t>(count, 1));
-    void *q = pool_take(want);
-    if (!q && hipMalloc(&q, want) != hipSuccess) return -1;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    void *q = pool_take(want, dev);
+    if (!q && hipMalloc(&q, want) != hipSuccess) {
+      // the idle buffers of this device count as used memory: give them back and try once more
+      (void)hipGetLastError();
+      if (pool_flush(dev) == 0 || hipMalloc(&q, want) != hipSuccess) return -1;
+    }
     p = (T *)q;
     cap_bytes = want;
     n = std::max<size_t>(count, 1);
@@ -86,12 +108,17 @@ struct PinnedBuf {
   size_t n = 0;
   size_t cap_bytes = 0;
   bool coh = false;
+  PinnedBuf() = default;
+  PinnedBuf(const PinnedBuf &) = delete;
+  PinnedBuf &operator=(const PinnedBuf &) = delete;
   ~PinnedBuf() { if (p) pinned_give(p, cap_bytes, coh); }
   // coherent: fine-grained memory -- what a kernel stores there (behind a system-scope fence) becomes visible to a host
   // that polls it while the kernel's stream is still busy
   int alloc(size_t count, bool coherent = false) {
     if (count <= n && p) return 0;
-    if (p) pinned_give(p, cap_bytes, coh);
+    // (a buffer regrown mid-life may still be read by a queued kernel: hipHostFree waits for the device; only a finished
+    // owner's buffer goes to the pool)
+    if (p) (void)hipHostFree(p);
     p = nullptr; n = 0;
     const size_t want = std::max<size_t>(count + count / 2, 64);
     const size_t bytes = pool_round(sizeof(T) * want);

@@ -79,7 +79,11 @@ def build_native():
     srcs = [os.path.join(_HERE, f) for f in ("orc_io.c", "orc_core.c", "orc_agent.c", "orc_align.c")]
     deps = srcs + [os.path.join(_HERE, f) for f in ("dpgo_oracle.h", "orc_internal.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
-        subprocess.check_call(["gcc"] + flags + ["-shared", "-o", so] + srcs + ["-lm"])
+        # (several processes may arrive here at once -- the ranks of a multi-process test: each builds its own file, the
+        # rename is atomic)
+        tmp = "%s.%d.tmp" % (so, os.getpid())
+        subprocess.check_call(["gcc"] + flags + ["-shared", "-o", tmp] + srcs + ["-lm"])
+        os.replace(tmp, so)
     try:
         ver = subprocess.check_output(["gcc", "--version"], text=True).splitlines()[0]
     except Exception:

@@ -9,15 +9,8 @@ if ROOT not in sys.path:
 
 DATA = os.path.join(ROOT, "data")
 
-# One HIP runtime per test process.  torch ships its own libamdhip64 / librccl (same sonames as /opt/rocm's, other builds) and
-# asks for them by a name the loader does not match against an already loaded /opt/rocm copy: a process that loads
-# libdpgo_hip.so (hence /opt/rocm's runtime) FIRST and imports torch LATER ends up with two runtimes and aborts at exit
-# ("double free or corruption": tests/test_gpu_rank_exchange.py in front of tests/test_gpu_distributed.py).  With torch
-# imported first, libdpgo_hip.so binds to torch's copies through their sonames -- whatever order the tests run in.
-try:
-    import torch  # noqa: F401
-except ImportError:
-    pass
+# One HIP runtime per test process: dpgo_ros_amd.capi.lib() imports torch (where it exists) in front of libdpgo_hip.so, so
+# the library binds to torch's copies of libamdhip64 / librccl whatever order the tests run in (see capi.lib).
 
 
 def pytest_configure(config):
