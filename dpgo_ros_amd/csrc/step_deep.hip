@@ -54,7 +54,10 @@ namespace dpgo {
 #define DPGO_FE_TRACE_BLOCK 100
 #endif
 #define FD_TRACE_DECL __shared__ unsigned long long fd_stamps[8 * 16];
-#define FD_STAMP(k) do { if ((threadIdx.x & 63) == 0) fd_stamps[(threadIdx.x >> 6) * 16 + (k)] = wall_clock64(); } while (0)
+#ifndef DPGO_FD_STAMP_MASK
+#define DPGO_FD_STAMP_MASK 0xFFFF
+#endif
+#define FD_STAMP(k) do { if (((DPGO_FD_STAMP_MASK >> (k)) & 1) && (threadIdx.x & 63) == 0) fd_stamps[(threadIdx.x >> 6) * 16 + (k)] = wall_clock64(); } while (0)
 #define FD_FLUSH() do { if ((threadIdx.x & 63) == 0) { const int w_ = threadIdx.x >> 6; \
     if (blockIdx.x == DPGO_FE_TRACE_BLOCK) for (int k_ = 0; k_ < 16; ++k_) ag.part[PART_E + 4000 * PART_STRIDE + w_ * 16 + k_] = (double)fd_stamps[w_ * 16 + k_]; \
     if (w_ == 4) { ag.part[PART_E + (4100 + 2 * (int)blockIdx.x) * PART_STRIDE] = (double)fd_stamps[4 * 16]; ag.part[PART_E + (4100 + 2 * (int)blockIdx.x) * PART_STRIDE + 1] = (double)fd_stamps[4 * 16 + 15]; } \
@@ -72,15 +75,34 @@ constexpr int FD_KC = 2048;
 #ifndef DPGO_FD_GC_LATE
 #define DPGO_FD_GC_LATE 0
 #endif
+#ifndef DPGO_FD_PACC_WT
+#define DPGO_FD_PACC_WT 0
+#endif
+#ifndef DPGO_FD_E_EARLY
+#define DPGO_FD_E_EARLY 0
+#endif
+#ifndef DPGO_FD_KA_PREFETCH
+#define DPGO_FD_KA_PREFETCH 1
+#endif
 constexpr int FD_HEAD = DPGO_FD_HEAD;  // 16-byte loads per lane of the NEXT agent's private chunks requested in front of barrier A
 
 // hand-offs between the waves of the workgroup: counters in LDS (see the head of the file)
-enum { FD_SY_C = 0, FD_SY_E, FD_SY_D, FD_SY_F, FD_SY_N, FD_SY_COUNT = 8 };
+enum { FD_SY_C = 0, FD_SY_E, FD_SY_D, FD_SY_F, FD_SY_N, FD_SY_RQ, FD_SY_COUNT = 8 };
 
 __device__ __forceinline__ void fd_signal(int *cnt) {
   // (the LDS operations of one wave execute in order: the count follows the wave's writes)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
   if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// "everything this wave needs is in the CU's memory queue": counted behind the wave's last request (the compiler may move
+// neither the requests below it nor the count above them)
+__device__ __forceinline__ void fd_signal_requested(int *cnt) {
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("" ::: "memory");
+  if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
 }
 
 __device__ __forceinline__ void fd_wait(int *cnt, int target) {
@@ -118,7 +140,8 @@ __device__ __forceinline__ void fd_xn_request(const AgentDev &ag, const FeBases 
   const int nsh = ag.nshared;
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
-    if (64 * q < nsh) {  // (uniform)
+    {  // (every slot, edges or not: loads under a wave-uniform `if` leave the compiler without a count of what is in flight
+       // behind the join, and the wait in front of the LDS writes becomes a wait for EVERYTHING the wave has requested)
       unsigned wsel = 0;
 #pragma unroll
       for (int k = 0; k < 32; ++k) {
@@ -161,8 +184,7 @@ struct FdCf {
 __device__ __forceinline__ void fd_cf_request(const AgentDev &ag, int ln, FdCf &cr) {
   const int nit = ag.nshared * 8;
 #pragma unroll
-  for (int j = 0; j < FdCf::TRIPS; ++j)
-    if (64 * j < nit) cr.v[j] = ld2(ag.fe_coef + 2 * min(64 * j + ln, nit - 1));
+  for (int j = 0; j < FdCf::TRIPS; ++j) cr.v[j] = ld2(ag.fe_coef + 2 * min(64 * j + ln, nit - 1));  // (every trip: see fd_xn_request)
 }
 
 template <int R>
@@ -251,6 +273,20 @@ __global__ __launch_bounds__(512) void k_step_fd(TeamDev *team, int sel, int nex
                                                  const double *__restrict__ pacc_in, double *__restrict__ pacc_out, int nblk_all,
                                                  int num_agents) {
   const AgentDev &ag = agv;
+#if DPGO_FD_KA_PREFETCH
+  {
+    // The launch's arguments (1.5 KB: the agent's descriptor by value, what it needs of the next two) sit in memory nobody
+    // has touched: fetched where they are first used, every scalar load misses in turn (traced: the wave that needs the
+    // edges' codes issued its first request 2.7 us into the launch).  One word of every 64-byte line now, all in flight at
+    // once: what follows hits the scalar cache.
+    const unsigned *ka = (const unsigned *)__builtin_amdgcn_kernarg_segment_ptr();
+    constexpr int KA_LINES = (int)((sizeof(AgentDev) + sizeof(FdNext) + sizeof(FeBases) + 160 + 63) / 64);
+    unsigned touch = 0;
+#pragma unroll
+    for (int i = 0; i < KA_LINES; ++i) touch |= ka[16 * i];
+    asm volatile("" ::"s"(touch));
+  }
+#endif
   // the poses live twice (step_fused.hip): this launch reads the copy of its parity and writes the other one
   const double *__restrict__ Xr = ag.buf[parity ? B_XALT : B_X];
   const double *__restrict__ Yr = ag.buf[parity ? B_YALT : B_Y];
@@ -278,7 +314,8 @@ __global__ __launch_bounds__(512) void k_step_fd(TeamDev *team, int sel, int nex
   __shared__ int sy[FD_SY_COUNT];
   FD_TRACE_DECL
   FD_STAMP(0);
-  if (tid < FD_SY_COUNT) sy[tid] = 0;  // (nobody signals in front of barrier A)
+  if (tid < FD_SY_COUNT) sy[tid] = 0;
+  lds_barrier();  // Z: the counters are zero (the only workgroup barrier; every wave is here within its first instructions)
   const int pj0 = own ? 2 * bx : 0, pj1 = (own && 2 * bx + 1 < n) ? 2 * bx + 1 : -1;
   const int npose = own ? ((pj1 >= 0) ? 2 : 1) : 0;
   constexpr int EPE = 4 * R + 16;
@@ -305,8 +342,6 @@ __global__ __launch_bounds__(512) void k_step_fd(TeamDev *team, int sel, int nex
 #pragma unroll
     for (int i = 0; i < FD_HEAD; ++i) mn[i] = ld2_nt(Md + min(2 * kl + 64 * (int)nx.ord_d[i], N4d - 2));
     FD_STAMP(10);
-    lds_barrier();  // A
-    FD_STAMP(11);
     __builtin_amdgcn_sched_barrier(0);
 #if DPGO_FD_GC_LATE
     {
@@ -322,6 +357,8 @@ __global__ __launch_bounds__(512) void k_step_fd(TeamDev *team, int sel, int nex
     }
     fd_signal(&sy[FD_SY_C]);
     FD_STAMP(1);
+    fd_wait(&sy[FD_SY_RQ], 4);  // A: waves 4-7 have requested all they need -- the stream queues behind it, not in front
+    FD_STAMP(11);
     // (nothing of the stream is requested in front of this hand-off: a wave stays at the issue of such loads, and the chain
     // waits for C -- the scheduler otherwise hoists the requests above the LDS writes)
     __builtin_amdgcn_sched_barrier(0);
@@ -360,7 +397,11 @@ __global__ __launch_bounds__(512) void k_step_fd(TeamDev *team, int sel, int nex
     }
     if ((flags & FD_P) && bx < nx.nblk_d) {
 #pragma unroll
+#if DPGO_FD_PACC_WT
+      for (int a = 0; a < R; ++a) st_c(pacc_out + ((size_t)bx * R + a) * 256 + tid, acc[a]);  // (write-through: not left dirty in L2 for the kernel boundary)
+#else
       for (int a = 0; a < R; ++a) gp(pacc_out)[((size_t)bx * R + a) * 256 + tid] = acc[a];
+#endif
     }
     FD_STAMP(15);
     FD_FLUSH();
@@ -383,6 +424,7 @@ __global__ __launch_bounds__(512) void k_step_fd(TeamDev *team, int sel, int nex
 #pragma unroll
       for (int i = 0; i < 4 * R; ++i) { w[i] = gp(Wc)[(size_t)i * npub + pqc]; x[i] = gp(Xc)[(size_t)i * npub + pqc]; }
     }
+    FD_STAMP(14);
     FdCur<R, NC> cu;
     fd_cur_request<R, M0, NC>(ag, pacc_in, bx, nblk, tid - 256, cu);
     // W (wave 5, behind its quarter of the product): the indices of the rows now (wave 4's copies are never used)
@@ -408,7 +450,7 @@ __global__ __launch_bounds__(512) void k_step_fd(TeamDev *team, int sel, int nex
     const NestState ns = nest_src[sel];
     __builtin_amdgcn_s_setprio(3);  // (the chain's instructions go first: the streamers' product shares the LDS with it)
     FD_STAMP(10);
-    lds_barrier();  // A
+    fd_signal_requested(&sy[FD_SY_RQ]);
     FD_STAMP(11);
     const int vs_off = fd_pos_off<R>(ag.fe_ord, pj);  // (where the pose's row goes: looked up while the edges' operands land)
     fd_wait(&sy[FD_SY_E], 2);  // the operands of the shared edges are in LDS
@@ -574,14 +616,16 @@ __global__ __launch_bounds__(512) void k_step_fd(TeamDev *team, int sel, int nex
   if (h == 0) {
     FdXn<R> er;
     fd_xn_request<R>(ag, fb, parity, ln, er);
+    FD_STAMP(9);
     FdCur<R, NC> cu;
     fd_cur_request<R, M0, NC>(ag, pacc_in, bx, nblk, tid - 256, cu);
     FD_STAMP(10);
-    lds_barrier();  // A
+    fd_signal_requested(&sy[FD_SY_RQ]);
     FD_STAMP(11);
     __builtin_amdgcn_s_setprio(3);
     fd_xn_to_lds<R>(ag, ln, er, Es);
     fd_signal(&sy[FD_SY_E]);
+    FD_STAMP(8);
     fd_wait(&sy[FD_SY_D], 2);  // this wave's quarter of the product over the last chunks
     fd_cur_product<R, M0, NC>(cu, vs, red, tid - 256);
     fd_signal(&sy[FD_SY_F]);
@@ -617,8 +661,18 @@ __global__ __launch_bounds__(512) void k_step_fd(TeamDev *team, int sel, int nex
   {
     FdCf er;
     fd_cf_request(ag, ln, er);
+    FD_STAMP(9);
     FdCur<R, NC> cu;
     fd_cur_request<R, M0, NC>(ag, pacc_in, bx, nblk, tid - 256, cu);
+    // (the coefficients go to LDS as soon as they are here -- the chain waits for them --, the look-ahead operands are
+    // requested behind that)
+#if DPGO_FD_E_EARLY
+    __builtin_amdgcn_sched_barrier(0);
+    fd_cf_to_lds<R>(ag, ln, er, Es);
+    fd_signal(&sy[FD_SY_E]);
+    FD_STAMP(8);
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     int pre[LOOKAHEAD_MAX_AGENTS + 1];
     pre[0] = 0;
 #pragma unroll
@@ -654,11 +708,14 @@ __global__ __launch_bounds__(512) void k_step_fd(TeamDev *team, int sel, int nex
     }
     const NestState ns = nest_src[sel];
     FD_STAMP(10);
-    lds_barrier();  // A
+    fd_signal_requested(&sy[FD_SY_RQ]);
     FD_STAMP(11);
     __builtin_amdgcn_s_setprio(3);
+#if !DPGO_FD_E_EARLY
     fd_cf_to_lds<R>(ag, ln, er, Es);
     fd_signal(&sy[FD_SY_E]);
+    FD_STAMP(8);
+#endif
     fd_wait(&sy[FD_SY_D], 2);  // this wave's quarter of the product over the last chunks
     fd_cur_product<R, M0, NC>(cu, vs, red, tid - 256);
     fd_signal(&sy[FD_SY_F]);

@@ -13,9 +13,9 @@ team.set_initial(T, Y)
 PART_E = 4 * 32768 * 8
 names = {
     "s": {0: "start", 10: "at A", 11: "past A", 1: "C signalled", 12: "bulk issued", 13: "next vector in LDS (N)", 15: "end (partial sums stored)"},
-    "c": {0: "start", 10: "at A", 11: "past A", 1: "edges in LDS (E)", 3: "G_j + projection", 2: "past C", 12: "rows written", 13: "D signalled", 4: "past D", 5: "product done", 6: "reduced", 7: "qf", 8: "V polar", 9: "Y polar", 15: "end"},
-    "w": {0: "start", 10: "at A", 11: "past A", 14: "end (rows left)"},
-    "l": {0: "start", 10: "at A", 11: "past A", 7: "first map", 15: "end"},
+    "c": {0: "start", 14: "W / X requested", 10: "at A", 11: "past A", 1: "edges in LDS (E)", 3: "G_j + projection", 2: "past C", 12: "rows written", 13: "D signalled", 4: "past D", 5: "product done", 6: "reduced", 7: "qf", 8: "V polar", 9: "Y polar", 15: "end"},
+    "w": {0: "start", 9: "edges requested", 10: "at A", 11: "past A", 8: "E signalled", 14: "end"},
+    "l": {0: "start", 9: "edges requested", 10: "at A", 11: "past A", 8: "E signalled", 7: "first map", 15: "end"},
 }
 AG = 1  # the agent of rep 46 of a 56-iteration graph (50 one-launch iterations): every producer flag set
 for rep in range(3):
