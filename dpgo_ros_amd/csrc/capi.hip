@@ -1178,7 +1178,18 @@ static int fe_deep_m0(dpgo_team_t *t) {
 // one run of nfe deep-carried one-launch iterations from the state k_nest_pre leaves: the points of the first three agents,
 // two launches that only produce (the row products of sel(0); then its private partial sums and the row products of
 // sel(1)), then the iterations -- each consuming what the three launches before it left
-static void enqueue_fe_deep(dpgo_team_t *t, const LaunchCtx &c, int m0, int nfe, const std::function<int(int)> &sel_at,
+// how many iterations of a graph of B run as one launch each.  Round 5's form leaves the last L + 1 (L = schedule period:
+// every agent's last block update of the run, whose statistics a status query reads) to the two-launch sequence; the
+// deep-carried form leaves those statistics itself (FD_STATS / FD_LASTAT) and hands over only the last iteration, which does
+// not look ahead.  An even number either way: the launches alternate between the two copies of the poses.
+static int fe_run_length(bool fe, int fd_m0, int B, int L) {
+  if (!fe) return 0;
+  if (fd_m0 > 0 && ((B - 1) & ~1) >= 4) return (B - 1) & ~1;
+  return std::max(0, B - L - 1) & ~1;
+}
+static bool fe_run_is_deep(bool fe, int fd_m0, int B) { return fe && fd_m0 > 0 && ((B - 1) & ~1) >= 4; }
+
+static void enqueue_fe_deep(dpgo_team_t *t, const LaunchCtx &c, int m0, int nfe, int B, int L, const std::function<int(int)> &sel_at,
                             NestState *nest_own, NestState *const nest_fe[2]) {
   const dpgo_params_t &p = t->prm;
   int nblk_all = 0;
@@ -1189,7 +1200,8 @@ static void enqueue_fe_deep(dpgo_team_t *t, const LaunchCtx &c, int m0, int nfe,
   launch_step_fd(c, m0, s0, s0, s0, s0, p.rgd_stepsize, p.num_robots, p.restart_interval, nest_own, nest_fe[1], 0, FD_W, pacc[0], pacc[1]);
   launch_step_fd(c, m0, s0, s0, s1, s0, p.rgd_stepsize, p.num_robots, p.restart_interval, nest_own, nest_fe[1], 0, FD_P | FD_W, pacc[1], pacc[0]);
   for (int rep = 0; rep < nfe; ++rep) {
-    const int flags = FD_IN | (rep + 1 < nfe ? FD_P : 0) | (rep + 2 < nfe ? FD_W : 0) | (rep + 3 < nfe ? FD_Y : 0);
+    const int flags = FD_IN | (rep + 1 < nfe ? FD_P : 0) | (rep + 2 < nfe ? FD_W : 0) | (rep + 3 < nfe ? FD_Y : 0) |
+                      (rep >= B - L ? FD_STATS : 0) | ((rep + 1 < B && rep + 1 >= B - L) ? FD_LASTAT : 0);
     launch_step_fd(c, m0, sel_at(rep), sel_at(rep + 1), sel_at(rep + 2), sel_at(rep + 3), p.rgd_stepsize, p.num_robots,
                    p.restart_interval, rep == 0 ? nest_own : nest_fe[rep & 1], nest_fe[(rep + 1) & 1], rep & 1, flags,
                    pacc[rep & 1], pacc[(rep + 1) & 1]);
@@ -1262,10 +1274,10 @@ static int team_run_impl(dpgo_team_t *t, int iters, bool prepare_only) {
       const int L = std::min(B, (int)t->sched.size());
       // iterations [0, nfe): one launch each (they are the ones that leave nothing behind: ahead == 3); an even number,
       // so that the poses end in the primary arrays
-      const int nfe = fe ? (std::max(0, B - L - 1) & ~1) : 0;
+      const int nfe = fe_run_length(fe, fd_m0, B, L);
       NestState *nest_own = t->d_nest_all.p, *nest_fe[2] = {t->d_nest_all.p + na, t->d_nest_all.p + 2 * na};
-      const bool deep = fd_m0 > 0 && nfe >= 4;
-      if (deep) enqueue_fe_deep(t, c, fd_m0, nfe, sel_at, nest_own, nest_fe);
+      const bool deep = fe_run_is_deep(fe, fd_m0, B);
+      if (deep) enqueue_fe_deep(t, c, fd_m0, nfe, B, L, sel_at, nest_own, nest_fe);
       for (int rep = deep ? nfe : 0; rep < B; ++rep) {
         const int ahead = (rep + 1 < B ? 3 : 0) | ((rep + 1 < B && rep + 1 >= B - L) ? 4 : 0) | (rep >= B - L ? 8 : 0);
         if (rep < nfe) {
@@ -1334,7 +1346,7 @@ static int team_run_impl(dpgo_team_t *t, int iters, bool prepare_only) {
       batch = fusedn + (restart ? 1 : 0);
       hipGraphExec_t ge = nullptr;
       // (prepared graphs are the ones a run will ask for: with the one-launch iterations if this team may take the lock)
-      const bool fe = fe_ok && fusedn > (int)t->sched.size() + 2;
+      const bool fe = fe_ok && (fd_m0 > 0 ? fusedn >= 6 : fusedn > (int)t->sched.size() + 2);
       const int grc = graph_for(restart, fusedn, cur_iter, fe, &ge);
       if (grc) return grc;
       if (prepare_only) {
@@ -1346,12 +1358,12 @@ static int team_run_impl(dpgo_team_t *t, int iters, bool prepare_only) {
       }
       ++t->epoch;
       HIPC(hipGraphLaunch(ge, t->stream));
-      const int nfe_run = fe ? (std::max(0, fusedn - std::min(fusedn, (int)t->sched.size()) - 1) & ~1) : 0;
+      const int nfe_run = fe_run_length(fe, fd_m0, fusedn, std::min(fusedn, (int)t->sched.size()));
       t->counters[7] += nfe_run;  // one-launch iterations
       {
         const int P_ = (int)t->sched.size(), it0 = t->iter;
         const std::function<int(int)> sel_run = [&](int rep) { return t->sched[(size_t)((it0 + rep) % P_)]; };
-        if (fd_m0 > 0 && nfe_run >= 4) { t->counters[8] += nfe_run; t->counters[9] += nfe_run; }  // ... deep-carried: every one of them
+        if (fe_run_is_deep(fe, fd_m0, fusedn)) { t->counters[8] += nfe_run; t->counters[9] += nfe_run; }  // ... deep-carried: every one of them
         else
         for (int q = 0; q < nfe_run; ++q) t->counters[8] += (fe_carry_flags(t, q, nfe_run, sel_run) & FE_CARRY_IN) ? 1 : 0;  // ... with carried rows
       }

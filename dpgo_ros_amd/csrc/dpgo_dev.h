@@ -155,10 +155,14 @@ constexpr int LOOKAHEAD_MAX_AGENTS = 8;  // look-ahead Nesterov steps locate a p
 struct FeBases {
   const double *ybase[LOOKAHEAD_MAX_AGENTS];
   int npose[LOOKAHEAD_MAX_AGENTS];
+  double *part[LOOKAHEAD_MAX_AGENTS];  // the agents' partial-sum scratch (step_deep.hip: the look-aheads that leave a status)
 };
 
 // deep-carried one-launch iteration (step_deep.hip): what a launch needs of the agents one and two iterations ahead (by value)
 constexpr int FD_IN = 1, FD_P = 2, FD_W = 4, FD_Y = 8;
+// ... and what the last iterations of a run leave for a status query (k_precond's ahead bits 3 and 2): FD_STATS -- this step
+// leaves its X2 snapshot and |X - XPrev|^2 (PART_B[2]); FD_LASTAT -- the look-aheads leave XPrev and |Y' - X|^2 per pose (PART_D)
+constexpr int FD_STATS = 16, FD_LASTAT = 32;
 struct FdNext {
   // d = the agent of the next iteration: the private part of its product is formed here
   const double *Md;            // its dense inverse

@@ -311,6 +311,7 @@ __global__ __launch_bounds__(512) void k_step_fd(TeamDev *team, int sel, int nex
   __shared__ double Es[FE_MAX_EDGES * (4 * R + 16)];
   __shared__ double tl_x[2 * 4 * R], tl_v[2 * 4 * R], tl_y[2 * 4 * R], tl_s[2 * 16];
   __shared__ double Ex[2 * 3 * 4 * R];
+  __shared__ double Psh[2 * 4 * R], tl_rel[2];  // XPrev of the two poses, their |X - XPrev|^2 (steps that leave statistics)
   __shared__ int sy[FD_SY_COUNT];
   FD_TRACE_DECL
   FD_STAMP(0);
@@ -441,11 +442,12 @@ __global__ __launch_bounds__(512) void k_step_fd(TeamDev *team, int sel, int nex
     // operands of the tail (the lanes of wave 4 that will hold them; wave 5's copies are never used)
     const int tl = tid - 256 - 64 * g;
     const size_t own_off = (size_t)((tl >= 4 * R) ? max(pj1, 0) : pj0) * 4 * R + (size_t)(tl % (4 * R));
-    double pre_x = 0, pre_v = 0, pre_y = 0;
+    double pre_x = 0, pre_v = 0, pre_y = 0, pre_p = 0;
     if (tl < npose * 4 * R) {
       pre_x = gp(Xr)[own_off];
       pre_v = gp(ag.buf[B_V])[own_off];
       pre_y = gp(Yr)[own_off];
+      pre_p = gp(ag.buf[B_XPREV])[own_off];
     }
     const NestState ns = nest_src[sel];
     __builtin_amdgcn_s_setprio(3);  // (the chain's instructions go first: the streamers' product shares the LDS with it)
@@ -492,7 +494,7 @@ __global__ __launch_bounds__(512) void k_step_fd(TeamDev *team, int sel, int nex
     fd_wait(&sy[FD_SY_D], 2);
     FD_STAMP(4);
     fd_cur_product<R, M0, NC>(cu, vs, red, tid - 256);
-    if (tl >= 0 && tl < npose * 4 * R) { Ysh[tl] = pre_x; Esh[0][tl] = pre_v; Esh[1][tl] = pre_y; }
+    if (tl >= 0 && tl < npose * 4 * R) { Ysh[tl] = pre_x; Esh[0][tl] = pre_v; Esh[1][tl] = pre_y; Psh[tl] = pre_p; }
     FD_STAMP(5);
     fd_signal(&sy[FD_SY_F]);
     if (g == 1) {
@@ -550,6 +552,8 @@ __global__ __launch_bounds__(512) void k_step_fd(TeamDev *team, int sel, int nex
     const bool restart_now = nn.restart_now, restart_next = nn.restart_next;
     const double nest_gamma = nn.nest_gamma, ahead_alpha = nn.ahead_alpha;
     const bool ahead_opt = next_sel == sel;
+    const bool stats = in && (flags & FD_STATS) != 0, lastat = in && (flags & FD_LASTAT) != 0;
+    if (ln < 2) tl_rel[ln] = 0.0;
     // ---- the step of the workgroup's two poses: one pose on 16 lanes, the pose in LDS (k_step_fe's tail, device_math.h
     // lane-parallel forms: bitwise the serial routines)
     {
@@ -567,6 +571,23 @@ __global__ __launch_bounds__(512) void k_step_fd(TeamDev *team, int sel, int nex
         lanes_sync();
         qf_lanes<R>(xs, Ss, s);
         FD_STAMP(7);
+        if (stats) {
+          // what k_precond's bit 3 leaves: the snapshot the closing statistics evaluate, |X - XPrev|^2 of the pose (one lane,
+          // the serial loop's order)
+          if (h0) gp(ag.buf[B_X2])[o + i0] = xs[i0];
+          if (h1) gp(ag.buf[B_X2])[o + i1] = xs[i1];
+          if (s == 0) {
+            const double *p0 = Psh + lp * 4 * R;
+            double rel = 0;
+#pragma unroll
+            for (int i = 0; i < 4 * R; ++i) { const double d = xs[i] - p0[i]; rel += d * d; }
+            tl_rel[lp] = rel;
+          }
+        }
+        if (lastat) {
+          if (h0) gp(ag.buf[B_XPREV])[o + i0] = xs[i0];
+          if (h1) gp(ag.buf[B_XPREV])[o + i1] = xs[i1];
+        }
         const bool reset = restart_now;
         if (reset) {
           if (h0) vsv[i0] = xs[i0];
@@ -591,6 +612,7 @@ __global__ __launch_bounds__(512) void k_step_fd(TeamDev *team, int sel, int nex
             if (!ahead_opt) { Yw[o + i1] = xs[i1]; vsv[i1] = xs[i1]; }
             else Yw[o + i1] = reset ? xs[i1] : y0[i1];
           }
+          if (lastat && !ahead_opt && s == 0) gp(ag.part)[PART_D + (lp ? pj1 : pj0)] = 0.0;
         } else {
           if (h0) ys[i0] = (1.0 - ahead_alpha) * xs[i0] + ahead_alpha * vsv[i0];
           if (h1) ys[i1] = (1.0 - ahead_alpha) * xs[i1] + ahead_alpha * vsv[i1];
@@ -599,11 +621,24 @@ __global__ __launch_bounds__(512) void k_step_fd(TeamDev *team, int sel, int nex
           FD_STAMP(9);
           if (h0 && in) { Yw[o + i0] = ys[i0]; Xw[o + i0] = ys[i0]; }
           if (h1 && in) { Yw[o + i1] = ys[i1]; Xw[o + i1] = ys[i1]; }
+          if (lastat && !ahead_opt && s == 0) {  // look-ahead steps leave |Y' - X|^2 per pose
+            double rel2 = 0;
+#pragma unroll
+            for (int i = 0; i < 4 * R; ++i) { const double d = ys[i] - xs[i]; rel2 += d * d; }
+            gp(ag.part)[PART_D + (lp ? pj1 : pj0)] = rel2;
+          }
         }
         lanes_sync();
         if (h0 && in) ag.buf[B_V][o + i0] = vsv[i0];
         if (h1 && in) ag.buf[B_V][o + i1] = vsv[i1];
       }
+    }
+    if (stats) {
+      // (k_precond: the two poses' sums through wave_sum, lane 0 stores)
+      WSYNC();
+      double rl = (ln < npose) ? tl_rel[ln] : 0.0;
+      rl = wave_sum(rl);
+      if (ln == 0 && own) gp(ag.part)[PART_B + (size_t)bx * PART_STRIDE + 2] = rl;
     }
     FD_STAMP(15);
     FD_FLUSH();
@@ -722,7 +757,15 @@ __global__ __launch_bounds__(512) void k_step_fd(TeamDev *team, int sel, int nex
     __builtin_amdgcn_s_setprio(0);
     const FdNest nn = fd_nest(ns, num_robots, restart_interval);
     if (lact) {
-      const bool st = in;
+      const bool st = in, lastat = in && (flags & FD_LASTAT) != 0;
+      double *pa_ = fb.part[0];
+#pragma unroll
+      for (int k = 1; k < LOOKAHEAD_MAX_AGENTS; ++k) pa_ = (a == k) ? fb.part[k] : pa_;
+      if (lastat) {
+        double *xprev = yp - (size_t)(B_Y - B_XPREV) * vlen;
+#pragma unroll
+        for (int i = 0; i < 4 * R; ++i) gp(xprev)[o + i] = la_x[i];
+      }
       if (nn.restart_next) {
         // (X stays; Y = V = X unless the agent optimizes next -- then Y stays too: both are carried into the other copy)
 #pragma unroll
@@ -731,11 +774,18 @@ __global__ __launch_bounds__(512) void k_step_fd(TeamDev *team, int sel, int nex
           if (!la_opt) { if (st) { oY[o + i] = la_x[i]; oV[o + i] = la_x[i]; } la_v[i] = la_x[i]; }
           else if (st) oY[o + i] = yr[o + i];
         }
+        if (lastat && !la_opt) gp(pa_)[PART_D + la_pose] = 0.0;
       } else {
         double y[4 * R];
 #pragma unroll
         for (int i = 0; i < 4 * R; ++i) y[i] = (1.0 - nn.ahead_alpha) * la_x[i] + nn.ahead_alpha * la_v[i];
         polar_inplace<R>(y);
+        if (lastat && !la_opt) {
+          double r2 = 0;
+#pragma unroll
+          for (int i = 0; i < 4 * R; ++i) { const double d = y[i] - la_x[i]; r2 += d * d; }
+          gp(pa_)[PART_D + la_pose] = r2;
+        }
 #pragma unroll
         for (int i = 0; i < 4 * R; ++i) { if (st) { oY[o + i] = y[i]; oX[o + i] = y[i]; } la_x[i] = y[i]; }
       }
@@ -840,7 +890,7 @@ void launch_step_fd(const LaunchCtx &c, int m0, int sel, int next_sel, int next2
   for (int k = 0; k < c.num_agents; ++k) nblk_all = std::max(nblk_all, (c.host_agents[k].N4 + 7) / 8);
   const int grid = (nblk_all + 7) / 8 * 8;
   FeBases fb = {};
-  for (int k = 0; k < c.num_agents && k < LOOKAHEAD_MAX_AGENTS; ++k) { fb.ybase[k] = c.host_agents[k].buf[B_Y]; fb.npose[k] = c.host_agents[k].n; }
+  for (int k = 0; k < c.num_agents && k < LOOKAHEAD_MAX_AGENTS; ++k) { fb.ybase[k] = c.host_agents[k].buf[B_Y]; fb.npose[k] = c.host_agents[k].n; fb.part[k] = c.host_agents[k].part; }
   FdNext nx = {};
   nx.Md = dd.M; nx.N4d = dd.N4; nx.nblk_d = (dd.N4 + 7) / 8; nx.Gd = dd.buf[B_CARRY_G];
   for (int i = 0; i < 32; ++i) { nx.ord_d[i] = dd.fe_ord[i]; nx.ord_e[i] = de.fe_ord[i]; }

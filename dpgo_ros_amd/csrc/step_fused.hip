@@ -769,7 +769,7 @@ void launch_step_fe(const LaunchCtx &c, int sel, int next_sel, double step, int 
   const int grid = ((d.N4 + 7) / 8 + 7) / 8 * 8;
   const int flags = carry & (FE_CARRY_W | FE_CARRY_Y);
   FeBases fb = {};
-  for (int k = 0; k < c.num_agents && k < LOOKAHEAD_MAX_AGENTS; ++k) { fb.ybase[k] = c.host_agents[k].buf[B_Y]; fb.npose[k] = c.host_agents[k].n; }
+  for (int k = 0; k < c.num_agents && k < LOOKAHEAD_MAX_AGENTS; ++k) { fb.ybase[k] = c.host_agents[k].buf[B_Y]; fb.npose[k] = c.host_agents[k].n; fb.part[k] = c.host_agents[k].part; }
 #define FE_LAUNCH(RR, WW)                                                                                              \
   hipLaunchKernelGGL((k_step_fe<RR, WW>), dim3(grid), dim3(512), 0, c.stream, c.agents, c.team, sel, next_sel, step, num_robots, \
                      restart_interval, nest_src, nest_dst, parity, d, next2_sel, flags, dn, fb)

@@ -68,7 +68,7 @@ def test_one_launch_iterations_bitwise_equal_the_two_launch_sequence(robots, r, 
     # the number of one-launch iterations even (they alternate between the two copies of the poses)
     P = robots
     expect = sum(max(0, b - P - 1) & ~1 for b in (23, 256, 44, 64, 7, 129))
-    assert tb.counters()[7] == expect, (tb.counters()[7], expect)
+    assert tb.counters()[7] == expect or (deep and robots == 5), (tb.counters()[7], expect)
     # carried rows: all but the first two one-launch iterations of every graph find the row products of their agent formed
     # by the launch before (round robin over >= 3 robots: three different agents in a row)
     carried = sum(max(0, (max(0, b - P - 1) & ~1) - 2) for b in (23, 256, 44, 64, 7, 129))
@@ -77,8 +77,10 @@ def test_one_launch_iterations_bitwise_equal_the_two_launch_sequence(robots, r, 
     assert (tb.counters()[9] > 0) == (deep and robots == 5)
     if tb.counters()[9] > 0:
         # every one-launch iteration of a deep-carried run consumes what the three launches before it left (the run opens
-        # with k_fd_prime and two producing launches)
-        assert tb.counters()[8] == expect and tb.counters()[9] == expect, (tb.counters()[8], tb.counters()[9], expect)
+        # with k_fd_prime and two producing launches), and the run reaches up to the last iteration of the graph: the
+        # launches of the last period leave the statistics a status query reads themselves
+        deep_expect = sum((b - 1) & ~1 if ((b - 1) & ~1) >= 4 else max(0, b - P - 1) & ~1 for b in (23, 256, 44, 64, 7, 129))
+        assert tb.counters()[7] == deep_expect and tb.counters()[8] == deep_expect and tb.counters()[9] == deep_expect
     else:
         assert tb.counters()[8] == carried and tb.counters()[9] == 0, (tb.counters()[8], carried)
     assert np.isclose(ta.cost(), tb.cost(), rtol=0, atol=0)
@@ -155,7 +157,8 @@ def test_one_launch_iterations_across_weight_updates():
         assert wa == wb
         for k in ta.ids:
             assert np.array_equal(ta.agents[k].measurements()["weight"], tb.agents[k].measurements()["weight"])
-    assert tb.counters()[7] == 3 * ((60 - 5 - 1) & ~1) and ta.counters()[7] == 0
+    # (deep-carried runs reach up to the last iteration of a graph: 58 of 60)
+    assert tb.counters()[7] == tb.counters()[9] == 3 * ((60 - 1) & ~1) and ta.counters()[7] == 0
     ta.close()
     tb.close()
 
@@ -257,7 +260,8 @@ def test_carried_rows_can_be_switched_off_and_change_no_bit():
         tb.synchronize()
         for k in ta.ids:
             assert np.array_equal(ta.agents[k].get_X(), tb.agents[k].get_X()), (iters, k)
-    assert ta.counters()[7] == tb.counters()[7] > 0
+    # (tb runs deep-carried: its runs reach further into every graph)
+    assert 0 < ta.counters()[7] <= tb.counters()[7]
     assert ta.counters()[8] == 0 and tb.counters()[8] > 0
     ta.close()
     tb.close()
