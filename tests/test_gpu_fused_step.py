@@ -88,6 +88,46 @@ def test_one_launch_iterations_bitwise_equal_the_two_launch_sequence(robots, r, 
     tb.close()
 
 
+def test_deep_carried_iterations_with_agents_of_different_sizes():
+    """sphere2500 cut to its first 2489 poses over 5 robots: four agents of 498 poses (249 workgroups) and one of 497 (249, the
+    last one with a single pose) next to launches sized for the largest -- workgroups that own none of the current agent's
+    columns still take their share of the other agents' work (step_deep.hip, `own`).  Bitwise the two-launch sequence,
+    restarts every 7 iterations"""
+    m, _, _ = load("sphere2500", 1)
+    n = 2489
+    m = m[(m["p1"] < n) & (m["p2"] < n)].copy()
+    mp = O.partition(m, n, 5)
+    kw = dict(RGD, restart_interval=7)
+    T, Y = O.odometry_init(m, n), O.fixed_stiefel(5)
+    teams = []
+    old = {k: os.environ.get(k) for k in ("DPGO_FUSED_EVAL", "DPGO_FE_MIN_N")}
+    try:
+        os.environ["DPGO_FE_MIN_N"] = "32"
+        for fe in ("0", "1"):
+            os.environ["DPGO_FUSED_EVAL"] = fe
+            t = capi.Team.from_measurements(mp.view(capi.MEAS_DTYPE), capi.default_params(r=5, num_robots=5, **kw))
+            t.set_initial(T, Y)
+            teams.append(t)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    for iters in (37, 256, 12, 101):
+        for t in teams:
+            t.run(iters)
+            t.synchronize()
+        for k in teams[0].ids:
+            assert np.array_equal(teams[0].agents[k].get_X(), teams[1].agents[k].get_X()), (iters, k)
+        sa, sb = teams[0].agents[4].status(), teams[1].agents[4].status()
+        assert sa.iteration_number == sb.iteration_number and sa.relative_change == sb.relative_change
+    assert teams[1].counters()[9] > 0
+    assert len({teams[1].agents[k].n for k in teams[1].ids}) > 1
+    for t in teams:
+        t.close()
+
+
 def test_one_launch_iterations_follow_the_oracle():
     """120 iterations of the bench configuration against the live oracle (the two-launch sequence is held to the same
     bound in test_gpu_parity.py)"""
