@@ -532,9 +532,10 @@ def gnc_leg(capi):
 
 # HBM traffic per launch (KB) from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in
 # separate runs of this command, profiles/collect.sh; FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md)
-PMC = {"source": "profiles/r05_pmc_fetch.md, profiles/r05_pmc_write.md",
+PMC = {"source": "profiles/r06_pmc_fetch.md, profiles/r06_pmc_write.md (k_step_fd); profiles/r05_pmc_*.md (the others)",
        "dense": {"step": (16541.5, 851.7), "apply": (16068.2, 85.9),       # k_precond<5,3,2048,false,true,true>, k_precond<5,0,2048,false,false,false>
-                 "fused_step": (17108.2, 1049.1)},                          # k_step_fe<5,0> (carried rows; <5,5>, every workgroup forming the rows: 18160.0, 997.6)
+                 "fused_step": (17108.2, 1049.1),                           # k_step_fe<5,0> (carried rows; <5,5>, every workgroup forming the rows: 18160.0, 997.6)
+                 "deep_step": (18510.0, 3512.7)},                           # k_step_fd<5,24> (round 6: + the partial sums, 2.6 MB out and back in)
        "two_level": {"step": (5469.3, 891.0), "apply": (4937.6, 125.3)}}   # k_precond<5,3,0,true,true,true>, k_precond<5,0,0,true,false,false>
 
 
@@ -586,7 +587,7 @@ def roofline_leg(team, agent_id, form="dense"):
                                     "products the previous launch left + preconditioner stream + RGD step + Nesterov V + "
                                     "look-ahead Nesterov step of all agents + the row products of the next agent)"),
                          "achieved": o_bytes / (o_ms * 1e-3) / 1e9, "bytes_per_launch": o_bytes, "us_per_launch": o_ms * 1e3,
-                         "traffic": (2 * PMC[form]["fused_step"][0] + PMC[form]["fused_step"][1]) * 1024,
+                         "traffic": (2 * PMC[form]["deep_step" if deep else "fused_step"][0] + PMC[form]["deep_step" if deep else "fused_step"][1]) * 1024,
                          "timing_note": "HIP events around 500 eager one-launch iterations (dispatch to dispatch); "
                                         "bytes_per_launch = M + the vectors of the step + the sparse operator and the "
                                         "neighbours' poses of the evaluation, once"})

@@ -1150,7 +1150,7 @@ static bool fused_eval_eligible(dpgo_team_t *t) {
 
 // The deep-carried form (step_deep.hip) may serve this team: the private part of every agent's product is formed one launch
 // early, its row products two, its evaluation point three -- so every FOUR consecutive agents of the schedule differ; the
-// first chunks of every agent's order are private (their number, 24 or 20, is returned; 0: not this team); an agent's
+// first 24 chunks of every agent's order are private (24 is returned; 0: not this team); an agent's
 // public poses fit two waves, its shared edges three edge slots of 64, and the partial sums have their buffers.
 static int fe_deep_m0(dpgo_team_t *t) {
   if (!t->use_fe_deep || !t->use_fe_carry || !fused_eval_eligible(t)) return 0;
@@ -1168,7 +1168,8 @@ static int fe_deep_m0(dpgo_team_t *t) {
   }
   for (auto &a : t->ag)
     if ((total - a->n + nblk_all - 1) / nblk_all > 64) return 0;
-  const int m0 = step_fd_pick_m0(min_priv);
+  int m0 = step_fd_pick_m0(min_priv);
+  if (const char *e = std::getenv("DPGO_FD_M0")) { const int f = std::atoi(e); if (f > 0 && f <= min_priv && step_fd_pick_m0(f) == f) m0 = f; }  // (experiments)
   if (m0 == 0) return 0;
   const size_t want = (size_t)2 * nblk_all * t->prm.r * 256;
   if (t->d_fd_pacc.n < want && t->d_fd_pacc.alloc(want)) return 0;

@@ -871,7 +871,10 @@ __global__ __launch_bounds__(64) void k_fd_prime(const AgentDev *__restrict__ ag
 // the deep-carried form needs: every agent's first M0 chunks private, its public poses on two waves (<= 128), its shared
 // edges on two waves' two slots (<= FE_MAX_EDGES, all co-resident: fe_code_ok), its rows in the lane-ordered copy
 int step_fd_pick_m0(int min_private_chunks) {
-  const int want[] = {24, 20};  // (fewer private chunks: the waves of the chain would carry too much of the stream)
+  // (fewer private chunks: the waves of the chain would carry too much of the stream.  Measured, round 6: M0 = 20 spills 14
+  // registers at r = 5 and runs 15.7 us per launch on sphere2500 / 5 -- slower than round 5's form (14.3); M0 = 16 spills 35:
+  // 0.0182 ms per iteration on sphere2500 / 6 against 0.0142)
+  const int want[] = {24};
   for (int m : want) if (min_private_chunks >= m) return m;
   return 0;
 }
@@ -903,7 +906,6 @@ void launch_step_fd(const LaunchCtx &c, int m0, int sel, int next_sel, int next2
 #define FD_LAUNCH_M(RR)                                   \
   switch (m0) {                                           \
     case 24: FD_LAUNCH(RR, 24); break;                    \
-    case 20: FD_LAUNCH(RR, 20); break;                    \
     default: break;                                       \
   }
   switch (c.r) {

@@ -36,6 +36,12 @@ for iters in (23, 300, 64, 7, 129, 41):
     print("iters %4d: %s (max diff %.3e)  counters fe %d carried %d deep %d" % (iters, "bitwise" if worst == 0 else "DIFFERENT", worst, tb.counters()[7], tb.counters()[8], tb.counters()[9]), flush=True)
 print("cost two-launch %.15g deep %.15g" % (ta.cost(), tb.cost()))
 print("RESULT", "OK" if ok else "MISMATCH")
+if True:
+    tc = team(True, deep=False)
+    for nm, tt in (("deep", tb), ("round-5 form", tc)):
+        tt.prepare(4000); tt.synchronize()
+        for rep in range(2):
+            a0 = time.perf_counter(); tt.run(4000); tt.synchronize(); print("%s ms/iter %.5f (deep-carried launches %d)" % (nm, (time.perf_counter() - a0) / 4000 * 1e3, tt.counters()[9]))
 if robots == 5 and r == 5:
     tb.prepare(4000); tb.synchronize()
     for rep in range(3):

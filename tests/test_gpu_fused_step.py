@@ -72,7 +72,7 @@ def test_one_launch_iterations_bitwise_equal_the_two_launch_sequence(robots, r, 
     # carried rows: all but the first two one-launch iterations of every graph find the row products of their agent formed
     # by the launch before (round robin over >= 3 robots: three different agents in a row)
     carried = sum(max(0, (max(0, b - P - 1) & ~1) - 2) for b in (23, 256, 44, 64, 7, 129))
-    # the deep-carried form needs the first 20 (or 24) 64-row chunks of every agent's order to be private: 500-pose agents
+    # the deep-carried form needs the first 24 64-row chunks of every agent's order to be private: 500-pose agents
     # of sphere2500 have 24 .. 28, 416-pose agents 18, 312-pose agents 12 -- those keep round 5's form
     assert (tb.counters()[9] > 0) == (deep and robots == 5)
     if tb.counters()[9] > 0:
@@ -89,12 +89,12 @@ def test_one_launch_iterations_bitwise_equal_the_two_launch_sequence(robots, r, 
 
 
 def test_deep_carried_iterations_with_agents_of_different_sizes():
-    """sphere2500 cut to its first 2489 poses over 5 robots: four agents of 498 poses (249 workgroups) and one of 497 (249, the
-    last one with a single pose) next to launches sized for the largest -- workgroups that own none of the current agent's
-    columns still take their share of the other agents' work (step_deep.hip, `own`).  Bitwise the two-launch sequence,
-    restarts every 7 iterations"""
+    """sphere2500 cut to its first 2494 poses over 5 robots: four agents of 499 poses (250 workgroups, the last with a single
+    pose) and one of 498 (249 workgroups); every agent keeps 24 private chunks.  The launches are sized for the largest agent:
+    a workgroup that owns none of the current agent's columns still takes its share of the other agents' work
+    (step_deep.hip, `own`).  Bitwise the two-launch sequence, restarts every 7 iterations"""
     m, _, _ = load("sphere2500", 1)
-    n = 2489
+    n = 2494
     m = m[(m["p1"] < n) & (m["p2"] < n)].copy()
     mp = O.partition(m, n, 5)
     kw = dict(RGD, restart_interval=7)
