@@ -92,6 +92,19 @@ def test_bad_rank_rejected():
         capi.Team(p, [0])
 
 
+def test_robust_cost_parameters_are_validated():
+    """the six cost types of src/PGOAgentROSNode.cpp:178-188 have C-ABI values in the facade's enum order; their thresholds
+    default to the library's ([UPSTREAM-RECALL] 10 / 3); anything else is refused before a device is looked for"""
+    assert (capi.COST_L2, capi.COST_L1, capi.COST_HUBER, capi.COST_TLS, capi.COST_GM, capi.COST_GNC_TLS) == (0, 1, 2, 3, 4, 5)
+    p = capi.default_params(r=5, num_robots=1)
+    assert p.tls_threshold == 10.0 and p.huber_threshold == 3.0
+    for bad in (dict(robust_cost_type=6), dict(robust_cost_type=-1), dict(robust_cost_type=capi.COST_TLS, tls_threshold=0.0),
+                dict(robust_cost_type=capi.COST_HUBER, huber_threshold=-1.0)):
+        with pytest.raises(capi.DpgoError) as e:
+            capi.Team(capi.default_params(r=5, num_robots=1, **bad), [0])
+        assert "robust_cost_type" in str(e.value) or "threshold" in str(e.value)
+
+
 def test_rank_exchange_fails_loudly_without_a_device():
     """no CPU fallback in the multi-rank path either: without a HIP device a communicator cannot be created (the error says
     why), and the planning layer -- host arithmetic -- rejects a rank outside its world"""
