@@ -118,6 +118,7 @@ dpgo_team_t *dpgo_team_create(int device, const dpgo_params_t *p, int num_local,
     if (const char *e6 = std::getenv("DPGO_FE_MIN_N")) t->fe_min_n = std::max(32, std::atoi(e6));
     if (const char *e7 = std::getenv("DPGO_FE_CARRY")) t->use_fe_carry = (e7[0] == '0') ? 0 : 1;
     if (const char *e8 = std::getenv("DPGO_FE_DEEP")) t->use_fe_deep = (e8[0] == '0') ? 0 : 1;
+    if (const char *e9 = std::getenv("DPGO_FE_PERSIST")) t->use_fe_persist = (e9[0] == '1') ? 1 : 0;
     if (t->d_nest_all.alloc(3 * std::max(1, num_local)) ||
         hipMemset(t->d_nest_all.p, 0, sizeof(NestState) * 3 * std::max(1, num_local)) != hipSuccess) {
       delete t; set_err("hand-off state allocation failed"); return nullptr;
@@ -162,7 +163,8 @@ static int check_exchange_error(dpgo_team_t *t) {
   for (auto &kv : t->graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);
   t->graphs.clear(); t->graph_flip.clear();
   set_err("an in-kernel exchange timed out (code " + std::to_string(code) + ": 2 hand-off of the one-launch RTR solve, 3 two-level "
-          "preconditioner, 4 mailbox of the device-side UPDATE token): the iterates since the last successful synchronisation are invalid");
+          "preconditioner, 4 mailbox of the device-side UPDATE token, 5 hand-off of the persistent RGD launch): the iterates since the last "
+          "successful synchronisation are invalid");
   return DPGO_ERR;
 }
 
@@ -1173,6 +1175,7 @@ static int fe_deep_m0(dpgo_team_t *t) {
   if (m0 == 0) return 0;
   const size_t want = (size_t)2 * nblk_all * t->prm.r * 256;
   if (t->d_fd_pacc.n < want && t->d_fd_pacc.alloc(want)) return 0;
+  if (t->use_fe_persist && !t->d_pd_bar.p && t->d_pd_bar.alloc(PD_BAR_WORDS)) return 0;
   return m0;
 }
 
@@ -1190,9 +1193,18 @@ static int fe_run_length(bool fe, int fd_m0, int B, int L) {
 }
 static bool fe_run_is_deep(bool fe, int fd_m0, int B) { return fe && fd_m0 > 0 && ((B - 1) & ~1) >= 4; }
 
-static void enqueue_fe_deep(dpgo_team_t *t, const LaunchCtx &c, int m0, int nfe, int B, int L, const std::function<int(int)> &sel_at,
+static void enqueue_fe_deep(dpgo_team_t *t, const LaunchCtx &c, int m0, int nfe, int B, int L, int iter0, const std::function<int(int)> &sel_at,
                             NestState *nest_own, NestState *const nest_fe[2]) {
   const dpgo_params_t &p = t->prm;
+  if (t->use_fe_persist && t->d_pd_bar.p) {
+    // the same run as ONE persistent launch (step_persist.hip): the points of the first three agents, the counters zeroed,
+    // then the two producing iterations and the nfe real ones behind grid hand-offs inside the kernel
+    launch_fd_prime(c, sel_at(0), sel_at(1), sel_at(2), t->max_n, p.num_robots, p.restart_interval, nest_own);
+    (void)hipMemsetAsync(t->d_pd_bar.p, 0, sizeof(unsigned long long) * PD_BAR_WORDS, c.stream);
+    launch_step_pd(c, m0, t->d_sched.p, (int)t->sched.size(), iter0 % (int)t->sched.size(), nfe, B, L, p.rgd_stepsize, p.num_robots,
+                   p.restart_interval, nest_own, nest_fe[nfe & 1], t->d_pd_bar.p, t->h_bar_err);
+    return;
+  }
   int nblk_all = 0;
   for (auto &a : t->ag) nblk_all = std::max(nblk_all, (4 * a->n + 7) / 8);
   double *pacc[2] = {t->d_fd_pacc.p, t->d_fd_pacc.p + (size_t)nblk_all * p.r * 256};
@@ -1250,6 +1262,14 @@ static int team_run_impl(dpgo_team_t *t, int iters, bool prepare_only) {
   // so they need neither each other's company on the device nor its lock
   const bool fe_ok = pipelined && graphable && fused_eval_eligible(t);
   const int fd_m0 = fe_ok ? fe_deep_m0(t) : 0;  // > 0: runs of one-launch iterations take the deep-carried form (step_deep.hip)
+  if (t->use_fe_persist && fd_m0 > 0 && !prepare_only && !acquire_fused_rtr_lock(t)) {
+    // the persistent form waits for its own workgroups: like the one-launch RTR solve it runs only under the device's lock
+    // (given back wherever the stream is known to have drained); without it the team keeps the per-launch form for good
+    t->use_fe_persist = 0;
+    for (auto &kv : t->graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);
+    t->graphs.clear();
+    t->graph_flip.clear();
+  }
   auto graph_for = [&](bool lead, int B, int iter0, bool fe, hipGraphExec_t *out) -> int {
     const int phase = bake ? iter0 % P : -1;
     const int base = ((((lead ? 1 : 0) + 2 * B) * 16 + phase + 1) * 2 + (fe ? 1 : 0)) * 2;
@@ -1278,7 +1298,7 @@ static int team_run_impl(dpgo_team_t *t, int iters, bool prepare_only) {
       const int nfe = fe_run_length(fe, fd_m0, B, L);
       NestState *nest_own = t->d_nest_all.p, *nest_fe[2] = {t->d_nest_all.p + na, t->d_nest_all.p + 2 * na};
       const bool deep = fe_run_is_deep(fe, fd_m0, B);
-      if (deep) enqueue_fe_deep(t, c, fd_m0, nfe, B, L, sel_at, nest_own, nest_fe);
+      if (deep) enqueue_fe_deep(t, c, fd_m0, nfe, B, L, iter0, sel_at, nest_own, nest_fe);
       for (int rep = deep ? nfe : 0; rep < B; ++rep) {
         const int ahead = (rep + 1 < B ? 3 : 0) | ((rep + 1 < B && rep + 1 >= B - L) ? 4 : 0) | (rep >= B - L ? 8 : 0);
         if (rep < nfe) {

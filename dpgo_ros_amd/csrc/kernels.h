@@ -69,6 +69,13 @@ int step_fe_carry_max_poses();
 // dpgo_dev.h).  m0: leading chunks of every agent's order that are private (step_fd_pick_m0 of the team's minimum; 0: the
 // team cannot run it).  pacc_in / pacc_out: the partial sums this launch continues / leaves, [workgroup][r][256]
 int step_fd_pick_m0(int min_private_chunks);
+// step_persist.hip: K deep-carried iterations (and the two producing ones in front of them) in ONE persistent launch.
+// d_sched / sched_len / it0: the team's schedule on the device and where the run starts in it; B, L: the graph's length and
+// the schedule period (which iterations leave their statistics); bar: >= 18 * 16 zeroed 64-bit words; err: the team's
+// pinned error word (5: a hand-off of this kernel timed out)
+constexpr int PD_BAR_WORDS = 18 * 16;
+void launch_step_pd(const LaunchCtx &c, int m0, const int *d_sched, int sched_len, int it0, int K, int B, int L, double step, int num_robots,
+                    int restart_interval, const NestState *nest_src, NestState *nest_dst, unsigned long long *bar, int *err);
 void launch_fd_prime(const LaunchCtx &c, int s0, int s1, int s2, int max_n, int num_robots, int restart_interval, const NestState *nest_src);
 void launch_step_fd(const LaunchCtx &c, int m0, int sel, int next_sel, int next2_sel, int next3_sel, double step, int num_robots,
                     int restart_interval, const NestState *nest_src, NestState *nest_dst, int parity, int flags,

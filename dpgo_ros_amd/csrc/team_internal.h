@@ -282,6 +282,8 @@ struct dpgo_team {
   int use_fused_eval = 1;  // DPGO_FUSED_EVAL=0: every pipelined iteration takes the two-launch sequence
   int use_fe_carry = 1;    // DPGO_FE_CARRY=0: every one-launch iteration forms the row products of its agent itself (no carried rows)
   int use_fe_deep = 1;     // DPGO_FE_DEEP=0: no deep-carried one-launch iterations (step_deep.hip): k_step_fe serves every run
+  int use_fe_persist = 0;  // DPGO_FE_PERSIST=1: a run of deep-carried iterations is ONE persistent launch (step_persist.hip)
+  dpgo_host::DevBuf<unsigned long long> d_pd_bar;  // its hand-off counters (zeroed in front of every launch)
   dpgo_host::DevBuf<double> d_fd_pacc;  // their partial sums: two alternating buffers of [workgroup][r][256] doubles
   int fe_min_n = 0;        // smallest agent the one-launch iteration serves (DPGO_FE_MIN_N; any n >= 32 works, bitwise).  0 = by
                            // measurement: 32 where every iteration finds carried rows (round 5), else 449 -- without carried rows:

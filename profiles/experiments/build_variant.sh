@@ -8,7 +8,7 @@ out=profiles/experiments/build/$name
 mkdir -p $out
 src=dpgo_ros_amd/csrc
 objs=""
-for f in spmm precond step_fused step_deep rtr_fused linesearch pose_ops dense_inverse twolevel assembly solve capi chordal; do
+for f in spmm precond step_fused step_deep step_persist rtr_fused linesearch pose_ops dense_inverse twolevel assembly solve capi chordal; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=on $flags -c $src/$f.hip -o $out/$f.o &
   objs="$objs $out/$f.o"
 done

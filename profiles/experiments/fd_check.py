@@ -13,7 +13,8 @@ r = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 RGD = dict(method=1, acceleration=1, rgd_stepsize=0.2, rgd_use_preconditioner=1, restart_interval=20)
 
 
-def team(fused, deep=True):
+def team(fused, deep=True, persist=False):
+    os.environ["DPGO_FE_PERSIST"] = "1" if persist else "0"
     os.environ["DPGO_FUSED_EVAL"] = "1" if fused else "0"
     os.environ["DPGO_FE_DEEP"] = "1" if deep else "0"
     os.environ["DPGO_FE_MIN_N"] = "32"
@@ -23,7 +24,8 @@ def team(fused, deep=True):
     return t
 
 
-ta, tb = team(False), team(True)
+PERSIST = os.environ.get("FD_CHECK_PERSIST") == "1"
+ta, tb = team(False), team(True, persist=PERSIST)
 ok = True
 for iters in (23, 300, 64, 7, 129, 41):
     ta.run(iters); ta.synchronize(); tb.run(iters); tb.synchronize()

@@ -128,6 +128,33 @@ def test_deep_carried_iterations_with_agents_of_different_sizes():
         t.close()
 
 
+def test_persistent_launch_of_deep_carried_iterations_is_bitwise_too():
+    """DPGO_FE_PERSIST=1 (opt-in, csrc/step_persist.hip): a run of deep-carried iterations as ONE persistent launch -- grid
+    hand-offs between the iterations, everything published write-through -- leaves the bits of the two-launch sequence.
+    (Measured slower than one launch per iteration, DESIGN.md section 4: it is not the default.)"""
+    old = os.environ.get("DPGO_FE_PERSIST")
+    os.environ["DPGO_FE_PERSIST"] = "1"
+    try:
+        tb = _team("sphere2500", 5, True, **RGD)
+    finally:
+        if old is None:
+            os.environ.pop("DPGO_FE_PERSIST", None)
+        else:
+            os.environ["DPGO_FE_PERSIST"] = old
+    ta = _team("sphere2500", 5, False, **RGD)
+    for iters in (23, 300, 7, 64):
+        for t in (ta, tb):
+            t.run(iters)
+            t.synchronize()
+        for k in ta.ids:
+            assert np.array_equal(ta.agents[k].get_X(), tb.agents[k].get_X()), (iters, k)
+        sa, sb = ta.agents[ta.ids[-1]].status(), tb.agents[tb.ids[-1]].status()
+        assert sa.iteration_number == sb.iteration_number and sa.relative_change == sb.relative_change
+    assert tb.counters()[9] > 0
+    ta.close()
+    tb.close()
+
+
 def test_one_launch_iterations_follow_the_oracle():
     """120 iterations of the bench configuration against the live oracle (the two-launch sequence is held to the same
     bound in test_gpu_parity.py)"""
