@@ -63,6 +63,12 @@ namespace dpgo {
     if (blockIdx.x == DPGO_FE_TRACE_BLOCK) for (int k_ = 0; k_ < 16; ++k_) ag.part[PART_E + 4000 * PART_STRIDE + w_ * 16 + k_] = (double)fd_stamps[w_ * 16 + k_]; \
     if (w_ == 4) { ag.part[PART_E + (4100 + 2 * (int)blockIdx.x) * PART_STRIDE] = (double)fd_stamps[4 * 16]; ag.part[PART_E + (4100 + 2 * (int)blockIdx.x) * PART_STRIDE + 1] = (double)fd_stamps[4 * 16 + 15]; } \
     if (w_ == 0) { ag.part[PART_E + (4100 + 2 * (int)blockIdx.x) * PART_STRIDE + 2] = (double)fd_stamps[15]; } } } while (0)
+#elif defined(DPGO_FD_ENDS)
+// -DDPGO_FD_ENDS: nothing but the time every wave of workgroup 100 leaves, straight to memory (one store per wave: the
+// build runs within 0.1 us of the product build) -- PART_E words [4000 + 16 w + 15]; wave 4 also leaves its start [64]
+#define FD_TRACE_DECL
+#define FD_STAMP(k) do { if ((k) == 0 && blockIdx.x == 100 && threadIdx.x == 256) ag.part[PART_E + 4000 * PART_STRIDE + 64] = (double)wall_clock64(); } while (0)
+#define FD_FLUSH() do { if (blockIdx.x == 100 && (threadIdx.x & 63) == 0) ag.part[PART_E + 4000 * PART_STRIDE + (threadIdx.x >> 6) * 16 + 15] = (double)wall_clock64(); } while (0)
 #else
 #define FD_TRACE_DECL
 #define FD_STAMP(k) do { } while (0)
