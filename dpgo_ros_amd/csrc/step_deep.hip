@@ -25,9 +25,10 @@
 //
 // Eight waves, eight roles, ONE workgroup barrier.  A wave that requests the stream stays at the issue of its loads until
 // most of them have landed (step_fused.hip), and every s_barrier behind that point waits for it -- the critical chain
-// (gradient of the public poses -> product over the last chunks -> tail) must not meet the streamers again.  So only
-// barrier A is an s_barrier (it orders the requests: everything the chain needs is in the CU's memory queue in front of
-// the stream); every later hand-off is a counter in LDS that only the waves concerned wait at:
+// (gradient of the public poses -> product over the last chunks -> tail) must not meet the streamers again.  So the only
+// s_barrier stands at the kernel's head (it zeroes the counters); every hand-off is a counter in LDS that only the waves
+// concerned wait at -- the first of them (RQ) orders the requests: waves 4-7 count themselves in behind their last load, the
+// streamers release the stream when all four have (everything the chain needs is in the CU's memory queue in front of it):
 //     waves 0-3  streamers: the carried gradient of c's last chunks -> LDS (C); then the whole P part on their own (N: their
 //                own hand-off; they start their product behind F, the chain's -- the two share the LDS)
 //     waves 4-5  the chain: one public pose per lane (G_j from LDS, projection; rows -> LDS: D) -> their quarters of the
@@ -37,8 +38,8 @@
 //     wave 7     coefficients of the shared edges -> LDS (E); its quarter of the product (F); look-ahead of the other
 //                agents' poses + Y
 //   Waves 4-7 run at raised priority while they are on the chain.
-// Where a launch's 12.5 us go (profiles/r06_deep_carry.md): 2.8 until everything is requested (134 KB per CU in front of
-// barrier A -- every workgroup finishes ALL public poses itself, the price of no exchange inside the launch), 1.0 until the
+// Where a launch's 12.6 us go (profiles/r06_deep_carry.md): 2.8 until everything is requested (134 KB per CU in front of
+// the stream -- every workgroup finishes ALL public poses itself, the price of no exchange inside the launch), 1.0 until the
 // edges' operands have landed, 1.9 gradient of the public poses, 0.9 product over the last chunks, 0.5 reduction, 3.2 tail,
 // 2.2 from the last workgroup's end to the next launch's first instruction.  The stream (128 KB per CU) lands under all
 // of it: the streamers are done 3 us before the tail.

@@ -7,6 +7,11 @@
 namespace dpgo {
 
 constexpr int FD_KC = 2048;
+// build switches of the experiments recorded in profiles/r06_deep_carry.md (every one measured SLOWER than the defaults but
+// the last): DPGO_FD_HEAD -- 16-byte loads per lane of the next agent's slab requested in front of the request hand-off;
+// DPGO_FD_GC_LATE -- the carried rows of the current agent requested behind it; DPGO_FD_PACC_WT -- partial sums stored
+// write-through; DPGO_FD_E_EARLY -- wave 7 hands the coefficients over before it requests its look-ahead operands;
+// DPGO_FD_KA_PREFETCH (default on) -- one word of every line of the kernel arguments touched up front
 #ifndef DPGO_FD_HEAD
 #define DPGO_FD_HEAD 0
 #endif
@@ -22,7 +27,7 @@ constexpr int FD_KC = 2048;
 #ifndef DPGO_FD_KA_PREFETCH
 #define DPGO_FD_KA_PREFETCH 1
 #endif
-constexpr int FD_HEAD = DPGO_FD_HEAD;  // 16-byte loads per lane of the NEXT agent's private chunks requested in front of barrier A
+constexpr int FD_HEAD = DPGO_FD_HEAD;  // 16-byte loads per lane of the NEXT agent's private chunks requested in front of the request hand-off
 
 // hand-offs between the waves of the workgroup: counters in LDS (see the head of the file)
 enum { FD_SY_C = 0, FD_SY_E, FD_SY_D, FD_SY_F, FD_SY_N, FD_SY_RQ, FD_SY_COUNT = 8 };
@@ -67,10 +72,10 @@ __device__ __forceinline__ int fd_pos_off(const unsigned char *ord, int pose) {
 //     lives comes from the edge's 16-bit code (frame | agent << 12) in the descriptor -- scalar registers and a select
 //     chain, no descriptor round trip (k_step_fe).  (Measured and dropped, round 6: 64 consecutive 16-byte parts per load --
 //     a quarter of the cache-line requests -- with the address handed from the edge's lane by ds_bpermute: the wave reached
-//     barrier A 1.5 us LATER; and with the codes looked up per part: scalar loads inside every trip, 4 us later.)
+//     the request hand-off 1.5 us LATER; and with the codes looked up per part: scalar loads inside every trip, 4 us later.)
 //   * wave 7, coefficients: the packed copy [edge][16] (AgentDev::fe_coef) read straight through, 1 KB per load -- 100
 //     cache-line requests where one lane per edge asked for 800 (the kernel's first microseconds are a count of such
-//     requests: ~4400 per CU in front of barrier A, and a CU's texture path takes about one a cycle).
+//     requests: ~4400 per CU in front of the stream, and a CU's texture path takes about one a cycle).
 template <int R>
 struct FdXn {
   double2 v[3][2 * R];
