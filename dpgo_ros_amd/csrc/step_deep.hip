@@ -233,7 +233,11 @@ __global__ __launch_bounds__(512) void k_step_fd(TeamDev *team, int sel, int nex
     {
       const double *Wc = ag.buf[B_CARRY_W], *Xc = ag.buf[B_CARRY_X];
 #pragma unroll
-      for (int i = 0; i < 4 * R; ++i) { w[i] = gp(Wc)[(size_t)i * npub + pqc]; x[i] = gp(Xc)[(size_t)i * npub + pqc]; }
+      for (int i = 0; i < 2 * R; ++i) {
+        // ([entry pair][public pose][2]: one 16-byte load per pair, a wave's 64 lanes one contiguous KB -- half the requests)
+        const double2 tw = ld2(Wc + ((size_t)i * npub + pqc) * 2), tx = ld2(Xc + ((size_t)i * npub + pqc) * 2);
+        w[2 * i] = tw.x; w[2 * i + 1] = tw.y; x[2 * i] = tx.x; x[2 * i + 1] = tx.y;
+      }
     }
     FD_STAMP(14);
     FdCur<R, NC> cu;
@@ -331,8 +335,8 @@ __global__ __launch_bounds__(512) void k_step_fd(TeamDev *team, int sel, int nex
       }
       const bool wr = pv && (flags & FD_W);
       if (wr && qi >= 0) {  // (a public pose: its launch finishes it -- row product and point, [entry][public pose])
-        gp(nx.We)[(size_t)we * nx.npub_e + qi] = acc;
-        gp(nx.Xe)[(size_t)we * nx.npub_e + qi] = xe_;
+        gp(nx.We)[((size_t)(we >> 1) * nx.npub_e + qi) * 2 + (we & 1)] = acc;
+        gp(nx.Xe)[((size_t)(we >> 1) * nx.npub_e + qi) * 2 + (we & 1)] = xe_;
       }
       if (wls < 3) { Ex[wls * 4 * R + we] = acc; Ex[3 * 4 * R + wls * 4 * R + we] = xe_; }
       WSYNC();

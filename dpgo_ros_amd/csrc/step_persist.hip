@@ -263,7 +263,11 @@ __global__ __launch_bounds__(512) void k_step_pd(const AgentDev *__restrict__ ag
       {
         const double *Wc = ag.buf[B_CARRY_W], *Xc = ag.buf[B_CARRY_X];
 #pragma unroll
-        for (int i = 0; i < 4 * R; ++i) { w[i] = ldc(Wc + (size_t)i * npub + pqc); x[i] = ldc(Xc + (size_t)i * npub + pqc); }
+        for (int i = 0; i < 2 * R; ++i) {
+          // ([entry pair][public pose][2]: one 16-byte load per pair, a wave's 64 lanes one contiguous KB -- half the requests)
+          w[2 * i] = ldc(Wc + ((size_t)i * npub + pqc) * 2); w[2 * i + 1] = ldc(Wc + ((size_t)i * npub + pqc) * 2 + 1);
+          x[2 * i] = ldc(Xc + ((size_t)i * npub + pqc) * 2); x[2 * i + 1] = ldc(Xc + ((size_t)i * npub + pqc) * 2 + 1);
+        }
       }
       FdCur<R, NC> cu;
       pd_cur_request<R, M0, NC>(ag, pacc_lds, bx, tid - 256, cu);
@@ -356,8 +360,8 @@ __global__ __launch_bounds__(512) void k_step_pd(const AgentDev *__restrict__ ag
         }
         const bool wr = pv && (flags & FD_W);
         if (wr && qi >= 0) {  // (a public pose: its launch finishes it -- row product and point, [entry][public pose])
-          st_c(age.buf[B_CARRY_W] + (size_t)we * age.npub + qi, acc);
-          st_c(age.buf[B_CARRY_X] + (size_t)we * age.npub + qi, xe_);
+          st_c(age.buf[B_CARRY_W] + ((size_t)(we >> 1) * age.npub + qi) * 2 + (we & 1), acc);
+          st_c(age.buf[B_CARRY_X] + ((size_t)(we >> 1) * age.npub + qi) * 2 + (we & 1), xe_);
         }
         if (wls < 3) { Ex[wls * 4 * R + we] = acc; Ex[3 * 4 * R + wls * 4 * R + we] = xe_; }
         WSYNC();
