@@ -1210,8 +1210,7 @@ static void enqueue_fe_deep(dpgo_team_t *t, const LaunchCtx &c, int m0, int nfe,
   double *pacc[2] = {t->d_fd_pacc.p, t->d_fd_pacc.p + (size_t)nblk_all * p.r * 256};
   const int s0 = sel_at(0), s1 = sel_at(1), s2 = sel_at(2);
   launch_fd_prime(c, s0, s1, s2, t->max_n, p.num_robots, p.restart_interval, nest_own);
-  launch_step_fd(c, m0, s0, s0, s0, s0, p.rgd_stepsize, p.num_robots, p.restart_interval, nest_own, nest_fe[1], 0, FD_W, pacc[0], pacc[1]);
-  launch_step_fd(c, m0, s0, s0, s1, s0, p.rgd_stepsize, p.num_robots, p.restart_interval, nest_own, nest_fe[1], 0, FD_P | FD_W, pacc[1], pacc[0]);
+  launch_fd_open(c, m0, s0, s1, pacc[0]);
   for (int rep = 0; rep < nfe; ++rep) {
     const int flags = FD_IN | (rep + 1 < nfe ? FD_P : 0) | (rep + 2 < nfe ? FD_W : 0) | (rep + 3 < nfe ? FD_Y : 0) |
                       (rep >= B - L ? FD_STATS : 0) | ((rep + 1 < B && rep + 1 >= B - L) ? FD_LASTAT : 0);
@@ -2119,8 +2118,7 @@ int dpgo_team_time_kernel(dpgo_team_t *t, int id, int which, int reps, double *a
       double *pacc[2] = {t->d_fd_pacc.p, t->d_fd_pacc.p + (size_t)nblk_all * p.r * 256};
       const int s0 = sel_at(0), s1 = sel_at(1), s2 = sel_at(2);
       launch_fd_prime(cc, s0, s1, s2, mn, p.num_robots, p.restart_interval, nest_own);
-      launch_step_fd(cc, fd_m0, s0, s0, s0, s0, p.rgd_stepsize, p.num_robots, p.restart_interval, nest_own, nest_fe[1], 0, FD_W, pacc[0], pacc[1]);
-      launch_step_fd(cc, fd_m0, s0, s0, s1, s0, p.rgd_stepsize, p.num_robots, p.restart_interval, nest_own, nest_fe[1], 0, FD_P | FD_W, pacc[1], pacc[0]);
+      launch_fd_open(cc, fd_m0, s0, s1, pacc[0]);
       for (int k = 0; k < total_reps; ++k) {
         if (k == 8) HIPC(hipEventRecord(e0, t->stream));
         const int flags = FD_IN | (k + 1 < total_reps ? FD_P : 0) | (k + 2 < total_reps ? FD_W : 0) | (k + 3 < total_reps ? FD_Y : 0);

@@ -76,6 +76,8 @@ int step_fd_pick_m0(int min_private_chunks);
 constexpr int PD_BAR_WORDS = 18 * 16;
 void launch_step_pd(const LaunchCtx &c, int m0, const int *d_sched, int sched_len, int it0, int K, int B, int L, double step, int num_robots,
                     int restart_interval, const NestState *nest_src, NestState *nest_dst, unsigned long long *bar, int *err);
+// behind k_fd_prime: the row products of the run's first two agents and the private partial sums of the first
+void launch_fd_open(const LaunchCtx &c, int m0, int s0, int s1, double *pacc_out);
 void launch_fd_prime(const LaunchCtx &c, int s0, int s1, int s2, int max_n, int num_robots, int restart_interval, const NestState *nest_src);
 void launch_step_fd(const LaunchCtx &c, int m0, int sel, int next_sel, int next2_sel, int next3_sel, double step, int num_robots,
                     int restart_interval, const NestState *nest_src, NestState *nest_dst, int parity, int flags,

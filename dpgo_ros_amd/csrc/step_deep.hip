@@ -21,7 +21,8 @@
 //     P   stream the M0 private chunks of M_d against carry-G(d): PACC(d)                    (consumed by launch k + 1)
 //     W   row products of e at its evaluation point, their tangent projection: carry-W/X/G(e) (k + 1: P, k + 2: IN)
 //     Y   the point f will be evaluated at: three look-ahead maps in a row, carry-Y(f)        (k + 1: W)
-// A run opens with k_fd_prime (the points of sel(0), sel(1), sel(2)) and two launches that only produce (W; then P + W).
+// A run opens with k_fd_prime (the points of sel(0), sel(1), sel(2)), k_fd_rows (W for sel(0) and sel(1)) and k_fd_partial
+// (P for sel(0)): three short launches.
 //
 // Eight waves, eight roles, ONE workgroup barrier.  A wave that requests the stream stays at the issue of its loads until
 // most of them have landed (step_fused.hip), and every s_barrier behind that point waits for it -- the critical chain
@@ -682,6 +683,105 @@ __global__ __launch_bounds__(64) void k_fd_prime(const AgentDev *__restrict__ ag
   for (int i = 0; i < 4 * R; ++i) gp(ag.buf[B_CARRY_Y])[o + i] = x[i];
 }
 
+// The two producers a run opens with, as launches of their own (they used to be two full k_step_fd launches whose iteration
+// part computed on nothing and stored nothing: 12 us each where these take a few).
+// k_fd_rows: W for the agents sel(0) and sel(1) (blockIdx.y) from the points k_fd_prime left -- the W wave of k_step_fd,
+// expression for expression, one wave per workgroup's share of the agent's poses.
+template <int R>
+__global__ __launch_bounds__(64) void k_fd_rows(const AgentDev *__restrict__ agents, int e0, int e1, int nblk_all) {
+  const AgentDev &age = agents[blockIdx.y == 0 ? e0 : e1];
+  const int bx = (int)blockIdx.x, ln = (int)threadIdx.x;
+  __shared__ double Ex[2 * 3 * 4 * R];
+  const int npw = (age.n + nblk_all - 1) / nblk_all;  // (<= 2)
+  const int wls = ln / (4 * R), we = ln - wls * (4 * R);
+  const int pw = bx * npw + wls;
+  const bool pv = wls < 3 && wls < npw && pw < age.n;
+  const int pwc = pv ? pw : 0;
+  const int wtile = pwc >> 6, wpl = pwc & 63, wdn = age.soa_w;
+  int ii[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) ii[u] = gp(age.soa_col)[((size_t)wtile * wdn + min(u, wdn - 1)) * 64 + wpl];
+  const int qi = gp(age.pub_index)[pwc];
+  const int c = we / R, a = we - c * R;
+  const double *__restrict__ Y2 = age.buf[B_CARRY_Y];
+  double xv[8][4], bv[8][4];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const double *xp = Y2 + (size_t)4 * R * ii[u] + a;
+    const double *bp = age.soa_val + ((size_t)wtile * wdn + min(u, wdn - 1)) * 1024 + (2 * c) * 128 + 2 * wpl;
+    xv[u][0] = gp(xp)[0]; xv[u][1] = gp(xp)[R]; xv[u][2] = gp(xp)[2 * R]; xv[u][3] = gp(xp)[3 * R];
+    bv[u][0] = gp(bp)[0]; bv[u][1] = gp(bp)[1]; bv[u][2] = gp(bp)[128]; bv[u][3] = gp(bp)[129];
+  }
+  const double xe_ = gp(Y2)[(size_t)4 * R * pwc + we];
+  double acc = 0.0;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const double t = fma4(xv[u][0], bv[u][0], xv[u][1], bv[u][1], xv[u][2], bv[u][2], xv[u][3], bv[u][3], acc);
+    acc = (u < wdn) ? t : acc;
+  }
+  if (pv && qi >= 0) {
+    gp(age.buf[B_CARRY_W])[((size_t)(we >> 1) * age.npub + qi) * 2 + (we & 1)] = acc;
+    gp(age.buf[B_CARRY_X])[((size_t)(we >> 1) * age.npub + qi) * 2 + (we & 1)] = xe_;
+  }
+  if (wls < 3) { Ex[wls * 4 * R + we] = acc; Ex[3 * 4 * R + wls * 4 * R + we] = xe_; }
+  WSYNC();
+  if (pv && we == 0) {
+    double ww[4 * R], xx[4 * R];
+#pragma unroll
+    for (int i = 0; i < 4 * R; ++i) { ww[i] = Ex[wls * 4 * R + i]; xx[i] = Ex[3 * 4 * R + wls * 4 * R + i]; }
+    tangent_inplace<R>(xx, ww);
+    double *Gn = age.buf[B_CARRY_G] + fd_pos_off<R>(age.fe_ord, pw);
+#pragma unroll
+    for (int i = 0; i < 4 * R; ++i) gp(Gn)[i] = ww[i];
+  }
+}
+
+// k_fd_partial: P for the agent sel(0) -- the streamers of k_step_fd, expression for expression: the first M0 chunks of its M
+// against the private rows of its carried gradient, the partial sums of every workgroup into pacc_out
+template <int R, int M0>
+__global__ __launch_bounds__(256) void k_fd_partial(const AgentDev *__restrict__ agents, int d, double *__restrict__ pacc_out) {
+  const AgentDev &agd = agents[d];
+  const int hb = (int)blockIdx.x;
+  const int bx = (hb % 8) * ((int)gridDim.x / 8) + hb / 8;
+  const int tid = threadIdx.x;
+  const int N4d = agd.N4;
+  if (bx >= (N4d + 7) / 8) return;
+  __shared__ double vs[M0 * 64 * R];
+  const int cg = (tid >> 5) & 7, kl = tid & 31;
+  const int cold = 8 * bx + cg;
+  const double *Md = agd.M + (size_t)((cold < N4d) ? cold : 0) * N4d;
+  constexpr int NGN = (M0 * 64 * R / 2 + 255) / 256;
+  double2 gn[NGN];
+#pragma unroll
+  for (int u = 0; u < NGN; ++u) gn[u] = ld2(agd.buf[B_CARRY_G] + min(2 * (tid + 256 * u), M0 * 64 * R - 2));
+  double2 mn[M0];
+#pragma unroll
+  for (int i = 0; i < M0; ++i) mn[i] = ld2_nt(Md + min(2 * kl + 64 * (int)agd.fe_ord[i], N4d - 2));
+#pragma unroll
+  for (int u = 0; u < NGN; ++u) {
+    const int tt = 2 * (tid + 256 * u);
+    if (tt < M0 * 64 * R) *reinterpret_cast<double2 *>(&vs[tt]) = gn[u];
+  }
+  lds_barrier();
+  double acc[R];
+#pragma unroll
+  for (int a = 0; a < R; ++a) acc[a] = 0;
+#pragma unroll
+  for (int i = 0; i < M0; ++i) {
+    const int k = 2 * kl + 64 * i;
+    double wv[2 * R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      const double2 t2 = *reinterpret_cast<const double2 *>(&vs[k * R + 2 * q]);
+      wv[2 * q] = t2.x; wv[2 * q + 1] = t2.y;
+    }
+#pragma unroll
+    for (int a = 0; a < R; ++a) acc[a] = __builtin_fma(wv[R + a], mn[i].y, __builtin_fma(wv[a], mn[i].x, acc[a]));
+  }
+#pragma unroll
+  for (int a = 0; a < R; ++a) gp(pacc_out)[((size_t)bx * R + a) * 256 + tid] = acc[a];
+}
+
 // the deep-carried form needs: every agent's first M0 chunks private, its public poses on two waves (<= 128), its shared
 // edges on two waves' two slots (<= FE_MAX_EDGES, all co-resident: fe_code_ok), its rows in the lane-ordered copy
 int step_fd_pick_m0(int min_private_chunks) {
@@ -696,6 +796,23 @@ int step_fd_pick_m0(int min_private_chunks) {
 void launch_fd_prime(const LaunchCtx &c, int s0, int s1, int s2, int max_n, int num_robots, int restart_interval, const NestState *nest_src) {
   DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL((k_fd_prime<R>), dim3((max_n + 63) / 64, 3), dim3(64), 0, c.stream, c.agents, s0, s1, s2,
                                           num_robots, restart_interval, nest_src));
+}
+
+// what a run opens with behind k_fd_prime: the row products of sel(0) and sel(1), then the private partial sums of sel(0)
+void launch_fd_open(const LaunchCtx &c, int m0, int s0, int s1, double *pacc_out) {
+  int nblk_all = 0;
+  for (int k = 0; k < c.num_agents; ++k) nblk_all = std::max(nblk_all, (c.host_agents[k].N4 + 7) / 8);
+  const int gridp = ((c.host_agents[s0].N4 + 7) / 8 + 7) / 8 * 8;
+  if (m0 != 24) return;
+  switch (c.r) {
+    case 3: hipLaunchKernelGGL((k_fd_rows<3>), dim3(nblk_all, 2), dim3(64), 0, c.stream, c.agents, s0, s1, nblk_all);
+            hipLaunchKernelGGL((k_fd_partial<3, 24>), dim3(gridp), dim3(256), 0, c.stream, c.agents, s0, pacc_out); break;
+    case 4: hipLaunchKernelGGL((k_fd_rows<4>), dim3(nblk_all, 2), dim3(64), 0, c.stream, c.agents, s0, s1, nblk_all);
+            hipLaunchKernelGGL((k_fd_partial<4, 24>), dim3(gridp), dim3(256), 0, c.stream, c.agents, s0, pacc_out); break;
+    case 5: hipLaunchKernelGGL((k_fd_rows<5>), dim3(nblk_all, 2), dim3(64), 0, c.stream, c.agents, s0, s1, nblk_all);
+            hipLaunchKernelGGL((k_fd_partial<5, 24>), dim3(gridp), dim3(256), 0, c.stream, c.agents, s0, pacc_out); break;
+    default: break;
+  }
 }
 
 // sel .. : agents c, d, e, f of the head of the file (d, e, f: any valid agent where the flag is off)

@@ -83,7 +83,6 @@ struct FdXn {
 
 template <int R>
 __device__ __forceinline__ void fd_xn_request(const AgentDev &ag, const FeBases &fb, int parity, int ln, FdXn<R> &xr) {
-  const int nsh = ag.nshared;
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
     {  // (every slot, edges or not: loads under a wave-uniform `if` leave the compiler without a count of what is in flight
