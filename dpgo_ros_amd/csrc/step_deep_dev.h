@@ -110,7 +110,8 @@ __device__ __forceinline__ void fd_xn_request(const AgentDev &ag, const FeBases 
 template <int R>
 __device__ __forceinline__ void fd_xn_to_lds(const AgentDev &ag, int ln, const FdXn<R> &xr, double *Es) {
   constexpr int EPE = 4 * R + 16;
-  const int nsh = ag.nshared;
+  int nsh = ag.nshared;
+  asm volatile("" : "+v"(nsh));  // (see fd_cf_to_lds)
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
     if (64 * q < nsh && 64 * q + ln < nsh) {
@@ -135,7 +136,11 @@ __device__ __forceinline__ void fd_cf_request(const AgentDev &ag, int ln, FdCf &
 template <int R>
 __device__ __forceinline__ void fd_cf_to_lds(const AgentDev &ag, int ln, const FdCf &cr, double *Es) {
   constexpr int EPE = 4 * R + 16;
-  const int nit = ag.nshared * 8;
+  // (held in a register: left as an expression of the descriptor the count was RE-READ from the kernel arguments in front of
+  // every one of the 20 stores below, each time behind a wait for the scalar load and the LDS store before it -- 0.9 us
+  // between this wave's last request and the hand-off the chain waits for; read off the ISA, round 6)
+  int nit = ag.nshared * 8;
+  asm volatile("" : "+v"(nit));
 #pragma unroll
   for (int j = 0; j < FdCf::TRIPS; ++j) {
     const int t = 64 * j + ln;
