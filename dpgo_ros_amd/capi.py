@@ -697,8 +697,8 @@ class Team:
         return _chk(lib().dpgo_team_update_weights(self.h), "team_update_weights")
 
     def counters(self):
-        out = np.zeros(10)
-        lib().dpgo_team_get_counters(self.h, _d(out), 10)
+        out = np.zeros(11)
+        lib().dpgo_team_get_counters(self.h, _d(out), 11)
         return out
 
     def stream(self):

@@ -119,6 +119,7 @@ dpgo_team_t *dpgo_team_create(int device, const dpgo_params_t *p, int num_local,
     if (const char *e7 = std::getenv("DPGO_FE_CARRY")) t->use_fe_carry = (e7[0] == '0') ? 0 : 1;
     if (const char *e8 = std::getenv("DPGO_FE_DEEP")) t->use_fe_deep = (e8[0] == '0') ? 0 : 1;
     if (const char *e9 = std::getenv("DPGO_FE_PERSIST")) t->use_fe_persist = (e9[0] == '1') ? 1 : 0;
+    if (const char *e10 = std::getenv("DPGO_REPORT_TAIL")) t->use_report_tail = (e10[0] == '0') ? 0 : 1;
     if (t->d_nest_all.alloc(3 * std::max(1, num_local)) ||
         hipMemset(t->d_nest_all.p, 0, sizeof(NestState) * 3 * std::max(1, num_local)) != hipSuccess) {
       delete t; set_err("hand-off state allocation failed"); return nullptr;
@@ -463,15 +464,9 @@ static int finish_report(dpgo_team_t *t, Agent *a) {
 // right after iterate(false) (publishStatus: the status of the last iterate(true), the iteration number) comes from it;
 // the first getter that needs its payload (get*SharedPoseDictWithNeighbor from runOnce, :109-113) waits for it, by which
 // time it has usually landed.
-static int report_after_iterate(dpgo_team_t *t, Agent *a, bool did_opt, bool advance, bool upload, bool one_seq = false,
-                                bool whole_iterate_false = false, bool wait = true) {
-  const size_t B = (size_t)4 * t->prm.r;
-  const size_t npub = 2 * (size_t)a->n_pub_all * B;
-  const bool want_status = did_opt && !t->prm.status_every_iterate && (a->opt_rel_src == 1 || a->opt_rel_src == 5);
-  const bool tiles = a->opt_rel_src == 5;
-  const int scnt = want_status ? (tiles ? (a->n + 63) / 64 : precond_nblk(*a)) : 0;
-  const int ppb = 64 / t->prm.r, nb = (a->n + ppb - 1) / ppb;
-  const bool want_opt = did_opt && a->opt_pending_rgd;
+// the pinned image and the sequence words of an agent's reports
+static int report_prepare(dpgo_team_t *t, Agent *a) {
+  const size_t npub = 2 * (size_t)a->n_pub_all * 4 * t->prm.r;
   // (an earlier report nobody asked for is superseded: this one rewrites the same pinned image behind it on the stream;
   // the image may only be re-allocated once the stream is past the earlier kernel)
   if (a->rep.pending && 8 + npub > a->h_down.n && finish_report(t, a)) return DPGO_ERR;
@@ -483,6 +478,17 @@ static int report_after_iterate(dpgo_team_t *t, Agent *a, bool did_opt, bool adv
     a->report_seq = 0;
     *reinterpret_cast<volatile unsigned long long *>(a->h_down.p) = 0ull;
   }
+  return DPGO_OK;
+}
+
+static int report_after_iterate(dpgo_team_t *t, Agent *a, bool did_opt, bool advance, bool upload, bool one_seq = false,
+                                bool whole_iterate_false = false, bool wait = true) {
+  const bool want_status = did_opt && !t->prm.status_every_iterate && (a->opt_rel_src == 1 || a->opt_rel_src == 5);
+  const bool tiles = a->opt_rel_src == 5;
+  const int scnt = want_status ? (tiles ? (a->n + 63) / 64 : precond_nblk(*a)) : 0;
+  const int ppb = 64 / t->prm.r, nb = (a->n + ppb - 1) / ppb;
+  const bool want_opt = did_opt && a->opt_pending_rgd;
+  if (report_prepare(t, a)) return DPGO_ERR;
   int up0 = 0, up1 = 0;
   if (upload && stage_to_pinned(t, *a, &up0, &up1)) return DPGO_ERR;
   const unsigned long long expect = ++a->report_seq;
@@ -523,12 +529,37 @@ int dpgo_agent_iterate(dpgo_team_t *t, int id, int do_optimization) {
   // an accelerated iterate(false) is ONE launch (k_iterate_false): Nesterov step, staged poses, bookkeeping and report
   const bool one_launch = defer_upload && !t->prm.status_every_iterate;
   if (one_launch) a->rel_src = 0;
+  // iterate(true) with a local solve: the report is offered to the call's last launch (solve.hip takes it when that is the
+  // closing statistics evaluation of a fused RGD step; anything else -- RTR, a restart iteration, the line search -- leaves it,
+  // and k_report follows as a launch of its own)
+  const bool offer = opt && will_report && !t->prm.status_every_iterate && t->use_report_tail;
+  std::chrono::steady_clock::time_point tq0{};
+  if (offer) {
+    if (report_prepare(t, a)) return DPGO_ERR;
+    t->rep_offer = dpgo_team::ReportOffer();
+    t->rep_offer.valid = true;
+    dpgo::ReportTail &rt = t->rep_offer.rt;
+    rt.out = a->h_down.p; rt.frames = a->d_pub_all.p; rt.count = a->n_pub_all;
+    rt.seq = a->d_report_seq.p; rt.ticket = a->d_report_seq.p + 1; rt.expect = a->report_seq + 1;
+    tq0 = std::chrono::steady_clock::now();
+  }
   const int rc = one_launch ? 0 : enqueue_iterate(t, a->local, opt ? 1 : (do_optimization ? 2 : 0), will_report);
+  const bool folded = offer && t->rep_offer.taken;
+  t->rep_offer = dpgo_team::ReportOffer();
   if (rc) return rc;
   if (do_optimization) mark_optimized(t, *a, opt ? (a->rel_src == 1 ? 1 : 5) : 2, opt);
   a->iter++;
   if (t->prm.acceleration || opt) a->publish_requested = true;
-  if (will_report) {
+  if (folded) {
+    // (what report_after_iterate would have asked k_report for: the status of a fused step -- PART_B partials -- and the
+    // result of the RGD solve)
+    if (a->opt_rel_src != 1 || !a->opt_pending_rgd) { set_err("internal: folded report on a path that is not the fused RGD step"); return DPGO_ERR; }
+    a->rep.pending = true; a->rep.expect = ++a->report_seq; a->rep.epoch = t->epoch; a->rep.one_seq = false;
+    a->rep.want_status = true; a->rep.want_opt = true; a->rep.t_launch = tq0;
+    t->counters[10] += 1;
+    const int rr = finish_report(t, a);
+    if (rr) return rr;
+  } else if (will_report) {
     // (an accelerated iterate(false) leaves X = Y at every pose: one sequence crosses the bus)
     // (what updateNeighborPoses staged stays on the host across iterate(false) calls -- nothing reads the slabs until
     // this agent's next iterate(true), whose first launch scatters the latest value of every slot)
@@ -1989,7 +2020,7 @@ int dpgo_agent_read_partials(dpgo_team_t *t, int id, int offset, double *out, in
 
 int dpgo_team_get_counters(dpgo_team_t *t, double *out, int n) {
   for (auto &a : t->ag) if (refresh_rtr_result(t, *a)) return DPGO_ERR;
-  for (int k = 0; k < n && k < 10; ++k) out[k] = t->counters[k];
+  for (int k = 0; k < n && k < 11; ++k) out[k] = t->counters[k];
   return 0;
 }
 

@@ -425,10 +425,14 @@ __device__ __forceinline__ void tile_put(Tile<R> &t, int row, const double *v) {
 // sel == -2):  V = proj(V)  [= proj(V + gamma (X - Y))], then the periodic restart X = XPrev,
 // V = Y = X; partial [0] of PART_D = |X_new - XPrev|^2.  First kernel of an accelerated iteration:
 // publishes team->cur_sel.
-template <int R>
+// `hook` runs once behind the loads of the agent's X and V tiles (k_nest_pre places reads of pinned host memory there: memory
+// reads return in order, so issued in FRONT of the tiles' loads they would hold the step up for a PCIe round trip, issued
+// behind them they land while it runs).
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+template <int R, class Hook = NoHook>
 __device__ __forceinline__ void nest_pre_body(const AgentDev *__restrict__ agents, TeamDev *team, int sel, int only_agent,
                                               int num_robots, int restart_interval, int bx, int by, Tile<R> &TX,
-                                              Tile<R> &TV, int fused_restart = 0) {
+                                              Tile<R> &TV, int fused_restart = 0, Hook hook = Hook()) {
   // fused_restart bit 0: the pipelined RGD sequence takes a restart iteration as one plain step from X (the accelerated
   // solve that the un-fused path runs first, and discards, is skipped), so the selected agent only saves XPrev.
   // bit 1 (keep X): iterate(true) whose neighbour poses have not all arrived -- the local solve is skipped and X stays
@@ -449,6 +453,7 @@ __device__ __forceinline__ void nest_pre_body(const AgentDev *__restrict__ agent
   if (bx == 0 && tid == 0) ag.scal[6] = gamma;  // read by the fused RGD tail instead of the (mutable) NestState
   tile_in<R>(TX, ag.buf[B_X], j0, cnt, tid);
   tile_in<R>(TV, ag.buf[B_V], j0, cnt, tid);
+  hook();
   __syncthreads();
   tile_out<R>(TX, ag.buf[B_XPREV], j0, cnt, tid);
   const bool keep_x = (fused_restart & 2) != 0;

@@ -40,10 +40,25 @@ struct EvalOpts {
   int accel = 0, num_robots = 1, restart_interval = 1;
 };
 
+// The report of the per-agent API (k_report, pose_ops.hip) as the TAIL of an evaluation launch (k_eval_report): every
+// workgroup copies its share of the agent's public poses into the pinned image in front of its evaluation, the workgroup that
+// draws the last ticket sums the partials, advances the agent and writes the sequence word the host polls.
+struct ReportTail {
+  double *out = nullptr;        // pinned host image: [8 scalars][X of the public frames][Y likewise]
+  const int *frames = nullptr;  // the public frames, neighbour after neighbour
+  int count = 0;
+  int stat_off = 0, stat_cnt = 0, stat_stride = 0, opt_nb = 0;
+  unsigned long long *seq = nullptr, *ticket = nullptr;
+  unsigned long long expect = 0;  // the sequence number this report carries (the device's word + 1)
+  int ai = 0, advance = 0, accel = 0, num_robots = 1, restart_interval = 1;
+};
+
 // `sel`: local agent index, or -1 = the agent the device-side schedule selects this iteration
 void launch_buildG(const LaunchCtx &c, int sel, int max_npub, int aux, int pull);
 void launch_pull(const LaunchCtx &c, int dst, int nshared);
 void launch_eval(const LaunchCtx &c, int sel, int max_n, int xb, int egb, int gfb, int poff, const EvalOpts &o);
+void launch_eval_report(const LaunchCtx &c, int sel, int max_n, int xb, int egb, int gfb, int poff, const EvalOpts &o,
+                        const ReportTail &rt);
 size_t eval_staged_lds_bytes(int r, int cap);
 constexpr int EVS_STATIC_LDS = 8 * 1024;  // room left for k_eval_staged's static arrays under the device's LDS limit
 void launch_hess(const LaunchCtx &c, int sel, int max_n, int xb, int egb, int vb, int ob, int poff);

@@ -89,6 +89,38 @@ __device__ __forceinline__ void upload_slice(const AgentDev &ag, const int *slot
   }
 }
 
+// The same scatter with the Nesterov step of the launch BETWEEN its loads and its stores: the first (and, up to 8 poses per
+// lane, only) trip's reads cross PCIe while the step runs instead of in front of it.
+template <int R>
+struct UploadTrip { double v[8]; int sl[8]; };
+
+template <int R>
+__device__ __forceinline__ void upload_request(const int *slots, const double *in, int n0, int n1, int first, int stride,
+                                               UploadTrip<R> &tr) {
+  const int total = (n0 + n1) * 4 * R;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int t = min(first + u * stride, total - 1);
+    tr.v[u] = in[t];
+    tr.sl[u] = slots[t / (4 * R)];
+  }
+}
+
+template <int R>
+__device__ __forceinline__ void upload_commit(const AgentDev &ag, const int *slots, const double *in, int n0, int n1, int first,
+                                              int stride, const UploadTrip<R> &tr) {
+  const int total = (n0 + n1) * 4 * R;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int t = first + u * stride;
+    if (t < total) {
+      const int q = t / (4 * R), k = t - q * 4 * R;
+      ag.nbr[q < n0 ? 0 : 1][(size_t)tr.sl[u] * 4 * R + k] = tr.v[u];
+    }
+  }
+  upload_slice<R>(ag, slots, in, n0, n1, first + 8 * stride, stride);  // (more than 8 per lane: the rest in turn)
+}
+
 template <int R>
 __global__ __launch_bounds__(64) void k_nest_pre(const AgentDev *__restrict__ agents, TeamDev *team, int sel, int only_agent,
                                                  int num_robots, int restart_interval, int fused_restart, const int *up_slots,
@@ -96,10 +128,19 @@ __global__ __launch_bounds__(64) void k_nest_pre(const AgentDev *__restrict__ ag
   __shared__ Tile<R> TX, TV;
   // (per-agent API, iterate(true): the neighbour poses staged on the host since the agent's last block update are
   // scattered into its slabs here -- nothing in this launch reads them, the evaluation behind it does)
-  if (up_n0 + up_n1 > 0 && only_agent >= 0)
-    upload_slice<R>(agents[only_agent], up_slots, up_in, up_n0, up_n1, (int)blockIdx.x * 64 + (int)threadIdx.x, 64 * (int)gridDim.x);
+  const bool up = up_n0 + up_n1 > 0 && only_agent >= 0;
+  const int first = (int)blockIdx.x * 64 + (int)threadIdx.x, stride = 64 * (int)gridDim.x;
+  UploadTrip<R> tr;
+  bool requested = false;
+  auto request = [&]() {
+    if (up) { upload_request<R>(up_slots, up_in, up_n0, up_n1, first, stride, tr); requested = true; }
+  };
   nest_pre_body<R>(agents, team, sel, only_agent, num_robots, restart_interval, (int)blockIdx.x, (int)blockIdx.y, TX, TV,
-                   fused_restart);
+                   fused_restart, request);
+  if (up) {
+    if (requested) upload_commit<R>(agents[only_agent], up_slots, up_in, up_n0, up_n1, first, stride, tr);
+    else upload_slice<R>(agents[only_agent], up_slots, up_in, up_n0, up_n1, first, stride);  // (a tile past the agent's poses)
+  }
 }
 
 // after the selected agent's local solve (unfused path):  V = proj(V + gamma' (X - Y)); on restart

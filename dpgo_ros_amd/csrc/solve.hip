@@ -131,7 +131,22 @@ int enqueue_optimize(dpgo_team *t, int sel, const OptFlags &fl) {
       launch_precond(c, sel, mn, PM_RGD_, B_X, B_GF, B_Z, 0, 0, p.rgd_stepsize, p.acceleration, p.num_robots,
                      fl.last_advances ? 1 : 0, p.restart_interval);
       // (mid-run iterations of a run of many -- dpgo_team_run_ranks -- leave the statistics out: nobody reads them)
-      if (!fl.skip_stats) launch_eval(c, sel, mn, B_X2, B_EGRAD2, B_GF2, PART_A, eval_opts(t, 0, 0, 0));
+      if (!fl.skip_stats) {
+        if (fl.report_tail && t->rep_offer.valid && sel >= 0 && !fl.capture) {
+          // (per-agent API: the report rides on this launch -- one launch and 4-5 us less in front of the host's wait)
+          Agent &a = *t->ag[sel];
+          ReportTail rt = t->rep_offer.rt;
+          const int ppb = 64 / p.r;
+          rt.ai = sel;
+          rt.stat_off = PART_B + 2; rt.stat_cnt = precond_nblk(a); rt.stat_stride = PART_STRIDE;
+          rt.opt_nb = (a.n + ppb - 1) / ppb;
+          rt.advance = 1; rt.accel = p.acceleration; rt.num_robots = p.num_robots; rt.restart_interval = p.restart_interval;
+          launch_eval_report(c, sel, mn, B_X2, B_EGRAD2, B_GF2, PART_A, eval_opts(t, 0, 0, 0), rt);
+          t->rep_offer.taken = true;
+        } else {
+          launch_eval(c, sel, mn, B_X2, B_EGRAD2, B_GF2, PART_A, eval_opts(t, 0, 0, 0));
+        }
+      }
     } else {
       int dirb = B_GF;
       if (p.rgd_use_preconditioner) {
@@ -282,6 +297,8 @@ int enqueue_iterate(dpgo_team *t, int li, int do_opt, bool defer_advance) {
   const bool fused = do_opt && p.method == DPGO_METHOD_RGD && p.rgd_use_preconditioner && !restart && !p.rgd_line_search;
   OptFlags fl;
   fl.fused = fused;
+  // (a fused step's statistics evaluation is the last launch of the call when the caller's report takes the bookkeeping)
+  fl.report_tail = fused && defer_advance && do_opt == 1;
   // a team that imported peers (dpgo_team_import_peer) has no messages to fill the neighbour slabs from: its per-agent
   // iterate reads every neighbour that is readable in place (imported or co-resident) in place, like the team schedule
   fl.pull = t->peers.empty() ? 0 : 1;

@@ -45,6 +45,62 @@ __global__ __launch_bounds__(64) void k_eval(const AgentDev *__restrict__ agents
   eval_body<R>(agents, team, sel, xb, egb, gfb, poff, gmode, aux, (int)blockIdx.x, Ysh, Wsh, agents[0]);
 }
 
+// k_eval + the report of the per-agent API (ReportTail, kernels.h): the closing statistics evaluation of an RGD
+// iterate(true) is the last launch of the call, and the report a launch of its own behind it cost the host's wait 7-10 us
+// (one workgroup: cold start, two dependent loads per public pose, the sums, a PCIe round trip for the fence).  Here
+//   * every workgroup first copies its share of the public poses (X, Y: final since the step kernel) into the pinned image
+//     -- posted writes, on their way while the evaluation runs --,
+//   * a system-scope fence behind the evaluation covers them and the workgroup's partial sums; one ticket per workgroup,
+//   * the workgroup with the last ticket does what k_report's waves did: the sums (same routines, same order: the same
+//     bits), the agent's end-of-iterate bookkeeping, the scalars, the sequence word.
+template <int R>
+__global__ __launch_bounds__(64) void k_eval_report(const AgentDev *__restrict__ agents, const TeamDev *team, int sel, int xb, int egb,
+                                                    int gfb, int poff, int gmode, int aux, const ReportTail rt) {
+  constexpr int PPB = 64 / R;
+  __shared__ double Ysh[PPB * 4 * R], Wsh[PPB * 4 * R];
+  const AgentDev &ra = agents[rt.ai];
+  const int tid = threadIdx.x;
+  {
+    const int len = rt.count * 4 * R, total = 2 * len, stride = 64 * (int)gridDim.x;
+    for (int base = (int)blockIdx.x * 64 + tid; base < total; base += 4 * stride) {
+      double v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int t = min(base + u * stride, total - 1);
+        const int sq = t >= len, w = t - sq * len, q = w / (4 * R), k = w - q * 4 * R;
+        v[u] = ra.buf[sq ? B_Y : B_X][(size_t)rt.frames[q] * 4 * R + k];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (base + u * stride < total) rt.out[8 + base + u * stride] = v[u];
+    }
+  }
+  eval_body<R>(agents, team, sel, xb, egb, gfb, poff, gmode, aux, (int)blockIdx.x, Ysh, Wsh, agents[0]);
+  __threadfence_system();
+  __syncthreads();
+  unsigned int tk = 0;
+  if (tid == 0) tk = (unsigned int)__hip_atomic_fetch_add(rt.ticket, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+  tk = (unsigned int)__builtin_amdgcn_readfirstlane((int)tk);
+  if (tk + 1u != gridDim.x) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (every lane of the wave reads the other workgroups' partials below)
+  if (rt.advance && tid == 63) advance_agent(ra, rt.accel, rt.num_robots, rt.restart_interval);
+  double sc[5] = {0, 0, 0, 0, 0};
+  if (rt.stat_cnt > 0) sc[0] = sum_partials(ra.part + rt.stat_off, rt.stat_cnt, rt.stat_stride, tid);
+  if (rt.opt_nb > 0) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w)  // 0 f_init, 1 g2_init (PART_C), 2 f_opt, 3 g2_opt (PART_A)
+      sc[1 + w] = sum_partials(ra.part + ((w < 2) ? PART_C : PART_A) + (w & 1), rt.opt_nb, PART_STRIDE, tid);
+  }
+  if (tid == 0) {
+    if (rt.stat_cnt > 0) rt.out[1] = sc[0];
+    if (rt.opt_nb > 0) { rt.out[2] = sc[1]; rt.out[3] = sc[2]; rt.out[4] = sc[3]; rt.out[5] = sc[4]; }
+    __hip_atomic_store(rt.ticket, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *rt.seq = rt.expect;
+  }
+  __threadfence_system();
+  if (tid == 0) __hip_atomic_store(reinterpret_cast<unsigned long long *>(rt.out), rt.expect, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // k_eval for agents whose poses carry MANY shared edges (the tunnels robots: up to 20 inter-robot loop closures per pose,
 // 3548 of the 4891 edges cross robots).  g_row_range chases them four at a time -- descriptor, then neighbour pose and
 // coefficients, two dependent round trips per four edges -- behind the lane's own SpMM.  Here three helper waves fetch the
@@ -413,6 +469,12 @@ void launch_eval(const LaunchCtx &c, int sel, int max_n, int xb, int egb, int gf
   }
   DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_eval<R>, dim3(spmm_grid(c.r, max_n), c.ny), dim3(64), 0, c.stream, c.agents,
                                           c.team, sel, xb, egb, gfb, poff, o.gmode, o.aux));
+}
+
+void launch_eval_report(const LaunchCtx &c, int sel, int max_n, int xb, int egb, int gfb, int poff, const EvalOpts &o,
+                        const ReportTail &rt) {
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_eval_report<R>, dim3(spmm_grid(c.r, max_n), 1), dim3(64), 0, c.stream, c.agents,
+                                          c.team, sel, xb, egb, gfb, poff, o.gmode, o.aux, rt));
 }
 
 void launch_hess(const LaunchCtx &c, int sel, int max_n, int xb, int egb, int vb, int ob, int poff) {

@@ -261,7 +261,7 @@ struct dpgo_team {
   std::map<int, hipGraphExec_t> graphs;            // key: see dpgo_team_run
   std::map<int, int> graph_flip;
   bool graph_valid = false;
-  double counters[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  double counters[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   // X / Y arrays of robots that live in other processes, imported through HIP IPC (dpgo_team_import_peer): their
   // public poses are read in place over peer access instead of travelling as messages
   struct Peer { double *base = nullptr; size_t off_x = 0, off_y = 0; int n = 0; };
@@ -282,6 +282,7 @@ struct dpgo_team {
   int use_fused_eval = 1;  // DPGO_FUSED_EVAL=0: every pipelined iteration takes the two-launch sequence
   int use_fe_carry = 1;    // DPGO_FE_CARRY=0: every one-launch iteration forms the row products of its agent itself (no carried rows)
   int use_fe_deep = 1;     // DPGO_FE_DEEP=0: no deep-carried one-launch iterations (step_deep.hip): k_step_fe serves every run
+  int use_report_tail = 1;  // DPGO_REPORT_TAIL=0: the report of an RGD iterate(true) stays a launch of its own (k_report)
   int use_fe_persist = 0;  // DPGO_FE_PERSIST=1: a run of deep-carried iterations is ONE persistent launch (step_persist.hip)
   dpgo_host::DevBuf<unsigned long long> d_pd_bar;  // its hand-off counters (zeroed in front of every launch)
   dpgo_host::DevBuf<double> d_fd_pacc;  // their partial sums: two alternating buffers of [workgroup][r][256] doubles
@@ -291,6 +292,9 @@ struct dpgo_team {
                            // 312 poses 0.0180 | 0.0192, 357: 0.0191 | 0.0197, 416: 0.0199 | 0.0202, 500: 0.0214 | 0.0207 ms
   // staged neighbour poses of the agent whose iterate(true) is being enqueued: its first launch (k_nest_pre) scatters them
   struct PendingUpload { const int *slots = nullptr; const double *in = nullptr; int n0 = 0, n1 = 0; } pend_up;
+  // the report of the iterate(true) that is being enqueued, offered to its LAST launch (dpgo_agent_iterate fills in where it
+  // goes; enqueue_optimize takes it when that launch is the closing statistics evaluation of a fused RGD step)
+  struct ReportOffer { bool valid = false, taken = false; dpgo::ReportTail rt; } rep_offer;
   int *h_bar_err = nullptr;
   int num_cus = 0;
   int max_lds = 160 * 1024;  // hipDeviceAttributeMaxSharedMemoryPerBlock
@@ -391,6 +395,7 @@ struct OptFlags {
   int rtr_tail = 0;  // one-launch RTR solve: fold the rest of the iteration into it (bit 0: Nesterov V update; status + advance)
   int ls_tail = 0;   // RGD line search: fold the rest of the iteration into k_ls_apply (1: status + advance, 3: + Nesterov V)
   bool skip_stats = false;  // ... and leave out the closing statistics evaluation (mid-run iterations of a graph: nobody reads them)
+  bool report_tail = false;  // the closing statistics evaluation is the call's last launch: it may carry the team's rep_offer
 };
 bool neighbor_poses_ready(const Agent &a, int aux);
 EvalOpts eval_opts(const dpgo_team *t, int gmode, int aux, int advance);

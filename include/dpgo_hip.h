@@ -360,7 +360,8 @@ int dpgo_agent_read_partials(dpgo_team_t *t, int id, int offset, double *out, in
  * [1] their bytes, [2] sparse evaluations, [3] their bytes, [4] iterations); diagnostics of the per-agent API: [5] host
  * microseconds between the launch of a report kernel and the arrival of its sequence word, [6] reports; [7] iterations
  * of dpgo_team_run that took the one-launch form (csrc/step_fused.hip), [8] those of them that found the row products of
- * their agent formed by the previous launch (carried rows) */
+ * their agent formed by the previous launch (carried rows), [9] the deep-carried ones (csrc/step_deep.hip); [10] reports
+ * of the per-agent API that rode on the last launch of their iterate(true) (k_eval_report) */
 int dpgo_team_get_counters(dpgo_team_t *t, double *out, int n);
 
 #ifdef __cplusplus

@@ -119,6 +119,63 @@ def test_agent_api_iterates(method, accel):
     th.close()
 
 
+@pytest.mark.parametrize("accel", [0, 1])
+def test_report_on_the_last_launch_is_the_report_kernel_bit_for_bit(accel, monkeypatch):
+    """The report of an RGD iterate(true) (public poses of both sequences, status, fInit / fOpt / gradient norms: what
+    src/PGOAgentROS.cpp:160-172 and :666-668 read behind the call) rides on the call's last launch, the closing statistics
+    evaluation (k_eval_report), instead of a launch of its own (k_report; DPGO_REPORT_TAIL=0).  One single-agent team per
+    robot as the wrapper runs them, sphere2500 / 5, restart interval 7 (restart iterations keep k_report): every published
+    pose, every status, every result and the final iterates are bitwise equal, and the counter says which form ran."""
+    N, r = 5, 5
+    m, mp, n = load("sphere2500", N)
+    T, Y = O.odometry_init(m, n), O.fixed_stiefel(r)
+    prm = capi.default_params(r=r, num_robots=N, method=capi.METHOD_RGD, acceleration=accel, rgd_stepsize=0.2, restart_interval=7)
+    sets = []
+    for tail in ("1", "0"):
+        monkeypatch.setenv("DPGO_REPORT_TAIL", tail)
+        teams = [capi.Team.from_measurements(mp.view(capi.MEAS_DTYPE), prm, device=0, local_ids=[a]) for a in range(N)]
+        for a in range(N):
+            teams[a].set_initial(T, Y, offsets=np.array([a * (n // N)], dtype=np.int32))
+        sets.append(teams)
+    log = [[], []]
+
+    def publish(k, ags, b):
+        for c in ags[b].neighbors():
+            for aux in ((False, True) if accel else (False,)):
+                ids, P = ags[b].get_public_poses(c, aux)
+                log[k].append(np.array(P, copy=True))
+                ags[c].update_neighbor_poses(b, ids, P, aux)
+
+    for k, teams in enumerate(sets):
+        ags = [teams[a].agents[a] for a in range(N)]
+        for b in range(N):
+            publish(k, ags, b)
+        for it in range(23):
+            sel = it % N
+            for b in range(N):
+                if b != sel:
+                    ags[b].iterate(False)
+                    log[k].append(ags[b].status().relative_change)
+            for b in range(N):
+                if b != sel and ags[b].publish_requested(True):
+                    publish(k, ags, b)
+            assert ags[sel].iterate(True)
+            st, res = ags[sel].status(), ags[sel].opt_result()
+            log[k] += [st.relative_change, res.f_init, res.f_opt, res.gradnorm_init, res.gradnorm_opt]
+            if ags[sel].publish_requested(True):
+                publish(k, ags, sel)
+    assert len(log[0]) == len(log[1])
+    for u, v in zip(log[0], log[1]):
+        assert np.array_equal(np.asarray(u), np.asarray(v))
+    for a in range(N):
+        assert np.array_equal(sets[0][a].agents[a].get_X(), sets[1][a].agents[a].get_X())
+    folded = sum(t.counters()[10] for t in sets[0])
+    assert folded >= 18 and sum(t.counters()[10] for t in sets[1]) == 0, folded  # (23 block updates, 3 of them restarts)
+    for teams in sets:
+        for t in teams:
+            t.close()
+
+
 @pytest.mark.parametrize("dataset,N,method,accel,iters", [
     ("smallGrid3D", 2, capi.METHOD_RGD, 0, 30),
     ("smallGrid3D", 2, capi.METHOD_RGD, 1, 30),
