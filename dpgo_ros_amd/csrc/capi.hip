@@ -120,6 +120,7 @@ dpgo_team_t *dpgo_team_create(int device, const dpgo_params_t *p, int num_local,
     if (const char *e8 = std::getenv("DPGO_FE_DEEP")) t->use_fe_deep = (e8[0] == '0') ? 0 : 1;
     if (const char *e9 = std::getenv("DPGO_FE_PERSIST")) t->use_fe_persist = (e9[0] == '1') ? 1 : 0;
     if (const char *e10 = std::getenv("DPGO_REPORT_TAIL")) t->use_report_tail = (e10[0] == '0') ? 0 : 1;
+    if (const char *e11 = std::getenv("DPGO_REPORT_PREFETCH")) t->prefetch_reports = (e11[0] == '0') ? 0 : 1;
     if (t->d_nest_all.alloc(3 * std::max(1, num_local)) ||
         hipMemset(t->d_nest_all.p, 0, sizeof(NestState) * 3 * std::max(1, num_local)) != hipSuccess) {
       delete t; set_err("hand-off state allocation failed"); return nullptr;
@@ -423,6 +424,13 @@ static int finish_report(dpgo_team_t *t, Agent *a) {
       }
     }
     std::atomic_thread_fence(std::memory_order_acquire);
+    // the image was written over PCIe: none of it is in this core's caches, and the getters that follow copy it 8 KB at a
+    // time (one dependent stream of misses each).  Ask for all of its lines now, side by side.
+    if (t->prefetch_reports) {
+      const char *img = reinterpret_cast<const char *>(a->h_down.p);
+      const size_t bytes = sizeof(double) * (8 + (rp.one_seq ? npub / 2 : npub));
+      for (size_t o = 64; o < bytes; o += 64) __builtin_prefetch(img + o, 0, 2);
+    }
   }
   // diagnostics (dpgo_team_get_counters [5..6]): host time between the launch of a report and its arrival (us), reports
   t->counters[5] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - rp.t_launch).count();

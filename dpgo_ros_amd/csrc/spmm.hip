@@ -55,14 +55,16 @@ __global__ __launch_bounds__(64) void k_eval(const AgentDev *__restrict__ agents
 //     bits), the agent's end-of-iterate bookkeeping, the scalars, the sequence word.
 template <int R>
 __global__ __launch_bounds__(64) void k_eval_report(const AgentDev *__restrict__ agents, const TeamDev *team, int sel, int xb, int egb,
-                                                    int gfb, int poff, int gmode, int aux, const ReportTail rt) {
+                                                    int gfb, int poff, int gmode, int aux, int nb_eval, const ReportTail rt) {
   constexpr int PPB = 64 / R;
   __shared__ double Ysh[PPB * 4 * R], Wsh[PPB * 4 * R];
   const AgentDev &ra = agents[rt.ai];
   const int tid = threadIdx.x;
-  {
-    const int len = rt.count * 4 * R, total = 2 * len, stride = 64 * (int)gridDim.x;
-    for (int base = (int)blockIdx.x * 64 + tid; base < total; base += 4 * stride) {
+  if ((int)blockIdx.x >= nb_eval) {
+    // the copy workgroups (behind the evaluation's in the grid: memory reads return in order, so in front of an evaluation's
+    // own loads these two dependent ones would hold it up)
+    const int len = rt.count * 4 * R, total = 2 * len, stride = 64 * ((int)gridDim.x - nb_eval);
+    for (int base = ((int)blockIdx.x - nb_eval) * 64 + tid; base < total; base += 4 * stride) {
       double v[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -74,8 +76,9 @@ __global__ __launch_bounds__(64) void k_eval_report(const AgentDev *__restrict__
       for (int u = 0; u < 4; ++u)
         if (base + u * stride < total) rt.out[8 + base + u * stride] = v[u];
     }
+  } else {
+    eval_body<R>(agents, team, sel, xb, egb, gfb, poff, gmode, aux, (int)blockIdx.x, Ysh, Wsh, agents[0]);
   }
-  eval_body<R>(agents, team, sel, xb, egb, gfb, poff, gmode, aux, (int)blockIdx.x, Ysh, Wsh, agents[0]);
   __threadfence_system();
   __syncthreads();
   unsigned int tk = 0;
@@ -84,12 +87,33 @@ __global__ __launch_bounds__(64) void k_eval_report(const AgentDev *__restrict__
   if (tk + 1u != gridDim.x) return;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (every lane of the wave reads the other workgroups' partials below)
   if (rt.advance && tid == 63) advance_agent(ra, rt.accel, rt.num_robots, rt.restart_interval);
+  // the five sums k_report forms on five waves, here on one: all their loads first (sum_partials / sum_partials2 keep their
+  // order of additions: the same bits)
   double sc[5] = {0, 0, 0, 0, 0};
-  if (rt.stat_cnt > 0) sc[0] = sum_partials(ra.part + rt.stat_off, rt.stat_cnt, rt.stat_stride, tid);
-  if (rt.opt_nb > 0) {
+  if (rt.stat_cnt <= 512 && rt.opt_nb <= 512) {
+    double sv[8];
+    double2 cv[8], av[8];
 #pragma unroll
-    for (int w = 0; w < 4; ++w)  // 0 f_init, 1 g2_init (PART_C), 2 f_opt, 3 g2_opt (PART_A)
-      sc[1 + w] = sum_partials(ra.part + ((w < 2) ? PART_C : PART_A) + (w & 1), rt.opt_nb, PART_STRIDE, tid);
+    for (int u = 0; u < 8; ++u) {
+      const int i = tid + 64 * u;
+      sv[u] = (i < rt.stat_cnt) ? gp(ra.part + rt.stat_off)[(size_t)i * rt.stat_stride] : 0.0;
+      cv[u] = make_double2(0.0, 0.0); av[u] = make_double2(0.0, 0.0);
+      if (i < rt.opt_nb) {
+        const v2d_t c = *(const __attribute__((address_space(1))) v2d_t *)(ra.part + PART_C + (size_t)i * PART_STRIDE);
+        const v2d_t a = *(const __attribute__((address_space(1))) v2d_t *)(ra.part + PART_A + (size_t)i * PART_STRIDE);
+        cv[u] = make_double2(c.x, c.y); av[u] = make_double2(a.x, a.y);
+      }
+    }
+    double s0 = 0, c0 = 0, c1 = 0, a0 = 0, a1 = 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { s0 += sv[u]; c0 += cv[u].x; c1 += cv[u].y; a0 += av[u].x; a1 += av[u].y; }
+    sc[0] = wave_sum(s0); sc[1] = wave_sum(c0); sc[2] = wave_sum(c1); sc[3] = wave_sum(a0); sc[4] = wave_sum(a1);
+  } else {
+    if (rt.stat_cnt > 0) sc[0] = sum_partials(ra.part + rt.stat_off, rt.stat_cnt, rt.stat_stride, tid);
+    if (rt.opt_nb > 0) {
+      sum_partials2(ra.part + PART_C, rt.opt_nb, PART_STRIDE, tid, sc[1], sc[2]);  // f_init, |grad|^2_init
+      sum_partials2(ra.part + PART_A, rt.opt_nb, PART_STRIDE, tid, sc[3], sc[4]);  // f_opt, |grad|^2_opt
+    }
   }
   if (tid == 0) {
     if (rt.stat_cnt > 0) rt.out[1] = sc[0];
@@ -473,8 +497,10 @@ void launch_eval(const LaunchCtx &c, int sel, int max_n, int xb, int egb, int gf
 
 void launch_eval_report(const LaunchCtx &c, int sel, int max_n, int xb, int egb, int gfb, int poff, const EvalOpts &o,
                         const ReportTail &rt) {
-  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_eval_report<R>, dim3(spmm_grid(c.r, max_n), 1), dim3(64), 0, c.stream, c.agents,
-                                          c.team, sel, xb, egb, gfb, poff, o.gmode, o.aux, rt));
+  // evaluation workgroups + one copy workgroup per 256 doubles of public poses (four per lane; 16 at most)
+  const int nb = spmm_grid(c.r, max_n), ncopy = std::max(1, std::min(16, (2 * rt.count * 4 * c.r + 255) / 256));
+  DPGO_DISPATCH_R(c.r, hipLaunchKernelGGL(k_eval_report<R>, dim3(nb + ncopy, 1), dim3(64), 0, c.stream, c.agents,
+                                          c.team, sel, xb, egb, gfb, poff, o.gmode, o.aux, nb, rt));
 }
 
 void launch_hess(const LaunchCtx &c, int sel, int max_n, int xb, int egb, int vb, int ob, int poff) {

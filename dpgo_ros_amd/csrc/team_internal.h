@@ -282,6 +282,7 @@ struct dpgo_team {
   int use_fused_eval = 1;  // DPGO_FUSED_EVAL=0: every pipelined iteration takes the two-launch sequence
   int use_fe_carry = 1;    // DPGO_FE_CARRY=0: every one-launch iteration forms the row products of its agent itself (no carried rows)
   int use_fe_deep = 1;     // DPGO_FE_DEEP=0: no deep-carried one-launch iterations (step_deep.hip): k_step_fe serves every run
+  int prefetch_reports = 1;  // DPGO_REPORT_PREFETCH=0: the host does not prefetch an arrived report's image
   int use_report_tail = 1;  // DPGO_REPORT_TAIL=0: the report of an RGD iterate(true) stays a launch of its own (k_report)
   int use_fe_persist = 0;  // DPGO_FE_PERSIST=1: a run of deep-carried iterations is ONE persistent launch (step_persist.hip)
   dpgo_host::DevBuf<unsigned long long> d_pd_bar;  // its hand-off counters (zeroed in front of every launch)
