@@ -560,10 +560,10 @@ int dpgo_agent_iterate(dpgo_team_t *t, int id, int do_optimization) {
   if (t->prm.acceleration || opt) a->publish_requested = true;
   if (folded) {
     // (what report_after_iterate would have asked k_report for: the status of a fused step -- PART_B partials -- and the
-    // result of the RGD solve)
-    if (a->opt_rel_src != 1 || !a->opt_pending_rgd) { set_err("internal: folded report on a path that is not the fused RGD step"); return DPGO_ERR; }
+    // result of an RGD solve; an RTR solve leaves its record in pinned memory itself)
+    if (a->opt_rel_src != 1) { set_err("internal: folded report on a path without the fused status partials"); return DPGO_ERR; }
     a->rep.pending = true; a->rep.expect = ++a->report_seq; a->rep.epoch = t->epoch; a->rep.one_seq = false;
-    a->rep.want_status = true; a->rep.want_opt = true; a->rep.t_launch = tq0;
+    a->rep.want_status = true; a->rep.want_opt = a->opt_pending_rgd; a->rep.t_launch = tq0;
     t->counters[10] += 1;
     const int rr = finish_report(t, a);
     if (rr) return rr;

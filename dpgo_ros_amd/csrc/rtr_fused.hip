@@ -31,7 +31,7 @@ constexpr long long RB_TIMEOUT_TICKS = 50000000;  // 0.5 s of the 100 MHz wall c
 // non-restart iterations): what k_nest_post, k_status and k_advance do in launches of their own --
 //   bit 0: V <- proj(V + gamma (X - Y)) on the own poses (gamma as k_nest_pre published it in scal[6]);
 //   always: |X - XPrev|^2 of the own poses -> PART_B[2] of this workgroup (the layout of the fused RGD step: rel_src 1);
-//   workgroup 0: the Nesterov scalars of every agent and the team's iteration counter advance.
+//   workgroup 0: the Nesterov scalars of every agent and the team's iteration counter advance (not with bit 2).
 // No hand-off: every workgroup touches its own two poses only, and nothing here reads what the advance writes.
 template <int R>
 __device__ __forceinline__ void solve_tail(const AgentDev *__restrict__ agents, const AgentDev &ag, TeamDev *team, int tail,
@@ -60,7 +60,7 @@ __device__ __forceinline__ void solve_tail(const AgentDev *__restrict__ agents, 
     rel = wave_sum(rel);
     if (tid == 0) ag.part[PART_B + (size_t)bx * PART_STRIDE + 2] = rel;
   }
-  if (bx == 0 && tid == 0) {
+  if (bx == 0 && tid == 0 && !(tail & 4)) {  // (bit 2: the per-agent API -- the caller's report advances this agent alone)
     for (int k = 0; k < team->num_agents; ++k) advance_agent(agents[k], tail & 1, num_robots, restart_interval);
     team->iter += 1;
   }

@@ -328,24 +328,32 @@ int enqueue_iterate(dpgo_team *t, int li, int do_opt, bool defer_advance) {
     c.up_n0 = c.up_n1 = 0;
     if (do_opt) {
       fl.aux = 1;
+      // RTR, non-restart iteration: the one-launch solve also takes the Nesterov V update and the status partials (what the
+      // team schedule folds, enqueue_team_iteration; bit 2: this agent's bookkeeping stays with the caller's report) -- two
+      // launches less in front of the host's wait; enqueue_optimize says whether that solve ran
+      if (p.method == DPGO_METHOD_RTR && !restart && defer_advance) fl.rtr_tail = 3 | 4;
       rc = enqueue_optimize(t, li, fl);
       if (rc) return rc;
-      if (!fused) launch_nest_post(c, li, a.n, p.num_robots, p.restart_interval);
+      const bool folded = p.method == DPGO_METHOD_RTR && fl.rtr_tail != 0 && t->last_rtr_folded;
+      if (!fused && !folded) launch_nest_post(c, li, a.n, p.num_robots, p.restart_interval);
       if (restart) {
         fl.aux = 0;
         rc = enqueue_optimize(t, li, fl);
         if (rc) return rc;
         launch_nest_reset(c, li, a.n);
       }
-      if (fused) a.rel_src = 1; else launch_status(c, li, li, 1, a.n, 1);
+      if (fused || folded) a.rel_src = 1; else launch_status(c, li, li, 1, a.n, 1);
     }
   } else {
     launch_copy(c, li, li, 1, a.n, B_X, B_XPREV, 0);
+    bool folded = false;
     if (do_opt) {
+      if (p.method == DPGO_METHOD_RTR && defer_advance) fl.rtr_tail = 2 | 4;
       rc = enqueue_optimize(t, li, fl);
       if (rc) return rc;
+      folded = p.method == DPGO_METHOD_RTR && fl.rtr_tail != 0 && t->last_rtr_folded;
     }
-    if (fused) a.rel_src = 1; else launch_status(c, li, li, 1, a.n, do_opt ? 1 : 0);
+    if (fused || folded) a.rel_src = 1; else launch_status(c, li, li, 1, a.n, do_opt ? 1 : 0);
   }
   if (!defer_advance) launch_advance(c, li, 1, p.acceleration, p.num_robots, p.restart_interval, 0);
   return 0;

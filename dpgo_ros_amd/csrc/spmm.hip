@@ -76,13 +76,21 @@ __global__ __launch_bounds__(64) void k_eval_report(const AgentDev *__restrict__
       for (int u = 0; u < 4; ++u)
         if (base + u * stride < total) rt.out[8 + base + u * stride] = v[u];
     }
+    __threadfence_system();  // (plain stores to host memory: complete once this workgroup's L2 has been written back)
   } else {
     eval_body<R>(agents, team, sel, xb, egb, gfb, poff, gmode, aux, (int)blockIdx.x, Ysh, Wsh, agents[0]);
+    // an evaluation workgroup publishes two partial sums: written once more, THROUGH to memory (st_c), and waited for --
+    // a release fence would write the whole L2 back in every one of them (what that costs: profiles/r06_agent_api.md)
+    if (tid == 0) {
+      double *P = ra.part + poff + (size_t)blockIdx.x * PART_STRIDE;
+      const double f = gp(P)[0], g = gp(P)[1];
+      st_c(P, f); st_c(P + 1, g);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
-  __threadfence_system();
   __syncthreads();
   unsigned int tk = 0;
-  if (tid == 0) tk = (unsigned int)__hip_atomic_fetch_add(rt.ticket, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) tk = (unsigned int)__hip_atomic_fetch_add(rt.ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   tk = (unsigned int)__builtin_amdgcn_readfirstlane((int)tk);
   if (tk + 1u != gridDim.x) return;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (every lane of the wave reads the other workgroups' partials below)

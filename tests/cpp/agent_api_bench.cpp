@@ -60,7 +60,7 @@ int main(int argc, char **argv) {
     }
   }
   buf.resize(maxp * 4 * r);
-  double t_get = 0, t_upd = 0;
+  double t_get = 0, t_upd = 0, t_get_aux = 0;
   auto publish = [&](int b) -> int {
     for (size_t q = 0; q < nbrs[b].size(); ++q) {
       const int c = nbrs[b][q];
@@ -70,6 +70,7 @@ int main(int argc, char **argv) {
         const auto g1 = std::chrono::steady_clock::now();
         CK(dpgo_agent_update_neighbor_poses(team[c], c, b, aux, (int)ids[b][q].size(), ids[b][q].data(), buf.data()));
         t_get += std::chrono::duration<double, std::micro>(g1 - g0).count();
+        if (aux) t_get_aux += std::chrono::duration<double, std::micro>(g1 - g0).count();
         t_upd += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - g1).count();
       }
     }
@@ -113,7 +114,7 @@ int main(int argc, char **argv) {
   };
   const int warm = 2 * N;
   for (int k = 0; k < warm; ++k) if (iteration(k)) return 1;
-  t_false = t_true = 0; t_get = t_upd = 0;
+  t_false = t_true = 0; t_get = t_upd = t_get_aux = 0;
   const auto t0 = std::chrono::steady_clock::now();
   for (int k = warm; k < warm + iters; ++k) if (iteration(k)) return 1;
   for (int a = 0; a < N; ++a) CK(dpgo_team_synchronize(team[a]));
@@ -134,8 +135,8 @@ int main(int argc, char **argv) {
     for (double v : Xa) checksum += std::fabs(v);
   }
   std::printf("{\"ms_per_iteration\": %.6f, \"iterations\": %d, \"us_per_iterate_false\": %.2f, \"us_per_iterate_true\": %.2f, "
-              "\"us_other_per_iteration\": %.2f, \"us_get_public_poses_per_iteration\": %.2f, \"us_update_neighbor_poses_per_iteration\": %.2f, \"us_report_wait\": %.2f, \"f_opt_last\": %.12g, \"relchange_sum\": %.12g, \"checksum\": %.15g}\n",
-              ms, iters, t_false / ((double)iters * (N - 1)), t_true / iters, 1e3 * ms - (t_false + t_true) / iters, t_get / iters, t_upd / iters, reports > 0 ? wait_us / reports : 0.0, res.f_opt, rel_sum,
+              "\"us_other_per_iteration\": %.2f, \"us_get_public_poses_per_iteration\": %.2f, \"us_get_aux_poses_per_iteration\": %.2f, \"us_update_neighbor_poses_per_iteration\": %.2f, \"us_report_wait\": %.2f, \"f_opt_last\": %.12g, \"relchange_sum\": %.12g, \"checksum\": %.15g}\n",
+              ms, iters, t_false / ((double)iters * (N - 1)), t_true / iters, 1e3 * ms - (t_false + t_true) / iters, t_get / iters, t_get_aux / iters, t_upd / iters, reports > 0 ? wait_us / reports : 0.0, res.f_opt, rel_sum,
               checksum);
   for (int a = 0; a < N; ++a) dpgo_team_destroy(team[a]);
   dpgo_free(m);
