@@ -264,8 +264,11 @@ __global__ __launch_bounds__(256) void k_syrk(const InvJob *jobs, int kb, int *f
   }
   if (bi == 0 && bj == 0 && kb + 1 < jb_.nblk) {
     // this workgroup has just finished the tile that holds the next diagonal block (s0, s0): factor it here, under the
-    // rest of the trailing update, instead of in a launch of its own on the critical path
-    __threadfence();
+    // rest of the trailing update, instead of in a launch of its own on the critical path.  (The tile was written by this
+    // workgroup's own threads: a WORKGROUP-scope fence orders it.  The device-scope fence that stood here until round 6
+    // wrote the whole L2 back, once per matrix of the batch, while the other workgroups were filling it: trailing updates
+    // of 169 and 145 us among ones of 35 in the UPDATE_WEIGHT round's first chain, profiles/experiments/jobs/r06_update_trace.sh)
+    __threadfence_block();
     __syncthreads();
     if (tid < 64) potrf_diag_body(jb_, kb + 1, fail, (int)blockIdx.z, &As[0][0]);  // (the operand tiles are done with)
   }
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(256) void k_syrk_sb(const InvJob *jobs, int kb0, in
         }
   }
   if (bi == 0 && bj == 0 && next_kb >= 0 && next_kb < jb_.nblk) {
-    __threadfence();
+    __threadfence_block();  // (see k_syrk)
     __syncthreads();
     if (tid < 64) potrf_diag_body(jb_, next_kb, fail, (int)blockIdx.z, &As[0][0]);
   }
