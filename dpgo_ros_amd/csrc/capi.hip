@@ -1656,16 +1656,23 @@ int dpgo_team_update_weights(dpgo_team_t *t) {
   {
     // every agent's residuals come from the current iterate: all the launches and copies first, ONE wait (a wait per agent
     // was 0.25 ms of a round on 8 agents)
+    // (into ONE pinned buffer: a copy into pageable memory stages, and the host waited 18 us per agent between a kernel and
+    // the next, profiles/r06_update_weight_timeline.txt)
     std::vector<std::vector<double>> res(t->ag.size());
+    std::vector<size_t> at(t->ag.size(), 0);
+    size_t total = 0;
+    for (size_t k = 0; k < t->ag.size(); ++k) { at[k] = total; if (t->ag[k]->has_X) total += (size_t)t->ag[k]->nedges; }
+    if (t->h_resid.alloc(std::max<size_t>(total, 1))) { set_err("pinned allocation failed"); return DPGO_ERR; }
     LaunchCtx c = t->ctx();
     for (size_t k = 0; k < t->ag.size(); ++k) {
       Agent &a = *t->ag[k];
       if (!a.has_X) continue;
       launch_residuals(c, a.local, a.nedges);
-      res[k].resize(a.nedges);
-      if (a.nedges) HIPC(hipMemcpyAsync(res[k].data(), a.dev.resid, sizeof(double) * a.nedges, hipMemcpyDeviceToHost, t->stream));
+      if (a.nedges) HIPC(hipMemcpyAsync(t->h_resid.p + at[k], a.dev.resid, sizeof(double) * a.nedges, hipMemcpyDeviceToHost, t->stream));
     }
     HIPC(hipStreamSynchronize(t->stream));
+    for (size_t k = 0; k < t->ag.size(); ++k)
+      if (t->ag[k]->has_X) res[k].assign(t->h_resid.p + at[k], t->h_resid.p + at[k] + t->ag[k]->nedges);
     for (size_t k = 0; k < t->ag.size(); ++k) if (update_weights_of(t, t->ag[k].get(), &res[k])) return DPGO_ERR;
   }
   const auto q2 = now();
