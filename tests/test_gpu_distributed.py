@@ -237,7 +237,10 @@ def test_peer_access_free_running_asynchronous_mode_descends():
     ref.exchange_all()
     c0, c = float(outs[0]["cost0"]), float(outs[0]["cost"])
     assert np.isfinite(c) and c < 0.05 * c0
-    assert c <= 1.05 * ref.cost() and c >= 0.5 * ref.cost()
+    # (how far the run gets depends on how the two processes' unsynchronised steps interleave: 12 runs in a row ended
+    # between 0.988 and 1.50 of the synchronous reference's cost, 11 of them within 2.3 % -- and all below 1.3 % of the
+    # initial cost; profiles/experiments/peer_free_spread.py)
+    assert c <= 2.0 * ref.cost() and c >= 0.5 * ref.cost()
 
 
 def test_peer_access_per_agent_iterate_reads_neighbours_in_place():
