@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void k_syrk(const InvJob *jobs, int kb, int *f
           if (i < N && j < N && i >= j) A[(size_t)j * N + i] = old[u][v][q] - acc.c[u][v][q];
         }
   }
-  if (bi == 0 && bj == 0 && kb + 1 < jb_.nblk) {
+  if (fail && bi == 0 && bj == 0 && kb + 1 < jb_.nblk) {
     // this workgroup has just finished the tile that holds the next diagonal block (s0, s0): factor it here, under the
     // rest of the trailing update, instead of in a launch of its own on the critical path.  (The tile was written by this
     // workgroup's own threads: a WORKGROUP-scope fence orders it.  The device-scope fence that stood here until round 6
@@ -477,14 +477,21 @@ int dense_spd_inverse_batched(hipStream_t stream, int count, double *const *A, d
   if (!work_is_zero)  // (one memset per matrix: a batch of a hundred subdomain blocks passes an area it has zeroed in one)
     for (int b = 0; b < count; ++b) (void)hipMemsetAsync(work[b], 0, sizeof(double) * (size_t)N[b] * N[b], stream);
   const unsigned nz = (unsigned)count;
+  // The diagonal block of step kb + 1 is factored by the trailing update of step kb (k_syrk, tile (0,0)) -- in a batch of
+  // FEW matrices, where that takes a launch off a chain nothing else fills (5 agents' M: 63 steps; the 8 Schur complements
+  // of an UPDATE_WEIGHT round: 20 us per folded step against 15 + 8 in two launches).  In a batch of many small matrices
+  // (the 112 subdomain blocks of the same round) the folded steps measured 40 / 110 / 108 / 26 / 21 / 37 us where the
+  // trailing update alone takes 23 / 32 / 30 / 13 / 8 / 10 and the factorisation 16: there it stays a launch of its own
+  // (profiles/experiments/jobs/r06_update_fold.sh; DPGO_SYRK_FOLD=0 / 1 forces either form).
+  static const int fold_env = std::getenv("DPGO_SYRK_FOLD") ? std::atoi(std::getenv("DPGO_SYRK_FOLD")) : -1;
+  const bool fold = fold_env >= 0 ? fold_env != 0 : count <= 32;
   for (int kb = 0; kb < max_blk; ++kb) {
     const int s0 = (kb + 1) * NB;
-    // the diagonal block of step kb + 1 is factored by the trailing update of step kb (k_syrk, tile (0,0))
-    if (kb == 0) hipLaunchKernelGGL(k_potrf_diag, dim3(1, 1, nz), dim3(64), 0, stream, jobs_d, kb, fail_d);
+    if (kb == 0 || !fold) hipLaunchKernelGGL(k_potrf_diag, dim3(1, 1, nz), dim3(64), 0, stream, jobs_d, kb, fail_d);
     if (s0 < max_n) {
       hipLaunchKernelGGL(k_trsm_panel, dim3((max_n - s0 + 63) / 64, 1, nz), dim3(256), 0, stream, jobs_d, kb);
       const int nt = (max_n - s0 + 63) / 64;
-      hipLaunchKernelGGL(k_syrk, dim3(nt, nt, nz), dim3(256), 0, stream, jobs_d, kb, fail_d);
+      hipLaunchKernelGGL(k_syrk, dim3(nt, nt, nz), dim3(256), 0, stream, jobs_d, kb, fold ? fail_d : (int *)nullptr);
     }
   }
   for (int ib = 0; ib < max_blk; ++ib) {
