@@ -292,6 +292,11 @@ struct dpgo_team {
                            // measured per iteration, two-launch | one-launch (profiles/experiments/fe_small.py, sphere2500, r = 5):
                            // 312 poses 0.0180 | 0.0192, 357: 0.0191 | 0.0197, 416: 0.0199 | 0.0202, 500: 0.0214 | 0.0207 ms
   // staged neighbour poses of the agent whose iterate(true) is being enqueued: its first launch (k_nest_pre) scatters them
+  // dpgo_team_update_weights: (owner's copy, receiver's copy, receiver's local index) of every shared edge whose two end points
+  // live in this team, valid while the agents' edge lists are the ones of shared_links_key
+  struct SharedLink { dpgo_measurement_t *from, *to; int to_local; };
+  std::vector<SharedLink> shared_links;
+  std::vector<std::pair<const void *, size_t>> shared_links_key;
   dpgo_host::PinnedBuf<double> h_resid;  // dpgo_team_update_weights: every agent's residuals land here (pinned: the copies do not stage)
   struct PendingUpload { const int *slots = nullptr; const double *in = nullptr; int n0 = 0, n1 = 0; } pend_up;
   // the report of the iterate(true) that is being enqueued, offered to its LAST launch (dpgo_agent_iterate fills in where it
