@@ -416,8 +416,17 @@ int finalize_agent(dpgo_team *t, Agent &a, double *scratch) {
   int maxlen = 0;
   for (int j = 0; j < n; ++j) maxlen = std::max(maxlen, a.rowptr[j + 1] - a.rowptr[j]);
   const int EW = std::min(maxlen, 8);
-  std::vector<int> ell_col((size_t)EW * n), trowptr(n + 1, 0), tcol;
-  std::vector<double> ell_val((size_t)EW * n * 16, 0.0), tval;
+  // A weight update (same pattern: struct_uploaded stands, build_Q cleared it otherwise) refreshes the VALUES of these
+  // layouts on the device from the block-CSR values (k_q_layouts): the host laid out and uploaded 1.2 MB per agent and
+  // round for what is a gather of the 0.3 MB it uploads anyway.
+  const bool values_only = a.struct_uploaded && a.d_rowptr.p && a.d_trowptr.p && a.d_ell_val.p &&
+                           a.d_ell_val.n >= (size_t)EW * n * 16 && a.d_qval.n >= a.qval.size() &&
+                           std::getenv("DPGO_HOST_LAYOUTS") == nullptr;
+  std::vector<int> ell_col, trowptr, tcol;
+  std::vector<double> ell_val, tval;
+  if (!values_only) {
+  ell_col.assign((size_t)EW * n, 0); trowptr.assign(n + 1, 0);
+  ell_val.assign((size_t)EW * n * 16, 0.0);
   for (int j = 0; j < n; ++j) {
     const int p0 = a.rowptr[j], p1 = a.rowptr[j + 1];
     for (int u = 0; u < EW; ++u) {
@@ -428,14 +437,15 @@ int finalize_agent(dpgo_team *t, Agent &a, double *scratch) {
     for (int p = p0 + EW; p < p1; ++p) { tcol.push_back(a.col[p]); tval.insert(tval.end(), a.qval.begin() + (size_t)16 * p, a.qval.begin() + (size_t)16 * (p + 1)); }
     trowptr[j + 1] = (int)tcol.size();
   }
+  }
   // rows without a tail also get the blocks in structure-of-arrays order, [slot][16-byte chunk][pose]: the one-launch
   // iteration (step_fused.hip) runs one lane per pose, and this way every load of its 64 lanes is one contiguous KB
   std::vector<double> soa_val;
   std::vector<int> soa_col;
   const int SW = std::max(EW, 5);
-  if (maxlen <= 8 && maxlen > 0) {
+  const int tiles = std::max((n + 63) / 64, 8);  // (the one-launch iteration runs 8 waves whatever the agent's size)
+  if (!values_only && maxlen <= 8 && maxlen > 0) {
     // [tile of 64 poses][slot][chunk][lane]: a wave's loads differ by compile-time offsets only
-    const int tiles = std::max((n + 63) / 64, 8);  // (the one-launch iteration runs 8 waves whatever the agent's size)
     soa_val.assign((size_t)tiles * SW * 8 * 64 * 2, 0.0);
     soa_col.resize((size_t)tiles * SW * 64);
     for (int jt = 0; jt < tiles * 64; ++jt) {
@@ -452,7 +462,7 @@ int finalize_agent(dpgo_team *t, Agent &a, double *scratch) {
       }
     }
   }
-  a.has_soa = !soa_val.empty();
+  if (!values_only) a.has_soa = !soa_val.empty();
   std::vector<int> pub_index(n, -1);
   for (size_t q = 0; q < pub_pose.size(); ++q) pub_index[pub_pose[q]] = (int)q;
   // index arrays depend on the measurement STRUCTURE only: a weight update (same edges, new weights) re-sends values
@@ -460,7 +470,7 @@ int finalize_agent(dpgo_team *t, Agent &a, double *scratch) {
   if ((idx && (a.d_ell_col.upload(ell_col, s) || a.d_trowptr.upload(trowptr, s) || a.d_tcol.upload(tcol, s) ||
                (a.has_soa && a.d_soa_col.upload(soa_col, s)) ||
                a.d_pub_index.upload(pub_index, s) || a.d_pose_eptr.upload(pose_eptr, s))) ||
-      a.d_ell_val.upload(ell_val, s) || a.d_tval.upload(tval, s) || (a.has_soa && a.d_soa_val.upload(soa_val, s))) {
+      (!values_only && (a.d_ell_val.upload(ell_val, s) || a.d_tval.upload(tval, s) || (a.has_soa && a.d_soa_val.upload(soa_val, s))))) {
     set_err("device allocation/upload failed");
     return DPGO_ERR;
   }
@@ -482,6 +492,9 @@ int finalize_agent(dpgo_team *t, Agent &a, double *scratch) {
     set_err("device allocation/upload failed");
     return DPGO_ERR;
   }
+  if (values_only)
+    launch_q_layouts(s, a.d_rowptr.p, a.d_qval.p, n, EW, a.d_ell_val.p, a.d_trowptr.p, a.d_tval.p, SW, tiles,
+                     a.has_soa ? a.d_soa_val.p : nullptr);
   if (fresh_vec) {
     HIPC(hipMemsetAsync(a.d_vec.p, 0, sizeof(double) * len * NBUF, s));
     HIPC(hipMemsetAsync(a.d_nbr.p, 0, sizeof(double) * a.d_nbr.n, s));

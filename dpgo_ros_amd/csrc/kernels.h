@@ -158,6 +158,8 @@ void launch_noop(const LaunchCtx &c, int grid, int block);
 void launch_copy(const LaunchCtx &c, int sel, int only_agent, int num_agents, int max_n, int from, int to, int publish);
 void launch_bsr_to_dense(hipStream_t s, const int *rowptr, const int *col, const double *qval, int n, double shift,
                          double *A);
+void launch_q_layouts(hipStream_t s, const int *rowptr, const double *qval, int n, int EW, double *ell_val, const int *trowptr,
+                      double *tval, int SW, int tiles, double *soa_val);
 
 // rtr_fused.hip: one launch per local RTR solve, the agent's preconditioner resident in LDS over the whole solve.
 // bar: RTR_BAR_WORDS zero-initialised 64-bit words owned by the AGENT (the arrival counts depend on its grid);

@@ -677,6 +677,43 @@ void launch_copy(const LaunchCtx &c, int sel, int only_agent, int num_agents, in
   hipLaunchKernelGGL(k_copy, grid, dim3(256), 0, c.stream, c.agents, c.team, sel, only_agent, c.r, from, to, publish);
 }
 
+// Q's other device layouts refreshed FROM its block-CSR values on the device (a weight update: same pattern, new values) --
+// the slot-major ELL copy, the CSR tail beyond its width, the lane-ordered copy of the one-launch iteration.  Pure copies
+// (the values are bitwise the block-CSR ones, as when the host lays them out); slots a row does not have keep the zeros
+// of the first, host-built upload.  One thread per (pose slot jt, 16-byte chunk q): assembly.hip says where each goes.
+__global__ void k_q_layouts(const int *rowptr, const double *qval, int n, int EW, double *ell_val, const int *trowptr, double *tval,
+                            int SW, int tiles, double *soa_val) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int jt = x >> 3, q = x & 7;
+  if (jt >= tiles * 64 && jt >= n) return;
+  const int j = min(jt, n - 1);
+  const int p0 = rowptr[j], p1 = rowptr[j + 1];
+  if (jt < n) {
+    for (int u = 0; u < EW && p0 + u < p1; ++u) {
+      const v2d_t v = *(const __attribute__((address_space(1))) v2d_t *)(qval + (size_t)16 * (p0 + u) + 2 * q);
+      *(__attribute__((address_space(1))) v2d_t *)(ell_val + ((size_t)u * n + j) * 16 + 2 * q) = v;
+    }
+    for (int p = p0 + EW; p < p1; ++p) {
+      const v2d_t v = *(const __attribute__((address_space(1))) v2d_t *)(qval + (size_t)16 * p + 2 * q);
+      *(__attribute__((address_space(1))) v2d_t *)(tval + (size_t)16 * (trowptr[j] + (p - p0 - EW)) + 2 * q) = v;
+    }
+  }
+  if (soa_val && jt < tiles * 64 && jt < n) {
+    const int tile = jt / 64, lane = jt % 64;
+    for (int u = 0; u < SW && p0 + u < p1; ++u) {
+      const v2d_t v = *(const __attribute__((address_space(1))) v2d_t *)(qval + (size_t)16 * (p0 + u) + 2 * q);
+      *(__attribute__((address_space(1))) v2d_t *)(soa_val + ((((size_t)tile * SW + u) * 8 + q) * 64 + lane) * 2) = v;
+    }
+  }
+}
+
+void launch_q_layouts(hipStream_t s, const int *rowptr, const double *qval, int n, int EW, double *ell_val, const int *trowptr,
+                      double *tval, int SW, int tiles, double *soa_val) {
+  const int slots = std::max(n, soa_val ? tiles * 64 : 0);
+  hipLaunchKernelGGL(k_q_layouts, dim3((slots * 8 + 255) / 256), dim3(256), 0, s, rowptr, qval, n, EW, ell_val, trowptr, tval, SW, tiles,
+                     soa_val);
+}
+
 void launch_bsr_to_dense(hipStream_t s, const int *rowptr, const int *col, const double *qval, int n, double shift,
                          double *A) {
   (void)hipMemsetAsync(A, 0, sizeof(double) * (size_t)16 * n * n, s);

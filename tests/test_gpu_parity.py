@@ -404,6 +404,49 @@ def test_gnc_tls_reweighting_rounds():
         th.close()
 
 
+@pytest.mark.parametrize("dataset,N,method", [("torus3D", 8, capi.METHOD_RTR), ("sphere2500", 5, capi.METHOD_RGD), ("long_rows", 1, capi.METHOD_RTR)])
+def test_weight_update_refreshes_the_layouts_of_q_on_the_device_bit_for_bit(dataset, N, method, monkeypatch):
+    """An UPDATE_WEIGHT round (same pattern, new values) re-creates Q's ELL copy, its CSR tail and the lane-ordered copy of the
+    one-launch iteration ON THE DEVICE from the block-CSR values it uploads (k_q_layouts) instead of laying them out on the
+    host and uploading them (DPGO_HOST_LAYOUTS=1): pure copies, so three GNC rounds with iterations between them end in
+    bitwise the same iterates and weights (two-level agents, dense agents with the one-launch iteration, rows with a CSR
+    tail)."""
+    if dataset == "long_rows":  # (the graph of test_long_rows_take_the_csr_tail: rows of up to 13 blocks)
+        rng = np.random.default_rng(5)
+        n = 40
+        pairs = [(i, i + 1) for i in range(n - 1)] + [(3, j) for j in range(6, 30, 2)] + [(j, 17) for j in range(20, 38, 3)]
+        m = np.zeros(len(pairs), dtype=O.MEAS_DTYPE)
+        for k, (i, j) in enumerate(pairs):
+            Q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+            Q *= np.sign(np.linalg.det(Q))
+            m[k]["p1"], m[k]["p2"] = i, j
+            m[k]["R"], m[k]["t"] = Q.reshape(-1), rng.standard_normal(3)
+            m[k]["kappa"], m[k]["tau"], m[k]["weight"] = 30.0 + k, 7.0, 1.0
+        mp = m
+    else:
+        m, mp, n = load(dataset, N)
+    kw = dict(method=method, acceleration=1 if method == capi.METHOD_RGD else 0, robust_cost_type=capi.COST_GNC_TLS, gnc_barc=3.0,
+              gradnorm_tol=0.5, rgd_stepsize=0.2)
+    outs = []
+    for host in ("1", None):
+        if host:
+            monkeypatch.setenv("DPGO_HOST_LAYOUTS", host)
+        else:
+            monkeypatch.delenv("DPGO_HOST_LAYOUTS", raising=False)
+        t = capi.Team.from_measurements(mp.view(capi.MEAS_DTYPE), capi.default_params(r=5, num_robots=N, **kw))
+        t.set_initial(O.odometry_init(m, n), O.fixed_stiefel(5))
+        for rnd in range(3):
+            t.run(3 * N)
+            t.update_weights()
+        t.run(2 * N)
+        outs.append(([t.agents[a].get_X() for a in t.ids], [t.agents[a].measurements()["weight"].copy() for a in t.ids]))
+        t.close()
+    for xa, xb in zip(outs[0][0], outs[1][0]):
+        assert np.array_equal(xa, xb)
+    for wa, wb in zip(outs[0][1], outs[1][1]):
+        assert np.array_equal(wa, wb)
+
+
 @pytest.mark.parametrize("kind,kw", [(capi.COST_L1, {}), (capi.COST_HUBER, dict(huber_threshold=1.0)),
                                      (capi.COST_TLS, dict(tls_threshold=2.5)), (capi.COST_GM, {})])
 def test_other_robust_cost_types_reweighting_rounds(kind, kw):
