@@ -3,8 +3,8 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/upd
-DPGO_TIMING=1 python $R/profiles/experiments/gnc_update_torus.py 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl\|amdgpu.ids" | tail -8 | tee $R/gpurun_out/upd/time.log
-rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/upd/trace -- python $R/profiles/experiments/gnc_update_torus.py > /dev/null 2>&1
+DPGO_TIMING=1 python $R/profiles/experiments/${UPD_SCRIPT:-gnc_update_torus.py} 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl\|amdgpu.ids" | tail -8 | tee $R/gpurun_out/upd/time.log
+rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/upd/trace -- python $R/profiles/experiments/${UPD_SCRIPT:-gnc_update_torus.py} > /dev/null 2>&1
 f=$(find $R/gpurun_out/upd/trace -name '*kernel_trace.csv' | head -1)
 python - <<PY
 import csv
