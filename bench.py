@@ -535,7 +535,7 @@ def gnc_leg(capi):
 PMC = {"source": "profiles/r06_pmc_fetch.md, profiles/r06_pmc_write.md (k_step_fd); profiles/r05_pmc_*.md (the others)",
        "dense": {"step": (16541.5, 851.7), "apply": (16068.2, 85.9),       # k_precond<5,3,2048,false,true,true>, k_precond<5,0,2048,false,false,false>
                  "fused_step": (17108.2, 1049.1),                           # k_step_fe<5,0> (carried rows; <5,5>, every workgroup forming the rows: 18160.0, 997.6)
-                 "deep_step": (18519.2, 3543.6)},                           # k_step_fd<5,24> (round 6: + the partial sums, 2.6 MB out and back in)
+                 "deep_step": (18519.2, 3543.7)},                           # k_step_fd<5,24> (round 6: + the partial sums, 2.6 MB out and back in)
        "two_level": {"step": (5469.3, 891.0), "apply": (4937.6, 125.3)}}   # k_precond<5,3,0,true,true,true>, k_precond<5,0,0,true,false,false>
 
 
