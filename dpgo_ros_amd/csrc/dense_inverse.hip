@@ -53,13 +53,19 @@ __device__ __forceinline__ double rsqrt_nr(double d) {
 // same way from the columns left in LDS: once w[k] is final, w[i] -= L[i][k] w[k] for all i > k.
 // History: the left-looking form (each column's sum accumulated serially, operands through v_readlane: ~8000
 // instructions) took 30 us, 11 of them in 32 predicated loads that were each waited for on their own.
-__device__ __forceinline__ void potrf_diag_body(const InvJob &jb_, int kb, int *fail, int z, double *cols) {
+// Two waves since round 6 (callers: the threads with tid < 128; `idg`: NB doubles, `prog`: one word of LDS the caller zeroed in
+// front of its last barrier): wave 0 factors, wave 1 forms the inverse ONE COLUMN BEHIND it -- column k of L and 1 / L[k][k]
+// are in LDS when wave 0 raises *prog to k + 1, and that is all step k of the substitution reads.  The two loops ran one after
+// the other on one wave (15 us per diagonal block: every block step of every factorisation waits for it); the arithmetic of
+// each is unchanged, so L and W are bitwise what they were.
+__device__ __forceinline__ void potrf_diag_body(const InvJob &jb_, int kb, int *fail, int z, double *cols, double *idg, int *prog) {
   double *A = jb_.A;
   const int N = jb_.N, k0 = kb * NB, nb = min(NB, N - k0);
   double *Linv = jb_.Linv + (size_t)kb * NB * NB;
   const int lane = threadIdx.x & 63;
   const bool own = lane < NB;
   const int ls = min(lane, NB - 1);  // LDS slot of this lane (lanes >= NB shadow the last one and never store)
+  if (((threadIdx.x >> 6) & 1) == 0) {
   // straight-line loads (a predicated load is waited for on its own): every lane reads NB values from clamped, valid
   // addresses, the padding is selected afterwards
   double row[NB];
@@ -72,19 +78,20 @@ __device__ __forceinline__ void potrf_diag_body(const InvJob &jb_, int kb, int *
     for (int j = 0; j < NB; ++j)
       row[j] = (own && lane < nb && j < nb && j <= lane) ? raw[j] : ((own && j == lane) ? 1.0 : 0.0);
   }
-  double idiag[NB];  // 1 / L[k][k], wave-uniform
 #pragma unroll
   for (int k = 0; k < NB; ++k) {
     double d = lane_bcast(row[k], k);
     if (!(d > 0.0)) { if (lane == 0) fail[z] = k0 + k + 1; d = 1.0; }
     const double inv = rsqrt_nr(d);
-    idiag[k] = inv;
     const double lik = (lane == k) ? d * inv : ((lane > k) ? row[k] * inv : 0.0);  // L[i][k]
     row[k] = lik;
     if (own) cols[k * NB + ls] = lik;
-    // (DS operations of one wave execute in order; the fences keep the compiler from moving the reads above the write)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    if (lane == 0) idg[k] = inv;
+    // (DS operations of one wave execute in order; the fences keep the compiler from moving the reads above the write --
+    // and the raise of *prog below behind the column it announces)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
+    if (lane == 0) __hip_atomic_store(prog, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     double lj[NB];
 #pragma unroll
@@ -97,13 +104,23 @@ __device__ __forceinline__ void potrf_diag_body(const InvJob &jb_, int kb, int *
     for (int j = 0; j < NB; ++j)
       if (j < nb && j <= lane) A[(size_t)(k0 + j) * N + k0 + lane] = row[j];
   }
-  // (the substitution in a loop of its own: merged into the loop above it costs registers and runs 30 % slower)
+  return;
+  }
+  // ---- wave 1: W = L^-1, lane j owns column j; step k waits for column k
   double w[NB];
 #pragma unroll
   for (int i = 0; i < NB; ++i) w[i] = (i == lane) ? 1.0 : 0.0;
 #pragma unroll
   for (int k = 0; k < NB; ++k) {
-    const double wk = (k >= lane) ? w[k] * idiag[k] : 0.0;
+    {
+      int spins = 0;
+      while (__hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < k + 1) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1 << 22)) { if (lane == 0) fail[z] = k0 + k + 1; break; }  // (never seen: a bound, not a path)
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    const double wk = (k >= lane) ? w[k] * idg[k] : 0.0;
     w[k] = wk;
     double li[NB];
 #pragma unroll
@@ -117,11 +134,14 @@ __device__ __forceinline__ void potrf_diag_body(const InvJob &jb_, int kb, int *
   }
 }
 
-__global__ __launch_bounds__(64) void k_potrf_diag(const InvJob *jobs, int kb, int *fail) {
+__global__ __launch_bounds__(128) void k_potrf_diag(const InvJob *jobs, int kb, int *fail) {
   const InvJob jb_ = jobs[blockIdx.z];
   if (kb >= jb_.nblk) return;
-  __shared__ double cols[NB * NB];
-  potrf_diag_body(jb_, kb, fail, (int)blockIdx.z, cols);
+  __shared__ double cols[NB * NB], idg[NB];
+  __shared__ int prog;
+  if (threadIdx.x == 0) prog = 0;
+  __syncthreads();
+  potrf_diag_body(jb_, kb, fail, (int)blockIdx.z, cols, idg, &prog);
 }
 
 // Staging of one NB x 64 operand tile (8 elements per thread): straight-line.  `at(t)` returns a CLAMPED, always valid
@@ -227,6 +247,8 @@ __global__ __launch_bounds__(256) void k_syrk(const InvJob *jobs, int kb, int *f
   const int bi = blockIdx.x, bj = blockIdx.y;
   if (bj > bi || s0 + 64 * bi >= N) return;
   __shared__ double As[NB][65], Bs[NB][65];
+  __shared__ double potrf_idg[NB];  // the folded factorisation of the next diagonal block (potrf_diag_body)
+  __shared__ int potrf_prog;
   const int i0 = s0 + 64 * bi, j0 = s0 + 64 * bj;
   const int tid = threadIdx.x;
   stage_tiles2(tid,
@@ -268,9 +290,10 @@ __global__ __launch_bounds__(256) void k_syrk(const InvJob *jobs, int kb, int *f
     // workgroup's own threads: a WORKGROUP-scope fence orders it.  The device-scope fence that stood here until round 6
     // wrote the whole L2 back, once per matrix of the batch, while the other workgroups were filling it: trailing updates
     // of 169 and 145 us among ones of 35 in the UPDATE_WEIGHT round's first chain, profiles/experiments/jobs/r06_update_trace.sh)
+    if (tid == 0) potrf_prog = 0;
     __threadfence_block();
     __syncthreads();
-    if (tid < 64) potrf_diag_body(jb_, kb + 1, fail, (int)blockIdx.z, &As[0][0]);  // (the operand tiles are done with)
+    if (tid < 128) potrf_diag_body(jb_, kb + 1, fail, (int)blockIdx.z, &As[0][0], potrf_idg, &potrf_prog);  // (the operand tiles are done with)
   }
 }
 
@@ -289,6 +312,8 @@ __global__ __launch_bounds__(256) void k_syrk_sb(const InvJob *jobs, int kb0, in
   const int i0 = t0 + 64 * bi, j0 = t0 + 64 * bj;
   if (bj > bi || i0 >= N || j0 >= jhi) return;
   __shared__ double As[NB][65], Bs[NB][65];
+  __shared__ double potrf_idg[NB];
+  __shared__ int potrf_prog;
   const int tid = threadIdx.x;
   TileAcc acc;
   tile_zero(acc);
@@ -328,9 +353,10 @@ __global__ __launch_bounds__(256) void k_syrk_sb(const InvJob *jobs, int kb0, in
         }
   }
   if (bi == 0 && bj == 0 && next_kb >= 0 && next_kb < jb_.nblk) {
+    if (tid == 0) potrf_prog = 0;
     __threadfence_block();  // (see k_syrk)
     __syncthreads();
-    if (tid < 64) potrf_diag_body(jb_, next_kb, fail, (int)blockIdx.z, &As[0][0]);
+    if (tid < 128) potrf_diag_body(jb_, next_kb, fail, (int)blockIdx.z, &As[0][0], potrf_idg, &potrf_prog);
   }
 }
 
@@ -487,7 +513,7 @@ int dense_spd_inverse_batched(hipStream_t stream, int count, double *const *A, d
   const bool fold = fold_env >= 0 ? fold_env != 0 : count <= 32;
   for (int kb = 0; kb < max_blk; ++kb) {
     const int s0 = (kb + 1) * NB;
-    if (kb == 0 || !fold) hipLaunchKernelGGL(k_potrf_diag, dim3(1, 1, nz), dim3(64), 0, stream, jobs_d, kb, fail_d);
+    if (kb == 0 || !fold) hipLaunchKernelGGL(k_potrf_diag, dim3(1, 1, nz), dim3(128), 0, stream, jobs_d, kb, fail_d);
     if (s0 < max_n) {
       hipLaunchKernelGGL(k_trsm_panel, dim3((max_n - s0 + 63) / 64, 1, nz), dim3(256), 0, stream, jobs_d, kb);
       const int nt = (max_n - s0 + 63) / 64;
@@ -622,7 +648,7 @@ int dense_spd_solve(hipStream_t stream, double *A, int N, double *B, double *Y, 
     const int sb1 = std::min(sb0 + SBK, job.nblk), c1 = std::min(N, sb1 * NB);
     for (int kb = sb0; kb < sb1; ++kb) {
       const int s0 = (kb + 1) * NB;
-      if (kb == 0) hipLaunchKernelGGL(k_potrf_diag, dim3(1, 1, 1), dim3(64), 0, stream, job_d, kb, fail_d);
+      if (kb == 0) hipLaunchKernelGGL(k_potrf_diag, dim3(1, 1, 1), dim3(128), 0, stream, job_d, kb, fail_d);
       if (s0 >= N) continue;
       const int nt = (N - s0 + 63) / 64;
       hipLaunchKernelGGL(k_trsm_panel, dim3(nt, 1, 1), dim3(256), 0, stream, job_d, kb);
