@@ -97,31 +97,28 @@ __global__ __launch_bounds__(64) void k_eval_report(const AgentDev *__restrict__
   if (rt.advance && tid == 63) advance_agent(ra, rt.accel, rt.num_robots, rt.restart_interval);
   // the five sums k_report forms on five waves, here on one: all their loads first (sum_partials / sum_partials2 keep their
   // order of additions: the same bits)
+  // (the partials of THIS launch were written by other workgroups, on other XCDs: read with agent-scope loads -- served
+  // past this XCD's L2 whatever it holds of their lines, two workgroups' partials share a 128-byte line)
+  auto ldc8 = [](const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
   double sc[5] = {0, 0, 0, 0, 0};
-  if (rt.stat_cnt <= 512 && rt.opt_nb <= 512) {
-    double sv[8];
-    double2 cv[8], av[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int i = tid + 64 * u;
-      sv[u] = (i < rt.stat_cnt) ? gp(ra.part + rt.stat_off)[(size_t)i * rt.stat_stride] : 0.0;
-      cv[u] = make_double2(0.0, 0.0); av[u] = make_double2(0.0, 0.0);
-      if (i < rt.opt_nb) {
-        const v2d_t c = *(const __attribute__((address_space(1))) v2d_t *)(ra.part + PART_C + (size_t)i * PART_STRIDE);
-        const v2d_t a = *(const __attribute__((address_space(1))) v2d_t *)(ra.part + PART_A + (size_t)i * PART_STRIDE);
-        cv[u] = make_double2(c.x, c.y); av[u] = make_double2(a.x, a.y);
-      }
-    }
+  {
     double s0 = 0, c0 = 0, c1 = 0, a0 = 0, a1 = 0;
+    const int most = max(rt.stat_cnt, rt.opt_nb);
+    for (int base = 0; base < most; base += 512) {  // (sum_partials' trips and order of additions: the same bits)
+      double sv[8], cv0[8], cv1[8], av0[8], av1[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) { s0 += sv[u]; c0 += cv[u].x; c1 += cv[u].y; a0 += av[u].x; a1 += av[u].y; }
-    sc[0] = wave_sum(s0); sc[1] = wave_sum(c0); sc[2] = wave_sum(c1); sc[3] = wave_sum(a0); sc[4] = wave_sum(a1);
-  } else {
-    if (rt.stat_cnt > 0) sc[0] = sum_partials(ra.part + rt.stat_off, rt.stat_cnt, rt.stat_stride, tid);
-    if (rt.opt_nb > 0) {
-      sum_partials2(ra.part + PART_C, rt.opt_nb, PART_STRIDE, tid, sc[1], sc[2]);  // f_init, |grad|^2_init
-      sum_partials2(ra.part + PART_A, rt.opt_nb, PART_STRIDE, tid, sc[3], sc[4]);  // f_opt, |grad|^2_opt
+      for (int u = 0; u < 8; ++u) {
+        const int i = base + tid + 64 * u;
+        sv[u] = (i < rt.stat_cnt) ? ldc8(ra.part + rt.stat_off + (size_t)i * rt.stat_stride) : 0.0;
+        const bool o = i < rt.opt_nb;
+        const double *pc = ra.part + PART_C + (size_t)(o ? i : 0) * PART_STRIDE, *pa = ra.part + PART_A + (size_t)(o ? i : 0) * PART_STRIDE;
+        cv0[u] = o ? ldc8(pc) : 0.0; cv1[u] = o ? ldc8(pc + 1) : 0.0;
+        av0[u] = o ? ldc8(pa) : 0.0; av1[u] = o ? ldc8(pa + 1) : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s0 += sv[u]; c0 += cv0[u]; c1 += cv1[u]; a0 += av0[u]; a1 += av1[u]; }
     }
+    sc[0] = wave_sum(s0); sc[1] = wave_sum(c0); sc[2] = wave_sum(c1); sc[3] = wave_sum(a0); sc[4] = wave_sum(a1);
   }
   if (tid == 0) {
     if (rt.stat_cnt > 0) rt.out[1] = sc[0];
