@@ -221,6 +221,8 @@ struct Agent {
   DevBuf<SharedEdgeDev> d_se;
   DevBuf<double> d_fe_coef;  // the coefficients of the shared edges once more, packed [edge][16] (step_deep.hip reads them with whole-line loads)
   std::vector<SharedEdgeDev> se_host;
+  std::vector<int> se_order;          // se_host[e] describes shared[se_order[e]] (sorted by local pose, stable)
+  std::vector<dpgo::EdgeDev> edges_host;  // the edge records of the residual / cost kernels (odometry, private, shared)
   DevBuf<int> d_pose_eptr;
   DevBuf<EdgeDev> d_edges;
   DevBuf<RtrState> d_st;
