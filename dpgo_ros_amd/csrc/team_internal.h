@@ -164,6 +164,8 @@ struct Agent {
   TLPlan tl_plan;
   std::vector<int> tl_rowptr, tl_col;  // the pattern the plan was made for
   int tl_plan_serial = 0, tl_tables_serial = -1;  // plan generation / generation the device tables were uploaded for
+  std::shared_ptr<void> tl_layout_cache;  // twolevel.hip: the host layout of tl_plan (TLHostLayout), valid for ...
+  int tl_layout_serial = -1;              // ... this plan generation (a weight update keeps the plan: 0.2 ms of layout per round)
   DevBuf<int> d_tl_blk, d_tl_lidx, d_tl_subptr, d_tl_subposes, d_tl_adjptr, d_tl_adjlist, d_tl_rowpose;
   DevBuf<long long> d_tl_doff, d_tl_eoff;
   DevBuf<dpgo::TLWg> d_tl_wg;

@@ -292,13 +292,18 @@ int tl_build(dpgo_team *t, const std::vector<Agent *> &agents) {
   if (agents.empty()) return 0;
   hipStream_t s = t->stream;
   const int na = (int)agents.size();
-  std::vector<TLHostLayout> lay(na);
+  std::vector<const TLHostLayout *> lay(na);
   std::vector<TLSetupAgent> setup(na);
   size_t scratch = 0;
   for (int k = 0; k < na; ++k) {
     Agent &a = *agents[k];
-    lay[k] = tl_layout(a.tl_plan);
-    scratch += 3 * lay[k].d_total + lay[k].e_total;
+    // (the layout depends on the dissection alone: kept with the agent across weight updates)
+    if (!a.tl_layout_cache || a.tl_layout_serial != a.tl_plan_serial) {
+      a.tl_layout_cache = std::make_shared<TLHostLayout>(tl_layout(a.tl_plan));
+      a.tl_layout_serial = a.tl_plan_serial;
+    }
+    lay[k] = static_cast<const TLHostLayout *>(a.tl_layout_cache.get());
+    scratch += 3 * lay[k]->d_total + lay[k]->e_total;
   }
   if (t->d_tmp.alloc(scratch)) { set_err("two-level preconditioner: scratch allocation failed"); return DPGO_ERR; }
   HIPC(hipMemsetAsync(t->d_tmp.p, 0, sizeof(double) * scratch, s));
@@ -310,7 +315,7 @@ int tl_build(dpgo_team *t, const std::vector<Agent *> &agents) {
   for (int k = 0; k < na; ++k) {
     Agent &a = *agents[k];
     const TLPlan &pl = a.tl_plan;
-    TLHostLayout &L = lay[k];
+    const TLHostLayout &L = *lay[k];
     const int P = (int)pl.sub.size();
     // the tables depend on the dissection alone: a weight update (same sparsity pattern, same plan) refills the slabs only
     const bool tables_current = a.tl_tables_serial == a.tl_plan_serial && a.d_tl_wg.p;
